@@ -1,0 +1,183 @@
+/*
+ * strawboat_hip.h — C ABI of the MI355X-native page encode/decode path of strawboat.
+ *
+ * This is the drop-in boundary a host (the Rust crate, or the C++/Python host layer in
+ * this repo) binds: plain pointers and sizes, no C++/torch types, `extern "C"`, int32
+ * status codes, errors as strings per context.  Every entry point names the reference
+ * seam it replaces (file:line under the sundy-li/strawboat tree).
+ *
+ * Unit of work: the *pages of leaf columns*.  A call takes a batch of columns; every
+ * (column, page) is an independent work item scheduled over the GPU.
+ * All work is enqueued on the context's HIP stream; nothing is valid on the host until
+ * sb_ctx_synchronize() returned SB_OK.
+ *
+ * Memory: buffers marked DEVICE are HBM pointers (hipMalloc / torch tensors on the
+ * context's device) when `mem == SB_MEM_DEVICE` — the measured configuration — or host
+ * pointers when `mem == SB_MEM_HOST` (the library stages them over PCIe itself; this is
+ * the shape the reference's `&[u8]` / `Vec<T>` callers have).
+ */
+#ifndef STRAWBOAT_HIP_H
+#define STRAWBOAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: arrow2::error::Error variants used on this path
+ *      (src/errors.rs:19-31, src/compression/mod.rs:78-80, basic.rs:104,116,129) */
+#define SB_OK 0
+#define SB_ERR_OUT_OF_SPEC (-1)  /* Error::OutOfSpec: unknown codec, corrupt page, size mismatch */
+#define SB_ERR_EXTERNAL (-2)     /* Error::External: LZ4/Zstd stream rejected, HIP runtime failure */
+#define SB_ERR_IO (-3)           /* Error::Io(UnexpectedEof): page shorter than its headers say */
+#define SB_ERR_NYI (-4)          /* Error::NotYetImplemented: codec/type not handled on the device */
+#define SB_ERR_INVALID (-5)      /* bad argument at the boundary (null pointer, capacity too small) */
+
+/* ---- on-disk codec ids: enum Compression (src/compression/mod.rs:37-51,92-108) */
+#define SB_CODEC_NONE 0
+#define SB_CODEC_LZ4 1
+#define SB_CODEC_ZSTD 2
+#define SB_CODEC_SNAPPY 3
+#define SB_CODEC_RLE 10
+#define SB_CODEC_DICT 11
+#define SB_CODEC_ONEVALUE 12
+#define SB_CODEC_FREQ 13
+#define SB_CODEC_BITPACKING 14
+#define SB_CODEC_DELTA_BITPACKING 15
+#define SB_CODEC_PATAS 16
+
+/* ---- physical kinds: the dispatch key of batch_read::read_simple
+ *      (src/read/batch_read.rs:37-63) and write_simple (src/write/serialize.rs:62-129).
+ *      Utf8/LargeUtf8 are written as Binary/LargeBinary (serialize.rs:92-121). */
+#define SB_TYPE_BOOLEAN 0
+#define SB_TYPE_INT8 1
+#define SB_TYPE_INT16 2
+#define SB_TYPE_INT32 3
+#define SB_TYPE_INT64 4
+#define SB_TYPE_UINT8 5
+#define SB_TYPE_UINT16 6
+#define SB_TYPE_UINT32 7
+#define SB_TYPE_UINT64 8
+#define SB_TYPE_INT128 9
+#define SB_TYPE_INT256 10
+#define SB_TYPE_FLOAT32 11
+#define SB_TYPE_FLOAT64 12
+#define SB_TYPE_BINARY 13       /* i32 offsets: Binary, Utf8 */
+#define SB_TYPE_LARGE_BINARY 14 /* i64 offsets: LargeBinary, LargeUtf8 */
+#define SB_TYPE_NULL 15
+
+#define SB_MEM_DEVICE 0
+#define SB_MEM_HOST 1
+
+/* PageMeta (src/lib.rs:75-80): bytes of the page in the file, rows (flat columns) */
+typedef struct sb_page_meta {
+    uint64_t length;
+    uint64_t num_values;
+} sb_page_meta;
+
+/* WriteOptions (src/write/common.rs:37-45) plus the two knobs a deterministic build needs
+ * (SURVEY.md App. B#1): a forced codec (the reference only has debug-build env switches,
+ * src/util/env.rs:20-24) and a seed for the sampling in compress_sample_ratio
+ * (src/compression/integer/mod.rs:310-347 uses thread_rng()). */
+typedef struct sb_write_options {
+    int32_t default_compression;       /* CommonCompression: SB_CODEC_NONE/LZ4/ZSTD/SNAPPY */
+    int32_t has_default_compress_ratio;/* Option<f64> discriminant */
+    double default_compress_ratio;
+    uint64_t max_page_size;            /* 0 = None */
+    uint32_t forbidden_compressions;   /* bit (1u << codec id) set = forbidden */
+    int32_t force_codec;               /* -1 = choose; else the page codec */
+    int32_t force_index_codec;         /* -1 = choose; else codec of Dict indices / Freq exceptions */
+    int32_t reserved;
+    uint64_t rng_seed;                 /* column-level seed; page p uses mix64(seed ^ p*K) */
+} sb_write_options;
+
+typedef struct sb_ctx sb_ctx;
+
+/* One context per host thread / stream, like one NativeWriter or column reader per thread
+ * upstream (src/read/deserialize.rs:28: iterators are Send + Sync, no shared state).
+ * `hip_stream` may be NULL (the context then creates its own non-blocking stream). */
+int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out);
+void sb_ctx_destroy(sb_ctx* ctx);
+/* waits for all enqueued work; returns the first error raised by a kernel since the last
+ * synchronize (status word in HBM) or by the runtime */
+int32_t sb_ctx_synchronize(sb_ctx* ctx);
+const char* sb_ctx_last_error(sb_ctx* ctx);
+void* sb_ctx_stream(sb_ctx* ctx);
+
+/* ------------------------------------------------------------------ decode
+ * Replaces, per leaf column, batch_read::read_simple -> read_integer / read_double /
+ * read_boolean / read_binary (src/read/batch_read.rs:27-64; src/read/array/integer.rs:210-238,
+ * boolean.rs:191-219, binary.rs:223-265), i.e. per page read_validity
+ * (src/read/read_basic.rs:36-63) + decompress_integer|double|boolean|binary
+ * (src/compression/integer/mod.rs:72-117, double/mod.rs:69-114, boolean/mod.rs:63-102,
+ * binary/mod.rs:95-183).  Output buffers receive the pages back to back, exactly what the
+ * reference appends to its Vec<T> / MutableBitmap / offsets+values Vecs. */
+typedef struct sb_column_read {
+    int32_t physical_type;   /* SB_TYPE_* */
+    int32_t is_nullable;     /* schema field nullable => pages carry a def-level section */
+    const uint8_t* pages;    /* DEVICE: the column's pages, concatenated as in the file */
+    uint64_t pages_len;
+    const sb_page_meta* metas; /* HOST: ColumnMeta.pages */
+    uint64_t n_pages;
+    /* outputs (DEVICE).  Capacities in bytes. */
+    void* values;            /* primitives: rows*w; boolean: ceil(rows/8) bitmap; binary: value bytes */
+    uint64_t values_capacity;
+    uint8_t* validity;       /* ceil(rows/8) bytes, LSB-first; required iff is_nullable */
+    uint64_t validity_capacity;
+    void* offsets;           /* binary: (rows+1) offsets of i32/i64 */
+    uint64_t offsets_capacity;
+    /* results (HOST, valid after sb_ctx_synchronize) */
+    uint64_t rows;           /* sum of num_values */
+    uint64_t values_len;     /* bytes produced in `values` */
+} sb_column_read;
+
+/* Enqueue the decode of `n` columns.  Binary columns whose value bytes are not known in
+ * advance: call sb_read_columns_sizes first, or pass a capacity that is large enough
+ * (the reference guesses 4x the page bytes, src/read/array/binary.rs:241). */
+int32_t sb_read_columns(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem);
+/* Parses only the page headers on the device and fills rows / values_len (synchronous). */
+int32_t sb_read_columns_sizes(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem);
+
+/* ------------------------------------------------------------------ encode
+ * Replaces, per leaf column, the page loop of NativeWriter::encode_chunk
+ * (src/write/common.rs:54-109): page slicing, then per page write::write -> write_simple
+ * (src/write/serialize.rs:36-132): write_validity (:200-215) + compress_integer|double|
+ * boolean|binary (src/compression/integer/mod.rs:35-70, double/mod.rs:32-67,
+ * boolean/mod.rs:23-61, binary/mod.rs:26-93), and the PageMeta bookkeeping (:102-107).
+ * Output: the column's pages back to back (the bytes NativeWriter would write_all) and
+ * one sb_page_meta per page. */
+typedef struct sb_column_write {
+    int32_t physical_type;
+    int32_t is_nullable;
+    uint64_t rows;
+    const void* values;          /* DEVICE: values buffer / boolean bitmap / binary value bytes */
+    uint64_t values_bit_offset;  /* boolean: bit offset of row 0 in `values` */
+    uint64_t values_len;         /* binary: byte length of the whole values buffer (array.values().len()) */
+    const uint8_t* validity;     /* DEVICE or NULL (no validity bitmap) */
+    uint64_t validity_bit_offset;
+    const void* offsets;         /* DEVICE: binary offsets, rows+1 entries */
+    /* outputs */
+    uint8_t* out_pages;          /* DEVICE, capacity >= sb_write_bound() */
+    uint64_t out_capacity;
+    sb_page_meta* out_metas;     /* HOST, capacity n_pages_capacity; valid after synchronize */
+    uint64_t n_pages_capacity;
+    /* results (HOST, valid after sb_ctx_synchronize) */
+    uint64_t n_pages;
+    uint64_t out_len;
+} sb_column_write;
+
+/* upper bound of the encoded size of a column, and its page count (A.4 page arithmetic) */
+uint64_t sb_write_bound(int32_t physical_type, int32_t is_nullable, uint64_t rows, uint64_t values_len,
+                        const sb_write_options* opts, uint64_t* n_pages);
+int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts,
+                         int32_t mem);
+
+/* version / build info string ("strawboat-hip <ver> gfx950") */
+const char* sb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRAWBOAT_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of include/strawboat_hip.h (the C ABI of libstrawboat_hip.so).
+
+The library is the product: if it is missing, or there is no GPU, every entry point fails
+loudly — there is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstrawboat_hip.so")
+
+SB_OK = 0
+SB_ERR_OUT_OF_SPEC, SB_ERR_EXTERNAL, SB_ERR_IO, SB_ERR_NYI, SB_ERR_INVALID = -1, -2, -3, -4, -5
+SB_MEM_DEVICE, SB_MEM_HOST = 0, 1
+
+# every symbol include/strawboat_hip.h declares
+EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
+           "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns")
+
+
+class PageMetaC(C.Structure):
+    _fields_ = [("length", C.c_uint64), ("num_values", C.c_uint64)]
+
+
+class WriteOptionsC(C.Structure):
+    _fields_ = [("default_compression", C.c_int32), ("has_default_compress_ratio", C.c_int32),
+                ("default_compress_ratio", C.c_double), ("max_page_size", C.c_uint64),
+                ("forbidden_compressions", C.c_uint32), ("force_codec", C.c_int32),
+                ("force_index_codec", C.c_int32), ("reserved", C.c_int32), ("rng_seed", C.c_uint64)]
+
+
+class ColumnReadC(C.Structure):
+    _fields_ = [("physical_type", C.c_int32), ("is_nullable", C.c_int32), ("pages", C.c_void_p),
+                ("pages_len", C.c_uint64), ("metas", C.POINTER(PageMetaC)), ("n_pages", C.c_uint64),
+                ("values", C.c_void_p), ("values_capacity", C.c_uint64), ("validity", C.c_void_p),
+                ("validity_capacity", C.c_uint64), ("offsets", C.c_void_p), ("offsets_capacity", C.c_uint64),
+                ("rows", C.c_uint64), ("values_len", C.c_uint64)]
+
+
+class ColumnWriteC(C.Structure):
+    _fields_ = [("physical_type", C.c_int32), ("is_nullable", C.c_int32), ("rows", C.c_uint64),
+                ("values", C.c_void_p), ("values_bit_offset", C.c_uint64), ("values_len", C.c_uint64),
+                ("validity", C.c_void_p), ("validity_bit_offset", C.c_uint64), ("offsets", C.c_void_p),
+                ("out_pages", C.c_void_p), ("out_capacity", C.c_uint64), ("out_metas", C.POINTER(PageMetaC)),
+                ("n_pages_capacity", C.c_uint64), ("n_pages", C.c_uint64), ("out_len", C.c_uint64)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("strawboat-hip error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libstrawboat_hip.so.  torch must be imported first so that one HIP runtime
+    (SONAME libamdhip64.so.7) is shared by torch and this library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or `make -C strawboat_amd/csrc`)" % LIB_PATH)
+    import torch  # noqa: F401  (loads the HIP runtime)
+    L = C.CDLL(LIB_PATH)
+    L.sb_version.restype = C.c_char_p
+    L.sb_ctx_create.restype = C.c_int32
+    L.sb_ctx_create.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.sb_ctx_destroy.argtypes = [C.c_void_p]
+    L.sb_ctx_synchronize.restype = C.c_int32
+    L.sb_ctx_synchronize.argtypes = [C.c_void_p]
+    L.sb_ctx_last_error.restype = C.c_char_p
+    L.sb_ctx_last_error.argtypes = [C.c_void_p]
+    L.sb_ctx_stream.restype = C.c_void_p
+    L.sb_ctx_stream.argtypes = [C.c_void_p]
+    L.sb_read_columns.restype = C.c_int32
+    L.sb_read_columns.argtypes = [C.c_void_p, C.POINTER(ColumnReadC), C.c_uint64, C.c_int32]
+    L.sb_read_columns_sizes.restype = C.c_int32
+    L.sb_read_columns_sizes.argtypes = [C.c_void_p, C.POINTER(ColumnReadC), C.c_uint64, C.c_int32]
+    L.sb_write_bound.restype = C.c_uint64
+    L.sb_write_bound.argtypes = [C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(WriteOptionsC),
+                                 C.POINTER(C.c_uint64)]
+    L.sb_write_columns.restype = C.c_int32
+    L.sb_write_columns.argtypes = [C.c_void_p, C.POINTER(ColumnWriteC), C.c_uint64, C.POINTER(WriteOptionsC),
+                                   C.c_int32]
+    _lib = L
+    return L

@@ -1,0 +1,56 @@
+"""One decode/encode context per host thread and HIP stream (like one NativeWriter or one
+column reader per thread upstream: src/read/deserialize.rs:28, iterators are Send + Sync and
+share no state)."""
+import ctypes as C
+
+from . import _native as N
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        """`stream`: a torch.cuda.Stream (default: the current stream of `device`)."""
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("strawboat_amd needs a GPU: torch.cuda.is_available() is False "
+                               "(there is no CPU fallback)")
+        self._lib = N.load()
+        self.device = int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        self.torch_stream = stream if stream is not None else torch.cuda.current_stream(self.torch_device)
+        h = C.c_void_p()
+        rc = self._lib.sb_ctx_create(self.device, C.c_void_p(self.torch_stream.cuda_stream), C.byref(h))
+        if rc != N.SB_OK:
+            raise N.NativeError(rc, "sb_ctx_create failed")
+        self._h = h
+        self._keep = []  # objects that must outlive the enqueued work
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sb_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != N.SB_OK:
+            msg = self._lib.sb_ctx_last_error(self._h)
+            raise N.NativeError(rc, msg.decode() if msg else "")
+
+    def synchronize(self):
+        """Waits for the enqueued work; raises the first error a kernel reported."""
+        rc = self._lib.sb_ctx_synchronize(self._h)
+        keep, self._keep = self._keep, []
+        try:
+            self._check(rc)
+        finally:
+            del keep

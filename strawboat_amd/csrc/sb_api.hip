@@ -1,0 +1,415 @@
+// strawboat-hip: C ABI (include/strawboat_hip.h) — context management and the decode entry
+// points.  Host logic only: page bookkeeping (the arithmetic of read_integer & co: running row
+// offset per page, src/read/array/integer.rs:210-238), table upload, kernel launches.
+#include <cstdio>
+#include <cstring>
+
+#include "sb_host.h"
+
+namespace sb {
+
+void launch_decode(const DecodeArgs& a, bool any_binary, bool any_prim, bool any_plan, uint64_t* col_values_len,
+                   hipStream_t s);
+void launch_parse_sizes(const DecodeArgs& a, uint64_t* col_values_len, hipStream_t s);
+
+int32_t check_hip(sb_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return SB_OK;
+    return ctx->fail(SB_ERR_EXTERNAL, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+bool ensure(sb_ctx* ctx, DevBuf& b, size_t need) {
+    if (need <= b.cap) return true;
+    // earlier launches may still use the old buffer
+    if (b.p) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = need + need / 4 + 4096;
+    if (hipMalloc((void**)&b.p, cap) != hipSuccess) {
+        b.p = nullptr;
+        return false;
+    }
+    b.cap = cap;
+    return true;
+}
+
+StageSlot* acquire_slot(sb_ctx* ctx, size_t need) {
+    StageSlot& s = ctx->slots[ctx->next_slot];
+    ctx->next_slot = (ctx->next_slot + 1) % sb_ctx::NSLOTS;
+    if (s.in_flight) {
+        (void)hipEventSynchronize(s.done);
+        s.in_flight = false;
+    }
+    if (s.cap < need) {
+        if (s.host) (void)hipHostFree(s.host);
+        size_t cap = need + need / 4 + 4096;
+        if (hipHostMalloc((void**)&s.host, cap, hipHostMallocDefault) != hipSuccess) {
+            s.host = nullptr;
+            s.cap = 0;
+            return nullptr;
+        }
+        s.cap = cap;
+    }
+    if (!s.done) (void)hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    return &s;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static uint32_t type_width(int32_t t) {
+    switch (t) {
+        case SB_TYPE_INT8:
+        case SB_TYPE_UINT8:
+            return 1;
+        case SB_TYPE_INT16:
+        case SB_TYPE_UINT16:
+            return 2;
+        case SB_TYPE_INT32:
+        case SB_TYPE_UINT32:
+        case SB_TYPE_FLOAT32:
+        case SB_TYPE_BINARY:
+            return 4;
+        case SB_TYPE_INT64:
+        case SB_TYPE_UINT64:
+        case SB_TYPE_FLOAT64:
+        case SB_TYPE_LARGE_BINARY:
+            return 8;
+        case SB_TYPE_INT128:
+            return 16;
+        case SB_TYPE_INT256:
+            return 32;
+    }
+    return 0;
+}
+static bool is_binary_t(int32_t t) { return t == SB_TYPE_BINARY || t == SB_TYPE_LARGE_BINARY; }
+
+static const char* status_text(const Status& s, char* buf, size_t n) {
+    const char* kind = s.code == SB_ERR_OUT_OF_SPEC ? "OutOfSpec"
+                       : s.code == SB_ERR_EXTERNAL  ? "External"
+                       : s.code == SB_ERR_IO        ? "Io(UnexpectedEof)"
+                       : s.code == SB_ERR_NYI       ? "NotYetImplemented"
+                                                    : "InvalidArgument";
+    snprintf(buf, n, "%s raised on the device: page %u, site %u", kind, s.page, s.where);
+    return buf;
+}
+
+}  // namespace sb
+
+using namespace sb;
+
+extern "C" {
+
+const char* sb_version(void) { return "strawboat-hip 0.1 gfx950"; }
+
+int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
+    if (!out) return SB_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SB_ERR_EXTERNAL;
+    if (hipSetDevice(device) != hipSuccess) return SB_ERR_EXTERNAL;
+    sb_ctx* ctx = new sb_ctx();
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return SB_ERR_EXTERNAL;
+        }
+        ctx->own_stream = true;
+    }
+    if (hipMalloc((void**)&ctx->d_status, sizeof(Status)) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_status, sizeof(Status), hipHostMallocDefault) != hipSuccess) {
+        sb_ctx_destroy(ctx);
+        return SB_ERR_EXTERNAL;
+    }
+    (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
+    *out = ctx;
+    return SB_OK;
+}
+
+void sb_ctx_destroy(sb_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->slots) {
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (void* p : ctx->temp_dev) (void)hipFree(p);
+    if (ctx->tables.p) (void)hipFree(ctx->tables.p);
+    if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
+    if (ctx->staging.p) (void)hipFree(ctx->staging.p);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* sb_ctx_last_error(sb_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+void* sb_ctx_stream(sb_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int32_t sb_ctx_synchronize(sb_ctx* ctx) {
+    if (!ctx) return SB_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    int32_t rc = ctx->sticky;
+    // status word travels with the stream
+    hipError_t e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(Status), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        rc = check_hip(ctx, e, "sb_ctx_synchronize");
+    } else if (ctx->h_status->code != 0) {
+        char buf[160];
+        if (!rc) {
+            rc = ctx->h_status->code;
+            ctx->last_error = status_text(*ctx->h_status, buf, sizeof buf);
+        }
+        (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
+    }
+    for (auto& s : ctx->slots) s.in_flight = false;
+    for (auto& p : ctx->pending) {
+        if (p.kind == Pending::READ_COL) {
+            sb_column_read* c = (sb_column_read*)p.user;
+            uint64_t v;
+            memcpy(&v, p.host, 8);
+            c->values_len = v;
+        } else {
+            sb_column_write* c = (sb_column_write*)p.user;
+            const uint64_t* lens = (const uint64_t*)p.host;  // [n_pages lengths][n_pages num_values][total]
+            for (uint64_t i = 0; i < p.n && i < c->n_pages_capacity; i++) {
+                c->out_metas[i].length = lens[i];
+                c->out_metas[i].num_values = lens[p.n + i];
+            }
+            c->n_pages = p.n;
+            c->out_len = lens[2 * p.n];
+        }
+    }
+    ctx->pending.clear();
+    for (auto& cb : ctx->copybacks) {
+        if (rc == SB_OK && cb.n) {
+            hipError_t ce = hipMemcpy(cb.host, cb.dev, cb.n, hipMemcpyDeviceToHost);
+            if (ce != hipSuccess) rc = check_hip(ctx, ce, "copy back");
+        }
+    }
+    ctx->copybacks.clear();
+    for (void* p : ctx->temp_dev) (void)hipFree(p);
+    ctx->temp_dev.clear();
+    ctx->sticky = 0;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ decode
+static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem, bool sizes_only) {
+    if (!ctx || (!cols && n)) return SB_ERR_INVALID;
+    if (n == 0) return SB_OK;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    uint64_t P = 0, T = 0;
+    bool any_binary = false, any_prim = false;
+    for (uint64_t i = 0; i < n; i++) {
+        sb_column_read& c = cols[i];
+        if (c.physical_type < 0 || c.physical_type > SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "bad physical_type");
+        if (c.n_pages && !c.metas) return ctx->fail(SB_ERR_INVALID, "metas is null");
+        if (c.pages_len && !c.pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "pages is null");
+        uint64_t rows = 0;
+        for (uint64_t p = 0; p < c.n_pages; p++) {
+            rows += c.metas[p].num_values;
+            T += (c.metas[p].num_values + TILE_ROWS - 1) / TILE_ROWS;
+        }
+        c.rows = rows;
+        c.values_len = 0;
+        P += c.n_pages;
+        if (is_binary_t(c.physical_type))
+            any_binary = true;
+        else if (c.physical_type != SB_TYPE_NULL)
+            any_prim = true;
+        if (!sizes_only && c.physical_type != SB_TYPE_NULL && rows) {
+            const uint32_t w = type_width(c.physical_type);
+            if (!c.values) return ctx->fail(SB_ERR_INVALID, "values is null");
+            if (c.is_nullable && (!c.validity || c.validity_capacity < (rows + 31) / 32 * 4))
+                return ctx->fail(SB_ERR_INVALID, "validity buffer missing or smaller than 4*ceil(rows/32) bytes");
+            if (is_binary_t(c.physical_type)) {
+                if (!c.offsets || c.offsets_capacity < (rows + 1) * w)
+                    return ctx->fail(SB_ERR_INVALID, "offsets buffer missing or too small");
+            } else if (c.physical_type == SB_TYPE_BOOLEAN) {
+                if (c.values_capacity < (rows + 31) / 32 * 4)
+                    return ctx->fail(SB_ERR_INVALID, "boolean values buffer smaller than 4*ceil(rows/32) bytes");
+            } else if (c.values_capacity < rows * w) {
+                return ctx->fail(SB_ERR_INVALID, "values buffer too small");
+            }
+        }
+    }
+    if (P >= 0x7FFFFFFFull || T >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many pages in one call");
+
+    // ---- table layout
+    size_t off = 0;
+    const size_t o_cols = off;
+    off = align_up(off + n * sizeof(ColDesc), 64);
+    const size_t o_tasks = off;
+    off = align_up(off + P * sizeof(PageTask), 64);
+    const size_t upload_bytes = off;
+    const size_t o_descs = off;
+    off = align_up(off + P * sizeof(PageDesc), 64);
+    const size_t o_tiles = off;
+    off = align_up(off + T * sizeof(TileTask), 64);
+    const size_t o_jobs_a = off;
+    off = align_up(off + 2 * P * sizeof(InflateJob), 64);
+    const size_t o_jobs_b = off;
+    off = align_up(off + P * sizeof(InflateJob), 64);
+    const size_t o_counts = off;
+    off = align_up(off + 64, 64);
+    const size_t o_vlen = off;
+    off = align_up(off + n * sizeof(uint64_t), 64);
+    if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
+
+    StageSlot* slot = acquire_slot(ctx, upload_bytes + n * sizeof(uint64_t));
+    if (!slot) return ctx->fail(SB_ERR_EXTERNAL, "hipHostMalloc(staging) failed");
+    ColDesc* hc = (ColDesc*)(slot->host + o_cols);
+    PageTask* ht = (PageTask*)(slot->host + o_tasks);
+
+    // SB_MEM_HOST: stage inputs/outputs in device temporaries
+    std::vector<uint8_t*> dev_pages(n, nullptr), dev_values(n, nullptr), dev_validity(n, nullptr), dev_offsets(n, nullptr);
+    if (mem == SB_MEM_HOST) {
+        for (uint64_t i = 0; i < n; i++) {
+            sb_column_read& c = cols[i];
+            auto alloc = [&](size_t bytes, uint8_t** out) -> bool {
+                *out = nullptr;
+                if (!bytes) return true;
+                if (hipMalloc((void**)out, bytes + 64) != hipSuccess) return false;
+                ctx->temp_dev.push_back(*out);
+                return true;
+            };
+            if (!alloc(c.pages_len, &dev_pages[i])) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(pages) failed");
+            if (c.pages_len &&
+                hipMemcpyAsync(dev_pages[i], c.pages, c.pages_len, hipMemcpyHostToDevice, s) != hipSuccess)
+                return ctx->fail(SB_ERR_EXTERNAL, "H2D pages failed");
+            if (!sizes_only) {
+                if (!alloc(c.values_capacity, &dev_values[i]) || !alloc(c.is_nullable ? c.validity_capacity : 0, &dev_validity[i]) ||
+                    !alloc(is_binary_t(c.physical_type) ? c.offsets_capacity : 0, &dev_offsets[i]))
+                    return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(outputs) failed");
+            }
+        }
+    }
+
+    size_t scratch_off = 0;
+    uint64_t page_i = 0, tile_i = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const sb_column_read& c = cols[i];
+        ColDesc& d = hc[i];
+        memset(&d, 0, sizeof d);
+        d.pages = mem == SB_MEM_HOST ? dev_pages[i] : c.pages;
+        d.pages_len = c.pages_len;
+        d.values = mem == SB_MEM_HOST ? dev_values[i] : (uint8_t*)c.values;
+        d.values_cap = sizes_only ? ~0ull : c.values_capacity;
+        d.validity = mem == SB_MEM_HOST ? dev_validity[i] : c.validity;
+        d.offsets = mem == SB_MEM_HOST ? dev_offsets[i] : (uint8_t*)c.offsets;
+        d.offsets_cap = c.offsets_capacity;
+        d.rows = c.rows;
+        d.ptype = c.physical_type;
+        d.nullable = c.is_nullable;
+        d.width = type_width(c.physical_type);
+        d.first_page = (uint32_t)page_i;
+        d.n_pages = (uint32_t)c.n_pages;
+        uint64_t in_off = 0, out_row = 0;
+        for (uint64_t p = 0; p < c.n_pages; p++, page_i++) {
+            PageTask& t = ht[page_i];
+            const uint64_t N = c.metas[p].num_values, L = c.metas[p].length;
+            const uint64_t ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+            t.in_off = in_off;
+            t.length = L;
+            t.num_values = N;
+            t.out_row = out_row;
+            t.col = (uint32_t)i;
+            t.first_tile = (uint32_t)tile_i;
+            t.aux_off = scratch_off;
+            scratch_off += align_up((L / 4 + N / 128 + 2 * ntiles + 16) * 4, 16);
+            t.infl_off = scratch_off;
+            scratch_off += align_up((N + 1) * 8 + 16, 16);
+            in_off += L;
+            out_row += N;
+            tile_i += ntiles;
+        }
+        if (in_off > c.pages_len) return ctx->fail(SB_ERR_IO, "sum of PageMeta.length exceeds pages_len");
+    }
+    if (!ensure(ctx, ctx->scratch, scratch_off + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(scratch) failed");
+
+    uint8_t* tb = ctx->tables.p;
+    hipError_t e = hipMemcpyAsync(tb, slot->host, upload_bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return check_hip(ctx, e, "table upload");
+
+    DecodeArgs a;
+    a.cols = (const ColDesc*)(tb + o_cols);
+    a.tasks = (const PageTask*)(tb + o_tasks);
+    a.descs = (PageDesc*)(tb + o_descs);
+    a.tiles = (TileTask*)(tb + o_tiles);
+    a.scratch = ctx->scratch.p;
+    a.status = ctx->d_status;
+    a.jobs_a = (InflateJob*)(tb + o_jobs_a);
+    a.jobs_b = (InflateJob*)(tb + o_jobs_b);
+    a.job_counts = (uint32_t*)(tb + o_counts);
+    a.n_pages = (uint32_t)P;
+    a.n_cols = (uint32_t)n;
+    a.n_tiles = (uint32_t)T;
+    uint64_t* d_vlen = (uint64_t*)(tb + o_vlen);
+
+    if (sizes_only) {
+        if (P) launch_parse_sizes(a, d_vlen, s);
+    } else {
+        // bitmaps are assembled with OR at page seams: start from zero
+        for (uint64_t i = 0; i < n; i++) {
+            const ColDesc& d = hc[i];
+            if (d.nullable && d.validity && d.rows) (void)hipMemsetAsync(d.validity, 0, (d.rows + 31) / 32 * 4, s);
+            if (d.ptype == SB_TYPE_BOOLEAN && d.values && d.rows) (void)hipMemsetAsync(d.values, 0, (d.rows + 31) / 32 * 4, s);
+        }
+        if (P) launch_decode(a, any_binary, any_prim, true, d_vlen, s);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return check_hip(ctx, e, "decode launch");
+
+    // results: values_len per column
+    uint8_t* hv = slot->host + upload_bytes;
+    if (P) {
+        e = hipMemcpyAsync(hv, d_vlen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return check_hip(ctx, e, "values_len readback");
+    } else {
+        memset(hv, 0, n * sizeof(uint64_t));
+    }
+    (void)hipEventRecord(slot->done, s);
+    slot->in_flight = true;
+    for (uint64_t i = 0; i < n; i++) {
+        Pending pd;
+        pd.kind = Pending::READ_COL;
+        pd.user = &cols[i];
+        pd.host = hv + i * sizeof(uint64_t);
+        pd.n = 0;
+        ctx->pending.push_back(pd);
+        if (mem == SB_MEM_HOST && !sizes_only) {
+            const sb_column_read& c = cols[i];
+            const uint32_t w = type_width(c.physical_type);
+            if (c.is_nullable && c.rows) ctx->copybacks.push_back({c.validity, dev_validity[i], (size_t)((c.rows + 7) / 8)});
+            if (is_binary_t(c.physical_type)) {
+                ctx->copybacks.push_back({c.offsets, dev_offsets[i], (size_t)((c.rows + 1) * w)});
+                ctx->copybacks.push_back({c.values, dev_values[i], (size_t)c.values_capacity});
+            } else if (c.physical_type == SB_TYPE_BOOLEAN) {
+                ctx->copybacks.push_back({c.values, dev_values[i], (size_t)((c.rows + 7) / 8)});
+            } else if (c.physical_type != SB_TYPE_NULL) {
+                ctx->copybacks.push_back({c.values, dev_values[i], (size_t)(c.rows * w)});
+            }
+        }
+    }
+    return SB_OK;
+}
+
+int32_t sb_read_columns(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem) {
+    return read_columns_impl(ctx, cols, n, mem, false);
+}
+
+int32_t sb_read_columns_sizes(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem) {
+    int32_t rc = read_columns_impl(ctx, cols, n, mem, true);
+    if (rc != SB_OK) return rc;
+    return sb_ctx_synchronize(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+// strawboat-hip: structures shared by host code and gfx950 kernels.
+//
+// Data layout in HBM: a call works on a batch of leaf columns.  The host
+// uploads one ColDesc per column and one PageTask per page; the parse kernel turns each
+// page's headers into a PageDesc and fills the tile table; every later kernel is indexed
+// either by page (plan kernels, one workgroup per page) or by tile (expand kernels, one
+// workgroup per TILE_ROWS rows of one page).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/strawboat_hip.h"
+
+namespace sb {
+
+constexpr int TILE_ROWS = 4096;  // rows of one page handled by one workgroup
+constexpr int WG = 256;          // threads per workgroup = 4 wave64
+constexpr int ROWS_PER_THREAD = TILE_ROWS / WG;
+
+struct ColDesc {
+    const uint8_t* pages;  // concatenated pages of the column
+    uint64_t pages_len;
+    uint8_t* values;
+    uint64_t values_cap;
+    uint8_t* validity;
+    uint8_t* offsets;
+    uint64_t offsets_cap;
+    uint64_t rows;
+    int32_t ptype;
+    int32_t nullable;
+    uint32_t width;       // bytes per value (primitives), 4/8 for binary offsets, 0 bool
+    uint32_t first_page;  // index into the page tables
+    uint32_t n_pages;
+    uint32_t pad;
+};
+
+struct PageTask {
+    uint64_t in_off;      // byte offset of the page in ColDesc.pages
+    uint64_t length;      // PageMeta.length
+    uint64_t num_values;  // PageMeta.num_values
+    uint64_t out_row;     // first row of the page in the column's output
+    uint64_t aux_off;     // byte offset of the page's u32 aux area in the scratch buffer
+    uint64_t infl_off;    // byte offset of the page's inflate area in the scratch buffer
+    uint32_t col;
+    uint32_t first_tile;
+};
+
+struct TileTask {
+    uint32_t page;
+    uint32_t tile;
+};
+
+// result of parsing one page's headers (hdr9 = u8 codec | u32 compressed | u32 uncompressed,
+// reference src/read/read_basic.rs:181-189)
+struct PageDesc {
+    const uint8_t* def_bits;  // validity bits of the def-level section (NULL: not nullable)
+    const uint8_t* body;      // body of the page's (first) block
+    const uint8_t* ibody;     // Dict: body of the nested u32 index block
+    const uint8_t* dict;      // Dict: first entry; binary OneValue: value bytes
+    const uint8_t* vbody;     // binary Basic: body of the values block
+    const uint8_t* src;       // where the expand step reads "plain" data from (body or inflated copy)
+    const uint8_t* isrc;      // same for nested indices
+    uint32_t csize, usize;    // of the first block
+    uint32_t icsize;          // nested block compressed size
+    uint32_t dict_n;          // Dict: entries; binary OneValue: value length
+    uint32_t vcsize, vusize;  // binary Basic values block
+    uint8_t codec;            // page codec
+    uint8_t icodec;           // nested codec (Dict) or 255
+    uint8_t ok;               // 1 = parsed, expand may run
+    uint8_t pad;
+    uint32_t n_runs;          // RLE: number of runs (filled by plan)
+    uint64_t val_bytes;       // binary: value bytes this page produces
+    uint64_t val_base;        // binary: first value byte of the page in the column output (colscan)
+    uint64_t off_last;        // binary: last offset of the page as decoded (page relative)
+    uint64_t off_base;        // binary: offset base of the page (colscan)
+};
+
+struct Status {
+    int32_t code;   // first error (SB_ERR_*), 0 = ok
+    uint32_t page;  // page index within the call
+    uint32_t where; // kernel-specific tag
+    uint32_t pad;
+};
+
+// one general-purpose block (LZ4 / Zstd / Snappy) to inflate: src -> dst
+struct InflateJob {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint32_t csize;
+    uint32_t out_len;
+    uint32_t codec;
+    uint32_t page;
+};
+
+struct DecodeArgs {
+    const ColDesc* cols;
+    const PageTask* tasks;
+    PageDesc* descs;
+    TileTask* tiles;
+    uint8_t* scratch;
+    Status* status;
+    InflateJob* jobs_a;  // capacity 2 * n_pages
+    InflateJob* jobs_b;  // capacity n_pages
+    uint32_t* job_counts;  // [0] = queue A, [1] = queue B
+    uint32_t n_pages;
+    uint32_t n_cols;
+    uint32_t n_tiles;
+};
+
+}  // namespace sb
+
+// ------------------------------------------------------------------ device helpers
+#if defined(__HIPCC__)
+namespace sb {
+
+// unaligned little-endian loads: page bytes sit at arbitrary byte offsets (9-byte headers,
+// def-level sections); gfx950 global loads handle unaligned addresses in hardware.
+__device__ __forceinline__ uint16_t ldu16(const uint8_t* p) {
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
+__device__ __forceinline__ uint32_t ldu32(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t ldu64(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void stu64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(1))) U16B {
+    u32x4 v;
+};
+__device__ __forceinline__ u32x4 ldu128(const uint8_t* p) { return ((const U16B*)p)->v; }
+__device__ __forceinline__ void stu128(uint8_t* p, u32x4 v) { ((U16B*)p)->v = v; }
+
+// value of W bytes as a register bundle
+template <int W>
+struct Val;
+template <>
+struct Val<1> {
+    uint8_t x;
+};
+template <>
+struct Val<2> {
+    uint16_t x;
+};
+template <>
+struct Val<4> {
+    uint32_t x;
+};
+template <>
+struct Val<8> {
+    uint64_t x;
+};
+template <>
+struct Val<16> {
+    u32x4 x;
+};
+template <>
+struct Val<32> {
+    u32x4 x, y;
+};
+template <int W>
+__device__ __forceinline__ Val<W> ld_val(const uint8_t* p) {  // unaligned
+    Val<W> v;
+    __builtin_memcpy(&v, p, W);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ void st_val(uint8_t* p, Val<W> v) {  // p aligned to min(W,16)
+    __builtin_memcpy(p, &v, W);
+}
+
+__device__ __forceinline__ void raise(Status* st, int32_t code, uint32_t page, uint32_t where) {
+    if (atomicCAS(&st->code, 0, code) == 0) {
+        st->page = page;
+        st->where = where;
+    }
+}
+
+// padded index into a TILE_ROWS-entry LDS array: one pad word per 16 entries so that a
+// thread owning 16 consecutive entries (the scan layout) hits distinct banks
+__device__ __forceinline__ int sidx(int i) { return i + (i >> 4); }
+constexpr int SIDX_WORDS = TILE_ROWS + TILE_ROWS / 16;
+
+// wave64 inclusive scan (u32 wrapping add)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Inclusive scan of the TILE_ROWS u32 entries of `a` (sidx layout), in place.  Thread t owns
+// entries [16t, 16t+16).  `wsum` is a 4-entry LDS scratch.  Returns the tile total.
+__device__ __forceinline__ uint32_t tile_incl_scan(uint32_t* a, uint32_t* wsum) {
+    const int t = threadIdx.x;
+    uint32_t loc[ROWS_PER_THREAD];
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_THREAD; j++) {
+        run += a[sidx(t * ROWS_PER_THREAD + j)];
+        loc[j] = run;
+    }
+    uint32_t incl = wave_incl_scan(run);
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    const int w = t >> 6;
+    uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
+    if (w > 0) base += w0;
+    if (w > 1) base += w1;
+    if (w > 2) base += w2;
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_THREAD; j++) a[sidx(t * ROWS_PER_THREAD + j)] = base + loc[j];
+    __syncthreads();
+    return w0 + w1 + w2 + w3;
+}
+
+// workgroup sum of one u32 / u64 per thread
+__device__ __forceinline__ uint64_t wg_sum64(uint64_t v, uint64_t* wsum4) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wsum4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return wsum4[0] + wsum4[1] + wsum4[2] + wsum4[3];
+}
+
+// BitPacker4x geometry: value j of a 128-block lives in lane (j&3) at slot (j>>2);
+// slot i of width nb starts at bit i*nb of the lane's stream; word k of lane l is the
+// u32 at index 4k+l of the block payload.
+__device__ __forceinline__ uint32_t bp4x_extract(const uint8_t* payload, uint32_t nb, int j) {
+    if (nb == 0) return 0;
+    const int l = j & 3, i = j >> 2;
+    const uint32_t bitpos = (uint32_t)i * nb, word = bitpos >> 5, sh = bitpos & 31;
+    uint32_t v = ldu32(payload + 4 * (4 * word + l)) >> sh;
+    if (sh + nb > 32) v |= ldu32(payload + 4 * (4 * (word + 1) + l)) << (32 - sh);
+    if (nb < 32) v &= (1u << nb) - 1;
+    return v;
+}
+
+}  // namespace sb
+#endif

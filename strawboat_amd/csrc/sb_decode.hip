@@ -1,0 +1,1082 @@
+// strawboat-hip: page decode kernels for gfx950 (MI355X).
+//
+// Replaces, on the device, the per-page work of the reference's batch read path:
+//   read_validity            src/read/read_basic.rs:36-63
+//   decompress_integer       src/compression/integer/mod.rs:72-117   (+ rle.rs, dict.rs, bp.rs,
+//   decompress_double        src/compression/double/mod.rs:69-114      delta_bp.rs, one_value.rs)
+//   decompress_boolean       src/compression/boolean/mod.rs:63-102   (+ rle.rs, one_value.rs)
+//   decompress_binary        src/compression/binary/mod.rs:95-183    (+ dict.rs, one_value.rs)
+// and the page concatenation of read_integer / read_boolean / read_binary
+// (src/read/array/integer.rs:210-238, boolean.rs:191-219, binary.rs:223-265).
+//
+// Kernel sequence of one call (all on one stream, no host round trip):
+//   k_parse    1 thread / page      headers -> PageDesc, tile table, inflate job queues
+//   k_inflate  1 wave / job         LZ4 blocks -> output or scratch (queue A, later queue B)
+//   k_plan     1 workgroup / page   page-wide scans: RLE run starts, bit-pack block offsets,
+//                                   delta bases, binary-dict entry offsets and byte totals
+//   k_colscan  1 workgroup / column binary columns: cross-page value/offset bases
+//   k_expand   1 workgroup / tile   TILE_ROWS rows of one page -> Arrow buffers
+// Bandwidth-bound integer work: no MFMA; coalesced 16-byte stores, unaligned 16-byte loads,
+// LDS for the per-tile scans, wave64 shuffles for the scan carries.
+#include "sb_common.h"
+
+namespace sb {
+
+__device__ __forceinline__ bool is_basic(uint32_t c) { return c <= 3; }
+__device__ __forceinline__ bool is_binary(int32_t t) { return t == SB_TYPE_BINARY || t == SB_TYPE_LARGE_BINARY; }
+
+__device__ __forceinline__ void push_job(InflateJob* q, uint32_t* cnt, const uint8_t* src, uint32_t csize,
+                                         uint8_t* dst, uint32_t out_len, uint32_t codec, uint32_t page) {
+    uint32_t i = atomicAdd(cnt, 1u);
+    InflateJob j;
+    j.src = src;
+    j.dst = dst;
+    j.csize = csize;
+    j.out_len = out_len;
+    j.codec = codec;
+    j.page = page;
+    q[i] = j;
+}
+
+// -------------------------------------------------------------------------------- parse
+__global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_pages) return;
+    const PageTask t = a.tasks[p];
+    const ColDesc c = a.cols[t.col];
+    PageDesc d;
+    __builtin_memset(&d, 0, sizeof(d));
+    d.icodec = 255;
+    const uint64_t N = t.num_values;
+    const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+    for (uint32_t i = 0; i < ntiles; i++) {
+        TileTask tt;
+        tt.page = p;
+        tt.tile = i;
+        a.tiles[t.first_tile + i] = tt;
+    }
+#define FAIL(code, tag)                   \
+    do {                                  \
+        raise(a.status, (code), p, (tag)); \
+        a.descs[p] = d;                   \
+        return;                           \
+    } while (0)
+    if (c.ptype == SB_TYPE_NULL) {  // empty pages (src/read/array/null.rs:48-52)
+        a.descs[p] = d;
+        return;
+    }
+    if (t.in_off + t.length > c.pages_len) FAIL(SB_ERR_IO, 1);
+    const uint8_t* cur = c.pages + t.in_off;
+    const uint8_t* end = cur + t.length;
+    // ---- def-level section: u32 def_len | ULEB128((ceil(N/8)<<1)|1) | bits  (read_basic.rs:36-63)
+    if (c.nullable) {
+        if (end - cur < 4) FAIL(SB_ERR_IO, 2);
+        const uint32_t def_len = ldu32(cur);
+        cur += 4;
+        if ((uint64_t)(end - cur) < def_len) FAIL(SB_ERR_IO, 3);
+        if (def_len == 0) {
+            if (N != 0) FAIL(SB_ERR_OUT_OF_SPEC, 4);  // reference: validity length mismatch
+        } else {
+            uint64_t ind = 0;
+            uint32_t sh = 0, k = 0;
+            for (;;) {
+                if (k >= def_len || k >= 10) FAIL(SB_ERR_OUT_OF_SPEC, 5);
+                uint8_t b = cur[k++];
+                ind |= (uint64_t)(b & 0x7F) << sh;
+                sh += 7;
+                if (!(b & 0x80)) break;
+            }
+            if (!(ind & 1)) FAIL(SB_ERR_OUT_OF_SPEC, 6);  // RLE run: unreachable!() upstream
+            uint64_t nbytes = ind >> 1;
+            if (nbytes > def_len - k) nbytes = def_len - k;
+            if (nbytes * 8 < N) FAIL(SB_ERR_OUT_OF_SPEC, 7);
+            d.def_bits = cur + k;
+        }
+        cur += def_len;
+    }
+    // ---- first block header
+    if (end - cur < 9) FAIL(SB_ERR_IO, 8);
+    d.codec = cur[0];
+    d.csize = ldu32(cur + 1);
+    d.usize = ldu32(cur + 5);
+    cur += 9;
+    d.body = cur;
+    d.src = cur;
+    if ((uint64_t)(end - cur) < d.csize) FAIL(SB_ERR_IO, 9);
+    const uint32_t codec = d.codec;
+    if (!(codec <= 3 || (codec >= 10 && codec <= 16))) FAIL(SB_ERR_OUT_OF_SPEC, 10);
+    uint8_t* infl = a.scratch + t.infl_off;
+
+    if (c.ptype == SB_TYPE_BOOLEAN) {
+        const uint64_t nbytes = (N + 7) / 8;
+        if (codec == SB_CODEC_NONE) {
+            if (d.csize != nbytes) FAIL(SB_ERR_OUT_OF_SPEC, 11);
+        } else if (is_basic(codec)) {
+            push_job(a.jobs_a, a.job_counts, d.body, d.csize, infl, (uint32_t)nbytes, codec, p);
+            d.src = infl;
+        } else if (codec == SB_CODEC_ONEVALUE) {
+            if (d.csize < 1) FAIL(SB_ERR_OUT_OF_SPEC, 12);
+        } else if (codec != SB_CODEC_RLE) {
+            FAIL(SB_ERR_OUT_OF_SPEC, 13);
+        }
+    } else if (is_binary(c.ptype)) {
+        const uint32_t ow = c.width;
+        if (is_basic(codec)) {
+            // BLOCK(offsets) | hdr9 | BLOCK(values)   (binary/mod.rs:119-173)
+            const uint64_t obytes = (N + 1) * ow;
+            if (codec == SB_CODEC_NONE) {
+                if (d.csize != obytes) FAIL(SB_ERR_OUT_OF_SPEC, 14);
+            } else {
+                push_job(a.jobs_a, a.job_counts, d.body, d.csize, infl, (uint32_t)obytes, codec, p);
+                d.src = infl;
+            }
+            const uint8_t* h2 = d.body + d.csize;
+            if (end - h2 < 9) FAIL(SB_ERR_IO, 15);
+            d.vcsize = ldu32(h2 + 1);
+            d.vusize = ldu32(h2 + 5);
+            d.vbody = h2 + 9;
+            if ((uint64_t)(end - d.vbody) < d.vcsize) FAIL(SB_ERR_IO, 16);
+            if (codec == SB_CODEC_NONE && d.vcsize != d.vusize) FAIL(SB_ERR_OUT_OF_SPEC, 17);
+            d.val_bytes = d.vusize;
+        } else if (codec == SB_CODEC_ONEVALUE) {  // u32 len | bytes  (binary/one_value.rs:70-97)
+            if (d.csize < 4) FAIL(SB_ERR_IO, 18);
+            d.dict_n = ldu32(d.body);
+            d.dict = d.body + 4;
+            if ((uint64_t)(end - d.dict) < d.dict_n) FAIL(SB_ERR_OUT_OF_SPEC, 19);
+            d.val_bytes = (uint64_t)d.dict_n * N;
+        } else if (codec == SB_CODEC_DICT) {
+            // handled below (shared with primitives)
+        } else {
+            FAIL(SB_ERR_NYI, 20);  // Freq (Roaring) pages take the host path for now
+        }
+    } else {
+        const uint32_t w = c.width;
+        if (codec == SB_CODEC_NONE) {
+            if (d.csize != N * w) FAIL(SB_ERR_OUT_OF_SPEC, 21);
+        } else if (is_basic(codec)) {
+            // inflate straight into the column's values buffer (integer/mod.rs:97-107)
+            push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec,
+                     p);
+            d.src = nullptr;  // nothing left for expand
+        } else if (codec == SB_CODEC_ONEVALUE) {
+            if (d.csize < w) FAIL(SB_ERR_IO, 22);
+        } else if (codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING) {
+            if (w != 4 || c.ptype == SB_TYPE_FLOAT32) FAIL(SB_ERR_OUT_OF_SPEC, 23);
+            if (N % 128 != 0) FAIL(SB_ERR_OUT_OF_SPEC, 24);  // whole blocks only (bp.rs:72-84)
+        } else if (codec == SB_CODEC_RLE || codec == SB_CODEC_DICT) {
+        } else {
+            FAIL(SB_ERR_NYI, 25);  // Freq / Patas pages take the host path for now
+        }
+    }
+    if (codec == SB_CODEC_DICT && c.ptype != SB_TYPE_BOOLEAN) {
+        // BLOCK<u32 indices> | u32 n | entries   (integer/dict.rs:75-103, binary/dict.rs:95-140)
+        if (d.csize < 9) FAIL(SB_ERR_IO, 26);
+        d.icodec = d.body[0];
+        d.icsize = ldu32(d.body + 1);
+        d.ibody = d.body + 9;
+        d.isrc = d.ibody;
+        if ((uint64_t)(end - d.ibody) < (uint64_t)d.icsize + 4) FAIL(SB_ERR_IO, 27);
+        const uint32_t ic = d.icodec;
+        if (ic == SB_CODEC_NONE) {
+            if (d.icsize != N * 4) FAIL(SB_ERR_OUT_OF_SPEC, 28);
+        } else if (is_basic(ic)) {
+            push_job(a.jobs_a, a.job_counts, d.ibody, d.icsize, infl, (uint32_t)(N * 4), ic, p);
+            d.isrc = infl;
+        } else if (ic == SB_CODEC_BITPACKING || ic == SB_CODEC_DELTA_BITPACKING) {
+            if (N % 128 != 0) FAIL(SB_ERR_OUT_OF_SPEC, 29);
+        } else if (ic == SB_CODEC_ONEVALUE) {
+            if (d.icsize < 4) FAIL(SB_ERR_IO, 30);
+        } else if (ic != SB_CODEC_RLE) {
+            FAIL(ic == SB_CODEC_FREQ || ic == SB_CODEC_DICT ? SB_ERR_NYI : SB_ERR_OUT_OF_SPEC, 31);
+        }
+        const uint8_t* q = d.ibody + d.icsize;
+        d.dict_n = ldu32(q);
+        d.dict = q + 4;
+        if (!is_binary(c.ptype)) {
+            if ((uint64_t)(end - d.dict) < (uint64_t)d.dict_n * c.width) FAIL(SB_ERR_OUT_OF_SPEC, 32);
+        }
+    }
+    d.ok = 1;
+    a.descs[p] = d;
+#undef FAIL
+}
+
+// -------------------------------------------------------------------------------- inflate (LZ4)
+// One wave per block.  Sequences are parsed wave-uniformly (every lane walks the same token
+// stream); literal and match copies are spread over the 64 lanes.  A match may overlap its own
+// output (offset < length): lane i reads history byte (i mod offset), which was written by an
+// earlier sequence, so the copy is still fully parallel.
+__device__ void lz4_inflate_wave(const InflateJob& j, Status* st) {
+    const int lane = threadIdx.x & 63;
+    const uint8_t* src = j.src;
+    uint8_t* dst = j.dst;
+    const uint32_t n = j.csize, out_len = j.out_len;
+    uint32_t ip = 0, op = 0;
+    if (n == 0) {
+        if (out_len != 0 && lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 100);
+        return;
+    }
+    for (;;) {
+        if (ip >= n) {
+            if (lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 101);
+            return;
+        }
+        const uint32_t token = src[ip++];
+        uint32_t lit = token >> 4;
+        if (lit == 15) {
+            uint32_t s;
+            do {
+                if (ip >= n) {
+                    if (lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 102);
+                    return;
+                }
+                s = src[ip++];
+                lit += s;
+            } while (s == 255);
+        }
+        if (lit > n - ip || lit > out_len - op) {
+            if (lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 103);
+            return;
+        }
+        for (uint32_t i = lane; i < lit; i += 64) dst[op + i] = src[ip + i];
+        ip += lit;
+        op += lit;
+        if (ip == n) break;  // last sequence carries literals only
+        if (n - ip < 2) {
+            if (lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 104);
+            return;
+        }
+        const uint32_t off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8);
+        ip += 2;
+        uint32_t ml = token & 15;
+        if (ml == 15) {
+            uint32_t s;
+            do {
+                if (ip >= n) {
+                    if (lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 105);
+                    return;
+                }
+                s = src[ip++];
+                ml += s;
+            } while (s == 255);
+        }
+        ml += 4;
+        if (off == 0 || off > op || ml > out_len - op) {
+            if (lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 106);
+            return;
+        }
+        // make this wave's earlier stores visible to its loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint8_t* hist = dst + op - off;
+        for (uint32_t i = lane; i < ml; i += 64) dst[op + i] = hist[off >= ml ? i : i % off];
+        op += ml;
+    }
+    if (op != out_len && lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 107);
+}
+
+__global__ void __launch_bounds__(WG) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st) {
+    const uint32_t job = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (job >= *count) return;
+    const InflateJob j = jobs[job];
+    if (j.codec == SB_CODEC_LZ4) {
+        lz4_inflate_wave(j, st);
+    } else if ((threadIdx.x & 63) == 0) {
+        raise(st, SB_ERR_NYI, j.page, 110);  // Zstd / Snappy blocks: host path for now
+    }
+}
+
+// -------------------------------------------------------------------------------- plan
+// aux layouts (u32 words at scratch + PageTask.aux_off):
+//   RLE (page or nested):   [0..R]    run_start (exclusive prefix of counts, clamped to N), R+1 words
+//                           [R+1.. ]  tile_k0[ntiles]: run that contains row tile*TILE_ROWS
+//   bit-packing:            [0..nblk] byte offset of each 128-block header inside the body
+//                           [nblk+1..] tile_base[ntiles]: delta prefix at the start of each tile
+//   binary Dict:            after the index aux (if any): ent_off[dict_n+1] (u32 byte offsets
+//                           of the entries' bytes relative to PageDesc.dict), tile_bytes[ntiles+1]
+struct AuxIdx {          // where things live for the *index producing* codec of a page
+    uint32_t* base;      // start of its aux words
+};
+
+// number of aux words used by the index codec of a page
+__device__ __forceinline__ uint32_t idx_aux_words(uint32_t codec, uint32_t n_runs, uint64_t N) {
+    const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+    if (codec == SB_CODEC_RLE) return n_runs + 1 + ntiles;
+    if (codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING) return (uint32_t)(N / 128) + 1 + ntiles;
+    return 0;
+}
+
+// RLE plan: scan the run counts of `body` (records of 4+W bytes) until they cover N rows.
+// Returns the number of runs (uniform).  LDS: s_a (SIDX_WORDS u32).
+__device__ uint32_t plan_rle(const uint8_t* body, uint32_t csize, uint32_t rec, uint64_t N, uint32_t* aux,
+                             uint32_t aux_cap_words, uint32_t* s_a, uint64_t* s_w64, Status* st, uint32_t page) {
+    const int t = threadIdx.x;
+    const uint32_t max_runs = csize / rec;
+    const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+    __shared__ uint32_t s_nruns;
+    __shared__ uint64_t s_carry;
+    if (t == 0) {
+        s_nruns = 0xFFFFFFFFu;
+        s_carry = 0;
+    }
+    __syncthreads();
+    // pass 1: run starts
+    for (uint32_t base = 0; base < max_runs; base += TILE_ROWS) {
+        uint64_t loc[ROWS_PER_THREAD];
+        uint64_t run = 0;
+#pragma unroll
+        for (int jx = 0; jx < ROWS_PER_THREAD; jx++) {
+            uint32_t k = base + t * ROWS_PER_THREAD + jx;
+            uint64_t cnt = k < max_runs ? (uint64_t)ldu32(body + (uint64_t)k * rec) : 0;
+            run += cnt;
+            loc[jx] = run;
+        }
+        uint64_t incl = wave_incl_scan64(run);
+        __syncthreads();
+        if ((t & 63) == 63) s_w64[t >> 6] = incl;
+        __syncthreads();
+        uint64_t pre = s_carry + incl - run;
+        const int w = t >> 6;
+        if (w > 0) pre += s_w64[0];
+        if (w > 1) pre += s_w64[1];
+        if (w > 2) pre += s_w64[2];
+        const uint64_t chunk_total = s_w64[0] + s_w64[1] + s_w64[2] + s_w64[3];
+#pragma unroll
+        for (int jx = 0; jx < ROWS_PER_THREAD; jx++) {
+            uint32_t k = base + t * ROWS_PER_THREAD + jx;
+            uint64_t start = pre + (jx ? loc[jx - 1] : 0);  // exclusive
+            uint64_t endr = pre + loc[jx];
+            if (k < max_runs && start < N) {
+                if (k + 1 < aux_cap_words) aux[k] = (uint32_t)start;
+                if (endr >= N) s_nruns = k + 1;  // exactly one run crosses N
+            }
+        }
+        __syncthreads();
+        if (t == 0) s_carry += chunk_total;
+        __syncthreads();
+        if (s_nruns != 0xFFFFFFFFu) break;
+    }
+    uint32_t R = s_nruns;
+    if (R == 0xFFFFFFFFu) {
+        if (N == 0) {
+            R = 0;
+        } else {
+            if (t == 0) raise(st, SB_ERR_IO, page, 200);  // runs end before N rows (read_u32 EOF upstream)
+            return 0xFFFFFFFFu;
+        }
+    }
+    if (R + 1 + ntiles > aux_cap_words) {
+        if (t == 0) raise(st, SB_ERR_INVALID, page, 201);
+        return 0xFFFFFFFFu;
+    }
+    if (t == 0) aux[R] = (uint32_t)N;
+    __syncthreads();
+    // pass 2: tile_k0
+    uint32_t* tile_k0 = aux + R + 1;
+    for (uint32_t k = t; k < R; k += WG) {
+        uint64_t s = aux[k], e = aux[k + 1];
+        if (e > s) {
+            uint64_t tl = (s + TILE_ROWS - 1) / TILE_ROWS;
+            for (; tl * TILE_ROWS < e && tl < ntiles; tl++) tile_k0[tl] = k;
+        }
+    }
+    (void)s_a;
+    __syncthreads();
+    return R;
+}
+
+// bit-packing plan: walk the block headers (u8 num_bits | 16*num_bits bytes) of `body`, record
+// the header offsets and, for delta pages, the running sum at each tile start.
+// The walk is a serial pointer chase (block k+1's position depends on block k's header); the
+// body is staged through LDS in windows so each step costs an LDS read, not an HBM miss.
+constexpr int BP_WINDOW = 32 * 1024;
+__device__ bool plan_bp(const uint8_t* body, uint32_t csize, uint64_t N, bool delta, uint32_t* aux,
+                        uint8_t* s_win, uint32_t* s_a, uint32_t* s_w, Status* st, uint32_t page) {
+    const int t = threadIdx.x;
+    const uint32_t nblk = (uint32_t)(N / 128);
+    const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+    __shared__ uint32_t s_pos, s_blk, s_err;
+    if (t == 0) {
+        s_pos = 0;
+        s_blk = 0;
+        s_err = 0;
+    }
+    __syncthreads();
+    while (s_blk < nblk && !s_err) {
+        const uint32_t win0 = s_pos;
+        const uint32_t wlen = min((uint32_t)BP_WINDOW, csize - min(csize, win0));
+        __syncthreads();
+        for (uint32_t i = t * 16; i < wlen; i += WG * 16) {
+            if (i + 16 <= wlen) {
+                *(u32x4*)(s_win + i) = ldu128(body + win0 + i);
+            } else {
+                for (uint32_t b = i; b < wlen; b++) s_win[b] = body[win0 + b];
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t pos = win0, blk = s_blk;
+            while (blk < nblk && pos - win0 < wlen) {
+                uint32_t nb = s_win[pos - win0];
+                if (nb > 32 || pos + 1 + 16 * nb > csize) {
+                    s_err = 1;
+                    break;
+                }
+                aux[blk] = pos;
+                pos += 1 + 16 * nb;
+                blk++;
+            }
+            if (blk < nblk && pos >= csize) s_err = 1;
+            s_pos = pos;
+            s_blk = blk;
+        }
+        __syncthreads();
+    }
+    if (s_err) {
+        if (t == 0) raise(st, SB_ERR_IO, page, 210);
+        return false;
+    }
+    if (t == 0) aux[nblk] = s_pos;
+    __syncthreads();
+    uint32_t* tile_base = aux + nblk + 1;
+    if (!delta) return true;
+    // delta pages: value[j] = sum of all deltas up to j (initial 0, delta_bp.rs:73,88); the
+    // expand step needs the running sum at each tile start
+    uint32_t carry = 0;
+    for (uint32_t tl = 0; tl < ntiles; tl++) {
+        if (t == 0) tile_base[tl] = carry;
+        const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, N - (uint64_t)tl * TILE_ROWS);
+        uint32_t acc = 0;
+        for (uint32_t j = t; j < rows; j += WG) {
+            uint32_t blk = tl * (TILE_ROWS / 128) + (j >> 7);
+            const uint8_t* hp = body + aux[blk];
+            acc += bp4x_extract(hp + 1, hp[0], j & 127);
+        }
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_down(acc, dd, 64);
+        __syncthreads();
+        if ((t & 63) == 0) s_w[t >> 6] = acc;
+        __syncthreads();
+        carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
+    (void)s_a;
+    return true;
+}
+
+// ---- index tiles -----------------------------------------------------------------------
+// Produce the u32 values of rows [r0, r0+rows) of a u32 stream coded with `codec` into the LDS
+// array s_a (sidx layout).  Used for Dict indices and for top-level 4-byte integer pages.
+struct U32Stream {
+    const uint8_t* src;   // body (or inflated copy)
+    const uint32_t* aux;  // plan output
+    uint32_t codec;
+    uint32_t n_runs;
+    uint64_t N;
+};
+
+__device__ void rle_tile_runidx(const uint32_t* aux, uint32_t R, uint64_t N, uint32_t tile, uint32_t rows,
+                                uint32_t* s_a, uint32_t* s_w) {
+    // s_a[row] <- index of the run covering row (relative to k0), via scatter of run starts + scan
+    const int t = threadIdx.x;
+    const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+    const uint32_t* tile_k0 = aux + R + 1;
+    const uint32_t k0 = tile_k0[tile];
+    const uint32_t kend = tile + 1 < ntiles ? tile_k0[tile + 1] + 1 : R;  // runs starting before the tile end
+    const uint32_t r0 = tile * TILE_ROWS;
+    for (int i = t; i < SIDX_WORDS; i += WG) s_a[i] = 0;
+    __syncthreads();
+    for (uint32_t k = k0 + 1 + t; k < kend; k += WG) {
+        uint32_t s = aux[k];
+        if (s >= r0 && s < r0 + rows) atomicAdd(&s_a[sidx((int)(s - r0))], 1u);
+    }
+    __syncthreads();
+    tile_incl_scan(s_a, s_w);
+}
+
+__device__ void u32_tile_to_lds(const U32Stream& s, uint32_t tile, uint32_t rows, uint32_t* s_a, uint32_t* s_w) {
+    const int t = threadIdx.x;
+    const uint64_t r0 = (uint64_t)tile * TILE_ROWS;
+    switch (s.codec) {
+        case SB_CODEC_NONE:
+        case SB_CODEC_LZ4:
+        case SB_CODEC_ZSTD:
+        case SB_CODEC_SNAPPY: {  // plain u32 (inflated beforehand if compressed)
+            const uint8_t* p = s.src + r0 * 4;
+            for (uint32_t i = t; i < rows; i += WG) s_a[sidx((int)i)] = ldu32(p + (uint64_t)i * 4);
+            __syncthreads();
+            break;
+        }
+        case SB_CODEC_ONEVALUE: {
+            const uint32_t v = ldu32(s.src);
+            for (uint32_t i = t; i < rows; i += WG) s_a[sidx((int)i)] = v;
+            __syncthreads();
+            break;
+        }
+        case SB_CODEC_RLE: {
+            rle_tile_runidx(s.aux, s.n_runs, s.N, tile, rows, s_a, s_w);
+            const uint32_t k0 = (s.aux + s.n_runs + 1)[tile];
+            for (uint32_t i = t; i < rows; i += WG) {
+                uint32_t k = k0 + s_a[sidx((int)i)];
+                s_a[sidx((int)i)] = ldu32(s.src + (uint64_t)k * 8 + 4);
+            }
+            __syncthreads();
+            break;
+        }
+        case SB_CODEC_BITPACKING:
+        case SB_CODEC_DELTA_BITPACKING: {
+            const uint32_t nblk = (uint32_t)(s.N / 128);
+            for (uint32_t j = t; j < rows; j += WG) {
+                uint32_t blk = tile * (TILE_ROWS / 128) + (j >> 7);
+                const uint8_t* hp = s.src + s.aux[blk];
+                s_a[sidx((int)j)] = bp4x_extract(hp + 1, hp[0], j & 127);
+            }
+            for (uint32_t j = rows + t; j < TILE_ROWS; j += WG) s_a[sidx((int)j)] = 0;
+            __syncthreads();
+            if (s.codec == SB_CODEC_DELTA_BITPACKING) {
+                tile_incl_scan(s_a, s_w);
+                const uint32_t base = (s.aux + nblk + 1)[tile];
+                for (uint32_t j = t; j < rows; j += WG) s_a[sidx((int)j)] += base;
+                __syncthreads();
+            }
+            break;
+        }
+        default:
+            break;
+    }
+}
+
+// binary Dict plan: entry offsets (serial walk over `u64 len | bytes` records, staged through
+// LDS) and per-tile byte totals of the page.
+__device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, const uint8_t* page_end, uint32_t* aux,
+                              uint32_t aux_cap_words, uint8_t* s_win, uint32_t* s_a, uint32_t* s_w, uint64_t* s_w64,
+                              Status* st, uint32_t page) {
+    const int t = threadIdx.x;
+    const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+    const uint32_t D = d.dict_n;
+    if ((uint64_t)D + 1 + ntiles + 1 > aux_cap_words) {
+        if (t == 0) raise(st, SB_ERR_INVALID, page, 220);
+        return false;
+    }
+    uint32_t* ent_off = aux;              // D+1 entries: offset of entry k's record (its u64 len) from d.dict
+    uint32_t* tile_bytes = aux + D + 1;   // ntiles+1: exclusive prefix of value bytes per tile
+    const uint64_t avail = (uint64_t)(page_end - d.dict);
+    __shared__ uint32_t s_pos, s_ent, s_err;
+    if (t == 0) {
+        s_pos = 0;
+        s_ent = 0;
+        s_err = 0;
+    }
+    __syncthreads();
+    while (s_ent < D && !s_err) {
+        const uint32_t win0 = s_pos;
+        const uint32_t wlen = (uint32_t)min((uint64_t)BP_WINDOW, avail - min(avail, (uint64_t)win0));
+        __syncthreads();
+        for (uint32_t i = t * 16; i < wlen; i += WG * 16) {
+            if (i + 16 <= wlen) {
+                *(u32x4*)(s_win + i) = ldu128(d.dict + win0 + i);
+            } else {
+                for (uint32_t b = i; b < wlen; b++) s_win[b] = d.dict[win0 + b];
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t pos = win0, e = s_ent;
+            while (e < D && pos - win0 + 8 <= wlen) {
+                uint64_t len;
+                __builtin_memcpy(&len, s_win + (pos - win0), 8);
+                if (len > avail - pos - 8) {
+                    s_err = 1;
+                    break;
+                }
+                ent_off[e] = pos;
+                pos += 8 + (uint32_t)len;
+                e++;
+            }
+            if (e < D && (uint64_t)pos + 8 > avail) s_err = 1;
+            s_pos = pos;
+            s_ent = e;
+        }
+        __syncthreads();
+    }
+    if (s_err) {
+        if (t == 0) raise(st, SB_ERR_OUT_OF_SPEC, page, 221);
+        return false;
+    }
+    if (t == 0) ent_off[D] = s_pos;
+    __syncthreads();
+    uint64_t carry = 0;
+    for (uint32_t tl = 0; tl < ntiles; tl++) {
+        const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, N - (uint64_t)tl * TILE_ROWS);
+        u32_tile_to_lds(is, tl, rows, s_a, s_w);
+        uint64_t acc = 0;
+        bool bad = false;
+        for (uint32_t i = t; i < rows; i += WG) {
+            uint32_t k = s_a[sidx((int)i)];
+            if (k >= D) {
+                bad = true;
+                break;
+            }
+            acc += ent_off[k + 1] - ent_off[k] - 8;
+        }
+        if (bad) raise(st, SB_ERR_OUT_OF_SPEC, page, 222);
+        if (t == 0) tile_bytes[tl] = (uint32_t)carry;
+        carry += wg_sum64(acc, s_w64);
+        __syncthreads();
+    }
+    if (t == 0) {
+        tile_bytes[ntiles] = (uint32_t)carry;
+        d.val_bytes = carry;
+    }
+    __syncthreads();
+    return true;
+}
+
+__global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
+    const uint32_t p = blockIdx.x;
+    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[BP_WINDOW];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint64_t s_w64[4];
+    PageDesc d = a.descs[p];
+    if (!d.ok) return;
+    const PageTask t = a.tasks[p];
+    const ColDesc c = a.cols[t.col];
+    const uint64_t N = t.num_values;
+    uint32_t* aux = (uint32_t*)(a.scratch + t.aux_off);
+    const uint32_t aux_cap = (uint32_t)((t.infl_off - t.aux_off) / 4);
+    const uint8_t* page_end = c.pages + t.in_off + t.length;
+    bool changed = false;
+    if (c.ptype == SB_TYPE_BOOLEAN) {
+        if (d.codec == SB_CODEC_RLE) {  // runs of u32 count | u8 value (boolean/rle.rs:41-55)
+            uint32_t R = plan_rle(d.body, (uint32_t)(page_end - d.body), 5, N, aux, aux_cap, s_a, s_w64, a.status, p);
+            if (R == 0xFFFFFFFFu) d.ok = 0;
+            d.n_runs = R;
+            changed = true;
+        }
+    } else if (d.codec == SB_CODEC_RLE) {  // runs see the rest of the buffer (integer/mod.rs:108-110)
+        uint32_t R = plan_rle(d.body, (uint32_t)(page_end - d.body), 4 + c.width, N, aux, aux_cap, s_a, s_w64,
+                              a.status, p);
+        if (R == 0xFFFFFFFFu) d.ok = 0;
+        d.n_runs = R;
+        changed = true;
+    } else if (d.codec == SB_CODEC_BITPACKING || d.codec == SB_CODEC_DELTA_BITPACKING) {
+        if (!plan_bp(d.body, (uint32_t)(page_end - d.body), N, d.codec == SB_CODEC_DELTA_BITPACKING, aux, s_win, s_a,
+                     s_w, a.status, p)) {
+            d.ok = 0;
+            changed = true;
+        }
+    } else if (d.codec == SB_CODEC_DICT) {
+        const uint32_t ic = d.icodec;
+        if (ic == SB_CODEC_RLE) {
+            uint32_t R = plan_rle(d.ibody, (uint32_t)(page_end - d.ibody), 8, N, aux, aux_cap, s_a, s_w64, a.status, p);
+            if (R == 0xFFFFFFFFu) d.ok = 0;
+            d.n_runs = R;
+            changed = true;
+        } else if (ic == SB_CODEC_BITPACKING || ic == SB_CODEC_DELTA_BITPACKING) {
+            if (!plan_bp(d.ibody, d.icsize, N, ic == SB_CODEC_DELTA_BITPACKING, aux, s_win, s_a, s_w, a.status, p)) {
+                d.ok = 0;
+                changed = true;
+            }
+        }
+        if (d.ok && is_binary(c.ptype)) {
+            const uint32_t used = idx_aux_words(ic, d.n_runs, N);
+            U32Stream is{d.isrc, aux, ic, d.n_runs, N};
+            __syncthreads();
+            if (!plan_bin_dict(d, is, N, page_end, aux + used, aux_cap - used, s_win, s_a, s_w, s_w64, a.status, p))
+                d.ok = 0;
+            changed = true;
+        }
+    }
+    // binary Basic: last decoded offset of the page (needed for the cross-page offset base)
+    if (d.ok && is_binary(c.ptype)) {
+        if (is_basic(d.codec)) {
+            d.off_last = c.width == 4 ? (uint64_t)ldu32(d.src + N * 4) : ldu64(d.src + N * 8);
+        } else {
+            d.off_last = d.val_bytes;
+        }
+        changed = true;
+    }
+    if (changed && threadIdx.x == 0) a.descs[p] = d;
+}
+
+// -------------------------------------------------------------------------------- colscan
+// binary columns: value-byte base and offset base of each page (the running `last` of
+// decompress_binary, binary/mod.rs:121,136-144, and values.len()), queue-B inflate jobs for
+// compressed values blocks, and the column's total value bytes.
+__global__ void k_colscan(DecodeArgs a, uint64_t* col_values_len) {
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= a.n_cols) return;
+    const ColDesc c = a.cols[ci];
+    if (!is_binary(c.ptype)) {
+        col_values_len[ci] = c.ptype == SB_TYPE_BOOLEAN ? (c.rows + 7) / 8 : c.rows * c.width;
+        return;
+    }
+    uint64_t vbase = 0, obase = 0;
+    for (uint32_t k = 0; k < c.n_pages; k++) {
+        const uint32_t p = c.first_page + k;
+        PageDesc d = a.descs[p];
+        d.val_base = vbase;
+        // page 0's offsets are taken verbatim (incl. offsets[0]); later pages add the running last offset
+        d.off_base = obase;
+        a.descs[p] = d;
+        if (!d.ok) continue;
+        if (is_basic(d.codec) && d.codec != SB_CODEC_NONE && vbase + d.vusize <= c.values_cap)
+            push_job(a.jobs_b, a.job_counts + 1, d.vbody, d.vcsize, c.values + vbase, d.vusize, d.codec, p);
+        vbase += d.val_bytes;
+        obase += d.off_last;
+    }
+    col_values_len[ci] = vbase;
+    if (vbase > c.values_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 300);
+}
+
+// -------------------------------------------------------------------------------- expand
+// copy `n` bytes from an arbitrarily aligned source to dst; the bulk moves as 16-byte stores
+__device__ __forceinline__ void tile_copy_bytes(uint8_t* dst, const uint8_t* src, uint32_t n) {
+    const int t = threadIdx.x;
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (head > n) head = n;
+    if ((uint32_t)t < head) dst[t] = src[t];
+    const uint32_t nvec = (n - head) >> 4;
+    uint8_t* d16 = dst + head;
+    const uint8_t* s16 = src + head;
+    uint32_t i = t;
+    for (; i + 3 * WG < nvec; i += 4 * WG) {  // 4 loads in flight per lane
+        u32x4 v0 = ldu128(s16 + (uint64_t)i * 16);
+        u32x4 v1 = ldu128(s16 + (uint64_t)(i + WG) * 16);
+        u32x4 v2 = ldu128(s16 + (uint64_t)(i + 2 * WG) * 16);
+        u32x4 v3 = ldu128(s16 + (uint64_t)(i + 3 * WG) * 16);
+        *(u32x4*)(d16 + (uint64_t)i * 16) = v0;
+        *(u32x4*)(d16 + (uint64_t)(i + WG) * 16) = v1;
+        *(u32x4*)(d16 + (uint64_t)(i + 2 * WG) * 16) = v2;
+        *(u32x4*)(d16 + (uint64_t)(i + 3 * WG) * 16) = v3;
+    }
+    for (; i < nvec; i += WG) *(u32x4*)(d16 + (uint64_t)i * 16) = ldu128(s16 + (uint64_t)i * 16);
+    const uint32_t tail0 = head + (nvec << 4);
+    if (tail0 + t < n) dst[tail0 + t] = src[tail0 + t];
+}
+
+// write `rows` values of W bytes, row i produced by get(i); 16-byte stores when the
+// destination allows it
+template <int W, class F>
+__device__ __forceinline__ void emit_rows(uint8_t* dst, uint32_t rows, F get) {
+    const int t = threadIdx.x;
+    if constexpr (W < 16) {
+        constexpr int RPL = 16 / W;
+        if (((uintptr_t)dst & 15) == 0) {
+            const uint32_t full = rows / RPL;
+            for (uint32_t g = t; g < full; g += WG) {
+                Val<W> v[RPL];
+#pragma unroll
+                for (int r = 0; r < RPL; r++) v[r] = get(g * RPL + r);
+                u32x4 pk;
+                __builtin_memcpy(&pk, v, 16);
+                *(u32x4*)(dst + (uint64_t)g * 16) = pk;
+            }
+            for (uint32_t i = full * RPL + t; i < rows; i += WG) st_val<W>(dst + (uint64_t)i * W, get(i));
+            return;
+        }
+    }
+    for (uint32_t i = t; i < rows; i += WG) st_val<W>(dst + (uint64_t)i * W, get(i));
+}
+
+// OR `nbits` (<= 32) bits `v` into the LSB-first bitmap at bit position `pos`
+__device__ __forceinline__ void bitmap_put(uint8_t* bm, uint64_t pos, uint32_t v, uint32_t nbits) {
+    if (nbits < 32) v &= (1u << nbits) - 1;
+    uint32_t* w = (uint32_t*)bm + (pos >> 5);
+    const uint32_t sh = (uint32_t)(pos & 31);
+    if (sh == 0 && nbits == 32) {
+        *w = v;
+        return;
+    }
+    if (v << sh) atomicOr(w, v << sh);
+    if (sh && (v >> (32 - sh))) atomicOr(w + 1, v >> (32 - sh));
+}
+
+// copy rows [r0, r0+rows) of an LSB-first source bitmap (starting at bit 0 of src) to the
+// destination bitmap at bit (dst_bit0 + r0 ...)
+__device__ __forceinline__ void tile_copy_bits(uint8_t* dst_bm, uint64_t dst_bit0, const uint8_t* src, uint64_t r0,
+                                               uint32_t rows, uint64_t src_total_bits) {
+    const int t = threadIdx.x;
+    const uint32_t ngroups = (rows + 31) / 32;
+    for (uint32_t g = t; g < ngroups; g += WG) {
+        const uint64_t sb = r0 + (uint64_t)g * 32;  // r0 is a multiple of TILE_ROWS => byte aligned
+        const uint32_t nb = min(32u, rows - g * 32);
+        const uint8_t* p = src + (sb >> 3);
+        uint32_t v;
+        const uint64_t bytes_left = ((src_total_bits + 7) >> 3) - (sb >> 3);
+        if (bytes_left >= 4) {
+            v = ldu32(p);
+        } else {
+            v = 0;
+            for (uint32_t b = 0; b < bytes_left; b++) v |= (uint32_t)p[b] << (8 * b);
+        }
+        bitmap_put(dst_bm, dst_bit0 + sb, v, nb);
+    }
+}
+
+template <int W>
+__device__ void expand_prim(const ColDesc& c, const PageTask& t, const PageDesc& d, uint32_t tile, uint32_t rows,
+                            uint8_t* scratch, uint32_t* s_a, uint32_t* s_w, Status* st, uint32_t page) {
+    const uint64_t r0 = (uint64_t)tile * TILE_ROWS;
+    uint8_t* dst = c.values + (t.out_row + r0) * W;
+    const uint32_t* aux = (const uint32_t*)(scratch + t.aux_off);
+    switch (d.codec) {
+        case SB_CODEC_NONE:  // integer/mod.rs:97-107 + basic.rs:67-70
+            tile_copy_bytes(dst, d.src + r0 * W, rows * W);
+            break;
+        case SB_CODEC_LZ4:
+        case SB_CODEC_ZSTD:
+        case SB_CODEC_SNAPPY:
+            break;  // inflated straight into place by k_inflate
+        case SB_CODEC_ONEVALUE: {  // integer/one_value.rs:77-94
+            const Val<W> v = ld_val<W>(d.body);
+            emit_rows<W>(dst, rows, [&](uint32_t) { return v; });
+            break;
+        }
+        case SB_CODEC_RLE: {  // integer/rle.rs:106-134
+            rle_tile_runidx(aux, d.n_runs, t.num_values, tile, rows, s_a, s_w);
+            const uint32_t k0 = (aux + d.n_runs + 1)[tile];
+            const uint8_t* body = d.body;
+            emit_rows<W>(dst, rows, [&](uint32_t i) {
+                uint32_t k = k0 + s_a[sidx((int)i)];
+                return ld_val<W>(body + (uint64_t)k * (4 + W) + 4);
+            });
+            break;
+        }
+        case SB_CODEC_DICT: {  // integer/dict.rs:75-103
+            U32Stream is{d.isrc, aux, d.icodec, d.n_runs, t.num_values};
+            u32_tile_to_lds(is, tile, rows, s_a, s_w);
+            const uint8_t* dict = d.dict;
+            const uint32_t D = d.dict_n;
+            bool bad = false;
+            emit_rows<W>(dst, rows, [&](uint32_t i) {
+                uint32_t k = s_a[sidx((int)i)];
+                if (k >= D) {
+                    bad = true;
+                    k = 0;
+                }
+                return ld_val<W>(dict + (uint64_t)k * W);
+            });
+            if (bad) raise(st, SB_ERR_OUT_OF_SPEC, page, 400);
+            break;
+        }
+        case SB_CODEC_BITPACKING:
+        case SB_CODEC_DELTA_BITPACKING: {  // integer/bp.rs:66-86, delta_bp.rs:70-92
+            if constexpr (W == 4) {
+                U32Stream vs{d.body, aux, d.codec, 0, t.num_values};
+                u32_tile_to_lds(vs, tile, rows, s_a, s_w);
+                emit_rows<4>(dst, rows, [&](uint32_t i) {
+                    Val<4> v;
+                    v.x = s_a[sidx((int)i)];
+                    return v;
+                });
+            }
+            break;
+        }
+        default:
+            break;
+    }
+}
+
+__device__ void expand_bool(const ColDesc& c, const PageTask& t, const PageDesc& d, uint32_t tile, uint32_t rows,
+                            uint8_t* scratch, uint32_t* s_a, uint32_t* s_w) {
+    const uint64_t r0 = (uint64_t)tile * TILE_ROWS;
+    const int tid = threadIdx.x;
+    if (is_basic(d.codec)) {  // boolean/mod.rs:87-92
+        tile_copy_bits(c.values, t.out_row, d.src, r0, rows, t.num_values);
+    } else if (d.codec == SB_CODEC_ONEVALUE) {  // boolean/one_value.rs:54-61
+        const uint32_t v = d.body[0] > 0 ? 0xFFFFFFFFu : 0u;
+        const uint32_t ngroups = (rows + 31) / 32;
+        for (uint32_t g = tid; g < ngroups; g += WG)
+            bitmap_put(c.values, t.out_row + r0 + (uint64_t)g * 32, v, min(32u, rows - g * 32));
+    } else if (d.codec == SB_CODEC_RLE) {  // boolean/rle.rs:41-55
+        const uint32_t* aux = (const uint32_t*)(scratch + t.aux_off);
+        rle_tile_runidx(aux, d.n_runs, t.num_values, tile, rows, s_a, s_w);
+        const uint32_t k0 = (aux + d.n_runs + 1)[tile];
+        for (uint32_t i0 = 0; i0 < TILE_ROWS; i0 += WG) {
+            const uint32_t i = i0 + tid;
+            bool bit = false;
+            if (i < rows) {
+                uint32_t k = k0 + s_a[sidx((int)i)];
+                bit = d.body[(uint64_t)k * 5 + 4] != 0;
+            }
+            const uint64_t m = __ballot(bit);
+            if ((tid & 31) == 0 && i < rows) {
+                const uint32_t half = (tid & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
+                bitmap_put(c.values, t.out_row + r0 + i, half, min(32u, rows - i));
+            }
+        }
+    }
+}
+
+template <class O>
+__device__ void expand_binary(const ColDesc& c, const PageTask& t, const PageDesc& d, uint32_t tile, uint32_t rows,
+                              uint8_t* scratch, uint32_t* s_a, uint32_t* s_len, uint32_t* s_w, Status* st,
+                              uint32_t page) {
+    const uint64_t r0 = (uint64_t)tile * TILE_ROWS;
+    const int tid = threadIdx.x;
+    const uint64_t N = t.num_values;
+    O* out_off = (O*)c.offsets;
+    const bool first_page = t.out_row == 0;
+    if (is_basic(d.codec)) {
+        // offsets: page 0 verbatim (N+1 entries); later pages drop their leading entry and add
+        // the running last offset (binary/mod.rs:136-144)
+        const uint8_t* so = d.src;
+        for (uint32_t i = tid; i < rows; i += WG) {
+            O v;
+            __builtin_memcpy(&v, so + (r0 + i + 1) * sizeof(O), sizeof(O));
+            out_off[t.out_row + r0 + i + 1] = (O)(v + (O)d.off_base);
+        }
+        if (first_page && tile == 0 && tid == 0) {
+            O v;
+            __builtin_memcpy(&v, so, sizeof(O));
+            out_off[0] = v;
+        }
+        // values: this tile copies its share of the page's value bytes
+        if (d.codec == SB_CODEC_NONE) {
+            const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+            const uint64_t per = (((uint64_t)d.vusize + ntiles - 1) / ntiles + 15) & ~(uint64_t)15;
+            const uint64_t b0 = min((uint64_t)d.vusize, per * tile), b1 = min((uint64_t)d.vusize, per * (tile + 1));
+            if (b1 > b0) tile_copy_bytes(c.values + d.val_base + b0, d.vbody + b0, (uint32_t)(b1 - b0));
+        }
+        return;
+    }
+    if (tile == 0 && first_page && tid == 0) out_off[0] = 0;
+    if (d.codec == SB_CODEC_ONEVALUE) {  // binary/one_value.rs:70-97
+        const uint32_t len = d.dict_n;
+        for (uint32_t i = tid; i < rows; i += WG)
+            out_off[t.out_row + r0 + i + 1] = (O)(d.off_base + (uint64_t)len * (r0 + i + 1));
+        uint8_t* vdst = c.values + d.val_base + (uint64_t)len * r0;
+        const uint64_t total = (uint64_t)len * rows;
+        if (len) {
+            for (uint64_t b = tid; b < total; b += WG) vdst[b] = d.dict[b % len];
+        }
+        return;
+    }
+    if (d.codec == SB_CODEC_DICT) {  // binary/dict.rs:95-140
+        const uint32_t* aux = (const uint32_t*)(scratch + t.aux_off);
+        U32Stream is{d.isrc, aux, d.icodec, d.n_runs, N};
+        const uint32_t used = idx_aux_words(d.icodec, d.n_runs, N);
+        const uint32_t* ent_off = aux + used;
+        const uint32_t D = d.dict_n;
+        const uint32_t* tile_bytes = ent_off + D + 1;
+        u32_tile_to_lds(is, tile, rows, s_a, s_w);
+        // s_a: index -> keep; lengths scanned in a second LDS array
+        for (uint32_t i = tid; i < TILE_ROWS; i += WG) {
+            uint32_t len = 0;
+            if (i < rows) {
+                uint32_t k = s_a[sidx((int)i)];
+                if (k < D) len = ent_off[k + 1] - ent_off[k] - 8;
+            }
+            s_len[sidx((int)i)] = len;
+        }
+        __syncthreads();
+        tile_incl_scan(s_len, s_w);
+        const uint64_t tb = tile_bytes[tile];
+        uint8_t* vdst = c.values + d.val_base + tb;
+        for (uint32_t i = tid; i < rows; i += WG) {
+            const uint32_t endb = s_len[sidx((int)i)];
+            out_off[t.out_row + r0 + i + 1] = (O)(d.off_base + tb + endb);
+            const uint32_t k = s_a[sidx((int)i)];
+            if (k < D) {
+                const uint32_t len = ent_off[k + 1] - ent_off[k] - 8;
+                const uint8_t* sp = d.dict + ent_off[k] + 8;
+                uint8_t* dp = vdst + (endb - len);
+                for (uint32_t b = 0; b < len; b++) dp[b] = sp[b];
+            }
+        }
+        (void)st;
+        (void)page;
+    }
+}
+
+// tile -> (page, tile) with an XCD-aware order: block b runs on XCD b%8, so give every XCD a
+// contiguous range of the tile table (tiles of one page share dictionary / aux lines in one L2)
+__device__ __forceinline__ uint32_t xcd_tile_index() {
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const uint32_t per = nb / 8, rem = nb % 8, x = b % 8, q = b / 8;
+    return x * per + min(x, rem) + q;
+}
+
+// primitives + booleans (17 KB LDS: 8 workgroups per CU)
+__global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
+    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ uint32_t s_w[4];
+    const TileTask tt = a.tiles[xcd_tile_index()];
+    const PageDesc d = a.descs[tt.page];
+    if (!d.ok) return;
+    const PageTask t = a.tasks[tt.page];
+    const ColDesc c = a.cols[t.col];
+    if (is_binary(c.ptype)) return;  // k_expand_binary
+    const uint64_t r0 = (uint64_t)tt.tile * TILE_ROWS;
+    const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, t.num_values - r0);
+    if (d.def_bits) tile_copy_bits(c.validity, t.out_row, d.def_bits, r0, rows, t.num_values);
+    if (c.ptype == SB_TYPE_BOOLEAN) {
+        expand_bool(c, t, d, tt.tile, rows, a.scratch, s_a, s_w);
+        return;
+    }
+    switch (c.width) {
+        case 1:
+            expand_prim<1>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            break;
+        case 2:
+            expand_prim<2>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            break;
+        case 4:
+            expand_prim<4>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            break;
+        case 8:
+            expand_prim<8>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            break;
+        case 16:
+            expand_prim<16>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            break;
+        case 32:
+            expand_prim<32>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            break;
+    }
+}
+
+// Binary / Utf8 columns (two LDS arrays)
+__global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
+    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ uint32_t s_len[SIDX_WORDS];
+    __shared__ uint32_t s_w[4];
+    const TileTask tt = a.tiles[xcd_tile_index()];
+    const PageDesc d = a.descs[tt.page];
+    if (!d.ok) return;
+    const PageTask t = a.tasks[tt.page];
+    const ColDesc c = a.cols[t.col];
+    if (!is_binary(c.ptype)) return;
+    const uint64_t r0 = (uint64_t)tt.tile * TILE_ROWS;
+    const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, t.num_values - r0);
+    if (d.def_bits) tile_copy_bits(c.validity, t.out_row, d.def_bits, r0, rows, t.num_values);
+    if (c.ptype == SB_TYPE_BINARY)
+        expand_binary<int32_t>(c, t, d, tt.tile, rows, a.scratch, s_a, s_len, s_w, a.status, tt.page);
+    else
+        expand_binary<int64_t>(c, t, d, tt.tile, rows, a.scratch, s_a, s_len, s_w, a.status, tt.page);
+}
+
+// -------------------------------------------------------------------------------- launcher
+void launch_decode(const DecodeArgs& a, bool any_binary, bool any_prim, bool any_plan, uint64_t* col_values_len,
+                   hipStream_t s) {
+    hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
+    k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
+    k_inflate<<<(2 * a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+    if (any_plan) k_plan<<<a.n_pages, WG, 0, s>>>(a);
+    k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
+    if (any_binary) k_inflate<<<(a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
+    if (a.n_tiles && any_prim) k_expand<<<a.n_tiles, WG, 0, s>>>(a);
+    if (a.n_tiles && any_binary) k_expand_binary<<<a.n_tiles, WG, 0, s>>>(a);
+}
+
+void launch_parse_sizes(const DecodeArgs& a, uint64_t* col_values_len, hipStream_t s) {
+    hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
+    k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
+    k_inflate<<<(2 * a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+    k_plan<<<a.n_pages, WG, 0, s>>>(a);
+    k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
+}
+
+}  // namespace sb

@@ -1,0 +1,70 @@
+// strawboat-hip: host-side context (workspace, staging ring, error plumbing).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "sb_common.h"
+
+namespace sb {
+
+struct DevBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+};
+
+// pinned host staging slot: uploads (tables) and readbacks (status, sizes, metas)
+struct StageSlot {
+    uint8_t* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+struct Pending {  // results to hand back to the caller's structs at synchronize
+    enum Kind { READ_COL, WRITE_COL } kind;
+    void* user;            // sb_column_read* / sb_column_write*
+    const uint8_t* host;   // where the readback lands (pinned)
+    uint64_t n;            // WRITE_COL: number of pages
+};
+
+}  // namespace sb
+
+struct sb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    int32_t sticky = 0;  // first host-side error since the last synchronize
+
+    sb::DevBuf tables;   // ColDesc / PageTask / PageDesc / TileTask / jobs / counters
+    sb::DevBuf scratch;  // per-page aux + inflate areas, encode slots
+    sb::DevBuf staging;  // device staging for SB_MEM_HOST callers
+    sb::Status* d_status = nullptr;
+    sb::Status* h_status = nullptr;  // pinned
+
+    static constexpr int NSLOTS = 8;
+    sb::StageSlot slots[NSLOTS];
+    int next_slot = 0;
+
+    std::vector<sb::Pending> pending;
+    // SB_MEM_HOST copies to hand back after the stream drains: (host dst, device src, bytes)
+    struct Copyback {
+        void* host;
+        const void* dev;
+        size_t n;
+    };
+    std::vector<Copyback> copybacks;
+    std::vector<void*> temp_dev;  // device temporaries to free at synchronize
+
+    int32_t fail(int32_t code, const std::string& msg) {
+        last_error = msg;
+        if (!sticky) sticky = code;
+        return code;
+    }
+};
+
+namespace sb {
+bool ensure(sb_ctx* ctx, DevBuf& b, size_t need);
+StageSlot* acquire_slot(sb_ctx* ctx, size_t need);
+int32_t check_hip(sb_ctx* ctx, hipError_t e, const char* what);
+}  // namespace sb

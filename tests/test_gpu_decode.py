@@ -1,0 +1,109 @@
+"""GPU parity: pages written by the CPU oracle, decoded by the HIP path through the C ABI,
+compared bit for bit with the oracle's decode of the same pages."""
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_decode(ctx, col, pages, metas):
+    import torch
+    from strawboat_amd import read
+    cp = read.ColumnPages(col["ptype"], col["nullable"], torch.from_numpy(pages).to(ctx.torch_device), metas)
+    return read.read_simple(ctx, cp)
+
+
+def check(ctx, col, **opt):
+    pages, metas = gen.oracle_write(col, **opt)
+    want = gen.oracle_read(col, pages, metas)
+    got = gpu_decode(ctx, col, pages, metas)
+    assert got.rows == want["rows"]
+    assert np.array_equal(got.values_numpy(), want["values"]), "values differ"
+    if col["nullable"] and col["ptype"] != S.T_NULL:
+        assert np.array_equal(got.validity_numpy(), want["validity"]), "validity differs"
+    if col["offsets"] is not None:
+        assert np.array_equal(got.offsets_numpy(), want["offsets"]), "offsets differ"
+    return pages, metas
+
+
+PRIMS = [S.T_I8, S.T_I16, S.T_I32, S.T_I64, S.T_U8, S.T_U16, S.T_U32, S.T_U64, S.T_F32, S.T_F64, S.T_I128, S.T_I256]
+
+
+@pytest.mark.parametrize("ptype", PRIMS)
+@pytest.mark.parametrize("codec", [S.NONE, S.RLE, S.DICT, S.ONEVALUE])
+def test_prim_codecs(gpu_ctx, ptype, codec):
+    uniq = 1 if codec == S.ONEVALUE else 100
+    col = gen.prim(ptype, 10_000, uniq=uniq, null_density=0.2, runs=8)
+    check(gpu_ctx, col, max_page_size=2048, force_codec=codec)
+    col = gen.prim(ptype, 10_000, uniq=uniq, runs=3)
+    check(gpu_ctx, col, max_page_size=4100, force_codec=codec)
+
+
+@pytest.mark.parametrize("ptype", [S.T_I32, S.T_U32])
+@pytest.mark.parametrize("codec", [S.BITPACK, S.DELTABP])
+def test_bitpacking(gpu_ctx, ptype, codec):
+    col = gen.prim(ptype, 128 * 100, uniq=1 << 13, sorted_=(codec == S.DELTABP))
+    check(gpu_ctx, col, max_page_size=128 * 40, force_codec=codec)
+    col = gen.prim(ptype, 128 * 1024, uniq=1 << 30, sorted_=(codec == S.DELTABP), seed=7)
+    check(gpu_ctx, col, max_page_size=65536, force_codec=codec)
+
+
+@pytest.mark.parametrize("icodec", [S.NONE, S.RLE, S.BITPACK, S.DELTABP, S.ONEVALUE, S.LZ4])
+def test_dict_index_codecs(gpu_ctx, icodec):
+    uniq = 1 if icodec == S.ONEVALUE else 200
+    col = gen.prim(S.T_F64, 128 * 300, uniq=uniq, null_density=0.1, runs=16, sorted_=(icodec == S.DELTABP))
+    check(gpu_ctx, col, max_page_size=128 * 100, force_codec=S.DICT, force_index_codec=icodec)
+
+
+def test_c1_int64_single_page(gpu_ctx):
+    rng = np.random.default_rng(42)
+    vals = rng.integers(0, 1 << 62, 1_000_000).astype(np.int64)
+    col = dict(ptype=S.T_I64, nullable=False, rows=vals.size, values=vals, validity=None, offsets=None)
+    pages, metas = check(gpu_ctx, col)
+    assert metas.shape[0] == 1 and metas[0, 0] == 8_000_009
+
+
+def test_c2_float64_pages(gpu_ctx):
+    col = gen.prim(S.T_F64, 1_000_000, uniq=256, null_density=0.1, runs=32)
+    for codec in (S.RLE, S.DICT, S.NONE):
+        check(gpu_ctx, col, max_page_size=65536, force_codec=codec)
+    check(gpu_ctx, col, max_page_size=65536, force_codec=S.DICT, force_index_codec=S.BITPACK)
+
+
+@pytest.mark.parametrize("codec", [S.NONE, S.RLE, S.ONEVALUE, S.LZ4])
+def test_boolean(gpu_ctx, codec):
+    p = 1.0 if codec == S.ONEVALUE else 0.5
+    col = gen.boolean(100_003, null_density=0.3, p_true=p, runs=5)
+    check(gpu_ctx, col, max_page_size=8192, force_codec=codec)
+    col = gen.boolean(10_000, p_true=p, runs=40)
+    check(gpu_ctx, col, max_page_size=1000, force_codec=codec)  # pages not multiples of 32 rows
+
+
+@pytest.mark.parametrize("large", [False, True])
+@pytest.mark.parametrize("codec", [S.NONE, S.DICT, S.ONEVALUE, S.LZ4])
+def test_binary(gpu_ctx, codec, large):
+    uniq = 1 if codec == S.ONEVALUE else 300
+    col = gen.binary(20_000, uniq=uniq, null_density=0.1, large=large, zipf=1.3)
+    check(gpu_ctx, col, max_page_size=4096, force_codec=codec)
+    col = gen.binary(5_000, uniq=uniq, large=large)
+    check(gpu_ctx, col, max_page_size=5000, force_codec=codec, force_index_codec=S.RLE)
+
+
+@pytest.mark.parametrize("ptype", [S.T_I32, S.T_I64, S.T_F64])
+def test_lz4_pages(gpu_ctx, ptype):
+    col = gen.prim(ptype, 50_000, uniq=50, null_density=0.1, runs=4)
+    check(gpu_ctx, col, max_page_size=8192, default_compression=S.LZ4)
+
+
+def test_corrupt_codec_raises(gpu_ctx):
+    from strawboat_amd._native import NativeError
+    col = gen.prim(S.T_I32, 1000, uniq=10)
+    pages, metas = gen.oracle_write(col)
+    pages = pages.copy()
+    pages[0] = 77  # unknown codec id
+    with pytest.raises(NativeError) as e:
+        gpu_decode(gpu_ctx, col, pages, metas)
+    assert e.value.code == -1

@@ -8,7 +8,8 @@ from . import _native as N
 
 class Context:
     def __init__(self, device=0, stream=None):
-        """`stream`: a torch.cuda.Stream (default: the current stream of `device`)."""
+        """`stream`: a torch.cuda.Stream to enqueue on (default: a new stream owned by the context;
+        the legacy null stream cannot be passed through the C ABI, its handle is NULL)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("strawboat_amd needs a GPU: torch.cuda.is_available() is False "
@@ -16,7 +17,11 @@ class Context:
         self._lib = N.load()
         self.device = int(device)
         self.torch_device = torch.device("cuda", self.device)
-        self.torch_stream = stream if stream is not None else torch.cuda.current_stream(self.torch_device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.torch_device)
+            if stream.cuda_stream == 0:
+                stream = torch.cuda.Stream(device=self.torch_device)
+        self.torch_stream = stream
         h = C.c_void_p()
         rc = self._lib.sb_ctx_create(self.device, C.c_void_p(self.torch_stream.cuda_stream), C.byref(h))
         if rc != N.SB_OK:

@@ -1,0 +1,135 @@
+"""GPU parity: Arrow buffers encoded by the HIP path through the C ABI must equal, byte for
+byte, the pages the CPU oracle writes for the same input and options (deterministic codecs),
+and decode back (GPU) to what the oracle decodes."""
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+
+pytestmark = pytest.mark.gpu
+
+
+def to_device_column(ctx, col):
+    import torch
+    from strawboat_amd.write import DeviceColumn
+    dev = ctx.torch_device
+
+    def up(a):
+        if a is None:
+            return None
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+    return DeviceColumn(col["ptype"], col["nullable"], col["rows"], up(col["values"]), up(col["validity"]),
+                        up(col["offsets"]))
+
+
+def gpu_encode(ctx, col, **opt):
+    from strawboat_amd import write, WriteOptions
+    wo = WriteOptions(default_compression=opt.get("default_compression", 0),
+                      default_compress_ratio=opt.get("ratio"), max_page_size=opt.get("max_page_size"),
+                      forbidden_compressions=list(opt.get("forbidden", ())), force_codec=opt.get("force_codec", -1),
+                      force_index_codec=opt.get("force_index_codec", -1), rng_seed=opt.get("rng_seed", 42))
+    return write.write(ctx, to_device_column(ctx, col), wo)
+
+
+def check(ctx, col, **opt):
+    want_pages, want_metas = gen.oracle_write(col, **opt)
+    enc = gpu_encode(ctx, col, **opt)
+    got_metas = enc.metas_array()
+    assert np.array_equal(got_metas, want_metas), "PageMeta differ:\n%s\n%s" % (got_metas[:4], want_metas[:4])
+    got = enc.pages_numpy()
+    if not np.array_equal(got, want_pages):
+        bad = int(np.argmax(got != want_pages[:got.size])) if got.size == want_pages.size else -1
+        raise AssertionError("page bytes differ (first mismatch at byte %d of %d)" % (bad, want_pages.size))
+
+
+PRIMS = [S.T_I8, S.T_I16, S.T_I32, S.T_I64, S.T_U8, S.T_U16, S.T_U32, S.T_U64, S.T_F32, S.T_F64, S.T_I128, S.T_I256]
+
+
+@pytest.mark.parametrize("ptype", PRIMS)
+@pytest.mark.parametrize("codec", [S.NONE, S.RLE, S.DICT, S.ONEVALUE])
+def test_prim_codecs(gpu_ctx, ptype, codec):
+    uniq = 1 if codec == S.ONEVALUE else 100
+    col = gen.prim(ptype, 10_000, uniq=uniq, null_density=0.2, runs=8)
+    check(gpu_ctx, col, max_page_size=2048, force_codec=codec)
+    col = gen.prim(ptype, 10_000, uniq=uniq, runs=3)
+    check(gpu_ctx, col, max_page_size=4100, force_codec=codec)
+
+
+def test_rle_edge_cases(gpu_ctx):
+    # leading nulls, all-null page, nulls between equal values, -0.0/+0.0 and NaN runs
+    vals = np.array([5, 5, 7, 7, 7, 1, 1, 2] * 700, np.int32)
+    valid = np.ones(vals.size, bool)
+    valid[:3] = False
+    valid[4096:8192] = False          # pages of 2048 rows that are entirely null
+    valid[9000:9005] = False
+    col = dict(ptype=S.T_I32, nullable=True, rows=vals.size, values=vals, validity=gen.pack_bits(valid), offsets=None)
+    check(gpu_ctx, col, max_page_size=2048, force_codec=S.RLE)
+    check(gpu_ctx, col, max_page_size=2048, force_codec=S.DICT)
+    f = np.array([0.0, -0.0, np.nan, np.nan, 1.5, 1.5, -0.0, 0.0] * 600, np.float64)
+    f.view(np.uint64)[3::8] |= 1      # a second NaN payload
+    col = dict(ptype=S.T_F64, nullable=False, rows=f.size, values=f, validity=None, offsets=None)
+    check(gpu_ctx, col, max_page_size=1000, force_codec=S.RLE)
+    check(gpu_ctx, col, max_page_size=1000, force_codec=S.DICT)
+
+
+@pytest.mark.parametrize("ptype", [S.T_I32, S.T_U32])
+@pytest.mark.parametrize("codec", [S.BITPACK, S.DELTABP])
+def test_bitpacking(gpu_ctx, ptype, codec):
+    col = gen.prim(ptype, 128 * 100, uniq=1 << 13, sorted_=(codec == S.DELTABP))
+    check(gpu_ctx, col, max_page_size=128 * 40, force_codec=codec)
+    col = gen.prim(ptype, 128 * 1024, uniq=1 << 30, sorted_=(codec == S.DELTABP), seed=7)
+    check(gpu_ctx, col, max_page_size=65536, force_codec=codec)
+    col = gen.prim(ptype, 128 * 64, uniq=2)   # 0/1 bit widths
+    check(gpu_ctx, col, max_page_size=128 * 64, force_codec=codec)
+
+
+@pytest.mark.parametrize("icodec", [S.NONE, S.RLE, S.BITPACK, S.DELTABP, S.ONEVALUE])
+def test_dict_index_codecs(gpu_ctx, icodec):
+    uniq = 1 if icodec == S.ONEVALUE else 200
+    col = gen.prim(S.T_F64, 128 * 300, uniq=uniq, null_density=0.1, runs=16, sorted_=(icodec == S.DELTABP))
+    check(gpu_ctx, col, max_page_size=128 * 100, force_codec=S.DICT, force_index_codec=icodec)
+
+
+def test_c1_int64_single_page(gpu_ctx):
+    rng = np.random.default_rng(42)
+    vals = rng.integers(0, 1 << 62, 1_000_000).astype(np.int64)
+    col = dict(ptype=S.T_I64, nullable=False, rows=vals.size, values=vals, validity=None, offsets=None)
+    check(gpu_ctx, col)
+
+
+def test_c2_float64_pages(gpu_ctx):
+    col = gen.prim(S.T_F64, 1_000_000, uniq=256, null_density=0.1, runs=32)
+    for codec in (S.RLE, S.DICT, S.NONE):
+        check(gpu_ctx, col, max_page_size=65536, force_codec=codec)
+
+
+@pytest.mark.parametrize("codec", [S.NONE, S.RLE, S.ONEVALUE])
+def test_boolean(gpu_ctx, codec):
+    p = 1.0 if codec == S.ONEVALUE else 0.5
+    col = gen.boolean(100_003, null_density=0.3, p_true=p, runs=5)
+    check(gpu_ctx, col, max_page_size=8192, force_codec=codec)
+    col = gen.boolean(10_000, p_true=p, runs=40)
+    check(gpu_ctx, col, max_page_size=1000, force_codec=codec)  # pages start at non byte-aligned bits
+
+
+@pytest.mark.parametrize("large", [False, True])
+@pytest.mark.parametrize("codec", [S.NONE, S.DICT, S.ONEVALUE])
+def test_binary(gpu_ctx, codec, large):
+    uniq = 1 if codec == S.ONEVALUE else 300
+    col = gen.binary(20_000, uniq=uniq, null_density=0.1, large=large, zipf=1.3)
+    check(gpu_ctx, col, max_page_size=4096, force_codec=codec)
+    col = gen.binary(5_000, uniq=uniq, large=large)
+    check(gpu_ctx, col, max_page_size=5000, force_codec=codec, force_index_codec=S.RLE)
+
+
+def test_roundtrip_gpu_only(gpu_ctx):
+    """encode on the GPU, decode on the GPU, compare with the input (tests/it/io.rs:440-528)."""
+    import torch
+    from strawboat_amd import read, write, WriteOptions
+    col = gen.prim(S.T_I64, 300_000, uniq=1 << 40)
+    dc = to_device_column(gpu_ctx, col)
+    enc = write.write(gpu_ctx, dc, WriteOptions(max_page_size=65536))
+    dec = read.read_simple(gpu_ctx, read.ColumnPages(col["ptype"], False, enc.pages[:enc.length].contiguous(),
+                                                     enc.metas_array()))
+    assert torch.equal(dec.values, dc.values)

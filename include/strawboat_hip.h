@@ -174,6 +174,18 @@ uint64_t sb_write_bound(int32_t physical_type, int32_t is_nullable, uint64_t row
 int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts,
                          int32_t mem);
 
+/* ------------------------------------------------------------------ measurement
+ * Optional per-kernel timing with HIP events recorded on the context's stream around every
+ * kernel launch (used by bench.py for the roofline figure).  Totals are accumulated at
+ * sb_ctx_synchronize(). */
+typedef struct sb_kernel_stat {
+    const char* name;   /* kernel name as it appears in rocprofv3 traces (without namespace) */
+    uint64_t launches;
+    double total_ms;
+} sb_kernel_stat;
+int32_t sb_ctx_profile(sb_ctx* ctx, int32_t enable);  /* enable/disable; resets the totals */
+uint32_t sb_ctx_profile_read(sb_ctx* ctx, sb_kernel_stat* out, uint32_t cap);
+
 /* version / build info string ("strawboat-hip <ver> gfx950") */
 const char* sb_version(void);
 

@@ -15,7 +15,8 @@ SB_MEM_DEVICE, SB_MEM_HOST = 0, 1
 
 # every symbol include/strawboat_hip.h declares
 EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
-           "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns")
+           "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns",
+           "sb_ctx_profile", "sb_ctx_profile_read")
 
 
 class PageMetaC(C.Structure):
@@ -43,6 +44,10 @@ class ColumnWriteC(C.Structure):
                 ("validity", C.c_void_p), ("validity_bit_offset", C.c_uint64), ("offsets", C.c_void_p),
                 ("out_pages", C.c_void_p), ("out_capacity", C.c_uint64), ("out_metas", C.POINTER(PageMetaC)),
                 ("n_pages_capacity", C.c_uint64), ("n_pages", C.c_uint64), ("out_len", C.c_uint64)]
+
+
+class KernelStatC(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
 
 class NativeError(RuntimeError):
@@ -85,5 +90,9 @@ def load():
     L.sb_write_columns.restype = C.c_int32
     L.sb_write_columns.argtypes = [C.c_void_p, C.POINTER(ColumnWriteC), C.c_uint64, C.POINTER(WriteOptionsC),
                                    C.c_int32]
+    L.sb_ctx_profile.restype = C.c_int32
+    L.sb_ctx_profile.argtypes = [C.c_void_p, C.c_int32]
+    L.sb_ctx_profile_read.restype = C.c_uint32
+    L.sb_ctx_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStatC), C.c_uint32]
     _lib = L
     return L

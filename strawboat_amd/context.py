@@ -59,3 +59,13 @@ class Context:
             self._check(rc)
         finally:
             del keep
+
+    def profile(self, enable=True):
+        """Per-kernel HIP-event timing on this context's stream (resets the totals)."""
+        self._check(self._lib.sb_ctx_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{kernel name: (launches, total_ms)} accumulated up to the last synchronize()."""
+        arr = (N.KernelStatC * 16)()
+        n = self._lib.sb_ctx_profile_read(self._h, arr, 16)
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n)}

@@ -8,9 +8,12 @@
 
 namespace sb {
 
-void launch_decode(const DecodeArgs& a, bool any_binary, bool any_prim, bool any_plan, uint64_t* col_values_len,
-                   hipStream_t s);
-void launch_parse_sizes(const DecodeArgs& a, uint64_t* col_values_len, hipStream_t s);
+void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len);
+void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len);
+
+static const char* const KERNEL_NAMES[K_COUNT] = {"k_parse", "k_inflate", "k_plan", "k_colscan", "k_inflate(values)",
+                                                  "k_expand", "k_expand_binary", "k_enc_emit_tiles",
+                                                  "k_enc_emit_pages", "k_enc_layout", "k_enc_compact"};
 
 int32_t check_hip(sb_ctx* ctx, hipError_t e, const char* what) {
     if (e == hipSuccess) return SB_OK;
@@ -139,6 +142,11 @@ void sb_ctx_destroy(sb_ctx* ctx) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     for (void* p : ctx->temp_dev) (void)hipFree(p);
+    for (auto& sp : ctx->spans) {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->tables.p) (void)hipFree(ctx->tables.p);
     if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
     if (ctx->staging.p) (void)hipFree(ctx->staging.p);
@@ -169,6 +177,16 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
     }
     for (auto& s : ctx->slots) s.in_flight = false;
+    for (auto& sp : ctx->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            ctx->prof_ms[sp.id] += ms;
+            ctx->prof_n[sp.id] += 1;
+        }
+        ctx->free_events.push_back(sp.a);
+        ctx->free_events.push_back(sp.b);
+    }
+    ctx->spans.clear();
     for (auto& p : ctx->pending) {
         if (p.kind == Pending::READ_COL) {
             sb_column_read* c = (sb_column_read*)p.user;
@@ -198,6 +216,30 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     ctx->temp_dev.clear();
     ctx->sticky = 0;
     return rc;
+}
+
+int32_t sb_ctx_profile(sb_ctx* ctx, int32_t enable) {
+    if (!ctx) return SB_ERR_INVALID;
+    int32_t rc = sb_ctx_synchronize(ctx);
+    ctx->profile = enable != 0;
+    for (int i = 0; i < K_COUNT; i++) {
+        ctx->prof_ms[i] = 0;
+        ctx->prof_n[i] = 0;
+    }
+    return rc;
+}
+
+uint32_t sb_ctx_profile_read(sb_ctx* ctx, sb_kernel_stat* out, uint32_t cap) {
+    if (!ctx) return 0;
+    uint32_t n = 0;
+    for (int i = 0; i < K_COUNT && n < cap; i++) {
+        if (!ctx->prof_n[i]) continue;
+        out[n].name = KERNEL_NAMES[i];
+        out[n].launches = ctx->prof_n[i];
+        out[n].total_ms = ctx->prof_ms[i];
+        n++;
+    }
+    return n;
 }
 
 // ------------------------------------------------------------------------------------ decode
@@ -313,6 +355,9 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         d.first_page = (uint32_t)page_i;
         d.n_pages = (uint32_t)c.n_pages;
         uint64_t in_off = 0, out_row = 0;
+        d.bits_aligned = 1;
+        for (uint64_t p = 0; p + 1 < c.n_pages; p++)
+            if (c.metas[p].num_values % 32) d.bits_aligned = 0;
         for (uint64_t p = 0; p < c.n_pages; p++, page_i++) {
             PageTask& t = ht[page_i];
             const uint64_t N = c.metas[p].num_values, L = c.metas[p].length;
@@ -355,15 +400,16 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     uint64_t* d_vlen = (uint64_t*)(tb + o_vlen);
 
     if (sizes_only) {
-        if (P) launch_parse_sizes(a, d_vlen, s);
+        if (P) launch_parse_sizes(ctx, a, d_vlen);
     } else {
         // bitmaps are assembled with OR at page seams: start from zero
         for (uint64_t i = 0; i < n; i++) {
             const ColDesc& d = hc[i];
+            if (d.bits_aligned) continue;  // no bitmap word is shared between pages: plain stores only
             if (d.nullable && d.validity && d.rows) (void)hipMemsetAsync(d.validity, 0, (d.rows + 31) / 32 * 4, s);
             if (d.ptype == SB_TYPE_BOOLEAN && d.values && d.rows) (void)hipMemsetAsync(d.values, 0, (d.rows + 31) / 32 * 4, s);
         }
-        if (P) launch_decode(a, any_binary, any_prim, true, d_vlen, s);
+        if (P) launch_decode(ctx, a, any_binary, any_prim, d_vlen);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return check_hip(ctx, e, "decode launch");

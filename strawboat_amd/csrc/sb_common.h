@@ -31,7 +31,7 @@ struct ColDesc {
     uint32_t width;       // bytes per value (primitives), 4/8 for binary offsets, 0 bool
     uint32_t first_page;  // index into the page tables
     uint32_t n_pages;
-    uint32_t pad;
+    uint32_t bits_aligned;  // every page starts at a multiple of 32 rows: bitmap words are never shared
 };
 
 struct PageTask {

@@ -18,7 +18,7 @@
 //   k_expand   1 workgroup / tile   TILE_ROWS rows of one page -> Arrow buffers
 // Bandwidth-bound integer work: no MFMA; coalesced 16-byte stores, unaligned 16-byte loads,
 // LDS for the per-tile scans, wave64 shuffles for the scan carries.
-#include "sb_common.h"
+#include "sb_host.h"
 
 namespace sb {
 
@@ -781,11 +781,11 @@ __device__ __forceinline__ void emit_rows(uint8_t* dst, uint32_t rows, F get) {
 }
 
 // OR `nbits` (<= 32) bits `v` into the LSB-first bitmap at bit position `pos`
-__device__ __forceinline__ void bitmap_put(uint8_t* bm, uint64_t pos, uint32_t v, uint32_t nbits) {
+__device__ __forceinline__ void bitmap_put(uint8_t* bm, uint64_t pos, uint32_t v, uint32_t nbits, bool aligned) {
     if (nbits < 32) v &= (1u << nbits) - 1;
     uint32_t* w = (uint32_t*)bm + (pos >> 5);
     const uint32_t sh = (uint32_t)(pos & 31);
-    if (sh == 0 && nbits == 32) {
+    if (aligned || (sh == 0 && nbits == 32)) {  // word owned by this page alone: plain store
         *w = v;
         return;
     }
@@ -796,7 +796,7 @@ __device__ __forceinline__ void bitmap_put(uint8_t* bm, uint64_t pos, uint32_t v
 // copy rows [r0, r0+rows) of an LSB-first source bitmap (starting at bit 0 of src) to the
 // destination bitmap at bit (dst_bit0 + r0 ...)
 __device__ __forceinline__ void tile_copy_bits(uint8_t* dst_bm, uint64_t dst_bit0, const uint8_t* src, uint64_t r0,
-                                               uint32_t rows, uint64_t src_total_bits) {
+                                               uint32_t rows, uint64_t src_total_bits, bool aligned) {
     const int t = threadIdx.x;
     const uint32_t ngroups = (rows + 31) / 32;
     for (uint32_t g = t; g < ngroups; g += WG) {
@@ -811,7 +811,7 @@ __device__ __forceinline__ void tile_copy_bits(uint8_t* dst_bm, uint64_t dst_bit
             v = 0;
             for (uint32_t b = 0; b < bytes_left; b++) v |= (uint32_t)p[b] << (8 * b);
         }
-        bitmap_put(dst_bm, dst_bit0 + sb, v, nb);
+        bitmap_put(dst_bm, dst_bit0 + sb, v, nb, aligned);
     }
 }
 
@@ -884,12 +884,12 @@ __device__ void expand_bool(const ColDesc& c, const PageTask& t, const PageDesc&
     const uint64_t r0 = (uint64_t)tile * TILE_ROWS;
     const int tid = threadIdx.x;
     if (is_basic(d.codec)) {  // boolean/mod.rs:87-92
-        tile_copy_bits(c.values, t.out_row, d.src, r0, rows, t.num_values);
+        tile_copy_bits(c.values, t.out_row, d.src, r0, rows, t.num_values, c.bits_aligned);
     } else if (d.codec == SB_CODEC_ONEVALUE) {  // boolean/one_value.rs:54-61
         const uint32_t v = d.body[0] > 0 ? 0xFFFFFFFFu : 0u;
         const uint32_t ngroups = (rows + 31) / 32;
         for (uint32_t g = tid; g < ngroups; g += WG)
-            bitmap_put(c.values, t.out_row + r0 + (uint64_t)g * 32, v, min(32u, rows - g * 32));
+            bitmap_put(c.values, t.out_row + r0 + (uint64_t)g * 32, v, min(32u, rows - g * 32), c.bits_aligned);
     } else if (d.codec == SB_CODEC_RLE) {  // boolean/rle.rs:41-55
         const uint32_t* aux = (const uint32_t*)(scratch + t.aux_off);
         rle_tile_runidx(aux, d.n_runs, t.num_values, tile, rows, s_a, s_w);
@@ -904,7 +904,7 @@ __device__ void expand_bool(const ColDesc& c, const PageTask& t, const PageDesc&
             const uint64_t m = __ballot(bit);
             if ((tid & 31) == 0 && i < rows) {
                 const uint32_t half = (tid & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
-                bitmap_put(c.values, t.out_row + r0 + i, half, min(32u, rows - i));
+                bitmap_put(c.values, t.out_row + r0 + i, half, min(32u, rows - i), c.bits_aligned);
             }
         }
     }
@@ -1011,7 +1011,7 @@ __global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
     if (is_binary(c.ptype)) return;  // k_expand_binary
     const uint64_t r0 = (uint64_t)tt.tile * TILE_ROWS;
     const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, t.num_values - r0);
-    if (d.def_bits) tile_copy_bits(c.validity, t.out_row, d.def_bits, r0, rows, t.num_values);
+    if (d.def_bits) tile_copy_bits(c.validity, t.out_row, d.def_bits, r0, rows, t.num_values, c.bits_aligned);
     if (c.ptype == SB_TYPE_BOOLEAN) {
         expand_bool(c, t, d, tt.tile, rows, a.scratch, s_a, s_w);
         return;
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
     if (!is_binary(c.ptype)) return;
     const uint64_t r0 = (uint64_t)tt.tile * TILE_ROWS;
     const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, t.num_values - r0);
-    if (d.def_bits) tile_copy_bits(c.validity, t.out_row, d.def_bits, r0, rows, t.num_values);
+    if (d.def_bits) tile_copy_bits(c.validity, t.out_row, d.def_bits, r0, rows, t.num_values, c.bits_aligned);
     if (c.ptype == SB_TYPE_BINARY)
         expand_binary<int32_t>(c, t, d, tt.tile, rows, a.scratch, s_a, s_len, s_w, a.status, tt.page);
     else
@@ -1059,20 +1059,42 @@ __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
 }
 
 // -------------------------------------------------------------------------------- launcher
-void launch_decode(const DecodeArgs& a, bool any_binary, bool any_prim, bool any_plan, uint64_t* col_values_len,
-                   hipStream_t s) {
-    hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
-    k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-    k_inflate<<<(2 * a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_a, a.job_counts, a.status);
-    if (any_plan) k_plan<<<a.n_pages, WG, 0, s>>>(a);
-    k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
-    if (any_binary) k_inflate<<<(a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
-    if (a.n_tiles && any_prim) k_expand<<<a.n_tiles, WG, 0, s>>>(a);
-    if (a.n_tiles && any_binary) k_expand_binary<<<a.n_tiles, WG, 0, s>>>(a);
+void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
+    hipStream_t s = ctx->stream;
+    (void)hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
+    {
+        KScope k(ctx, K_PARSE);
+        k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
+    }
+    {
+        KScope k(ctx, K_INFLATE_A);
+        k_inflate<<<(2 * a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+    }
+    {
+        KScope k(ctx, K_PLAN);
+        k_plan<<<a.n_pages, WG, 0, s>>>(a);
+    }
+    {
+        KScope k(ctx, K_COLSCAN);
+        k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
+    }
+    if (any_binary) {
+        KScope k(ctx, K_INFLATE_B);
+        k_inflate<<<(a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
+    }
+    if (a.n_tiles && any_prim) {
+        KScope k(ctx, K_EXPAND);
+        k_expand<<<a.n_tiles, WG, 0, s>>>(a);
+    }
+    if (a.n_tiles && any_binary) {
+        KScope k(ctx, K_EXPAND_BIN);
+        k_expand_binary<<<a.n_tiles, WG, 0, s>>>(a);
+    }
 }
 
-void launch_parse_sizes(const DecodeArgs& a, uint64_t* col_values_len, hipStream_t s) {
-    hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
+void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len) {
+    hipStream_t s = ctx->stream;
+    (void)hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     k_inflate<<<(2 * a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_a, a.job_counts, a.status);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);

@@ -21,6 +21,8 @@
 // Pages whose size is known up front (None / OneValue of fixed-width types) are written straight
 // to their final position ("direct"), everything else goes through a worst-case sized slot.
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "sb_host.h"
 
@@ -240,83 +242,244 @@ __device__ __forceinline__ void wg_copy(uint8_t* dst, const uint8_t* src, uint64
 }
 
 // ------------------------------------------------------------------------------ RLE
-// One workgroup walks the page in TILE_ROWS chunks.  Run boundaries are valid rows whose value
-// differs from the previous valid row's value; nulls extend the current run; leading nulls join
-// the first run (integer/rle.rs:75-101).  Records: u32 count | value.
-struct RleCarry {
-    uint64_t run_start;  // row where the open run started
-    uint32_t nrec;       // records written so far
-    uint32_t have;       // a valid row has been seen
+// Run boundaries are valid rows whose value differs from the previous valid row's value; nulls
+// extend the current run; leading nulls join the first run (integer/rle.rs:75-101).  Records:
+// u32 count | value.  A run's value is the value of the row that opened it (the reference keeps
+// `last_value` from the run's first row, so a float run carries the FIRST value's bits,
+// rle.rs:79,87).
+//
+// gfx950 shape: one workgroup walks the page in chunks of 256*R rows; wave w owns R consecutive
+// groups of 64 rows (lane = row).  "Previous valid row", "rank among boundaries" and "previous
+// boundary" are wave64 ballots / v_mbcnt / readlane on 64-bit lane masks held in SGPRs, the
+// carries between a wave's groups stay scalar, and the only cross-wave state is one small LDS
+// record per wave (two LDS-only barriers per chunk, double-buffered).  Values are loaded once
+// (coalesced) and stay in registers.
+template <int W>
+struct RleShape {
+    static constexpr int R = W <= 8 ? 8 : (W == 16 ? 4 : 2);  // 64-row groups per wave per chunk
 };
+template <int W>
+__device__ __forceinline__ Val<W> shfl_val(const Val<W>& v, int src) {
+    Val<W> r;
+    if constexpr (W <= 4) {
+        r.x = (decltype(r.x))__shfl((uint32_t)v.x, src, 64);
+    } else {
+        uint32_t a[W / 4], b[W / 4];
+        __builtin_memcpy(a, &v, W);
+#pragma unroll
+        for (int k = 0; k < W / 4; k++) b[k] = __shfl(a[k], src, 64);
+        __builtin_memcpy(&r, b, W);
+    }
+    return r;
+}
+// value held by lane `src` (wave-uniform index) as a wave-uniform value (v_readlane -> SGPRs)
+template <int W>
+__device__ __forceinline__ Val<W> readlane_val(const Val<W>& v, int src) {
+    Val<W> r;
+    if constexpr (W <= 4) {
+        r.x = (decltype(r.x))__builtin_amdgcn_readlane((int)(uint32_t)v.x, src);
+    } else {
+        int a[W / 4], b[W / 4];
+        __builtin_memcpy(a, &v, W);
+#pragma unroll
+        for (int k = 0; k < W / 4; k++) b[k] = __builtin_amdgcn_readlane(a[k], src);
+        __builtin_memcpy(&r, b, W);
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int top_bit(uint64_t m) { return 63 - __clzll((long long)m); }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // set bits of m below my lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
 
-template <int W, class GetVal>
-__device__ uint64_t enc_rle(GetVal getv, const ValidView& vv, uint64_t N, uint32_t fkind, uint8_t* dst, uint32_t* sA,
-                            uint32_t* sB, uint32_t* sC, uint32_t* s_w) {
-    const int t = threadIdx.x;
+// equality used for run detection: FK 0 = bit pattern, 1 = OrderedFloat<f32>, 2 = OrderedFloat<f64>
+template <int W, int FK>
+__device__ __forceinline__ bool rle_eq(const Val<W>& a, const Val<W>& b) {
+    if constexpr (FK == 1 && W == 4) {
+        if (a.x == b.x) return true;
+        const uint32_t ax = a.x & 0x7FFFFFFFu, bx = b.x & 0x7FFFFFFFu;
+        return ((ax | bx) == 0) || (ax > 0x7F800000u && bx > 0x7F800000u);  // +-0, NaN == NaN
+    } else if constexpr (FK == 2 && W == 8) {
+        if (a.x == b.x) return true;
+        const uint64_t ax = a.x & 0x7FFFFFFFFFFFFFFFull, bx = b.x & 0x7FFFFFFFFFFFFFFFull;
+        return ((ax | bx) == 0) || (ax > 0x7FF0000000000000ull && bx > 0x7FF0000000000000ull);
+    } else {
+        return val_eq<W>(a, b, 0);
+    }
+}
+
+// validity mask of the 64-row group g of the chunk starting at page row cb (n rows in the chunk)
+__device__ __forceinline__ uint64_t group_mask(const ValidView& vv, uint64_t vtotal, uint64_t cb, uint32_t g,
+                                               uint32_t n) {
+    if (64 * g >= n) return 0;
+    uint64_t m = ~0ull;
+    if (vv.bits) {
+        const uint64_t p = vv.off + cb + 64 * g, byte = p >> 3, nbytes = (vtotal + 7) >> 3;
+        const uint32_t sh = (uint32_t)(p & 7);
+        if (byte + 9 <= nbytes) {
+            const uint64_t lo = ldu64(vv.bits + byte);
+            m = sh ? (lo >> sh) | ((uint64_t)vv.bits[byte + 8] << (64 - sh)) : lo;
+        } else {
+            m = (uint64_t)bits32(vv.bits, p, vtotal) | ((uint64_t)bits32(vv.bits, p + 32, vtotal) << 32);
+        }
+    }
+    if (n - 64 * g < 64) m &= (1ull << (n - 64 * g)) - 1;
+    return m;
+}
+
+// LDS use: sA >= 64 words, sB >= 8 * W bytes
+template <int W, int FK, class GetVal>
+__device__ uint64_t enc_rle(GetVal getv, const ValidView& vv, uint64_t N, uint8_t* dst, uint32_t* sA, uint32_t* sB) {
     constexpr int REC = 4 + W;
-    __shared__ uint32_t s_fv;  // first valid row of the chunk (only needed until a valid row was seen)
-    RleCarry c{0, 0, 0};
-    // value of the open run = value of the row that opened it (the reference keeps `last_value`
-    // from the run's first row: for floats the run carries the FIRST value's bits, rle.rs:79,87)
-    Val<W> run_val = val_zero<W>();
-    for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
-        const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, N - cb);
-        if (t == 0) s_fv = EMPTY;
-        __syncthreads();
-        for (uint32_t i = t; i < TILE_ROWS; i += WG) {
-            const bool v = i < n && vv.get(cb + i);
-            sA[sidx((int)i)] = v ? i + 1 : 0;
-            if (v && !c.have) atomicMin(&s_fv, i);
+    constexpr int R = RleShape<W>::R;
+    constexpr uint32_t WROWS = 64 * R;       // rows per wave per chunk
+    constexpr uint32_t CHUNK = 4 * WROWS;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t lt = (1ull << lane) - 1;
+    uint64_t run_start = 0;  // row where the open run started
+    uint32_t nrec = 0;       // records closed so far (the open run is record `nrec`)
+    bool have = false;       // a valid row has been seen
+    Val<W> last = val_zero<W>();  // value of the last valid row seen so far
+    const uint64_t vtotal = vv.off + N;
+    auto lds_barrier = []() {  // LDS-only hand-off between the four waves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    uint32_t par = 0;
+    for (uint64_t cb = 0; cb < N; cb += CHUNK, par ^= 1) {
+        uint32_t* s_has = sA + par * 16;          // [4] wave has a valid row
+        uint32_t* s_cnt = sA + par * 16 + 4;      // [4] boundaries found by the wave
+        uint32_t* s_blast = sA + par * 16 + 8;    // [4] (last boundary row in chunk)+1, 0 = none
+        Val<W>* s_last = (Val<W>*)sB + par * 4;   // [4] value of the wave's last valid row
+        const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
+        const uint32_t wrow = (uint32_t)w * WROWS;
+        // ---- loads: values (coalesced, clamped in range) and the validity masks of my groups
+        Val<W> v[R];
+        uint64_t vm[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const uint32_t row = wrow + 64 * j + lane;
+            v[j] = getv(cb + (row < n ? row : n - 1));
         }
-        __syncthreads();
-        if (!c.have && s_fv != EMPTY) {
-            c.have = 1;
-            run_val = getv(cb + s_fv);
+        {
+            const uint64_t mine = lane < R ? group_mask(vv, vtotal, cb, (uint32_t)w * R + lane, n) : 0;
+#pragma unroll
+            for (int j = 0; j < R; j++) vm[j] = readlane_u64(mine, j);
         }
-        tile_incl_scan_max(sA, s_w);
-        for (uint32_t i = t; i < TILE_ROWS; i += WG) {
-            uint32_t b = 0;
-            if (i < n && vv.get(cb + i)) {
-                const uint32_t pv = i ? sA[sidx((int)i - 1)] : 0;
-                if (pv) {
-                    b = !val_eq<W>(getv(cb + pv - 1), getv(cb + i), fkind);
-                } else if (c.have) {  // first valid row of the chunk: compare with the open run
-                    b = !val_eq<W>(run_val, getv(cb + i), fkind);
+        // ---- phase 1: wave summary (has a valid row, value of the last one)
+        bool has_w = false;
+        Val<W> last_w = val_zero<W>();
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (vm[j]) {
+                has_w = true;
+                last_w = readlane_val<W>(v[j], top_bit(vm[j]));
+            }
+        if (lane == 0) {
+            s_has[w] = has_w;
+            s_last[w] = last_w;
+        }
+        lds_barrier();
+        // carry-in of this wave: nearest earlier wave with a valid row, else the chunk carry
+        bool chas = have;
+        Val<W> cval = last;
+        bool earlier_has = false;
+        for (int pw = 0; pw < 3; pw++)
+            if (pw < w && s_has[pw]) {
+                chas = true;
+                earlier_has = true;
+                cval = s_last[pw];
+            }
+        // the first run takes the first valid row's value
+        if (!have && !earlier_has && has_w) {
+            Val<W> fv = val_zero<W>();
+            bool got = false;
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                if (!got && vm[j]) {
+                    got = true;
+                    fv = readlane_val<W>(v[j], (int)__ffsll((long long)vm[j]) - 1);
                 }
+            if (lane == 0) __builtin_memcpy(dst + 4, &fv, W);
+        }
+        // ---- phase 2: boundaries
+        uint64_t bm[R];
+        uint32_t cnt_w = 0, blast_w = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm[j]);
+            const uint64_t pm = vm[j] & lt;
+            const Val<W> pv = shfl_val<W>(v[j], pm ? top_bit(pm) : 0);
+            const bool ne_prev = !rle_eq<W, FK>(pv, v[j]);
+            const bool ne_carry = chas && !rle_eq<W, FK>(cval, v[j]);
+            const bool b = valid && (pm ? ne_prev : ne_carry);
+            bm[j] = __ballot(b);
+            if (vm[j]) {
+                chas = true;
+                cval = readlane_val<W>(v[j], top_bit(vm[j]));
             }
-            sB[sidx((int)i)] = b;
-            sC[sidx((int)i)] = b ? i + 1 : 0;
-        }
-        __syncthreads();
-        tile_incl_scan(sB, s_w);
-        tile_incl_scan_max(sC, s_w);
-        for (uint32_t i = t; i < n; i += WG) {
-            const uint32_t rk = sB[sidx((int)i)];
-            const uint32_t rkp = i ? sB[sidx((int)i - 1)] : 0;
-            if (rk != rkp) {  // boundary at row cb+i: close the run that ends here
-                const uint32_t pb = i ? sC[sidx((int)i - 1)] : 0;
-                const uint64_t start = pb ? cb + pb - 1 : c.run_start;
-                const Val<W> rv = pb ? getv(cb + pb - 1) : run_val;
-                uint8_t* r = dst + (uint64_t)(c.nrec + rk - 1) * REC;
-                stu32(r, (uint32_t)(cb + i - start));
-                __builtin_memcpy(r + 4, &rv, W);
+            if (bm[j]) {
+                cnt_w += (uint32_t)__popcll(bm[j]);
+                blast_w = wrow + 64 * j + (uint32_t)top_bit(bm[j]) + 1;
             }
         }
-        const uint32_t tot = sB[sidx((int)n - 1)], lastb = sC[sidx((int)n - 1)];
-        if (lastb) {
-            c.run_start = cb + lastb - 1;
-            run_val = getv(cb + lastb - 1);
+        if (lane == 0) {
+            s_cnt[w] = cnt_w;
+            s_blast[w] = blast_w;
         }
-        c.nrec += tot;
-        __syncthreads();
+        lds_barrier();
+        // ---- phase 3: ranks and records
+        uint32_t base = nrec;
+        uint64_t start_prev = run_start;
+        for (int pw = 0; pw < 3; pw++)
+            if (pw < w) {
+                base += s_cnt[pw];
+                if (s_blast[pw]) start_prev = cb + s_blast[pw] - 1;
+            }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (bm[j] == 0) continue;
+            const bool b = __builtin_amdgcn_inverse_ballot_w64(bm[j]);
+            const uint64_t grow = cb + wrow + 64 * j;
+            const uint64_t pbm = bm[j] & lt;
+            const uint64_t start = pbm ? grow + top_bit(pbm) : start_prev;
+            if (b) {
+                const uint32_t rk = base + mbcnt64(bm[j]);  // boundaries before this one
+                uint8_t* closed = dst + (uint64_t)rk * REC;
+                stu32(closed, (uint32_t)(grow + lane - start));  // count of the run that ends here
+                __builtin_memcpy(closed + REC + 4, &v[j], W);    // value of the run that starts here
+            }
+            base += (uint32_t)__popcll(bm[j]);
+            start_prev = grow + top_bit(bm[j]);
+        }
+        // ---- chunk carries (wave-uniform, identical in every wave)
+        for (int pw = 0; pw < 4; pw++) {
+            if (s_has[pw]) {
+                have = true;
+                last = s_last[pw];
+            }
+            nrec += s_cnt[pw];
+            if (s_blast[pw]) run_start = cb + s_blast[pw] - 1;
+        }
     }
     if (N == 0) return 0;
-    if (t == 0) {  // final run; an all-null page is one run of T::default() (rle.rs:98-101)
-        uint8_t* r = dst + (uint64_t)c.nrec * REC;
-        stu32(r, (uint32_t)(N - c.run_start));
-        __builtin_memcpy(r + 4, &run_val, W);
+    if (threadIdx.x == 0) {  // close the final run; an all-null page is one run of T::default() (rle.rs:98-101)
+        uint8_t* r = dst + (uint64_t)nrec * REC;
+        stu32(r, (uint32_t)(N - run_start));
+        if (!have) {
+            const Val<W> z = val_zero<W>();
+            __builtin_memcpy(r + 4, &z, W);
+        }
     }
-    return (uint64_t)(c.nrec + 1) * REC;
+    __syncthreads();
+    return (uint64_t)(nrec + 1) * REC;
 }
 
 // ------------------------------------------------------------------------------ bit-packing
@@ -410,7 +573,7 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
             body = N * 4;
             break;
         case SB_CODEC_RLE:
-            body = enc_rle<4>(getv, none, N, 0, dst + 9, sA, sB, sC, s_w);
+            body = enc_rle<4, 0>(getv, none, N, dst + 9, sA, sB);
             break;
         case SB_CODEC_ONEVALUE:
             if (threadIdx.x == 0) stu32(dst + 9, N ? idx[0] : 0);
@@ -648,90 +811,86 @@ __device__ __forceinline__ uint8_t* page_slot(const EncodeArgs& a, const EncCol&
     return a.scratch + off;
 }
 
-template <int W>
-__device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, int32_t codec,
-                                   uint8_t* blk, const ValidView& vv, uint32_t* sA, uint32_t* sB, uint32_t* sC,
-                                   uint32_t* s_w) {
+template <int W, int CODEC>
+__device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, uint8_t* blk,
+                                   const ValidView& vv, uint32_t* sA, uint32_t* sB, uint32_t* sC, uint32_t* s_w) {
     const uint64_t N = p.rows;
     const uint8_t* vals = c.values + p.row0 * W;
     auto getv = [=](uint64_t i) { return ld_val<W>(vals + i * W); };
     uint64_t body = 0;
-    switch (codec) {
-        case SB_CODEC_RLE:
-            body = enc_rle<W>(getv, vv, N, c.fkind, blk + 9, sA, sB, sC, s_w);
-            break;
-        case SB_CODEC_ONEVALUE: {  // first valid value or T::default() (one_value.rs:63-75)
-            __shared__ unsigned long long s_first;
-            if (threadIdx.x == 0) s_first = ~0ull;
-            __syncthreads();
-            unsigned long long mine = ~0ull;
-            for (uint64_t i = threadIdx.x; i < N && mine == ~0ull; i += WG)
-                if (vv.get(i)) mine = i;
-            if (mine != ~0ull) atomicMin(&s_first, mine);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                Val<W> v = s_first == ~0ull ? val_zero<W>() : getv(s_first);
-                __builtin_memcpy(blk + 9, &v, W);
-            }
-            body = W;
-            break;
+    if constexpr (CODEC == SB_CODEC_RLE) {
+        if (c.fkind == 1 && W == 4)
+            body = enc_rle<W, (W == 4 ? 1 : 0)>(getv, vv, N, blk + 9, sA, sB);
+        else if (c.fkind == 2 && W == 8)
+            body = enc_rle<W, (W == 8 ? 2 : 0)>(getv, vv, N, blk + 9, sA, sB);
+        else
+            body = enc_rle<W, 0>(getv, vv, N, blk + 9, sA, sB);
+    } else if constexpr (CODEC == SB_CODEC_ONEVALUE) {  // first valid value or T::default() (one_value.rs:63-75)
+        __shared__ unsigned long long s_first;
+        if (threadIdx.x == 0) s_first = ~0ull;
+        __syncthreads();
+        unsigned long long mine = ~0ull;
+        for (uint64_t i = threadIdx.x; i < N && mine == ~0ull; i += WG)
+            if (vv.get(i)) mine = i;
+        if (mine != ~0ull) atomicMin(&s_first, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Val<W> v = s_first == ~0ull ? val_zero<W>() : getv(s_first);
+            __builtin_memcpy(blk + 9, &v, W);
         }
-        case SB_CODEC_BITPACKING:
-        case SB_CODEC_DELTA_BITPACKING:
-            if constexpr (W == 4) {
-                if (N % 128 != 0 || c.ptype == SB_TYPE_FLOAT32) {
-                    if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 520);
-                    return 0;
-                }
-                auto getu = [=](uint64_t i) { return ldu32(vals + i * 4); };
-                body = enc_bp(getu, N, codec == SB_CODEC_DELTA_BITPACKING, blk + 9, sA, sB, s_w);
-            } else {
-                if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 521);
+        body = W;
+    } else if constexpr (CODEC == SB_CODEC_BITPACKING || CODEC == SB_CODEC_DELTA_BITPACKING) {
+        if constexpr (W == 4) {
+            if (N % 128 != 0 || c.ptype == SB_TYPE_FLOAT32) {
+                if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 520);
                 return 0;
             }
-            break;
-        case SB_CODEC_DICT: {
-            PrimKeys<W> ko{vals, vv, c.fkind};
-            uint32_t *idx, *firsts;
-            uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
-            const uint32_t D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
-            if (D == EMPTY) return 0;
-            int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
-            const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
-            if (ib == 0) return 0;
-            uint8_t* q = blk + 9 + ib;
-            if (threadIdx.x == 0) stu32(q, D);
-            for (uint32_t k = threadIdx.x; k < D; k += WG) {
-                Val<W> v = ko.key(firsts[k]);
-                __builtin_memcpy(q + 4 + (uint64_t)k * W, &v, W);
-            }
-            body = ib + 4 + (uint64_t)D * W;
-            break;
-        }
-        default:
-            if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 522);  // LZ4/Zstd/Freq/Patas encode: host path
+            auto getu = [=](uint64_t i) { return ldu32(vals + i * 4); };
+            body = enc_bp(getu, N, CODEC == SB_CODEC_DELTA_BITPACKING, blk + 9, sA, sB, s_w);
+        } else {
+            if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 521);
             return 0;
+        }
+    } else if constexpr (CODEC == SB_CODEC_DICT) {
+        PrimKeys<W> ko{vals, vv, c.fkind};
+        uint32_t *idx, *firsts;
+        uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
+        const uint32_t D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
+        if (D == EMPTY) return 0;
+        int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
+        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
+        if (ib == 0) return 0;
+        uint8_t* q = blk + 9 + ib;
+        if (threadIdx.x == 0) stu32(q, D);
+        for (uint32_t k = threadIdx.x; k < D; k += WG) {
+            Val<W> v = ko.key(firsts[k]);
+            __builtin_memcpy(q + 4 + (uint64_t)k * W, &v, W);
+        }
+        body = ib + 4 + (uint64_t)D * W;
+    } else {
+        if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 522);  // LZ4/Zstd/Freq/Patas encode: host path
+        return 0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)codec, (uint32_t)body, (uint32_t)(N * W));
+    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)CODEC, (uint32_t)body, (uint32_t)(N * W));
     return 9 + body;
 }
 
-__device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, int32_t codec,
-                                   uint8_t* blk, const ValidView& vv, uint32_t* sA, uint32_t* sB, uint32_t* sC,
-                                   uint32_t* s_w) {
+template <int CODEC>
+__device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, uint8_t* blk,
+                                   const ValidView& vv, uint32_t* sA, uint32_t* sB, uint32_t* sC, uint32_t* s_w) {
     const uint64_t N = p.rows;
     const uint8_t* bits = c.values;
     const uint64_t boff = c.values_bit_offset + p.row0;
     uint64_t body = 0;
-    if (codec == SB_CODEC_RLE) {  // values as u8 0/1 (boolean/rle.rs:31-39)
+    if constexpr (CODEC == SB_CODEC_RLE) {  // values as u8 0/1 (boolean/rle.rs:31-39)
         auto getv = [=](uint64_t i) {
             Val<1> v;
             v.x = bit_at(bits, boff + i) ? 1 : 0;
             return v;
         };
-        body = enc_rle<1>(getv, vv, N, 0, blk + 9, sA, sB, sC, s_w);
-    } else if (codec == SB_CODEC_ONEVALUE) {  // boolean/one_value.rs:44-52
+        body = enc_rle<1, 0>(getv, vv, N, blk + 9, sA, sB);
+    } else if constexpr (CODEC == SB_CODEC_ONEVALUE) {  // boolean/one_value.rs:44-52
         __shared__ unsigned long long s_firstb;
         if (threadIdx.x == 0) s_firstb = ~0ull;
         __syncthreads();
@@ -747,14 +906,14 @@ __device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const E
         return 0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)codec, (uint32_t)body, (uint32_t)N);  // rows, not bytes (mod.rs:59)
+    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)CODEC, (uint32_t)body, (uint32_t)N);  // rows, not bytes (mod.rs:59)
     return 9 + body;
 }
 
-template <class O>
+template <class O, int CODEC>
 __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page,
-                                     int32_t codec, uint8_t* blk, const ValidView& vv, uint32_t* sA, uint32_t* sB,
-                                     uint32_t* sC, uint32_t* s_w) {
+                                     uint8_t* blk, const ValidView& vv, uint32_t* sA, uint32_t* sB, uint32_t* sC,
+                                     uint32_t* s_w) {
     const uint64_t N = p.rows;
     const uint8_t* offs = c.offsets + p.row0 * sizeof(O);
     auto off_at = [=](uint64_t i) {
@@ -763,7 +922,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         return (uint64_t)o;
     };
     uint64_t body = 0;
-    if (codec == SB_CODEC_ONEVALUE) {  // u32 len | bytes of the first valid row (binary/one_value.rs:50-68)
+    if constexpr (CODEC == SB_CODEC_ONEVALUE) {  // u32 len | bytes of the first valid row (binary/one_value.rs:50-68)
         __shared__ unsigned long long s_firstv;
         if (threadIdx.x == 0) s_firstv = ~0ull;
         __syncthreads();
@@ -780,7 +939,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         if (threadIdx.x == 0) stu32(blk + 9, (uint32_t)(e - b));
         wg_copy(blk + 13, c.values + b, e - b);
         body = 4 + (e - b);
-    } else if (codec == SB_CODEC_DICT) {  // binary/dict.rs:55-93
+    } else if constexpr (CODEC == SB_CODEC_DICT) {  // binary/dict.rs:55-93
         BinKeys<O> ko{offs, c.values, vv};
         uint32_t *idx, *firsts;
         uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
@@ -823,19 +982,37 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
     }
     __syncthreads();
     // uncompressed_size = array.values().len(): the whole shared buffer (binary/mod.rs:88)
-    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)codec, (uint32_t)body, (uint32_t)c.values_len);
+    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)CODEC, (uint32_t)body, (uint32_t)c.values_len);
     return 9 + body;
 }
 
-// pages with an extended codec: one workgroup per page
-__global__ void __launch_bounds__(WG) k_enc_emit_pages(EncodeArgs a) {
-    __shared__ uint32_t sA[SIDX_WORDS], sB[SIDX_WORDS], sC[SIDX_WORDS];
+// Pages with an extended codec: one workgroup per page.  One kernel instance per (KIND, CODEC):
+// KIND = value width 1..32 for primitives, 0 = boolean, -4 / -8 = binary with i32 / i64 offsets.
+// A monolithic kernel over all kinds needs 300 VGPRs (1 wave/SIMD); the split instances stay
+// within 4 waves/SIMD.  Pages of another kind/codec exit at once.
+template <int KIND, int CODEC>
+__global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_ONEVALUE) ? 4 : 3)
+    k_enc_emit_pages(EncodeArgs a) {
+    // RLE / OneValue only need the small per-group records; Dict and bit-packing use full tile arrays
+    constexpr int LW = (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_ONEVALUE) ? 256 : SIDX_WORDS;
+    __shared__ uint32_t sA[LW], sB[LW], sC[LW];
     __shared__ uint32_t s_w[4];
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
+    if (p.codec != CODEC) return;
     const EncCol c = a.cols[p.col];
-    const int32_t codec = p.codec;
-    if (codec == SB_CODEC_NONE || c.ptype == SB_TYPE_NULL) return;  // k_enc_emit_tiles
+    if (c.ptype == SB_TYPE_NULL) return;
+    const bool is_bool = c.ptype == SB_TYPE_BOOLEAN;
+    const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
+    if constexpr (KIND == 0) {
+        if (!is_bool) return;
+    } else if constexpr (KIND == -4) {
+        if (c.ptype != SB_TYPE_BINARY) return;
+    } else if constexpr (KIND == -8) {
+        if (c.ptype != SB_TYPE_LARGE_BINARY) return;
+    } else {
+        if (is_bool || is_bin || c.width != (uint32_t)KIND) return;
+    }
     uint8_t* slot = page_slot(a, c, p);
     const uint64_t N = p.rows;
     uint64_t pos = 0;
@@ -849,47 +1026,65 @@ __global__ void __launch_bounds__(WG) k_enc_emit_pages(EncodeArgs a) {
     }
     uint64_t blen = 0;
     uint8_t* blk = slot + pos;
-    switch (c.ptype) {
-        case SB_TYPE_BOOLEAN:
-            blen = emit_bool_page(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-            break;
-        case SB_TYPE_BINARY:
-            blen = emit_binary_page<int32_t>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-            break;
-        case SB_TYPE_LARGE_BINARY:
-            blen = emit_binary_page<int64_t>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-            break;
-        default:
-            switch (c.width) {
-                case 1:
-                    blen = emit_prim_page<1>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-                    break;
-                case 2:
-                    blen = emit_prim_page<2>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-                    break;
-                case 4:
-                    blen = emit_prim_page<4>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-                    break;
-                case 8:
-                    blen = emit_prim_page<8>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-                    break;
-                case 16:
-                    blen = emit_prim_page<16>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-                    break;
-                case 32:
-                    blen = emit_prim_page<32>(a, c, p, page, codec, blk, vv, sA, sB, sC, s_w);
-                    break;
-            }
-    }
+    if constexpr (KIND == 0)
+        blen = emit_bool_page<CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+    else if constexpr (KIND == -4)
+        blen = emit_binary_page<int32_t, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+    else if constexpr (KIND == -8)
+        blen = emit_binary_page<int64_t, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+    else
+        blen = emit_prim_page<KIND, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
     if (threadIdx.x == 0) {
         EncOut o;
         o.length = blen ? pos + blen : 0;
         o.out_off = 0;
         o.slot = slot;
-        o.codec = (uint32_t)codec;
+        o.codec = (uint32_t)CODEC;
         o.pad = 0;
         a.outs[page] = o;
     }
+}
+
+typedef void (*EncPageKernel)(EncodeArgs);
+template <int KIND>
+static EncPageKernel enc_page_kernel_for_codec(int32_t codec) {
+    switch (codec) {
+        case SB_CODEC_RLE:
+            return k_enc_emit_pages<KIND, SB_CODEC_RLE>;
+        case SB_CODEC_DICT:
+            return k_enc_emit_pages<KIND, SB_CODEC_DICT>;
+        case SB_CODEC_ONEVALUE:
+            return k_enc_emit_pages<KIND, SB_CODEC_ONEVALUE>;
+        case SB_CODEC_BITPACKING:
+            return k_enc_emit_pages<KIND, SB_CODEC_BITPACKING>;
+        case SB_CODEC_DELTA_BITPACKING:
+            return k_enc_emit_pages<KIND, SB_CODEC_DELTA_BITPACKING>;
+    }
+    return nullptr;
+}
+// kind: 1,2,4,8,16,32 / 0 / -4 / -8 (see k_enc_emit_pages)
+static EncPageKernel enc_page_kernel(int kind, int32_t codec) {
+    switch (kind) {
+        case 0:
+            return enc_page_kernel_for_codec<0>(codec);
+        case 1:
+            return enc_page_kernel_for_codec<1>(codec);
+        case 2:
+            return enc_page_kernel_for_codec<2>(codec);
+        case 4:
+            return enc_page_kernel_for_codec<4>(codec);
+        case 8:
+            return enc_page_kernel_for_codec<8>(codec);
+        case 16:
+            return enc_page_kernel_for_codec<16>(codec);
+        case 32:
+            return enc_page_kernel_for_codec<32>(codec);
+        case -4:
+            return enc_page_kernel_for_codec<-4>(codec);
+        case -8:
+            return enc_page_kernel_for_codec<-8>(codec);
+    }
+    return nullptr;
 }
 
 // pages with codec None: (page, tile) parallel plain copies
@@ -1237,10 +1432,37 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.default_compression = (uint32_t)opts->default_compression;
 
     (void)hipMemsetAsync(a.outs, 0, P * sizeof(EncOut), s);
-    if (any_tiles) k_enc_emit_tiles<<<dim3((uint32_t)P, (uint32_t)max_tiles), WG, 0, s>>>(a);
-    if (any_pages) k_enc_emit_pages<<<(uint32_t)P, WG, 0, s>>>(a);
-    k_enc_layout<<<(uint32_t)((n + 63) / 64), 64, 0, s>>>(a, (const uint64_t*)(tb + o_resoff));
-    if (any_compact) k_enc_compact<<<dim3((uint32_t)P, (uint32_t)max_chunks), WG, 0, s>>>(a);
+    if (any_tiles) {
+        KScope k(ctx, K_ENC_TILES);
+        k_enc_emit_tiles<<<dim3((uint32_t)P, (uint32_t)max_tiles), WG, 0, s>>>(a);
+    }
+    if (any_pages) {
+        // one kernel instance per (kind, codec) present in the batch
+        std::vector<std::pair<int, int32_t>> done;
+        for (uint64_t i = 0; i < n; i++) {
+            const EncCol& d = hc[i];
+            if (d.ptype == SB_TYPE_NULL || host_codec == SB_CODEC_NONE) continue;
+            const int kind = d.ptype == SB_TYPE_BOOLEAN ? 0 : d.ptype == SB_TYPE_BINARY ? -4
+                             : d.ptype == SB_TYPE_LARGE_BINARY ? -8 : (int)d.width;
+            std::pair<int, int32_t> key(kind, host_codec);
+            bool seen = false;
+            for (auto& q : done) seen |= q == key;
+            if (seen) continue;
+            done.push_back(key);
+            EncPageKernel kf = enc_page_kernel(kind, host_codec);
+            if (!kf) return ctx->fail(SB_ERR_NYI, "no device encoder for this codec (LZ4/Zstd/Snappy/Freq/Patas pages are not built yet)");
+            KScope k(ctx, K_ENC_PAGES);
+            kf<<<(uint32_t)P, WG, 0, s>>>(a);
+        }
+    }
+    {
+        KScope k(ctx, K_ENC_LAYOUT);
+        k_enc_layout<<<(uint32_t)((n + 63) / 64), 64, 0, s>>>(a, (const uint64_t*)(tb + o_resoff));
+    }
+    if (any_compact) {
+        KScope k(ctx, K_ENC_COMPACT);
+        k_enc_compact<<<dim3((uint32_t)P, (uint32_t)max_chunks), WG, 0, s>>>(a);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return check_hip(ctx, e, "encode launch");
 

@@ -27,6 +27,15 @@ struct Pending {  // results to hand back to the caller's structs at synchronize
     uint64_t n;            // WRITE_COL: number of pages
 };
 
+enum KernelId {
+    K_PARSE, K_INFLATE_A, K_PLAN, K_COLSCAN, K_INFLATE_B, K_EXPAND, K_EXPAND_BIN,
+    K_ENC_TILES, K_ENC_PAGES, K_ENC_LAYOUT, K_ENC_COMPACT, K_COUNT
+};
+struct ProfSpan {
+    int id;
+    hipEvent_t a, b;
+};
+
 }  // namespace sb
 
 struct sb_ctx {
@@ -56,6 +65,13 @@ struct sb_ctx {
     std::vector<Copyback> copybacks;
     std::vector<void*> temp_dev;  // device temporaries to free at synchronize
 
+    // optional per-kernel HIP-event timing (sb_ctx_profile)
+    bool profile = false;
+    std::vector<sb::ProfSpan> spans;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[sb::K_COUNT] = {0};
+    uint64_t prof_n[sb::K_COUNT] = {0};
+
     int32_t fail(int32_t code, const std::string& msg) {
         last_error = msg;
         if (!sticky) sticky = code;
@@ -64,6 +80,33 @@ struct sb_ctx {
 };
 
 namespace sb {
+// brackets one kernel launch with events when profiling is on
+struct KScope {
+    sb_ctx* ctx;
+    ProfSpan sp;
+    KScope(sb_ctx* c, int id) : ctx(c) {
+        if (!ctx->profile) return;
+        sp.id = id;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!ctx->free_events.empty()) {
+                e = ctx->free_events.back();
+                ctx->free_events.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        sp.a = get();
+        sp.b = get();
+        (void)hipEventRecord(sp.a, ctx->stream);
+    }
+    ~KScope() {
+        if (!ctx->profile) return;
+        (void)hipEventRecord(sp.b, ctx->stream);
+        ctx->spans.push_back(sp);
+    }
+};
 bool ensure(sb_ctx* ctx, DevBuf& b, size_t need);
 StageSlot* acquire_slot(sb_ctx* ctx, size_t need);
 int32_t check_hip(sb_ctx* ctx, hipError_t e, const char* what);

@@ -108,55 +108,69 @@ def batch_read_sizes(ctx, columns: List[ColumnPages]):
     return [(int(arr[i].rows), int(arr[i].values_len)) for i in range(len(columns))]
 
 
+class ReadBatch:
+    """A prepared decode of a batch of leaf columns: the C descriptors and the output buffers
+    are built once; enqueue() then costs one C call (steady-state readers, bench.py)."""
+
+    def __init__(self, ctx, columns: List[ColumnPages], values_capacity: Optional[Sequence[int]] = None,
+                 out: Optional[List[DeviceArray]] = None):
+        import torch
+        self.ctx = ctx
+        arr, keep = _prepare(ctx, columns)
+        n = len(columns)
+        need_sizes = [i for i, col in enumerate(columns)
+                      if PhysicalType.is_binary(col.physical_type) and values_capacity is None and out is None]
+        caps = list(values_capacity) if values_capacity is not None else [None] * n
+        if need_sizes:
+            sizes = batch_read_sizes(ctx, [columns[i] for i in need_sizes])
+            for i, (_, vlen) in zip(need_sizes, sizes):
+                caps[i] = vlen
+        res = []
+        dev = ctx.torch_device
+        with torch.cuda.stream(ctx.torch_stream):
+            for i, col in enumerate(columns):
+                c = arr[i]
+                rows = int(col.metas_array()[:, 1].sum()) if c.n_pages else 0
+                t = col.physical_type
+                if out is not None:
+                    o = out[i]
+                    values, validity, offsets = o.values, o.validity, o.offsets
+                else:
+                    validity = offsets = None
+                    if t == PhysicalType.NULL:
+                        values = None
+                    elif t == PhysicalType.BOOLEAN:
+                        values = torch.empty(((rows + 31) // 32) * 4, dtype=torch.uint8, device=dev)
+                    elif PhysicalType.is_binary(t):
+                        values = torch.empty(max(int(caps[i]), 1), dtype=torch.uint8, device=dev)
+                        offsets = torch.empty((rows + 1) * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
+                    else:
+                        values = torch.empty(rows * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
+                    if col.is_nullable and t != PhysicalType.NULL:
+                        validity = torch.empty(((rows + 31) // 32) * 4, dtype=torch.uint8, device=dev)
+                keep.extend([values, validity, offsets])
+                c.values = _dev_ptr(values)
+                c.values_capacity = values.numel() if values is not None else 0
+                c.validity = _dev_ptr(validity)
+                c.validity_capacity = validity.numel() if validity is not None else 0
+                c.offsets = _dev_ptr(offsets)
+                c.offsets_capacity = offsets.numel() if offsets is not None else 0
+                res.append(DeviceArray(t, col.is_nullable, rows, values, validity, offsets, c))
+        self._arr, self._keep, self._n = arr, keep, n
+        self.arrays = res
+
+    def enqueue(self):
+        ctx = self.ctx
+        ctx._keep.append(self)
+        ctx._check(ctx._lib.sb_read_columns(ctx._h, self._arr, self._n, N.SB_MEM_DEVICE))
+        return self.arrays
+
+
 def batch_read_columns(ctx, columns: List[ColumnPages], values_capacity: Optional[Sequence[int]] = None,
                        out: Optional[List[DeviceArray]] = None) -> List[DeviceArray]:
     """Enqueue the decode of a batch of leaf columns on ctx's stream; returns the device
-    arrays (valid after ctx.synchronize()).  `out` re-uses previously returned arrays' buffers
-    (steady-state decode without allocation)."""
-    import torch
-    arr, keep = _prepare(ctx, columns)
-    n = len(columns)
-    need_sizes = [i for i, col in enumerate(columns)
-                  if PhysicalType.is_binary(col.physical_type) and values_capacity is None and out is None]
-    caps = list(values_capacity) if values_capacity is not None else [None] * n
-    if need_sizes:
-        sizes = batch_read_sizes(ctx, [columns[i] for i in need_sizes])
-        for i, (_, vlen) in zip(need_sizes, sizes):
-            caps[i] = vlen
-    res = []
-    dev = ctx.torch_device
-    with torch.cuda.stream(ctx.torch_stream):
-        for i, col in enumerate(columns):
-            c = arr[i]
-            rows = int(col.metas_array()[:, 1].sum()) if c.n_pages else 0
-            t = col.physical_type
-            if out is not None:
-                o = out[i]
-                values, validity, offsets = o.values, o.validity, o.offsets
-            else:
-                validity = offsets = None
-                if t == PhysicalType.NULL:
-                    values = None
-                elif t == PhysicalType.BOOLEAN:
-                    values = torch.empty(((rows + 31) // 32) * 4, dtype=torch.uint8, device=dev)
-                elif PhysicalType.is_binary(t):
-                    values = torch.empty(max(int(caps[i]), 1), dtype=torch.uint8, device=dev)
-                    offsets = torch.empty((rows + 1) * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
-                else:
-                    values = torch.empty(rows * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
-                if col.is_nullable and t != PhysicalType.NULL:
-                    validity = torch.empty(((rows + 31) // 32) * 4, dtype=torch.uint8, device=dev)
-            keep.extend([values, validity, offsets])
-            c.values = _dev_ptr(values)
-            c.values_capacity = values.numel() if values is not None else 0
-            c.validity = _dev_ptr(validity)
-            c.validity_capacity = validity.numel() if validity is not None else 0
-            c.offsets = _dev_ptr(offsets)
-            c.offsets_capacity = offsets.numel() if offsets is not None else 0
-            res.append(DeviceArray(t, col.is_nullable, rows, values, validity, offsets, c))
-    ctx._keep.append(keep)
-    ctx._check(ctx._lib.sb_read_columns(ctx._h, arr, n, N.SB_MEM_DEVICE))
-    return res
+    arrays (valid after ctx.synchronize()).  `out` re-uses previously returned arrays' buffers."""
+    return ReadBatch(ctx, columns, values_capacity, out).enqueue()
 
 
 def read_simple(ctx, column: ColumnPages) -> DeviceArray:

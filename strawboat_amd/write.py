@@ -86,47 +86,63 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
 
 
+class WriteBatch:
+    """A prepared encode of a batch of leaf columns (descriptors and output buffers built
+    once; enqueue() costs one C call)."""
+
+    def __init__(self, ctx, columns: List[DeviceColumn], options: WriteOptions,
+                 out: Optional[List[EncodedColumn]] = None):
+        import torch
+        self.ctx = ctx
+        n = len(columns)
+        oc = options_c(options)
+        arr = (N.ColumnWriteC * n)()
+        keep = [arr, oc]
+        res = []
+        with torch.cuda.stream(ctx.torch_stream):
+            for i, col in enumerate(columns):
+                c = arr[i]
+                for name in ("values", "validity", "offsets"):
+                    t = getattr(col, name)
+                    if t is not None and (t.dtype != torch.uint8 or t.device != ctx.torch_device or
+                                          not t.is_contiguous()):
+                        raise ValueError("%s must be a contiguous uint8 tensor on %s" % (name, ctx.torch_device))
+                c.physical_type = col.physical_type
+                c.is_nullable = 1 if col.is_nullable else 0
+                c.rows = col.rows
+                c.values = _ptr(col.values)
+                c.values_bit_offset = col.values_bit_offset
+                c.values_len = col.values.numel() if col.values is not None else 0
+                c.validity = _ptr(col.validity)
+                c.validity_bit_offset = col.validity_bit_offset
+                c.offsets = _ptr(col.offsets)
+                if out is not None:
+                    pages, metas = out[i].pages, out[i]._metas
+                else:
+                    bound, npages = write_bound(ctx, col, oc)
+                    pages = torch.empty(max(bound, 1), dtype=torch.uint8, device=ctx.torch_device)
+                    metas = (N.PageMetaC * max(npages, 1))()
+                c.out_pages = _ptr(pages)
+                c.out_capacity = pages.numel()
+                c.out_metas = metas
+                c.n_pages_capacity = len(metas)
+                keep.extend([col.values, col.validity, col.offsets, pages, metas])
+                res.append(EncodedColumn(pages, metas, c))
+        self._arr, self._oc, self._keep, self._n = arr, oc, keep, n
+        self.encoded = res
+
+    def enqueue(self):
+        ctx = self.ctx
+        ctx._keep.append(self)
+        ctx._check(ctx._lib.sb_write_columns(ctx._h, self._arr, self._n, C.byref(self._oc), N.SB_MEM_DEVICE))
+        return self.encoded
+
+
 def encode_columns(ctx, columns: List[DeviceColumn], options: WriteOptions,
                    out: Optional[List[EncodedColumn]] = None) -> List[EncodedColumn]:
     """Enqueue the encode of a batch of leaf columns on ctx's stream (valid after
     ctx.synchronize()).  `out` re-uses the buffers of a previous result."""
-    import torch
-    n = len(columns)
-    oc = options_c(options)
-    arr = (N.ColumnWriteC * n)()
-    keep = [arr, oc]
-    res = []
-    with torch.cuda.stream(ctx.torch_stream):
-        for i, col in enumerate(columns):
-            c = arr[i]
-            for name in ("values", "validity", "offsets"):
-                t = getattr(col, name)
-                if t is not None and (t.dtype != torch.uint8 or t.device != ctx.torch_device or not t.is_contiguous()):
-                    raise ValueError("%s must be a contiguous uint8 tensor on %s" % (name, ctx.torch_device))
-            c.physical_type = col.physical_type
-            c.is_nullable = 1 if col.is_nullable else 0
-            c.rows = col.rows
-            c.values = _ptr(col.values)
-            c.values_bit_offset = col.values_bit_offset
-            c.values_len = col.values.numel() if col.values is not None else 0
-            c.validity = _ptr(col.validity)
-            c.validity_bit_offset = col.validity_bit_offset
-            c.offsets = _ptr(col.offsets)
-            if out is not None:
-                pages, metas = out[i].pages, out[i]._metas
-            else:
-                bound, npages = write_bound(ctx, col, oc)
-                pages = torch.empty(max(bound, 1), dtype=torch.uint8, device=ctx.torch_device)
-                metas = (N.PageMetaC * max(npages, 1))()
-            c.out_pages = _ptr(pages)
-            c.out_capacity = pages.numel()
-            c.out_metas = metas
-            c.n_pages_capacity = len(metas)
-            keep.extend([col.values, col.validity, col.offsets, pages, metas])
-            res.append(EncodedColumn(pages, metas, c))
-    ctx._keep.append(keep)
-    ctx._check(ctx._lib.sb_write_columns(ctx._h, arr, n, C.byref(oc), N.SB_MEM_DEVICE))
-    return res
+    return WriteBatch(ctx, columns, options, out).enqueue()
 
 
 def write(ctx, column: DeviceColumn, options: WriteOptions) -> EncodedColumn:

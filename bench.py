@@ -128,9 +128,10 @@ def main():
         step()
     ctx.synchronize()
     if world > 1:  # the one collective of the path: page metas of every rank (RCCL all_gather)
-        m = torch.from_numpy(np.concatenate([e.metas_array() for e in enc]).astype(np.int64)).to(dev)
-        gathered = [torch.empty_like(m) for _ in range(world)]
-        dist.all_gather(gathered, m)
+        from strawboat_amd import shard
+        local = {rank * B + i: e.metas_array() for i, e in enumerate(enc)}
+        all_metas = shard.gather_metas(local, world * B, device=dev)
+        assert len(shard.column_metas(all_metas)) == world * B
     barrier()
     t1 = time.perf_counter()
     stats = ctx.profile_read()

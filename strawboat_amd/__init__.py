@@ -7,7 +7,7 @@ streams only.  There is no CPU fallback: without the built library and a GPU, ca
 from .types import (ColumnMeta, CommonCompression, Compression, PageMeta, PhysicalType,  # noqa: F401
                     WriteOptions)
 from .context import Context  # noqa: F401
-from . import read, write  # noqa: F401
+from . import read, shard, write  # noqa: F401
 
 __all__ = ["Context", "read", "write", "WriteOptions", "PageMeta", "ColumnMeta", "Compression",
            "CommonCompression", "PhysicalType"]

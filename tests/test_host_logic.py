@@ -1,0 +1,40 @@
+"""Host-side logic that needs no GPU: sharding plan, ColumnMeta offsets, option mapping."""
+import numpy as np
+
+from strawboat_amd import shard
+from strawboat_amd.types import Compression, WriteOptions
+from strawboat_amd.write import options_c
+
+
+def test_plan_shards_balances_by_bytes():
+    # C4: 8 columns, Utf8 ~3x heavier than Boolean
+    sizes = [40, 40, 80, 80, 240, 240, 2, 2]
+    shards = shard.plan_shards(sizes, 8)
+    assert sorted(sum(shards, [])) == list(range(8)) and all(len(s) == 1 for s in shards)
+    shards = shard.plan_shards(sizes, 2)
+    loads = [sum(sizes[i] for i in s) for s in shards]
+    assert abs(loads[0] - loads[1]) <= 4
+    assert shard.plan_shards([5, 5, 5], 4)[3] == []
+
+
+def test_column_metas_offsets():
+    metas = [np.array([[100, 10], [50, 5]], np.uint64), np.array([[7, 1]], np.uint64), np.zeros((0, 2), np.uint64)]
+    cm = shard.column_metas(metas)
+    assert [c.offset for c in cm] == [8, 158, 165]
+    assert cm[0].pages[1].num_values == 5 and cm[0].total_len() == 150
+
+
+def test_gather_metas_single_process():
+    local = {0: np.array([[10, 1]], np.uint64), 1: np.array([[20, 2], [30, 3]], np.uint64)}
+    out = shard.gather_metas(local, 2)
+    assert out[1].tolist() == [[20, 2], [30, 3]]
+
+
+def test_options_mapping():
+    o = options_c(WriteOptions(default_compression=Compression.LZ4, default_compress_ratio=2.0, max_page_size=8192,
+                               forbidden_compressions=[Compression.FREQ, Compression.PATAS], force_codec=10, rng_seed=7))
+    assert o.default_compression == 1 and o.has_default_compress_ratio == 1 and o.default_compress_ratio == 2.0
+    assert o.max_page_size == 8192 and o.forbidden_compressions == (1 << 13) | (1 << 16)
+    assert o.force_codec == 10 and o.force_index_codec == -1 and o.rng_seed == 7
+    o = options_c(WriteOptions())
+    assert o.has_default_compress_ratio == 0 and o.max_page_size == 0

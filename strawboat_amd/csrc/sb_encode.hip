@@ -352,27 +352,35 @@ __device__ uint64_t enc_rle(GetVal getv, const ValidView& vv, uint64_t N, uint8_
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
+    // software pipeline: the loads of chunk k+1 are issued before chunk k is processed
+    Val<W> vn[R];
+    uint64_t mn = 0;
+    auto fetch = [&](uint64_t cb) {
+        const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
+        const uint32_t wrow = (uint32_t)w * WROWS;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const uint32_t row = wrow + 64 * j + lane;
+            vn[j] = getv(cb + (row < n ? row : n - 1));
+        }
+        mn = lane < R ? group_mask(vv, vtotal, cb, (uint32_t)w * R + lane, n) : 0;
+    };
+    if (N) fetch(0);
     uint32_t par = 0;
     for (uint64_t cb = 0; cb < N; cb += CHUNK, par ^= 1) {
         uint32_t* s_has = sA + par * 16;          // [4] wave has a valid row
         uint32_t* s_cnt = sA + par * 16 + 4;      // [4] boundaries found by the wave
         uint32_t* s_blast = sA + par * 16 + 8;    // [4] (last boundary row in chunk)+1, 0 = none
         Val<W>* s_last = (Val<W>*)sB + par * 4;   // [4] value of the wave's last valid row
-        const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
         const uint32_t wrow = (uint32_t)w * WROWS;
-        // ---- loads: values (coalesced, clamped in range) and the validity masks of my groups
         Val<W> v[R];
         uint64_t vm[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            const uint32_t row = wrow + 64 * j + lane;
-            v[j] = getv(cb + (row < n ? row : n - 1));
+            v[j] = vn[j];
+            vm[j] = readlane_u64(mn, j);
         }
-        {
-            const uint64_t mine = lane < R ? group_mask(vv, vtotal, cb, (uint32_t)w * R + lane, n) : 0;
-#pragma unroll
-            for (int j = 0; j < R; j++) vm[j] = readlane_u64(mine, j);
-        }
+        if (cb + CHUNK < N) fetch(cb + CHUNK);
         // ---- phase 1: wave summary (has a valid row, value of the last one)
         bool has_w = false;
         Val<W> last_w = val_zero<W>();
@@ -409,26 +417,26 @@ __device__ uint64_t enc_rle(GetVal getv, const ValidView& vv, uint64_t N, uint8_
                 }
             if (lane == 0) __builtin_memcpy(dst + 4, &fv, W);
         }
-        // ---- phase 2: boundaries
+        // ---- phase 2: boundaries.  One compare per row: against the previous valid row of the
+        // group if there is one, else against the carried value (lanes before the group's first
+        // valid row).  Scalar work is kept minimal: the CU has ONE scalar ALU for its 16 waves.
         uint64_t bm[R];
         uint32_t cnt_w = 0, blast_w = 0;
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm[j]);
             const uint64_t pm = vm[j] & lt;
-            const Val<W> pv = shfl_val<W>(v[j], pm ? top_bit(pm) : 0);
-            const bool ne_prev = !rle_eq<W, FK>(pv, v[j]);
-            const bool ne_carry = chas && !rle_eq<W, FK>(cval, v[j]);
-            const bool b = valid && (pm ? ne_prev : ne_carry);
-            bm[j] = __ballot(b);
-            if (vm[j]) {
-                chas = true;
-                cval = readlane_val<W>(v[j], top_bit(vm[j]));
-            }
-            if (bm[j]) {
-                cnt_w += (uint32_t)__popcll(bm[j]);
-                blast_w = wrow + 64 * j + (uint32_t)top_bit(bm[j]) + 1;
-            }
+            const bool has_prev = pm != 0;
+            const Val<W> pv = shfl_val<W>(v[j], has_prev ? top_bit(pm) : 0);
+            Val<W> other = has_prev ? pv : cval;
+            const bool ne = !rle_eq<W, FK>(other, v[j]);
+            const uint64_t nem = __ballot(ne && (has_prev || chas));
+            bm[j] = nem & vm[j];
+            const int tv = vm[j] ? top_bit(vm[j]) : 0;
+            const Val<W> lv = readlane_val<W>(v[j], tv);
+            chas = chas || (vm[j] != 0);
+            cval = vm[j] ? lv : cval;
+            cnt_w += (uint32_t)__popcll(bm[j]);
+            blast_w = bm[j] ? wrow + 64 * j + (uint32_t)top_bit(bm[j]) + 1 : blast_w;
         }
         if (lane == 0) {
             s_cnt[w] = cnt_w;

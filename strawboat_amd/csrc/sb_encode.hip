@@ -44,6 +44,8 @@ struct EncCol {
     uint32_t first_page;
     uint32_t n_pages;
     uint32_t fkind;  // 0 = bitwise equality, 1 = f32, 2 = f64 (OrderedFloat equality for RLE)
+    uint32_t nk;     // NumKind: signed / unsigned / f32 / f64 (typed order of the selector)
+    uint32_t pad;
 };
 
 struct EncPage {
@@ -75,10 +77,22 @@ struct EncodeArgs {
     uint8_t* scratch;
     Status* status;
     uint64_t* results;  // per column: [n_pages lengths][n_pages num_values][total]
+    int32_t* codecs;    // per page: codec chosen on the device (adaptive mode)
+    double ratio;       // default_compress_ratio
+    uint32_t has_ratio;
+    uint32_t forbidden;
     uint32_t n_pages;
     uint32_t n_cols;
     uint32_t default_compression;
 };
+
+__device__ __forceinline__ int32_t codec_of(const EncodeArgs& a, const EncPage& p, uint32_t page) {
+    return p.codec >= 0 ? p.codec : a.codecs[page];
+}
+__device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
+    return codec == SB_CODEC_NONE || codec == SB_CODEC_RLE || codec == SB_CODEC_DICT || codec == SB_CODEC_ONEVALUE ||
+           codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING;
+}
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t COMPACT_CHUNK = 64 * 1024;
@@ -792,6 +806,397 @@ struct BinKeys {
     }
 };
 
+// ------------------------------------------------------------------------------ adaptive selection
+}  // namespace sb
+#include "sb_select.h"
+namespace sb {
+
+struct SelScratch {
+    uint32_t* lds_tab;   // SEL_LDS_SLOTS words
+    uint32_t* s_misc;    // >= 2*WG + 16 words
+    uint8_t* sample_mem; // SAMPLE_ROWS * (W + 1) bytes, 16-byte aligned
+    uint32_t* gtab;      // HBM table for the distinct count (may be null)
+    uint64_t gslots;
+};
+
+// row-index hash-set operations over canonical primitive keys
+template <int W, class Key>
+struct KeyOpsPrim {
+    Key key;
+    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return stat_hash<W>(key(i)); }
+    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return bits_eq<W>(key(a), key(b)); }
+    __device__ __forceinline__ uint32_t weight(uint64_t) const { return 0; }
+};
+
+// Exact number of distinct keys among rows [0,N), or a value > limit once the count is known to
+// exceed it.  LDS tier first; restart on the HBM table when more than SEL_LDS_SLOTS/2 keys show
+// up.  *weight_sum receives the sum of ops.weight(i) over the first row of every distinct key.
+template <class Ops>
+__device__ uint32_t distinct_count(Ops ops, uint64_t N, uint32_t limit, const SelScratch& sc, uint64_t* weight_sum) {
+    const int t = threadIdx.x;
+    __shared__ uint32_t s_cnt;
+    __shared__ unsigned long long s_wsum;
+    for (int tier = 0; tier < 2; tier++) {
+        uint32_t* tab = tier == 0 ? sc.lds_tab : sc.gtab;
+        const uint64_t slots = tier == 0 ? SEL_LDS_SLOTS : sc.gslots;
+        if (tier == 1 && (!sc.gtab || sc.gslots < 2 * N)) return limit + 1;
+        const uint32_t cap = tier == 0 ? SEL_LDS_SLOTS / 2 : 0xFFFFFFFFu;
+        for (uint64_t i = t; i < slots; i += WG) tab[i] = SEL_EMPTY;
+        if (t == 0) {
+            s_cnt = 0;
+            s_wsum = 0;
+        }
+        __syncthreads();
+        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t mask = (uint32_t)(slots - 1);
+        bool overflow = false;
+        for (uint64_t base = 0; base < N; base += WG * 16) {
+            for (int j = 0; j < 16; j++) {
+                const uint64_t i = base + (uint64_t)j * WG + t;
+                if (i >= N) break;
+                uint32_t h = ops.hash(i) & mask;
+                for (;;) {
+                    uint32_t cur = tier == 0 ? tab[h]
+                                             : __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == SEL_EMPTY) {
+                        const uint32_t old = atomicCAS(&tab[h], SEL_EMPTY, (uint32_t)i);
+                        if (old == SEL_EMPTY) {
+                            atomicAdd(&s_cnt, 1u);
+                            const uint32_t wgt = ops.weight(i);
+                            if (wgt) atomicAdd(&s_wsum, (unsigned long long)wgt);
+                            break;
+                        }
+                        cur = old;
+                    }
+                    if (cur == (uint32_t)i || ops.eq(cur, i)) break;
+                    h = (h + 1) & mask;
+                }
+            }
+            __syncthreads();
+            const uint32_t c = s_cnt;
+            if (c > limit) return c;
+            if (c > cap) {
+                overflow = true;
+                break;
+            }
+        }
+        __syncthreads();
+        if (!overflow) {
+            if (weight_sum) *weight_sum = s_wsum;
+            return s_cnt;
+        }
+    }
+    return limit + 1;
+}
+
+// Boyer-Moore majority candidate (row index or SEL_EMPTY) with an exact count of its key.
+template <class Ops>
+__device__ uint32_t majority_count(Ops ops, uint64_t N, uint32_t* s_a /* 2*WG + 4 words */) {
+    const int t = threadIdx.x;
+    uint32_t cand = SEL_EMPTY, cnt = 0;
+    for (uint64_t i = t; i < N; i += WG) {
+        if (cnt == 0) {
+            cand = (uint32_t)i;
+            cnt = 1;
+        } else if (ops.eq(cand, i)) {
+            cnt++;
+        } else {
+            cnt--;
+        }
+    }
+    s_a[t] = cand;
+    s_a[WG + t] = cnt;
+    __syncthreads();
+    for (int stride = WG / 2; stride > 0; stride >>= 1) {
+        if (t < stride) {
+            const uint32_t c0 = s_a[t], n0 = s_a[WG + t], c1 = s_a[t + stride], n1 = s_a[WG + t + stride];
+            uint32_t c = c0, n = n0;
+            if (n1) {
+                if (n0 == 0) {
+                    c = c1;
+                    n = n1;
+                } else if (ops.eq(c0, c1)) {
+                    n = n0 + n1;
+                } else if (n1 > n0) {
+                    c = c1;
+                    n = n1 - n0;
+                } else {
+                    n = n0 - n1;
+                }
+            }
+            s_a[t] = c;
+            s_a[WG + t] = n;
+        }
+        __syncthreads();
+    }
+    const uint32_t c = s_a[WG] ? s_a[0] : SEL_EMPTY;
+    __syncthreads();
+    if (c == SEL_EMPTY) return 0;
+    uint32_t mine = 0;
+    for (uint64_t i = t; i < N; i += WG) mine += ops.eq(c, i) ? 1 : 0;
+    return wg_sum32(mine, s_a + 2 * WG);
+}
+
+// choose_compressor for primitives (integer/mod.rs:231-308, double/mod.rs:231-307)
+template <int W, class GetVal, class Valid>
+__device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t nk, const SelectOpts& o,
+                                const SelScratch& sc) {
+    const int t = threadIdx.x;
+    auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
+    if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
+    if (!o.has_ratio || N == 0) return o.default_codec;
+    const bool is_float = nk >= NK_F32;
+    auto key = [&](uint64_t i) { return stat_key<W>(getv(i), nk); };
+    uint32_t* s4 = sc.s_misc + 2 * WG;
+    // ---- streaming statistics
+    const Val<W> k0 = key(0);
+    uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, nulls = 0;
+    Val<W> tmax = getv(0);
+    for (uint64_t i = t; i < N; i += WG) {
+        const Val<W> v = getv(i);
+        if (!bits_eq<W>(stat_key<W>(v, nk), k0)) f_neq0 = 1;
+        if (!valid(i)) nulls++;
+        if (!is_float) {
+            if (int_lt<W>(tmax, v, nk)) tmax = v;
+            if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(v, nk) < 0) f_neg = 1;
+            if (W == 4 && i > 0 && int_lt<W>(v, getv(i - 1), nk)) f_unsorted = 1;
+        }
+    }
+    const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
+    const uint32_t null_count = wg_sum32(nulls, s4);
+    const bool all_equal = !(flags & 1);
+    bool is_sorted = !(flags & 2);
+    const bool any_neg = flags & 4;
+    if (!is_float && W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(getv(0), nk) < 0) is_sorted = false;  // vs last_value = 0
+    // typed maximum (only Freq for integers looks at it: max.as_i64() >= 256, freq.rs:146)
+    int64_t max_i64 = 0;
+    if (!is_float && !forbidden(SB_CODEC_FREQ)) {
+        Val<W>* red = (Val<W>*)sc.sample_mem;  // 256 * W bytes <= 8 KB, free until the samples are drawn
+        red[t] = tmax;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride && int_lt<W>(red[t], red[t + stride], nk)) red[t] = red[t + stride];
+            __syncthreads();
+        }
+        max_i64 = as_i64<W>(red[0], nk);
+        __syncthreads();
+    }
+    const double tuple_count = (double)N;
+    const double total_bytes = (double)(N * W);
+    double max_ratio = o.ratio;
+    uint32_t result = o.default_codec;
+    static const uint8_t INT_ORDER[6] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT,
+                                         SB_CODEC_RLE, SB_CODEC_BITPACKING, SB_CODEC_DELTA_BITPACKING};
+    static const uint8_t DBL_ORDER[5] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT, SB_CODEC_PATAS, SB_CODEC_RLE};
+    const int norder = is_float ? 5 : 6;
+    KeyOpsPrim<W, decltype(key)> kops{key};
+    Sample<W> smp;
+    smp.val = (Val<W>*)sc.sample_mem;
+    smp.valid = sc.sample_mem + SAMPLE_CAP * W;
+    for (int oi = 0; oi < norder; oi++) {
+        const uint32_t c = is_float ? DBL_ORDER[oi] : INT_ORDER[oi];
+        if (forbidden(c)) continue;
+        double r = 0.0;
+        switch (c) {
+            case SB_CODEC_ONEVALUE:  // one_value.rs:53-59
+                r = all_equal ? tuple_count : 0.0;
+                break;
+            case SB_CODEC_FREQ: {  // freq.rs:129-151
+                if (all_equal) break;
+                if ((double)null_count / tuple_count >= 0.9) {
+                    r = (double)(N - 1);
+                    break;
+                }
+                const uint32_t mc = majority_count(kops, N, sc.s_misc);
+                const bool big = is_float ? true : (max_i64 >= 256);
+                if ((double)mc / tuple_count >= 0.9 && big) r = (double)(N - 1);
+                break;
+            }
+            case SB_CODEC_DICT: {  // dict.rs:109-120
+                if (N < 3) break;
+                const uint32_t limit = (uint32_t)((N - 1) / 3);  // largest unique with unique*3 < N
+                const uint32_t uq = all_equal ? 1u : distinct_count(kops, N, limit, sc, nullptr);
+                if ((uint64_t)uq * 3 >= N) break;
+                uint64_t after = (uint64_t)uq * W + N * (uint64_t)(bits_needed(uq) / 8);
+                after += N * 2 / 128;
+                r = total_bytes / (double)after;
+                break;
+            }
+            case SB_CODEC_RLE: {  // rle.rs:58-60
+                load_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_RLE, smp);
+                uint32_t runs;
+                if (nk == NK_F32)
+                    runs = sample_rle_runs<W, (W == 4 ? 1 : 0)>(smp, s4);
+                else if (nk == NK_F64)
+                    runs = sample_rle_runs<W, (W == 8 ? 2 : 0)>(smp, s4);
+                else
+                    runs = sample_rle_runs<W, 0>(smp, s4);
+                r = (double)((uint64_t)smp.n * W) / (double)((uint64_t)runs * (4 + W));
+                __syncthreads();
+                break;
+            }
+            case SB_CODEC_BITPACKING:  // bp.rs:92-100
+            case SB_CODEC_DELTA_BITPACKING: {  // delta_bp.rs:97-109
+                if constexpr (W == 4) {
+                    if (any_neg || N % 128 != 0) break;
+                    if (c == SB_CODEC_DELTA_BITPACKING && (!is_sorted || null_count > 0)) break;
+                    load_sample<4>(getv, valid, N, o.seed, o.depth, c, smp);
+                    const uint32_t size = sample_bp_size(smp, s4, sc.s_misc);
+                    r = (double)((uint64_t)smp.n * 4) / (double)size;
+                    if (c == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
+                    __syncthreads();
+                }
+                break;
+            }
+            case SB_CODEC_PATAS: {  // patas.rs:139-141
+                if constexpr (W == 4 || W == 8) {
+                    load_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_PATAS, smp);
+                    const uint32_t size = sample_patas_size<W>(smp, s4);
+                    r = (double)((uint64_t)smp.n * W) / (double)size;
+                    __syncthreads();
+                }
+                break;
+            }
+        }
+        if (r > max_ratio) {
+            max_ratio = r;
+            result = c;
+            if (r == tuple_count) break;
+        }
+    }
+    return result;
+}
+
+// choose_compressor for booleans (boolean/mod.rs:194-238) with gen_stats (:151-192)
+__device__ uint32_t choose_bool(const uint8_t* bits, uint64_t boff, const ValidView& vv, uint64_t N, const SelectOpts& o,
+                                const SelScratch& sc) {
+    auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
+    if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
+    if (!o.has_ratio || N == 0) return o.default_codec;
+    uint32_t* s4 = sc.s_misc + 2 * WG;
+    uint32_t nt = 0, nf = 0;
+    for (uint64_t i = threadIdx.x; i < N; i += WG)
+        if (vv.get(i)) {
+            if (bit_at(bits, boff + i))
+                nt++;
+            else
+                nf++;
+        }
+    const uint32_t true_count = wg_sum32(nt, s4), false_count = wg_sum32(nf, s4);
+    double max_ratio = o.ratio;
+    uint32_t result = o.default_codec;
+    if (!forbidden(SB_CODEC_ONEVALUE)) {  // one_value.rs:36-42
+        const double r = (true_count == 0 || false_count == 0) ? (double)N : 0.0;
+        if (r > max_ratio) {
+            max_ratio = r;
+            result = SB_CODEC_ONEVALUE;
+            if (r == (double)N) return result;
+        }
+    }
+    if (!forbidden(SB_CODEC_RLE)) {  // boolean/rle.rs:61-63 -> compress_sample_ratio (:240-278)
+        Sample<1> smp;
+        smp.val = (Val<1>*)sc.sample_mem;
+        smp.valid = sc.sample_mem + SAMPLE_CAP;
+        auto getv = [&](uint64_t i) {
+            Val<1> v;
+            v.x = bit_at(bits, boff + i) ? 1 : 0;
+            return v;
+        };
+        auto valid = [&](uint64_t i) { return vv.get(i); };
+        // total_bytes = values().len() / 8 of the (sample) array; sizes: 5 bytes per run
+        double r;
+        if (N / SAMPLE_COUNT <= SAMPLE_SIZE) {
+            smp.whole = true;
+            // whole array: count runs over all N rows (may exceed the LDS sample): stream it
+            uint32_t cnt = 0;
+            for (uint64_t k = threadIdx.x; k < N; k += WG) {
+                if (!vv.get(k)) continue;
+                int64_t p = (int64_t)k - 1;
+                while (p >= 0 && !vv.get((uint64_t)p)) p--;
+                if (p >= 0 && bit_at(bits, boff + (uint64_t)p) != bit_at(bits, boff + k)) cnt++;
+            }
+            const uint32_t runs = wg_sum32(cnt, s4) + 1;
+            r = (double)(N / 8) / (double)((uint64_t)runs * 5);
+        } else {
+            load_sample<1>(getv, valid, N, o.seed, 0, SB_CODEC_RLE, smp);
+            const uint32_t runs = sample_rle_runs<1, 0>(smp, s4);
+            r = (double)(SAMPLE_ROWS / 8) / (double)((uint64_t)runs * 5);
+            __syncthreads();
+        }
+        if (r > max_ratio) {
+            max_ratio = r;
+            result = SB_CODEC_RLE;
+        }
+    }
+    return result;
+}
+
+// row-index hash-set operations over all rows of a binary page (gen_stats, binary/mod.rs:265-291)
+template <class O>
+struct KeyOpsBin {
+    BinKeys<O> k;
+    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return k.hash(i); }
+    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return k.eq(a, b); }
+    __device__ __forceinline__ uint32_t weight(uint64_t i) const { return (uint32_t)(k.beg(i + 1) - k.beg(i)) + 8; }
+};
+
+// choose_compressor for binary (binary/mod.rs:293-348)
+template <class O>
+__device__ uint32_t choose_bin(const BinKeys<O>& bk, uint64_t N, uint64_t values_len_total, const SelectOpts& o,
+                               const SelScratch& sc) {
+    auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
+    if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
+    if (!o.has_ratio || N == 0) return o.default_codec;
+    uint32_t* s4 = sc.s_misc + 2 * WG;
+    KeyOpsBin<O> ops{bk};
+    uint32_t f_neq0 = 0, nulls = 0;
+    for (uint64_t i = threadIdx.x; i < N; i += WG) {
+        if (!ops.eq(0, i)) f_neq0 = 1;
+        if (!bk.vv.get(i)) nulls++;
+    }
+    const bool all_equal = !wg_or32(f_neq0, s4);
+    const uint32_t null_count = wg_sum32(nulls, s4);
+    const double tuple_count = (double)N;
+    const double total_bytes = (double)(values_len_total + (N + 1) * sizeof(O));
+    double max_ratio = o.ratio;
+    uint32_t result = o.default_codec;
+    static const uint8_t ORDER[3] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT};
+    for (int oi = 0; oi < 3; oi++) {
+        const uint32_t c = ORDER[oi];
+        if (forbidden(c)) continue;
+        double r = 0.0;
+        if (c == SB_CODEC_ONEVALUE) {  // binary/one_value.rs:42-48
+            r = all_equal ? tuple_count : 0.0;
+        } else if (c == SB_CODEC_FREQ) {  // binary/freq.rs:147-169
+            if (!all_equal) {
+                if ((double)null_count / tuple_count >= 0.9) {
+                    r = (double)(N - 1);
+                } else {
+                    const uint32_t mc = majority_count(ops, N, sc.s_misc);
+                    if ((double)mc / tuple_count >= 0.9) r = (double)(N - 1);
+                }
+            }
+        } else {  // binary/dict.rs:43-53
+            if (N >= 3) {
+                const uint32_t limit = (uint32_t)((N - 1) / 3);
+                uint64_t tus = 0;
+                const uint32_t uq = distinct_count(ops, N, limit, sc, &tus);
+                if ((uint64_t)uq * 3 < N) {
+                    uint64_t after = tus + N * (uint64_t)(bits_needed(uq) / 8);
+                    after += N * 2 / 128;
+                    r = total_bytes / (double)after;
+                }
+            }
+        }
+        if (r > max_ratio) {
+            max_ratio = r;
+            result = c;
+            if (r == tuple_count) break;
+        }
+    }
+    return result;
+}
+
 // ------------------------------------------------------------------------------ page kernels
 struct PageCtx {
     const EncCol* c;
@@ -866,6 +1271,14 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
         const uint32_t D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
         if (D == EMPTY) return 0;
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
+        if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
+            SelectOpts so{a.ratio, 1u, a.forbidden | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, 1u};
+            SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
+            const uint32_t* ip = idx;
+            ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = ip[i]; return v; },
+                                         [](uint64_t) { return true; }, N, NK_UNSIGNED, so, sc);
+            __syncthreads();
+        }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
         if (ib == 0) return 0;
         uint8_t* q = blk + 9 + ib;
@@ -954,6 +1367,14 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         const uint32_t D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
         if (D == EMPTY) return 0;
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
+        if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
+            SelectOpts so{a.ratio, 1u, a.forbidden | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, 1u};
+            SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
+            const uint32_t* ip = idx;
+            ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = ip[i]; return v; },
+                                         [](uint64_t) { return true; }, N, NK_UNSIGNED, so, sc);
+            __syncthreads();
+        }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
         if (ib == 0) return 0;
         uint8_t* q = blk + 9 + ib;
@@ -994,6 +1415,82 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
     return 9 + body;
 }
 
+// codec choice per page (adaptive mode): one workgroup per page, one instance per KIND
+template <int KIND>
+__global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
+    __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
+    __shared__ uint32_t s_misc[2 * WG + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16];
+    const uint32_t page = blockIdx.x;
+    const EncPage p = a.pages[page];
+    if (p.codec >= 0) return;
+    const EncCol c = a.cols[p.col];
+    if (c.ptype == SB_TYPE_NULL) return;
+    const bool is_bool = c.ptype == SB_TYPE_BOOLEAN;
+    const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
+    if constexpr (KIND == 0) {
+        if (!is_bool) return;
+    } else if constexpr (KIND == -4) {
+        if (c.ptype != SB_TYPE_BINARY) return;
+    } else if constexpr (KIND == -8) {
+        if (c.ptype != SB_TYPE_LARGE_BINARY) return;
+    } else {
+        if (is_bool || is_bin || c.width != (uint32_t)KIND) return;
+    }
+    const uint64_t N = p.rows;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    SelectOpts so{a.ratio, a.has_ratio, a.forbidden, a.default_compression, -1, p.seed, 0u};
+    SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
+    if (sc.gtab) {  // the Dict aux area starts with a table of pow2 >= 2N slots
+        uint64_t M = 64;
+        while (M < 2 * N) M <<= 1;
+        sc.gslots = M;
+    }
+    uint32_t codec;
+    if constexpr (KIND == 0) {
+        codec = choose_bool(c.values, c.values_bit_offset + p.row0, vv, N, so, sc);
+    } else if constexpr (KIND == -4) {
+        BinKeys<int32_t> bk{c.offsets + p.row0 * 4, c.values, vv};
+        codec = choose_bin<int32_t>(bk, N, c.values_len, so, sc);
+    } else if constexpr (KIND == -8) {
+        BinKeys<int64_t> bk{c.offsets + p.row0 * 8, c.values, vv};
+        codec = choose_bin<int64_t>(bk, N, c.values_len, so, sc);
+    } else {
+        const uint8_t* vals = c.values + p.row0 * KIND;
+        codec = choose_prim<KIND>([=](uint64_t i) { return ld_val<KIND>(vals + i * KIND); },
+                                  [=](uint64_t i) { return vv.get(i); }, N, c.nk, so, sc);
+    }
+    if (threadIdx.x == 0) {
+        a.codecs[page] = (int32_t)codec;
+        if (!has_device_encoder(codec)) raise(a.status, SB_ERR_NYI, page, 700 + codec);
+    }
+}
+
+typedef void (*EncSelectKernel)(EncodeArgs);
+static EncSelectKernel enc_select_kernel(int kind) {
+    switch (kind) {
+        case 0:
+            return k_enc_select<0>;
+        case 1:
+            return k_enc_select<1>;
+        case 2:
+            return k_enc_select<2>;
+        case 4:
+            return k_enc_select<4>;
+        case 8:
+            return k_enc_select<8>;
+        case 16:
+            return k_enc_select<16>;
+        case 32:
+            return k_enc_select<32>;
+        case -4:
+            return k_enc_select<-4>;
+        case -8:
+            return k_enc_select<-8>;
+    }
+    return nullptr;
+}
+
 // Pages with an extended codec: one workgroup per page.  One kernel instance per (KIND, CODEC):
 // KIND = value width 1..32 for primitives, 0 = boolean, -4 / -8 = binary with i32 / i64 offsets.
 // A monolithic kernel over all kinds needs 300 VGPRs (1 wave/SIMD); the split instances stay
@@ -1003,11 +1500,12 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     k_enc_emit_pages(EncodeArgs a) {
     // RLE / OneValue only need the small per-group records; Dict and bit-packing use full tile arrays
     constexpr int LW = (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_ONEVALUE) ? 256 : SIDX_WORDS;
-    __shared__ uint32_t sA[LW], sB[LW], sC[LW];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * LW];
+    uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
     __shared__ uint32_t s_w[4];
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
-    if (p.codec != CODEC) return;
+    if (codec_of(a, p, page) != CODEC) return;
     const EncCol c = a.cols[p.col];
     if (c.ptype == SB_TYPE_NULL) return;
     const bool is_bool = c.ptype == SB_TYPE_BOOLEAN;
@@ -1108,7 +1606,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_tiles(EncodeArgs a) {
         }
         return;
     }
-    if (p.codec != SB_CODEC_NONE) return;
+    if (codec_of(a, p, page) != SB_CODEC_NONE) return;
     const uint64_t N = p.rows;
     const uint64_t r0 = (uint64_t)tile * TILE_ROWS;
     if (r0 >= N && !(tile == 0)) return;
@@ -1297,11 +1795,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         host_codec = opts->force_codec;
     else if (!opts->has_default_compress_ratio)
         host_codec = opts->default_compression;
-    if (host_codec < 0)
-        return ctx->fail(SB_ERR_NYI, "adaptive codec selection on the device is not built yet: pass force_codec or "
-                                     "default_compress_ratio = None");
-    if (host_codec == SB_CODEC_DICT && opts->has_default_compress_ratio && opts->force_index_codec < 0)
-        return ctx->fail(SB_ERR_NYI, "adaptive choice of the Dict index codec is not built yet: pass force_index_codec");
+    const bool adaptive = host_codec < 0;  // codec chosen per page on the device (k_enc_select)
+    const uint32_t forb = opts->forbidden_compressions;
 
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
     for (uint64_t i = 0; i < n; i++) {
@@ -1332,6 +1827,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     const size_t o_results = off;
     const size_t results_words = 2 * P + n;
     off = align_up(off + results_words * sizeof(uint64_t), 64);
+    const size_t o_codecs = off;
+    off = align_up(off + P * sizeof(int32_t), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
     StageSlot* slot = acquire_slot(ctx, upload_bytes + results_words * sizeof(uint64_t));
@@ -1361,11 +1858,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         d.width = enc_type_width(c.physical_type);
         d.first_page = (uint32_t)pi;
         d.fkind = c.physical_type == SB_TYPE_FLOAT32 ? 1 : c.physical_type == SB_TYPE_FLOAT64 ? 2 : 0;
+        d.nk = c.physical_type == SB_TYPE_FLOAT32 ? NK_F32 : c.physical_type == SB_TYPE_FLOAT64 ? NK_F64
+               : (c.physical_type >= SB_TYPE_UINT8 && c.physical_type <= SB_TYPE_UINT64) ? NK_UNSIGNED : NK_SIGNED;
         const uint64_t ps = page_size_of(c.rows, opts);
         const bool bin = enc_is_binary(c.physical_type);
         int32_t codec = host_codec;
         // sizes known up front => write straight to the final position
-        const bool direct = !bin && (codec == SB_CODEC_NONE || codec == SB_CODEC_ONEVALUE) && c.physical_type != SB_TYPE_NULL;
+        const bool direct = !adaptive && !bin && (codec == SB_CODEC_NONE || codec == SB_CODEC_ONEVALUE) &&
+                            c.physical_type != SB_TYPE_NULL;
         uint64_t direct_off = 0, k = 0;
         if (bin) scratch_off = align_up(scratch_off, 16);
         const size_t col_slot_base = scratch_off;
@@ -1378,7 +1878,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             p.col = (uint32_t)i;
             p.codec = codec;
             p.icodec = opts->force_index_codec;
-            p.seed = opts->rng_seed;
+            p.seed = page_seed_of(opts->rng_seed, k);
             p.direct = direct ? 1 : 0;
             if (direct) {
                 p.direct_off = direct_off;
@@ -1391,15 +1891,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 scratch_off += align_up(slot_fixed_bytes(c.physical_type, c.is_nullable, N), 16);
                 any_compact = true;
             }
-            if (codec == SB_CODEC_DICT) {
+            if (codec == SB_CODEC_DICT || (adaptive && !((forb >> SB_CODEC_DICT) & 1) && c.physical_type != SB_TYPE_BOOLEAN &&
+                                           c.physical_type != SB_TYPE_NULL)) {
                 uint64_t M = 64;
                 while (M < 2 * N) M <<= 1;
                 p.aux_bytes = (M + 3 * N) * 4;
             }
-            if (codec == SB_CODEC_NONE)
+            if (codec == SB_CODEC_NONE || (adaptive && opts->default_compression == SB_CODEC_NONE))
                 any_tiles = true;
-            else
-                any_pages = true;
+            if (codec != SB_CODEC_NONE) any_pages = true;
         }
         if (bin) scratch_off += align_up(c.values_len + c.values_len / 64 + 64 * k + 64, 16);
         (void)col_slot_base;
@@ -1435,32 +1935,56 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.scratch = ctx->scratch.p;
     a.status = ctx->d_status;
     a.results = (uint64_t*)(tb + o_results);
+    a.codecs = (int32_t*)(tb + o_codecs);
+    a.ratio = opts->default_compress_ratio;
+    a.has_ratio = opts->has_default_compress_ratio ? 1u : 0u;
+    a.forbidden = forb;
     a.n_pages = (uint32_t)P;
     a.n_cols = (uint32_t)n;
     a.default_compression = (uint32_t)opts->default_compression;
 
     (void)hipMemsetAsync(a.outs, 0, P * sizeof(EncOut), s);
+    auto kind_of = [](const EncCol& d) {
+        return d.ptype == SB_TYPE_BOOLEAN ? 0 : d.ptype == SB_TYPE_BINARY ? -4 : d.ptype == SB_TYPE_LARGE_BINARY ? -8 : (int)d.width;
+    };
+    std::vector<int> kinds;
+    for (uint64_t i = 0; i < n; i++) {
+        if (hc[i].ptype == SB_TYPE_NULL) continue;
+        const int kd = kind_of(hc[i]);
+        bool seen = false;
+        for (int q : kinds) seen |= q == kd;
+        if (!seen) kinds.push_back(kd);
+    }
+    if (adaptive) {
+        for (int kd : kinds) {
+            KScope k(ctx, K_ENC_SELECT);
+            enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(a);
+        }
+    }
     if (any_tiles) {
         KScope k(ctx, K_ENC_TILES);
         k_enc_emit_tiles<<<dim3((uint32_t)P, (uint32_t)max_tiles), WG, 0, s>>>(a);
     }
     if (any_pages) {
-        // one kernel instance per (kind, codec) present in the batch
-        std::vector<std::pair<int, int32_t>> done;
-        for (uint64_t i = 0; i < n; i++) {
-            const EncCol& d = hc[i];
-            if (d.ptype == SB_TYPE_NULL || host_codec == SB_CODEC_NONE) continue;
-            const int kind = d.ptype == SB_TYPE_BOOLEAN ? 0 : d.ptype == SB_TYPE_BINARY ? -4
-                             : d.ptype == SB_TYPE_LARGE_BINARY ? -8 : (int)d.width;
-            std::pair<int, int32_t> key(kind, host_codec);
-            bool seen = false;
-            for (auto& q : done) seen |= q == key;
-            if (seen) continue;
-            done.push_back(key);
-            EncPageKernel kf = enc_page_kernel(kind, host_codec);
-            if (!kf) return ctx->fail(SB_ERR_NYI, "no device encoder for this codec (LZ4/Zstd/Snappy/Freq/Patas pages are not built yet)");
-            KScope k(ctx, K_ENC_PAGES);
-            kf<<<(uint32_t)P, WG, 0, s>>>(a);
+        // one kernel instance per (kind, codec) that can occur in the batch
+        static const int32_t CAND[5] = {SB_CODEC_ONEVALUE, SB_CODEC_DICT, SB_CODEC_RLE, SB_CODEC_BITPACKING,
+                                        SB_CODEC_DELTA_BITPACKING};
+        for (int kd : kinds) {
+            for (int32_t cd : CAND) {
+                if (!adaptive && cd != host_codec) continue;
+                if (adaptive) {
+                    if ((forb >> cd) & 1) continue;
+                    if ((cd == SB_CODEC_BITPACKING || cd == SB_CODEC_DELTA_BITPACKING) && kd != 4) continue;
+                    if (kd == 0 && cd == SB_CODEC_DICT) continue;
+                    if (kd < 0 && cd == SB_CODEC_RLE) continue;
+                }
+                EncPageKernel kf = enc_page_kernel(kd, cd);
+                if (!kf) continue;
+                KScope k(ctx, K_ENC_PAGES);
+                kf<<<(uint32_t)P, WG, 0, s>>>(a);
+            }
+            if (!adaptive && host_codec != SB_CODEC_NONE && !enc_page_kernel(kd, host_codec))
+                return ctx->fail(SB_ERR_NYI, "no device encoder for this codec (LZ4/Zstd/Snappy/Freq/Patas pages are not built yet)");
         }
     }
     {

@@ -1,0 +1,91 @@
+"""GPU parity of the adaptive selector: with default_compress_ratio = Some(r) the codec of every
+page is chosen on the device (statistics + seeded sampling); the choice and the page bytes must
+equal what the CPU oracle produces for the same options and seed."""
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+from tests.test_gpu_encode import gpu_encode
+
+pytestmark = pytest.mark.gpu
+
+NOT_ON_DEVICE = (S.FREQ, S.PATAS)
+
+
+def check(ctx, col, **opt):
+    opt.setdefault("forbidden", NOT_ON_DEVICE)
+    want_pages, want_metas = gen.oracle_write(col, **opt)
+    want_codecs, want_inner = S.stat_column(col["ptype"], col["nullable"], want_pages, want_metas)
+    enc = gpu_encode(ctx, col, **opt)
+    got_metas = enc.metas_array()
+    got = enc.pages_numpy()
+    got_codecs, got_inner = S.stat_column(col["ptype"], col["nullable"], got, got_metas)
+    assert got_codecs.tolist() == want_codecs.tolist(), "page codecs differ"
+    assert got_inner.tolist() == want_inner.tolist(), "nested codecs differ"
+    assert np.array_equal(got_metas, want_metas)
+    assert np.array_equal(got, want_pages), "page bytes differ"
+    return want_codecs
+
+
+@pytest.mark.parametrize("ptype", [S.T_I8, S.T_I16, S.T_I32, S.T_U32, S.T_I64, S.T_U64, S.T_F32, S.T_F64, S.T_I128])
+def test_prim_shapes(gpu_ctx, ptype):
+    seen = set()
+    for kw in (dict(uniq=1), dict(uniq=8), dict(uniq=200, runs=20), dict(uniq=1 << 20), dict(uniq=3, null_density=0.3),
+               dict(uniq=50, runs=40, null_density=0.1), dict(uniq=1000, sorted_=True)):
+        uq = min(kw.get("uniq", 1000), 100 if ptype == S.T_I8 else 1 << 30)
+        col = gen.prim(ptype, 128 * 160, **dict(kw, uniq=uq))
+        for ratio in (1.2, 2.0):
+            seen |= set(check(gpu_ctx, col, max_page_size=128 * 64, ratio=ratio).tolist())
+    assert len(seen) >= 2, "the shapes should exercise several codecs, got %s" % seen
+
+
+def test_small_pages_use_whole_array_trials(gpu_ctx):
+    # N / 10 <= 64: compress_sample_ratio compresses the whole page (no sampling)
+    col = gen.prim(S.T_I32, 640 * 5, uniq=4, runs=6, null_density=0.1)
+    check(gpu_ctx, col, max_page_size=640, ratio=1.5)
+    col = gen.prim(S.T_U32, 512 * 4, uniq=1 << 10, sorted_=True)
+    check(gpu_ctx, col, max_page_size=512, ratio=1.1)
+    col = gen.prim(S.T_F64, 600 * 3, uniq=5, runs=9)
+    check(gpu_ctx, col, max_page_size=600, ratio=1.5)
+
+
+def test_seed_changes_sampling_not_parity(gpu_ctx):
+    col = gen.prim(S.T_I32, 128 * 512, uniq=300, runs=3)
+    for seed in (1, 2, 3):
+        check(gpu_ctx, col, max_page_size=65536, ratio=1.3, rng_seed=seed)
+
+
+def test_c2_adaptive(gpu_ctx):
+    import bench
+    vals, valid = bench.gen_c2_column(42)
+    col = dict(ptype=S.T_F64, nullable=True, rows=vals.size, values=vals, validity=valid, offsets=None)
+    codecs = check(gpu_ctx, col, max_page_size=65536, ratio=2.0)
+    assert (codecs == S.RLE).all()
+
+
+def test_boolean(gpu_ctx):
+    for kw in (dict(p_true=1.0), dict(p_true=0.0, null_density=0.2), dict(runs=100), dict(runs=2), dict(runs=30, null_density=0.3)):
+        col = gen.boolean(20_000, **kw)
+        check(gpu_ctx, col, max_page_size=8192, ratio=1.5)
+    check(gpu_ctx, gen.boolean(600, runs=50), max_page_size=600, ratio=1.2)
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_binary(gpu_ctx, large):
+    for kw in (dict(uniq=1), dict(uniq=20, zipf=1.5), dict(uniq=5000), dict(uniq=50, null_density=0.2)):
+        col = gen.binary(12_000, large=large, **kw)
+        check(gpu_ctx, col, max_page_size=4096, ratio=1.5)
+
+
+def test_unsupported_choice_is_loud(gpu_ctx):
+    # 95 % of the rows hold one (large) value -> the selector picks Freq, which has no device encoder yet
+    from strawboat_amd._native import NativeError
+    vals = np.full(8192, 100000, np.int32)
+    vals[::20] = np.arange(8192 // 20 + 1)[: vals[::20].size] + 7
+    col = dict(ptype=S.T_I32, nullable=False, rows=vals.size, values=vals, validity=None, offsets=None)
+    pages, metas = gen.oracle_write(col, ratio=2.0)
+    assert S.stat_column(S.T_I32, False, pages, metas)[0].tolist() == [S.FREQ]
+    with pytest.raises(NativeError) as e:
+        gpu_encode(gpu_ctx, col, ratio=2.0)
+    assert e.value.code == -4

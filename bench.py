@@ -9,8 +9,10 @@ Workload at N=1 (BASELINE.json configs[1], "C2"): columns of 1 M-row nullable Fl
 64 Ki-row pages, value = float(k) with k piecewise constant (run length ~ Geometric(mean 32),
 k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (default 64 =
 64 M rows, 520 MB of Arrow bytes) so that the working set exceeds the 256 MB Infinity Cache
-(SURVEY.md §8d).  Page codec = RLE, which is what the reference's adaptive selector picks for
-this data (ratio ~14 vs Dict 7.6; checked with the CPU oracle in tests/test_oracle_select.py).
+(SURVEY.md §8d).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
+page is chosen on the device by the reference's selector (it picks RLE for this data: sampled
+ratio ~14 vs Dict 7.6; the CPU oracle agrees, tests/test_oracle_golden.py).  Freq and Patas have
+no device encoder yet and are in forbidden_compressions.
 
 Multi-GPU (torchrun, one rank per GPU): every rank owns its own `--columns` columns (weak
 scaling, pages of independent columns shard with no data-path collective); the only collective
@@ -52,7 +54,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--columns", type=int, default=64, help="1 M-row columns per GPU in one batch")
-    ap.add_argument("--codec", default="rle", choices=["rle", "none", "dict"])
+    ap.add_argument("--codec", default="adaptive", choices=["adaptive", "rle", "none", "dict"],
+                    help="adaptive = default_compress_ratio 2.0, codec chosen per page on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -76,8 +79,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     ctx = sb.Context(local_rank)
     B = args.columns
-    codec = {"rle": Compression.RLE, "none": Compression.NONE, "dict": Compression.DICT}[args.codec]
-    opts = WriteOptions(max_page_size=PAGE, force_codec=codec)
+    codec = {"adaptive": -1, "rle": Compression.RLE, "none": Compression.NONE, "dict": Compression.DICT}[args.codec]
+    if codec < 0:   # the reference's adaptive mode; Freq/Patas have no device encoder yet and are forbidden
+        opts = WriteOptions(max_page_size=PAGE, default_compress_ratio=2.0,
+                            forbidden_compressions=[Compression.FREQ, Compression.PATAS])
+    else:
+        opts = WriteOptions(max_page_size=PAGE, force_codec=codec)
 
     # ---- synthetic batch, resident in HBM before the timed region
     cols = []
@@ -149,7 +156,8 @@ def main():
         # ---- roofline of the dominant kernel: algorithmic bytes / HIP-event time
         A = {"k_expand": page_bytes + U,            # A_dec = page bytes read + Arrow bytes written
              "k_enc_emit_pages": U + page_bytes,    # A_enc = Arrow bytes read + page bytes written
-             "k_enc_emit_tiles": U + page_bytes}
+             "k_enc_emit_tiles": U + page_bytes,
+             "k_enc_select": U}                     # the selector reads the Arrow buffers once
         dom = max((k for k in stats if k in A), key=lambda k: stats[k][1], default=None)
         roof = None
         if dom:
@@ -164,7 +172,10 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import sbo
-            o = sbo.make_options(max_page_size=PAGE, force_codec=codec)
+            if codec < 0:
+                o = sbo.make_options(max_page_size=PAGE, ratio=2.0, forbidden=(sbo.FREQ, sbo.PATAS))
+            else:
+                o = sbo.make_options(max_page_size=PAGE, force_codec=codec)
             tw, tr = sbo.time_roundtrip(sbo.T_F64, True, ROWS, host0[0], validity=host0[1], options=o, iters=3)
             cpu = {"value": round(2.0 * U_col / (tw + tr) / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
                    "sample": "1 column (1 M rows, 16 pages) of the same workload, encode+decode, best of 3, "

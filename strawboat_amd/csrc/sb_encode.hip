@@ -948,18 +948,75 @@ __device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t n
     const bool is_float = nk >= NK_F32;
     auto key = [&](uint64_t i) { return stat_key<W>(getv(i), nk); };
     uint32_t* s4 = sc.s_misc + 2 * WG;
-    // ---- streaming statistics
+    // ---- one streaming pass: flags, null count, typed max, Boyer-Moore vote, and (W <= 8) an LDS
+    // hash set of the canonical keys for the exact distinct count Dict needs
     const Val<W> k0 = key(0);
     uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, nulls = 0;
     Val<W> tmax = getv(0);
+    constexpr bool SMALL = W <= 8;
+    constexpr uint64_t SENT = ~0ull;
+    constexpr uint32_t KSLOTS = SEL_LDS_SLOTS / 2, KCAP = KSLOTS / 2;  // 4096 u64 slots, 2048 keys
+    unsigned long long* kset = (unsigned long long*)sc.lds_tab;
+    __shared__ uint32_t s_kcnt, s_ksent;
+    const bool want_set = SMALL && !forbidden(SB_CODEC_DICT) && N >= 3;
+    const bool want_vote = SMALL && !forbidden(SB_CODEC_FREQ);
+    if (want_set) {
+        for (uint32_t i = t; i < KSLOTS; i += WG) kset[i] = SENT;
+        if (t == 0) {
+            s_kcnt = 0;
+            s_ksent = 0;
+        }
+        __syncthreads();
+    }
+    auto k64 = [&](const Val<W>& k) {
+        uint64_t x = 0;
+        if constexpr (SMALL) __builtin_memcpy(&x, &k, W);
+        return x;
+    };
+    uint64_t vote_k = 0;
+    uint32_t vote_n = 0;
     for (uint64_t i = t; i < N; i += WG) {
         const Val<W> v = getv(i);
-        if (!bits_eq<W>(stat_key<W>(v, nk), k0)) f_neq0 = 1;
+        const Val<W> kk = stat_key<W>(v, nk);
+        if (!bits_eq<W>(kk, k0)) f_neq0 = 1;
         if (!valid(i)) nulls++;
         if (!is_float) {
             if (int_lt<W>(tmax, v, nk)) tmax = v;
             if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(v, nk) < 0) f_neg = 1;
             if (W == 4 && i > 0 && int_lt<W>(v, getv(i - 1), nk)) f_unsorted = 1;
+        }
+        if constexpr (SMALL) {
+            const uint64_t x = k64(kk);
+            if (want_vote) {
+                if (vote_n == 0) {
+                    vote_k = x;
+                    vote_n = 1;
+                } else if (vote_k == x) {
+                    vote_n++;
+                } else {
+                    vote_n--;
+                }
+            }
+            if (want_set && s_kcnt <= KCAP) {
+                if (x == SENT) {
+                    s_ksent = 1;
+                } else {
+                    uint32_t h = (uint32_t)(mix64(x) >> 9) & (KSLOTS - 1);
+                    for (;;) {
+                        unsigned long long cur = kset[h];
+                        if (cur == x) break;
+                        if (cur == SENT) {
+                            const unsigned long long old = atomicCAS(&kset[h], (unsigned long long)SENT, (unsigned long long)x);
+                            if (old == SENT) {
+                                atomicAdd(&s_kcnt, 1u);
+                                break;
+                            }
+                            if (old == x) break;
+                        }
+                        h = (h + 1) & (KSLOTS - 1);
+                    }
+                }
+            }
         }
     }
     const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
@@ -968,6 +1025,46 @@ __device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t n
     bool is_sorted = !(flags & 2);
     const bool any_neg = flags & 4;
     if (!is_float && W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(getv(0), nk) < 0) is_sorted = false;  // vs last_value = 0
+    // exact distinct count from the LDS set (valid unless it overflowed)
+    uint32_t set_unique = 0;
+    bool set_ok = false;
+    if (want_set) {
+        set_unique = s_kcnt + s_ksent;
+        set_ok = s_kcnt <= KCAP;
+    }
+    // merged Boyer-Moore vote: (key, margin); a key with >= 90 % of the rows leaves margin >= 0.8 N
+    uint64_t maj_k = 0;
+    uint32_t maj_n = 0;
+    if (want_vote) {
+        unsigned long long* vk = (unsigned long long*)sc.sample_mem;  // 256 * 8 B, free until the samples are drawn
+        uint32_t* vn = sc.s_misc;
+        vk[t] = vote_k;
+        vn[t] = vote_n;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                const unsigned long long c0 = vk[t], c1 = vk[t + stride];
+                const uint32_t n0 = vn[t], n1 = vn[t + stride];
+                if (n1) {
+                    if (n0 == 0) {
+                        vk[t] = c1;
+                        vn[t] = n1;
+                    } else if (c0 == c1) {
+                        vn[t] = n0 + n1;
+                    } else if (n1 > n0) {
+                        vk[t] = c1;
+                        vn[t] = n1 - n0;
+                    } else {
+                        vn[t] = n0 - n1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        maj_k = vk[0];
+        maj_n = vn[0];
+        __syncthreads();
+    }
     // typed maximum (only Freq for integers looks at it: max.as_i64() >= 256, freq.rs:146)
     int64_t max_i64 = 0;
     if (!is_float && !forbidden(SB_CODEC_FREQ)) {
@@ -1007,7 +1104,17 @@ __device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t n
                     r = (double)(N - 1);
                     break;
                 }
-                const uint32_t mc = majority_count(kops, N, sc.s_misc);
+                uint32_t mc;
+                if constexpr (SMALL) {
+                    mc = 0;
+                    if ((double)maj_n + 1.0 >= 0.8 * tuple_count) {  // only then can a key hold >= 90 % of the rows
+                        uint32_t mine = 0;
+                        for (uint64_t i = t; i < N; i += WG) mine += k64(key(i)) == maj_k ? 1 : 0;
+                        mc = wg_sum32(mine, s4);
+                    }
+                } else {
+                    mc = majority_count(kops, N, sc.s_misc);
+                }
                 const bool big = is_float ? true : (max_i64 >= 256);
                 if ((double)mc / tuple_count >= 0.9 && big) r = (double)(N - 1);
                 break;
@@ -1015,7 +1122,7 @@ __device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t n
             case SB_CODEC_DICT: {  // dict.rs:109-120
                 if (N < 3) break;
                 const uint32_t limit = (uint32_t)((N - 1) / 3);  // largest unique with unique*3 < N
-                const uint32_t uq = all_equal ? 1u : distinct_count(kops, N, limit, sc, nullptr);
+                const uint32_t uq = all_equal ? 1u : (set_ok ? set_unique : distinct_count(kops, N, limit, sc, nullptr));
                 if ((uint64_t)uq * 3 >= N) break;
                 uint64_t after = (uint64_t)uq * W + N * (uint64_t)(bits_needed(uq) / 8);
                 after += N * 2 / 128;

@@ -90,8 +90,8 @@ __device__ __forceinline__ int32_t codec_of(const EncodeArgs& a, const EncPage& 
     return p.codec >= 0 ? p.codec : a.codecs[page];
 }
 __device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
-    return codec == SB_CODEC_NONE || codec == SB_CODEC_RLE || codec == SB_CODEC_DICT || codec == SB_CODEC_ONEVALUE ||
-           codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING;
+    return codec == SB_CODEC_NONE || codec == SB_CODEC_LZ4 || codec == SB_CODEC_RLE || codec == SB_CODEC_DICT ||
+           codec == SB_CODEC_ONEVALUE || codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING;
 }
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -577,6 +577,166 @@ __device__ uint64_t enc_bp(GetU32 getv, uint64_t N, bool delta, uint8_t* dst, ui
     return out_pos;
 }
 
+// ------------------------------------------------------------------------------ LZ4 block encode
+// Byte-exact restatement of LZ4_compress_default (liblz4 1.9.x: greedy parse, one hash probe per
+// position, skip acceleration 1) — what lz4::block::compress_to_buffer(src, None, false, dst) runs
+// (reference call site src/compression/basic.rs:108-120).  The parse is inherently serial (every
+// probe sees the table as left by all earlier positions), so one lane walks the block; the 16 KB
+// hash table lives in LDS, and a CU runs as many blocks as its LDS holds.  Parallelism comes from
+// the number of blocks (pages x sub-blocks) in flight, not from within a block.
+__device__ __forceinline__ uint32_t lz4_hash(const uint8_t* p, bool by_u16) {
+    if (by_u16) return (ldu32(p) * 2654435761u) >> (32 - 13);
+    return (uint32_t)(((ldu64(p) << 24) * 889523592379ull) >> (64 - 12));
+}
+__device__ __forceinline__ uint32_t lz4_tab_get(const void* tab, uint32_t h, bool by_u16) {
+    return by_u16 ? (uint32_t)((const uint16_t*)tab)[h] : ((const uint32_t*)tab)[h];
+}
+__device__ __forceinline__ void lz4_tab_put(void* tab, uint32_t h, uint32_t v, bool by_u16) {
+    if (by_u16)
+        ((uint16_t*)tab)[h] = (uint16_t)v;
+    else
+        ((uint32_t*)tab)[h] = v;
+}
+__device__ __forceinline__ uint32_t lz4_count(const uint8_t* ip, const uint8_t* match, const uint8_t* limit) {
+    const uint8_t* s = ip;
+    while (ip + 8 <= limit) {
+        const uint64_t d = ldu64(ip) ^ ldu64(match);
+        if (d) return (uint32_t)(ip - s) + (uint32_t)((__ffsll((long long)d) - 1) >> 3);
+        ip += 8;
+        match += 8;
+    }
+    while (ip < limit && *ip == *match) {
+        ip++;
+        match++;
+    }
+    return (uint32_t)(ip - s);
+}
+// executed by ONE lane; `tab` = 16 KB of LDS (zeroed by the caller)
+__device__ uint32_t lz4_compress_lane(const uint8_t* src, uint32_t n, uint8_t* dst, void* tab) {
+    const bool by_u16 = n < 65536u + 11u;  // LZ4_64Klimit
+    const uint8_t* ip = src;
+    const uint8_t* anchor = src;
+    const uint8_t* iend = src + n;
+    const uint8_t* mflimitPlusOne = iend - 12 + 1;
+    const uint8_t* matchlimit = iend - 5;
+    uint8_t* op = dst;
+    if (n >= 13) {
+        lz4_tab_put(tab, lz4_hash(ip, by_u16), 0, by_u16);
+        ip++;
+        uint32_t forwardH = lz4_hash(ip, by_u16);
+        for (;;) {
+            const uint8_t* match;
+            uint8_t* token;
+            {
+                const uint8_t* forwardIp = ip;
+                int step = 1, searchMatchNb = 1 << 6;
+                bool done = false;
+                for (;;) {
+                    const uint32_t h = forwardH;
+                    const uint32_t current = (uint32_t)(forwardIp - src);
+                    const uint32_t matchIndex = lz4_tab_get(tab, h, by_u16);
+                    ip = forwardIp;
+                    forwardIp += step;
+                    step = (searchMatchNb++ >> 6);
+                    if (forwardIp > mflimitPlusOne) {
+                        done = true;
+                        break;
+                    }
+                    match = src + matchIndex;
+                    forwardH = lz4_hash(forwardIp, by_u16);
+                    lz4_tab_put(tab, h, current, by_u16);
+                    if (!by_u16 && matchIndex + 65535u < current) continue;
+                    if (ldu32(match) == ldu32(ip)) break;
+                }
+                if (done) break;
+            }
+            while (ip > anchor && match > src && ip[-1] == match[-1]) {
+                ip--;
+                match--;
+            }
+            {
+                const uint32_t litLength = (uint32_t)(ip - anchor);
+                token = op++;
+                if (litLength >= 15) {
+                    int len = (int)(litLength - 15);
+                    *token = 15 << 4;
+                    for (; len >= 255; len -= 255) *op++ = 255;
+                    *op++ = (uint8_t)len;
+                } else {
+                    *token = (uint8_t)(litLength << 4);
+                }
+                uint32_t k = 0;
+                for (; k + 8 <= litLength; k += 8) stu64(op + k, ldu64(anchor + k));
+                for (; k < litLength; k++) op[k] = anchor[k];
+                op += litLength;
+            }
+            bool end_of_chunk = false;
+            for (;;) {
+                const uint32_t off = (uint32_t)(ip - match);
+                op[0] = (uint8_t)off;
+                op[1] = (uint8_t)(off >> 8);
+                op += 2;
+                uint32_t matchCode = lz4_count(ip + 4, match + 4, matchlimit);
+                ip += matchCode + 4;
+                if (matchCode >= 15) {
+                    *token += 15;
+                    matchCode -= 15;
+                    while (matchCode >= 255) {
+                        *op++ = 255;
+                        matchCode -= 255;
+                    }
+                    *op++ = (uint8_t)matchCode;
+                } else {
+                    *token += (uint8_t)matchCode;
+                }
+                anchor = ip;
+                if (ip >= mflimitPlusOne) {
+                    end_of_chunk = true;
+                    break;
+                }
+                lz4_tab_put(tab, lz4_hash(ip - 2, by_u16), (uint32_t)(ip - 2 - src), by_u16);
+                const uint32_t h = lz4_hash(ip, by_u16);
+                const uint32_t current = (uint32_t)(ip - src);
+                const uint32_t matchIndex = lz4_tab_get(tab, h, by_u16);
+                match = src + matchIndex;
+                lz4_tab_put(tab, h, current, by_u16);
+                if ((by_u16 || matchIndex + 65535u >= current) && ldu32(match) == ldu32(ip)) {
+                    token = op++;
+                    *token = 0;
+                    continue;
+                }
+                break;
+            }
+            if (end_of_chunk) break;
+            forwardH = lz4_hash(++ip, by_u16);
+        }
+    }
+    {
+        const uint32_t lastRun = (uint32_t)(iend - anchor);
+        if (lastRun >= 15) {
+            uint32_t acc = lastRun - 15;
+            *op++ = 15 << 4;
+            for (; acc >= 255; acc -= 255) *op++ = 255;
+            *op++ = (uint8_t)acc;
+        } else {
+            *op++ = (uint8_t)(lastRun << 4);
+        }
+        for (uint32_t k = 0; k < lastRun; k++) op[k] = anchor[k];
+        op += lastRun;
+    }
+    return (uint32_t)(op - dst);
+}
+// one wave compresses one block: the table (4096 words of LDS) is cleared by all lanes, lane 0 parses
+__device__ uint32_t lz4_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* tab4096) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < 4096; i += 64) tab4096[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t size = 0;
+    if (lane == 0) size = lz4_compress_lane(src, n, dst, tab4096);
+    return (uint32_t)__shfl((int)size, 0, 64);
+}
+
 // ------------------------------------------------------------------------------ u32 blocks (nested)
 // compress_integer::<u32> of an index array without validity: hdr9 + body.  Returns bytes written.
 __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec, uint8_t* dst, uint32_t* sA,
@@ -601,6 +761,16 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
             if (threadIdx.x == 0) stu32(dst + 9, N ? idx[0] : 0);
             body = 4;
             break;
+        case SB_CODEC_LZ4: {  // Basic(Lz4) over the raw index bytes (integer/mod.rs:55-58)
+            __syncthreads();
+            uint32_t sz = 0;
+            if (threadIdx.x < 64) sz = lz4_compress_wave((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, sA);
+            __syncthreads();
+            if (threadIdx.x == 0) s_w[0] = sz;
+            __syncthreads();
+            body = s_w[0];
+            break;
+        }
         case SB_CODEC_BITPACKING:
         case SB_CODEC_DELTA_BITPACKING:
             if (N % 128 != 0) {
@@ -1700,6 +1870,84 @@ static EncPageKernel enc_page_kernel(int kind, int32_t codec) {
     return nullptr;
 }
 
+// pages whose codec is LZ4 (CommonCompression::Lz4 as the default, or chosen by the selector):
+// def levels + hdr9 + one LZ4 block (binary: offsets block + values block), one workgroup per page
+__global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
+    __shared__ uint32_t tab[4096];
+    __shared__ uint32_t s_sz;
+    const uint32_t page = blockIdx.x;
+    const EncPage p = a.pages[page];
+    if (codec_of(a, p, page) != SB_CODEC_LZ4) return;
+    const EncCol c = a.cols[p.col];
+    if (c.ptype == SB_TYPE_NULL) return;
+    uint8_t* slot = page_slot(a, c, p);
+    const uint64_t N = p.rows;
+    uint64_t pos = 0;
+    if (c.nullable) {
+        uint8_t* bits = def_header(slot, N);
+        for (uint64_t r0 = 0; r0 < N; r0 += TILE_ROWS)
+            def_bits_tile(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows, r0,
+                          (uint32_t)min((uint64_t)TILE_ROWS, N - r0));
+        pos = def_section_bytes(N);
+    }
+    uint8_t* blk = slot + pos;
+    uint8_t* stage = a.scratch + p.aux_off;
+    const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
+    auto compress = [&](const uint8_t* src, uint32_t n, uint8_t* dst) -> uint32_t {
+        __syncthreads();
+        uint32_t sz = 0;
+        if (threadIdx.x < 64) sz = lz4_compress_wave(src, n, dst, tab);
+        if (threadIdx.x == 0) s_sz = sz;
+        __syncthreads();
+        return s_sz;
+    };
+    uint64_t length;
+    if (c.ptype == SB_TYPE_BOOLEAN) {  // boolean/mod.rs:44-54
+        const uint64_t boff = c.values_bit_offset + p.row0, nbytes = (N + 7) / 8;
+        const uint8_t* src = c.values + (boff >> 3);
+        if (boff & 7) {
+            const uint64_t total_bits = c.values_bit_offset + c.rows;
+            for (uint64_t b = threadIdx.x; b < nbytes; b += WG) {
+                uint32_t w = bits32(c.values, boff + b * 8, total_bits);
+                const uint64_t nb = min((uint64_t)8, N - b * 8);
+                if (nb < 8) w &= (1u << nb) - 1;
+                stage[b] = (uint8_t)w;
+            }
+            src = stage;
+        }
+        const uint32_t sz = compress(src, (uint32_t)nbytes, blk + 9);
+        if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, sz, (uint32_t)N);
+        length = pos + 9 + sz;
+    } else if (is_bin) {  // binary/mod.rs:42-81
+        const uint32_t ow = c.width;
+        const uint8_t* offs = c.offsets + p.row0 * ow;
+        const uint64_t first = ow == 4 ? (uint64_t)ldu32(offs) : ldu64(offs);
+        const uint64_t last = ow == 4 ? (uint64_t)ldu32(offs + N * 4) : ldu64(offs + N * 8);
+        const uint64_t obytes = (N + 1) * ow, vbytes = last - first;
+        for (uint64_t i = threadIdx.x; i <= N; i += WG) {
+            if (ow == 4)
+                stu32(stage + i * 4, (uint32_t)(ldu32(offs + i * 4) - first));
+            else
+                stu64(stage + i * 8, ldu64(offs + i * 8) - first);
+        }
+        const uint32_t s1 = compress(stage, (uint32_t)obytes, blk + 9);
+        if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, s1, (uint32_t)obytes);
+        uint8_t* b2 = blk + 9 + s1;
+        const uint32_t s2 = compress(c.values + first, (uint32_t)vbytes, b2 + 9);
+        if (threadIdx.x == 0) put_hdr9(b2, SB_CODEC_LZ4, s2, (uint32_t)vbytes);
+        length = pos + 9 + s1 + 9 + s2;
+    } else {
+        const uint32_t w = c.width;
+        const uint32_t sz = compress(c.values + p.row0 * w, (uint32_t)(N * w), blk + 9);
+        if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, sz, (uint32_t)(N * w));
+        length = pos + 9 + sz;
+    }
+    if (threadIdx.x == 0) {
+        EncOut o{length, 0, slot, SB_CODEC_LZ4, 0};
+        a.outs[page] = o;
+    }
+}
+
 // pages with codec None: (page, tile) parallel plain copies
 __global__ void __launch_bounds__(WG) k_enc_emit_tiles(EncodeArgs a) {
     const uint32_t page = blockIdx.x;
@@ -1946,7 +2194,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
 
     size_t scratch_off = 0;
     uint64_t pi = 0, res_off = 0;
-    bool any_tiles = false, any_pages = false, any_compact = false;
+    bool any_tiles = false, any_pages = false, any_compact = false, any_lz4 = false;
     for (uint64_t i = 0; i < n; i++) {
         const sb_column_write& c = cols[i];
         EncCol& d = hc[i];
@@ -2004,9 +2252,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 while (M < 2 * N) M <<= 1;
                 p.aux_bytes = (M + 3 * N) * 4;
             }
+            if (codec == SB_CODEC_LZ4 || (adaptive && opts->default_compression == SB_CODEC_LZ4)) {
+                any_lz4 = true;  // staging for re-based offsets / re-packed bitmaps
+                const uint64_t st = bin ? (N + 1) * d.width + 16 : (c.physical_type == SB_TYPE_BOOLEAN ? (N + 7) / 8 + 16 : 0);
+                if (st > p.aux_bytes) p.aux_bytes = st;
+            }
             if (codec == SB_CODEC_NONE || (adaptive && opts->default_compression == SB_CODEC_NONE))
                 any_tiles = true;
-            if (codec != SB_CODEC_NONE) any_pages = true;
+            if (codec != SB_CODEC_NONE && codec != SB_CODEC_LZ4) any_pages = true;
         }
         if (bin) scratch_off += align_up(c.values_len + c.values_len / 64 + 64 * k + 64, 16);
         (void)col_slot_base;
@@ -2071,6 +2324,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (any_tiles) {
         KScope k(ctx, K_ENC_TILES);
         k_enc_emit_tiles<<<dim3((uint32_t)P, (uint32_t)max_tiles), WG, 0, s>>>(a);
+    }
+    if (any_lz4) {
+        KScope k(ctx, K_ENC_LZ4);
+        k_enc_emit_lz4<<<(uint32_t)P, WG, 0, s>>>(a);
     }
     if (any_pages) {
         // one kernel instance per (kind, codec) that can occur in the batch

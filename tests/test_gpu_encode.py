@@ -133,3 +133,33 @@ def test_roundtrip_gpu_only(gpu_ctx):
     dec = read.read_simple(gpu_ctx, read.ColumnPages(col["ptype"], False, enc.pages[:enc.length].contiguous(),
                                                      enc.metas_array()))
     assert torch.equal(dec.values, dc.values)
+
+
+@pytest.mark.parametrize("ptype", [S.T_I8, S.T_I32, S.T_I64, S.T_F64, S.T_I256])
+def test_lz4_default_compression(gpu_ctx, ptype):
+    """Basic(Lz4) pages: the device runs the same greedy parse as LZ4_compress_default, so the
+    bytes equal the oracle's (which equal liblz4's, tests/test_oracle_blocks.py)."""
+    col = gen.prim(ptype, 40_000, uniq=50, null_density=0.1, runs=4)
+    check(gpu_ctx, col, max_page_size=8192, default_compression=S.LZ4)
+    col = gen.prim(ptype, 3000, uniq=1 << 20)          # incompressible, small blocks (< 64 KiB: u16 table)
+    check(gpu_ctx, col, max_page_size=1000, default_compression=S.LZ4)
+    col = gen.prim(ptype, 70_000, uniq=3, runs=100)    # long matches, one block > 64 KiB (u32 table)
+    check(gpu_ctx, col, default_compression=S.LZ4)
+
+
+def test_lz4_boolean_and_binary(gpu_ctx):
+    check(gpu_ctx, gen.boolean(50_003, null_density=0.2, runs=7), max_page_size=8192, default_compression=S.LZ4)
+    check(gpu_ctx, gen.boolean(10_000, runs=3), max_page_size=1001, default_compression=S.LZ4)
+    for large in (False, True):
+        col = gen.binary(20_000, uniq=300, null_density=0.1, large=large, zipf=1.3)
+        check(gpu_ctx, col, max_page_size=4096, default_compression=S.LZ4)
+
+
+def test_lz4_nested_and_adaptive(gpu_ctx):
+    col = gen.prim(S.T_F64, 30_000, uniq=100, runs=5)
+    check(gpu_ctx, col, max_page_size=8192, default_compression=S.LZ4, force_codec=S.DICT)   # indices: Basic(Lz4)
+    check(gpu_ctx, col, max_page_size=8192, default_compression=S.LZ4, force_codec=S.DICT, force_index_codec=S.LZ4)
+    # adaptive with LZ4 as the fallback: incompressible pages fall back to Basic(Lz4)
+    rnd = gen.prim(S.T_I64, 20_000, uniq=1 << 40)
+    check(gpu_ctx, rnd, max_page_size=4096, default_compression=S.LZ4, ratio=2.0, forbidden=(S.FREQ, S.PATAS))
+    check(gpu_ctx, col, max_page_size=4096, default_compression=S.LZ4, ratio=2.0, forbidden=(S.FREQ, S.PATAS))

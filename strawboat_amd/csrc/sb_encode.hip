@@ -866,7 +866,7 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
                 cur = old;
             }
             if (ko.eq(cur, i)) {
-                atomicMin(&table[h], (uint32_t)i);
+                if ((uint32_t)i < cur) atomicMin(&table[h], (uint32_t)i);  // rows arrive roughly in order: rarely needed
                 break;
             }
             h = (h + 1) & mask;
@@ -2140,9 +2140,38 @@ uint64_t sb_write_bound(int32_t physical_type, int32_t is_nullable, uint64_t row
 int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts, int32_t mem) {
     if (!ctx || (!cols && n) || !opts) return SB_ERR_INVALID;
     if (n == 0) return SB_OK;
-    if (mem != SB_MEM_DEVICE) return ctx->fail(SB_ERR_NYI, "sb_write_columns: SB_MEM_HOST staging is not built yet");
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
+    // SB_MEM_HOST: the caller holds host Arrow buffers (the reference's shape); stage them over PCIe
+    std::vector<const uint8_t*> dv(n, nullptr), dval(n, nullptr), doff(n, nullptr);
+    std::vector<uint8_t*> dout(n, nullptr);
+    if (mem == SB_MEM_HOST) {
+        auto stage_in = [&](const void* host, size_t bytes, const uint8_t** out) -> bool {
+            *out = nullptr;
+            if (!host || !bytes) return true;
+            uint8_t* d = nullptr;
+            if (hipMalloc((void**)&d, bytes + 64) != hipSuccess) return false;
+            ctx->temp_dev.push_back(d);
+            *out = d;
+            return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+        };
+        for (uint64_t i = 0; i < n; i++) {
+            const sb_column_write& c = cols[i];
+            const uint32_t w = enc_type_width(c.physical_type);
+            size_t vbytes = c.physical_type == SB_TYPE_BOOLEAN ? (size_t)((c.values_bit_offset + c.rows + 7) / 8)
+                            : enc_is_binary(c.physical_type) ? (size_t)c.values_len : (size_t)(c.rows * w);
+            if (!stage_in(c.values, vbytes, &dv[i]) ||
+                !stage_in(c.validity, (size_t)((c.validity_bit_offset + c.rows + 7) / 8), &dval[i]) ||
+                !stage_in(enc_is_binary(c.physical_type) ? c.offsets : nullptr, (size_t)((c.rows + 1) * w), &doff[i]))
+                return ctx->fail(SB_ERR_EXTERNAL, "staging of host buffers failed");
+            if (c.out_capacity) {
+                if (hipMalloc((void**)&dout[i], c.out_capacity + 64) != hipSuccess)
+                    return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(out_pages) failed");
+                ctx->temp_dev.push_back(dout[i]);
+                ctx->copybacks.push_back({c.out_pages, dout[i], (size_t)c.out_capacity});
+            }
+        }
+    }
 
     // codec known on the host? (forced, or default_compress_ratio == None => Basic(default))
     int32_t host_codec = -1;
@@ -2199,10 +2228,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const sb_column_write& c = cols[i];
         EncCol& d = hc[i];
         memset(&d, 0, sizeof d);
-        d.values = (const uint8_t*)c.values;
-        d.validity = c.validity;
-        d.offsets = (const uint8_t*)c.offsets;
-        d.out = c.out_pages;
+        d.values = mem == SB_MEM_HOST ? dv[i] : (const uint8_t*)c.values;
+        d.validity = mem == SB_MEM_HOST ? dval[i] : c.validity;
+        d.offsets = mem == SB_MEM_HOST ? doff[i] : (const uint8_t*)c.offsets;
+        d.out = mem == SB_MEM_HOST ? dout[i] : c.out_pages;
         d.values_bit_offset = c.values_bit_offset;
         d.values_len = c.values_len;
         d.validity_bit_offset = c.validity_bit_offset;

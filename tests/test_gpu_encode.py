@@ -163,3 +163,43 @@ def test_lz4_nested_and_adaptive(gpu_ctx):
     rnd = gen.prim(S.T_I64, 20_000, uniq=1 << 40)
     check(gpu_ctx, rnd, max_page_size=4096, default_compression=S.LZ4, ratio=2.0, forbidden=(S.FREQ, S.PATAS))
     check(gpu_ctx, col, max_page_size=4096, default_compression=S.LZ4, ratio=2.0, forbidden=(S.FREQ, S.PATAS))
+
+
+def test_host_memory_boundary(gpu_ctx):
+    """SB_MEM_HOST: host Arrow buffers in, host page bytes out, and back (the shape the reference's
+    callers have); the library stages over PCIe itself."""
+    import ctypes as C
+    from strawboat_amd import _native as N
+    from strawboat_amd.types import WriteOptions
+    from strawboat_amd.write import options_c
+    col = gen.prim(S.T_F64, 50_000, uniq=64, null_density=0.1, runs=9)
+    want_pages, want_metas = gen.oracle_write(col, max_page_size=8192, force_codec=S.RLE)
+    lib, h = gpu_ctx._lib, gpu_ctx._h
+    oc = options_c(WriteOptions(max_page_size=8192, force_codec=S.RLE))
+    vals = np.ascontiguousarray(col["values"]).view(np.uint8)
+    npg = C.c_uint64()
+    bound = lib.sb_write_bound(col["ptype"], 1, col["rows"], 0, C.byref(oc), C.byref(npg))
+    out = np.zeros(bound, np.uint8)
+    metas = (N.PageMetaC * npg.value)()
+    cw = (N.ColumnWriteC * 1)()
+    cw[0].physical_type, cw[0].is_nullable, cw[0].rows = col["ptype"], 1, col["rows"]
+    cw[0].values, cw[0].validity = vals.ctypes.data, col["validity"].ctypes.data
+    cw[0].out_pages, cw[0].out_capacity = out.ctypes.data, out.size
+    cw[0].out_metas, cw[0].n_pages_capacity = metas, npg.value
+    gpu_ctx._check(lib.sb_write_columns(h, cw, 1, C.byref(oc), N.SB_MEM_HOST))
+    gpu_ctx.synchronize()
+    assert cw[0].out_len == want_pages.size and np.array_equal(out[:cw[0].out_len], want_pages)
+    # decode from host page bytes into host buffers
+    want = gen.oracle_read(col, want_pages, want_metas)
+    cr = (N.ColumnReadC * 1)()
+    m = np.ascontiguousarray(want_metas)
+    v_out = np.zeros(col["rows"] * 8, np.uint8)
+    b_out = np.zeros((col["rows"] + 31) // 32 * 4, np.uint8)
+    cr[0].physical_type, cr[0].is_nullable = col["ptype"], 1
+    cr[0].pages, cr[0].pages_len = out.ctypes.data, int(cw[0].out_len)
+    cr[0].metas, cr[0].n_pages = m.ctypes.data_as(C.POINTER(N.PageMetaC)), m.shape[0]
+    cr[0].values, cr[0].values_capacity = v_out.ctypes.data, v_out.size
+    cr[0].validity, cr[0].validity_capacity = b_out.ctypes.data, b_out.size
+    gpu_ctx._check(lib.sb_read_columns(h, cr, 1, N.SB_MEM_HOST))
+    gpu_ctx.synchronize()
+    assert np.array_equal(v_out, want["values"]) and np.array_equal(b_out[:(col["rows"] + 7) // 8], want["validity"])

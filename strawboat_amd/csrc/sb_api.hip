@@ -150,6 +150,7 @@ void sb_ctx_destroy(sb_ctx* ctx) {
     if (ctx->tables.p) (void)hipFree(ctx->tables.p);
     if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
     if (ctx->staging.p) (void)hipFree(ctx->staging.p);
+    if (ctx->zlit.p) (void)hipFree(ctx->zlit.p);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -379,12 +380,14 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         if (in_off > c.pages_len) return ctx->fail(SB_ERR_IO, "sum of PageMeta.length exceeds pages_len");
     }
     if (!ensure(ctx, ctx->scratch, scratch_off + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(scratch) failed");
+    if (!ensure(ctx, ctx->zlit, (size_t)1024 * (128 * 1024 + 64))) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zlit) failed");
 
     uint8_t* tb = ctx->tables.p;
     hipError_t e = hipMemcpyAsync(tb, slot->host, upload_bytes, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return check_hip(ctx, e, "table upload");
 
     DecodeArgs a;
+    a.zlit = ctx->zlit.p;
     a.cols = (const ColDesc*)(tb + o_cols);
     a.tasks = (const PageTask*)(tb + o_tasks);
     a.descs = (PageDesc*)(tb + o_descs);

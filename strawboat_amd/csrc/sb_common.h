@@ -102,6 +102,7 @@ struct DecodeArgs {
     InflateJob* jobs_a;  // capacity 2 * n_pages
     InflateJob* jobs_b;  // capacity n_pages
     uint32_t* job_counts;  // [0] = queue A, [1] = queue B
+    uint8_t* zlit;         // Zstd literal buffers, one per inflate wave
     uint32_t n_pages;
     uint32_t n_cols;
     uint32_t n_tiles;

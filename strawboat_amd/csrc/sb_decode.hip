@@ -19,6 +19,7 @@
 // Bandwidth-bound integer work: no MFMA; coalesced 16-byte stores, unaligned 16-byte loads,
 // LDS for the per-tile scans, wave64 shuffles for the scan carries.
 #include "sb_host.h"
+#include "sb_zstd.h"
 
 namespace sb {
 
@@ -276,14 +277,25 @@ __device__ void lz4_inflate_wave(const InflateJob& j, Status* st) {
     if (op != out_len && lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, 107);
 }
 
-__global__ void __launch_bounds__(WG) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st) {
-    const uint32_t job = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
-    if (job >= *count) return;
-    const InflateJob j = jobs[job];
-    if (j.codec == SB_CODEC_LZ4) {
-        lz4_inflate_wave(j, st);
-    } else if ((threadIdx.x & 63) == 0) {
-        raise(st, SB_ERR_NYI, j.page, 110);  // Zstd / Snappy blocks: host path for now
+// one wave per workgroup; the grid is a fixed pool of waves that loops over the job queue, so the
+// per-wave Zstd literal buffers (zlit) are a fixed pool too
+constexpr uint32_t INFLATE_POOL = 1024;
+constexpr uint32_t ZLIT_STRIDE = 128 * 1024 + 64;
+__global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st,
+                                                uint8_t* zlit) {
+    __shared__ ZWork wk;
+    const uint32_t njobs = *count;
+    for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+        const InflateJob j = jobs[job];
+        if (j.codec == SB_CODEC_LZ4) {
+            lz4_inflate_wave(j, st);
+        } else if (j.codec == SB_CODEC_ZSTD) {
+            zstd_inflate_wave(j.src, j.csize, j.dst, j.out_len, &wk, zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE);
+            if (threadIdx.x == 0 && wk.err) raise(st, SB_ERR_EXTERNAL, j.page, 120 + (uint32_t)wk.err);
+            __syncthreads();
+        } else if (threadIdx.x == 0) {
+            raise(st, SB_ERR_NYI, j.page, 110);  // Snappy blocks: not on the device yet
+        }
     }
 }
 
@@ -1068,7 +1080,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     {
         KScope k(ctx, K_INFLATE_A);
-        k_inflate<<<(2 * a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+        k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
     }
     {
         KScope k(ctx, K_PLAN);
@@ -1080,7 +1092,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
-        k_inflate<<<(a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
+        k_inflate<<<min(a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
     }
     if (a.n_tiles && any_prim) {
         KScope k(ctx, K_EXPAND);
@@ -1096,7 +1108,7 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-    k_inflate<<<(2 * a.n_pages + 3) / 4, WG, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+    k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
 }

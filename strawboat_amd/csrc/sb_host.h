@@ -48,6 +48,7 @@ struct sb_ctx {
     sb::DevBuf tables;   // ColDesc / PageTask / PageDesc / TileTask / jobs / counters
     sb::DevBuf scratch;  // per-page aux + inflate areas, encode slots
     sb::DevBuf staging;  // device staging for SB_MEM_HOST callers
+    sb::DevBuf zlit;     // Zstd literal buffers (fixed pool of inflate waves)
     sb::Status* d_status = nullptr;
     sb::Status* h_status = nullptr;  // pinned
 

@@ -1,0 +1,612 @@
+// strawboat-hip: Zstandard frame decoder on the device (RFC 8878), codec id 2.
+//
+// Replaces zstd::bulk::decompress_to_buffer (libzstd) at the reference call site
+// src/compression/basic.rs:93-97.  One wave per frame.  The entropy stages are serial by
+// construction (FSE / Huffman bit streams are consumed backwards, every symbol depends on the
+// state left by the previous one), so lane 0 walks them with the tables in LDS; the four Huffman
+// literal streams decode on four lanes; sequence *execution* (literal and match copies into the
+// page's output) is spread over all 64 lanes in batches of 64 decoded sequences.  Blocks of a
+// frame and frames of different pages are independent of each other only at frame granularity:
+// parallelism comes from the number of pages in flight.
+#pragma once
+#include "sb_common.h"
+
+namespace sb {
+
+struct ZFse {
+    uint8_t symbol, nbits;
+    uint16_t base;
+};
+struct ZSeq {
+    uint32_t ll, ml, off;
+};
+struct ZWork {  // per-wave LDS workspace (~12 KB)
+    ZFse ll[512], of[256], ml[512];
+    uint8_t hsym[2048], hlen[2048];
+    uint8_t wts[256];
+    int16_t norm[64];
+    uint16_t next[64];
+    ZSeq seq[64];
+    uint32_t ll_log, of_log, ml_log, have_ll, have_of, have_ml, have_huf, huf_bits;
+    uint32_t rep[3];
+    int32_t err;
+    uint32_t nbatch;
+};
+
+#define ZFAIL(code)         \
+    do {                    \
+        wk->err = (code);   \
+        return 0;           \
+    } while (0)
+
+// bits [bitpos-nb, bitpos) of the stream as a number whose MSB is bit bitpos-1; bits below 0 read as 0
+__device__ __forceinline__ uint32_t z_peek(const uint8_t* p, int64_t bitpos, int nb) {
+    if (nb <= 0) return 0;
+    int64_t lo = bitpos - nb;
+    if (lo >= 0) {
+        const int64_t byte0 = lo >> 3;
+        const int sh = (int)(lo & 7);
+        const int need = (sh + nb + 7) >> 3;
+        uint64_t w = 0;
+        for (int k = 0; k < need; k++) w |= (uint64_t)p[byte0 + k] << (8 * k);
+        return (uint32_t)((w >> sh) & ((1ull << nb) - 1));
+    }
+    if (bitpos <= 0) return 0;
+    const int avail = (int)bitpos;
+    const int need = (avail + 7) >> 3;
+    uint64_t w = 0;
+    for (int k = 0; k < need; k++) w |= (uint64_t)p[k] << (8 * k);
+    return (uint32_t)((w & ((1ull << avail) - 1)) << (int)(-lo));
+}
+
+__device__ inline bool z_fse_build(ZFse* t, ZWork* wk, const int16_t* norm, int nsym, int log) {
+    const int size = 1 << log;
+    int high = size - 1;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == -1) {
+            t[high--].symbol = (uint8_t)s;
+            wk->next[s] = 1;
+        } else {
+            wk->next[s] = (uint16_t)norm[s];
+        }
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            t[pos].symbol = (uint8_t)s;
+            do {
+                pos = (pos + step) & mask;
+            } while (pos > high);
+        }
+    if (pos != 0) return false;
+    for (int i = 0; i < size; i++) {
+        const uint8_t s = t[i].symbol;
+        const uint16_t ns = wk->next[s]++;
+        const int nb = log - (31 - __clz((int)ns));
+        t[i].nbits = (uint8_t)nb;
+        t[i].base = (uint16_t)(((uint32_t)ns << nb) - (uint32_t)size);
+    }
+    return true;
+}
+
+// FSE table description (forward bit stream); returns bytes consumed or 0 on error
+__device__ inline uint32_t z_fse_header(const uint8_t* src, uint32_t n, int max_sym, int max_log, int16_t* norm,
+                                        int* nsym_out, int* log_out) {
+    uint64_t bitpos = 0;
+    auto peek = [&](int nb) -> uint32_t {
+        uint64_t v = 0;
+        const uint64_t byte = bitpos >> 3;
+        for (int i = 0; i < 6 && byte + i < n; i++) v |= (uint64_t)src[byte + i] << (8 * i);
+        v >>= (bitpos & 7);
+        return (uint32_t)(v & ((1ull << nb) - 1));
+    };
+    const int log = (int)peek(4) + 5;
+    bitpos += 4;
+    if (log > max_log) return 0;
+    int remaining = (1 << log) + 1, threshold = 1 << log, nbits = log + 1, sym = 0;
+    bool prev0 = false;
+    for (int i = 0; i <= max_sym; i++) norm[i] = 0;
+    while (remaining > 1 && sym <= max_sym) {
+        if (prev0) {
+            for (;;) {
+                const uint32_t r = peek(2);
+                bitpos += 2;
+                sym += (int)r;
+                if (r != 3) break;
+            }
+            prev0 = false;
+            if (sym > max_sym) return 0;
+            continue;
+        }
+        const int mx = (2 * threshold - 1) - remaining;
+        int count;
+        const uint32_t v = peek(nbits);
+        if ((int)(v & (uint32_t)(threshold - 1)) < mx) {
+            count = (int)(v & (uint32_t)(threshold - 1));
+            bitpos += nbits - 1;
+        } else {
+            count = (int)(v & (uint32_t)(2 * threshold - 1));
+            if (count >= threshold) count -= mx;
+            bitpos += nbits;
+        }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        norm[sym++] = (int16_t)count;
+        prev0 = count == 0;
+        while (remaining < threshold) {
+            nbits--;
+            threshold >>= 1;
+        }
+    }
+    if (remaining != 1) return 0;
+    const uint32_t used = (uint32_t)((bitpos + 7) >> 3);
+    if (used > n) return 0;
+    *nsym_out = sym;
+    *log_out = log;
+    return used;
+}
+
+__device__ inline bool z_huf_build(ZWork* wk, int nw) {
+    uint32_t total = 0;
+    for (int i = 0; i < nw; i++) {
+        if (wk->wts[i] > 11) return false;
+        total += wk->wts[i] ? (1u << (wk->wts[i] - 1)) : 0;
+    }
+    if (total == 0) return false;
+    const int max_bits = 32 - __clz((int)total);
+    const uint32_t left = (1u << max_bits) - total;
+    if (left == 0 || (left & (left - 1)) || max_bits > 11) return false;
+    wk->wts[nw] = (uint8_t)(32 - __clz((int)left));
+    const int n = nw + 1;
+    wk->huf_bits = (uint32_t)max_bits;
+    uint32_t code = 0;
+    for (int wt = 1; wt <= max_bits; wt++)
+        for (int s = 0; s < n; s++) {
+            if (wk->wts[s] != wt) continue;
+            const uint32_t span = 1u << (wt - 1);
+            for (uint32_t k = 0; k < span; k++) {
+                wk->hsym[code + k] = (uint8_t)s;
+                wk->hlen[code + k] = (uint8_t)(max_bits + 1 - wt);
+            }
+            code += span;
+        }
+    return true;
+}
+
+// Huffman tree description; returns bytes consumed or 0
+__device__ inline uint32_t z_huf_read(ZWork* wk, const uint8_t* src, uint32_t n) {
+    if (n < 1) return 0;
+    const uint8_t hb = src[0];
+    int nw;
+    uint32_t used;
+    if (hb >= 128) {
+        nw = hb - 127;
+        const uint32_t bytes = (uint32_t)(nw + 1) / 2;
+        if (n < 1 + bytes) return 0;
+        for (int i = 0; i < nw; i++) {
+            const uint8_t b = src[1 + i / 2];
+            wk->wts[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+        used = 1 + bytes;
+    } else {
+        const uint32_t clen = hb;
+        if (n < 1 + clen || clen < 2) return 0;
+        int nsym, log;
+        const uint32_t hsz = z_fse_header(src + 1, clen, 12, 6, wk->norm, &nsym, &log);
+        if (!hsz || hsz >= clen) return 0;
+        ZFse* t = wk->ll;  // scratch: the literal-length table is rebuilt later
+        if (!z_fse_build(t, wk, wk->norm, nsym, log)) return 0;
+        const uint8_t* bs = src + 1 + hsz;
+        const uint32_t bn = clen - hsz;
+        if (bs[bn - 1] == 0) return 0;
+        int64_t bitpos = (int64_t)(bn - 1) * 8 + (31 - __clz((int)bs[bn - 1]));
+        uint32_t s1 = z_peek(bs, bitpos, log);
+        bitpos -= log;
+        uint32_t s2 = z_peek(bs, bitpos, log);
+        bitpos -= log;
+        nw = 0;
+        for (;;) {  // two interleaved FSE states; when the stream runs dry the other state is flushed
+            if (nw >= 254) return 0;
+            wk->wts[nw++] = t[s1].symbol;
+            if (bitpos < t[s1].nbits) {
+                wk->wts[nw++] = t[s2].symbol;
+                break;
+            }
+            {
+                const uint32_t nb = t[s1].nbits;
+                s1 = t[s1].base + z_peek(bs, bitpos, (int)nb);
+                bitpos -= nb;
+            }
+            wk->wts[nw++] = t[s2].symbol;
+            if (bitpos < t[s2].nbits) {
+                wk->wts[nw++] = t[s1].symbol;
+                break;
+            }
+            {
+                const uint32_t nb = t[s2].nbits;
+                s2 = t[s2].base + z_peek(bs, bitpos, (int)nb);
+                bitpos -= nb;
+            }
+        }
+        used = 1 + clen;
+    }
+    if (!z_huf_build(wk, nw)) return 0;
+    wk->have_huf = 1;
+    return used;
+}
+
+// one Huffman stream (executed by one lane); returns false on error
+__device__ inline bool z_huf_stream(const ZWork* wk, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out) {
+    if (n == 0 || src[n - 1] == 0) return false;
+    int64_t bitpos = (int64_t)(n - 1) * 8 + (31 - __clz((int)src[n - 1]));
+    const int mb = (int)wk->huf_bits;
+    for (uint32_t i = 0; i < out; i++) {
+        const uint32_t idx = z_peek(src, bitpos, mb);
+        dst[i] = wk->hsym[idx];
+        bitpos -= wk->hlen[idx];
+    }
+    return bitpos == 0;
+}
+
+__constant__ int16_t Z_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                         2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ int16_t Z_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                         1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ int16_t Z_OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                         1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+__constant__ uint32_t Z_LL_BASE[36] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,   10,  11,  12,  13,   14,   15,   16,   18,
+                                       20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+__constant__ uint8_t Z_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                      1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ uint32_t Z_ML_BASE[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                       21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
+                                       43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__constant__ uint8_t Z_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                      0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+// sets one of the three sequence tables according to its compression mode; returns bytes consumed
+// from `src` (0 is a valid answer), or 0xFFFFFFFF on error
+__device__ inline uint32_t z_seq_table(ZWork* wk, int mode, ZFse* t, uint32_t* log_out, uint32_t* have,
+                                       const int16_t* def, int def_n, int def_log, int max_sym, int max_log,
+                                       const uint8_t* src, uint32_t n) {
+    if (mode == 0) {
+        for (int i = 0; i < def_n; i++) wk->norm[i] = def[i];
+        if (!z_fse_build(t, wk, wk->norm, def_n, def_log)) return 0xFFFFFFFFu;
+        *log_out = (uint32_t)def_log;
+        *have = 1;
+        return 0;
+    }
+    if (mode == 1) {
+        if (n < 1 || src[0] > max_sym) return 0xFFFFFFFFu;
+        t[0].symbol = src[0];
+        t[0].nbits = 0;
+        t[0].base = 0;
+        *log_out = 0;
+        *have = 1;
+        return 1;
+    }
+    if (mode == 2) {
+        int nsym, log;
+        const uint32_t used = z_fse_header(src, n, max_sym, max_log, wk->norm, &nsym, &log);
+        if (!used) return 0xFFFFFFFFu;
+        if (!z_fse_build(t, wk, wk->norm, nsym, log)) return 0xFFFFFFFFu;
+        *log_out = (uint32_t)log;
+        *have = 1;
+        return used;
+    }
+    return *have ? 0 : 0xFFFFFFFFu;
+}
+
+// Decodes one frame.  All 64 lanes call it with identical arguments; returns bytes produced
+// (wk->err != 0 on failure).  `lit` = a 128 KiB + 32 literal buffer owned by this wave.
+__device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out_len, ZWork* wk,
+                                      uint8_t* lit) {
+    const int lane = threadIdx.x & 63;
+    auto wsync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    if (lane == 0) {
+        wk->err = 0;
+        wk->have_ll = wk->have_of = wk->have_ml = wk->have_huf = 0;
+        wk->rep[0] = 1;
+        wk->rep[1] = 4;
+        wk->rep[2] = 8;
+    }
+    wsync();
+    uint32_t ip = 0, op = 0;
+#define ZERR(c)                        \
+    do {                               \
+        if (lane == 0) wk->err = (c);  \
+        wsync();                       \
+        return 0;                      \
+    } while (0)
+    // frame header (all lanes, uniform)
+    for (;;) {  // skippable frames
+        if (n - ip < 4) ZERR(1);
+        const uint32_t magic = ldu32(src + ip);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            if (n - ip < 8) ZERR(2);
+            const uint32_t sz = ldu32(src + ip + 4);
+            if (n - ip - 8 < sz) ZERR(3);
+            ip += 8 + sz;
+            continue;
+        }
+        if (magic != 0xFD2FB528u) ZERR(4);
+        ip += 4;
+        break;
+    }
+    if (ip >= n) ZERR(5);
+    const uint8_t fhd = src[ip++];
+    const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+    if (fhd & 0x08) ZERR(6);
+    if (!single) ip += 1;
+    const int did_bytes = did == 0 ? 0 : did == 1 ? 1 : did == 2 ? 2 : 4;
+    if (did) {
+        uint32_t id = 0;
+        for (int i = 0; i < did_bytes; i++) id |= (uint32_t)src[ip + i] << (8 * i);
+        if (id) ZERR(7);  // dictionaries are never used by the reference
+        ip += did_bytes;
+    }
+    const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
+    uint64_t fcs = 0;
+    if (fcs_bytes) {
+        if (n - ip < (uint32_t)fcs_bytes) ZERR(8);
+        for (int i = 0; i < fcs_bytes; i++) fcs |= (uint64_t)src[ip + i] << (8 * i);
+        if (fcs_bytes == 2) fcs += 256;
+        ip += fcs_bytes;
+    }
+    for (;;) {  // blocks
+        if (n - ip < 3) ZERR(9);
+        const uint32_t bh = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
+        ip += 3;
+        const bool last = bh & 1;
+        const int btype = (bh >> 1) & 3;
+        const uint32_t bsize = bh >> 3;
+        if (btype == 0) {
+            if (n - ip < bsize || out_len - op < bsize) ZERR(10);
+            for (uint32_t i = lane; i < bsize; i += 64) dst[op + i] = src[ip + i];
+            ip += bsize;
+            op += bsize;
+        } else if (btype == 1) {
+            if (n - ip < 1 || out_len - op < bsize) ZERR(11);
+            const uint8_t v = src[ip++];
+            for (uint32_t i = lane; i < bsize; i += 64) dst[op + i] = v;
+            op += bsize;
+        } else if (btype == 2) {
+            if (bsize > 128 * 1024 || n - ip < bsize) ZERR(12);
+            const uint8_t* bs = src + ip;
+            uint32_t bp = 0;
+            // ---- literals section
+            if (bsize < 1) ZERR(13);
+            const uint8_t b0 = bs[bp++];
+            const int ltype = b0 & 3, sf = (b0 >> 2) & 3;
+            uint32_t regen = 0, csize = 0;
+            int streams = 1;
+            const uint8_t* litp = lit;
+            if (ltype == 0 || ltype == 1) {
+                if (sf == 0 || sf == 2) {
+                    regen = b0 >> 3;
+                } else if (sf == 1) {
+                    regen = (b0 >> 4) | ((uint32_t)bs[bp] << 4);
+                    bp += 1;
+                } else {
+                    regen = (b0 >> 4) | ((uint32_t)bs[bp] << 4) | ((uint32_t)bs[bp + 1] << 12);
+                    bp += 2;
+                }
+                if (ltype == 0) {
+                    if (bsize - bp < regen) ZERR(14);
+                    litp = bs + bp;  // raw literals are used in place
+                    bp += regen;
+                } else {
+                    if (regen > 128 * 1024) ZERR(15);
+                    const uint8_t v = bs[bp++];
+                    for (uint32_t i = lane; i < regen; i += 64) lit[i] = v;
+                    wsync();
+                }
+            } else {
+                if (sf == 0 || sf == 1) {
+                    const uint32_t v = (b0 >> 4) | ((uint32_t)bs[bp] << 4) | ((uint32_t)bs[bp + 1] << 12);
+                    bp += 2;
+                    regen = v & 0x3FF;
+                    csize = v >> 10;
+                    streams = sf == 0 ? 1 : 4;
+                } else if (sf == 2) {
+                    const uint32_t v = (b0 >> 4) | ((uint32_t)bs[bp] << 4) | ((uint32_t)bs[bp + 1] << 12) |
+                                       ((uint32_t)bs[bp + 2] << 20);
+                    bp += 3;
+                    regen = v & 0x3FFF;
+                    csize = v >> 14;
+                    streams = 4;
+                } else {
+                    const uint64_t v = (b0 >> 4) | ((uint64_t)bs[bp] << 4) | ((uint64_t)bs[bp + 1] << 12) |
+                                       ((uint64_t)bs[bp + 2] << 20) | ((uint64_t)bs[bp + 3] << 28);
+                    bp += 4;
+                    regen = (uint32_t)(v & 0x3FFFF);
+                    csize = (uint32_t)(v >> 18);
+                    streams = 4;
+                }
+                if (bsize - bp < csize || regen > 128 * 1024) ZERR(16);
+                const uint8_t* ls = bs + bp;
+                uint32_t lleft = csize;
+                bp += csize;
+                if (ltype == 2) {
+                    if (lane == 0) {
+                        const uint32_t used = z_huf_read(wk, ls, lleft);
+                        if (!used) wk->err = 17;
+                        wk->nbatch = used;
+                    }
+                    wsync();
+                    if (wk->err) return 0;
+                    ls += wk->nbatch;
+                    lleft -= wk->nbatch;
+                } else if (!wk->have_huf) {
+                    ZERR(18);
+                }
+                if (streams == 1) {
+                    if (lane == 0 && !z_huf_stream(wk, ls, lleft, lit, regen)) wk->err = 19;
+                } else {
+                    if (lleft < 6) ZERR(20);
+                    const uint32_t s1 = ls[0] | ((uint32_t)ls[1] << 8), s2 = ls[2] | ((uint32_t)ls[3] << 8),
+                                   s3 = ls[4] | ((uint32_t)ls[5] << 8);
+                    if (6 + s1 + s2 + s3 > lleft) ZERR(21);
+                    const uint32_t s4 = lleft - 6 - s1 - s2 - s3;
+                    const uint32_t per = (regen + 3) / 4;
+                    if (per * 3 > regen) ZERR(22);
+                    const uint8_t* q = ls + 6;
+                    if (lane < 4) {  // the four streams decode on four lanes
+                        const uint32_t so[4] = {0, s1, s1 + s2, s1 + s2 + s3};
+                        const uint32_t sn[4] = {s1, s2, s3, s4};
+                        const uint32_t outn = lane < 3 ? per : regen - 3 * per;
+                        if (!z_huf_stream(wk, q + so[lane], sn[lane], lit + (uint32_t)lane * per, outn)) wk->err = 23;
+                    }
+                }
+                wsync();
+                if (wk->err) return 0;
+            }
+            // ---- sequences section
+            if (bsize - bp < 1) ZERR(24);
+            uint32_t nseq;
+            {
+                const uint8_t s0 = bs[bp++];
+                if (s0 < 128) {
+                    nseq = s0;
+                } else if (s0 < 255) {
+                    nseq = ((uint32_t)(s0 - 128) << 8) + bs[bp];
+                    bp += 1;
+                } else {
+                    nseq = (uint32_t)bs[bp] + ((uint32_t)bs[bp + 1] << 8) + 0x7F00;
+                    bp += 2;
+                }
+            }
+            uint32_t lit_pos = 0;
+            if (nseq > 0) {
+                if (lane == 0) {
+                    const uint8_t modes = bs[bp];
+                    uint32_t q = bp + 1;
+                    uint32_t u = (modes & 3) ? 0xFFFFFFFFu : 0;
+                    if (u == 0) u = z_seq_table(wk, (modes >> 6) & 3, wk->ll, &wk->ll_log, &wk->have_ll, Z_LL_DEFAULT, 36, 6, 35, 9, bs + q, bsize - q);
+                    if (u != 0xFFFFFFFFu) {
+                        q += u;
+                        u = z_seq_table(wk, (modes >> 4) & 3, wk->of, &wk->of_log, &wk->have_of, Z_OF_DEFAULT, 29, 5, 31, 8, bs + q, bsize - q);
+                    }
+                    if (u != 0xFFFFFFFFu) {
+                        q += u;
+                        u = z_seq_table(wk, (modes >> 2) & 3, wk->ml, &wk->ml_log, &wk->have_ml, Z_ML_DEFAULT, 53, 6, 52, 9, bs + q, bsize - q);
+                    }
+                    if (u == 0xFFFFFFFFu)
+                        wk->err = 25;
+                    else
+                        wk->nbatch = q + u;
+                }
+                wsync();
+                if (wk->err) return 0;
+                bp = wk->nbatch;
+                const uint8_t* sb_ = bs + bp;
+                const uint32_t sn_ = bsize - bp;
+                if (sn_ == 0 || sb_[sn_ - 1] == 0) ZERR(26);
+                // lane 0 keeps the bit reader and the three FSE states; batches of 64 sequences
+                int64_t bitpos = (int64_t)(sn_ - 1) * 8 + (31 - __clz((int)sb_[sn_ - 1]));
+                uint32_t sl = 0, so = 0, sm = 0;
+                if (lane == 0) {
+                    sl = z_peek(sb_, bitpos, (int)wk->ll_log);
+                    bitpos -= wk->ll_log;
+                    so = z_peek(sb_, bitpos, (int)wk->of_log);
+                    bitpos -= wk->of_log;
+                    sm = z_peek(sb_, bitpos, (int)wk->ml_log);
+                    bitpos -= wk->ml_log;
+                }
+                for (uint32_t done = 0; done < nseq; done += 64) {
+                    const uint32_t nb = min(64u, nseq - done);
+                    if (lane == 0) {
+                        for (uint32_t k = 0; k < nb; k++) {
+                            const uint8_t ofc = wk->of[so].symbol, mlc = wk->ml[sm].symbol, llc = wk->ll[sl].symbol;
+                            if (ofc > 31 || mlc > 52 || llc > 35) {
+                                wk->err = 27;
+                                break;
+                            }
+                            const uint64_t ofv = ((uint64_t)1 << ofc) + z_peek(sb_, bitpos, ofc);
+                            bitpos -= ofc;
+                            const uint32_t mlen = Z_ML_BASE[mlc] + z_peek(sb_, bitpos, Z_ML_BITS[mlc]);
+                            bitpos -= Z_ML_BITS[mlc];
+                            const uint32_t llen = Z_LL_BASE[llc] + z_peek(sb_, bitpos, Z_LL_BITS[llc]);
+                            bitpos -= Z_LL_BITS[llc];
+                            uint32_t offset;
+                            if (ofv > 3) {
+                                offset = (uint32_t)(ofv - 3);
+                                wk->rep[2] = wk->rep[1];
+                                wk->rep[1] = wk->rep[0];
+                                wk->rep[0] = offset;
+                            } else {
+                                uint32_t idx = (uint32_t)ofv - 1;
+                                if (llen == 0) idx++;
+                                if (idx == 0) {
+                                    offset = wk->rep[0];
+                                } else {
+                                    offset = idx < 3 ? wk->rep[idx] : wk->rep[0] - 1;
+                                    if (offset == 0) {
+                                        wk->err = 28;
+                                        break;
+                                    }
+                                    if (idx > 1) wk->rep[2] = wk->rep[1];
+                                    wk->rep[1] = wk->rep[0];
+                                    wk->rep[0] = offset;
+                                }
+                            }
+                            if (done + k + 1 < nseq) {
+                                const uint32_t n1 = wk->ll[sl].nbits, n2 = wk->ml[sm].nbits, n3 = wk->of[so].nbits;
+                                sl = wk->ll[sl].base + z_peek(sb_, bitpos, (int)n1);
+                                bitpos -= n1;
+                                sm = wk->ml[sm].base + z_peek(sb_, bitpos, (int)n2);
+                                bitpos -= n2;
+                                so = wk->of[so].base + z_peek(sb_, bitpos, (int)n3);
+                                bitpos -= n3;
+                            }
+                            wk->seq[k].ll = llen;
+                            wk->seq[k].ml = mlen;
+                            wk->seq[k].off = offset;
+                        }
+                        if (done + nb == nseq && !wk->err && bitpos != 0) wk->err = 29;
+                    }
+                    wsync();
+                    if (wk->err) return 0;
+                    // execute the batch: copies spread over the lanes, sequences in order
+                    for (uint32_t k = 0; k < nb; k++) {
+                        const uint32_t llen = wk->seq[k].ll, mlen = wk->seq[k].ml, off = wk->seq[k].off;
+                        if (lit_pos + llen > regen || out_len - op < llen + mlen || off > op + llen) ZERR(30);
+                        for (uint32_t i = lane; i < llen; i += 64) dst[op + i] = litp[lit_pos + i];
+                        op += llen;
+                        lit_pos += llen;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_s_waitcnt(0);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const uint8_t* hist = dst + op - off;
+                        for (uint32_t i = lane; i < mlen; i += 64) dst[op + i] = hist[off >= mlen ? i : i % off];
+                        op += mlen;
+                    }
+                    wsync();
+                }
+            }
+            const uint32_t rest = regen - lit_pos;
+            if (out_len - op < rest) ZERR(31);
+            for (uint32_t i = lane; i < rest; i += 64) dst[op + i] = litp[lit_pos + i];
+            op += rest;
+            ip += bsize;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            ZERR(32);
+        }
+        if (last) break;
+    }
+    if (checksum) ip += 4;
+    if (fcs_bytes && fcs != op) ZERR(33);
+    if (op != out_len) ZERR(34);
+#undef ZERR
+    return op;
+}
+
+}  // namespace sb

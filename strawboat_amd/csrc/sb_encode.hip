@@ -90,7 +90,7 @@ __device__ __forceinline__ int32_t codec_of(const EncodeArgs& a, const EncPage& 
     return p.codec >= 0 ? p.codec : a.codecs[page];
 }
 __device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
-    return codec == SB_CODEC_NONE || codec == SB_CODEC_LZ4 || codec == SB_CODEC_RLE || codec == SB_CODEC_DICT ||
+    return codec == SB_CODEC_NONE || codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD || codec == SB_CODEC_RLE || codec == SB_CODEC_DICT ||
            codec == SB_CODEC_ONEVALUE || codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING;
 }
 
@@ -737,6 +737,8 @@ __device__ uint32_t lz4_compress_wave(const uint8_t* src, uint32_t n, uint8_t* d
     return (uint32_t)__shfl((int)size, 0, 64);
 }
 
+__device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);
+
 // ------------------------------------------------------------------------------ u32 blocks (nested)
 // compress_integer::<u32> of an index array without validity: hdr9 + body.  Returns bytes written.
 __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec, uint8_t* dst, uint32_t* sA,
@@ -760,6 +762,10 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
         case SB_CODEC_ONEVALUE:
             if (threadIdx.x == 0) stu32(dst + 9, N ? idx[0] : 0);
             body = 4;
+            break;
+        case SB_CODEC_ZSTD:
+            __syncthreads();
+            body = zstd_store_frame_wg((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, s_w);
             break;
         case SB_CODEC_LZ4: {  // Basic(Lz4) over the raw index bytes (integer/mod.rs:55-58)
             __syncthreads();
@@ -1870,6 +1876,43 @@ static EncPageKernel enc_page_kernel(int kind, int32_t codec) {
     return nullptr;
 }
 
+// Zstd frame made of raw / RLE blocks (valid RFC 8878, accepted by libzstd and hence by the
+// reference's decompress_zstd, basic.rs:93-97; no entropy stage yet, so no size reduction
+// unless a 128 KiB block is constant).  Byte-identical to oracle/sbo_zstd.cpp zstd_compress.
+// Executed by the whole workgroup; returns the frame size.
+__device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4) {
+    if (threadIdx.x == 0) {
+        stu32(dst, 0xFD2FB528u);
+        dst[4] = (uint8_t)((3u << 6) | (1u << 5));  // single segment, 8-byte frame content size
+        stu64(dst + 5, (uint64_t)n);
+    }
+    uint32_t op = 13, pos = 0;
+    do {
+        const uint32_t len = min(128u * 1024u, n - pos);
+        const bool last = pos + len == n;
+        uint32_t diff = 0;
+        for (uint32_t i = threadIdx.x; i < len; i += WG) diff |= src[pos + i] != src[pos];
+        const bool rle = len > 0 && wg_or32(diff, s4) == 0;
+        if (threadIdx.x == 0) {
+            const uint32_t hdr = (last ? 1u : 0u) | ((rle ? 1u : 0u) << 1) | (len << 3);
+            dst[op] = (uint8_t)hdr;
+            dst[op + 1] = (uint8_t)(hdr >> 8);
+            dst[op + 2] = (uint8_t)(hdr >> 16);
+            if (rle) dst[op + 3] = src[pos];
+        }
+        op += 3;
+        if (rle) {
+            op += 1;
+        } else {
+            wg_copy(dst + op, src + pos, len);
+            op += len;
+        }
+        pos += len;
+    } while (pos < n);
+    __syncthreads();
+    return op;
+}
+
 // pages whose codec is LZ4 (CommonCompression::Lz4 as the default, or chosen by the selector):
 // def levels + hdr9 + one LZ4 block (binary: offsets block + values block), one workgroup per page
 __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
@@ -1877,7 +1920,8 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     __shared__ uint32_t s_sz;
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
-    if (codec_of(a, p, page) != SB_CODEC_LZ4) return;
+    const int32_t bc = codec_of(a, p, page);
+    if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD) return;
     const EncCol c = a.cols[p.col];
     if (c.ptype == SB_TYPE_NULL) return;
     uint8_t* slot = page_slot(a, c, p);
@@ -1895,6 +1939,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
     auto compress = [&](const uint8_t* src, uint32_t n, uint8_t* dst) -> uint32_t {
         __syncthreads();
+        if (bc == SB_CODEC_ZSTD) return zstd_store_frame_wg(src, n, dst, tab);
         uint32_t sz = 0;
         if (threadIdx.x < 64) sz = lz4_compress_wave(src, n, dst, tab);
         if (threadIdx.x == 0) s_sz = sz;
@@ -1916,7 +1961,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
             src = stage;
         }
         const uint32_t sz = compress(src, (uint32_t)nbytes, blk + 9);
-        if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, sz, (uint32_t)N);
+        if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)bc, sz, (uint32_t)N);
         length = pos + 9 + sz;
     } else if (is_bin) {  // binary/mod.rs:42-81
         const uint32_t ow = c.width;
@@ -1931,19 +1976,19 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
                 stu64(stage + i * 8, ldu64(offs + i * 8) - first);
         }
         const uint32_t s1 = compress(stage, (uint32_t)obytes, blk + 9);
-        if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, s1, (uint32_t)obytes);
+        if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)bc, s1, (uint32_t)obytes);
         uint8_t* b2 = blk + 9 + s1;
         const uint32_t s2 = compress(c.values + first, (uint32_t)vbytes, b2 + 9);
-        if (threadIdx.x == 0) put_hdr9(b2, SB_CODEC_LZ4, s2, (uint32_t)vbytes);
+        if (threadIdx.x == 0) put_hdr9(b2, (uint32_t)bc, s2, (uint32_t)vbytes);
         length = pos + 9 + s1 + 9 + s2;
     } else {
         const uint32_t w = c.width;
         const uint32_t sz = compress(c.values + p.row0 * w, (uint32_t)(N * w), blk + 9);
-        if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, sz, (uint32_t)(N * w));
+        if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)bc, sz, (uint32_t)(N * w));
         length = pos + 9 + sz;
     }
     if (threadIdx.x == 0) {
-        EncOut o{length, 0, slot, SB_CODEC_LZ4, 0};
+        EncOut o{length, 0, slot, (uint32_t)bc, 0};
         a.outs[page] = o;
     }
 }
@@ -2281,14 +2326,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 while (M < 2 * N) M <<= 1;
                 p.aux_bytes = (M + 3 * N) * 4;
             }
-            if (codec == SB_CODEC_LZ4 || (adaptive && opts->default_compression == SB_CODEC_LZ4)) {
+            if (codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD ||
+                (adaptive && (opts->default_compression == SB_CODEC_LZ4 || opts->default_compression == SB_CODEC_ZSTD))) {
                 any_lz4 = true;  // staging for re-based offsets / re-packed bitmaps
                 const uint64_t st = bin ? (N + 1) * d.width + 16 : (c.physical_type == SB_TYPE_BOOLEAN ? (N + 7) / 8 + 16 : 0);
                 if (st > p.aux_bytes) p.aux_bytes = st;
             }
             if (codec == SB_CODEC_NONE || (adaptive && opts->default_compression == SB_CODEC_NONE))
                 any_tiles = true;
-            if (codec != SB_CODEC_NONE && codec != SB_CODEC_LZ4) any_pages = true;
+            if (codec != SB_CODEC_NONE && codec != SB_CODEC_LZ4 && codec != SB_CODEC_ZSTD) any_pages = true;
         }
         if (bin) scratch_off += align_up(c.values_len + c.values_len / 64 + 64 * k + 64, 16);
         (void)col_slot_base;

@@ -116,31 +116,41 @@ namespace sb {
 
 // unaligned little-endian loads: page bytes sit at arbitrary byte offsets (9-byte headers,
 // def-level sections); gfx950 global loads handle unaligned addresses in hardware.
+// All page bytes and Arrow buffers live in HBM: casting to the global address space makes the
+// compiler emit global_load/global_store instead of flat_* (pointers read from descriptor tables
+// are otherwise "generic", and flat accesses tie up the LDS counter as well).
+typedef __attribute__((address_space(1))) const uint8_t* gcptr;
+typedef __attribute__((address_space(1))) uint8_t* gptr;
+__device__ __forceinline__ uint8_t ldu8(const uint8_t* p) { return *(gcptr)p; }
 __device__ __forceinline__ uint16_t ldu16(const uint8_t* p) {
     uint16_t v;
-    __builtin_memcpy(&v, p, 2);
+    __builtin_memcpy(&v, (gcptr)p, 2);
     return v;
 }
 __device__ __forceinline__ uint32_t ldu32(const uint8_t* p) {
     uint32_t v;
-    __builtin_memcpy(&v, p, 4);
+    __builtin_memcpy(&v, (gcptr)p, 4);
     return v;
 }
 __device__ __forceinline__ uint64_t ldu64(const uint8_t* p) {
     uint64_t v;
-    __builtin_memcpy(&v, p, 8);
+    __builtin_memcpy(&v, (gcptr)p, 8);
     return v;
 }
-__device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
-__device__ __forceinline__ void stu64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy((gptr)p, &v, 4); }
+__device__ __forceinline__ void stu64(uint8_t* p, uint64_t v) { __builtin_memcpy((gptr)p, &v, 8); }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(1))) U16B {
     u32x4 v;
 };
-__device__ __forceinline__ u32x4 ldu128(const uint8_t* p) { return ((const U16B*)p)->v; }
-__device__ __forceinline__ void stu128(uint8_t* p, u32x4 v) { ((U16B*)p)->v = v; }
+__device__ __forceinline__ u32x4 ldu128(const uint8_t* p) {
+    u32x4 v;
+    __builtin_memcpy(&v, (gcptr)p, 16);
+    return v;
+}
+__device__ __forceinline__ void stu128(uint8_t* p, u32x4 v) { __builtin_memcpy((gptr)p, &v, 16); }
 
 // value of W bytes as a register bundle
 template <int W>
@@ -172,12 +182,12 @@ struct Val<32> {
 template <int W>
 __device__ __forceinline__ Val<W> ld_val(const uint8_t* p) {  // unaligned
     Val<W> v;
-    __builtin_memcpy(&v, p, W);
+    __builtin_memcpy(&v, (gcptr)p, W);
     return v;
 }
 template <int W>
 __device__ __forceinline__ void st_val(uint8_t* p, Val<W> v) {  // p aligned to min(W,16)
-    __builtin_memcpy(p, &v, W);
+    __builtin_memcpy((gptr)p, &v, W);
 }
 
 __device__ __forceinline__ void raise(Status* st, int32_t code, uint32_t page, uint32_t where) {

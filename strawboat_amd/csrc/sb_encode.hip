@@ -98,7 +98,7 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t COMPACT_CHUNK = 64 * 1024;
 
 // ------------------------------------------------------------------------------ small helpers
-__device__ __forceinline__ bool bit_at(const uint8_t* p, uint64_t i) { return (p[i >> 3] >> (i & 7)) & 1; }
+__device__ __forceinline__ bool bit_at(const uint8_t* p, uint64_t i) { return (ldu8(p + (i >> 3)) >> (i & 7)) & 1; }
 
 struct ValidView {
     const uint8_t* bits;  // NULL = all valid
@@ -115,7 +115,7 @@ __device__ __forceinline__ uint32_t bits32(const uint8_t* p, uint64_t pos, uint6
     if (b0 + 8 <= nbytes) {
         v = ldu64(p + b0);
     } else {
-        for (uint32_t k = 0; k < 8 && b0 + k < nbytes; k++) v |= (uint64_t)p[b0 + k] << (8 * k);
+        for (uint32_t k = 0; k < 8 && b0 + k < nbytes; k++) v |= (uint64_t)ldu8(p + b0 + k) << (8 * k);
     }
     return (uint32_t)(v >> sh);
 }
@@ -337,7 +337,7 @@ __device__ __forceinline__ uint64_t group_mask(const ValidView& vv, uint64_t vto
         const uint32_t sh = (uint32_t)(p & 7);
         if (byte + 9 <= nbytes) {
             const uint64_t lo = ldu64(vv.bits + byte);
-            m = sh ? (lo >> sh) | ((uint64_t)vv.bits[byte + 8] << (64 - sh)) : lo;
+            m = sh ? (lo >> sh) | ((uint64_t)ldu8(vv.bits + byte + 8) << (64 - sh)) : lo;
         } else {
             m = (uint64_t)bits32(vv.bits, p, vtotal) | ((uint64_t)bits32(vv.bits, p + 32, vtotal) << 32);
         }
@@ -1114,9 +1114,10 @@ __device__ uint32_t majority_count(Ops ops, uint64_t N, uint32_t* s_a /* 2*WG + 
 }
 
 // choose_compressor for primitives (integer/mod.rs:231-308, double/mod.rs:231-307)
-template <int W, class GetVal, class Valid>
-__device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t nk, const SelectOpts& o,
+template <int W, class GetVal>
+__device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, uint32_t nk, const SelectOpts& o,
                                 const SelScratch& sc) {
+    auto valid = [&](uint64_t i) { return vv.get(i); };
     const int t = threadIdx.x;
     auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
     if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
@@ -1151,15 +1152,52 @@ __device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t n
     };
     uint64_t vote_k = 0;
     uint32_t vote_n = 0;
-    for (uint64_t i = t; i < N; i += WG) {
-        const Val<W> v = getv(i);
+    // The page is walked in chunks of CH rows.  The chunk's validity bits are staged in LDS first
+    // (the only place that touches the bitmap's byte/bit offsets), so the row loop is branch-free:
+    // U independent value loads per thread are issued back to back, then processed.
+    constexpr int U = W <= 8 ? 8 : 2;
+    constexpr uint32_t CH = 8192;
+    __shared__ uint32_t s_vb[CH / 32];
+    for (uint64_t cb = 0; cb < N; cb += CH) {
+     const uint32_t cn = (uint32_t)min((uint64_t)CH, N - cb);
+     __syncthreads();
+     if (t < (int)(CH / 32)) {
+         const uint32_t bit0 = (uint32_t)t * 32;
+         uint32_t wv = 0;
+         if (bit0 < cn) {
+             wv = vv.bits ? bits32(vv.bits, vv.off + cb + bit0, vv.off + N) : 0xFFFFFFFFu;
+             if (cn - bit0 < 32) wv &= (1u << (cn - bit0)) - 1;
+         }
+         s_vb[t] = wv;
+     }
+     __syncthreads();
+     for (uint64_t ib = cb + t; ib < cb + cn; ib += (uint64_t)WG * U) {
+      Val<W> vbuf[U], pbuf[U];
+      bool okb[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+          const uint64_t i = ib + (uint64_t)u * WG;
+          const uint64_t ic = i < N ? i : N - 1;
+          vbuf[u] = getv(ic);
+          if (!is_float && W == 4) pbuf[u] = getv(ic ? ic - 1 : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+          const uint32_t r = (uint32_t)(ib - cb) + (uint32_t)u * WG;
+          okb[u] = r < cn ? (s_vb[r >> 5] >> (r & 31)) & 1 : false;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint64_t i = ib + (uint64_t)u * WG;
+        if (i >= N) break;
+        const Val<W> v = vbuf[u];
         const Val<W> kk = stat_key<W>(v, nk);
         if (!bits_eq<W>(kk, k0)) f_neq0 = 1;
-        if (!valid(i)) nulls++;
+        if (!okb[u]) nulls++;
         if (!is_float) {
             if (int_lt<W>(tmax, v, nk)) tmax = v;
             if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(v, nk) < 0) f_neg = 1;
-            if (W == 4 && i > 0 && int_lt<W>(v, getv(i - 1), nk)) f_unsorted = 1;
+            if (W == 4 && i > 0 && int_lt<W>(v, pbuf[u], nk)) f_unsorted = 1;
         }
         if constexpr (SMALL) {
             const uint64_t x = k64(kk);
@@ -1177,7 +1215,7 @@ __device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t n
                 if (x == SENT) {
                     s_ksent = 1;
                 } else {
-                    uint32_t h = (uint32_t)(mix64(x) >> 9) & (KSLOTS - 1);
+                    uint32_t h = (((uint32_t)x ^ (uint32_t)(x >> 32) * 0x85EBCA6Bu) * 0x9E3779B1u >> 15) & (KSLOTS - 1);
                     for (;;) {
                         unsigned long long cur = kset[h];
                         if (cur == x) break;
@@ -1194,6 +1232,8 @@ __device__ uint32_t choose_prim(GetVal getv, Valid valid, uint64_t N, uint32_t n
                 }
             }
         }
+      }
+     }
     }
     const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
     const uint32_t null_count = wg_sum32(nulls, s4);
@@ -1559,7 +1599,7 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
             SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
             const uint32_t* ip = idx;
             ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = ip[i]; return v; },
-                                         [](uint64_t) { return true; }, N, NK_UNSIGNED, so, sc);
+                                         ValidView{nullptr, 0}, N, NK_UNSIGNED, so, sc);
             __syncthreads();
         }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
@@ -1655,7 +1695,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
             const uint32_t* ip = idx;
             ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = ip[i]; return v; },
-                                         [](uint64_t) { return true; }, N, NK_UNSIGNED, so, sc);
+                                         ValidView{nullptr, 0}, N, NK_UNSIGNED, so, sc);
             __syncthreads();
         }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
@@ -1740,8 +1780,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
         codec = choose_bin<int64_t>(bk, N, c.values_len, so, sc);
     } else {
         const uint8_t* vals = c.values + p.row0 * KIND;
-        codec = choose_prim<KIND>([=](uint64_t i) { return ld_val<KIND>(vals + i * KIND); },
-                                  [=](uint64_t i) { return vv.get(i); }, N, c.nk, so, sc);
+        codec = choose_prim<KIND>([=](uint64_t i) { return ld_val<KIND>(vals + i * KIND); }, vv, N, c.nk, so, sc);
     }
     if (threadIdx.x == 0) {
         a.codecs[page] = (int32_t)codec;

@@ -168,6 +168,17 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_kernel_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": A[dom]}
         kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / v[0], 4)} for k, v in stats.items()}
+        # HBM traffic of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate passes of this same command; summary committed under profiles/)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if roof and pmc["config"] == {"workload": "C2", "columns_per_gpu": B, "codec": args.codec}:
+                cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0] == dom]
+                if cand:
+                    roof["traffic"] = max(cand)   # several template instances share a name: the one that did the work
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC, per launch, gfx950 FETCH_SIZE x2 correction)"
+        except (OSError, KeyError, ValueError):
+            pass
 
         cpu = None
         if not args.no_cpu_baseline:

@@ -237,3 +237,99 @@ def time_roundtrip(ptype, nullable, rows, values=None, validity=None, offsets=No
     if L.sbo_time_roundtrip(C.byref(c), C.byref(o), iters, _ptr(out2), err, 512) != 0:
         raise OracleError(err.value.decode())
     return float(out2[0]), float(out2[1])
+
+
+# ---------------------------------------------------------------- nested (Dremel) level sections
+K_PRIMITIVE, K_LIST, K_LARGE_LIST, K_STRUCT = 0, 1, 2, 3
+
+
+class _NestedLevel(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("is_optional", C.c_int32), ("validity", C.c_void_p),
+                ("validity_off", C.c_uint64), ("offsets", C.c_void_p), ("length", C.c_uint64)]
+
+
+def _nested_lib():
+    L = lib()
+    if not getattr(L, "_nested_ready", False):
+        L.sbo_nested_write.restype = C.c_void_p
+        L.sbo_nested_write.argtypes = [C.POINTER(_NestedLevel), C.c_int32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_size_t]
+        L.sbo_nested_written_len.restype = C.c_uint64
+        L.sbo_nested_written_len.argtypes = [C.c_void_p]
+        L.sbo_nested_written_data.restype = C.c_void_p
+        L.sbo_nested_written_data.argtypes = [C.c_void_p]
+        L.sbo_nested_written_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.sbo_nested_written_free.argtypes = [C.c_void_p]
+        L.sbo_nested_read.restype = C.c_void_p
+        L.sbo_nested_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t]
+        for nm in ("sbo_nested_read_consumed", "sbo_nested_read_nleaf_validity"):
+            getattr(L, nm).restype = C.c_uint64
+            getattr(L, nm).argtypes = [C.c_void_p]
+        for nm in ("sbo_nested_read_length", "sbo_nested_read_noffsets", "sbo_nested_read_nvalidity"):
+            getattr(L, nm).restype = C.c_uint64
+            getattr(L, nm).argtypes = [C.c_void_p, C.c_int32]
+        for nm in ("sbo_nested_read_offsets", "sbo_nested_read_validity"):
+            getattr(L, nm).restype = C.c_void_p
+            getattr(L, nm).argtypes = [C.c_void_p, C.c_int32]
+        L.sbo_nested_read_leaf_validity.restype = C.c_void_p
+        L.sbo_nested_read_leaf_validity.argtypes = [C.c_void_p]
+        L.sbo_nested_read_free.argtypes = [C.c_void_p]
+        L._nested_ready = True
+    return L
+
+
+def nested_levels_array(levels, keep):
+    """levels: list of dicts(kind, is_optional, validity (packed bits or None), offsets (np or None), length)."""
+    arr = (_NestedLevel * len(levels))()
+    for k, lv in enumerate(levels):
+        v = _bytes_view(lv.get("validity"))
+        o = _bytes_view(lv.get("offsets"))
+        keep.extend([v, o])
+        arr[k].kind, arr[k].is_optional = lv["kind"], int(bool(lv["is_optional"]))
+        arr[k].validity, arr[k].validity_off = _ptr(v), lv.get("validity_off", 0)
+        arr[k].offsets, arr[k].length = _ptr(o), lv["length"]
+    return arr
+
+
+def nested_write_levels(levels, r0, length):
+    """write_nested_validity for top-level rows [r0, r0+length): (bytes, num_values, leaf_start, leaf_count)."""
+    L = _nested_lib()
+    keep = []
+    arr = nested_levels_array(levels, keep)
+    err = C.create_string_buffer(512)
+    h = L.sbo_nested_write(arr, len(levels), r0, length, err, 512)
+    if not h:
+        raise OracleError(err.value.decode())
+    try:
+        n = L.sbo_nested_written_len(h)
+        data = np.ctypeslib.as_array(C.cast(L.sbo_nested_written_data(h), C.POINTER(C.c_uint8)), (n,)).copy()
+        info = np.zeros(3, np.uint64)
+        L.sbo_nested_written_info(h, _ptr(info))
+    finally:
+        L.sbo_nested_written_free(h)
+    return data, int(info[0]), int(info[1]), int(info[2])
+
+
+def nested_read_levels(page, num_values, kinds, nullable):
+    """read_validity_nested: dict(consumed, lengths, offsets[k], validity[k], leaf_validity)."""
+    L = _nested_lib()
+    page = np.ascontiguousarray(page, dtype=np.uint8)
+    kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+    nullable = np.ascontiguousarray(nullable, dtype=np.int32)
+    err = C.create_string_buffer(512)
+    h = L.sbo_nested_read(_ptr(page), page.size, num_values, _ptr(kinds), _ptr(nullable), kinds.size, err, 512)
+    if not h:
+        raise OracleError(err.value.decode())
+    try:
+        def grab(ptr, n, ctype, dt):
+            if n == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (n,)).copy()
+        D = kinds.size
+        out = dict(consumed=int(L.sbo_nested_read_consumed(h)),
+                   lengths=[int(L.sbo_nested_read_length(h, k)) for k in range(D)],
+                   offsets=[grab(L.sbo_nested_read_offsets(h, k), L.sbo_nested_read_noffsets(h, k), C.c_int64, np.int64) for k in range(D)],
+                   validity=[grab(L.sbo_nested_read_validity(h, k), L.sbo_nested_read_nvalidity(h, k), C.c_uint8, np.uint8) for k in range(D)],
+                   leaf_validity=grab(L.sbo_nested_read_leaf_validity(h), L.sbo_nested_read_nleaf_validity(h), C.c_uint8, np.uint8))
+    finally:
+        L.sbo_nested_read_free(h)
+    return out

@@ -131,6 +131,10 @@ typedef struct sb_column_read {
     /* results (HOST, valid after sb_ctx_synchronize) */
     uint64_t rows;           /* sum of num_values */
     uint64_t values_len;     /* bytes produced in `values` */
+    /* optional (HOST, n_pages entries): byte offset of every page's data inside `pages`.  NULL =
+     * the pages are back to back.  Used for the leaf blocks of nested pages, which sit behind
+     * their level sections (sb_nested_read_levels reports the offsets). */
+    const uint64_t* page_offsets;
 } sb_column_read;
 
 /* Enqueue the decode of `n` columns.  Binary columns whose value bytes are not known in
@@ -166,6 +170,14 @@ typedef struct sb_column_write {
     /* results (HOST, valid after sb_ctx_synchronize) */
     uint64_t n_pages;
     uint64_t out_len;
+    /* optional explicit paging (nested leaves): rows of every page instead of max_page_size, and
+     * a head (the page's level section, produced by sb_nested_write_levels) that is placed in
+     * front of every page's block.  page_rows / page_head_bytes: HOST arrays of n_pages_in
+     * entries; page_heads: DEVICE, the heads back to back. */
+    const uint64_t* page_rows;
+    const uint64_t* page_head_bytes;
+    const uint8_t* page_heads;
+    uint64_t n_pages_in;
 } sb_column_write;
 
 /* upper bound of the encoded size of a column, and its page count (A.4 page arithmetic) */
@@ -173,6 +185,65 @@ uint64_t sb_write_bound(int32_t physical_type, int32_t is_nullable, uint64_t row
                         const sb_write_options* opts, uint64_t* n_pages);
 int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts,
                          int32_t mem);
+
+/* ------------------------------------------------------------------ nested level sections
+ * A nested page is `u32 page_rows | u32 rep_len | u32 def_len | rep | def | leaf BLOCK`
+ * (src/write/serialize.rs:135-198).  The level sections are produced / consumed here; the leaf
+ * BLOCK goes through sb_write_columns / sb_read_columns with explicit paging (page_rows +
+ * page_heads on write, page_offsets on read), so every codec of the flat path applies.
+ *
+ * sb_nested_level describes one node on the path root -> leaf (arrow2 `Nested`, to_nested in
+ * src/write/serialize.rs:135): kind 0 primitive leaf, 1 list (i32 offsets), 2 large list (i64
+ * offsets), 3 struct.  All pointers are DEVICE memory. */
+#define SB_NESTED_PRIMITIVE 0
+#define SB_NESTED_LIST 1
+#define SB_NESTED_LARGE_LIST 2
+#define SB_NESTED_STRUCT 3
+#define SB_NESTED_MAX_DEPTH 8
+typedef struct sb_nested_level {
+    const uint8_t* validity;      /* LSB-first bitmap or NULL (all valid) */
+    const void* offsets;          /* lists: length + 1 entries */
+    uint64_t validity_bit_offset;
+    uint64_t length;              /* elements at this level (levels[0].length == rows) */
+    int32_t kind;
+    int32_t is_optional;
+} sb_nested_level;
+typedef struct sb_nested_page {
+    uint64_t level_bytes;  /* 12 + rep_len + def_len */
+    uint64_t num_values;   /* PageMeta.num_values of a nested page = level entries (write/common.rs:84-92) */
+    uint64_t leaf_start;   /* slice of the leaf array this page carries (slice_parquet_array) */
+    uint64_t leaf_count;
+} sb_nested_page;
+/* replaces write_nested_validity (src/write/serialize.rs:217-232) + the page cut of
+ * write/common.rs:79-107 for one nested leaf column.  Writes every page's level section back to
+ * back into out_levels (DEVICE) and fills pages[] (HOST).  Synchronises the context. */
+uint64_t sb_nested_levels_bound(const sb_nested_level* levels, uint32_t n_levels, uint64_t rows,
+                                uint64_t max_page_size);
+int32_t sb_nested_write_levels(sb_ctx* ctx, const sb_nested_level* levels, uint32_t n_levels, uint64_t rows,
+                               uint64_t max_page_size, uint8_t* out_levels, uint64_t out_capacity,
+                               sb_nested_page* pages, uint64_t n_pages_capacity, uint64_t* n_pages_out);
+
+/* replaces read_validity_nested (src/read/read_basic.rs:65-173) over all pages of one nested leaf
+ * column.  Per level the caller passes DEVICE outputs: `offsets` (lists: column-level i64 offsets,
+ * elements + 1 entries) and `validity` (nullable list/struct levels: LSB-first bitmap; 4-byte
+ * aligned, capacity a multiple of 4 bytes); `length` returns the elements decoded at that level.
+ * leaf_validity (DEVICE, same alignment rule) receives the leaf's validity when the leaf is
+ * nullable.  page_leaf_counts / page_block_offsets (HOST, n_pages entries) return the number of
+ * leaf slots of every page and the byte offset of its leaf BLOCK inside `pages`: feed them to
+ * sb_read_columns as metas[].num_values / page_offsets.  Synchronises the context. */
+typedef struct sb_nested_level_out {
+    int64_t* offsets;
+    uint8_t* validity;
+    uint64_t offsets_capacity;   /* entries */
+    uint64_t validity_capacity;  /* bytes */
+    uint64_t length;             /* result */
+    int32_t kind;
+    int32_t is_nullable;
+} sb_nested_level_out;
+int32_t sb_nested_read_levels(sb_ctx* ctx, const uint8_t* pages, uint64_t pages_len, const sb_page_meta* metas,
+                              uint64_t n_pages, sb_nested_level_out* levels, uint32_t n_levels,
+                              uint8_t* leaf_validity, uint64_t leaf_validity_capacity,
+                              uint64_t* page_leaf_counts, uint64_t* page_block_offsets);
 
 /* ------------------------------------------------------------------ measurement
  * Optional per-kernel timing with HIP events recorded on the context's stream around every

@@ -16,7 +16,8 @@ SB_MEM_DEVICE, SB_MEM_HOST = 0, 1
 # every symbol include/strawboat_hip.h declares
 EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
            "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns",
-           "sb_ctx_profile", "sb_ctx_profile_read")
+           "sb_ctx_profile", "sb_ctx_profile_read", "sb_nested_levels_bound", "sb_nested_write_levels",
+           "sb_nested_read_levels")
 
 
 class PageMetaC(C.Structure):
@@ -35,7 +36,7 @@ class ColumnReadC(C.Structure):
                 ("pages_len", C.c_uint64), ("metas", C.POINTER(PageMetaC)), ("n_pages", C.c_uint64),
                 ("values", C.c_void_p), ("values_capacity", C.c_uint64), ("validity", C.c_void_p),
                 ("validity_capacity", C.c_uint64), ("offsets", C.c_void_p), ("offsets_capacity", C.c_uint64),
-                ("rows", C.c_uint64), ("values_len", C.c_uint64)]
+                ("rows", C.c_uint64), ("values_len", C.c_uint64), ("page_offsets", C.c_void_p)]
 
 
 class ColumnWriteC(C.Structure):
@@ -43,7 +44,25 @@ class ColumnWriteC(C.Structure):
                 ("values", C.c_void_p), ("values_bit_offset", C.c_uint64), ("values_len", C.c_uint64),
                 ("validity", C.c_void_p), ("validity_bit_offset", C.c_uint64), ("offsets", C.c_void_p),
                 ("out_pages", C.c_void_p), ("out_capacity", C.c_uint64), ("out_metas", C.POINTER(PageMetaC)),
-                ("n_pages_capacity", C.c_uint64), ("n_pages", C.c_uint64), ("out_len", C.c_uint64)]
+                ("n_pages_capacity", C.c_uint64), ("n_pages", C.c_uint64), ("out_len", C.c_uint64),
+                ("page_rows", C.c_void_p), ("page_head_bytes", C.c_void_p), ("page_heads", C.c_void_p),
+                ("n_pages_in", C.c_uint64)]
+
+
+class NestedLevelC(C.Structure):
+    _fields_ = [("validity", C.c_void_p), ("offsets", C.c_void_p), ("validity_bit_offset", C.c_uint64),
+                ("length", C.c_uint64), ("kind", C.c_int32), ("is_optional", C.c_int32)]
+
+
+class NestedPageC(C.Structure):
+    _fields_ = [("level_bytes", C.c_uint64), ("num_values", C.c_uint64), ("leaf_start", C.c_uint64),
+                ("leaf_count", C.c_uint64)]
+
+
+class NestedLevelOutC(C.Structure):
+    _fields_ = [("offsets", C.c_void_p), ("validity", C.c_void_p), ("offsets_capacity", C.c_uint64),
+                ("validity_capacity", C.c_uint64), ("length", C.c_uint64), ("kind", C.c_int32),
+                ("is_nullable", C.c_int32)]
 
 
 class KernelStatC(C.Structure):
@@ -94,5 +113,15 @@ def load():
     L.sb_ctx_profile.argtypes = [C.c_void_p, C.c_int32]
     L.sb_ctx_profile_read.restype = C.c_uint32
     L.sb_ctx_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStatC), C.c_uint32]
+    L.sb_nested_levels_bound.restype = C.c_uint64
+    L.sb_nested_levels_bound.argtypes = [C.POINTER(NestedLevelC), C.c_uint32, C.c_uint64, C.c_uint64]
+    L.sb_nested_write_levels.restype = C.c_int32
+    L.sb_nested_write_levels.argtypes = [C.c_void_p, C.POINTER(NestedLevelC), C.c_uint32, C.c_uint64, C.c_uint64,
+                                         C.c_void_p, C.c_uint64, C.POINTER(NestedPageC), C.c_uint64,
+                                         C.POINTER(C.c_uint64)]
+    L.sb_nested_read_levels.restype = C.c_int32
+    L.sb_nested_read_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PageMetaC), C.c_uint64,
+                                        C.POINTER(NestedLevelOutC), C.c_uint32, C.c_void_p, C.c_uint64,
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L

@@ -363,8 +363,9 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             PageTask& t = ht[page_i];
             const uint64_t N = c.metas[p].num_values, L = c.metas[p].length;
             const uint64_t ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
-            t.in_off = in_off;
+            t.in_off = c.page_offsets ? c.page_offsets[p] : in_off;
             t.length = L;
+            if (c.page_offsets && t.in_off + L > c.pages_len) return ctx->fail(SB_ERR_IO, "page_offsets + length exceeds pages_len");
             t.num_values = N;
             t.out_row = out_row;
             t.col = (uint32_t)i;

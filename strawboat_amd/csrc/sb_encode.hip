@@ -32,6 +32,7 @@ struct EncCol {
     const uint8_t* values;
     const uint8_t* validity;
     const uint8_t* offsets;
+    const uint8_t* heads;  // optional per-page heads (nested level sections), back to back
     uint8_t* out;
     uint64_t values_bit_offset;
     uint64_t values_len;
@@ -60,6 +61,8 @@ struct EncPage {
     int32_t codec;        // codec decided by the host (-1: decided on the device)
     int32_t icodec;       // nested codec for Dict indices
     uint32_t direct;
+    uint64_t head_off;    // offset of the page's head (level section) in EncCol.heads
+    uint64_t head_bytes;  // bytes reserved in front of the page's block
 };
 
 struct EncOut {
@@ -1529,7 +1532,7 @@ struct PageCtx {
 };
 
 __device__ __forceinline__ uint8_t* page_slot(const EncodeArgs& a, const EncCol& c, const EncPage& p) {
-    if (p.direct) return c.out + p.direct_off;
+    if (p.direct) return c.out + p.direct_off + p.head_bytes;
     uint64_t off = p.slot_off;
     if (c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY) {
         // value-dependent share of the slot space: bytes of this column's values before the page
@@ -2129,12 +2132,13 @@ __global__ void k_enc_layout(EncodeArgs a, const uint64_t* res_off) {
         const uint32_t pg = c.first_page + k;
         EncOut o = a.outs[pg];
         if (o.length == 0 && c.ptype != SB_TYPE_NULL) bad = true;
-        o.out_off = off;
+        const uint64_t head = a.pages[pg].head_bytes;
+        o.out_off = off + head;  // the block goes behind the page's head
         a.outs[pg] = o;
-        res[k] = o.length;
+        res[k] = head + o.length;
         res[c.n_pages + k] = a.pages[pg].rows;
         if (a.pages[pg].direct && a.pages[pg].direct_off != off) bad = true;
-        off += o.length;
+        off += head + o.length;
     }
     res[2 * c.n_pages] = off;
     if (off > c.out_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 600);
@@ -2144,12 +2148,14 @@ __global__ void k_enc_layout(EncodeArgs a, const uint64_t* res_off) {
 __global__ void __launch_bounds__(WG) k_enc_compact(EncodeArgs a) {
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
-    if (p.direct) return;
     const EncOut o = a.outs[page];
-    const uint64_t b0 = (uint64_t)blockIdx.y * COMPACT_CHUNK;
-    if (b0 >= o.length) return;
     const EncCol c = a.cols[p.col];
     if (o.out_off + o.length > c.out_cap) return;
+    if (blockIdx.y == 0 && p.head_bytes && c.heads)  // the page's head (nested level section)
+        wg_copy(c.out + o.out_off - p.head_bytes, c.heads + p.head_off, p.head_bytes);
+    if (p.direct) return;
+    const uint64_t b0 = (uint64_t)blockIdx.y * COMPACT_CHUNK;
+    if (b0 >= o.length) return;
     const uint64_t n = min((uint64_t)COMPACT_CHUNK, o.length - b0);
     wg_copy(c.out + o.out_off + b0, o.slot + b0, n);
 }
@@ -2274,11 +2280,21 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (c.physical_type != SB_TYPE_NULL && !c.values) return ctx->fail(SB_ERR_INVALID, "values is null");
         if (enc_is_binary(c.physical_type) && !c.offsets) return ctx->fail(SB_ERR_INVALID, "offsets is null");
         const uint64_t ps = page_size_of(c.rows, opts);
-        const uint64_t np = (c.rows + ps - 1) / ps;
+        const uint64_t np = c.page_rows ? c.n_pages_in : (c.rows + ps - 1) / ps;
+        if (c.page_rows) {
+            uint64_t sum = 0;
+            for (uint64_t q = 0; q < np; q++) sum += c.page_rows[q];
+            if (sum != c.rows) return ctx->fail(SB_ERR_INVALID, "page_rows do not add up to rows");
+        }
         if (np > c.n_pages_capacity || !c.out_metas) return ctx->fail(SB_ERR_INVALID, "out_metas too small");
         if (!c.out_pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "out_pages is null");
         P += np;
-        max_tiles = std::max<uint64_t>(max_tiles, (ps + TILE_ROWS - 1) / TILE_ROWS);
+        {
+            uint64_t mx = ps;
+            if (c.page_rows)
+                for (uint64_t q = 0; q < np; q++) mx = std::max<uint64_t>(mx, c.page_rows[q]);
+            max_tiles = std::max<uint64_t>(max_tiles, (mx + TILE_ROWS - 1) / TILE_ROWS);
+        }
     }
     if (P >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many pages in one call");
 
@@ -2316,6 +2332,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         d.validity = mem == SB_MEM_HOST ? dval[i] : c.validity;
         d.offsets = mem == SB_MEM_HOST ? doff[i] : (const uint8_t*)c.offsets;
         d.out = mem == SB_MEM_HOST ? dout[i] : c.out_pages;
+        d.heads = c.page_heads;
         d.values_bit_offset = c.values_bit_offset;
         d.values_len = c.values_len;
         d.validity_bit_offset = c.validity_bit_offset;
@@ -2337,10 +2354,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         uint64_t direct_off = 0, k = 0;
         if (bin) scratch_off = align_up(scratch_off, 16);
         const size_t col_slot_base = scratch_off;
-        for (uint64_t r = 0; r < c.rows; r += ps, k++, pi++) {
+        uint64_t head_off = 0;
+        for (uint64_t r = 0; r < c.rows || (c.page_rows && k < c.n_pages_in); k++, pi++) {
             EncPage& p = hp[pi];
             memset(&p, 0, sizeof p);
-            const uint64_t N = r + ps > c.rows ? c.rows - r : ps;
+            const uint64_t N = c.page_rows ? c.page_rows[k] : (r + ps > c.rows ? c.rows - r : ps);
+            p.head_bytes = c.page_head_bytes ? c.page_head_bytes[k] : 0;
+            p.head_off = head_off;
+            head_off += p.head_bytes;
             p.row0 = r;
             p.rows = N;
             p.col = (uint32_t)i;
@@ -2353,7 +2374,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 const uint64_t body = c.physical_type == SB_TYPE_BOOLEAN
                                           ? (codec == SB_CODEC_NONE ? (N + 7) / 8 : 1)
                                           : (codec == SB_CODEC_NONE ? N * d.width : d.width);
-                direct_off += (c.is_nullable ? def_section_bytes(N) : 0) + 9 + body;
+                direct_off += p.head_bytes + (c.is_nullable ? def_section_bytes(N) : 0) + 9 + body;
             } else if (c.physical_type != SB_TYPE_NULL) {
                 p.slot_off = scratch_off;
                 scratch_off += align_up(slot_fixed_bytes(c.physical_type, c.is_nullable, N), 16);
@@ -2374,6 +2395,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             if (codec == SB_CODEC_NONE || (adaptive && opts->default_compression == SB_CODEC_NONE))
                 any_tiles = true;
             if (codec != SB_CODEC_NONE && codec != SB_CODEC_LZ4 && codec != SB_CODEC_ZSTD) any_pages = true;
+            if (p.head_bytes) any_compact = true;  // k_enc_compact also places the heads
+            r += N;
+            if (N == 0 && !c.page_rows) break;
         }
         if (bin) scratch_off += align_up(c.values_len + c.values_len / 64 + 64 * k + 64, 16);
         (void)col_slot_base;

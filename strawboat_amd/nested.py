@@ -1,0 +1,234 @@
+"""Nested (list / struct) leaf columns — write_nested / read_nested of the reference on the GPU.
+
+Write side mirrors `write_nested` (src/write/serialize.rs:135-198): per page
+`u32 page_rows | u32 rep_len | u32 def_len | rep | def | leaf BLOCK`; the page cut follows
+src/write/common.rs:79-107 (top-level rows per page, `slice_parquet_array` for the leaf range,
+PageMeta.num_values = number of level entries).  Read side mirrors `read_nested_*` /
+`read_validity_nested` (src/read/read_basic.rs:65-173, src/read/array/integer.rs:240-283): the
+level streams rebuild list offsets, struct/list validity and leaf validity; the leaf BLOCK is an
+ordinary block.
+
+The level work runs in sb_nested_write_levels / sb_nested_read_levels; the leaf BLOCKs go
+through the flat sb_write_columns / sb_read_columns with explicit paging, so every codec of
+the flat path applies unchanged.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .read import ColumnPages, DeviceArray
+from .types import PageMeta, PhysicalType, WriteOptions
+from .write import DeviceColumn, EncodedColumn, options_c
+
+PRIMITIVE, LIST, LARGE_LIST, STRUCT = 0, 1, 2, 3
+
+
+@dataclass
+class NestedLevel:
+    """One node on the path root -> leaf (arrow2 `Nested`); buffers are torch.uint8 tensors in HBM."""
+    kind: int
+    is_optional: bool
+    length: int
+    validity: Optional[object] = None
+    offsets: Optional[object] = None       # lists: (length + 1) i32 / i64 offsets as bytes
+    validity_bit_offset: int = 0
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
+
+
+def _levels_c(levels: Sequence[NestedLevel]):
+    arr = (N.NestedLevelC * len(levels))()
+    for k, lv in enumerate(levels):
+        arr[k].validity = _ptr(lv.validity)
+        arr[k].offsets = _ptr(lv.offsets)
+        arr[k].validity_bit_offset = lv.validity_bit_offset
+        arr[k].length = lv.length
+        arr[k].kind = lv.kind
+        arr[k].is_optional = 1 if lv.is_optional else 0
+    return arr
+
+
+class NestedLevels:
+    """Result of write_levels: every page's level section back to back in HBM + per-page info."""
+
+    def __init__(self, sections, info):
+        self.sections = sections
+        self.level_bytes = info[:, 0].copy()
+        self.num_values = info[:, 1].copy()
+        self.leaf_start = info[:, 2].copy()
+        self.leaf_count = info[:, 3].copy()
+
+    @property
+    def n_pages(self):
+        return int(self.level_bytes.size)
+
+
+def write_levels(ctx, levels: Sequence[NestedLevel], rows: int, max_page_size: Optional[int]) -> NestedLevels:
+    """write_nested_validity for every page of one nested leaf column (synchronous)."""
+    import torch
+    arr = _levels_c(levels)
+    mps = 0 if max_page_size is None else int(max_page_size)
+    bound = int(ctx._lib.sb_nested_levels_bound(arr, len(levels), rows, mps))
+    ps = min(mps, rows) if mps else rows
+    npages = (rows + ps - 1) // ps if rows else 0
+    with torch.cuda.stream(ctx.torch_stream):
+        out = torch.empty(max(bound, 1), dtype=torch.uint8, device=ctx.torch_device)
+    pages = (N.NestedPageC * max(npages, 1))()
+    got = C.c_uint64(0)
+    ctx._check(ctx._lib.sb_nested_write_levels(ctx._h, arr, len(levels), rows, mps, _ptr(out), out.numel(), pages,
+                                               len(pages), C.byref(got)))
+    info = np.array([[p.level_bytes, p.num_values, p.leaf_start, p.leaf_count] for p in pages[:got.value]],
+                    dtype=np.uint64).reshape(-1, 4)
+    return NestedLevels(out, info)
+
+
+class NestedEncodedColumn(EncodedColumn):
+    """Pages of a nested leaf column; PageMeta.num_values counts level entries (write/common.rs:84-92)."""
+
+    def __init__(self, pages, metas_c, cstruct, num_values):
+        super().__init__(pages, metas_c, cstruct)
+        self._num_values = num_values
+
+    @property
+    def metas(self) -> List[PageMeta]:
+        return [PageMeta(int(m.length), int(v)) for m, v in zip(self._metas[:self.n_pages], self._num_values)]
+
+    def metas_array(self):
+        return np.array([[m.length, v] for m, v in zip(self._metas[:self.n_pages], self._num_values)],
+                        dtype=np.uint64).reshape(-1, 2)
+
+
+def write_nested(ctx, levels: Sequence[NestedLevel], leaf: DeviceColumn, options: WriteOptions) -> NestedEncodedColumn:
+    """Encode one nested leaf column (synchronous).  `leaf` holds the leaf array's buffers
+    (leaf.rows = levels[-1].length; its validity is the leaf validity, also referenced by
+    levels[-1].validity); options.max_page_size counts TOP-LEVEL rows like upstream."""
+    import torch
+    rows = levels[0].length
+    lv = write_levels(ctx, levels, rows, options.max_page_size)
+    if int(lv.leaf_start[0]) != 0:
+        raise ValueError("leaf slice must start at 0")
+    oc = options_c(options)
+    oc.max_page_size = 0
+    arr = (N.ColumnWriteC * 1)()
+    c = arr[0]
+    c.physical_type = leaf.physical_type
+    c.is_nullable = 0  # the def levels carry the validity; the BLOCK has no def section
+    total_leaf = int(lv.leaf_count.sum())
+    c.rows = total_leaf
+    c.values = _ptr(leaf.values)
+    c.values_bit_offset = leaf.values_bit_offset
+    c.values_len = leaf.values.numel() if leaf.values is not None else 0
+    c.validity = _ptr(leaf.validity)
+    c.validity_bit_offset = leaf.validity_bit_offset
+    c.offsets = _ptr(leaf.offsets)
+    vlen = c.values_len if PhysicalType.is_binary(leaf.physical_type) else 0
+    npg = C.c_uint64(0)
+    bound = int(ctx._lib.sb_write_bound(leaf.physical_type, 0, max(total_leaf, 1), vlen, C.byref(oc), C.byref(npg)))
+    bound += lv.n_pages * 512 + int(lv.level_bytes.sum())
+    with torch.cuda.stream(ctx.torch_stream):
+        pages = torch.empty(bound, dtype=torch.uint8, device=ctx.torch_device)
+    metas = (N.PageMetaC * lv.n_pages)()
+    c.out_pages = _ptr(pages)
+    c.out_capacity = pages.numel()
+    c.out_metas = metas
+    c.n_pages_capacity = lv.n_pages
+    page_rows = np.ascontiguousarray(lv.leaf_count, dtype=np.uint64)
+    heads = np.ascontiguousarray(lv.level_bytes, dtype=np.uint64)
+    c.page_rows = page_rows.ctypes.data_as(C.c_void_p)
+    c.page_head_bytes = heads.ctypes.data_as(C.c_void_p)
+    c.page_heads = _ptr(lv.sections)
+    c.n_pages_in = lv.n_pages
+    ctx._keep.append((arr, oc, page_rows, heads, lv, leaf, pages, metas))
+    ctx._check(ctx._lib.sb_write_columns(ctx._h, arr, 1, C.byref(oc), N.SB_MEM_DEVICE))
+    ctx.synchronize()
+    return NestedEncodedColumn(pages, metas, c, lv.num_values)
+
+
+class NestedArray:
+    """Decoded nested column: per level the column-level offsets / validity, plus the leaf array."""
+
+    def __init__(self, kinds, nullable, lengths, offsets, validity, leaf: DeviceArray):
+        self.kinds, self.nullable, self.lengths = kinds, nullable, lengths
+        self.offsets, self.validity, self.leaf = offsets, validity, leaf
+
+    def offsets_numpy(self, k):
+        return self.offsets[k][:(self.lengths[k] + 1) * 8].cpu().numpy().view(np.int64)
+
+    def validity_numpy(self, k):
+        return self.validity[k][:(self.lengths[k] + 7) // 8].cpu().numpy()
+
+
+def read_nested(ctx, column: ColumnPages, kinds: Sequence[int], nullable: Sequence[bool]) -> NestedArray:
+    """read_nested_* for one leaf column (synchronous): `kinds`/`nullable` are the InitNested chain
+    root -> leaf (src/read/batch_read.rs:66-230 builds it from the schema)."""
+    import torch
+    D = len(kinds)
+    metas = column.metas_array()
+    n_pages = metas.shape[0]
+    entries = int(metas[:, 1].sum()) if n_pages else 0
+    dev = ctx.torch_device
+    lv = (N.NestedLevelOutC * D)()
+    offs, vals = [None] * D, [None] * D
+    vbytes = ((entries + 31) // 32) * 4
+    with torch.cuda.stream(ctx.torch_stream):
+        for k in range(D):
+            lv[k].kind = kinds[k]
+            lv[k].is_nullable = 1 if nullable[k] else 0
+            if kinds[k] in (LIST, LARGE_LIST):
+                offs[k] = torch.empty((entries + 1) * 8, dtype=torch.uint8, device=dev)
+                lv[k].offsets = _ptr(offs[k])
+                lv[k].offsets_capacity = entries + 1
+            if nullable[k] and kinds[k] != PRIMITIVE:
+                vals[k] = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev)
+                lv[k].validity = _ptr(vals[k])
+                lv[k].validity_capacity = vals[k].numel()
+        leaf_validity = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev) if nullable[-1] else None
+    counts = np.zeros(max(n_pages, 1), np.uint64)
+    block_offs = np.zeros(max(n_pages, 1), np.uint64)
+    pages = column.pages
+    ctx._check(ctx._lib.sb_nested_read_levels(
+        ctx._h, _ptr(pages), pages.numel(), metas.ctypes.data_as(C.POINTER(N.PageMetaC)), n_pages, lv, D,
+        _ptr(leaf_validity), leaf_validity.numel() if leaf_validity is not None else 0,
+        counts.ctypes.data_as(C.POINTER(C.c_uint64)), block_offs.ctypes.data_as(C.POINTER(C.c_uint64))))
+    lengths = [int(lv[k].length) for k in range(D)]
+    # the leaf BLOCKs through the flat decoder
+    starts = np.concatenate([[0], np.cumsum(metas[:, 0])[:-1]]).astype(np.uint64) if n_pages else np.zeros(0, np.uint64)
+    leaf_metas = np.zeros((n_pages, 2), np.uint64)
+    leaf_metas[:, 0] = metas[:, 0] - (block_offs[:n_pages] - starts)
+    leaf_metas[:, 1] = counts[:n_pages]
+    t = column.physical_type
+    rows = int(counts[:n_pages].sum())
+    arr = (N.ColumnReadC * 1)()
+    c = arr[0]
+    c.physical_type = t
+    c.is_nullable = 0
+    c.pages = _ptr(pages)
+    c.pages_len = pages.numel()
+    c.metas = leaf_metas.ctypes.data_as(C.POINTER(N.PageMetaC))
+    c.n_pages = n_pages
+    po = np.ascontiguousarray(block_offs[:n_pages])
+    c.page_offsets = po.ctypes.data_as(C.c_void_p)
+    values = offsets = None
+    with torch.cuda.stream(ctx.torch_stream):
+        if t == PhysicalType.BOOLEAN:
+            values = torch.empty(((rows + 31) // 32) * 4 + 4, dtype=torch.uint8, device=dev)
+        elif PhysicalType.is_binary(t):
+            ctx._check(ctx._lib.sb_read_columns_sizes(ctx._h, arr, 1, N.SB_MEM_DEVICE))
+            values = torch.empty(max(int(c.values_len), 1), dtype=torch.uint8, device=dev)
+            offsets = torch.empty((rows + 1) * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
+        elif t != PhysicalType.NULL:
+            values = torch.empty(max(rows * PhysicalType.WIDTH[t], 1), dtype=torch.uint8, device=dev)
+    c.values = _ptr(values)
+    c.values_capacity = values.numel() if values is not None else 0
+    c.offsets = _ptr(offsets)
+    c.offsets_capacity = offsets.numel() if offsets is not None else 0
+    ctx._keep.append((arr, leaf_metas, po, pages, values, offsets))
+    ctx._check(ctx._lib.sb_read_columns(ctx._h, arr, 1, N.SB_MEM_DEVICE))
+    ctx.synchronize()
+    leaf = DeviceArray(t, bool(nullable[-1]), rows, values, leaf_validity, offsets, c)
+    return NestedArray(list(kinds), list(nullable), lengths, offs, vals, leaf)

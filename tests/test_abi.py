@@ -67,5 +67,5 @@ def test_struct_layouts_match_header():
     from strawboat_amd import _native as N
     assert C.sizeof(N.PageMetaC) == 16
     assert C.sizeof(N.WriteOptionsC) == 48
-    assert C.sizeof(N.ColumnReadC) == 104
-    assert C.sizeof(N.ColumnWriteC) == 112
+    assert C.sizeof(N.ColumnReadC) == 112
+    assert C.sizeof(N.ColumnWriteC) == 144

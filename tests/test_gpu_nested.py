@@ -1,0 +1,153 @@
+"""GPU parity of the nested (Dremel) path through the C ABI:
+  * level sections produced by sb_nested_write_levels == oracle's write_nested_validity, byte for byte;
+  * whole nested pages (levels + leaf BLOCK through the flat encoder with explicit paging) == the
+    oracle's composition of the same page;
+  * sb_nested_read_levels + flat decode rebuild the Arrow buffers the levels were made from
+    (the shapes of the reference's tests/it/io.rs:167-278: list, list_list, list_struct, struct_list)."""
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+from tests.nested_gen import expected_state, make_nested
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = ["list", "large_list", "list_list", "list_struct", "struct_list", "struct_struct", "list_required"]
+
+
+def up(ctx, a):
+    import torch
+    if a is None:
+        return None
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(ctx.torch_device)
+
+
+def device_levels(ctx, levels):
+    from strawboat_amd.nested import NestedLevel
+    return [NestedLevel(lv["kind"], bool(lv["is_optional"]), lv["length"], up(ctx, lv.get("validity")),
+                        up(ctx, lv.get("offsets"))) for lv in levels]
+
+
+def leaf_values(levels, ptype, seed, runs=None):
+    n = levels[-1]["length"]
+    col = gen.prim(ptype, max(n, 1), uniq=50, seed=seed, runs=runs)
+    w = col["values"].dtype.itemsize
+    return col["values"][:n], w
+
+
+def oracle_pages(levels, ptype, values, rows, page_rows, **opt):
+    """The bytes write_nested would emit page by page: level section + compress_* of the leaf slice."""
+    out, metas = [], []
+    leaf = levels[-1]
+    for r0 in range(0, rows, page_rows):
+        ln = min(page_rows, rows - r0)
+        b, nv, ls, lc = S.nested_write_levels(levels, r0, ln)
+        o = S.make_options(max_page_size=None, **opt)
+        if lc:
+            blk, _ = S.write_column(ptype, False, lc, values[ls:ls + lc], leaf.get("validity"), None, o,
+                                    validity_bit_offset=ls)
+        else:
+            blk = np.zeros(0, np.uint8)
+        out += [np.asarray(b), blk]
+        metas.append((len(b) + blk.size, nv))
+    return np.concatenate(out), np.array(metas, np.uint64).reshape(-1, 2)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("seed", [1, 2])
+def test_level_sections_match_oracle(gpu_ctx, shape, seed):
+    from strawboat_amd import nested
+    levels, rows = make_nested(shape, 3000, seed)
+    dl = device_levels(gpu_ctx, levels)
+    for mps in (None, 1000, 777, 1):
+        if mps == 1 and seed == 2:
+            continue
+        got = nested.write_levels(gpu_ctx, dl, rows, mps)
+        ps = rows if mps is None else mps
+        sec = got.sections.cpu().numpy()
+        off = 0
+        assert got.n_pages == (rows + ps - 1) // ps
+        for p, r0 in enumerate(range(0, rows, ps)):
+            ln = min(ps, rows - r0)
+            b, nv, ls, lc = S.nested_write_levels(levels, r0, ln)
+            assert (int(got.num_values[p]), int(got.leaf_start[p]), int(got.leaf_count[p])) == (nv, ls, lc), (p, r0)
+            assert int(got.level_bytes[p]) == len(b), (p, r0)
+            assert bytes(sec[off:off + len(b)]) == bytes(b), "page %d (rows %d..%d, mps %s)" % (p, r0, r0 + ln, mps)
+            off += len(b)
+
+
+@pytest.mark.parametrize("shape", ["list", "list_list", "list_struct", "struct_list"])
+@pytest.mark.parametrize("codec,ptype", [(S.NONE, S.T_I32), (S.RLE, S.T_I64), (S.DICT, S.T_F64), (S.LZ4, S.T_I32)])
+def test_nested_pages_match_oracle(gpu_ctx, shape, codec, ptype):
+    from strawboat_amd import WriteOptions, nested
+    from strawboat_amd.write import DeviceColumn
+    levels, rows = make_nested(shape, 5000, 3)
+    values, w = leaf_values(levels, ptype, 5, runs=6)
+    leaf = levels[-1]
+    opt = dict(force_codec=codec) if codec != S.LZ4 else dict(default_compression=S.LZ4)
+    want_pages, want_metas = oracle_pages(levels, ptype, values, rows, 1024, **opt)
+    wo = WriteOptions(default_compression=opt.get("default_compression", 0), max_page_size=1024,
+                      force_codec=opt.get("force_codec", -1))
+    dcol = DeviceColumn(ptype, False, leaf["length"], up(gpu_ctx, values), up(gpu_ctx, leaf.get("validity")))
+    enc = nested.write_nested(gpu_ctx, device_levels(gpu_ctx, levels), dcol, wo)
+    assert np.array_equal(enc.metas_array(), want_metas)
+    got = enc.pages_numpy()
+    assert got.size == want_pages.size
+    assert np.array_equal(got, want_pages), "first mismatch at %d" % int(np.argmax(got != want_pages))
+
+
+def check_decoded(arr, levels, rows, values, w):
+    want = expected_state(levels, 0, rows)
+    assert arr.lengths == want["lengths"]
+    for k, lv in enumerate(levels):
+        if lv["kind"] in (S.K_LIST, S.K_LARGE_LIST):
+            offs = arr.offsets_numpy(k)
+            assert offs[:-1].tolist() == want["offsets"][k], "offsets of level %d" % k
+            assert int(offs[-1]) == want["lengths"][k + 1]
+        if lv["is_optional"] and lv["kind"] != S.K_PRIMITIVE:
+            bits = np.unpackbits(arr.validity_numpy(k), bitorder="little")[:want["lengths"][k]]
+            assert bits.tolist() == want["validity"][k], "validity of level %d" % k
+    if levels[-1]["is_optional"]:
+        bits = np.unpackbits(arr.leaf.validity_numpy(), bitorder="little")[:want["leaf_count"]]
+        assert bits.tolist() == want["leaf_validity"]
+    got = arr.leaf.values[:want["leaf_count"] * w].cpu().numpy()
+    assert np.array_equal(got, np.ascontiguousarray(values).view(np.uint8)[:want["leaf_count"] * w])
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_read_oracle_written_nested_pages(gpu_ctx, shape):
+    from strawboat_amd import nested
+    from strawboat_amd.read import ColumnPages
+    levels, rows = make_nested(shape, 4000, 7)
+    values, w = leaf_values(levels, S.T_I32, 11)
+    pages, metas = oracle_pages(levels, S.T_I32, values, rows, 900, force_codec=S.NONE)
+    col = ColumnPages(S.T_I32, False, up(gpu_ctx, pages), metas)
+    arr = nested.read_nested(gpu_ctx, col, [lv["kind"] for lv in levels], [bool(lv["is_optional"]) for lv in levels])
+    check_decoded(arr, levels, rows, values, w)
+
+
+@pytest.mark.parametrize("shape", ["list_list", "list_struct"])
+def test_large_round_trip_on_device(gpu_ctx, shape):
+    """size-independent property at a size the oracle would not finish quickly: encode -> decode on
+    the device rebuilds the Arrow buffers the levels came from"""
+    from strawboat_amd import WriteOptions, nested
+    from strawboat_amd.read import ColumnPages
+    from strawboat_amd.write import DeviceColumn
+    levels, rows = make_nested(shape, 300_000, 9)
+    values, w = leaf_values(levels, S.T_I64, 13)
+    leaf = levels[-1]
+    dcol = DeviceColumn(S.T_I64, False, leaf["length"], up(gpu_ctx, values), up(gpu_ctx, leaf.get("validity")))
+    enc = nested.write_nested(gpu_ctx, device_levels(gpu_ctx, levels), dcol,
+                              WriteOptions(max_page_size=65536, force_codec=S.NONE))
+    col = ColumnPages(S.T_I64, False, enc.pages[:enc.length].contiguous(), enc.metas_array())
+    arr = nested.read_nested(gpu_ctx, col, [lv["kind"] for lv in levels], [bool(lv["is_optional"]) for lv in levels])
+    want = expected_state(levels, 0, rows)
+    assert arr.lengths == want["lengths"]
+    for k, lv in enumerate(levels):
+        if lv["kind"] in (S.K_LIST, S.K_LARGE_LIST):
+            assert np.array_equal(arr.offsets_numpy(k), np.asarray(lv["offsets"]).astype(np.int64))
+    got = arr.leaf.values[:want["leaf_count"] * w].cpu().numpy()
+    assert np.array_equal(got, values.view(np.uint8)[:want["leaf_count"] * w])
+    bits = np.unpackbits(arr.leaf.validity_numpy(), bitorder="little")[:want["leaf_count"]]
+    assert np.array_equal(bits, np.unpackbits(leaf["validity"], bitorder="little")[:want["leaf_count"]])

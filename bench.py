@@ -158,11 +158,13 @@ def main():
              "k_enc_emit_pages": U + page_bytes,    # A_enc = Arrow bytes read + page bytes written
              "k_enc_emit_tiles": U + page_bytes,
              "k_enc_select": U}                     # the selector reads the Arrow buffers once
-        dom = max((k for k in stats if k in A), key=lambda k: stats[k][1], default=None)
+        base = lambda k: k.split("<")[0]
+        dom = max((k for k in stats if base(k) in A), key=lambda k: stats[k][1], default=None)
         roof = None
         if dom:
             n, tot = stats[dom]
             avg_ms = tot / n
+            A = {k: A[base(k)] for k in stats if base(k) in A}
             achieved = A[dom] / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -173,7 +175,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if roof and pmc["config"] == {"workload": "C2", "columns_per_gpu": B, "codec": args.codec}:
-                cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0] == dom]
+                cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0] == dom.split("<")[0]]
                 if cand:
                     roof["traffic"] = max(cand)   # several template instances share a name: the one that did the work
                 roof["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC, per launch, gfx950 FETCH_SIZE x2 correction)"

@@ -66,6 +66,6 @@ class Context:
 
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated up to the last synchronize()."""
-        arr = (N.KernelStatC * 16)()
-        n = self._lib.sb_ctx_profile_read(self._h, arr, 16)
+        arr = (N.KernelStatC * 32)()
+        n = self._lib.sb_ctx_profile_read(self._h, arr, 32)
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n)}

@@ -115,12 +115,41 @@ __device__ __forceinline__ uint32_t bits32(const uint8_t* p, uint64_t pos, uint6
     const uint64_t b0 = pos >> 3;
     const uint32_t sh = (uint32_t)(pos & 7);
     uint64_t v = 0;
-    if (b0 + 8 <= nbytes) {
-        v = ldu64(p + b0);
+    if (nbytes >= 8) {  // one 8-byte load, pulled back inside the bitmap near its end (no divergent tail loop)
+        const uint64_t b = b0 + 8 <= nbytes ? b0 : nbytes - 8;
+        v = ldu64(p + b);
+        const uint64_t skip = (b0 - b) * 8;
+        v = skip < 64 ? v >> skip : 0;
     } else {
         for (uint32_t k = 0; k < 8 && b0 + k < nbytes; k++) v |= (uint64_t)ldu8(p + b0 + k) << (8 * k);
     }
     return (uint32_t)(v >> sh);
+}
+
+// Split form of bits32 for software pipelining: issue() only starts the 8-byte load, word() does the
+// shifting when the bits are consumed (one loop iteration later), so the load's latency is not
+// exposed in front of the loads that follow it.  `want` = number of bits needed (0..32).
+struct VWord {
+    uint64_t raw;
+    uint32_t shift, mask;
+    __device__ __forceinline__ uint32_t word() const { return (uint32_t)(raw >> shift) & mask; }
+};
+__device__ __forceinline__ VWord vword_issue(const uint8_t* p, uint64_t pos, uint64_t total_bits, uint32_t want) {
+    VWord r;
+    r.mask = want >= 32 ? 0xFFFFFFFFu : (1u << want) - 1;
+    r.shift = 0;
+    r.raw = ~0ull;
+    if (!p || want == 0) return r;
+    const uint64_t nbytes = (total_bits + 7) >> 3;
+    const uint64_t b0 = pos >> 3;
+    if (nbytes >= 8) {
+        const uint64_t b = b0 + 8 <= nbytes ? b0 : nbytes - 8;
+        r.raw = ldu64(p + b);
+        r.shift = (uint32_t)((b0 - b) * 8 + (pos & 7));  // <= 56 + 7
+    } else {
+        r.raw = bits32(p, pos, total_bits);
+    }
+    return r;
 }
 
 template <int W>
@@ -493,6 +522,189 @@ __device__ uint64_t enc_rle(GetVal getv, const ValidView& vv, uint64_t N, uint8_
             nrec += s_cnt[pw];
             if (s_blast[pw]) run_start = cb + s_blast[pw] - 1;
         }
+    }
+    if (N == 0) return 0;
+    if (threadIdx.x == 0) {  // close the final run; an all-null page is one run of T::default() (rle.rs:98-101)
+        uint8_t* r = dst + (uint64_t)nrec * REC;
+        stu32(r, (uint32_t)(N - run_start));
+        if (!have) {
+            const Val<W> z = val_zero<W>();
+            __builtin_memcpy(r + 4, &z, W);
+        }
+    }
+    __syncthreads();
+    return (uint64_t)(nrec + 1) * REC;
+}
+
+// ---- RLE, row-segment shape (used for whole pages; the ballot shape above stays for the u32
+// index streams nested in Dict pages, which only have a few LDS words to spare).
+//
+// lane = row costs ~1.7 VALU + ~1.7 SALU wave-instructions per row, because every 64-row group pays
+// for its own 64-bit mask bookkeeping and the CU has a single scalar unit.  Here a thread owns K
+// CONSECUTIVE rows instead: the chunk (256*K rows) is loaded coalesced, transposed through LDS
+// (one pad element per thread segment -> conflict-free), and each thread walks its rows carrying
+// "previous valid value".  Cross-thread state is one ballot + one permute per wave per chunk
+// (carry of the last valid value, rank of the first boundary, previous boundary row); cross-wave
+// state is four small LDS records.  The next chunk's global loads are issued one iteration ahead
+// and stay in flight across the LDS-only barriers.
+template <int W>
+struct RleRows {
+    static constexpr int K = W <= 8 ? 16 : (W == 16 ? 8 : 4);       // rows per thread per chunk
+    static constexpr uint32_t CHUNK = WG * K;
+    static constexpr uint32_t VAL_BYTES = (CHUNK + WG) * W;            // padded value tile
+    static constexpr uint32_t WORDS = (VAL_BYTES + 15) / 16 * 4 + CHUNK / 32 + 64 + 4 * W;  // + s_vb + sA + sB
+};
+
+template <int W, int FK, class GetVal>
+__device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, uint8_t* dst, uint32_t* lds) {
+    constexpr int REC = 4 + W;
+    constexpr int K = RleRows<W>::K;
+    constexpr uint32_t CHUNK = RleRows<W>::CHUNK;
+    Val<W>* s_val = (Val<W>*)lds;
+    uint32_t* s_vb = lds + (RleRows<W>::VAL_BYTES + 15) / 16 * 4;
+    uint32_t* sA = s_vb + CHUNK / 32;
+    uint32_t* sB = sA + 64;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t lt = (1ull << lane) - 1;
+    uint64_t run_start = 0;  // row where the open run started
+    uint32_t nrec = 0;       // records closed so far (the open run is record `nrec`)
+    bool have = false;       // a valid row has been seen
+    Val<W> last = val_zero<W>();
+    const uint64_t vtotal = vv.off + N;
+    auto lds_barrier = []() {  // LDS-only hand-off: global loads / stores stay in flight across it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    Val<W> vn[K];
+    VWord wvn;  // validity word t of the chunk (threads < CHUNK/32), finished when it is staged
+    auto fetch = [&](uint64_t cb) {
+        const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const uint32_t row = (uint32_t)t + (uint32_t)u * WG;
+            vn[u] = getv(cb + (row < n ? row : n - 1));
+        }
+        const uint32_t vb0 = (uint32_t)t * 32;
+        wvn = vword_issue(vv.bits, vv.off + cb + vb0, vtotal, vb0 < n ? min(32u, n - vb0) : 0u);
+        if (vb0 >= n) wvn.mask = 0;
+    };
+    if (N) fetch(0);
+    uint32_t par = 0;
+    for (uint64_t cb = 0; cb < N; cb += CHUNK, par ^= 1) {
+        uint32_t* s_has = sA + par * 16;          // [4] wave has a valid row
+        uint32_t* s_cnt = sA + par * 16 + 4;      // [4] boundaries found by the wave
+        uint32_t* s_blast = sA + par * 16 + 8;    // [4] (last boundary row in chunk)+1, 0 = none
+        Val<W>* s_last = (Val<W>*)sB + par * 4;   // [4] value of the wave's last valid row
+        // ---- stage the chunk: values transposed through LDS, validity words
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const uint32_t i = (uint32_t)t + (uint32_t)u * WG;
+            s_val[i + i / K] = vn[u];
+        }
+        if (t < (int)(CHUNK / 32)) s_vb[t] = wvn.word();
+        lds_barrier();
+        if (cb + CHUNK < N) fetch(cb + CHUNK);  // next chunk's loads fly while this one is processed
+        const uint32_t bit0 = (uint32_t)t * K;
+        const uint32_t m = (s_vb[bit0 >> 5] >> (bit0 & 31)) & ((1u << K) - 1);
+        // ---- phase 1: last valid value per thread -> per wave
+        const Val<W> lastv = s_val[t * K + t + (m ? 31 - __clz((int)m) : 0)];
+        const uint64_t hm = __ballot(m != 0);
+        const bool has_w = hm != 0;
+        const Val<W> last_w = readlane_val<W>(lastv, has_w ? top_bit(hm) : 0);
+        if (lane == 0) {
+            s_has[w] = has_w;
+            s_last[w] = last_w;
+        }
+        lds_barrier();
+        bool chas = have;
+        Val<W> cval = last;
+        for (int pw = 0; pw < 3; pw++)
+            if (pw < w && s_has[pw]) {
+                chas = true;
+                cval = s_last[pw];
+            }
+        // carry into this thread: nearest earlier lane of the wave with a valid row, else the wave's carry
+        const uint64_t pm = hm & lt;
+        const Val<W> pvs = shfl_val<W>(lastv, pm ? top_bit(pm) : 0);
+        const bool pc = pm ? true : chas;
+        const Val<W> pv = pm ? pvs : cval;
+        if (!pc && m) {  // the very first valid row of the page gives the first run its value
+            const Val<W> firstv = s_val[t * K + t + __ffs((int)m) - 1];
+            __builtin_memcpy(dst + 4, &firstv, W);
+        }
+        // ---- phase 2: boundaries of my rows.  Forward-fill the previous valid value over null rows;
+        // a row whose filled value differs BITWISE from its predecessor's is a candidate (null rows
+        // never are).  Floats then drop the candidates OrderedFloat calls equal (+-0, NaN == NaN).
+        uint32_t bmask = 0;
+        {
+            Val<W> e = pv;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const Val<W> ej = ((m >> j) & 1) ? s_val[t * K + t + j] : e;
+                if (!val_eq<W>(ej, e, 0)) bmask |= 1u << j;
+                e = ej;
+            }
+        }
+        if (!pc && m) bmask &= ~(1u << (__ffs((int)m) - 1));  // nothing before it: not a boundary
+        if constexpr (FK != 0) {
+            uint32_t cc = bmask;
+            while (cc) {
+                const int j = __ffs((int)cc) - 1;
+                cc &= cc - 1;
+                const uint32_t below = m & ((1u << j) - 1);
+                const Val<W> cur = s_val[t * K + t + j];
+                const Val<W> prev = below ? s_val[t * K + t + (31 - __clz((int)below))] : pv;
+                if (rle_eq<W, FK>(prev, cur)) bmask &= ~(1u << j);
+            }
+        }
+        const uint32_t cnt = (uint32_t)__popc(bmask);
+        const uint32_t blast = bmask ? (uint32_t)t * K + (31u - (uint32_t)__clz((int)bmask)) + 1 : 0;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint64_t bmk = __ballot(bmask != 0);
+        const uint64_t pb = bmk & lt;
+        const uint32_t prev_blast = __shfl(blast, pb ? top_bit(pb) : 0, 64);
+        const uint32_t cnt_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t blast_w = (uint32_t)__builtin_amdgcn_readlane((int)blast, bmk ? top_bit(bmk) : 0);
+        if (lane == 0) {
+            s_cnt[w] = cnt_w;
+            s_blast[w] = bmk ? blast_w : 0;
+        }
+        lds_barrier();
+        // ---- phase 3: ranks and records
+        uint32_t base = nrec;
+        uint64_t start_prev = run_start;
+        for (int pw = 0; pw < 3; pw++)
+            if (pw < w) {
+                base += s_cnt[pw];
+                if (s_blast[pw]) start_prev = cb + s_blast[pw] - 1;
+            }
+        uint32_t rk = base + incl - cnt;  // boundaries before my first one
+        uint64_t start = pb ? cb + prev_blast - 1 : start_prev;
+        uint32_t bmm = bmask;
+        while (bmm) {
+            const int j = __ffs((int)bmm) - 1;
+            bmm &= bmm - 1;
+            const uint64_t row = cb + (uint64_t)t * K + j;
+            const Val<W> bv = s_val[t * K + t + j];
+            uint8_t* closed = dst + (uint64_t)rk * REC;
+            stu32(closed, (uint32_t)(row - start));        // count of the run that ends here
+            __builtin_memcpy(closed + REC + 4, &bv, W);    // value of the run that starts here
+            start = row;
+            rk++;
+        }
+        // ---- chunk carries (wave-uniform, identical in every wave)
+        for (int pw = 0; pw < 4; pw++) {
+            if (s_has[pw]) {
+                have = true;
+                last = s_last[pw];
+            }
+            nrec += s_cnt[pw];
+            if (s_blast[pw]) run_start = cb + s_blast[pw] - 1;
+        }
+        // the next chunk's staging overwrites s_val / s_vb: wait until every thread is past its reads
+        lds_barrier();
     }
     if (N == 0) return 0;
     if (threadIdx.x == 0) {  // close the final run; an all-null page is one run of T::default() (rle.rs:98-101)
@@ -1160,20 +1372,23 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
     // U independent value loads per thread are issued back to back, then processed.
     constexpr int U = W <= 8 ? 8 : 2;
     constexpr uint32_t CH = 8192;
-    __shared__ uint32_t s_vb[CH / 32];
+    uint32_t* s_vb = (uint32_t*)sc.sample_mem;  // CH/32 words (1 KB): free until the samples are drawn
+    static_assert(CH / 8 <= SAMPLE_CAP * 2, "validity staging must fit the sample area");
+    auto vword = [&](uint64_t cb) {  // validity word t of the chunk at cb (threads < CH/32): load only
+        const uint32_t cn = (uint32_t)min((uint64_t)CH, N - cb);
+        const uint32_t bit0 = (uint32_t)t * 32;
+        const bool mine = t < (int)(CH / 32) && bit0 < cn;
+        VWord r = vword_issue(vv.bits, vv.off + cb + bit0, vv.off + N, mine ? min(32u, cn - bit0) : 0u);
+        if (!mine) r.mask = 0;
+        return r;
+    };
+    VWord wv_next = vword(0);
     for (uint64_t cb = 0; cb < N; cb += CH) {
      const uint32_t cn = (uint32_t)min((uint64_t)CH, N - cb);
      __syncthreads();
-     if (t < (int)(CH / 32)) {
-         const uint32_t bit0 = (uint32_t)t * 32;
-         uint32_t wv = 0;
-         if (bit0 < cn) {
-             wv = vv.bits ? bits32(vv.bits, vv.off + cb + bit0, vv.off + N) : 0xFFFFFFFFu;
-             if (cn - bit0 < 32) wv &= (1u << (cn - bit0)) - 1;
-         }
-         s_vb[t] = wv;
-     }
+     if (t < (int)(CH / 32)) s_vb[t] = wv_next.word();
      __syncthreads();
+     if (cb + CH < N) wv_next = vword(cb + CH);  // in flight while this chunk is processed
      for (uint64_t ib = cb + t; ib < cb + cn; ib += (uint64_t)WG * U) {
       Val<W> vbuf[U], pbuf[U];
       bool okb[U];
@@ -1559,11 +1774,11 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
     uint64_t body = 0;
     if constexpr (CODEC == SB_CODEC_RLE) {
         if (c.fkind == 1 && W == 4)
-            body = enc_rle<W, (W == 4 ? 1 : 0)>(getv, vv, N, blk + 9, sA, sB);
+            body = enc_rle_rows<W, (W == 4 ? 1 : 0)>(getv, vv, N, blk + 9, sA);
         else if (c.fkind == 2 && W == 8)
-            body = enc_rle<W, (W == 8 ? 2 : 0)>(getv, vv, N, blk + 9, sA, sB);
+            body = enc_rle_rows<W, (W == 8 ? 2 : 0)>(getv, vv, N, blk + 9, sA);
         else
-            body = enc_rle<W, 0>(getv, vv, N, blk + 9, sA, sB);
+            body = enc_rle_rows<W, 0>(getv, vv, N, blk + 9, sA);
     } else if constexpr (CODEC == SB_CODEC_ONEVALUE) {  // first valid value or T::default() (one_value.rs:63-75)
         __shared__ unsigned long long s_first;
         if (threadIdx.x == 0) s_first = ~0ull;
@@ -1636,7 +1851,7 @@ __device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const E
             v.x = bit_at(bits, boff + i) ? 1 : 0;
             return v;
         };
-        body = enc_rle<1, 0>(getv, vv, N, blk + 9, sA, sB);
+        body = enc_rle_rows<1, 0>(getv, vv, N, blk + 9, sA);
     } else if constexpr (CODEC == SB_CODEC_ONEVALUE) {  // boolean/one_value.rs:44-52
         __shared__ unsigned long long s_firstb;
         if (threadIdx.x == 0) s_firstb = ~0ull;
@@ -1824,7 +2039,9 @@ template <int KIND, int CODEC>
 __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_ONEVALUE) ? 4 : 3)
     k_enc_emit_pages(EncodeArgs a) {
     // RLE / OneValue only need the small per-group records; Dict and bit-packing use full tile arrays
-    constexpr int LW = (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_ONEVALUE) ? 256 : SIDX_WORDS;
+    constexpr int LW = CODEC == SB_CODEC_ONEVALUE ? 256
+                       : CODEC == SB_CODEC_RLE ? (int)(RleRows<(KIND > 0 ? KIND : 1)>::WORDS + 2) / 3
+                                               : SIDX_WORDS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * LW];
     uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
     __shared__ uint32_t s_w[4];
@@ -2482,7 +2699,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 }
                 EncPageKernel kf = enc_page_kernel(kd, cd);
                 if (!kf) continue;
-                KScope k(ctx, K_ENC_PAGES);
+                KScope k(ctx, cd == SB_CODEC_RLE ? K_ENC_PAGES : cd == SB_CODEC_DICT ? K_ENC_PAGES_DICT
+                                : cd == SB_CODEC_ONEVALUE ? K_ENC_PAGES_ONEVALUE : K_ENC_PAGES_BP);
                 kf<<<(uint32_t)P, WG, 0, s>>>(a);
             }
             if (!adaptive && host_codec != SB_CODEC_NONE && !enc_page_kernel(kd, host_codec))

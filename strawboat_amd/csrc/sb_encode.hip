@@ -264,9 +264,43 @@ __device__ __forceinline__ void def_bits_tile(uint8_t* bits_dst, const ValidView
         const uint32_t nb = min(32u, rows - bit0);
         if (nb < 32) w &= (1u << nb) - 1;
         const uint32_t nby = min(4u, nbytes - b4);
-        for (uint32_t k = 0; k < nby; k++) d[b4 + k] = (uint8_t)(w >> (8 * k));
+        if (nby == 4) {
+            stu32(d + b4, w);
+        } else {
+            for (uint32_t k = 0; k < nby; k++) *(gptr)(d + b4 + k) = (uint8_t)(w >> (8 * k));
+        }
     }
     (void)N;
+}
+
+// the whole def-level bit section of a page by one workgroup: U independent bitmap loads in flight per
+// thread, unaligned dword stores (the section starts at an odd offset behind the ULEB header)
+__device__ __forceinline__ void def_bits_page(uint8_t* bits_dst, const ValidView& v, uint64_t page_row0, uint64_t N,
+                                              uint64_t total_rows) {
+    constexpr int U = 4;
+    const uint32_t nbytes = (uint32_t)((N + 7) / 8), nwords = (nbytes + 3) / 4;
+    for (uint32_t w0 = threadIdx.x; w0 < nwords; w0 += WG * U) {
+        VWord r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t bit0 = (uint64_t)(w0 + u * WG) * 32;
+            const uint32_t want = bit0 < N ? (uint32_t)min((uint64_t)32, N - bit0) : 0u;
+            r[u] = vword_issue(v.bits, v.off + page_row0 + bit0, v.off + total_rows, want);
+            if (!want) r[u].mask = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t wi = w0 + u * WG;
+            if (wi >= nwords) break;
+            const uint32_t w = r[u].word();
+            uint8_t* d = bits_dst + (uint64_t)wi * 4;
+            if (wi * 4 + 4 <= nbytes) {
+                stu32(d, w);
+            } else {
+                for (uint32_t k = 0; wi * 4 + k < nbytes; k++) *(gptr)(d + k) = (uint8_t)(w >> (8 * k));
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void put_hdr9(uint8_t* p, uint32_t codec, uint32_t csize, uint32_t usize) {
@@ -555,6 +589,19 @@ struct RleRows {
     static constexpr uint32_t WORDS = (VAL_BYTES + 15) / 16 * 4 + CHUNK / 32 + 64 + 4 * W;  // + s_vb + sA + sB
 };
 
+#ifdef SB_RLE_TIMELINE  // scripts/micro/rle_timeline.hip: s_memtime stamps of one workgroup's phases
+__device__ unsigned long long* g_tl;
+#define TL_INIT unsigned long long* tl_ = blockIdx.x == 100 ? g_tl : nullptr; uint32_t tl_c = 0;
+#define TL(p)                                                                                        \
+    do {                                                                                             \
+        if (tl_ && lane == 0 && tl_c < 16) tl_[(w * 16 + tl_c) * 8 + (p)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define TL_NEXT tl_c++;
+#else
+#define TL_INIT
+#define TL(p)
+#define TL_NEXT
+#endif
 template <int W, int FK, class GetVal>
 __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, uint8_t* dst, uint32_t* lds) {
     constexpr int REC = 4 + W;
@@ -592,6 +639,7 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
     };
     if (N) fetch(0);
     uint32_t par = 0;
+    TL_INIT
     for (uint64_t cb = 0; cb < N; cb += CHUNK, par ^= 1) {
         uint32_t* s_has = sA + par * 16;          // [4] wave has a valid row
         uint32_t* s_cnt = sA + par * 16 + 4;      // [4] boundaries found by the wave
@@ -603,9 +651,12 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
             const uint32_t i = (uint32_t)t + (uint32_t)u * WG;
             s_val[i + i / K] = vn[u];
         }
+        TL(0);
         if (t < (int)(CHUNK / 32)) s_vb[t] = wvn.word();
         lds_barrier();
+        TL(1);
         if (cb + CHUNK < N) fetch(cb + CHUNK);  // next chunk's loads fly while this one is processed
+        TL(2);
         const uint32_t bit0 = (uint32_t)t * K;
         const uint32_t m = (s_vb[bit0 >> 5] >> (bit0 & 31)) & ((1u << K) - 1);
         // ---- phase 1: last valid value per thread -> per wave
@@ -618,6 +669,7 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
             s_last[w] = last_w;
         }
         lds_barrier();
+        TL(3);
         bool chas = have;
         Val<W> cval = last;
         for (int pw = 0; pw < 3; pw++)
@@ -632,17 +684,20 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
         const Val<W> pv = pm ? pvs : cval;
         if (!pc && m) {  // the very first valid row of the page gives the first run its value
             const Val<W> firstv = s_val[t * K + t + __ffs((int)m) - 1];
-            __builtin_memcpy(dst + 4, &firstv, W);
+            st_val<W>(dst + 4, firstv);
         }
         // ---- phase 2: boundaries of my rows.  Forward-fill the previous valid value over null rows;
         // a row whose filled value differs BITWISE from its predecessor's is a candidate (null rows
         // never are).  Floats then drop the candidates OrderedFloat calls equal (+-0, NaN == NaN).
         uint32_t bmask = 0;
         {
+            Val<W> v[K];  // all K LDS reads are issued back to back (one wait), then the dependent chain runs
+#pragma unroll
+            for (int j = 0; j < K; j++) v[j] = s_val[t * K + t + j];
             Val<W> e = pv;
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                const Val<W> ej = ((m >> j) & 1) ? s_val[t * K + t + j] : e;
+                const Val<W> ej = ((m >> j) & 1) ? v[j] : e;
                 if (!val_eq<W>(ej, e, 0)) bmask |= 1u << j;
                 e = ej;
             }
@@ -659,6 +714,7 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
                 if (rle_eq<W, FK>(prev, cur)) bmask &= ~(1u << j);
             }
         }
+        TL(4);
         const uint32_t cnt = (uint32_t)__popc(bmask);
         const uint32_t blast = bmask ? (uint32_t)t * K + (31u - (uint32_t)__clz((int)bmask)) + 1 : 0;
         const uint32_t incl = wave_incl_scan(cnt);
@@ -672,6 +728,7 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
             s_blast[w] = bmk ? blast_w : 0;
         }
         lds_barrier();
+        TL(5);
         // ---- phase 3: ranks and records
         uint32_t base = nrec;
         uint64_t start_prev = run_start;
@@ -690,7 +747,7 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
             const Val<W> bv = s_val[t * K + t + j];
             uint8_t* closed = dst + (uint64_t)rk * REC;
             stu32(closed, (uint32_t)(row - start));        // count of the run that ends here
-            __builtin_memcpy(closed + REC + 4, &bv, W);    // value of the run that starts here
+            st_val<W>(closed + REC + 4, bv);               // value of the run that starts here
             start = row;
             rk++;
         }
@@ -703,8 +760,11 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
             nrec += s_cnt[pw];
             if (s_blast[pw]) run_start = cb + s_blast[pw] - 1;
         }
+        TL(6);
         // the next chunk's staging overwrites s_val / s_vb: wait until every thread is past its reads
         lds_barrier();
+        TL(7);
+        TL_NEXT
     }
     if (N == 0) return 0;
     if (threadIdx.x == 0) {  // close the final run; an all-null page is one run of T::default() (rle.rs:98-101)
@@ -2067,9 +2127,7 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     ValidView vv{c.validity, c.validity_bit_offset + p.row0};
     if (c.nullable) {
         uint8_t* bits = def_header(slot, N);
-        for (uint64_t r0 = 0; r0 < N; r0 += TILE_ROWS)
-            def_bits_tile(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows, r0,
-                          (uint32_t)min((uint64_t)TILE_ROWS, N - r0));
+        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
         pos = def_section_bytes(N);
     }
     uint64_t blen = 0;
@@ -2188,9 +2246,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     uint64_t pos = 0;
     if (c.nullable) {
         uint8_t* bits = def_header(slot, N);
-        for (uint64_t r0 = 0; r0 < N; r0 += TILE_ROWS)
-            def_bits_tile(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows, r0,
-                          (uint32_t)min((uint64_t)TILE_ROWS, N - r0));
+        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
         pos = def_section_bytes(N);
     }
     uint8_t* blk = slot + pos;

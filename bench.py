@@ -128,7 +128,6 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
-    ctx.profile(True)   # HIP events around every kernel launch, on the stream the kernels run on
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -141,6 +140,13 @@ def main():
         assert len(shard.column_metas(all_metas)) == world * B
     barrier()
     t1 = time.perf_counter()
+    # ---- the same K steps once more with HIP events around every kernel launch (recorded by the
+    # library on the stream the kernels run on): per-kernel durations for the roofline figure.  Kept
+    # out of the timed region above because 2 event records per launch cost ~15 % of a 0.6 ms step.
+    ctx.profile(True)
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
     stats = ctx.profile_read()
     ctx.profile(False)
 

@@ -1225,6 +1225,8 @@ struct PrimKeys {
     __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return dict_eq<W>(key(a), key(b), fkind); }
 };
 
+#include "sb_dict_lds.h"
+
 template <class O>
 struct BinKeys {
     const uint8_t* offs;  // page offsets (N+1), absolute into values
@@ -1869,7 +1871,9 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
         PrimKeys<W> ko{vals, vv, c.fkind};
         uint32_t *idx, *firsts;
         uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
-        const uint32_t D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
+        uint32_t D = DICT_FALLBACK;
+        if constexpr (W <= 8) D = dict_build_lds<W>(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA);
+        if (D == DICT_FALLBACK) D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
         if (D == EMPTY) return 0;
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
         if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)

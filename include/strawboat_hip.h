@@ -245,6 +245,35 @@ int32_t sb_nested_read_levels(sb_ctx* ctx, const uint8_t* pages, uint64_t pages_
                               uint8_t* leaf_validity, uint64_t leaf_validity_capacity,
                               uint64_t* page_leaf_counts, uint64_t* page_block_offsets);
 
+/* ------------------------------------------------------------------ file framing (host only)
+ * "ARROW2" 00 00 | column pages ... | schema bytes | metas | u32 schema_size | u32 meta_size | EOS
+ * (SURVEY App. A.1).  Writer: NativeWriter::start / write / finish (src/write/writer.rs:91-167);
+ * one sb_file_writer_write_column per leaf column in leaf order, with the pages and PageMeta that
+ * sb_write_columns produced (copied to HOST memory).  The schema is an opaque Arrow IPC Schema
+ * message flatbuffer (arrow2 schema_to_bytes upstream).  Errors carry the reference's messages;
+ * sb_file_last_error() is thread-local. */
+typedef struct sb_file_writer sb_file_writer;
+typedef struct sb_file_reader sb_file_reader;
+const char* sb_file_last_error(void);
+int32_t sb_file_writer_open(const char* path, sb_file_writer** out);
+int32_t sb_file_writer_start(sb_file_writer* w);
+int32_t sb_file_writer_write_column(sb_file_writer* w, const uint8_t* pages, uint64_t pages_len,
+                                    const sb_page_meta* metas, uint64_t n_pages);
+int32_t sb_file_writer_finish(sb_file_writer* w, const uint8_t* schema_bytes, uint64_t schema_len,
+                              uint64_t* total_size);
+void sb_file_writer_close(sb_file_writer* w);
+/* Reader: read_meta / deserialize_meta (src/read/reader.rs:148-178), the schema bytes of
+ * infer_schema (:227-241), and page ranges of a column (ColumnMeta::slice src/lib.rs:47-61 +
+ * NativeReader::next src/read/reader.rs:117-127) into HOST memory. */
+int32_t sb_file_reader_open(const char* path, sb_file_reader** out);
+uint64_t sb_file_reader_n_columns(const sb_file_reader* r);
+int32_t sb_file_reader_column(const sb_file_reader* r, uint64_t col, uint64_t* offset, uint64_t* n_pages,
+                              const sb_page_meta** pages);
+int32_t sb_file_reader_schema(const sb_file_reader* r, const uint8_t** bytes, uint64_t* len);
+int32_t sb_file_reader_read_pages(sb_file_reader* r, uint64_t col, uint64_t first_page, uint64_t n_pages,
+                                  uint8_t* dst, uint64_t capacity, uint64_t* bytes_read);
+void sb_file_reader_close(sb_file_reader* r);
+
 /* ------------------------------------------------------------------ measurement
  * Optional per-kernel timing with HIP events recorded on the context's stream around every
  * kernel launch (used by bench.py for the roofline figure).  Totals are accumulated at

@@ -17,7 +17,10 @@ SB_MEM_DEVICE, SB_MEM_HOST = 0, 1
 EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
            "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns",
            "sb_ctx_profile", "sb_ctx_profile_read", "sb_nested_levels_bound", "sb_nested_write_levels",
-           "sb_nested_read_levels")
+           "sb_nested_read_levels", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
+           "sb_file_writer_write_column", "sb_file_writer_finish", "sb_file_writer_close", "sb_file_reader_open",
+           "sb_file_reader_n_columns", "sb_file_reader_column", "sb_file_reader_schema", "sb_file_reader_read_pages",
+           "sb_file_reader_close")
 
 
 class PageMetaC(C.Structure):
@@ -123,5 +126,28 @@ def load():
     L.sb_nested_read_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PageMetaC), C.c_uint64,
                                         C.POINTER(NestedLevelOutC), C.c_uint32, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sb_file_last_error.restype = C.c_char_p
+    L.sb_file_writer_open.restype = C.c_int32
+    L.sb_file_writer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.sb_file_writer_start.restype = C.c_int32
+    L.sb_file_writer_start.argtypes = [C.c_void_p]
+    L.sb_file_writer_write_column.restype = C.c_int32
+    L.sb_file_writer_write_column.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PageMetaC), C.c_uint64]
+    L.sb_file_writer_finish.restype = C.c_int32
+    L.sb_file_writer_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sb_file_writer_close.argtypes = [C.c_void_p]
+    L.sb_file_reader_open.restype = C.c_int32
+    L.sb_file_reader_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.sb_file_reader_n_columns.restype = C.c_uint64
+    L.sb_file_reader_n_columns.argtypes = [C.c_void_p]
+    L.sb_file_reader_column.restype = C.c_int32
+    L.sb_file_reader_column.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.POINTER(PageMetaC))]
+    L.sb_file_reader_schema.restype = C.c_int32
+    L.sb_file_reader_schema.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.sb_file_reader_read_pages.restype = C.c_int32
+    L.sb_file_reader_read_pages.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                            C.POINTER(C.c_uint64)]
+    L.sb_file_reader_close.argtypes = [C.c_void_p]
     _lib = L
     return L

@@ -100,6 +100,25 @@ __device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t COMPACT_CHUNK = 64 * 1024;
 
+#ifdef SB_RLE_TIMELINE  // scripts/micro/rle_timeline.hip: s_memtime stamps of one workgroup's phases
+__device__ unsigned long long* g_tl;
+#define TL_INIT unsigned long long* tl_ = blockIdx.x == 100 ? g_tl : nullptr; uint32_t tl_c = 0;
+#define TL(p)                                                                                        \
+    do {                                                                                             \
+        if (tl_ && lane == 0 && tl_c < 16) tl_[(w * 16 + tl_c) * 8 + (p)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define TL_NEXT tl_c++;
+#define STL(p)                                                                                       \
+    do {                                                                                             \
+        if (g_tl && blockIdx.x == 100 && threadIdx.x == 0) g_tl[512 + (p)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TL_INIT
+#define TL(p)
+#define TL_NEXT
+#define STL(p)
+#endif
+
 // ------------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ bool bit_at(const uint8_t* p, uint64_t i) { return (ldu8(p + (i >> 3)) >> (i & 7)) & 1; }
 
@@ -589,19 +608,6 @@ struct RleRows {
     static constexpr uint32_t WORDS = (VAL_BYTES + 15) / 16 * 4 + CHUNK / 32 + 64 + 4 * W;  // + s_vb + sA + sB
 };
 
-#ifdef SB_RLE_TIMELINE  // scripts/micro/rle_timeline.hip: s_memtime stamps of one workgroup's phases
-__device__ unsigned long long* g_tl;
-#define TL_INIT unsigned long long* tl_ = blockIdx.x == 100 ? g_tl : nullptr; uint32_t tl_c = 0;
-#define TL(p)                                                                                        \
-    do {                                                                                             \
-        if (tl_ && lane == 0 && tl_c < 16) tl_[(w * 16 + tl_c) * 8 + (p)] = __builtin_readcyclecounter(); \
-    } while (0)
-#define TL_NEXT tl_c++;
-#else
-#define TL_INIT
-#define TL(p)
-#define TL_NEXT
-#endif
 template <int W, int FK, class GetVal>
 __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, uint8_t* dst, uint32_t* lds) {
     constexpr int REC = 4 + W;
@@ -1404,6 +1410,7 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
     uint32_t* s4 = sc.s_misc + 2 * WG;
     // ---- one streaming pass: flags, null count, typed max, Boyer-Moore vote, and (W <= 8) an LDS
     // hash set of the canonical keys for the exact distinct count Dict needs
+    STL(0);
     const Val<W> k0 = key(0);
     uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, nulls = 0;
     Val<W> tmax = getv(0);
@@ -1435,7 +1442,6 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
     constexpr int U = W <= 8 ? 8 : 2;
     constexpr uint32_t CH = 8192;
     uint32_t* s_vb = (uint32_t*)sc.sample_mem;  // CH/32 words (1 KB): free until the samples are drawn
-    static_assert(CH / 8 <= SAMPLE_CAP * 2, "validity staging must fit the sample area");
     auto vword = [&](uint64_t cb) {  // validity word t of the chunk at cb (threads < CH/32): load only
         const uint32_t cn = (uint32_t)min((uint64_t)CH, N - cb);
         const uint32_t bit0 = (uint32_t)t * 32;
@@ -1445,53 +1451,27 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
         return r;
     };
     VWord wv_next = vword(0);
-    for (uint64_t cb = 0; cb < N; cb += CH) {
-     const uint32_t cn = (uint32_t)min((uint64_t)CH, N - cb);
-     __syncthreads();
-     if (t < (int)(CH / 32)) s_vb[t] = wv_next.word();
-     __syncthreads();
-     if (cb + CH < N) wv_next = vword(cb + CH);  // in flight while this chunk is processed
-     for (uint64_t ib = cb + t; ib < cb + cn; ib += (uint64_t)WG * U) {
-      Val<W> vbuf[U], pbuf[U];
-      bool okb[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-          const uint64_t i = ib + (uint64_t)u * WG;
-          const uint64_t ic = i < N ? i : N - 1;
-          vbuf[u] = getv(ic);
-          if (!is_float && W == 4) pbuf[u] = getv(ic ? ic - 1 : 0);
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-          const uint32_t r = (uint32_t)(ib - cb) + (uint32_t)u * WG;
-          okb[u] = r < cn ? (s_vb[r >> 5] >> (r & 31)) & 1 : false;
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint64_t i = ib + (uint64_t)u * WG;
-        if (i >= N) break;
-        const Val<W> v = vbuf[u];
-        const Val<W> kk = stat_key<W>(v, nk);
-        if (!bits_eq<W>(kk, k0)) f_neq0 = 1;
-        if (!okb[u]) nulls++;
-        if (!is_float) {
-            if (int_lt<W>(tmax, v, nk)) tmax = v;
-            if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(v, nk) < 0) f_neg = 1;
-            if (W == 4 && i > 0 && int_lt<W>(v, pbuf[u], nk)) f_unsorted = 1;
-        }
-        if constexpr (SMALL) {
-            const uint64_t x = k64(kk);
-            if (want_vote) {
-                if (vote_n == 0) {
-                    vote_k = x;
-                    vote_n = 1;
-                } else if (vote_k == x) {
-                    vote_n++;
-                } else {
-                    vote_n--;
-                }
-            }
-            if (want_set && s_kcnt <= KCAP) {
+    // Distinct keys (W <= 8): rows are not probed one by one.  Lane = row, so a run of equal values
+    // sits in neighbouring lanes: only the lanes whose raw bits differ from the lane before them
+    // (ballot) append their key to a small per-wave LDS buffer, and the buffer is probed into the
+    // hash set 64 keys at a time when it fills.  For run-heavy pages that is one probe pass per
+    // ~1000 rows instead of one per 64; the comparison with row 0's key (all_equal) rides along.
+    using KE = typename std::conditional<(W == 8), unsigned long long, uint32_t>::type;
+    constexpr uint32_t CBUF = 128;  // entries per wave
+    const int lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    KE* cbuf = (KE*)(sc.sample_mem + CH / 8) + wv * CBUF;
+    uint32_t ccount = 0;
+    auto flush = [&]() {
+        for (uint32_t base = 0; base < ccount; base += 64) {
+            const bool act = base + lane < ccount;
+            uint64_t raw = act ? (uint64_t)cbuf[base + lane] : 0;
+            Val<W> rv;
+            if constexpr (SMALL) __builtin_memcpy(&rv, &raw, W);
+            const Val<W> kk = stat_key<W>(rv, nk);
+            if (act && !bits_eq<W>(kk, k0)) f_neq0 = 1;
+            if (want_set && act && s_kcnt <= KCAP) {
+                const uint64_t x = k64(kk);
                 if (x == SENT) {
                     s_ksent = 1;
                 } else {
@@ -1512,9 +1492,69 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                 }
             }
         }
+        ccount = 0;
+    };
+    for (uint64_t cb = 0; cb < N; cb += CH) {
+     const uint32_t cn = (uint32_t)min((uint64_t)CH, N - cb);
+     __syncthreads();
+     if (t < (int)(CH / 32)) s_vb[t] = wv_next.word();
+     __syncthreads();
+     if (cb + CH < N) wv_next = vword(cb + CH);  // in flight while this chunk is processed
+     for (uint64_t ib0 = cb; ib0 < cb + cn; ib0 += (uint64_t)WG * U) {  // uniform trip count: wave-wide ops inside
+      const uint64_t ib = ib0 + t;
+      Val<W> vbuf[U], pbuf[U];
+      bool okb[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+          const uint64_t i = ib + (uint64_t)u * WG;
+          const uint64_t ic = i < N ? i : N - 1;
+          vbuf[u] = getv(ic);
+          if (!is_float && W == 4) pbuf[u] = getv(ic ? ic - 1 : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+          const uint32_t r = (uint32_t)(ib - cb) + (uint32_t)u * WG;
+          okb[u] = r < cn ? (s_vb[r >> 5] >> (r & 31)) & 1 : false;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint64_t i = ib + (uint64_t)u * WG;
+        const bool in = i < N;
+        const Val<W> v = vbuf[u];
+        if (in && !okb[u]) nulls++;
+        if (!is_float && in) {
+            if (int_lt<W>(tmax, v, nk)) tmax = v;
+            if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(v, nk) < 0) f_neg = 1;
+            if (W == 4 && i > 0 && int_lt<W>(v, pbuf[u], nk)) f_unsorted = 1;
+        }
+        if constexpr (SMALL) {
+            if (want_vote && in) {
+                const uint64_t x = k64(stat_key<W>(v, nk));
+                if (vote_n == 0) {
+                    vote_k = x;
+                    vote_n = 1;
+                } else if (vote_k == x) {
+                    vote_n++;
+                } else {
+                    vote_n--;
+                }
+            }
+            const KE raw = (KE)k64(v);
+            const KE prev = (KE)__shfl_up(raw, 1, 64);
+            const bool bnd = in && (lane == 0 || raw != prev);
+            const uint64_t bm = __ballot(bnd);
+            const uint32_t nb = (uint32_t)__popcll(bm);
+            if (ccount + nb > CBUF) flush();
+            if (bnd) cbuf[ccount + mbcnt64(bm)] = raw;
+            ccount += nb;
+        } else {
+            if (in && !bits_eq<W>(stat_key<W>(v, nk), k0)) f_neq0 = 1;
+        }
       }
      }
     }
+    if constexpr (SMALL) flush();
+    STL(1);
     const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
     const uint32_t null_count = wg_sum32(nulls, s4);
     const bool all_equal = !(flags & 1);
@@ -1574,6 +1614,7 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
         max_i64 = as_i64<W>(red[0], nk);
         __syncthreads();
     }
+    STL(2);
     const double tuple_count = (double)N;
     const double total_bytes = (double)(N * W);
     double max_ratio = o.ratio;
@@ -1661,12 +1702,14 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                 break;
             }
         }
+        STL(3 + oi);
         if (r > max_ratio) {
             max_ratio = r;
             result = c;
             if (r == tuple_count) break;
         }
     }
+    STL(10);
     return result;
 }
 
@@ -2025,7 +2068,9 @@ template <int KIND>
 __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
     __shared__ uint32_t s_misc[2 * WG + 16];
-    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16];
+    // sample area, also the streaming scratch of choose_prim: 1 KB validity words + 4 x 128 keys
+    constexpr int SMP = SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16, STR = 1024 + 4 * 128 * (KIND == 8 ? 8 : 4);
+    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SMP > STR ? SMP : STR];
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
     if (p.codec >= 0) return;

@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--columns", type=int, default=64, help="1 M-row columns per GPU in one batch")
+    ap.add_argument("--columns", type=int, default=256, help="1 M-row columns per GPU in one batch")
     ap.add_argument("--codec", default="adaptive", choices=["adaptive", "rle", "none", "dict"],
                     help="adaptive = default_compress_ratio 2.0, codec chosen per page on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")

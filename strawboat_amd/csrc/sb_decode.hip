@@ -776,6 +776,21 @@ __device__ __forceinline__ void emit_rows(uint8_t* dst, uint32_t rows, F get) {
     if constexpr (W < 16) {
         constexpr int RPL = 16 / W;
         if (((uintptr_t)dst & 15) == 0) {
+            if (rows == TILE_ROWS) {  // full tile: every gather of the thread is issued before its first store
+                constexpr int G = TILE_ROWS / RPL / WG;
+                Val<W> v[G][RPL];
+#pragma unroll
+                for (int j = 0; j < G; j++)
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) v[j][r] = get((uint32_t)(t + j * WG) * RPL + r);
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    u32x4 pk;
+                    __builtin_memcpy(&pk, v[j], 16);
+                    stu128(dst + (uint64_t)(t + j * WG) * 16, pk);
+                }
+                return;
+            }
             const uint32_t full = rows / RPL;
             for (uint32_t g = t; g < full; g += WG) {
                 Val<W> v[RPL];
@@ -783,7 +798,7 @@ __device__ __forceinline__ void emit_rows(uint8_t* dst, uint32_t rows, F get) {
                 for (int r = 0; r < RPL; r++) v[r] = get(g * RPL + r);
                 u32x4 pk;
                 __builtin_memcpy(&pk, v, 16);
-                *(u32x4*)(dst + (uint64_t)g * 16) = pk;
+                stu128(dst + (uint64_t)g * 16, pk);
             }
             for (uint32_t i = full * RPL + t; i < rows; i += WG) st_val<W>(dst + (uint64_t)i * W, get(i));
             return;

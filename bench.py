@@ -7,9 +7,11 @@ produced back (pages -> Arrow buffers), through the C ABI of libstrawboat_hip.so
 
 Workload at N=1 (BASELINE.json configs[1], "C2"): columns of 1 M-row nullable Float64,
 64 Ki-row pages, value = float(k) with k piecewise constant (run length ~ Geometric(mean 32),
-k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (default 64 =
-64 M rows, 520 MB of Arrow bytes) so that the working set exceeds the 256 MB Infinity Cache
-(SURVEY.md §8d).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
+k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (default 256 =
+256 M rows, 2.08 GB of Arrow bytes, 4096 pages): far beyond the 256 MB Infinity Cache
+(SURVEY.md §8d), and enough pages that the one-workgroup-per-page kernels run several rounds per
+CU instead of exactly one (with 64 columns = 1024 pages = 4 per CU every phase of every workgroup
+runs in lockstep and the fixed ~0.1 ms of small kernels and launch gaps weighs 20 %).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
 page is chosen on the device by the reference's selector (it picks RLE for this data: sampled
 ratio ~14 vs Dict 7.6; the CPU oracle agrees, tests/test_oracle_golden.py).  Freq and Patas have
 no device encoder yet and are in forbidden_compressions.

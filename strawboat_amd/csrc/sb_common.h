@@ -48,6 +48,10 @@ struct PageTask {
 struct TileTask {
     uint32_t page;
     uint32_t tile;
+    uint32_t col;  // = tasks[page].col: lets k_expand fetch its three descriptors in one round trip
+    uint32_t k0;   // RLE pages (k_plan): first run of the tile ...
+    uint32_t kend; // ... and one past its last run; 0 / 0 otherwise
+    uint32_t pad;
 };
 
 // result of parsing one page's headers (hdr9 = u8 codec | u32 compressed | u32 uncompressed,

@@ -40,6 +40,16 @@ __device__ __forceinline__ void push_job(InflateJob* q, uint32_t* cnt, const uin
 }
 
 // -------------------------------------------------------------------------------- parse
+#ifdef SB_TIMELINE  // scripts/micro/expand_timeline.hip: s_memtime stamps of one tile's phases
+__device__ unsigned long long* g_dtl;
+#define DTL(p)                                                                                           \
+    do {                                                                                                 \
+        if (g_dtl && blockIdx.x == 5000 && threadIdx.x == 0) g_dtl[(p)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DTL(p)
+#endif
+
 __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_pages) return;
@@ -54,6 +64,8 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
         TileTask tt;
         tt.page = p;
         tt.tile = i;
+        tt.col = t.col;
+        tt.k0 = tt.kend = tt.pad = 0;
         a.tiles[t.first_tile + i] = tt;
     }
 #define FAIL(code, tag)                   \
@@ -322,7 +334,8 @@ __device__ __forceinline__ uint32_t idx_aux_words(uint32_t codec, uint32_t n_run
 // RLE plan: scan the run counts of `body` (records of 4+W bytes) until they cover N rows.
 // Returns the number of runs (uniform).  LDS: s_a (SIDX_WORDS u32).
 __device__ uint32_t plan_rle(const uint8_t* body, uint32_t csize, uint32_t rec, uint64_t N, uint32_t* aux,
-                             uint32_t aux_cap_words, uint32_t* s_a, uint64_t* s_w64, Status* st, uint32_t page) {
+                             uint32_t aux_cap_words, uint32_t* s_a, uint64_t* s_w64, Status* st, uint32_t page,
+                             TileTask* page_tiles = nullptr) {
     const int t = threadIdx.x;
     const uint32_t max_runs = csize / rec;
     const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
@@ -395,6 +408,11 @@ __device__ uint32_t plan_rle(const uint8_t* body, uint32_t csize, uint32_t rec, 
     }
     (void)s_a;
     __syncthreads();
+    if (page_tiles)  // the tile's run range travels with its task: no dependent aux loads in k_expand
+        for (uint32_t tl = t; tl < ntiles; tl += WG) {
+            page_tiles[tl].k0 = tile_k0[tl];
+            page_tiles[tl].kend = tl + 1 < ntiles ? tile_k0[tl + 1] + 1 : R;
+        }
     return R;
 }
 
@@ -487,9 +505,38 @@ struct U32Stream {
     uint64_t N;
 };
 
+// The first 4*WG run starts of a tile, fetched ahead of time (RLE pages of ~32-row runs have ~130)
+struct RleStarts {
+    uint32_t st[4];
+};
+__device__ __forceinline__ RleStarts rle_fetch_starts(const uint32_t* aux, uint32_t k0, uint32_t kend) {
+    RleStarts r;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t k = k0 + 1 + threadIdx.x + j * WG;
+        r.st[j] = k < kend ? aux[k] : 0xFFFFFFFFu;
+    }
+    return r;
+}
+// s_a[row] <- index of the run covering row (relative to k0), via scatter of run starts + scan
+__device__ void rle_tile_runidx_k(const uint32_t* aux, uint32_t k0, uint32_t kend, uint32_t tile, uint32_t rows,
+                                  uint32_t* s_a, uint32_t* s_w, const RleStarts& pre) {
+    const int t = threadIdx.x;
+    const uint32_t r0 = tile * TILE_ROWS;
+    for (int i = t; i < SIDX_WORDS; i += WG) s_a[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (pre.st[j] >= r0 && pre.st[j] < r0 + rows) atomicAdd(&s_a[sidx((int)(pre.st[j] - r0))], 1u);
+    for (uint32_t k = k0 + 1 + t + 4 * WG; k < kend; k += WG) {
+        uint32_t s = aux[k];
+        if (s >= r0 && s < r0 + rows) atomicAdd(&s_a[sidx((int)(s - r0))], 1u);
+    }
+    __syncthreads();
+    tile_incl_scan(s_a, s_w);
+}
 __device__ void rle_tile_runidx(const uint32_t* aux, uint32_t R, uint64_t N, uint32_t tile, uint32_t rows,
                                 uint32_t* s_a, uint32_t* s_w) {
-    // s_a[row] <- index of the run covering row (relative to k0), via scatter of run starts + scan
     const int t = threadIdx.x;
     const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
     const uint32_t* tile_k0 = aux + R + 1;
@@ -668,7 +715,7 @@ __global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
         }
     } else if (d.codec == SB_CODEC_RLE) {  // runs see the rest of the buffer (integer/mod.rs:108-110)
         uint32_t R = plan_rle(d.body, (uint32_t)(page_end - d.body), 4 + c.width, N, aux, aux_cap, s_a, s_w64,
-                              a.status, p);
+                              a.status, p, a.tiles + t.first_tile);
         if (R == 0xFFFFFFFFu) d.ok = 0;
         d.n_runs = R;
         changed = true;
@@ -822,6 +869,15 @@ __device__ __forceinline__ void bitmap_put(uint8_t* bm, uint64_t pos, uint32_t v
 
 // copy rows [r0, r0+rows) of an LSB-first source bitmap (starting at bit 0 of src) to the
 // destination bitmap at bit (dst_bit0 + r0 ...)
+// 32 bits of a page's def-level section starting at (byte-aligned) bit `sb`
+__device__ __forceinline__ uint32_t tile_bits_load(const uint8_t* src, uint64_t sb, uint64_t src_total_bits) {
+    const uint8_t* p = src + (sb >> 3);
+    const uint64_t bytes_left = ((src_total_bits + 7) >> 3) - (sb >> 3);
+    if (bytes_left >= 4) return ldu32(p);
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < bytes_left; b++) v |= (uint32_t)p[b] << (8 * b);
+    return v;
+}
 __device__ __forceinline__ void tile_copy_bits(uint8_t* dst_bm, uint64_t dst_bit0, const uint8_t* src, uint64_t r0,
                                                uint32_t rows, uint64_t src_total_bits, bool aligned) {
     const int t = threadIdx.x;
@@ -844,7 +900,8 @@ __device__ __forceinline__ void tile_copy_bits(uint8_t* dst_bm, uint64_t dst_bit
 
 template <int W>
 __device__ void expand_prim(const ColDesc& c, const PageTask& t, const PageDesc& d, uint32_t tile, uint32_t rows,
-                            uint8_t* scratch, uint32_t* s_a, uint32_t* s_w, Status* st, uint32_t page) {
+                            uint8_t* scratch, uint32_t* s_a, uint32_t* s_w, Status* st, uint32_t page, uint32_t tk0,
+                            uint32_t tkend, const RleStarts& rle_pre) {
     const uint64_t r0 = (uint64_t)tile * TILE_ROWS;
     uint8_t* dst = c.values + (t.out_row + r0) * W;
     const uint32_t* aux = (const uint32_t*)(scratch + t.aux_off);
@@ -862,13 +919,15 @@ __device__ void expand_prim(const ColDesc& c, const PageTask& t, const PageDesc&
             break;
         }
         case SB_CODEC_RLE: {  // integer/rle.rs:106-134
-            rle_tile_runidx(aux, d.n_runs, t.num_values, tile, rows, s_a, s_w);
-            const uint32_t k0 = (aux + d.n_runs + 1)[tile];
+            rle_tile_runidx_k(aux, tk0, tkend, tile, rows, s_a, s_w, rle_pre);
+            DTL(3);
+            const uint32_t k0 = tk0;
             const uint8_t* body = d.body;
             emit_rows<W>(dst, rows, [&](uint32_t i) {
                 uint32_t k = k0 + s_a[sidx((int)i)];
                 return ld_val<W>(body + (uint64_t)k * (4 + W) + 4);
             });
+            DTL(4);
             break;
         }
         case SB_CODEC_DICT: {  // integer/dict.rs:75-103
@@ -1027,45 +1086,61 @@ __device__ __forceinline__ uint32_t xcd_tile_index() {
 }
 
 // primitives + booleans (17 KB LDS: 8 workgroups per CU)
+// Under a saturated memory system every dependent HBM round trip of a tile costs 2-3 us, and a
+// tile's chain is what bounds this kernel (8 workgroups per CU in flight).  So the chain is kept
+// short: the tile task carries the column index and, for RLE pages, the tile's run range (k_plan),
+// which lets the three descriptors, the validity word and the run starts be fetched in two steps;
+// only the gather of the run values follows.
 __global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
     __shared__ uint32_t s_a[SIDX_WORDS];
     __shared__ uint32_t s_w[4];
+    static_assert(TILE_ROWS / 32 <= WG, "one validity word per thread");
+    DTL(0);
     const TileTask tt = a.tiles[xcd_tile_index()];
     const PageDesc d = a.descs[tt.page];
-    if (!d.ok) return;
     const PageTask t = a.tasks[tt.page];
-    const ColDesc c = a.cols[t.col];
+    const ColDesc c = a.cols[tt.col];
+    if (!d.ok) return;
     if (is_binary(c.ptype)) return;  // k_expand_binary
     const uint64_t r0 = (uint64_t)tt.tile * TILE_ROWS;
     const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, t.num_values - r0);
-    if (d.def_bits) tile_copy_bits(c.validity, t.out_row, d.def_bits, r0, rows, t.num_values, c.bits_aligned);
+    DTL(1);
+    // issue the validity word and (RLE) the run starts together, consume them afterwards
+    const uint32_t g = threadIdx.x, ngroups = (rows + 31) / 32;
+    const bool has_vb = d.def_bits && g < ngroups;
+    uint32_t vb = 0;
+    if (has_vb) vb = tile_bits_load(d.def_bits, r0 + (uint64_t)g * 32, t.num_values);
+    RleStarts st;
+    if (d.codec == SB_CODEC_RLE && c.ptype != SB_TYPE_BOOLEAN)
+        st = rle_fetch_starts((const uint32_t*)(a.scratch + t.aux_off), tt.k0, tt.kend);
+    if (has_vb) bitmap_put(c.validity, t.out_row + r0 + (uint64_t)g * 32, vb, min(32u, rows - g * 32), c.bits_aligned);
+    DTL(2);
     if (c.ptype == SB_TYPE_BOOLEAN) {
         expand_bool(c, t, d, tt.tile, rows, a.scratch, s_a, s_w);
         return;
     }
     switch (c.width) {
         case 1:
-            expand_prim<1>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            expand_prim<1>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page, tt.k0, tt.kend, st);
             break;
         case 2:
-            expand_prim<2>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            expand_prim<2>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page, tt.k0, tt.kend, st);
             break;
         case 4:
-            expand_prim<4>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            expand_prim<4>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page, tt.k0, tt.kend, st);
             break;
         case 8:
-            expand_prim<8>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            expand_prim<8>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page, tt.k0, tt.kend, st);
             break;
         case 16:
-            expand_prim<16>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            expand_prim<16>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page, tt.k0, tt.kend, st);
             break;
         case 32:
-            expand_prim<32>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page);
+            expand_prim<32>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page, tt.k0, tt.kend, st);
             break;
     }
 }
 
-// Binary / Utf8 columns (two LDS arrays)
 __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
     __shared__ uint32_t s_a[SIDX_WORDS];
     __shared__ uint32_t s_len[SIDX_WORDS];

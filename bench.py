@@ -163,6 +163,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: algorithmic bytes / HIP-event time
         A = {"k_expand": page_bytes + U,            # A_dec = page bytes read + Arrow bytes written
+             "k_expand_rle": page_bytes + U,
              "k_enc_emit_pages": U + page_bytes,    # A_enc = Arrow bytes read + page bytes written
              "k_enc_emit_tiles": U + page_bytes,
              "k_enc_select": U}                     # the selector reads the Arrow buffers once

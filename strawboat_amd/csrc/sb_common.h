@@ -73,6 +73,8 @@ struct PageDesc {
     uint8_t ok;               // 1 = parsed, expand may run
     uint8_t pad;
     uint32_t n_runs;          // RLE: number of runs (filled by plan)
+    uint32_t tile_base;       // first entry of the page in the compact tile list (k_parse)
+    uint32_t pad2;
     uint64_t val_bytes;       // binary: value bytes this page produces
     uint64_t val_base;        // binary: first value byte of the page in the column output (colscan)
     uint64_t off_last;        // binary: last offset of the page as decoded (page relative)

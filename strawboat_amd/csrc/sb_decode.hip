@@ -50,6 +50,12 @@ __device__ unsigned long long* g_dtl;
 #define DTL(p)
 #endif
 
+// primitive RLE pages of <= 8-byte values are expanded by one workgroup per page (k_expand_rle)
+__device__ __forceinline__ bool rle_by_page(const ColDesc& c, const PageDesc& d) {
+    return d.ok && d.codec == SB_CODEC_RLE && c.ptype != SB_TYPE_BOOLEAN && c.ptype != SB_TYPE_NULL && !is_binary(c.ptype) &&
+           c.width <= 8;
+}
+
 __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_pages) return;
@@ -60,14 +66,6 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
     d.icodec = 255;
     const uint64_t N = t.num_values;
     const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
-    for (uint32_t i = 0; i < ntiles; i++) {
-        TileTask tt;
-        tt.page = p;
-        tt.tile = i;
-        tt.col = t.col;
-        tt.k0 = tt.kend = tt.pad = 0;
-        a.tiles[t.first_tile + i] = tt;
-    }
 #define FAIL(code, tag)                   \
     do {                                  \
         raise(a.status, (code), p, (tag)); \
@@ -210,6 +208,21 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
         }
     }
     d.ok = 1;
+    // Tile tasks for k_expand / k_expand_binary, appended to a compact list (job_counts[2] entries):
+    // pages that a page-level kernel expands (k_expand_rle) contribute none, so a batch of RLE pages
+    // does not launch tens of thousands of workgroups that only find out they have nothing to do.
+    if (!rle_by_page(c, d) && ntiles) {
+        const uint32_t base = atomicAdd(&a.job_counts[2], ntiles);
+        d.tile_base = base;
+        for (uint32_t i = 0; i < ntiles; i++) {
+            TileTask tt;
+            tt.page = p;
+            tt.tile = i;
+            tt.col = t.col;
+            tt.k0 = tt.kend = tt.pad = 0;
+            a.tiles[base + i] = tt;
+        }
+    }
     a.descs[p] = d;
 #undef FAIL
 }
@@ -713,9 +726,11 @@ __global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
             d.n_runs = R;
             changed = true;
         }
+    } else if (rle_by_page(c, d)) {
+        return;  // k_expand_rle walks the runs itself
     } else if (d.codec == SB_CODEC_RLE) {  // runs see the rest of the buffer (integer/mod.rs:108-110)
         uint32_t R = plan_rle(d.body, (uint32_t)(page_end - d.body), 4 + c.width, N, aux, aux_cap, s_a, s_w64,
-                              a.status, p, a.tiles + t.first_tile);
+                              a.status, p, a.tiles + d.tile_base);
         if (R == 0xFFFFFFFFu) d.ok = 0;
         d.n_runs = R;
         changed = true;
@@ -1096,7 +1111,8 @@ __global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
     __shared__ uint32_t s_w[4];
     static_assert(TILE_ROWS / 32 <= WG, "one validity word per thread");
     DTL(0);
-    const TileTask tt = a.tiles[xcd_tile_index()];
+    if (blockIdx.x >= a.job_counts[2]) return;  // (the grid is sized by the host's upper bound)
+    const TileTask tt = a.tiles[blockIdx.x];
     const PageDesc d = a.descs[tt.page];
     const PageTask t = a.tasks[tt.page];
     const ColDesc c = a.cols[tt.col];
@@ -1141,11 +1157,162 @@ __global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
     }
 }
 
+// ---- RLE pages of <= 8-byte values, one workgroup per page (integer/rle.rs:106-134, double/rle.rs:105-135).
+// The runs are walked in chunks of 4 per thread: counts are scanned into start rows (u64 carry, the
+// reference adds u32 counts until the page's row count is reached), the chunk's values are staged in
+// LDS, and the rows the chunk covers are written tile by tile: run starts scattered into a flag
+// array, scanned into a run index per row, values gathered from LDS, 16-byte stores.  No plan pass,
+// no run-start array in HBM, descriptors and validity handled once per page, and the next chunk of
+// records is already in flight while the current one is expanded.
+constexpr int RLE_RPT = 4;                      // runs per thread per chunk
+constexpr uint32_t RLE_CHUNK = WG * RLE_RPT;    // 1024 runs
+
+template <int W>
+__device__ void expand_rle_page(const ColDesc& c, const PageTask& t, const PageDesc& d, uint32_t* s_flag, uint8_t* s_vals_raw,
+                                uint32_t* s_w, uint64_t* s_w64, Status* st, uint32_t page) {
+    constexpr int REC = 4 + W;
+    const int tid = threadIdx.x;
+    const uint64_t N = t.num_values;
+    uint8_t* dst = c.values + t.out_row * W;
+    const uint8_t* body = d.body;
+    const uint8_t* page_end = c.pages + t.in_off + t.length;
+    const uint32_t max_runs = (uint32_t)((uint64_t)(page_end - body) / REC);
+    Val<W>* s_vals = (Val<W>*)s_vals_raw;
+    uint32_t ncnt[RLE_RPT];
+    Val<W> nval[RLE_RPT];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (int j = 0; j < RLE_RPT; j++) {
+            const uint32_t k = base + (uint32_t)tid * RLE_RPT + j;
+            const bool in = k < max_runs;
+            const uint8_t* r = body + (uint64_t)(in ? k : 0) * REC;
+            ncnt[j] = in ? ldu32(r) : 0;
+            nval[j] = in ? ld_val<W>(r + 4) : Val<W>{};
+        }
+    };
+    if (max_runs) fetch(0);
+    uint64_t carry = 0;  // rows covered by the chunks before this one
+    for (uint32_t base = 0; carry < N; base += RLE_CHUNK) {
+        if (base >= max_runs) {
+            if (tid == 0) raise(st, SB_ERR_IO, page, 200);  // runs end before N rows (read_u32 EOF upstream)
+            return;
+        }
+        uint32_t cnt[RLE_RPT];
+#pragma unroll
+        for (int j = 0; j < RLE_RPT; j++) {
+            cnt[j] = ncnt[j];
+            s_vals[tid * RLE_RPT + j] = nval[j];
+        }
+        if (base + RLE_CHUNK < max_runs) fetch(base + RLE_CHUNK);
+        // start rows of my runs
+        uint64_t loc[RLE_RPT], run = 0;
+#pragma unroll
+        for (int j = 0; j < RLE_RPT; j++) {
+            run += cnt[j];
+            loc[j] = run;
+        }
+        const uint64_t incl = wave_incl_scan64(run);
+        __syncthreads();  // previous chunk's readers of s_w64 / s_vals are done; my s_vals stores are ordered before the tile loop's barriers
+        if ((tid & 63) == 63) s_w64[tid >> 6] = incl;
+        __syncthreads();
+        uint64_t pre = carry + incl - run;
+        const int w = tid >> 6;
+        if (w > 0) pre += s_w64[0];
+        if (w > 1) pre += s_w64[1];
+        if (w > 2) pre += s_w64[2];
+        const uint64_t chunk_total = s_w64[0] + s_w64[1] + s_w64[2] + s_w64[3];
+        uint64_t start[RLE_RPT];
+#pragma unroll
+        for (int j = 0; j < RLE_RPT; j++) start[j] = pre + (j ? loc[j - 1] : 0);
+        const uint64_t S0 = carry, S1 = min(N, carry + chunk_total);
+        for (uint64_t tile_lo = S0 / TILE_ROWS * TILE_ROWS; tile_lo < S1; tile_lo += TILE_ROWS) {
+            const uint64_t lo = max(S0, tile_lo), hi = min(S1, tile_lo + TILE_ROWS);
+            for (int i = tid; i < SIDX_WORDS; i += WG) s_flag[i] = 0;
+            // A = (runs of the chunk that start at or before row lo) - 1: the run covering row lo
+            uint32_t le = 0;
+#pragma unroll
+            for (int j = 0; j < RLE_RPT; j++) le += (base + (uint32_t)tid * RLE_RPT + j < max_runs && start[j] <= lo) ? 1u : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < RLE_RPT; j++)
+                if (base + (uint32_t)tid * RLE_RPT + j < max_runs && start[j] > lo && start[j] < hi)
+                    atomicAdd(&s_flag[sidx((int)(start[j] - tile_lo))], 1u);
+            // workgroup sum of `le` (s_w is free until tile_incl_scan uses it)
+            uint32_t v = le;
+#pragma unroll
+            for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_down(v, dlt, 64);
+            if ((tid & 63) == 0) s_w[tid >> 6] = v;
+            __syncthreads();
+            const uint32_t A = s_w[0] + s_w[1] + s_w[2] + s_w[3] - 1;
+            __syncthreads();
+            tile_incl_scan(s_flag, s_w);
+            const uint32_t off = (uint32_t)(lo - tile_lo);
+            emit_rows<W>(dst + lo * W, (uint32_t)(hi - lo), [&](uint32_t i) {
+                const uint32_t k = A + s_flag[sidx((int)(off + i))];
+                return s_vals[k];
+            });
+            __syncthreads();  // s_flag / s_w are reused by the next tile
+        }
+        carry += chunk_total;
+        if (chunk_total == 0 && base + RLE_CHUNK >= max_runs && carry < N) {
+            if (tid == 0) raise(st, SB_ERR_IO, page, 200);
+            return;
+        }
+    }
+}
+
+// the page's def-level bits -> the column's validity bitmap (all tiles at once)
+__device__ void page_copy_bits(uint8_t* dst_bm, uint64_t dst_bit0, const uint8_t* src, uint64_t N, bool aligned) {
+    constexpr int U = 8;
+    const uint32_t nwords = (uint32_t)((N + 31) / 32);
+    for (uint32_t g0 = threadIdx.x; g0 < nwords; g0 += WG * U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t g = g0 + u * WG;
+            v[u] = g < nwords ? tile_bits_load(src, (uint64_t)g * 32, N) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t g = g0 + u * WG;
+            if (g < nwords) bitmap_put(dst_bm, dst_bit0 + (uint64_t)g * 32, v[u], (uint32_t)min((uint64_t)32, N - (uint64_t)g * 32), aligned);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WG) k_expand_rle(DecodeArgs a) {
+    __shared__ uint32_t s_flag[SIDX_WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_vals[RLE_CHUNK * 8];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint64_t s_w64[4];
+    const uint32_t p = blockIdx.x;
+    const PageDesc d = a.descs[p];
+    const PageTask t = a.tasks[p];
+    const ColDesc c = a.cols[t.col];
+    if (!rle_by_page(c, d)) return;
+    if (d.def_bits) page_copy_bits(c.validity, t.out_row, d.def_bits, t.num_values, c.bits_aligned);
+    switch (c.width) {
+        case 1:
+            expand_rle_page<1>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            break;
+        case 2:
+            expand_rle_page<2>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            break;
+        case 4:
+            expand_rle_page<4>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            break;
+        default:
+            expand_rle_page<8>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            break;
+    }
+}
+
 __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
     __shared__ uint32_t s_a[SIDX_WORDS];
     __shared__ uint32_t s_len[SIDX_WORDS];
     __shared__ uint32_t s_w[4];
-    const TileTask tt = a.tiles[xcd_tile_index()];
+    if (blockIdx.x >= a.job_counts[2]) return;
+    const TileTask tt = a.tiles[blockIdx.x];
     const PageDesc d = a.descs[tt.page];
     if (!d.ok) return;
     const PageTask t = a.tasks[tt.page];
@@ -1163,7 +1330,7 @@ __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
 // -------------------------------------------------------------------------------- launcher
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 3 * sizeof(uint32_t), s);
     {
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
@@ -1184,6 +1351,10 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k(ctx, K_INFLATE_B);
         k_inflate<<<min(a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
     }
+    if (any_prim) {
+        KScope k(ctx, K_EXPAND_RLE);
+        k_expand_rle<<<a.n_pages, WG, 0, s>>>(a);
+    }
     if (a.n_tiles && any_prim) {
         KScope k(ctx, K_EXPAND);
         k_expand<<<a.n_tiles, WG, 0, s>>>(a);
@@ -1196,7 +1367,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
 
 void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 2 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 3 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);

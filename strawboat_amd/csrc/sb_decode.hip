@@ -1225,6 +1225,11 @@ __device__ void expand_rle_page(const ColDesc& c, const PageTask& t, const PageD
 #pragma unroll
         for (int j = 0; j < RLE_RPT; j++) start[j] = pre + (j ? loc[j - 1] : 0);
         const uint64_t S0 = carry, S1 = min(N, carry + chunk_total);
+        // the run that reaches row N must end exactly there: upstream pushes whole runs and then
+        // asserts the decoded length (read/array/integer.rs:81)
+#pragma unroll
+        for (int j = 0; j < RLE_RPT; j++)
+            if (start[j] < N && start[j] + cnt[j] > N) raise(st, SB_ERR_OUT_OF_SPEC, page, 202);
         for (uint64_t tile_lo = S0 / TILE_ROWS * TILE_ROWS; tile_lo < S1; tile_lo += TILE_ROWS) {
             const uint64_t lo = max(S0, tile_lo), hi = min(S1, tile_lo + TILE_ROWS);
             for (int i = tid; i < SIDX_WORDS; i += WG) s_flag[i] = 0;

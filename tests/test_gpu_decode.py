@@ -112,3 +112,50 @@ def test_corrupt_codec_raises(gpu_ctx):
     with pytest.raises(NativeError) as e:
         gpu_decode(gpu_ctx, col, pages, metas)
     assert e.value.code == -1
+
+
+# ---- hand-built RLE pages: what the page-level RLE kernel must get right beyond oracle-written data
+def _rle_page(runs, w, dtype):
+    body = b"".join(int(c).to_bytes(4, "little") + np.array([v], dtype).tobytes() for c, v in runs)
+    return np.frombuffer(bytes([S.RLE]) + len(body).to_bytes(4, "little") + (0).to_bytes(4, "little") + body, np.uint8)
+
+
+def _decode_rle_pages(ctx, ptype, page_list, rows_list):
+    import torch
+    from strawboat_amd import read
+    pages = np.concatenate(page_list)
+    metas = np.array([[p.size, n] for p, n in zip(page_list, rows_list)], np.uint64)
+    cp = read.ColumnPages(ptype, False, torch.from_numpy(pages).to(ctx.torch_device), metas)
+    got = read.read_simple(ctx, cp)
+    want = S.read_column(ptype, False, pages, metas)
+    assert got.rows == want["rows"] == sum(rows_list)
+    assert np.array_equal(got.values_numpy(), want["values"])
+    return got
+
+
+@pytest.mark.parametrize("ptype,dtype,w", [(S.T_U8, np.uint8, 1), (S.T_I16, np.int16, 2), (S.T_I32, np.int32, 4),
+                                           (S.T_F64, np.float64, 8)])
+def test_rle_hand_built_pages(gpu_ctx, ptype, dtype, w):
+    rng = np.random.default_rng(5)
+    # zero-count runs, a run that overshoots the page, > 1024 runs (several chunks), rows % 4096 != 0
+    runs = [(0, 99), (3, 1), (0, 2), (0, 3), (5000, 4)] + [(int(c), int(v)) for c, v in zip(rng.integers(0, 9, 3000), rng.integers(0, 100, 3000))]
+    n1 = sum(c for c, _ in runs)
+    one = [(12345, 42)]                       # a page that is one run
+    # three pages with odd row counts: the second and third start at odd output rows; trailing runs
+    # after the page is full are never read (the decoder stops at N rows)
+    _decode_rle_pages(gpu_ctx, ptype, [_rle_page(runs, w, dtype), _rle_page(one + [(7, 1)], w, dtype), _rle_page(runs[:50], w, dtype)],
+                      [n1, 12345, sum(c for c, _ in runs[:50])])
+
+
+def test_rle_run_overshooting_the_page_is_out_of_spec(gpu_ctx):
+    from strawboat_amd._native import NativeError
+    with pytest.raises(NativeError) as e:  # upstream: assert on the decoded length (read/array/integer.rs:81)
+        _decode_rle_pages(gpu_ctx, S.T_I64, [_rle_page([(10, 1), (10, 2)], 8, np.int64)], [16])
+    assert e.value.code == -1
+
+
+def test_rle_runs_end_before_the_page_is_full(gpu_ctx):
+    from strawboat_amd._native import NativeError
+    with pytest.raises(NativeError) as e:  # read_u32 hits EOF upstream (integer/rle.rs:128-131)
+        _decode_rle_pages(gpu_ctx, S.T_I32, [_rle_page([(10, 1), (0, 2), (5, 3)], 4, np.int32)], [16])
+    assert e.value.code == -3

@@ -1,0 +1,110 @@
+"""BASELINE.json's configurations at their full per-GPU sizes (SURVEY.md §8d inputs): the pages the
+device writes equal the oracle's byte for byte (same options, same sampling seed), and the device
+decodes them back to the Arrow buffers they came from.
+
+  C1  1 M-row non-nullable Int64, one page, no compression
+  C3  1 M-row Utf8, zipf(1.1) over 10 000 words of length 4..24, LZ4 default, ratio 2.0 -> Dict pages
+  C4  the per-GPU shard of the mixed schema: Int32 / Float64 / Utf8 / Boolean columns, 64 Ki-row pages,
+      LZ4 default, ratio 2.0 (1 M rows per column here; the 10 M-row job is the same pages x 10)
+  C5  1 M-row List<Struct<Int64, Utf8>>, Zstd default, whole-file round trip
+(C2 is tests/test_gpu_select.py::test_c2_adaptive and bench.py itself.)"""
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+from tests.test_gpu_decode import gpu_decode
+from tests.test_gpu_encode import gpu_encode
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 1_000_000
+NOT_ON_DEVICE = (S.FREQ, S.PATAS)
+
+
+def encode_matches_oracle_and_round_trips(ctx, col, **opt):
+    want_pages, want_metas = gen.oracle_write(col, **opt)
+    enc = gpu_encode(ctx, col, **opt)
+    assert np.array_equal(enc.metas_array(), want_metas)
+    assert np.array_equal(enc.pages_numpy(), want_pages), "page bytes differ from the oracle's"
+    got = gpu_decode(ctx, col, want_pages, want_metas)
+    want = gen.oracle_read(col, want_pages, want_metas)
+    assert got.rows == col["rows"]
+    assert np.array_equal(got.values_numpy(), want["values"])
+    if col["nullable"]:
+        assert np.array_equal(got.validity_numpy(), want["validity"])
+    if col["offsets"] is not None:
+        assert np.array_equal(got.offsets_numpy(), want["offsets"])
+    return S.stat_column(col["ptype"], col["nullable"], want_pages, want_metas)[0]
+
+
+def zipf_utf8(rows, seed, null_density=None):
+    rng = np.random.default_rng(seed)
+    vocab = [("w%d" % k).ljust(int(rng.integers(4, 25)), "x").encode() for k in range(10_000)]
+    rank = np.minimum(rng.zipf(1.1, rows), 10_000) - 1
+    lens = np.array([len(v) for v in vocab], np.int64)[rank]
+    offs = np.zeros(rows + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"".join(vocab[i] for i in rank), np.uint8).copy()
+    validity = gen.make_validity(rng, rows, null_density)
+    return dict(ptype=S.T_BIN32, nullable=True, rows=rows, values=data, validity=validity, offsets=offs.astype(np.int32))
+
+
+def test_c1_int64_one_page_no_compression(gpu_ctx):
+    rng = np.random.default_rng(42)
+    col = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=rng.integers(0, 2**63 - 1, ROWS), validity=None, offsets=None)
+    codecs = encode_matches_oracle_and_round_trips(gpu_ctx, col)
+    assert codecs.tolist() == [S.NONE]
+
+
+def test_c3_utf8_zipf_dict_lz4(gpu_ctx):
+    col = zipf_utf8(ROWS, 42)
+    codecs = encode_matches_oracle_and_round_trips(gpu_ctx, col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0,
+                                                   forbidden=NOT_ON_DEVICE)
+    assert (codecs == S.DICT).all()
+    # and the forced Basic(LZ4) variant: offsets block + values block
+    encode_matches_oracle_and_round_trips(gpu_ctx, zipf_utf8(200_000, 7), max_page_size=65536, default_compression=S.LZ4)
+
+
+@pytest.mark.parametrize("kind", ["int32", "float64", "utf8", "boolean"])
+def test_c4_mixed_schema_shard(gpu_ctx, kind):
+    import bench
+    rng = np.random.default_rng(42)
+    if kind == "int32":
+        col = dict(ptype=S.T_I32, nullable=True, rows=ROWS, values=rng.integers(0, 1000, ROWS).astype(np.int32),
+                   validity=None, offsets=None)
+    elif kind == "float64":
+        vals, valid = bench.gen_c2_column(43)
+        col = dict(ptype=S.T_F64, nullable=True, rows=vals.size, values=vals, validity=valid, offsets=None)
+    elif kind == "utf8":
+        col = zipf_utf8(ROWS, 44, null_density=0.1)
+    else:
+        col = gen.boolean(ROWS, null_density=0.1, seed=45)
+    encode_matches_oracle_and_round_trips(gpu_ctx, col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0,
+                                          forbidden=NOT_ON_DEVICE)
+
+
+def test_c5_nested_list_struct_zstd_file(gpu_ctx, tmp_path):
+    import pyarrow as pa
+    from strawboat_amd import WriteOptions, file as F
+    from strawboat_amd.types import Compression as C
+    rng = np.random.default_rng(42)
+    list_valid = rng.random(ROWS) > 0.1
+    lens = np.where(list_valid, rng.integers(0, 3, ROWS), 0)            # Uniform{0,1,2}, null lists are empty
+    offs = np.zeros(ROWS + 1, np.int32)
+    np.cumsum(lens, out=offs[1:])
+    n = int(offs[-1])
+    a = pa.array(rng.integers(-2**40, 2**40, n), mask=rng.random(n) < 0.2)
+    words = np.array(["s%d" % k for k in range(500)], dtype=object)
+    b = pa.array(words[rng.integers(0, 500, n)], mask=rng.random(n) < 0.2)
+    st = pa.StructArray.from_arrays([a, b], fields=[pa.field("a", pa.int64()), pa.field("b", pa.string())])
+    col = pa.ListArray.from_arrays(pa.array(offs), st, mask=pa.array(~list_valid))
+    t = pa.Table.from_arrays([col], schema=pa.schema([pa.field("ls", col.type)]))
+    path = tmp_path / "c5.sb"
+    with F.NativeWriter(gpu_ctx, path, t.schema, WriteOptions(max_page_size=65536, default_compression=C.ZSTD)) as w:
+        w.start()
+        w.write(t)
+        w.finish()
+        assert [len(m.pages) for m in w.metas] == [16, 16]          # 2 leaf columns x 16 pages
+    got = F.read_table(gpu_ctx, path)
+    assert got.column("ls").combine_chunks().equals(t.column("ls").combine_chunks())

@@ -306,6 +306,72 @@ __device__ void lz4_inflate_wave(const InflateJob& j, Status* st) {
 // per-wave Zstd literal buffers (zlit) are a fixed pool too
 constexpr uint32_t INFLATE_POOL = 1024;
 constexpr uint32_t ZLIT_STRIDE = 128 * 1024 + 64;
+// Snappy raw format (basic.rs:99-106 -> snap::raw::Decoder [3P]): uvarint length, then literal /
+// copy elements.  Same shape as the LZ4 decoder: elements are parsed wave-uniformly, the byte
+// copies are spread over the 64 lanes.
+__device__ void snappy_inflate_wave(const InflateJob& j, Status* st) {
+    const int lane = threadIdx.x & 63;
+    const uint8_t* src = j.src;
+    uint8_t* dst = j.dst;
+    const uint32_t n = j.csize, out_len = j.out_len;
+    uint32_t ip = 0, op = 0;
+    auto bad = [&](uint32_t tag) {
+        if (lane == 0) raise(st, SB_ERR_EXTERNAL, j.page, tag);
+    };
+    uint64_t ulen = 0;
+    for (uint32_t sh = 0;; sh += 7) {
+        if (ip >= n || sh > 28) return bad(130);
+        const uint32_t b = src[ip++];
+        ulen |= (uint64_t)(b & 0x7F) << sh;
+        if (!(b & 0x80)) break;
+    }
+    if (ulen != out_len) return bad(131);
+    while (ip < n) {
+        const uint32_t tag = src[ip++];
+        uint32_t len, off = 0;
+        if ((tag & 3) == 0) {  // literal
+            len = tag >> 2;
+            if (len >= 60) {
+                const uint32_t nb = len - 59;
+                if (n - ip < nb) return bad(132);
+                len = 0;
+                for (uint32_t k = 0; k < nb; k++) len |= (uint32_t)src[ip + k] << (8 * k);
+                ip += nb;
+            }
+            len += 1;
+            if (len > n - ip || len > out_len - op) return bad(133);
+            for (uint32_t i = lane; i < len; i += 64) dst[op + i] = src[ip + i];
+            ip += len;
+            op += len;
+            continue;
+        }
+        if ((tag & 3) == 1) {
+            if (n - ip < 1) return bad(134);
+            len = ((tag >> 2) & 7) + 4;
+            off = ((tag >> 5) << 8) | src[ip];
+            ip += 1;
+        } else if ((tag & 3) == 2) {
+            if (n - ip < 2) return bad(135);
+            len = (tag >> 2) + 1;
+            off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8);
+            ip += 2;
+        } else {
+            if (n - ip < 4) return bad(136);
+            len = (tag >> 2) + 1;
+            off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16) | ((uint32_t)src[ip + 3] << 24);
+            ip += 4;
+        }
+        if (off == 0 || off > op || len > out_len - op) return bad(137);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's earlier stores -> its loads
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint8_t* hist = dst + op - off;
+        for (uint32_t i = lane; i < len; i += 64) dst[op + i] = hist[off >= len ? i : i % off];
+        op += len;
+    }
+    if (op != out_len) bad(138);
+}
+
 __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st,
                                                 uint8_t* zlit) {
     __shared__ ZWork wk;
@@ -318,8 +384,10 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
             zstd_inflate_wave(j.src, j.csize, j.dst, j.out_len, &wk, zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE);
             if (threadIdx.x == 0 && wk.err) raise(st, SB_ERR_EXTERNAL, j.page, 120 + (uint32_t)wk.err);
             __syncthreads();
+        } else if (j.codec == SB_CODEC_SNAPPY) {
+            snappy_inflate_wave(j, st);
         } else if (threadIdx.x == 0) {
-            raise(st, SB_ERR_NYI, j.page, 110);  // Snappy blocks: not on the device yet
+            raise(st, SB_ERR_OUT_OF_SPEC, j.page, 110);
         }
     }
 }

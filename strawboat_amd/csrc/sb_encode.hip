@@ -93,7 +93,8 @@ __device__ __forceinline__ int32_t codec_of(const EncodeArgs& a, const EncPage& 
     return p.codec >= 0 ? p.codec : a.codecs[page];
 }
 __device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
-    return codec == SB_CODEC_NONE || codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD || codec == SB_CODEC_RLE || codec == SB_CODEC_DICT ||
+    return codec == SB_CODEC_NONE || codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD || codec == SB_CODEC_SNAPPY || codec == SB_CODEC_RLE ||
+           codec == SB_CODEC_DICT ||
            codec == SB_CODEC_ONEVALUE || codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING;
 }
 
@@ -1019,6 +1020,36 @@ __device__ uint32_t lz4_compress_wave(const uint8_t* src, uint32_t n, uint8_t* d
 }
 
 __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);
+// Snappy raw stream made of one literal element (uvarint length | literal tag + length | bytes): what
+// snap::raw::Decoder (basic.rs:99-106) and sb's own decoder read back; no matching is attempted.
+__device__ uint32_t snappy_store_wg(const uint8_t* src, uint32_t n, uint8_t* dst) {
+    uint32_t op = 0;
+    uint32_t v = n;
+    while (v >= 0x80) {
+        if (threadIdx.x == 0) dst[op] = (uint8_t)(v | 0x80);
+        v >>= 7;
+        op++;
+    }
+    if (threadIdx.x == 0) dst[op] = (uint8_t)v;
+    op++;
+    if (n == 0) return op;
+    const uint32_t m = n - 1;
+    if (m < 60) {
+        if (threadIdx.x == 0) dst[op] = (uint8_t)(m << 2);
+        op += 1;
+    } else {
+        const uint32_t nb = m < (1u << 8) ? 1 : m < (1u << 16) ? 2 : m < (1u << 24) ? 3 : 4;
+        if (threadIdx.x == 0) {
+            dst[op] = (uint8_t)((59 + nb) << 2);
+            for (uint32_t k = 0; k < nb; k++) dst[op + 1 + k] = (uint8_t)(m >> (8 * k));
+        }
+        op += 1 + nb;
+    }
+    wg_copy(dst + op, src, n);
+    __syncthreads();
+    return op + n;
+}
+
 
 // ------------------------------------------------------------------------------ u32 blocks (nested)
 // compress_integer::<u32> of an index array without validity: hdr9 + body.  Returns bytes written.
@@ -1047,6 +1078,10 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
         case SB_CODEC_ZSTD:
             __syncthreads();
             body = zstd_store_frame_wg((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, s_w);
+            break;
+        case SB_CODEC_SNAPPY:
+            __syncthreads();
+            body = snappy_store_wg((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9);
             break;
         case SB_CODEC_LZ4: {  // Basic(Lz4) over the raw index bytes (integer/mod.rs:55-58)
             __syncthreads();
@@ -2287,7 +2322,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
     const int32_t bc = codec_of(a, p, page);
-    if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD) return;
+    if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD && bc != SB_CODEC_SNAPPY) return;
     const EncCol c = a.cols[p.col];
     if (c.ptype == SB_TYPE_NULL) return;
     uint8_t* slot = page_slot(a, c, p);
@@ -2304,6 +2339,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     auto compress = [&](const uint8_t* src, uint32_t n, uint8_t* dst) -> uint32_t {
         __syncthreads();
         if (bc == SB_CODEC_ZSTD) return zstd_store_frame_wg(src, n, dst, tab);
+        if (bc == SB_CODEC_SNAPPY) return snappy_store_wg(src, n, dst);
         uint32_t sz = 0;
         if (threadIdx.x < 64) sz = lz4_compress_wave(src, n, dst, tab);
         if (threadIdx.x == 0) s_sz = sz;
@@ -2708,15 +2744,16 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 while (M < 2 * N) M <<= 1;
                 p.aux_bytes = (M + 3 * N) * 4;
             }
-            if (codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD ||
-                (adaptive && (opts->default_compression == SB_CODEC_LZ4 || opts->default_compression == SB_CODEC_ZSTD))) {
+            if (codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD || codec == SB_CODEC_SNAPPY ||
+                (adaptive && (opts->default_compression == SB_CODEC_LZ4 || opts->default_compression == SB_CODEC_ZSTD ||
+                              opts->default_compression == SB_CODEC_SNAPPY))) {
                 any_lz4 = true;  // staging for re-based offsets / re-packed bitmaps
                 const uint64_t st = bin ? (N + 1) * d.width + 16 : (c.physical_type == SB_TYPE_BOOLEAN ? (N + 7) / 8 + 16 : 0);
                 if (st > p.aux_bytes) p.aux_bytes = st;
             }
             if (codec == SB_CODEC_NONE || (adaptive && opts->default_compression == SB_CODEC_NONE))
                 any_tiles = true;
-            if (codec != SB_CODEC_NONE && codec != SB_CODEC_LZ4 && codec != SB_CODEC_ZSTD) any_pages = true;
+            if (codec != SB_CODEC_NONE && codec != SB_CODEC_LZ4 && codec != SB_CODEC_ZSTD && codec != SB_CODEC_SNAPPY) any_pages = true;
             if (p.head_bytes) any_compact = true;  // k_enc_compact also places the heads
             r += N;
             if (N == 0 && !c.page_rows) break;

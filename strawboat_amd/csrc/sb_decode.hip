@@ -175,8 +175,13 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             if (w != 4 || c.ptype == SB_TYPE_FLOAT32) FAIL(SB_ERR_OUT_OF_SPEC, 23);
             if (N % 128 != 0) FAIL(SB_ERR_OUT_OF_SPEC, 24);  // whole blocks only (bp.rs:72-84)
         } else if (codec == SB_CODEC_RLE || codec == SB_CODEC_DICT) {
+        } else if (codec == SB_CODEC_PATAS) {
+            if (c.ptype == SB_TYPE_FLOAT32) FAIL(SB_ERR_NYI, 26);   // f32 Patas decode is broken upstream
+            if (c.ptype != SB_TYPE_FLOAT64) FAIL(SB_ERR_OUT_OF_SPEC, 27);  // "Unknown compression codec Patas for integer"
+            push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
+            d.src = nullptr;
         } else {
-            FAIL(SB_ERR_NYI, 25);  // Freq / Patas pages take the host path for now
+            FAIL(SB_ERR_NYI, 25);  // Freq pages take the host path for now
         }
     }
     if (codec == SB_CODEC_DICT && c.ptype != SB_TYPE_BOOLEAN) {
@@ -372,9 +377,108 @@ __device__ void snappy_inflate_wave(const InflateJob& j, Status* st) {
     if (op != out_len) bad(138);
 }
 
+// Patas pages of f64 (double/patas.rs:106-133): first value, then per value `u16 packed | sig bytes`,
+// packed = ref_diff << 9 | (sig_bytes & 7) << 6 | trailing_zeros; value = (bits << tz) ^ out[i - diff].
+// Record positions are a pointer chase and references may chain, so a wave takes 64 values at a time:
+// the window of input bytes is staged in LDS, lane 0 walks the record boundaries there, every lane
+// then decodes its own record, and references are resolved in rounds (a lane is done once the lane
+// or earlier output it refers to is).  Runs as an inflate job straight into the column's values.
+__device__ void patas_inflate_wave(const InflateJob& j, Status* st, uint8_t* s_win /* 64*10+8 */, uint16_t* s_pos /* 65 */) {
+    const int lane = threadIdx.x & 63;
+    const uint8_t* src = j.src;
+    unsigned long long* out = (unsigned long long*)j.dst;
+    const uint32_t n = j.csize;
+    const uint64_t N = j.out_len / 8;
+    auto bad = [&](uint32_t tag) {
+        if (lane == 0) raise(st, SB_ERR_OUT_OF_SPEC, j.page, tag);
+    };
+    if (N == 0) return bad(140);  // upstream indexes the first value unconditionally
+    if (n < 8) return bad(141);
+    if (lane == 0) out[0] = ldu64(src);
+    uint32_t ip = 8;
+    for (uint64_t base = 1; base < N; base += 64) {
+        const uint32_t nb = (uint32_t)min((uint64_t)64, N - base);
+        const uint32_t wl = min(nb * 10, n - ip);  // bytes of input that can belong to this batch
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < wl; i += 64) s_win[i] = src[ip + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) {  // record boundaries
+            uint32_t pos = 0;
+            bool ok = true;
+            for (uint32_t k = 0; k < nb; k++) {
+                s_pos[k] = (uint16_t)pos;
+                if (pos + 2 > wl) {
+                    ok = false;
+                    break;
+                }
+                const uint32_t pk = (uint32_t)s_win[pos] | ((uint32_t)s_win[pos + 1] << 8);
+                uint32_t sb = (pk >> 6) & 7;
+                if ((pk & 0x3F) < 63 && sb == 0) sb = 8;  // unpack (patas.rs:152-163)
+                pos += 2 + sb;
+                if (pos > wl) {
+                    ok = false;
+                    break;
+                }
+            }
+            s_pos[64] = ok ? (uint16_t)pos : (uint16_t)0xFFFF;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t used = s_pos[64];
+        if (used == 0xFFFF) return bad(142);  // truncated page (read_exact EOF upstream)
+        // my record
+        const bool act = (uint32_t)lane < nb;
+        uint64_t sval = 0;
+        uint32_t diff = 1;
+        if (act) {
+            const uint32_t pos = s_pos[lane];
+            const uint32_t pk = (uint32_t)s_win[pos] | ((uint32_t)s_win[pos + 1] << 8);
+            diff = (pk >> 9) & 0x7F;
+            uint32_t sb = (pk >> 6) & 7;
+            const uint32_t tz = pk & 0x3F;
+            if (tz < 63 && sb == 0) sb = 8;
+            uint64_t v = 0;
+            for (uint32_t b = 0; b < sb; b++) v |= (uint64_t)s_win[pos + 2 + b] << (8 * b);
+            sval = v << tz;
+        }
+        const uint64_t i = base + lane;
+        const bool bad_ref = act && (diff == 0 || diff > i);
+        if (__ballot(bad_ref)) return bad(143);
+        // references: earlier batches come from memory, in-batch ones from the lane that holds them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint64_t ref = act ? i - diff : 0;
+        const bool outside = ref < base;
+        uint64_t x = 0;
+        bool done = !act;
+        if (act && outside) {
+            x = sval ^ __hip_atomic_load(&out[ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            done = true;
+        }
+        const int srcl = act && !outside ? (int)(ref - base) : 0;
+        for (;;) {
+            const uint64_t dm = __ballot(done);
+            if (dm == ~0ull) break;
+            const uint64_t px = __shfl(x, srcl, 64);
+            if (!done && ((dm >> srcl) & 1)) {
+                x = sval ^ px;
+                done = true;
+            }
+        }
+        if (act) out[i] = x;
+        ip += used;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st,
                                                 uint8_t* zlit) {
     __shared__ ZWork wk;
+    __shared__ uint8_t s_win[64 * 10 + 8];
+    __shared__ uint16_t s_pos[65];
     const uint32_t njobs = *count;
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
@@ -386,6 +490,8 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
             __syncthreads();
         } else if (j.codec == SB_CODEC_SNAPPY) {
             snappy_inflate_wave(j, st);
+        } else if (j.codec == SB_CODEC_PATAS) {
+            patas_inflate_wave(j, st, s_win, s_pos);
         } else if (threadIdx.x == 0) {
             raise(st, SB_ERR_OUT_OF_SPEC, j.page, 110);
         }

@@ -10,6 +10,7 @@ namespace sb {
 
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len);
 void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len);
+void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, const uint64_t* ex_off, const uint8_t* ex_base);
 
 static const char* const KERNEL_NAMES[K_COUNT] = {"k_parse", "k_inflate", "k_plan", "k_colscan", "k_inflate(values)",
                                                   "k_expand", "k_expand_binary", "k_enc_emit_tiles",
@@ -149,6 +150,7 @@ void sb_ctx_destroy(sb_ctx* ctx) {
         (void)hipEventDestroy(sp.b);
     }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    for (auto& l : ctx->freq_logs) (void)hipFree(l.dev);
     if (ctx->tables.p) (void)hipFree(ctx->tables.p);
     if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
     if (ctx->staging.p) (void)hipFree(ctx->staging.p);
@@ -161,6 +163,85 @@ void sb_ctx_destroy(sb_ctx* ctx) {
 
 const char* sb_ctx_last_error(sb_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 void* sb_ctx_stream(sb_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem, bool sizes_only);
+
+// Freq pages (integer/freq.rs:90-127) found by the decode calls of this synchronize interval: their
+// exception blocks are ordinary BLOCK<T>s, so they go through the decoder once more as one-page
+// columns that land in a temporary buffer; k_freq_scatter then writes them over the top value.
+// Only runs when k_parse logged a Freq page; costs one 4-byte readback per log otherwise.
+static int32_t freq_second_pass(sb_ctx* ctx) {
+    struct Batch {
+        const FreqEntry* d_entries;
+        uint32_t n;
+        uint8_t* ex_base;
+        uint64_t* d_off;
+    };
+    std::vector<Batch> batches;
+    ctx->freq_cols.clear();
+    ctx->freq_metas.clear();
+    for (auto& log : ctx->freq_logs) {
+        if (!log.reserved) continue;
+        log.reserved = 0;
+        uint32_t cnt = 0;
+        if (hipMemcpy(&cnt, log.dev, 4, hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(SB_ERR_EXTERNAL, "freq log readback failed");
+        if (cnt == 0) continue;
+        (void)hipMemsetAsync(log.dev, 0, 16, ctx->stream);
+        cnt = std::min(cnt, log.cap);
+        std::vector<FreqEntry> ents(cnt);
+        if (hipMemcpy(ents.data(), log.dev + 16, (size_t)cnt * sizeof(FreqEntry), hipMemcpyDeviceToHost) != hipSuccess)
+            return ctx->fail(SB_ERR_EXTERNAL, "freq log readback failed");
+        std::vector<uint64_t> ex_off(cnt);
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < cnt; i++) {
+            ex_off[i] = total;
+            total += ((uint64_t)ents[i].n_exceptions * ents[i].width + 15) / 16 * 16;
+        }
+        Batch b;
+        b.d_entries = (const FreqEntry*)(log.dev + 16);
+        b.n = cnt;
+        if (hipMalloc((void**)&b.ex_base, total + 64) != hipSuccess) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(freq exceptions) failed");
+        ctx->temp_dev.push_back(b.ex_base);
+        if (hipMalloc((void**)&b.d_off, (size_t)cnt * 8) != hipSuccess) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(freq offsets) failed");
+        ctx->temp_dev.push_back(b.d_off);
+        if (hipMemcpy(b.d_off, ex_off.data(), (size_t)cnt * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return ctx->fail(SB_ERR_EXTERNAL, "freq offsets upload failed");
+        for (uint32_t i = 0; i < cnt; i++) {
+            sb_column_read c;
+            memset(&c, 0, sizeof c);
+            c.physical_type = (int32_t)ents[i].ptype;
+            c.is_nullable = 0;
+            c.pages = ents[i].nested;
+            c.pages_len = ents[i].nested_len;
+            c.n_pages = 1;
+            c.values = b.ex_base + ex_off[i];
+            c.values_capacity = (uint64_t)ents[i].n_exceptions * ents[i].width;
+            ctx->freq_cols.push_back(c);
+            sb_page_meta m;
+            m.length = ents[i].nested_len;
+            m.num_values = ents[i].n_exceptions;
+            ctx->freq_metas.push_back(m);
+        }
+        batches.push_back(b);
+    }
+    if (batches.empty()) return SB_OK;
+    for (size_t i = 0; i < ctx->freq_cols.size(); i++) ctx->freq_cols[i].metas = &ctx->freq_metas[i];
+    ctx->in_freq_pass = true;
+    int32_t rc = read_columns_impl(ctx, ctx->freq_cols.data(), ctx->freq_cols.size(), SB_MEM_DEVICE, false);
+    ctx->in_freq_pass = false;
+    if (rc != SB_OK) return rc;
+    for (const Batch& b : batches) launch_freq_scatter(ctx, b.d_entries, b.n, b.d_off, b.ex_base);
+    hipError_t e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(Status), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return check_hip(ctx, e, "freq second pass");
+    if (ctx->h_status->code != 0) {
+        char buf[160];
+        rc = ctx->h_status->code;
+        ctx->last_error = status_text(*ctx->h_status, buf, sizeof buf);
+        (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
+    }
+    return rc;
+}
 
 int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     if (!ctx) return SB_ERR_INVALID;
@@ -179,6 +260,7 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         }
         (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
     }
+    if (rc == SB_OK) rc = freq_second_pass(ctx);
     for (auto& s : ctx->slots) s.in_flight = false;
     for (auto& sp : ctx->spans) {
         float ms = 0;
@@ -403,6 +485,26 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     a.n_pages = (uint32_t)P;
     a.n_cols = (uint32_t)n;
     a.n_tiles = (uint32_t)T;
+    a.freq_log = nullptr;
+    a.freq_count = nullptr;
+    a.freq_cap = 0;
+    a.no_freq = ctx->in_freq_pass ? 1u : 0u;
+    if (!sizes_only && !ctx->in_freq_pass && P) {  // room for every page of this call to be a Freq page
+        sb_ctx::FreqLog* log = ctx->freq_logs.empty() ? nullptr : &ctx->freq_logs.back();
+        if (!log || (uint64_t)log->reserved + P > log->cap) {
+            sb_ctx::FreqLog nl;
+            nl.cap = (uint32_t)std::max<uint64_t>(8192, 2 * P);
+            if (hipMalloc((void**)&nl.dev, 16 + (size_t)nl.cap * sizeof(FreqEntry)) != hipSuccess)
+                return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(freq log) failed");
+            (void)hipMemsetAsync(nl.dev, 0, 16, s);
+            ctx->freq_logs.push_back(nl);
+            log = &ctx->freq_logs.back();
+        }
+        log->reserved += (uint32_t)P;
+        a.freq_count = (uint32_t*)log->dev;
+        a.freq_log = (FreqEntry*)(log->dev + 16);
+        a.freq_cap = log->cap;
+    }
     uint64_t* d_vlen = (uint64_t*)(tb + o_vlen);
 
     if (sizes_only) {

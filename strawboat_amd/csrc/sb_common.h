@@ -98,6 +98,20 @@ struct InflateJob {
     uint32_t page;
 };
 
+// one Freq page (integer/freq.rs:90-127), logged by k_parse: its exceptions block is an ordinary
+// BLOCK<T> that a second decode pass expands, then k_freq_scatter puts the values in place
+struct FreqEntry {
+    const uint8_t* roaring;  // serialized RoaringBitmap of the exception rows
+    const uint8_t* nested;   // BLOCK<T exceptions>
+    uint8_t* out;            // the page's values in the column output
+    uint64_t nested_len;     // bytes from `nested` to the end of the page
+    uint64_t rows;
+    uint32_t roaring_len;
+    uint32_t n_exceptions;
+    uint32_t ptype, width;
+    uint32_t page, pad;
+};
+
 struct DecodeArgs {
     const ColDesc* cols;
     const PageTask* tasks;
@@ -112,6 +126,10 @@ struct DecodeArgs {
     uint32_t n_pages;
     uint32_t n_cols;
     uint32_t n_tiles;
+    FreqEntry* freq_log;   // Freq pages found by k_parse (shared by the calls of one synchronize interval)
+    uint32_t* freq_count;
+    uint32_t freq_cap;
+    uint32_t no_freq;      // second pass: an exceptions block never holds a Freq block (freq.rs:78-79)
 };
 
 }  // namespace sb

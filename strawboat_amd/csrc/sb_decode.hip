@@ -180,8 +180,53 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             if (c.ptype != SB_TYPE_FLOAT64) FAIL(SB_ERR_OUT_OF_SPEC, 27);  // "Unknown compression codec Patas for integer"
             push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
             d.src = nullptr;
+        } else if (codec == SB_CODEC_FREQ) {  // top[w] | u32 rb_size | roaring | BLOCK<T exceptions>  (freq.rs:71-83)
+            if (a.no_freq) FAIL(SB_ERR_OUT_OF_SPEC, 28);
+            if ((uint64_t)(end - d.body) < (uint64_t)w + 4) FAIL(SB_ERR_IO, 29);
+            const uint32_t rb_size = ldu32(d.body + w);
+            const uint8_t* rb = d.body + w + 4;
+            if ((uint64_t)(end - rb) < rb_size) FAIL(SB_ERR_IO, 33);
+            // cardinality from the portable header: cookie, container count, (key, cardinality - 1) pairs
+            if (rb_size < 8) FAIL(SB_ERR_EXTERNAL, 34);
+            const uint32_t cookie = ldu32(rb);
+            uint32_t nc, hp;
+            if ((cookie & 0xFFFF) == 12347) {
+                nc = (cookie >> 16) + 1;
+                hp = 4 + (nc + 7) / 8;
+            } else if (cookie == 12346) {
+                nc = ldu32(rb + 4);
+                hp = 8;
+            } else {
+                FAIL(SB_ERR_EXTERNAL, 35);
+            }
+            if (nc > 65536 || (uint64_t)hp + 4ull * nc > rb_size) FAIL(SB_ERR_EXTERNAL, 36);
+            uint64_t card = 0;
+            for (uint32_t k = 0; k < nc; k++) card += (uint64_t)ldu16(rb + hp + 4 * k + 2) + 1;
+            if (card > N) FAIL(SB_ERR_OUT_OF_SPEC, 37);
+            const uint8_t* nested = rb + rb_size;
+            if (end - nested < 9) FAIL(SB_ERR_IO, 38);
+            if (!a.freq_log) {  // header-only pass (sb_read_columns_sizes): nothing to log
+                d.ok = 1;
+                a.descs[p] = d;
+                return;
+            }
+            const uint32_t slot = atomicAdd(a.freq_count, 1u);
+            if (slot >= a.freq_cap) FAIL(SB_ERR_INVALID, 39);
+            FreqEntry fe;
+            fe.roaring = rb;
+            fe.nested = nested;
+            fe.out = c.values + t.out_row * w;
+            fe.nested_len = (uint64_t)(end - nested);
+            fe.rows = N;
+            fe.roaring_len = rb_size;
+            fe.n_exceptions = (uint32_t)card;
+            fe.ptype = c.ptype;
+            fe.width = w;
+            fe.page = p;
+            fe.pad = 0;
+            a.freq_log[slot] = fe;
         } else {
-            FAIL(SB_ERR_NYI, 25);  // Freq pages take the host path for now
+            FAIL(SB_ERR_OUT_OF_SPEC, 25);
         }
     }
     if (codec == SB_CODEC_DICT && c.ptype != SB_TYPE_BOOLEAN) {
@@ -1102,6 +1147,7 @@ __device__ void expand_prim(const ColDesc& c, const PageTask& t, const PageDesc&
         case SB_CODEC_ZSTD:
         case SB_CODEC_SNAPPY:
             break;  // inflated straight into place by k_inflate
+        case SB_CODEC_FREQ:        // top value everywhere; k_freq_scatter overwrites the exception rows
         case SB_CODEC_ONEVALUE: {  // integer/one_value.rs:77-94
             const Val<W> v = ld_val<W>(d.body);
             emit_rows<W>(dst, rows, [&](uint32_t) { return v; });
@@ -1507,6 +1553,93 @@ __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
 }
 
 // -------------------------------------------------------------------------------- launcher
+// Second pass of a Freq page: out[index of the k-th set bit] = exceptions[k] (freq.rs:120-122).
+// One workgroup per page walks the Roaring containers (array / bitmap / run, portable format).
+__global__ void __launch_bounds__(WG) k_freq_scatter(const FreqEntry* entries, const uint64_t* ex_off, const uint8_t* ex_base,
+                                                       Status* st) {
+    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ uint32_t s_w[4];
+    const FreqEntry fe = entries[blockIdx.x];
+    const uint8_t* ex = ex_base + ex_off[blockIdx.x];
+    const uint8_t* rb = fe.roaring;
+    const uint32_t w = fe.width;
+    const int t = threadIdx.x;
+    const uint32_t cookie = ldu32(rb);
+    const bool has_run = (cookie & 0xFFFF) == 12347;
+    const uint32_t nc = has_run ? (cookie >> 16) + 1 : ldu32(rb + 4);
+    const uint8_t* run_bits = rb + 4;
+    const uint32_t hp = has_run ? 4 + (nc + 7) / 8 : 8;
+    uint32_t pos = hp + 4 * nc;
+    if (!has_run || nc >= 4) pos += 4 * nc;  // offset header
+    auto put = [&](uint64_t row, uint64_t k) {
+        if (row >= fe.rows) {
+            raise(st, SB_ERR_OUT_OF_SPEC, fe.page, 410);  // exception index out of bounds
+            return;
+        }
+        const uint8_t* s = ex + k * w;
+        uint8_t* d = fe.out + row * w;
+        for (uint32_t b = 0; b < w; b++) d[b] = s[b];
+    };
+    uint64_t cum = 0;
+    for (uint32_t ci = 0; ci < nc; ci++) {
+        const uint32_t hi = (uint32_t)ldu16(rb + hp + 4 * ci) << 16;
+        const uint32_t card = (uint32_t)ldu16(rb + hp + 4 * ci + 2) + 1;
+        const bool run = has_run && ((run_bits[ci >> 3] >> (ci & 7)) & 1);
+        if (run) {
+            if (pos + 2 > fe.roaring_len) break;
+            const uint32_t nr = ldu16(rb + pos);
+            pos += 2;
+            if (pos + 4ull * nr > fe.roaring_len) break;
+            if (t == 0) {  // runs are rare in what roaring's serialize_into writes (never without run_optimize)
+                uint64_t k = cum;
+                for (uint32_t r = 0; r < nr; r++) {
+                    const uint32_t s0 = ldu16(rb + pos + 4 * r), len = ldu16(rb + pos + 4 * r + 2);
+                    for (uint32_t v = s0; v <= s0 + len; v++) put(hi | v, k++);
+                }
+            }
+            pos += 4 * nr;
+        } else if (card > 4096) {  // bitmap container: 1024 u64 words
+            if (pos + 8192ull > fe.roaring_len) break;
+            const uint8_t* bm = rb + pos;
+            for (int i = t; i < SIDX_WORDS; i += WG) s_a[i] = 0;
+            __syncthreads();
+            // thread t owns 64-bit words [4t, 4t + 4): popcounts -> exclusive prefix over the workgroup
+            uint64_t wd[4];
+            uint32_t mine = 0;
+            for (int q = 0; q < 4; q++) {
+                wd[q] = ldu64(bm + (uint64_t)(4 * t + q) * 8);
+                mine += (uint32_t)__popcll(wd[q]);
+            }
+            const uint32_t incl = wave_incl_scan(mine);
+            if ((t & 63) == 63) s_w[t >> 6] = incl;
+            __syncthreads();
+            uint32_t k = incl - mine;
+            for (int pw = 0; pw < 3; pw++)
+                if (pw < (t >> 6)) k += s_w[pw];
+            for (int q = 0; q < 4; q++) {
+                uint64_t m = wd[q];
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    put(hi | (uint32_t)((4 * t + q) * 64 + b), cum + k++);
+                }
+            }
+            __syncthreads();
+            pos += 8192;
+        } else {  // array container: sorted u16 values
+            if (pos + 2ull * card > fe.roaring_len) break;
+            for (uint32_t k = t; k < card; k += WG) put(hi | ldu16(rb + pos + 2 * k), cum + k);
+            pos += 2 * card;
+        }
+        cum += card;
+    }
+    if (cum != fe.n_exceptions && t == 0) raise(st, SB_ERR_EXTERNAL, fe.page, 411);  // malformed Roaring bitmap
+}
+
+void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, const uint64_t* ex_off, const uint8_t* ex_base) {
+    if (n) k_freq_scatter<<<n, WG, 0, ctx->stream>>>(entries, ex_off, ex_base, ctx->d_status);
+}
+
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 3 * sizeof(uint32_t), s);

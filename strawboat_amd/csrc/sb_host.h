@@ -66,6 +66,15 @@ struct sb_ctx {
     };
     std::vector<Copyback> copybacks;
     std::vector<void*> temp_dev;  // device temporaries to free at synchronize
+    // Freq pages logged by the decode calls since the last synchronize: [u32 count | pad][FreqEntry...]
+    struct FreqLog {
+        uint8_t* dev = nullptr;
+        uint32_t cap = 0, reserved = 0;
+    };
+    std::vector<FreqLog> freq_logs;
+    bool in_freq_pass = false;
+    std::vector<sb_column_read> freq_cols;  // the second pass's one-page columns (alive until synchronize returns)
+    std::vector<sb_page_meta> freq_metas;
 
     // optional per-kernel HIP-event timing (sb_ctx_profile)
     bool profile = false;

@@ -1,0 +1,70 @@
+"""GPU parity for Freq pages of primitives (codec id 13, src/compression/integer/freq.rs:90-127,
+double/freq.rs): pages written by the oracle (top value | Roaring bitmap | nested exceptions block),
+decoded on the device in two passes (exceptions block through the normal decoder, then a scatter),
+compared with the oracle's decode."""
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+from tests.test_gpu_decode import check, gpu_decode
+
+pytestmark = pytest.mark.gpu
+
+NP = {S.T_U8: np.uint8, S.T_I32: np.int32, S.T_I64: np.int64, S.T_F64: np.float64, S.T_F32: np.float32, S.T_I16: np.int16}
+
+
+def sparse(ptype, rows, p_exc, seed, null_density=None, exc_uniq=1 << 20, top=7):
+    rng = np.random.default_rng(seed)
+    v = np.full(rows, top, dtype=NP[ptype])
+    exc = rng.random(rows) < p_exc
+    hi = min(exc_uniq, 100 if ptype == S.T_U8 else exc_uniq)
+    v[exc] = (rng.integers(300 if ptype != S.T_U8 else 8, 300 + hi if ptype != S.T_U8 else 8 + hi, int(exc.sum()))).astype(NP[ptype])
+    validity = gen.make_validity(rng, rows, null_density)
+    return dict(ptype=ptype, nullable=validity is not None, rows=rows, values=v, validity=validity, offsets=None)
+
+
+@pytest.mark.parametrize("ptype", [S.T_U8, S.T_I16, S.T_I32, S.T_I64, S.T_F32, S.T_F64])
+def test_freq_pages(gpu_ctx, ptype):
+    check(gpu_ctx, sparse(ptype, 20_000, 0.05, 1), max_page_size=4096, force_codec=S.FREQ)
+    check(gpu_ctx, sparse(ptype, 20_000, 0.05, 2, null_density=0.1), max_page_size=5000, force_codec=S.FREQ)
+    check(gpu_ctx, sparse(ptype, 9_000, 0.0, 3), max_page_size=3000, force_codec=S.FREQ)            # no exceptions at all
+
+
+def test_freq_mostly_null_pages(gpu_ctx):
+    # >= 90 % nulls: the top value "is null" and every valid row is an exception (freq.rs:46-48)
+    col = gen.prim(S.T_I64, 30_000, uniq=1000, null_density=0.95, seed=4)
+    check(gpu_ctx, col, max_page_size=8192, force_codec=S.FREQ)
+
+
+def test_freq_roaring_containers(gpu_ctx):
+    # > 4096 exceptions inside one 64 Ki-row container -> bitmap container; 200 000-row pages -> 4 containers
+    check(gpu_ctx, sparse(S.T_I32, 65_536, 0.09, 5), max_page_size=65_536, force_codec=S.FREQ)
+    check(gpu_ctx, sparse(S.T_I64, 400_000, 0.08, 6), max_page_size=200_000, force_codec=S.FREQ)
+
+
+def test_freq_nested_exception_codecs(gpu_ctx):
+    # the exceptions block is an ordinary adaptive block: few distinct values -> Dict / RLE / bit-packing, LZ4 default ...
+    seen = set()
+    for kw, opt in ((dict(exc_uniq=3), dict(ratio=1.2)), (dict(exc_uniq=1 << 20), dict(default_compression=S.LZ4)),
+                    (dict(exc_uniq=200), dict(ratio=1.1, default_compression=S.ZSTD)), (dict(exc_uniq=1), dict(ratio=1.5))):
+        col = sparse(S.T_I32, 128 * 700, 0.07, 7, **kw)
+        pages, metas = check(gpu_ctx, col, max_page_size=128 * 350, force_codec=S.FREQ, **opt)
+        seen |= set(S.stat_column(col["ptype"], col["nullable"], pages, metas)[1].tolist())
+    assert len(seen) >= 3, "the nested exceptions blocks should use several codecs, got %s" % seen
+
+
+def test_freq_and_other_pages_in_one_batch(gpu_ctx):
+    import torch
+    from strawboat_amd import read
+    cols, want = [], []
+    for k, (col, opt) in enumerate([(sparse(S.T_I64, 30_000, 0.04, 8), dict(force_codec=S.FREQ)),
+                                    (gen.prim(S.T_I64, 30_000, uniq=50, runs=9), dict(force_codec=S.RLE)),
+                                    (sparse(S.T_F64, 30_000, 0.06, 9, null_density=0.2), dict(force_codec=S.FREQ))]):
+        pages, metas = gen.oracle_write(col, max_page_size=8192, **opt)
+        want.append(gen.oracle_read(col, pages, metas))
+        cols.append(read.ColumnPages(col["ptype"], col["nullable"], torch.from_numpy(pages).to(gpu_ctx.torch_device), metas))
+    got = read.batch_read_columns(gpu_ctx, cols)
+    gpu_ctx.synchronize()
+    for g, w in zip(got, want):
+        assert np.array_equal(g.values_numpy(), w["values"])

@@ -13,8 +13,8 @@ k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (defau
 CU instead of exactly one (with 64 columns = 1024 pages = 4 per CU every phase of every workgroup
 runs in lockstep and the fixed ~0.1 ms of small kernels and launch gaps weighs 20 %).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
 page is chosen on the device by the reference's selector (it picks RLE for this data: sampled
-ratio ~14 vs Dict 7.6; the CPU oracle agrees, tests/test_oracle_golden.py).  Freq and Patas have
-no device encoder yet and are in forbidden_compressions.
+ratio ~14 vs Dict 7.6 vs Patas; the CPU oracle agrees, tests/test_oracle_golden.py).  Freq has no
+device encoder yet and is in forbidden_compressions (the reference's own option).
 
 Multi-GPU (torchrun, one rank per GPU): every rank owns its own `--columns` columns (weak
 scaling, pages of independent columns shard with no data-path collective); the only collective
@@ -82,9 +82,9 @@ def main():
     ctx = sb.Context(local_rank)
     B = args.columns
     codec = {"adaptive": -1, "rle": Compression.RLE, "none": Compression.NONE, "dict": Compression.DICT}[args.codec]
-    if codec < 0:   # the reference's adaptive mode; Freq/Patas have no device encoder yet and are forbidden
+    if codec < 0:   # the reference's adaptive mode; Freq has no device encoder yet and is forbidden
         opts = WriteOptions(max_page_size=PAGE, default_compress_ratio=2.0,
-                            forbidden_compressions=[Compression.FREQ, Compression.PATAS])
+                            forbidden_compressions=[Compression.FREQ])
     else:
         opts = WriteOptions(max_page_size=PAGE, force_codec=codec)
 
@@ -195,7 +195,7 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import sbo
             if codec < 0:
-                o = sbo.make_options(max_page_size=PAGE, ratio=2.0, forbidden=(sbo.FREQ, sbo.PATAS))
+                o = sbo.make_options(max_page_size=PAGE, ratio=2.0, forbidden=(sbo.FREQ,))
             else:
                 o = sbo.make_options(max_page_size=PAGE, force_codec=codec)
             tw, tr = sbo.time_roundtrip(sbo.T_F64, True, ROWS, host0[0], validity=host0[1], options=o, iters=3)

@@ -31,7 +31,7 @@ int main() {
     hipMemcpy(dv, hv.data(), P * N / 8, hipMemcpyHostToDevice);
     hipMemset(tl, 0, 8 * 4096);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
-    const uint32_t forb = (1u << SB_CODEC_FREQ) | (1u << SB_CODEC_PATAS);
+    const uint32_t forb = (1u << SB_CODEC_FREQ);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; i++) k_sel<<<P, WG>>>(d, dv, N, codecs, forb);
     hipEventRecord(a);
@@ -42,7 +42,7 @@ int main() {
     printf("k_sel: %.3f ms per launch (%.2f TB/s), page 100 -> codec %d\n", ms / 10, P * N * 8 / (ms / 10) / 1e9, c0);
     std::vector<unsigned long long> t(4096);
     hipMemcpy(t.data(), tl, 8 * 4096, hipMemcpyDeviceToHost);
-    const char* names[11] = {"start", "stream", "reduce", "(tail)", "OneValue", "Freq", "Dict", "Patas", "RLE", "-", "end"};
+    const char* names[11] = {"start", "stream", "reduce", "OneValue", "Freq", "Dict", "Patas", "RLE", "-", "-", "end"};
     for (int p = 1; p <= 10; p++) {
         if (!t[512 + p]) continue;
         int q = p - 1; while (q > 0 && !t[512 + q]) q--;

@@ -95,7 +95,7 @@ __device__ __forceinline__ int32_t codec_of(const EncodeArgs& a, const EncPage& 
 __device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
     return codec == SB_CODEC_NONE || codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD || codec == SB_CODEC_SNAPPY || codec == SB_CODEC_RLE ||
            codec == SB_CODEC_DICT ||
-           codec == SB_CODEC_ONEVALUE || codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING;
+           codec == SB_CODEC_ONEVALUE || codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING || codec == SB_CODEC_PATAS;
 }
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -786,6 +786,99 @@ __device__ uint64_t enc_rle_rows(GetVal getv, const ValidView& vv, uint64_t N, u
     return (uint64_t)(nrec + 1) * REC;
 }
 
+// ------------------------------------------------------------------------------ Patas (floats)
+// double/patas.rs:36-104: first value raw, then per value `u16 packed | significant bytes` of
+// bits ^ bits[ref], where ref = the last earlier row with the same bit pattern if it is less than 128
+// rows back, else the previous row — and row 0 for a pattern not seen before while i < 128
+// (`indices.get(..).unwrap_or(0)`, patas.rs:59-65).  Validity is ignored (null slots are values).
+// A chunk of 4096 rows is staged in LDS behind a 128-row halo; every row searches its window
+// backwards (one step inside runs), record lengths are scanned into byte positions, records are
+// written with byte stores (they are 2..10 bytes at arbitrary offsets).
+template <int W, class GetVal>
+__device__ uint64_t enc_patas(GetVal getv, uint64_t N, uint8_t* dst, uint32_t* sA, uint32_t* s_w, uint8_t* s_raw) {
+    static_assert(W == 4 || W == 8, "Patas is defined for f32 / f64");
+    using B = typename std::conditional<(W == 8), unsigned long long, uint32_t>::type;
+    constexpr int BITS = W * 8;
+    constexpr uint32_t HALO = 128;
+    B* s_v = (B*)s_raw;  // HALO + TILE_ROWS entries
+    const int t = threadIdx.x;
+    if (N == 0) return 0;
+    auto bits_of = [&](uint64_t i) {
+        const Val<W> v = getv(i);
+        B b = 0;
+        __builtin_memcpy(&b, &v, W);
+        return b;
+    };
+    if (t == 0) {
+        const B b0 = bits_of(0);
+        for (int k = 0; k < W; k++) *(gptr)(dst + k) = (uint8_t)(b0 >> (8 * k));
+    }
+    uint64_t out_pos = W;
+    for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
+        const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, N - cb);
+        for (uint32_t r = t; r < HALO + n; r += WG) {  // halo rows cb-128 .. cb-1, then the chunk
+            const int64_t i = (int64_t)cb - HALO + r;
+            s_v[r] = i >= 0 ? bits_of((uint64_t)i) : (B)0;
+        }
+        __syncthreads();
+        uint32_t pk[ROWS_PER_THREAD], len[ROWS_PER_THREAD];
+        B sv[ROWS_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < ROWS_PER_THREAD; j++) {
+            const uint32_t r = (uint32_t)t + (uint32_t)j * WG;
+            const uint64_t i = cb + r;
+            pk[j] = 0;
+            len[j] = 0;
+            sv[j] = 0;
+            if (r < n && i > 0) {
+                const B b = s_v[HALO + r];
+                const uint32_t back = (uint32_t)min((uint64_t)127, i);
+                uint32_t diff = 0;
+                for (uint32_t d0 = 1; d0 <= back && diff == 0; d0 += 8) {  // 8 LDS reads in flight per step
+                    B cnd[8];
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; q++) cnd[q] = s_v[HALO + r - (d0 + q <= back ? d0 + q : 0)];
+#pragma unroll
+                    for (int q = 7; q >= 0; q--)
+                        if (d0 + q <= back && cnd[q] == b) diff = d0 + q;
+                }
+                if (diff == 0) diff = i < 128 ? (uint32_t)i : 1u;  // unseen: row 0 while i < 128, else the previous row
+                const B x = b ^ s_v[HALO + r - diff];
+                uint32_t tz, lz;
+                if constexpr (W == 8) {
+                    tz = x ? (uint32_t)__builtin_ctzll(x) : 64u;
+                    lz = x ? (uint32_t)__builtin_clzll(x) : 64u;
+                } else {
+                    tz = x ? (uint32_t)__builtin_ctz(x) : 32u;
+                    lz = x ? (uint32_t)__builtin_clz(x) : 32u;
+                }
+                const uint32_t is_equal = x == 0 ? 1u : 0u;
+                const uint32_t sig_bits = is_equal ? 0u : BITS - tz - lz;
+                const uint32_t sig_bytes = (sig_bits >> 3) + ((sig_bits & 7) != 0);
+                const uint32_t sh = tz - is_equal;
+                pk[j] = (((diff & 0xFF) << 9) | ((sig_bytes & 7) << 6) | (sh & 0xFF)) & 0xFFFF;  // patas.rs:145-149
+                sv[j] = sh >= (uint32_t)BITS ? (B)0 : (B)(x >> sh);
+                len[j] = 2 + sig_bytes;
+            }
+            sA[sidx((int)r)] = len[j];
+        }
+        __syncthreads();
+        const uint32_t total = tile_incl_scan(sA, s_w);
+#pragma unroll
+        for (int j = 0; j < ROWS_PER_THREAD; j++) {
+            const uint32_t r = (uint32_t)t + (uint32_t)j * WG;
+            if (len[j] == 0) continue;
+            uint8_t* q = dst + out_pos + sA[sidx((int)r)] - len[j];
+            *(gptr)q = (uint8_t)pk[j];
+            *(gptr)(q + 1) = (uint8_t)(pk[j] >> 8);
+            for (uint32_t k = 0; k + 2 < len[j]; k++) *(gptr)(q + 2 + k) = (uint8_t)(sv[j] >> (8 * k));
+        }
+        out_pos += total;
+        __syncthreads();
+    }
+    return out_pos;
+}
+
 // ------------------------------------------------------------------------------ bit-packing
 // u8 num_bits | 16*num_bits bytes per 128 values (integer/bp.rs:48-62); num_bits from the RAW
 // values also for the delta variant (delta_bp.rs:50); packing ORs unmasked values like the
@@ -1446,6 +1539,20 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
     // ---- one streaming pass: flags, null count, typed max, Boyer-Moore vote, and (W <= 8) an LDS
     // hash set of the canonical keys for the exact distinct count Dict needs
     STL(0);
+    // sample rows of the trials that can run, fetched now (see SamplePre)
+    SamplePre<W> pre_rle, pre_bp, pre_dbp, pre_patas;
+    if (N) {
+        if (!forbidden(SB_CODEC_RLE)) pre_rle = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_RLE);
+        if constexpr (W == 4) {
+            if (!is_float && !forbidden(SB_CODEC_BITPACKING) && N % 128 == 0)
+                pre_bp = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_BITPACKING);
+            if (!is_float && !forbidden(SB_CODEC_DELTA_BITPACKING) && N % 128 == 0)
+                pre_dbp = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_DELTA_BITPACKING);
+        }
+        if constexpr (W == 4 || W == 8) {
+            if (is_float && !forbidden(SB_CODEC_PATAS)) pre_patas = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_PATAS);
+        }
+    }
     const Val<W> k0 = key(0);
     uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, nulls = 0;
     Val<W> tmax = getv(0);
@@ -1702,7 +1809,7 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                 break;
             }
             case SB_CODEC_RLE: {  // rle.rs:58-60
-                load_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_RLE, smp);
+                commit_sample<W>(pre_rle, N, smp);
                 uint32_t runs;
                 if (nk == NK_F32)
                     runs = sample_rle_runs<W, (W == 4 ? 1 : 0)>(smp, s4);
@@ -1719,7 +1826,7 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                 if constexpr (W == 4) {
                     if (any_neg || N % 128 != 0) break;
                     if (c == SB_CODEC_DELTA_BITPACKING && (!is_sorted || null_count > 0)) break;
-                    load_sample<4>(getv, valid, N, o.seed, o.depth, c, smp);
+                    commit_sample<4>(c == SB_CODEC_BITPACKING ? pre_bp : pre_dbp, N, smp);
                     const uint32_t size = sample_bp_size(smp, s4, sc.s_misc);
                     r = (double)((uint64_t)smp.n * 4) / (double)size;
                     if (c == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
@@ -1729,7 +1836,7 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
             }
             case SB_CODEC_PATAS: {  // patas.rs:139-141
                 if constexpr (W == 4 || W == 8) {
-                    load_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_PATAS, smp);
+                    commit_sample<W>(pre_patas, N, smp);
                     const uint32_t size = sample_patas_size<W>(smp, s4);
                     r = (double)((uint64_t)smp.n * W) / (double)size;
                     __syncthreads();
@@ -1943,6 +2050,17 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
             body = enc_bp(getu, N, CODEC == SB_CODEC_DELTA_BITPACKING, blk + 9, sA, sB, s_w);
         } else {
             if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 521);
+            return 0;
+        }
+    } else if constexpr (CODEC == SB_CODEC_PATAS) {
+        if constexpr (W == 4 || W == 8) {
+            if (c.fkind == 0) {  // "Unknown compression codec Patas for integer"
+                if (threadIdx.x == 0) raise(a.status, SB_ERR_OUT_OF_SPEC, page, 523);
+                return 0;
+            }
+            body = enc_patas<W>(getv, N, blk + 9, sA, s_w, (uint8_t*)sB);
+        } else {
+            if (threadIdx.x == 0) raise(a.status, SB_ERR_OUT_OF_SPEC, page, 523);
             return 0;
         }
     } else if constexpr (CODEC == SB_CODEC_DICT) {
@@ -2249,6 +2367,9 @@ static EncPageKernel enc_page_kernel_for_codec(int32_t codec) {
             return k_enc_emit_pages<KIND, SB_CODEC_BITPACKING>;
         case SB_CODEC_DELTA_BITPACKING:
             return k_enc_emit_pages<KIND, SB_CODEC_DELTA_BITPACKING>;
+        case SB_CODEC_PATAS:
+            if constexpr (KIND == 4 || KIND == 8) return k_enc_emit_pages<KIND, SB_CODEC_PATAS>;
+            return nullptr;
     }
     return nullptr;
 }
@@ -2828,8 +2949,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     }
     if (any_pages) {
         // one kernel instance per (kind, codec) that can occur in the batch
-        static const int32_t CAND[5] = {SB_CODEC_ONEVALUE, SB_CODEC_DICT, SB_CODEC_RLE, SB_CODEC_BITPACKING,
-                                        SB_CODEC_DELTA_BITPACKING};
+        static const int32_t CAND[6] = {SB_CODEC_ONEVALUE, SB_CODEC_DICT, SB_CODEC_RLE, SB_CODEC_BITPACKING,
+                                        SB_CODEC_DELTA_BITPACKING, SB_CODEC_PATAS};
         for (int kd : kinds) {
             for (int32_t cd : CAND) {
                 if (!adaptive && cd != host_codec) continue;
@@ -2838,15 +2959,20 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     if ((cd == SB_CODEC_BITPACKING || cd == SB_CODEC_DELTA_BITPACKING) && kd != 4) continue;
                     if (kd == 0 && cd == SB_CODEC_DICT) continue;
                     if (kd < 0 && cd == SB_CODEC_RLE) continue;
+                    if (cd == SB_CODEC_PATAS) {  // candidates of float columns only (double/mod.rs:271-277)
+                        bool any_float = false;
+                        for (uint64_t i = 0; i < n; i++) any_float |= hc[i].fkind != 0 && (int)hc[i].width == kd;
+                        if (!any_float) continue;
+                    }
                 }
                 EncPageKernel kf = enc_page_kernel(kd, cd);
                 if (!kf) continue;
                 KScope k(ctx, cd == SB_CODEC_RLE ? K_ENC_PAGES : cd == SB_CODEC_DICT ? K_ENC_PAGES_DICT
-                                : cd == SB_CODEC_ONEVALUE ? K_ENC_PAGES_ONEVALUE : K_ENC_PAGES_BP);
+                                : cd == SB_CODEC_ONEVALUE ? K_ENC_PAGES_ONEVALUE : cd == SB_CODEC_PATAS ? K_ENC_PAGES_PATAS : K_ENC_PAGES_BP);
                 kf<<<(uint32_t)P, WG, 0, s>>>(a);
             }
             if (!adaptive && host_codec != SB_CODEC_NONE && !enc_page_kernel(kd, host_codec))
-                return ctx->fail(SB_ERR_NYI, "no device encoder for this codec (LZ4/Zstd/Snappy/Freq/Patas pages are not built yet)");
+                return ctx->fail(SB_ERR_NYI, "no device encoder for this codec (Freq pages are not built yet; Patas is for f32/f64)");
         }
     }
     {

@@ -215,6 +215,50 @@ __device__ uint32_t sample_rle_runs(const Sample<W>& s, uint32_t* s4) {
     return s.n ? b + 1 : 0;
 }
 
+// The sample rows depend only on (N, seed, trial), not on the data: their (random, latency-bound)
+// loads are issued before the streaming pass and committed to LDS when the trial runs, so the
+// trials at the end of every page do not each expose an HBM round trip.
+template <int W>
+struct SamplePre {
+    static constexpr int R = (SAMPLE_CAP + WG - 1) / WG;  // sample rows per thread
+    Val<W> v[R];
+    uint32_t okm;  // bit r: row valid
+};
+template <int W, class GetVal, class Valid>
+__device__ __forceinline__ SamplePre<W> prefetch_sample(GetVal getv, Valid valid, uint64_t N, uint64_t seed, uint32_t depth,
+                                                        uint32_t trial) {
+    SamplePre<W> p;
+    const bool whole = N / SAMPLE_COUNT <= SAMPLE_SIZE;
+    const uint32_t n = whole ? (uint32_t)N : SAMPLE_ROWS;
+    p.okm = 0;
+#pragma unroll
+    for (int r = 0; r < SamplePre<W>::R; r++) {
+        const uint32_t k = threadIdx.x + (uint32_t)r * WG;
+        uint64_t row = 0;
+        if (k < n) sample_row(N, seed, depth, trial, k, row);
+        p.v[r] = getv(k < n ? row : 0);
+        if (k < n && valid(row)) p.okm |= 1u << r;
+    }
+    return p;
+}
+template <int W>
+__device__ void commit_sample(const SamplePre<W>& p, uint64_t N, Sample<W>& s) {
+    const bool whole = N / SAMPLE_COUNT <= SAMPLE_SIZE;
+    s.whole = whole;
+    s.n = whole ? (uint32_t)N : SAMPLE_ROWS;
+#pragma unroll
+    for (int r = 0; r < SamplePre<W>::R; r++) {
+        const uint32_t k = threadIdx.x + (uint32_t)r * WG;
+        if (k >= s.n) continue;
+        const bool v = (p.okm >> r) & 1;
+        Val<W> x = p.v[r];
+        if (!whole && !v) __builtin_memset(&x, 0, sizeof(x));  // MutablePrimitiveArray pushes T::default()
+        s.val[k] = x;
+        s.valid[k] = v ? 1 : 0;
+    }
+    __syncthreads();
+}
+
 // Bitpacking size of the sample (bp.rs:36-64): sum over 128-blocks of 1 + 16 * bits(OR)
 __device__ uint32_t sample_bp_size(const Sample<4>& s, uint32_t* s4, uint32_t* s_blk /* >= 8 words */) {
     const uint32_t nblk = s.n / 128;
@@ -232,18 +276,43 @@ __device__ uint32_t sample_bp_size(const Sample<4>& s, uint32_t* s4, uint32_t* s
 template <int W>
 __device__ uint32_t sample_patas_size(const Sample<W>& s, uint32_t* s4) {
     static_assert(W == 4 || W == 8, "Patas is for f32 / f64");
+    // reference index: the most recent identical bit pattern if it is < 128 back, else i-1; an unseen
+    // value refers to index 0 while i < 128 (indices.get().unwrap_or(0), patas.rs:59-65).
+    // Most rows repeat their predecessor (d = 1).  The others are taken one at a time by the whole
+    // wave: 64 lanes compare the 126 remaining window slots at once (two ballots).
+    using B = decltype(s.val[0].x);
+    const int lane = threadIdx.x & 63;
     uint32_t bytes = 0;
-    for (uint32_t i = threadIdx.x; i < s.n; i += WG) {
-        if (i == 0) continue;
-        // reference index: the most recent identical bit pattern if it is < 128 back, else i-1;
-        // an unseen value refers to index 0 while i < 128 (indices.get().unwrap_or(0), patas.rs:59-65)
+    for (uint32_t i0 = 0; i0 < s.n; i0 += WG) {  // uniform trip count: wave-wide ops inside
+        const uint32_t i = i0 + threadIdx.x;
+        const bool act = i < s.n && i > 0;
+        const B me = act ? s.val[i].x : (B)0;
         int ref = -1;
-        const int lo = (int)i - 127 > 0 ? (int)i - 127 : 0;
-        for (int j = (int)i - 1; j >= lo; j--)
-            if (s.val[j].x == s.val[i].x) {
-                ref = j;
-                break;
-            }
+        constexpr int NEAR = 6;  // every lane looks at its NEAR predecessors itself (runs, values split by a null slot)
+        if (act) {
+            B c[NEAR];
+#pragma unroll
+            for (int q = 0; q < NEAR; q++) c[q] = s.val[i > (uint32_t)q ? i - 1 - q : 0].x;
+#pragma unroll
+            for (int q = NEAR - 1; q >= 0; q--)
+                if ((uint32_t)q < i && c[q] == me) ref = (int)i - 1 - q;
+        }
+        uint64_t todo = __ballot(act && ref < 0 && i > (uint32_t)NEAR);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t il = i0 + (threadIdx.x & ~63u) + (uint32_t)l;
+            const B val = s.val[il].x;  // same address in every lane: LDS broadcast
+            const uint32_t back = il < 127 ? il : 127;
+            const uint32_t dA = NEAR + 1 + (uint32_t)lane, dB = NEAR + 65 + (uint32_t)lane;
+            const bool mA = dA <= back && s.val[il - dA].x == val;
+            const bool mB = dB <= back && s.val[il - dB].x == val;
+            const uint64_t bA = __ballot(mA), bB = __ballot(mB);
+            const uint32_t d = bA ? NEAR + 1 + (uint32_t)(__ffsll((long long)bA) - 1)
+                                  : (bB ? NEAR + 65 + (uint32_t)(__ffsll((long long)bB) - 1) : 0);
+            if (lane == l && d) ref = (int)il - (int)d;
+        }
+        if (!act) continue;
         if (ref < 0) ref = i < 128 ? 0 : (int)i - 1;
         const auto x = s.val[i].x ^ s.val[ref].x;
         uint32_t sig_bits = 0;

@@ -10,7 +10,7 @@ from tests.test_gpu_encode import gpu_encode
 
 pytestmark = pytest.mark.gpu
 
-NOT_ON_DEVICE = (S.FREQ, S.PATAS)
+NOT_ON_DEVICE = (S.FREQ,)
 
 
 def check(ctx, col, **opt):

@@ -84,7 +84,7 @@ def main():
     codec = {"adaptive": -1, "rle": Compression.RLE, "none": Compression.NONE, "dict": Compression.DICT}[args.codec]
     if codec < 0:   # the reference's adaptive mode; Freq has no device encoder yet and is forbidden
         opts = WriteOptions(max_page_size=PAGE, default_compress_ratio=2.0,
-                            forbidden_compressions=[Compression.FREQ])
+                            forbidden_compressions=[])
     else:
         opts = WriteOptions(max_page_size=PAGE, force_codec=codec)
 
@@ -195,7 +195,7 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import sbo
             if codec < 0:
-                o = sbo.make_options(max_page_size=PAGE, ratio=2.0, forbidden=(sbo.FREQ,))
+                o = sbo.make_options(max_page_size=PAGE, ratio=2.0, forbidden=())
             else:
                 o = sbo.make_options(max_page_size=PAGE, force_codec=codec)
             tw, tr = sbo.time_roundtrip(sbo.T_F64, True, ROWS, host0[0], validity=host0[1], options=o, iters=3)

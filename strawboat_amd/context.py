@@ -46,17 +46,21 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
-    def _check(self, rc):
+    def _check(self, rc, drain=True):
         if rc != N.SB_OK:
             msg = self._lib.sb_ctx_last_error(self._h)
-            raise N.NativeError(rc, msg.decode() if msg else "")
+            text = msg.decode() if msg else ""
+            if drain:  # an enqueue call failed: drop the context's pending state with it
+                self._lib.sb_ctx_synchronize(self._h)
+                self._keep = []
+            raise N.NativeError(rc, text)
 
     def synchronize(self):
         """Waits for the enqueued work; raises the first error a kernel reported."""
         rc = self._lib.sb_ctx_synchronize(self._h)
         keep, self._keep = self._keep, []
         try:
-            self._check(rc)
+            self._check(rc, drain=False)
         finally:
             del keep
 

@@ -63,6 +63,15 @@ struct EncPage {
     uint32_t direct;
     uint64_t head_off;    // offset of the page's head (level section) in EncCol.heads
     uint64_t head_bytes;  // bytes reserved in front of the page's block
+    // Freq: the page's exceptions become a "virtual page" (entry n_pages + page of the tables) that runs
+    // through the same select / emit kernels in a second wave (integer/freq.rs:76-83)
+    uint64_t ex_off;      // scratch: exception values (rows * width bytes)
+    uint64_t vslot_off;   // scratch: slot of the virtual page
+    uint64_t vaux_off;    // scratch: Dict aux of the virtual page
+    uint64_t vaux_bytes;
+    uint64_t slot_cap;    // bytes available in the page's slot (Freq pages append a block of unknown size)
+    uint32_t depth;       // nesting depth of this block (sampling RNG stream; 0 = page)
+    uint32_t forb_extra;  // codecs forbidden for this block in addition to the options'
 };
 
 struct EncOut {
@@ -87,15 +96,28 @@ struct EncodeArgs {
     uint32_t n_pages;
     uint32_t n_cols;
     uint32_t default_compression;
+    const EncCol* vcols;  // virtual columns / pages of Freq exceptions: entries n_cols.. / n_pages.. (device-written)
+    const EncPage* vpages;
+    uint32_t* freq_count;  // pages that chose Freq in this call (the Freq kernels return at once when 0)
+    uint32_t page_base;   // first table entry this launch works on (0: pages, n_pages: virtual pages)
+    int32_t nested_force; // force_index_codec: the codec forced on nested blocks (-1: none)
 };
 
+__device__ __forceinline__ EncPage get_page(const EncodeArgs& a, uint32_t i) {
+    return i < a.n_pages ? a.pages[i] : a.vpages[i - a.n_pages];
+}
+__device__ __forceinline__ EncCol get_col(const EncodeArgs& a, uint32_t i) {
+    return i < a.n_cols ? a.cols[i] : a.vcols[i - a.n_cols];
+}
+constexpr int32_t CODEC_ON_DEVICE = -1;  // EncPage.codec: chosen by k_enc_select; < -1: table entry not in use
 __device__ __forceinline__ int32_t codec_of(const EncodeArgs& a, const EncPage& p, uint32_t page) {
-    return p.codec >= 0 ? p.codec : a.codecs[page];
+    return p.codec >= 0 ? p.codec : (p.codec == CODEC_ON_DEVICE ? a.codecs[page] : -2);
 }
 __device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
     return codec == SB_CODEC_NONE || codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD || codec == SB_CODEC_SNAPPY || codec == SB_CODEC_RLE ||
            codec == SB_CODEC_DICT ||
-           codec == SB_CODEC_ONEVALUE || codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING || codec == SB_CODEC_PATAS;
+           codec == SB_CODEC_ONEVALUE || codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING || codec == SB_CODEC_PATAS ||
+           codec == SB_CODEC_FREQ;  // (Freq: primitives only, checked where the codec is chosen)
 }
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -2073,7 +2095,7 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
         if (D == EMPTY) return 0;
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
         if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
-            SelectOpts so{a.ratio, 1u, a.forbidden | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, 1u};
+            SelectOpts so{a.ratio, 1u, a.forbidden | p.forb_extra | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, p.depth + 1};
             SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
             const uint32_t* ip = idx;
             ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = ip[i]; return v; },
@@ -2169,7 +2191,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         if (D == EMPTY) return 0;
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
         if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
-            SelectOpts so{a.ratio, 1u, a.forbidden | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, 1u};
+            SelectOpts so{a.ratio, 1u, a.forbidden | p.forb_extra | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, p.depth + 1};
             SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
             const uint32_t* ip = idx;
             ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = ip[i]; return v; },
@@ -2224,10 +2246,10 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     // sample area, also the streaming scratch of choose_prim: 1 KB validity words + 4 x 128 keys
     constexpr int SMP = SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16, STR = 1024 + 4 * 128 * (KIND == 8 ? 8 : 4);
     __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SMP > STR ? SMP : STR];
-    const uint32_t page = blockIdx.x;
-    const EncPage p = a.pages[page];
-    if (p.codec >= 0) return;
-    const EncCol c = a.cols[p.col];
+    const uint32_t page = blockIdx.x + a.page_base;
+    const EncPage p = get_page(a, page);
+    if (p.codec != CODEC_ON_DEVICE) return;
+    const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     const bool is_bool = c.ptype == SB_TYPE_BOOLEAN;
     const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
@@ -2242,7 +2264,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     }
     const uint64_t N = p.rows;
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
-    SelectOpts so{a.ratio, a.has_ratio, a.forbidden, a.default_compression, -1, p.seed, 0u};
+    SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
     SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
     if (sc.gtab) {  // the Dict aux area starts with a table of pow2 >= 2N slots
         uint64_t M = 64;
@@ -2264,7 +2286,10 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     }
     if (threadIdx.x == 0) {
         a.codecs[page] = (int32_t)codec;
-        if (!has_device_encoder(codec)) raise(a.status, SB_ERR_NYI, page, 700 + codec);
+        if (!has_device_encoder(codec) || (codec == SB_CODEC_FREQ && (KIND <= 0 || KIND > 8)))
+            raise(a.status, SB_ERR_NYI, page, 700 + codec);  // binary / 128-bit Freq pages: oracle only
+        else if (codec == SB_CODEC_FREQ && page < a.n_pages)
+            atomicAdd(a.freq_count, 1u);
     }
 }
 
@@ -2307,10 +2332,10 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * LW];
     uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
     __shared__ uint32_t s_w[4];
-    const uint32_t page = blockIdx.x;
-    const EncPage p = a.pages[page];
+    const uint32_t page = blockIdx.x + a.page_base;
+    const EncPage p = get_page(a, page);
     if (codec_of(a, p, page) != CODEC) return;
-    const EncCol c = a.cols[p.col];
+    const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     const bool is_bool = c.ptype == SB_TYPE_BOOLEAN;
     const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
@@ -2435,16 +2460,422 @@ __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t*
     return op;
 }
 
+// ------------------------------------------------------------------------------ Freq (primitives)
+// integer/freq.rs:34-88, double/freq.rs: top[w] | u32 rb_size | RoaringBitmap of the exception rows |
+// compress_integer(exceptions) with Freq forbidden.  k_enc_freq_prep writes everything up to the
+// bitmap and turns the exceptions into a virtual page (table entry n_pages + page, its own column
+// entry n_cols + page) that goes through k_enc_select / the emit kernels in a second wave;
+// k_enc_freq_finish appends the block that wave produced and closes the header.
+//   top value: T::default() when >= 90 % of the rows are null (every valid row is an exception), else
+//   the most frequent value over ALL slots (null slots count, integer/mod.rs:211) — found by a
+//   Boyer-Moore vote, which is exact whenever Freq can be chosen (>= 90 % equal); a page without a
+//   majority value (only reachable with force_codec) raises NYI.
+//   Roaring portable format [3P roaring 0.10.1 serialize_into]: cookie 12346, container count,
+//   (key, cardinality-1) pairs, offsets, then per non-empty 64 Ki-row container a sorted u16 array
+//   (cardinality <= 4096) or a 1024 x u64 bitmap.
+constexpr uint32_t FREQ_MAX_CONTAINERS = 64;  // pages of up to 4 Mi rows
+
+template <int W>
+__device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pages_rw, const EncCol& c, const EncPage& p,
+                               uint32_t page, uint32_t* lds) {
+    const int t = threadIdx.x, lane = t & 63;
+    const uint64_t N = p.rows;
+    const uint8_t* vals = c.values + p.row0 * W;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    uint32_t* sA = lds;                       // SIDX_WORDS: tile scans
+    uint32_t* s_w = lds + SIDX_WORDS;         // 4
+    uint32_t* s_card = s_w + 8;               // FREQ_MAX_CONTAINERS
+    unsigned long long* s_u64 = (unsigned long long*)(s_card + FREQ_MAX_CONTAINERS);  // vote keys (WG) / misc
+    uint32_t* s_cnt = (uint32_t*)(s_u64 + WG);                                         // vote counts (WG)
+    uint8_t* slot = page_slot(a, c, p);
+    uint64_t pos = 0;
+    if (c.nullable) {
+        uint8_t* bits = def_header(slot, N);
+        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
+        pos = def_section_bytes(N);
+    }
+    uint8_t* blk = slot + pos;
+    const uint32_t nc_all = (uint32_t)((N + 65535) / 65536);
+    if (nc_all > FREQ_MAX_CONTAINERS) {
+        if (t == 0) raise(a.status, SB_ERR_NYI, page, 540);
+        return;
+    }
+    auto key64 = [&](uint64_t i) {  // canonical key of slot i (the equality of distinct_values / `*val != top_value`)
+        const Val<W> k = stat_key<W>(ld_val<W>(vals + i * W), c.nk);
+        uint64_t x = 0;
+        __builtin_memcpy(&x, &k, W);
+        return x;
+    };
+    // ---- null share and the vote
+    uint32_t nulls = 0;
+    uint64_t vk = 0;
+    uint32_t vn = 0;
+    for (uint64_t i = t; i < N; i += WG) {
+        if (!vv.get(i)) nulls++;
+        const uint64_t x = key64(i);
+        if (vn == 0) {
+            vk = x;
+            vn = 1;
+        } else if (vk == x) {
+            vn++;
+        } else {
+            vn--;
+        }
+    }
+    const uint32_t null_count = wg_sum32(nulls, s_w);
+    const bool top_is_null = (double)null_count / (double)N >= 0.9;
+    uint64_t topk = 0;
+    Val<W> top = val_zero<W>();
+    if (!top_is_null) {
+        s_u64[t] = vk;
+        s_cnt[t] = vn;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                const unsigned long long c0 = s_u64[t], c1 = s_u64[t + stride];
+                const uint32_t n0 = s_cnt[t], n1 = s_cnt[t + stride];
+                if (n1) {
+                    if (n0 == 0) {
+                        s_u64[t] = c1;
+                        s_cnt[t] = n1;
+                    } else if (c0 == c1) {
+                        s_cnt[t] = n0 + n1;
+                    } else if (n1 > n0) {
+                        s_u64[t] = c1;
+                        s_cnt[t] = n1 - n0;
+                    } else {
+                        s_cnt[t] = n0 - n1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        topk = s_u64[0];
+        __syncthreads();
+        // its count and first occurrence (the value written is the first slot's raw bits)
+        uint32_t mine = 0;
+        unsigned long long first = ~0ull;
+        for (uint64_t i = t; i < N; i += WG)
+            if (key64(i) == topk) {
+                mine++;
+                if (first == ~0ull) first = i;
+            }
+        const uint32_t mc = wg_sum32(mine, s_w);
+        if (t == 0) s_u64[0] = ~0ull;
+        __syncthreads();
+        if (first != ~0ull) atomicMin(&s_u64[0], first);
+        __syncthreads();
+        if ((uint64_t)mc * 2 <= N) {  // no majority: the exact arg-max needs full counts (host-forced Freq only)
+            if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
+            return;
+        }
+        top = ld_val<W>(vals + s_u64[0] * W);
+        __syncthreads();
+    }
+    auto is_exc = [&](uint64_t i) { return vv.get(i) && (top_is_null || key64(i) != topk); };
+    // ---- pass A: cardinality per 64 Ki-row container
+    for (uint32_t q = t; q < FREQ_MAX_CONTAINERS; q += WG) s_card[q] = 0;
+    __syncthreads();
+    for (uint32_t cq = 0; cq < nc_all; cq++) {
+        const uint64_t b = (uint64_t)cq * 65536, e = min(N, b + 65536);
+        uint32_t cnt = 0;
+        for (uint64_t i = b + t; i < e; i += WG) cnt += is_exc(i) ? 1u : 0u;
+        const uint32_t tot = wg_sum32(cnt, s_w);
+        if (t == 0) s_card[cq] = tot;
+    }
+    __syncthreads();
+    // header
+    uint32_t ncne = 0, n_ex = 0;
+    for (uint32_t cq = 0; cq < nc_all; cq++) {
+        ncne += s_card[cq] ? 1u : 0u;
+        n_ex += s_card[cq];
+    }
+    uint8_t* rb = blk + 9 + W + 4;
+    uint32_t rb_size = 8 + 8 * ncne;
+    for (uint32_t cq = 0; cq < nc_all; cq++)
+        if (s_card[cq]) rb_size += s_card[cq] > 4096 ? 8192u : 2 * s_card[cq];
+    if (t == 0) {
+        st_val<W>(blk + 9, top);
+        stu32(blk + 9 + W, rb_size);
+        stu32(rb, 12346u);
+        stu32(rb + 4, ncne);
+        uint32_t k = 0, off = 8 + 8 * ncne;
+        for (uint32_t cq = 0; cq < nc_all; cq++) {
+            if (!s_card[cq]) continue;
+            *(gptr)(rb + 8 + 4 * k) = (uint8_t)cq;
+            *(gptr)(rb + 8 + 4 * k + 1) = (uint8_t)(cq >> 8);
+            *(gptr)(rb + 8 + 4 * k + 2) = (uint8_t)(s_card[cq] - 1);
+            *(gptr)(rb + 8 + 4 * k + 3) = (uint8_t)((s_card[cq] - 1) >> 8);
+            stu32(rb + 8 + 4 * ncne + 4 * k, off);
+            off += s_card[cq] > 4096 ? 8192u : 2 * s_card[cq];
+            k++;
+        }
+    }
+    // ---- pass B: containers and the exception values
+    uint8_t* ex = a.scratch + p.ex_off;
+    uint32_t data_off = 8 + 8 * ncne, ex_base = 0;
+    for (uint32_t cq = 0; cq < nc_all; cq++) {
+        const uint32_t card = s_card[cq];
+        if (!card) continue;
+        const bool bitmap = card > 4096;
+        const uint64_t b = (uint64_t)cq * 65536, e = min(N, b + 65536);
+        if (bitmap)  // rows past the end of the page are not visited below
+            for (uint32_t i = t; i < 2048; i += WG) stu32(rb + data_off + 4 * i, 0);
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint64_t cb = b; cb < e; cb += TILE_ROWS) {
+            const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, e - cb);
+            bool f[ROWS_PER_THREAD];
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_THREAD; j++) {
+                const uint32_t r = (uint32_t)t + (uint32_t)j * WG;
+                f[j] = r < n && is_exc(cb + r);
+                sA[sidx((int)r)] = f[j] ? 1u : 0u;
+                if (bitmap) {  // 64 consecutive rows per wave step: one u64 word of the container
+                    const uint64_t m = __ballot(f[j]);
+                    if (lane == 0 && (r & ~63u) < n) stu64(rb + data_off + ((cb - b + (r & ~63u)) >> 6) * 8, m);
+                }
+            }
+            __syncthreads();
+            const uint32_t tot = tile_incl_scan(sA, s_w);
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_THREAD; j++) {
+                const uint32_t r = (uint32_t)t + (uint32_t)j * WG;
+                if (!f[j]) continue;
+                const uint32_t k = carry + sA[sidx((int)r)] - 1;
+                if (!bitmap) {
+                    const uint32_t lo16 = (uint32_t)(cb - b) + r;
+                    *(gptr)(rb + data_off + 2 * k) = (uint8_t)lo16;
+                    *(gptr)(rb + data_off + 2 * k + 1) = (uint8_t)(lo16 >> 8);
+                }
+                st_val<W>(ex + (uint64_t)(ex_base + k) * W, ld_val<W>(vals + (cb + r) * W));
+            }
+            carry += tot;
+            __syncthreads();
+        }
+        data_off += bitmap ? 8192u : 2 * card;
+        ex_base += card;
+    }
+    // ---- the virtual page that carries the exceptions through the second wave
+    if (t == 0) {
+        EncCol vc = c;
+        vc.values = ex;
+        vc.validity = nullptr;
+        vc.offsets = nullptr;
+        vc.heads = nullptr;
+        vc.out = nullptr;
+        vc.values_bit_offset = 0;
+        vc.validity_bit_offset = 0;
+        vc.out_cap = 0;
+        vc.rows = n_ex;
+        vc.nullable = 0;
+        vc.first_page = a.n_pages + page;
+        vc.n_pages = 1;
+        cols_rw[page] = vc;
+        EncPage vp;
+        __builtin_memset(&vp, 0, sizeof vp);
+        vp.rows = n_ex;
+        vp.slot_off = p.vslot_off;
+        vp.aux_off = p.vaux_off;
+        vp.aux_bytes = p.vaux_bytes;
+        vp.seed = p.seed;
+        vp.col = a.n_cols + page;
+        vp.codec = a.nested_force >= 0 && !(((a.forbidden | (1u << SB_CODEC_FREQ)) >> a.nested_force) & 1)
+                       ? a.nested_force
+                       : (a.has_ratio ? CODEC_ON_DEVICE : (int32_t)a.default_compression);
+        vp.icodec = -1;
+        vp.depth = p.depth + 1;
+        vp.forb_extra = p.forb_extra | (1u << SB_CODEC_FREQ);
+        pages_rw[page] = vp;
+        EncOut o;
+        o.length = pos + 9 + W + 4 + rb_size;  // so far; k_enc_freq_finish adds the nested block
+        o.out_off = 0;
+        o.slot = slot;
+        o.codec = SB_CODEC_FREQ;
+        o.pad = 0;
+        a.outs[page] = o;
+    }
+}
+
+__global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a, EncCol* cols_rw, EncPage* pages_rw) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SIDX_WORDS + 8 + FREQ_MAX_CONTAINERS + 3 * WG + 16];
+    if (*a.freq_count == 0) return;
+  for (uint32_t page = blockIdx.x; page < a.n_pages; page += gridDim.x) {
+    __syncthreads();
+    const EncPage p = get_page(a, page);
+    if (codec_of(a, p, page) != SB_CODEC_FREQ) continue;
+    const EncCol c = get_col(a, p.col);
+    if (c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY || c.ptype == SB_TYPE_NULL ||
+        c.width > 8 || p.rows == 0) {
+        if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 542);  // binary / 128-bit Freq pages: oracle only
+        continue;
+    }
+    switch (c.width) {
+        case 1:
+            freq_prep_page<1>(a, cols_rw, pages_rw, c, p, page, lds);
+            break;
+        case 2:
+            freq_prep_page<2>(a, cols_rw, pages_rw, c, p, page, lds);
+            break;
+        case 4:
+            freq_prep_page<4>(a, cols_rw, pages_rw, c, p, page, lds);
+            break;
+        default:
+            freq_prep_page<8>(a, cols_rw, pages_rw, c, p, page, lds);
+            break;
+    }
+  }
+}
+
+// The exceptions block of a Freq page (a virtual page): selection and encoding in ONE kernel, every
+// codec behind a runtime switch.  These blocks are small (<= 10 % of a page when Freq was chosen), so
+// the register cost of the monolithic shape does not matter, and a batch without Freq pages pays for
+// one near-empty launch per value width instead of one per (width, codec).
+template <int W>
+__device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* lds, uint32_t* s_w, uint32_t* s_misc2) {
+    uint32_t& s_sz = s_misc2[0];
+    uint32_t& s_codec = s_misc2[1];
+    uint32_t *sA = lds, *sB = lds + SIDX_WORDS, *sC = lds + 2 * SIDX_WORDS;
+    const EncPage p = get_page(a, page);
+    if (p.codec < CODEC_ON_DEVICE) return;  // no Freq page here
+    const EncCol c = get_col(a, p.col);
+    if (c.width != (uint32_t)W) return;
+    const uint64_t N = p.rows;
+    const uint8_t* vals = c.values;
+    const ValidView vv{nullptr, 0};
+    int32_t codec = p.codec;
+    if (codec == CODEC_ON_DEVICE) {
+        SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
+        SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16),
+                      p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
+        if (sc.gtab) {
+            uint64_t M = 64;
+            while (M < 2 * N) M <<= 1;
+            sc.gslots = M;
+        }
+        const uint32_t ch = choose_prim<W>([=](uint64_t i) { return ld_val<W>(vals + i * W); }, vv, N, c.nk, so, sc);
+        __syncthreads();
+        if (threadIdx.x == 0) s_codec = ch;
+        __syncthreads();
+        codec = (int32_t)s_codec;
+        __syncthreads();
+    }
+    uint8_t* blk = a.scratch + p.slot_off;
+    uint64_t blen = 0;
+    switch (codec) {
+        case SB_CODEC_NONE:
+            wg_copy(blk + 9, vals, N * W);
+            if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_NONE, (uint32_t)(N * W), (uint32_t)(N * W));
+            blen = 9 + N * W;
+            break;
+        case SB_CODEC_LZ4:
+        case SB_CODEC_ZSTD:
+        case SB_CODEC_SNAPPY: {
+            uint32_t sz;
+            __syncthreads();
+            if (codec == SB_CODEC_ZSTD) {
+                sz = zstd_store_frame_wg(vals, (uint32_t)(N * W), blk + 9, s_w);
+            } else if (codec == SB_CODEC_SNAPPY) {
+                sz = snappy_store_wg(vals, (uint32_t)(N * W), blk + 9);
+            } else {
+                uint32_t z = 0;
+                if (threadIdx.x < 64) z = lz4_compress_wave(vals, (uint32_t)(N * W), blk + 9, sA);
+                if (threadIdx.x == 0) s_sz = z;
+                __syncthreads();
+                sz = s_sz;
+            }
+            if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)codec, sz, (uint32_t)(N * W));
+            blen = 9 + sz;
+            break;
+        }
+        case SB_CODEC_RLE:
+            blen = emit_prim_page<W, SB_CODEC_RLE>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            break;
+        case SB_CODEC_DICT:
+            blen = emit_prim_page<W, SB_CODEC_DICT>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            break;
+        case SB_CODEC_ONEVALUE:
+            blen = emit_prim_page<W, SB_CODEC_ONEVALUE>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            break;
+        case SB_CODEC_BITPACKING:
+            blen = emit_prim_page<W, SB_CODEC_BITPACKING>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            break;
+        case SB_CODEC_DELTA_BITPACKING:
+            blen = emit_prim_page<W, SB_CODEC_DELTA_BITPACKING>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            break;
+        case SB_CODEC_PATAS:
+            blen = emit_prim_page<W, SB_CODEC_PATAS>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            break;
+        default:
+            if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 545);
+            break;
+    }
+    if (threadIdx.x == 0) {
+        EncOut o{blen, 0, blk, (uint32_t)codec, 0};
+        a.outs[page] = o;
+    }
+}
+// a few hundred workgroups walk all virtual pages: a batch without Freq pages costs a short launch
+template <int W>
+__global__ void __launch_bounds__(WG) k_enc_nested(EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * SIDX_WORDS];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_misc2[2];
+    if (*a.freq_count == 0) return;
+    for (uint32_t q = blockIdx.x; q < a.n_pages; q += gridDim.x) {
+        enc_nested_block<W>(a, a.n_pages + q, lds, s_w, s_misc2);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
+    if (*a.freq_count == 0) return;
+    const uint32_t page = blockIdx.x;
+    const EncPage p = get_page(a, page);
+    if (codec_of(a, p, page) != SB_CODEC_FREQ) return;
+    const EncOut o = a.outs[page];
+    if (o.codec != SB_CODEC_FREQ || o.length == 0) return;  // prep raised
+    const EncOut vo = a.outs[a.n_pages + page];
+    const EncCol c = get_col(a, p.col);
+    if (vo.length == 0) {
+        if (threadIdx.x == 0) {
+            raise(a.status, SB_ERR_NYI, page, 543);  // the exceptions block could not be encoded on the device
+            EncOut z = o;
+            z.length = 0;
+            a.outs[page] = z;
+        }
+        return;
+    }
+    if (o.length + vo.length > p.slot_cap) {  // only reachable when Freq is forced on a page that is mostly exceptions
+        if (threadIdx.x == 0) {
+            raise(a.status, SB_ERR_NYI, page, 544);
+            EncOut z = o;
+            z.length = 0;
+            a.outs[page] = z;
+        }
+        return;
+    }
+    wg_copy(o.slot + o.length, vo.slot, vo.length);
+    if (threadIdx.x == 0) {
+        const uint64_t pos = c.nullable ? def_section_bytes(p.rows) : 0;
+        const uint64_t total = o.length + vo.length;
+        put_hdr9(o.slot + pos, SB_CODEC_FREQ, (uint32_t)(total - pos - 9), (uint32_t)(p.rows * c.width));
+        EncOut z = o;
+        z.length = total;
+        a.outs[page] = z;
+    }
+}
+
 // pages whose codec is LZ4 (CommonCompression::Lz4 as the default, or chosen by the selector):
 // def levels + hdr9 + one LZ4 block (binary: offsets block + values block), one workgroup per page
 __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     __shared__ uint32_t tab[4096];
     __shared__ uint32_t s_sz;
-    const uint32_t page = blockIdx.x;
-    const EncPage p = a.pages[page];
+    const uint32_t page = blockIdx.x + a.page_base;
+    const EncPage p = get_page(a, page);
     const int32_t bc = codec_of(a, p, page);
     if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD && bc != SB_CODEC_SNAPPY) return;
-    const EncCol c = a.cols[p.col];
+    const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     uint8_t* slot = page_slot(a, c, p);
     const uint64_t N = p.rows;
@@ -2516,10 +2947,11 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
 
 // pages with codec None: (page, tile) parallel plain copies
 __global__ void __launch_bounds__(WG) k_enc_emit_tiles(EncodeArgs a) {
-    const uint32_t page = blockIdx.x;
+    const uint32_t page = blockIdx.x + a.page_base;
     const uint32_t tile = blockIdx.y;
-    const EncPage p = a.pages[page];
-    const EncCol c = a.cols[p.col];
+    const EncPage p = get_page(a, page);
+    if (p.codec < CODEC_ON_DEVICE) return;  // table entry not in use
+    const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) {
         if (tile == 0 && threadIdx.x == 0) {
             EncOut o{0, 0, c.out, 0, 0};
@@ -2626,9 +3058,9 @@ __global__ void k_enc_layout(EncodeArgs a, const uint64_t* res_off) {
 
 __global__ void __launch_bounds__(WG) k_enc_compact(EncodeArgs a) {
     const uint32_t page = blockIdx.x;
-    const EncPage p = a.pages[page];
+    const EncPage p = get_page(a, page);
     const EncOut o = a.outs[page];
-    const EncCol c = a.cols[p.col];
+    const EncCol c = get_col(a, p.col);
     if (o.out_off + o.length > c.out_cap) return;
     if (blockIdx.y == 0 && p.head_bytes && c.heads)  // the page's head (nested level section)
         wg_copy(c.out + o.out_off - p.head_bytes, c.heads + p.head_off, p.head_bytes);
@@ -2750,6 +3182,19 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         host_codec = opts->default_compression;
     const bool adaptive = host_codec < 0;  // codec chosen per page on the device (k_enc_select)
     const uint32_t forb = opts->forbidden_compressions;
+    if (host_codec == SB_CODEC_FREQ)
+        for (uint64_t i = 0; i < n; i++) {
+            const int32_t t = cols[i].physical_type;
+            if (t == SB_TYPE_BOOLEAN || t == SB_TYPE_NULL || enc_is_binary(t) || enc_type_width(t) > 8)
+                return ctx->fail(SB_ERR_NYI, "Freq pages of binary / 128-bit / boolean columns have no device encoder");
+        }
+    // Freq pages (chosen or forced) send their exceptions through a second wave of the same kernels
+    bool freq_possible = false;
+    if (host_codec == SB_CODEC_FREQ || (adaptive && !((forb >> SB_CODEC_FREQ) & 1)))
+        for (uint64_t i = 0; i < n; i++) {
+            const int32_t t = cols[i].physical_type;
+            freq_possible |= t != SB_TYPE_BOOLEAN && t != SB_TYPE_NULL && !enc_is_binary(t) && enc_type_width(t) <= 8;
+        }
 
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
     for (uint64_t i = 0; i < n; i++) {
@@ -2786,12 +3231,18 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     off = align_up(off + n * sizeof(uint64_t), 64);
     const size_t upload_bytes = off;
     const size_t o_outs = off;
-    off = align_up(off + P * sizeof(EncOut), 64);
+    off = align_up(off + 2 * P * sizeof(EncOut), 64);
     const size_t o_results = off;
     const size_t results_words = 2 * P + n;
     off = align_up(off + results_words * sizeof(uint64_t), 64);
     const size_t o_codecs = off;
-    off = align_up(off + P * sizeof(int32_t), 64);
+    off = align_up(off + 2 * P * sizeof(int32_t), 64);
+    const size_t o_freqcnt = off;
+    off = align_up(off + 64, 64);
+    const size_t o_vcols = off;
+    off = align_up(off + (freq_possible ? P : 0) * sizeof(EncCol), 64);
+    const size_t o_vpages = off;
+    off = align_up(off + (freq_possible ? P : 0) * sizeof(EncPage), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
     StageSlot* slot = acquire_slot(ctx, upload_bytes + results_words * sizeof(uint64_t));
@@ -2858,12 +3309,26 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 p.slot_off = scratch_off;
                 scratch_off += align_up(slot_fixed_bytes(c.physical_type, c.is_nullable, N), 16);
                 any_compact = true;
+                if (freq_possible && !bin && c.physical_type != SB_TYPE_BOOLEAN && d.width <= 8) {
+                    // a Freq page also holds the Roaring bitmap (<= 8 KiB + 8 B per 64 Ki rows, + header)
+                    scratch_off += align_up(N / 8 + 16 * (N / 65536 + 1) + 8192 + 64, 16);
+                    p.slot_cap = scratch_off - p.slot_off;
+                    p.ex_off = scratch_off;  // exception values
+                    scratch_off += align_up(N * d.width + 64, 16);
+                    p.vslot_off = scratch_off;  // slot of the exceptions block (a non-nullable page of <= N rows)
+                    scratch_off += align_up(slot_fixed_bytes(c.physical_type, 0, N), 16);
+                }
             }
             if (codec == SB_CODEC_DICT || (adaptive && !((forb >> SB_CODEC_DICT) & 1) && c.physical_type != SB_TYPE_BOOLEAN &&
                                            c.physical_type != SB_TYPE_NULL)) {
                 uint64_t M = 64;
                 while (M < 2 * N) M <<= 1;
                 p.aux_bytes = (M + 3 * N) * 4;
+            }
+            if (p.vslot_off && !((forb >> SB_CODEC_DICT) & 1)) {  // the exceptions block may be a Dict block
+                uint64_t M = 64;
+                while (M < 2 * N) M <<= 1;
+                p.vaux_bytes = (M + 3 * N) * 4;
             }
             if (codec == SB_CODEC_LZ4 || codec == SB_CODEC_ZSTD || codec == SB_CODEC_SNAPPY ||
                 (adaptive && (opts->default_compression == SB_CODEC_LZ4 || opts->default_compression == SB_CODEC_ZSTD ||
@@ -2893,9 +3358,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             hp[q].aux_off = scratch_off;
             scratch_off += hp[q].aux_bytes;
         }
+        if (hp[q].vaux_bytes) {
+            scratch_off = align_up(scratch_off, 16);
+            hp[q].vaux_off = scratch_off;
+            scratch_off += hp[q].vaux_bytes;
+        }
         if (!hp[q].direct) {
             const EncCol& d = hc[hp[q].col];
-            uint64_t cap = slot_fixed_bytes(d.ptype, d.nullable, hp[q].rows);
+            uint64_t cap = std::max<uint64_t>(slot_fixed_bytes(d.ptype, d.nullable, hp[q].rows), hp[q].slot_cap);
             if (enc_is_binary(d.ptype)) cap += d.values_len;
             max_chunks = std::max<uint64_t>(max_chunks, (cap + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
         }
@@ -2920,8 +3390,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.n_pages = (uint32_t)P;
     a.n_cols = (uint32_t)n;
     a.default_compression = (uint32_t)opts->default_compression;
+    a.vcols = (const EncCol*)(tb + o_vcols);
+    a.vpages = (const EncPage*)(tb + o_vpages);
+    a.page_base = 0;
+    a.nested_force = opts->force_index_codec;
+    a.freq_count = (uint32_t*)(tb + o_freqcnt);
+    (void)hipMemsetAsync(a.freq_count, host_codec == SB_CODEC_FREQ ? 1 : 0, 4, s);  // forced: every page is a Freq page
 
-    (void)hipMemsetAsync(a.outs, 0, P * sizeof(EncOut), s);
+    (void)hipMemsetAsync(a.outs, 0, 2 * P * sizeof(EncOut), s);
+    if (freq_possible) (void)hipMemsetAsync(tb + o_vpages, 0xFE, P * sizeof(EncPage), s);  // codec < -1: entry not in use
     auto kind_of = [](const EncCol& d) {
         return d.ptype == SB_TYPE_BOOLEAN ? 0 : d.ptype == SB_TYPE_BINARY ? -4 : d.ptype == SB_TYPE_LARGE_BINARY ? -8 : (int)d.width;
     };
@@ -2933,47 +3410,81 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         for (int q : kinds) seen |= q == kd;
         if (!seen) kinds.push_back(kd);
     }
-    if (adaptive) {
-        for (int kd : kinds) {
-            KScope k(ctx, K_ENC_SELECT);
-            enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(a);
-        }
-    }
-    if (any_tiles) {
-        KScope k(ctx, K_ENC_TILES);
-        k_enc_emit_tiles<<<dim3((uint32_t)P, (uint32_t)max_tiles), WG, 0, s>>>(a);
-    }
-    if (any_lz4) {
-        KScope k(ctx, K_ENC_LZ4);
-        k_enc_emit_lz4<<<(uint32_t)P, WG, 0, s>>>(a);
-    }
-    if (any_pages) {
-        // one kernel instance per (kind, codec) that can occur in the batch
-        static const int32_t CAND[6] = {SB_CODEC_ONEVALUE, SB_CODEC_DICT, SB_CODEC_RLE, SB_CODEC_BITPACKING,
-                                        SB_CODEC_DELTA_BITPACKING, SB_CODEC_PATAS};
-        for (int kd : kinds) {
-            for (int32_t cd : CAND) {
-                if (!adaptive && cd != host_codec) continue;
-                if (adaptive) {
-                    if ((forb >> cd) & 1) continue;
-                    if ((cd == SB_CODEC_BITPACKING || cd == SB_CODEC_DELTA_BITPACKING) && kd != 4) continue;
-                    if (kd == 0 && cd == SB_CODEC_DICT) continue;
-                    if (kd < 0 && cd == SB_CODEC_RLE) continue;
-                    if (cd == SB_CODEC_PATAS) {  // candidates of float columns only (double/mod.rs:271-277)
-                        bool any_float = false;
-                        for (uint64_t i = 0; i < n; i++) any_float |= hc[i].fkind != 0 && (int)hc[i].width == kd;
-                        if (!any_float) continue;
-                    }
-                }
-                EncPageKernel kf = enc_page_kernel(kd, cd);
-                if (!kf) continue;
-                KScope k(ctx, cd == SB_CODEC_RLE ? K_ENC_PAGES : cd == SB_CODEC_DICT ? K_ENC_PAGES_DICT
-                                : cd == SB_CODEC_ONEVALUE ? K_ENC_PAGES_ONEVALUE : cd == SB_CODEC_PATAS ? K_ENC_PAGES_PATAS : K_ENC_PAGES_BP);
-                kf<<<(uint32_t)P, WG, 0, s>>>(a);
+    // One wave of select + emit kernels over the table entries [aa.page_base, aa.page_base + P).
+    // wave_adaptive: codecs are chosen on the device; wave_codec: the one codec otherwise (-1: several possible).
+    auto run_wave = [&](const EncodeArgs& aa, bool wave_adaptive, int32_t wave_codec, bool nested) -> int32_t {
+        if (wave_adaptive) {
+            for (int kd : kinds) {
+                if (nested && (kd <= 0 || kd > 8)) continue;
+                KScope k(ctx, K_ENC_SELECT);
+                enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(aa);
             }
-            if (!adaptive && host_codec != SB_CODEC_NONE && !enc_page_kernel(kd, host_codec))
-                return ctx->fail(SB_ERR_NYI, "no device encoder for this codec (Freq pages are not built yet; Patas is for f32/f64)");
         }
+        const int32_t dc = opts->default_compression;
+        const bool basic_comp = dc == SB_CODEC_LZ4 || dc == SB_CODEC_ZSTD || dc == SB_CODEC_SNAPPY;
+        if (nested ? (wave_adaptive ? dc == SB_CODEC_NONE : wave_codec == SB_CODEC_NONE) : any_tiles) {
+            KScope k(ctx, K_ENC_TILES);
+            k_enc_emit_tiles<<<dim3((uint32_t)P, (uint32_t)max_tiles), WG, 0, s>>>(aa);
+        }
+        if (nested ? (wave_adaptive ? basic_comp : (wave_codec >= 1 && wave_codec <= 3)) : any_lz4) {
+            KScope k(ctx, K_ENC_LZ4);
+            k_enc_emit_lz4<<<(uint32_t)P, WG, 0, s>>>(aa);
+        }
+        if (nested || any_pages) {
+            // one kernel instance per (kind, codec) that can occur in the batch
+            static const int32_t CAND[6] = {SB_CODEC_ONEVALUE, SB_CODEC_DICT, SB_CODEC_RLE, SB_CODEC_BITPACKING,
+                                            SB_CODEC_DELTA_BITPACKING, SB_CODEC_PATAS};
+            for (int kd : kinds) {
+                if (nested && (kd <= 0 || kd > 8)) continue;
+                for (int32_t cd : CAND) {
+                    if (!wave_adaptive && cd != wave_codec) continue;
+                    if (wave_adaptive) {
+                        if ((forb >> cd) & 1) continue;
+                        if ((cd == SB_CODEC_BITPACKING || cd == SB_CODEC_DELTA_BITPACKING) && kd != 4) continue;
+                        if (kd == 0 && cd == SB_CODEC_DICT) continue;
+                        if (kd < 0 && cd == SB_CODEC_RLE) continue;
+                        if (cd == SB_CODEC_PATAS) {  // candidates of float columns only (double/mod.rs:271-277)
+                            bool any_float = false;
+                            for (uint64_t i = 0; i < n; i++) any_float |= hc[i].fkind != 0 && (int)hc[i].width == kd;
+                            if (!any_float) continue;
+                        }
+                    }
+                    EncPageKernel kf = enc_page_kernel(kd, cd);
+                    if (!kf) continue;
+                    KScope k(ctx, cd == SB_CODEC_RLE ? K_ENC_PAGES : cd == SB_CODEC_DICT ? K_ENC_PAGES_DICT
+                                    : cd == SB_CODEC_ONEVALUE ? K_ENC_PAGES_ONEVALUE : cd == SB_CODEC_PATAS ? K_ENC_PAGES_PATAS : K_ENC_PAGES_BP);
+                    kf<<<(uint32_t)P, WG, 0, s>>>(aa);
+                }
+                if (!nested && !wave_adaptive && wave_codec != SB_CODEC_NONE && wave_codec != SB_CODEC_FREQ && wave_codec > 3 &&
+                    !enc_page_kernel(kd, wave_codec))
+                    return ctx->fail(SB_ERR_NYI, "no device encoder for this codec and column type");
+            }
+        }
+        return SB_OK;
+    };
+    {
+        const int32_t rc = run_wave(a, adaptive, host_codec, false);
+        if (rc != SB_OK) return rc;
+    }
+    if (freq_possible) {  // Freq pages: bitmap + exceptions, then the exceptions block like any other block
+        {
+            KScope k(ctx, K_ENC_FREQ);
+            k_enc_freq_prep<<<(uint32_t)std::min<uint64_t>(P, 1024), WG, 0, s>>>(a, (EncCol*)(tb + o_vcols), (EncPage*)(tb + o_vpages));
+        }
+        for (int kd : kinds) {
+            if (kd != 1 && kd != 2 && kd != 4 && kd != 8) continue;
+            KScope k(ctx, K_ENC_FREQ);
+            if (kd == 1)
+                k_enc_nested<1><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
+            else if (kd == 2)
+                k_enc_nested<2><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
+            else if (kd == 4)
+                k_enc_nested<4><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
+            else
+                k_enc_nested<8><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
+        }
+        KScope k(ctx, K_ENC_FREQ);
+        k_enc_freq_finish<<<(uint32_t)P, WG, 0, s>>>(a);
     }
     {
         KScope k(ctx, K_ENC_LAYOUT);

@@ -68,3 +68,37 @@ def test_freq_and_other_pages_in_one_batch(gpu_ctx):
     gpu_ctx.synchronize()
     for g, w in zip(got, want):
         assert np.array_equal(g.values_numpy(), w["values"])
+
+
+# ---- encode: Freq pages written on the device equal the oracle's (integer/freq.rs:34-88)
+def test_freq_encode_matches_oracle(gpu_ctx):
+    from tests.test_gpu_encode import check as enc_check
+    for ptype in (S.T_U8, S.T_I16, S.T_I32, S.T_I64, S.T_F32, S.T_F64):
+        enc_check(gpu_ctx, sparse(ptype, 20_000, 0.05, 21), max_page_size=4096, force_codec=S.FREQ)
+        enc_check(gpu_ctx, sparse(ptype, 20_000, 0.05, 22, null_density=0.1), max_page_size=5000, force_codec=S.FREQ)
+        enc_check(gpu_ctx, sparse(ptype, 9_000, 0.0, 23), max_page_size=3000, force_codec=S.FREQ)      # no exceptions
+    enc_check(gpu_ctx, gen.prim(S.T_I64, 30_000, uniq=1000, null_density=0.95, seed=24), max_page_size=8192, force_codec=S.FREQ)
+    enc_check(gpu_ctx, sparse(S.T_I32, 65_536, 0.09, 25), max_page_size=65_536, force_codec=S.FREQ)   # bitmap container
+    enc_check(gpu_ctx, sparse(S.T_I64, 400_000, 0.08, 26), max_page_size=200_000, force_codec=S.FREQ)  # 4 containers
+
+
+def test_freq_encode_nested_codecs(gpu_ctx):
+    from tests.test_gpu_encode import check as enc_check
+    for kw, opt in ((dict(exc_uniq=3), dict(ratio=1.2)), (dict(exc_uniq=1 << 20), dict(default_compression=S.LZ4)),
+                    (dict(exc_uniq=200), dict(ratio=1.1, default_compression=S.ZSTD)), (dict(exc_uniq=1), dict(ratio=1.5)),
+                    (dict(exc_uniq=50), dict(force_index_codec=S.RLE)), (dict(exc_uniq=50), dict(force_index_codec=S.DICT))):
+        if opt.get("default_compression") == S.ZSTD:
+            continue  # Zstd blocks are format-valid but not byte-pinned
+        enc_check(gpu_ctx, sparse(S.T_I32, 128 * 700, 0.07, 27, **kw), max_page_size=128 * 350, force_codec=S.FREQ, **opt)
+
+
+def test_adaptive_selection_with_nothing_forbidden(gpu_ctx):
+    """the reference's default options: every codec is a candidate, and sparse pages come out as Freq"""
+    from tests.test_gpu_select import check as sel_check
+    seen = set()
+    for col in (sparse(S.T_I64, 128 * 300, 0.03, 31), sparse(S.T_F64, 128 * 300, 0.04, 32, null_density=0.05),
+                sparse(S.T_I32, 128 * 300, 0.02, 33, top=1000), gen.prim(S.T_I64, 128 * 300, uniq=500, null_density=0.95, seed=34),
+                gen.prim(S.T_I32, 128 * 300, uniq=40, runs=30, seed=35)):
+        for ratio in (1.2, 2.0):
+            seen |= set(sel_check(gpu_ctx, col, max_page_size=128 * 100, ratio=ratio, forbidden=()).tolist())
+    assert S.FREQ in seen and len(seen) >= 2, seen

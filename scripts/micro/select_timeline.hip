@@ -31,7 +31,7 @@ int main() {
     hipMemcpy(dv, hv.data(), P * N / 8, hipMemcpyHostToDevice);
     hipMemset(tl, 0, 8 * 4096);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
-    const uint32_t forb = (1u << SB_CODEC_FREQ);
+    const uint32_t forb = 0;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; i++) k_sel<<<P, WG>>>(d, dv, N, codecs, forb);
     hipEventRecord(a);

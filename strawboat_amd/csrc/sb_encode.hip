@@ -1621,10 +1621,12 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
     // hash set 64 keys at a time when it fills.  For run-heavy pages that is one probe pass per
     // ~1000 rows instead of one per 64; the comparison with row 0's key (all_equal) rides along.
     using KE = typename std::conditional<(W == 8), unsigned long long, uint32_t>::type;
-    constexpr uint32_t CBUF = 128;  // entries per wave
+    constexpr uint32_t CBUF = 96;  // entries per wave (a wave appends at most 64 at a time)
     const int lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     KE* cbuf = (KE*)(sc.sample_mem + CH / 8) + wv * CBUF;
+    // run length of every buffered key inside its 64-row group: the weight of the Freq vote
+    uint8_t* cwgt = sc.sample_mem + CH / 8 + 4 * CBUF * sizeof(KE) + wv * CBUF;
     uint32_t ccount = 0;
     auto flush = [&]() {
         for (uint32_t base = 0; base < ccount; base += 64) {
@@ -1634,6 +1636,18 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
             if constexpr (SMALL) __builtin_memcpy(&rv, &raw, W);
             const Val<W> kk = stat_key<W>(rv, nk);
             if (act && !bits_eq<W>(kk, k0)) f_neq0 = 1;
+            if (want_vote && act) {  // Boyer-Moore with run-length weights (== feeding the run's rows one by one)
+                const uint64_t x = k64(kk);
+                const uint32_t wgt = cwgt[base + lane];
+                if (vote_k == x) {
+                    vote_n += wgt;
+                } else if (vote_n >= wgt) {
+                    vote_n -= wgt;
+                } else {
+                    vote_k = x;
+                    vote_n = wgt - vote_n;
+                }
+            }
             if (want_set && act && s_kcnt <= KCAP) {
                 const uint64_t x = k64(kk);
                 if (x == SENT) {
@@ -1692,24 +1706,22 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
             if (W == 4 && i > 0 && int_lt<W>(v, pbuf[u], nk)) f_unsorted = 1;
         }
         if constexpr (SMALL) {
-            if (want_vote && in) {
-                const uint64_t x = k64(stat_key<W>(v, nk));
-                if (vote_n == 0) {
-                    vote_k = x;
-                    vote_n = 1;
-                } else if (vote_k == x) {
-                    vote_n++;
-                } else {
-                    vote_n--;
-                }
-            }
             const KE raw = (KE)k64(v);
             const KE prev = (KE)__shfl_up(raw, 1, 64);
             const bool bnd = in && (lane == 0 || raw != prev);
             const uint64_t bm = __ballot(bnd);
             const uint32_t nb = (uint32_t)__popcll(bm);
+            const uint32_t nin = (uint32_t)__popcll(__ballot(in));  // rows in range are a lane prefix
             if (ccount + nb > CBUF) flush();
-            if (bnd) cbuf[ccount + mbcnt64(bm)] = raw;
+            if (bnd) {
+                const uint32_t slot = ccount + mbcnt64(bm);
+                cbuf[slot] = raw;
+                if (want_vote) {  // rows up to the next boundary (or the end of the rows in range)
+                    const uint64_t later = lane == 63 ? 0ull : bm & (~0ull << (lane + 1));
+                    const uint32_t end = later ? (uint32_t)(__ffsll((long long)later) - 1) : nin;
+                    cwgt[slot] = (uint8_t)(end - (uint32_t)lane);
+                }
+            }
             ccount += nb;
         } else {
             if (in && !bits_eq<W>(stat_key<W>(v, nk), k0)) f_neq0 = 1;
@@ -1858,6 +1870,9 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
             }
             case SB_CODEC_PATAS: {  // patas.rs:139-141
                 if constexpr (W == 4 || W == 8) {
+                    // every value costs at least 2 bytes: the ratio stays below W / 2, so the trial cannot
+                    // change the outcome once another codec is at or above that (same choice, no work)
+                    if (max_ratio >= (double)W / 2) break;
                     commit_sample<W>(pre_patas, N, smp);
                     const uint32_t size = sample_patas_size<W>(smp, s4);
                     r = (double)((uint64_t)smp.n * W) / (double)size;
@@ -2244,7 +2259,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
     __shared__ uint32_t s_misc[2 * WG + 16];
     // sample area, also the streaming scratch of choose_prim: 1 KB validity words + 4 x 128 keys
-    constexpr int SMP = SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16, STR = 1024 + 4 * 128 * (KIND == 8 ? 8 : 4);
+    constexpr int SMP = SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16, STR = 1024 + 4 * 96 * (KIND == 8 ? 8 : 4) + 4 * 96;
     __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SMP > STR ? SMP : STR];
     const uint32_t page = blockIdx.x + a.page_base;
     const EncPage p = get_page(a, page);

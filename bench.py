@@ -13,8 +13,8 @@ k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (defau
 CU instead of exactly one (with 64 columns = 1024 pages = 4 per CU every phase of every workgroup
 runs in lockstep and the fixed ~0.1 ms of small kernels and launch gaps weighs 20 %).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
 page is chosen on the device by the reference's selector (it picks RLE for this data: sampled
-ratio ~14 vs Dict 7.6 vs Patas; the CPU oracle agrees, tests/test_oracle_golden.py).  Freq has no
-device encoder yet and is in forbidden_compressions (the reference's own option).
+ratio ~14 vs Dict 7.6 vs Patas < 4; the CPU oracle agrees, tests/test_oracle_golden.py).  Nothing is in
+forbidden_compressions: every codec of the reference is a candidate, as with its default options.
 
 Multi-GPU (torchrun, one rank per GPU): every rank owns its own `--columns` columns (weak
 scaling, pages of independent columns shard with no data-path collective); the only collective
@@ -82,7 +82,7 @@ def main():
     ctx = sb.Context(local_rank)
     B = args.columns
     codec = {"adaptive": -1, "rle": Compression.RLE, "none": Compression.NONE, "dict": Compression.DICT}[args.codec]
-    if codec < 0:   # the reference's adaptive mode; Freq has no device encoder yet and is forbidden
+    if codec < 0:   # the reference's adaptive mode with its default options: nothing forbidden
         opts = WriteOptions(max_page_size=PAGE, default_compress_ratio=2.0,
                             forbidden_compressions=[])
     else:

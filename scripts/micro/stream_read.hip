@@ -44,6 +44,22 @@ __global__ void __launch_bounds__(256) k_stream(const uint8_t* base, u64 page_by
     if (acc == 0x123456789ull) out[0] = acc;
 }
 
+// thread t reads 128 contiguous bytes (8 x 16 B loads) -- lanes are 128 B apart: no lane coalescing,
+// every cache line is consumed by one thread over 8 instructions
+__global__ void __launch_bounds__(256) k_stream_rows(const uint8_t* base, u64 page_bytes, u64* out) {
+    const uint8_t* p = base + (u64)blockIdx.x * page_bytes;
+    const int t = threadIdx.x;
+    u64 acc = 0;
+    for (u64 cb = 0; cb < page_bytes; cb += 256 * 128) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *(const u32x4*)(p + cb + (u64)t * 128 + u * 16);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x123456789ull) out[0] = acc;
+}
+
 template <int VEC, int K, int BAR, int PRE>
 void run(const char* name, const uint8_t* d, u64 pages, u64 page_bytes, int wpp, u64* out) {
     hipEvent_t a, b;
@@ -63,7 +79,18 @@ int main() {
     hipMalloc(&d, pages * page_bytes + 4096);
     hipMalloc(&out, 64);
     hipMemset(d, 1, pages * page_bytes);
-    for (int wpp : {1, 2, 4, 8}) {
+    {
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 3; i++) k_stream_rows<<<pages, 256>>>(d, page_bytes, out);
+        hipEventRecord(a);
+        for (int i = 0; i < 20; i++) k_stream_rows<<<pages, 256>>>(d, page_bytes, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); ms /= 20;
+        printf("%-44s wgs/page 1  %.3f ms  %.2f TB/s\n", "thread-contiguous 128 B (8 x 16 B), no LDS", ms, pages * page_bytes / ms / 1e9);
+    }
+    for (int wpp : {1}) {
         run<8, 16, 0, 1>("8B x16 prefetch, no barrier", d, pages, page_bytes, wpp, out);
         run<8, 16, 4, 1>("8B x16 prefetch, 4 barriers/chunk", d, pages, page_bytes, wpp, out);
         run<16, 8, 0, 1>("16B x8 prefetch, no barrier", d, pages, page_bytes, wpp, out);

@@ -1547,6 +1547,203 @@ __device__ uint32_t majority_count(Ops ops, uint64_t N, uint32_t* s_a /* 2*WG + 
 }
 
 // choose_compressor for primitives (integer/mod.rs:231-308, double/mod.rs:231-307)
+// thread-local partial statistics of one page, produced by a streaming pass (choose_prim's lane = row
+// pass, or the row-segment pass of the fused select + RLE kernel) and reduced by decide_prim
+template <int W>
+struct PrimPartials {
+    uint32_t f_neq0, f_unsorted, f_neg, nulls;
+    Val<W> tmax;
+    uint64_t vote_k;
+    uint32_t vote_n;
+};
+
+// gen_stats' reductions + choose_compressor (integer/mod.rs:231-308, double/mod.rs:231-307): the part of
+// the selector that does not depend on how the page was streamed
+template <int W, class GetVal>
+__device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, uint32_t nk, const SelectOpts& o,
+                                const SelScratch& sc, const PrimPartials<W>& pp, bool want_set, bool want_vote, uint32_t s_kcnt,
+                                uint32_t s_ksent, const SamplePre<W>& pre_rle, const SamplePre<W>& pre_bp,
+                                const SamplePre<W>& pre_dbp, const SamplePre<W>& pre_patas) {
+    auto valid = [&](uint64_t i) { return vv.get(i); };
+    (void)valid;
+    const int t = threadIdx.x;
+    auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
+    const bool is_float = nk >= NK_F32;
+    auto key = [&](uint64_t i) { return stat_key<W>(getv(i), nk); };
+    uint32_t* s4 = sc.s_misc + 2 * WG;
+    constexpr bool SMALL = W <= 8;
+    constexpr uint32_t KSLOTS = SEL_LDS_SLOTS / 2, KCAP = KSLOTS / 2;
+    auto k64 = [&](const Val<W>& k) {
+        uint64_t x = 0;
+        if constexpr (SMALL) __builtin_memcpy(&x, &k, W);
+        return x;
+    };
+    const uint32_t f_neq0 = pp.f_neq0, f_unsorted = pp.f_unsorted, f_neg = pp.f_neg, nulls = pp.nulls;
+    const Val<W> tmax = pp.tmax;
+    const uint64_t vote_k = pp.vote_k;
+    const uint32_t vote_n = pp.vote_n;
+    STL(1);
+    const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
+    const uint32_t null_count = wg_sum32(nulls, s4);
+    const bool all_equal = !(flags & 1);
+    bool is_sorted = !(flags & 2);
+    const bool any_neg = flags & 4;
+    if (!is_float && W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(getv(0), nk) < 0) is_sorted = false;  // vs last_value = 0
+    // exact distinct count from the LDS set (valid unless it overflowed)
+    uint32_t set_unique = 0;
+    bool set_ok = false;
+    if (want_set) {
+        set_unique = s_kcnt + s_ksent;
+        set_ok = s_kcnt <= KCAP;
+    }
+    // merged Boyer-Moore vote: (key, margin); a key with >= 90 % of the rows leaves margin >= 0.8 N
+    uint64_t maj_k = 0;
+    uint32_t maj_n = 0;
+    if (want_vote) {
+        unsigned long long* vk = (unsigned long long*)sc.sample_mem;  // 256 * 8 B, free until the samples are drawn
+        uint32_t* vn = sc.s_misc;
+        vk[t] = vote_k;
+        vn[t] = vote_n;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                const unsigned long long c0 = vk[t], c1 = vk[t + stride];
+                const uint32_t n0 = vn[t], n1 = vn[t + stride];
+                if (n1) {
+                    if (n0 == 0) {
+                        vk[t] = c1;
+                        vn[t] = n1;
+                    } else if (c0 == c1) {
+                        vn[t] = n0 + n1;
+                    } else if (n1 > n0) {
+                        vk[t] = c1;
+                        vn[t] = n1 - n0;
+                    } else {
+                        vn[t] = n0 - n1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        maj_k = vk[0];
+        maj_n = vn[0];
+        __syncthreads();
+    }
+    // typed maximum (only Freq for integers looks at it: max.as_i64() >= 256, freq.rs:146)
+    int64_t max_i64 = 0;
+    if (!is_float && !forbidden(SB_CODEC_FREQ)) {
+        Val<W>* red = (Val<W>*)sc.sample_mem;  // 256 * W bytes <= 8 KB, free until the samples are drawn
+        red[t] = tmax;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride && int_lt<W>(red[t], red[t + stride], nk)) red[t] = red[t + stride];
+            __syncthreads();
+        }
+        max_i64 = as_i64<W>(red[0], nk);
+        __syncthreads();
+    }
+    STL(2);
+    const double tuple_count = (double)N;
+    const double total_bytes = (double)(N * W);
+    double max_ratio = o.ratio;
+    uint32_t result = o.default_codec;
+    static const uint8_t INT_ORDER[6] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT,
+                                         SB_CODEC_RLE, SB_CODEC_BITPACKING, SB_CODEC_DELTA_BITPACKING};
+    static const uint8_t DBL_ORDER[5] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT, SB_CODEC_PATAS, SB_CODEC_RLE};
+    const int norder = is_float ? 5 : 6;
+    KeyOpsPrim<W, decltype(key)> kops{key};
+    Sample<W> smp;
+    smp.val = (Val<W>*)sc.sample_mem;
+    smp.valid = sc.sample_mem + SAMPLE_CAP * W;
+    for (int oi = 0; oi < norder; oi++) {
+        const uint32_t c = is_float ? DBL_ORDER[oi] : INT_ORDER[oi];
+        if (forbidden(c)) continue;
+        double r = 0.0;
+        switch (c) {
+            case SB_CODEC_ONEVALUE:  // one_value.rs:53-59
+                r = all_equal ? tuple_count : 0.0;
+                break;
+            case SB_CODEC_FREQ: {  // freq.rs:129-151
+                if (all_equal) break;
+                if ((double)null_count / tuple_count >= 0.9) {
+                    r = (double)(N - 1);
+                    break;
+                }
+                uint32_t mc;
+                if constexpr (SMALL) {
+                    mc = 0;
+                    if ((double)maj_n + 1.0 >= 0.8 * tuple_count) {  // only then can a key hold >= 90 % of the rows
+                        uint32_t mine = 0;
+                        for (uint64_t i = t; i < N; i += WG) mine += k64(key(i)) == maj_k ? 1 : 0;
+                        mc = wg_sum32(mine, s4);
+                    }
+                } else {
+                    mc = majority_count(kops, N, sc.s_misc);
+                }
+                const bool big = is_float ? true : (max_i64 >= 256);
+                if ((double)mc / tuple_count >= 0.9 && big) r = (double)(N - 1);
+                break;
+            }
+            case SB_CODEC_DICT: {  // dict.rs:109-120
+                if (N < 3) break;
+                const uint32_t limit = (uint32_t)((N - 1) / 3);  // largest unique with unique*3 < N
+                const uint32_t uq = all_equal ? 1u : (set_ok ? set_unique : distinct_count(kops, N, limit, sc, nullptr));
+                if ((uint64_t)uq * 3 >= N) break;
+                uint64_t after = (uint64_t)uq * W + N * (uint64_t)(bits_needed(uq) / 8);
+                after += N * 2 / 128;
+                r = total_bytes / (double)after;
+                break;
+            }
+            case SB_CODEC_RLE: {  // rle.rs:58-60
+                commit_sample<W>(pre_rle, N, smp);
+                uint32_t runs;
+                if (nk == NK_F32)
+                    runs = sample_rle_runs<W, (W == 4 ? 1 : 0)>(smp, s4);
+                else if (nk == NK_F64)
+                    runs = sample_rle_runs<W, (W == 8 ? 2 : 0)>(smp, s4);
+                else
+                    runs = sample_rle_runs<W, 0>(smp, s4);
+                r = (double)((uint64_t)smp.n * W) / (double)((uint64_t)runs * (4 + W));
+                __syncthreads();
+                break;
+            }
+            case SB_CODEC_BITPACKING:  // bp.rs:92-100
+            case SB_CODEC_DELTA_BITPACKING: {  // delta_bp.rs:97-109
+                if constexpr (W == 4) {
+                    if (any_neg || N % 128 != 0) break;
+                    if (c == SB_CODEC_DELTA_BITPACKING && (!is_sorted || null_count > 0)) break;
+                    commit_sample<4>(c == SB_CODEC_BITPACKING ? pre_bp : pre_dbp, N, smp);
+                    const uint32_t size = sample_bp_size(smp, s4, sc.s_misc);
+                    r = (double)((uint64_t)smp.n * 4) / (double)size;
+                    if (c == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
+                    __syncthreads();
+                }
+                break;
+            }
+            case SB_CODEC_PATAS: {  // patas.rs:139-141
+                if constexpr (W == 4 || W == 8) {
+                    // every value costs at least 2 bytes: the ratio stays below W / 2, so the trial cannot
+                    // change the outcome once another codec is at or above that (same choice, no work)
+                    if (max_ratio >= (double)W / 2) break;
+                    commit_sample<W>(pre_patas, N, smp);
+                    const uint32_t size = sample_patas_size<W>(smp, s4);
+                    r = (double)((uint64_t)smp.n * W) / (double)size;
+                    __syncthreads();
+                }
+                break;
+            }
+        }
+        STL(3 + oi);
+        if (r > max_ratio) {
+            max_ratio = r;
+            result = c;
+            if (r == tuple_count) break;
+        }
+    }
+    STL(10);
+    return result;
+}
+
 template <int W, class GetVal>
 __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, uint32_t nk, const SelectOpts& o,
                                 const SelScratch& sc) {
@@ -1730,166 +1927,9 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
      }
     }
     if constexpr (SMALL) flush();
-    STL(1);
-    const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
-    const uint32_t null_count = wg_sum32(nulls, s4);
-    const bool all_equal = !(flags & 1);
-    bool is_sorted = !(flags & 2);
-    const bool any_neg = flags & 4;
-    if (!is_float && W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(getv(0), nk) < 0) is_sorted = false;  // vs last_value = 0
-    // exact distinct count from the LDS set (valid unless it overflowed)
-    uint32_t set_unique = 0;
-    bool set_ok = false;
-    if (want_set) {
-        set_unique = s_kcnt + s_ksent;
-        set_ok = s_kcnt <= KCAP;
-    }
-    // merged Boyer-Moore vote: (key, margin); a key with >= 90 % of the rows leaves margin >= 0.8 N
-    uint64_t maj_k = 0;
-    uint32_t maj_n = 0;
-    if (want_vote) {
-        unsigned long long* vk = (unsigned long long*)sc.sample_mem;  // 256 * 8 B, free until the samples are drawn
-        uint32_t* vn = sc.s_misc;
-        vk[t] = vote_k;
-        vn[t] = vote_n;
-        __syncthreads();
-        for (int stride = WG / 2; stride > 0; stride >>= 1) {
-            if (t < stride) {
-                const unsigned long long c0 = vk[t], c1 = vk[t + stride];
-                const uint32_t n0 = vn[t], n1 = vn[t + stride];
-                if (n1) {
-                    if (n0 == 0) {
-                        vk[t] = c1;
-                        vn[t] = n1;
-                    } else if (c0 == c1) {
-                        vn[t] = n0 + n1;
-                    } else if (n1 > n0) {
-                        vk[t] = c1;
-                        vn[t] = n1 - n0;
-                    } else {
-                        vn[t] = n0 - n1;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        maj_k = vk[0];
-        maj_n = vn[0];
-        __syncthreads();
-    }
-    // typed maximum (only Freq for integers looks at it: max.as_i64() >= 256, freq.rs:146)
-    int64_t max_i64 = 0;
-    if (!is_float && !forbidden(SB_CODEC_FREQ)) {
-        Val<W>* red = (Val<W>*)sc.sample_mem;  // 256 * W bytes <= 8 KB, free until the samples are drawn
-        red[t] = tmax;
-        __syncthreads();
-        for (int stride = WG / 2; stride > 0; stride >>= 1) {
-            if (t < stride && int_lt<W>(red[t], red[t + stride], nk)) red[t] = red[t + stride];
-            __syncthreads();
-        }
-        max_i64 = as_i64<W>(red[0], nk);
-        __syncthreads();
-    }
-    STL(2);
-    const double tuple_count = (double)N;
-    const double total_bytes = (double)(N * W);
-    double max_ratio = o.ratio;
-    uint32_t result = o.default_codec;
-    static const uint8_t INT_ORDER[6] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT,
-                                         SB_CODEC_RLE, SB_CODEC_BITPACKING, SB_CODEC_DELTA_BITPACKING};
-    static const uint8_t DBL_ORDER[5] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT, SB_CODEC_PATAS, SB_CODEC_RLE};
-    const int norder = is_float ? 5 : 6;
-    KeyOpsPrim<W, decltype(key)> kops{key};
-    Sample<W> smp;
-    smp.val = (Val<W>*)sc.sample_mem;
-    smp.valid = sc.sample_mem + SAMPLE_CAP * W;
-    for (int oi = 0; oi < norder; oi++) {
-        const uint32_t c = is_float ? DBL_ORDER[oi] : INT_ORDER[oi];
-        if (forbidden(c)) continue;
-        double r = 0.0;
-        switch (c) {
-            case SB_CODEC_ONEVALUE:  // one_value.rs:53-59
-                r = all_equal ? tuple_count : 0.0;
-                break;
-            case SB_CODEC_FREQ: {  // freq.rs:129-151
-                if (all_equal) break;
-                if ((double)null_count / tuple_count >= 0.9) {
-                    r = (double)(N - 1);
-                    break;
-                }
-                uint32_t mc;
-                if constexpr (SMALL) {
-                    mc = 0;
-                    if ((double)maj_n + 1.0 >= 0.8 * tuple_count) {  // only then can a key hold >= 90 % of the rows
-                        uint32_t mine = 0;
-                        for (uint64_t i = t; i < N; i += WG) mine += k64(key(i)) == maj_k ? 1 : 0;
-                        mc = wg_sum32(mine, s4);
-                    }
-                } else {
-                    mc = majority_count(kops, N, sc.s_misc);
-                }
-                const bool big = is_float ? true : (max_i64 >= 256);
-                if ((double)mc / tuple_count >= 0.9 && big) r = (double)(N - 1);
-                break;
-            }
-            case SB_CODEC_DICT: {  // dict.rs:109-120
-                if (N < 3) break;
-                const uint32_t limit = (uint32_t)((N - 1) / 3);  // largest unique with unique*3 < N
-                const uint32_t uq = all_equal ? 1u : (set_ok ? set_unique : distinct_count(kops, N, limit, sc, nullptr));
-                if ((uint64_t)uq * 3 >= N) break;
-                uint64_t after = (uint64_t)uq * W + N * (uint64_t)(bits_needed(uq) / 8);
-                after += N * 2 / 128;
-                r = total_bytes / (double)after;
-                break;
-            }
-            case SB_CODEC_RLE: {  // rle.rs:58-60
-                commit_sample<W>(pre_rle, N, smp);
-                uint32_t runs;
-                if (nk == NK_F32)
-                    runs = sample_rle_runs<W, (W == 4 ? 1 : 0)>(smp, s4);
-                else if (nk == NK_F64)
-                    runs = sample_rle_runs<W, (W == 8 ? 2 : 0)>(smp, s4);
-                else
-                    runs = sample_rle_runs<W, 0>(smp, s4);
-                r = (double)((uint64_t)smp.n * W) / (double)((uint64_t)runs * (4 + W));
-                __syncthreads();
-                break;
-            }
-            case SB_CODEC_BITPACKING:  // bp.rs:92-100
-            case SB_CODEC_DELTA_BITPACKING: {  // delta_bp.rs:97-109
-                if constexpr (W == 4) {
-                    if (any_neg || N % 128 != 0) break;
-                    if (c == SB_CODEC_DELTA_BITPACKING && (!is_sorted || null_count > 0)) break;
-                    commit_sample<4>(c == SB_CODEC_BITPACKING ? pre_bp : pre_dbp, N, smp);
-                    const uint32_t size = sample_bp_size(smp, s4, sc.s_misc);
-                    r = (double)((uint64_t)smp.n * 4) / (double)size;
-                    if (c == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
-                    __syncthreads();
-                }
-                break;
-            }
-            case SB_CODEC_PATAS: {  // patas.rs:139-141
-                if constexpr (W == 4 || W == 8) {
-                    // every value costs at least 2 bytes: the ratio stays below W / 2, so the trial cannot
-                    // change the outcome once another codec is at or above that (same choice, no work)
-                    if (max_ratio >= (double)W / 2) break;
-                    commit_sample<W>(pre_patas, N, smp);
-                    const uint32_t size = sample_patas_size<W>(smp, s4);
-                    r = (double)((uint64_t)smp.n * W) / (double)size;
-                    __syncthreads();
-                }
-                break;
-            }
-        }
-        STL(3 + oi);
-        if (r > max_ratio) {
-            max_ratio = r;
-            result = c;
-            if (r == tuple_count) break;
-        }
-    }
-    STL(10);
-    return result;
+    PrimPartials<W> pp{f_neq0, f_unsorted, f_neg, nulls, tmax, vote_k, vote_n};
+    return decide_prim<W>(getv, vv, N, nk, o, sc, pp, want_set, want_vote, want_set ? s_kcnt : 0u, want_set ? s_ksent : 0u, pre_rle,
+                          pre_bp, pre_dbp, pre_patas);
 }
 
 // choose_compressor for booleans (boolean/mod.rs:194-238) with gen_stats (:151-192)

@@ -1927,6 +1927,7 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
      }
     }
     if constexpr (SMALL) flush();
+    __syncthreads();  // every wave's keys are in the set before its size is read
     PrimPartials<W> pp{f_neq0, f_unsorted, f_neg, nulls, tmax, vote_k, vote_n};
     return decide_prim<W>(getv, vv, N, nk, o, sc, pp, want_set, want_vote, want_set ? s_kcnt : 0u, want_set ? s_ksent : 0u, pre_rle,
                           pre_bp, pre_dbp, pre_patas);

@@ -2295,6 +2295,8 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
 }
 
 // codec choice per page (adaptive mode): one workgroup per page, one instance per KIND
+#include "sb_select_rle.h"
+
 template <int KIND>
 __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
@@ -2349,6 +2351,41 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     }
 }
 
+// Adaptive pages of 4- / 8-byte values: statistics and speculative RLE in one pass (sb_select_rle.h).
+// One instance per (width, float-ness): the RLE equality differs, and keeping each instance a kernel of
+// its own keeps it at 4 waves / SIMD (several big inlined paths in one kernel double the registers).
+template <int KIND, int FK>
+__global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
+    __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
+    __shared__ uint32_t s_misc[2 * WG + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * (KIND + 1) + 16];
+    __shared__ uint32_t s_cnt2[2];
+    const uint32_t page = blockIdx.x;
+    const EncPage p = a.pages[page];
+    if (p.codec != CODEC_ON_DEVICE) return;
+    const EncCol c = a.cols[p.col];
+    if (c.ptype == SB_TYPE_NULL || c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY) return;
+    if (c.width != (uint32_t)KIND || (c.fkind != 0) != (FK != 0)) return;
+    const uint64_t N = p.rows;
+    SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
+    SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
+    if (sc.gtab) {  // the Dict aux area starts with a table of pow2 >= 2N slots
+        uint64_t M = 64;
+        while (M < 2 * N) M <<= 1;
+        sc.gslots = M;
+    }
+    uint32_t codec = so.default_codec;
+    bool kept = false;
+    if (N > 0) codec = select_rle_page<KIND, FK>(a, c, p, page, so, sc, s_cnt2, &kept);
+    if (threadIdx.x == 0) {
+        a.codecs[page] = (int32_t)codec;
+        if (!has_device_encoder(codec))
+            raise(a.status, SB_ERR_NYI, page, 700 + codec);
+        else if (codec == SB_CODEC_FREQ)
+            atomicAdd(a.freq_count, 1u);
+    }
+}
+
 typedef void (*EncSelectKernel)(EncodeArgs);
 static EncSelectKernel enc_select_kernel(int kind) {
     switch (kind) {
@@ -2391,6 +2428,9 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     const uint32_t page = blockIdx.x + a.page_base;
     const EncPage p = get_page(a, page);
     if (codec_of(a, p, page) != CODEC) return;
+    if constexpr (CODEC == SB_CODEC_RLE) {
+        if (a.outs[page].pad == 1 && a.outs[page].length != 0) return;  // already emitted by the fused select + RLE pass
+    }
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     const bool is_bool = c.ptype == SB_TYPE_BOOLEAN;
@@ -3472,6 +3512,29 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (wave_adaptive) {
             for (int kd : kinds) {
                 if (nested && (kd <= 0 || kd > 8)) continue;
+                if (!nested && (kd == 4 || kd == 8)) {  // statistics + speculative RLE in one pass
+                    bool any_f = false, any_i = false;
+                    for (uint64_t i = 0; i < n; i++)
+                        if ((int)hc[i].width == kd && hc[i].ptype != SB_TYPE_BOOLEAN && !enc_is_binary(hc[i].ptype)) {
+                            any_f |= hc[i].fkind != 0;
+                            any_i |= hc[i].fkind == 0;
+                        }
+                    if (any_f) {
+                        KScope k(ctx, K_ENC_SELECT);
+                        if (kd == 4)
+                            k_enc_select_rle<4, 1><<<(uint32_t)P, WG, 0, s>>>(aa);
+                        else
+                            k_enc_select_rle<8, 2><<<(uint32_t)P, WG, 0, s>>>(aa);
+                    }
+                    if (any_i) {
+                        KScope k(ctx, K_ENC_SELECT);
+                        if (kd == 4)
+                            k_enc_select_rle<4, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
+                        else
+                            k_enc_select_rle<8, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
+                    }
+                    continue;
+                }
                 KScope k(ctx, K_ENC_SELECT);
                 enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(aa);
             }

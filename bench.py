@@ -166,7 +166,7 @@ def main():
              "k_expand_rle": page_bytes + U,
              "k_enc_emit_pages": U + page_bytes,    # A_enc = Arrow bytes read + page bytes written
              "k_enc_emit_tiles": U + page_bytes,
-             "k_enc_select": U}                     # the selector reads the Arrow buffers once
+             "k_enc_select": U + page_bytes}        # fused selection + RLE: Arrow bytes read once, pages written
         base = lambda k: k.split("<")[0]
         dom = max((k for k in stats if base(k) in A), key=lambda k: stats[k][1], default=None)
         roof = None

@@ -84,3 +84,16 @@ def test_unsupported_choice_is_loud(gpu_ctx):
     with pytest.raises(NativeError) as e:
         gpu_encode(gpu_ctx, gen.binary(8192, uniq=40, seed=5), force_codec=S.FREQ)
     assert e.value.code == -4
+
+
+def test_rle_chosen_after_the_speculation_stopped(gpu_ctx):
+    """runs of ~2.5 rows: the fused select + RLE pass gives up writing records (< 4 rows per run), the
+    selector still picks RLE (everything else is forbidden or worse), and the ordinary RLE kernel encodes"""
+    for ptype in (S.T_I64, S.T_F64, S.T_I32, S.T_F32):
+        col = gen.prim(ptype, 128 * 512, uniq=1 << 20, runs=3, null_density=0.05)
+        codecs = check(gpu_ctx, col, max_page_size=128 * 128, ratio=1.1, forbidden=(S.DICT, S.FREQ, S.PATAS, S.BITPACK, S.DELTABP))
+        assert (codecs == S.RLE).all()
+    # and the other way round: long runs in a page whose first rows are all different
+    v = np.concatenate([np.arange(3000), np.repeat(np.arange(50), 1000)]).astype(np.int64)
+    col = dict(ptype=S.T_I64, nullable=False, rows=v.size, values=v, validity=None, offsets=None)
+    check(gpu_ctx, col, ratio=1.5, forbidden=(S.DICT,))

@@ -1563,7 +1563,7 @@ template <int W, class GetVal>
 __device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, uint32_t nk, const SelectOpts& o,
                                 const SelScratch& sc, const PrimPartials<W>& pp, bool want_set, bool want_vote, uint32_t s_kcnt,
                                 uint32_t s_ksent, const SamplePre<W>& pre_rle, const SamplePre<W>& pre_bp,
-                                const SamplePre<W>& pre_dbp, const SamplePre<W>& pre_patas) {
+                                const SamplePre<W>& pre_dbp, const SamplePre<W>& pre_patas, bool prefetched = true) {
     auto valid = [&](uint64_t i) { return vv.get(i); };
     (void)valid;
     const int t = threadIdx.x;
@@ -1695,7 +1695,10 @@ __device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                 break;
             }
             case SB_CODEC_RLE: {  // rle.rs:58-60
-                commit_sample<W>(pre_rle, N, smp);
+                if (prefetched)
+                    commit_sample<W>(pre_rle, N, smp);
+                else
+                    load_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_RLE, smp);
                 uint32_t runs;
                 if (nk == NK_F32)
                     runs = sample_rle_runs<W, (W == 4 ? 1 : 0)>(smp, s4);
@@ -1712,7 +1715,10 @@ __device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                 if constexpr (W == 4) {
                     if (any_neg || N % 128 != 0) break;
                     if (c == SB_CODEC_DELTA_BITPACKING && (!is_sorted || null_count > 0)) break;
-                    commit_sample<4>(c == SB_CODEC_BITPACKING ? pre_bp : pre_dbp, N, smp);
+                    if (prefetched)
+                        commit_sample<4>(c == SB_CODEC_BITPACKING ? pre_bp : pre_dbp, N, smp);
+                    else
+                        load_sample<4>(getv, valid, N, o.seed, o.depth, c, smp);
                     const uint32_t size = sample_bp_size(smp, s4, sc.s_misc);
                     r = (double)((uint64_t)smp.n * 4) / (double)size;
                     if (c == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
@@ -1725,7 +1731,10 @@ __device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                     // every value costs at least 2 bytes: the ratio stays below W / 2, so the trial cannot
                     // change the outcome once another codec is at or above that (same choice, no work)
                     if (max_ratio >= (double)W / 2) break;
-                    commit_sample<W>(pre_patas, N, smp);
+                    if (prefetched)
+                        commit_sample<W>(pre_patas, N, smp);
+                    else
+                        load_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_PATAS, smp);
                     const uint32_t size = sample_patas_size<W>(smp, s4);
                     r = (double)((uint64_t)smp.n * W) / (double)size;
                     __syncthreads();

@@ -20,7 +20,7 @@ template <int W, int FK>
 __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, const SelectOpts& o,
                                     const SelScratch& sc, uint32_t* s_cnt2 /* s_kcnt, s_ksent */, bool* rle_kept) {
     static_assert(W == 4 || W == 8, "fused select + RLE: 4- and 8-byte values");
-    constexpr int K = 8;
+    constexpr int K = 16;
     constexpr uint32_t CHUNK = WG * K;
     constexpr int REC = 4 + W;
     constexpr uint64_t SENT = ~0ull;
@@ -44,16 +44,7 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
         return x;
     };
     *rle_kept = false;
-    // sample rows of the trials (SamplePre): fetched before the pass, committed by decide_prim
-    SamplePre<W> pre_rle, pre_bp, pre_dbp, pre_patas;
-    if (!forbidden(SB_CODEC_RLE)) pre_rle = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_RLE);
-    if constexpr (W == 4) {
-        if (!is_float && !forbidden(SB_CODEC_BITPACKING) && N % 128 == 0)
-            pre_bp = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_BITPACKING);
-        if (!is_float && !forbidden(SB_CODEC_DELTA_BITPACKING) && N % 128 == 0)
-            pre_dbp = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_DELTA_BITPACKING);
-    }
-    if (is_float && !forbidden(SB_CODEC_PATAS)) pre_patas = prefetch_sample<W>(getv, valid, N, o.seed, o.depth, SB_CODEC_PATAS);
+    // (the trials' sample rows are loaded by decide_prim: prefetching them here costs the registers K = 16 needs)
     // ---- selector state
     const Val<W> k0 = stat_key<W>(getv(0), nk);
     uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, nulls = 0;
@@ -70,7 +61,7 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
         s_kcnt = 0;
         s_ksent = 0;
     }
-    KE* cbuf = (KE*)sc.sample_mem + w * CBUF;          // canonical keys waiting to be probed (per wave)
+    KE* cbuf = (KE*)sc.sample_mem + w * CBUF;          // values whose key changed, waiting to be probed (per wave)
     uint32_t* sA = (uint32_t*)(sc.sample_mem + 4 * CBUF * sizeof(KE));  // RLE wave records (64 words)
     uint32_t* sB = sA + 64;                             // RLE wave values (8 * W bytes)
     __syncthreads();
@@ -78,9 +69,11 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
     auto flush = [&]() {
         for (uint32_t base = 0; base < ccount; base += 64) {
             const bool act = base + lane < ccount;
-            const uint64_t x = act ? (uint64_t)cbuf[base + lane] : 0;
-            Val<W> kk;
-            __builtin_memcpy(&kk, &x, W);
+            const uint64_t rawx = act ? (uint64_t)cbuf[base + lane] : 0;
+            Val<W> rv;
+            __builtin_memcpy(&rv, &rawx, W);
+            const Val<W> kk = stat_key<W>(rv, nk);  // the buffer holds raw values: one canonicalisation per 64 keys
+            const uint64_t x = k64(kk);
             if (act && !bits_eq<W>(kk, k0)) f_neq0 = 1;
             if (want_set && act && s_kcnt <= KCAP) {
                 if (x == SENT) {
@@ -200,7 +193,7 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
                     uint32_t at = ccount + incl - mycnt;
 #pragma unroll
                     for (int j = 0; j < K; j++)
-                        if ((sbm >> j) & 1) cbuf[at++] = (KE)k64(stat_key<W>(v[j], nk));
+                        if ((sbm >> j) & 1) cbuf[at++] = (KE)k64(v[j]);
                     ccount += total;
                 } else {  // more changes than the buffer holds (no runs at all): row position by row position
 #pragma unroll
@@ -209,7 +202,7 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
                         const uint64_t bm = __ballot(b);
                         const uint32_t nb = (uint32_t)__popcll(bm);
                         if (ccount + nb > CBUF) flush();
-                        if (b) cbuf[ccount + mbcnt64(bm)] = (KE)k64(stat_key<W>(v[j], nk));
+                        if (b) cbuf[ccount + mbcnt64(bm)] = (KE)k64(v[j]);
                         ccount += nb;
                     }
                 }
@@ -296,7 +289,9 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
     __syncthreads();  // every wave's keys are in the set before its size is read
     PrimPartials<W> pp{f_neq0, f_unsorted, f_neg, nulls, tmax, vote_k, vote_n};
     const uint32_t s_k = want_set ? s_kcnt : 0u, s_s = want_set ? s_ksent : 0u;
-    const uint32_t codec = decide_prim<W>(getv, vv, N, nk, o, sc, pp, want_set, want_vote, s_k, s_s, pre_rle, pre_bp, pre_dbp, pre_patas);
+    SamplePre<W> none;
+    __builtin_memset(&none, 0, sizeof none);
+    const uint32_t codec = decide_prim<W>(getv, vv, N, nk, o, sc, pp, want_set, want_vote, s_k, s_s, none, none, none, none, false);
     if (codec == SB_CODEC_RLE && spec) {  // keep the records: close the last run, add the def levels and the header
         if (t == 0) {
             uint8_t* r = dst + (uint64_t)nrec * REC;

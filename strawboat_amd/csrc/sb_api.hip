@@ -524,11 +524,14 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
 
     // results: values_len per column
     uint8_t* hv = slot->host + upload_bytes;
-    if (P) {
+    if (P && (any_binary || sizes_only)) {
         e = hipMemcpyAsync(hv, d_vlen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return check_hip(ctx, e, "values_len readback");
     } else {
-        memset(hv, 0, n * sizeof(uint64_t));
+        for (uint64_t i = 0; i < n; i++) {  // fixed-width columns: rows * width (booleans: bitmap bytes)
+            const uint64_t v = !P ? 0 : hc[i].ptype == SB_TYPE_BOOLEAN ? (hc[i].rows + 7) / 8 : hc[i].rows * hc[i].width;
+            memcpy(hv + i * sizeof(uint64_t), &v, sizeof v);
+        }
     }
     (void)hipEventRecord(slot->done, s);
     slot->in_flight = true;

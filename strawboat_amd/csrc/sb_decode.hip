@@ -1326,13 +1326,13 @@ __device__ __forceinline__ uint32_t xcd_tile_index() {
 // short: the tile task carries the column index and, for RLE pages, the tile's run range (k_plan),
 // which lets the three descriptors, the validity word and the run starts be fetched in two steps;
 // only the gather of the run values follows.
-__global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
-    __shared__ uint32_t s_a[SIDX_WORDS];
-    __shared__ uint32_t s_w[4];
+constexpr uint32_t TILES_PER_WG = 4;  // a workgroup takes 4 entries of the tile list, one after the other: the
+                                      // grid is sized by the host's upper bound, and entries that do not exist
+                                      // (pages expanded by k_expand_rle) should not each cost a workgroup launch
+__device__ void expand_tile(const DecodeArgs& a, uint32_t ti, uint32_t* s_a, uint32_t* s_w) {
     static_assert(TILE_ROWS / 32 <= WG, "one validity word per thread");
     DTL(0);
-    if (blockIdx.x >= a.job_counts[2]) return;  // (the grid is sized by the host's upper bound)
-    const TileTask tt = a.tiles[blockIdx.x];
+    const TileTask tt = a.tiles[ti];
     const PageDesc d = a.descs[tt.page];
     const PageTask t = a.tasks[tt.page];
     const ColDesc c = a.cols[tt.col];
@@ -1374,6 +1374,18 @@ __global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
         case 32:
             expand_prim<32>(c, t, d, tt.tile, rows, a.scratch, s_a, s_w, a.status, tt.page, tt.k0, tt.kend, st);
             break;
+    }
+}
+
+__global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
+    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ uint32_t s_w[4];
+    const uint32_t count = a.job_counts[2];
+    for (uint32_t q = 0; q < TILES_PER_WG; q++) {
+        const uint32_t ti = blockIdx.x * TILES_PER_WG + q;
+        if (ti >= count) return;
+        expand_tile(a, ti, s_a, s_w);
+        __syncthreads();
     }
 }
 
@@ -1532,12 +1544,8 @@ __global__ void __launch_bounds__(WG) k_expand_rle(DecodeArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
-    __shared__ uint32_t s_a[SIDX_WORDS];
-    __shared__ uint32_t s_len[SIDX_WORDS];
-    __shared__ uint32_t s_w[4];
-    if (blockIdx.x >= a.job_counts[2]) return;
-    const TileTask tt = a.tiles[blockIdx.x];
+__device__ void expand_binary_tile(const DecodeArgs& a, uint32_t ti, uint32_t* s_a, uint32_t* s_len, uint32_t* s_w) {
+    const TileTask tt = a.tiles[ti];
     const PageDesc d = a.descs[tt.page];
     if (!d.ok) return;
     const PageTask t = a.tasks[tt.page];
@@ -1550,6 +1558,19 @@ __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
         expand_binary<int32_t>(c, t, d, tt.tile, rows, a.scratch, s_a, s_len, s_w, a.status, tt.page);
     else
         expand_binary<int64_t>(c, t, d, tt.tile, rows, a.scratch, s_a, s_len, s_w, a.status, tt.page);
+}
+
+__global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
+    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ uint32_t s_len[SIDX_WORDS];
+    __shared__ uint32_t s_w[4];
+    const uint32_t count = a.job_counts[2];
+    for (uint32_t q = 0; q < TILES_PER_WG; q++) {
+        const uint32_t ti = blockIdx.x * TILES_PER_WG + q;
+        if (ti >= count) return;
+        expand_binary_tile(a, ti, s_a, s_len, s_w);
+        __syncthreads();
+    }
 }
 
 // -------------------------------------------------------------------------------- launcher
@@ -1655,7 +1676,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k(ctx, K_PLAN);
         k_plan<<<a.n_pages, WG, 0, s>>>(a);
     }
-    {
+    if (any_binary) {  // (without binary columns the host knows every values_len itself)
         KScope k(ctx, K_COLSCAN);
         k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
     }
@@ -1669,11 +1690,11 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     if (a.n_tiles && any_prim) {
         KScope k(ctx, K_EXPAND);
-        k_expand<<<a.n_tiles, WG, 0, s>>>(a);
+        k_expand<<<(a.n_tiles + TILES_PER_WG - 1) / TILES_PER_WG, WG, 0, s>>>(a);
     }
     if (a.n_tiles && any_binary) {
         KScope k(ctx, K_EXPAND_BIN);
-        k_expand_binary<<<a.n_tiles, WG, 0, s>>>(a);
+        k_expand_binary<<<(a.n_tiles + TILES_PER_WG - 1) / TILES_PER_WG, WG, 0, s>>>(a);
     }
 }
 

@@ -184,7 +184,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if roof and pmc["config"] == {"workload": "C2", "columns_per_gpu": B, "codec": args.codec}:
-                cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0] == dom.split("<")[0]]
+                cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0].startswith(dom.split("<")[0])]
                 if cand:
                     roof["traffic"] = max(cand)   # several template instances share a name: the one that did the work
                 roof["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC, per launch, gfx950 FETCH_SIZE x2 correction)"

@@ -157,8 +157,26 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             d.val_bytes = (uint64_t)d.dict_n * N;
         } else if (codec == SB_CODEC_DICT) {
             // handled below (shared with primitives)
+        } else if (codec == SB_CODEC_FREQ) {
+            // u64 top_len | top | u32 rb_size | Roaring | per exception `u64 len | bytes` (binary/freq.rs:103-145).
+            // k_plan turns the page into a virtual Dict page: entry 0 = the top value, entry 1 + k = the k-th
+            // exception record, index of a row = 0 or 1 + its rank in the bitmap.
+            if ((uint64_t)(end - d.body) < 8) FAIL(SB_ERR_IO, 40);
+            const uint64_t top_len = ldu64(d.body);
+            if ((uint64_t)(end - d.body) - 8 < top_len) FAIL(SB_ERR_OUT_OF_SPEC, 41);  // "data size is less than"
+            const uint8_t* rbp = d.body + 8 + top_len;
+            if (end - rbp < 4) FAIL(SB_ERR_IO, 42);
+            const uint32_t rb_size = ldu32(rbp);
+            if ((uint64_t)(end - rbp) - 4 < rb_size) FAIL(SB_ERR_IO, 43);
+            if (rb_size < 8) FAIL(SB_ERR_EXTERNAL, 44);
+            d.dict = d.body;
+            d.vbody = rbp + 4;
+            d.vcsize = rb_size;
+            d.vusize = (uint32_t)top_len;
+            d.icodec = SB_CODEC_NONE;
+            d.isrc = infl;  // u32 index per row, written by k_plan
         } else {
-            FAIL(SB_ERR_NYI, 20);  // Freq (Roaring) pages take the host path for now
+            FAIL(SB_ERR_OUT_OF_SPEC, 20);  // "Unknown compression codec ... for binary"
         }
     } else {
         const uint32_t w = c.width;
@@ -837,11 +855,83 @@ __device__ void u32_tile_to_lds(const U32Stream& s, uint32_t tile, uint32_t rows
     }
 }
 
+// Walks the containers of a serialized RoaringBitmap (portable format: array / bitmap / run) with one
+// workgroup: put(value, k) for the k-th set bit.  Returns the number of bits visited (~0 on a truncated
+// or malformed stream).
+template <class Put>
+__device__ uint64_t roaring_walk(const uint8_t* rb, uint32_t rb_len, uint32_t* s_a, uint32_t* s_w, Put put) {
+    const int t = threadIdx.x;
+    if (rb_len < 8) return ~0ull;
+    const uint32_t cookie = ldu32(rb);
+    const bool has_run = (cookie & 0xFFFF) == 12347;
+    if (!has_run && cookie != 12346) return ~0ull;
+    const uint32_t nc = has_run ? (cookie >> 16) + 1 : ldu32(rb + 4);
+    const uint8_t* run_bits = rb + 4;
+    const uint32_t hp = has_run ? 4 + (nc + 7) / 8 : 8;
+    if (nc > 65536 || (uint64_t)hp + 4ull * nc > rb_len) return ~0ull;
+    uint32_t pos = hp + 4 * nc;
+    if (!has_run || nc >= 4) pos += 4 * nc;  // offset header
+    uint64_t cum = 0;
+    for (uint32_t ci = 0; ci < nc; ci++) {
+        const uint32_t hi = (uint32_t)ldu16(rb + hp + 4 * ci) << 16;
+        const uint32_t card = (uint32_t)ldu16(rb + hp + 4 * ci + 2) + 1;
+        const bool run = has_run && ((run_bits[ci >> 3] >> (ci & 7)) & 1);
+        if (run) {
+            if (pos + 2 > rb_len) return ~0ull;
+            const uint32_t nr = ldu16(rb + pos);
+            pos += 2;
+            if (pos + 4ull * nr > rb_len) return ~0ull;
+            if (t == 0) {  // runs are rare in what roaring's serialize_into writes (never without run_optimize)
+                uint64_t k = cum;
+                for (uint32_t r = 0; r < nr; r++) {
+                    const uint32_t s0 = ldu16(rb + pos + 4 * r), len = ldu16(rb + pos + 4 * r + 2);
+                    for (uint32_t v = s0; v <= s0 + len; v++) put(hi | v, k++);
+                }
+            }
+            pos += 4 * nr;
+        } else if (card > 4096) {  // bitmap container: 1024 u64 words
+            if (pos + 8192ull > rb_len) return ~0ull;
+            const uint8_t* bm = rb + pos;
+            __syncthreads();
+            // thread t owns 64-bit words [4t, 4t + 4): popcounts -> exclusive prefix over the workgroup
+            uint64_t wd[4];
+            uint32_t mine = 0;
+            for (int q = 0; q < 4; q++) {
+                wd[q] = ldu64(bm + (uint64_t)(4 * t + q) * 8);
+                mine += (uint32_t)__popcll(wd[q]);
+            }
+            const uint32_t incl = wave_incl_scan(mine);
+            if ((t & 63) == 63) s_w[t >> 6] = incl;
+            __syncthreads();
+            uint32_t k = incl - mine;
+            for (int pw = 0; pw < 3; pw++)
+                if (pw < (t >> 6)) k += s_w[pw];
+            for (int q = 0; q < 4; q++) {
+                uint64_t m = wd[q];
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    put(hi | (uint32_t)((4 * t + q) * 64 + b), cum + k++);
+                }
+            }
+            __syncthreads();
+            pos += 8192;
+        } else {  // array container: sorted u16 values
+            if (pos + 2ull * card > rb_len) return ~0ull;
+            for (uint32_t k = t; k < card; k += WG) put(hi | ldu16(rb + pos + 2 * k), cum + k);
+            pos += 2 * card;
+        }
+        cum += card;
+    }
+    (void)s_a;
+    return cum;
+}
+
 // binary Dict plan: entry offsets (serial walk over `u64 len | bytes` records, staged through
 // LDS) and per-tile byte totals of the page.
 __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, const uint8_t* page_end, uint32_t* aux,
                               uint32_t aux_cap_words, uint8_t* s_win, uint32_t* s_a, uint32_t* s_w, uint64_t* s_w64,
-                              Status* st, uint32_t page) {
+                              Status* st, uint32_t page, uint32_t gap = 0 /* bytes between entry 0 and entry 1 (Freq) */) {
     const int t = threadIdx.x;
     const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
     const uint32_t D = d.dict_n;
@@ -883,6 +973,14 @@ __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, cons
                 ent_off[e] = pos;
                 pos += 8 + (uint32_t)len;
                 e++;
+                if (e == 1 && gap) {  // Freq: the bitmap sits between the top value and the exceptions
+                    if ((uint64_t)pos + gap > avail) {
+                        s_err = 1;
+                        break;
+                    }
+                    pos += gap;
+                    break;  // the window moves
+                }
             }
             if (e < D && (uint64_t)pos + 8 > avail) s_err = 1;
             s_pos = pos;
@@ -908,7 +1006,7 @@ __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, cons
                 bad = true;
                 break;
             }
-            acc += ent_off[k + 1] - ent_off[k] - 8;
+            acc += ent_off[k + 1] - ent_off[k] - 8 - (k == 0 ? gap : 0);
         }
         if (bad) raise(st, SB_ERR_OUT_OF_SPEC, page, 222);
         if (t == 0) tile_bytes[tl] = (uint32_t)carry;
@@ -980,6 +1078,29 @@ __global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
                 d.ok = 0;
             changed = true;
         }
+    }
+    else if (d.codec == SB_CODEC_FREQ && is_binary(c.ptype)) {  // virtual Dict page (see k_parse)
+        uint32_t* idx = (uint32_t*)(a.scratch + t.infl_off);
+        __shared__ uint32_t s_inrange;
+        if (threadIdx.x == 0) s_inrange = 0;
+        for (uint64_t i = threadIdx.x; i < N; i += WG) idx[i] = 0;
+        __syncthreads();
+        const uint64_t cum = roaring_walk(d.vbody, d.vcsize, s_a, s_w, [&](uint64_t row, uint64_t k) {
+            if (row < N) {  // bits past the page are never consulted (`contains(i)` for i < length)
+                idx[row] = (uint32_t)k + 1;
+                atomicAdd(&s_inrange, 1u);
+            }
+        });
+        __syncthreads();
+        if (cum == ~0ull) {
+            if (threadIdx.x == 0) raise(a.status, SB_ERR_EXTERNAL, p, 224);  // RoaringBitmap::deserialize_from failed
+            d.ok = 0;
+        } else {
+            d.dict_n = s_inrange + 1;
+            U32Stream is{(const uint8_t*)idx, aux, SB_CODEC_NONE, 0, N};
+            if (!plan_bin_dict(d, is, N, page_end, aux, aux_cap, s_win, s_a, s_w, s_w64, a.status, p, 4 + d.vcsize)) d.ok = 0;
+        }
+        changed = true;
     }
     // binary Basic: last decoded offset of the page (needed for the cross-page offset base)
     if (d.ok && is_binary(c.ptype)) {
@@ -1275,10 +1396,11 @@ __device__ void expand_binary(const ColDesc& c, const PageTask& t, const PageDes
         }
         return;
     }
-    if (d.codec == SB_CODEC_DICT) {  // binary/dict.rs:95-140
+    if (d.codec == SB_CODEC_DICT || d.codec == SB_CODEC_FREQ) {  // binary/dict.rs:95-140; Freq as a virtual Dict page
         const uint32_t* aux = (const uint32_t*)(scratch + t.aux_off);
+        const uint32_t gap = d.codec == SB_CODEC_FREQ ? 4 + d.vcsize : 0;
         U32Stream is{d.isrc, aux, d.icodec, d.n_runs, N};
-        const uint32_t used = idx_aux_words(d.icodec, d.n_runs, N);
+        const uint32_t used = d.codec == SB_CODEC_FREQ ? 0 : idx_aux_words(d.icodec, d.n_runs, N);
         const uint32_t* ent_off = aux + used;
         const uint32_t D = d.dict_n;
         const uint32_t* tile_bytes = ent_off + D + 1;
@@ -1288,7 +1410,7 @@ __device__ void expand_binary(const ColDesc& c, const PageTask& t, const PageDes
             uint32_t len = 0;
             if (i < rows) {
                 uint32_t k = s_a[sidx((int)i)];
-                if (k < D) len = ent_off[k + 1] - ent_off[k] - 8;
+                if (k < D) len = ent_off[k + 1] - ent_off[k] - 8 - (k == 0 ? gap : 0);
             }
             s_len[sidx((int)i)] = len;
         }
@@ -1301,7 +1423,7 @@ __device__ void expand_binary(const ColDesc& c, const PageTask& t, const PageDes
             out_off[t.out_row + r0 + i + 1] = (O)(d.off_base + tb + endb);
             const uint32_t k = s_a[sidx((int)i)];
             if (k < D) {
-                const uint32_t len = ent_off[k + 1] - ent_off[k] - 8;
+                const uint32_t len = ent_off[k + 1] - ent_off[k] - 8 - (k == 0 ? gap : 0);
                 const uint8_t* sp = d.dict + ent_off[k] + 8;
                 uint8_t* dp = vdst + (endb - len);
                 for (uint32_t b = 0; b < len; b++) dp[b] = sp[b];
@@ -1578,21 +1700,12 @@ __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
 // One workgroup per page walks the Roaring containers (array / bitmap / run, portable format).
 __global__ void __launch_bounds__(WG) k_freq_scatter(const FreqEntry* entries, const uint64_t* ex_off, const uint8_t* ex_base,
                                                        Status* st) {
-    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ uint32_t s_a[4];
     __shared__ uint32_t s_w[4];
     const FreqEntry fe = entries[blockIdx.x];
     const uint8_t* ex = ex_base + ex_off[blockIdx.x];
-    const uint8_t* rb = fe.roaring;
     const uint32_t w = fe.width;
-    const int t = threadIdx.x;
-    const uint32_t cookie = ldu32(rb);
-    const bool has_run = (cookie & 0xFFFF) == 12347;
-    const uint32_t nc = has_run ? (cookie >> 16) + 1 : ldu32(rb + 4);
-    const uint8_t* run_bits = rb + 4;
-    const uint32_t hp = has_run ? 4 + (nc + 7) / 8 : 8;
-    uint32_t pos = hp + 4 * nc;
-    if (!has_run || nc >= 4) pos += 4 * nc;  // offset header
-    auto put = [&](uint64_t row, uint64_t k) {
+    const uint64_t cum = roaring_walk(fe.roaring, fe.roaring_len, s_a, s_w, [&](uint64_t row, uint64_t k) {
         if (row >= fe.rows) {
             raise(st, SB_ERR_OUT_OF_SPEC, fe.page, 410);  // exception index out of bounds
             return;
@@ -1600,61 +1713,8 @@ __global__ void __launch_bounds__(WG) k_freq_scatter(const FreqEntry* entries, c
         const uint8_t* s = ex + k * w;
         uint8_t* d = fe.out + row * w;
         for (uint32_t b = 0; b < w; b++) d[b] = s[b];
-    };
-    uint64_t cum = 0;
-    for (uint32_t ci = 0; ci < nc; ci++) {
-        const uint32_t hi = (uint32_t)ldu16(rb + hp + 4 * ci) << 16;
-        const uint32_t card = (uint32_t)ldu16(rb + hp + 4 * ci + 2) + 1;
-        const bool run = has_run && ((run_bits[ci >> 3] >> (ci & 7)) & 1);
-        if (run) {
-            if (pos + 2 > fe.roaring_len) break;
-            const uint32_t nr = ldu16(rb + pos);
-            pos += 2;
-            if (pos + 4ull * nr > fe.roaring_len) break;
-            if (t == 0) {  // runs are rare in what roaring's serialize_into writes (never without run_optimize)
-                uint64_t k = cum;
-                for (uint32_t r = 0; r < nr; r++) {
-                    const uint32_t s0 = ldu16(rb + pos + 4 * r), len = ldu16(rb + pos + 4 * r + 2);
-                    for (uint32_t v = s0; v <= s0 + len; v++) put(hi | v, k++);
-                }
-            }
-            pos += 4 * nr;
-        } else if (card > 4096) {  // bitmap container: 1024 u64 words
-            if (pos + 8192ull > fe.roaring_len) break;
-            const uint8_t* bm = rb + pos;
-            for (int i = t; i < SIDX_WORDS; i += WG) s_a[i] = 0;
-            __syncthreads();
-            // thread t owns 64-bit words [4t, 4t + 4): popcounts -> exclusive prefix over the workgroup
-            uint64_t wd[4];
-            uint32_t mine = 0;
-            for (int q = 0; q < 4; q++) {
-                wd[q] = ldu64(bm + (uint64_t)(4 * t + q) * 8);
-                mine += (uint32_t)__popcll(wd[q]);
-            }
-            const uint32_t incl = wave_incl_scan(mine);
-            if ((t & 63) == 63) s_w[t >> 6] = incl;
-            __syncthreads();
-            uint32_t k = incl - mine;
-            for (int pw = 0; pw < 3; pw++)
-                if (pw < (t >> 6)) k += s_w[pw];
-            for (int q = 0; q < 4; q++) {
-                uint64_t m = wd[q];
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    put(hi | (uint32_t)((4 * t + q) * 64 + b), cum + k++);
-                }
-            }
-            __syncthreads();
-            pos += 8192;
-        } else {  // array container: sorted u16 values
-            if (pos + 2ull * card > fe.roaring_len) break;
-            for (uint32_t k = t; k < card; k += WG) put(hi | ldu16(rb + pos + 2 * k), cum + k);
-            pos += 2 * card;
-        }
-        cum += card;
-    }
-    if (cum != fe.n_exceptions && t == 0) raise(st, SB_ERR_EXTERNAL, fe.page, 411);  // malformed Roaring bitmap
+    });
+    if (cum != fe.n_exceptions && threadIdx.x == 0) raise(st, SB_ERR_EXTERNAL, fe.page, 411);  // malformed Roaring bitmap
 }
 
 void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, const uint64_t* ex_off, const uint8_t* ex_base) {

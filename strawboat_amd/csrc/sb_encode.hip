@@ -2353,8 +2353,8 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     }
     if (threadIdx.x == 0) {
         a.codecs[page] = (int32_t)codec;
-        if (!has_device_encoder(codec) || (codec == SB_CODEC_FREQ && (KIND <= 0 || KIND > 8)))
-            raise(a.status, SB_ERR_NYI, page, 700 + codec);  // binary / 128-bit Freq pages: oracle only
+        if (!has_device_encoder(codec))
+            raise(a.status, SB_ERR_NYI, page, 700 + codec);
         else if (codec == SB_CODEC_FREQ && page < a.n_pages)
             atomicAdd(a.freq_count, 1u);
     }
@@ -2578,106 +2578,15 @@ __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t*
 //   Roaring portable format [3P roaring 0.10.1 serialize_into]: cookie 12346, container count,
 //   (key, cardinality-1) pairs, offsets, then per non-empty 64 Ki-row container a sorted u16 array
 //   (cardinality <= 4096) or a 1024 x u64 bitmap.
+// Roaring portable serialization of the exception rows of one page (format note above):
+// header + containers at `rb`, its byte size also stored at `size_field`; on_exc(row, k) is called for
+// the k-th exception.  All threads of the workgroup call this.
 constexpr uint32_t FREQ_MAX_CONTAINERS = 64;  // pages of up to 4 Mi rows
-
-template <int W>
-__device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pages_rw, const EncCol& c, const EncPage& p,
-                               uint32_t page, uint32_t* lds) {
+template <class IsExc, class OnExc>
+__device__ void freq_roaring(uint64_t N, uint8_t* rb, uint8_t* size_field, uint32_t* sA, uint32_t* s_w, uint32_t* s_card,
+                             IsExc is_exc, OnExc on_exc, uint32_t& rb_size_out, uint32_t& n_ex_out) {
     const int t = threadIdx.x, lane = t & 63;
-    const uint64_t N = p.rows;
-    const uint8_t* vals = c.values + p.row0 * W;
-    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
-    uint32_t* sA = lds;                       // SIDX_WORDS: tile scans
-    uint32_t* s_w = lds + SIDX_WORDS;         // 4
-    uint32_t* s_card = s_w + 8;               // FREQ_MAX_CONTAINERS
-    unsigned long long* s_u64 = (unsigned long long*)(s_card + FREQ_MAX_CONTAINERS);  // vote keys (WG) / misc
-    uint32_t* s_cnt = (uint32_t*)(s_u64 + WG);                                         // vote counts (WG)
-    uint8_t* slot = page_slot(a, c, p);
-    uint64_t pos = 0;
-    if (c.nullable) {
-        uint8_t* bits = def_header(slot, N);
-        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
-        pos = def_section_bytes(N);
-    }
-    uint8_t* blk = slot + pos;
     const uint32_t nc_all = (uint32_t)((N + 65535) / 65536);
-    if (nc_all > FREQ_MAX_CONTAINERS) {
-        if (t == 0) raise(a.status, SB_ERR_NYI, page, 540);
-        return;
-    }
-    auto key64 = [&](uint64_t i) {  // canonical key of slot i (the equality of distinct_values / `*val != top_value`)
-        const Val<W> k = stat_key<W>(ld_val<W>(vals + i * W), c.nk);
-        uint64_t x = 0;
-        __builtin_memcpy(&x, &k, W);
-        return x;
-    };
-    // ---- null share and the vote
-    uint32_t nulls = 0;
-    uint64_t vk = 0;
-    uint32_t vn = 0;
-    for (uint64_t i = t; i < N; i += WG) {
-        if (!vv.get(i)) nulls++;
-        const uint64_t x = key64(i);
-        if (vn == 0) {
-            vk = x;
-            vn = 1;
-        } else if (vk == x) {
-            vn++;
-        } else {
-            vn--;
-        }
-    }
-    const uint32_t null_count = wg_sum32(nulls, s_w);
-    const bool top_is_null = (double)null_count / (double)N >= 0.9;
-    uint64_t topk = 0;
-    Val<W> top = val_zero<W>();
-    if (!top_is_null) {
-        s_u64[t] = vk;
-        s_cnt[t] = vn;
-        __syncthreads();
-        for (int stride = WG / 2; stride > 0; stride >>= 1) {
-            if (t < stride) {
-                const unsigned long long c0 = s_u64[t], c1 = s_u64[t + stride];
-                const uint32_t n0 = s_cnt[t], n1 = s_cnt[t + stride];
-                if (n1) {
-                    if (n0 == 0) {
-                        s_u64[t] = c1;
-                        s_cnt[t] = n1;
-                    } else if (c0 == c1) {
-                        s_cnt[t] = n0 + n1;
-                    } else if (n1 > n0) {
-                        s_u64[t] = c1;
-                        s_cnt[t] = n1 - n0;
-                    } else {
-                        s_cnt[t] = n0 - n1;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        topk = s_u64[0];
-        __syncthreads();
-        // its count and first occurrence (the value written is the first slot's raw bits)
-        uint32_t mine = 0;
-        unsigned long long first = ~0ull;
-        for (uint64_t i = t; i < N; i += WG)
-            if (key64(i) == topk) {
-                mine++;
-                if (first == ~0ull) first = i;
-            }
-        const uint32_t mc = wg_sum32(mine, s_w);
-        if (t == 0) s_u64[0] = ~0ull;
-        __syncthreads();
-        if (first != ~0ull) atomicMin(&s_u64[0], first);
-        __syncthreads();
-        if ((uint64_t)mc * 2 <= N) {  // no majority: the exact arg-max needs full counts (host-forced Freq only)
-            if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
-            return;
-        }
-        top = ld_val<W>(vals + s_u64[0] * W);
-        __syncthreads();
-    }
-    auto is_exc = [&](uint64_t i) { return vv.get(i) && (top_is_null || key64(i) != topk); };
     // ---- pass A: cardinality per 64 Ki-row container
     for (uint32_t q = t; q < FREQ_MAX_CONTAINERS; q += WG) s_card[q] = 0;
     __syncthreads();
@@ -2695,13 +2604,11 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
         ncne += s_card[cq] ? 1u : 0u;
         n_ex += s_card[cq];
     }
-    uint8_t* rb = blk + 9 + W + 4;
     uint32_t rb_size = 8 + 8 * ncne;
     for (uint32_t cq = 0; cq < nc_all; cq++)
         if (s_card[cq]) rb_size += s_card[cq] > 4096 ? 8192u : 2 * s_card[cq];
     if (t == 0) {
-        st_val<W>(blk + 9, top);
-        stu32(blk + 9 + W, rb_size);
+        stu32(size_field, rb_size);
         stu32(rb, 12346u);
         stu32(rb + 4, ncne);
         uint32_t k = 0, off = 8 + 8 * ncne;
@@ -2717,7 +2624,6 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
         }
     }
     // ---- pass B: containers and the exception values
-    uint8_t* ex = a.scratch + p.ex_off;
     uint32_t data_off = 8 + 8 * ncne, ex_base = 0;
     for (uint32_t cq = 0; cq < nc_all; cq++) {
         const uint32_t card = s_card[cq];
@@ -2753,7 +2659,7 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
                     *(gptr)(rb + data_off + 2 * k) = (uint8_t)lo16;
                     *(gptr)(rb + data_off + 2 * k + 1) = (uint8_t)(lo16 >> 8);
                 }
-                st_val<W>(ex + (uint64_t)(ex_base + k) * W, ld_val<W>(vals + (cb + r) * W));
+                on_exc(cb + r, ex_base + k);
             }
             carry += tot;
             __syncthreads();
@@ -2761,6 +2667,110 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
         data_off += bitmap ? 8192u : 2 * card;
         ex_base += card;
     }
+    rb_size_out = rb_size;
+    n_ex_out = n_ex;
+}
+
+template <int W>
+__device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pages_rw, const EncCol& c, const EncPage& p,
+                               uint32_t page, uint32_t* lds) {
+    const int t = threadIdx.x, lane = t & 63;
+    const uint64_t N = p.rows;
+    const uint8_t* vals = c.values + p.row0 * W;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    uint32_t* sA = lds;                       // SIDX_WORDS: tile scans
+    uint32_t* s_w = lds + SIDX_WORDS;         // 4
+    uint32_t* s_card = s_w + 8;               // FREQ_MAX_CONTAINERS
+    unsigned long long* s_first = (unsigned long long*)(s_card + FREQ_MAX_CONTAINERS);  // first row of the top value
+    uint32_t* s_cnt = (uint32_t*)(s_first + 2);                                          // vote counts (WG)
+    Val<W>* s_key = (Val<W>*)(((uintptr_t)(s_cnt + WG) + 15) & ~(uintptr_t)15);            // vote keys (WG)
+    uint8_t* slot = page_slot(a, c, p);
+    uint64_t pos = 0;
+    if (c.nullable) {
+        uint8_t* bits = def_header(slot, N);
+        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
+        pos = def_section_bytes(N);
+    }
+    uint8_t* blk = slot + pos;
+    const uint32_t nc_all = (uint32_t)((N + 65535) / 65536);
+    if (nc_all > FREQ_MAX_CONTAINERS) {
+        if (t == 0) raise(a.status, SB_ERR_NYI, page, 540);
+        return;
+    }
+    // canonical key of slot i (the equality of distinct_values / `*val != top_value`)
+    auto keyof = [&](uint64_t i) { return stat_key<W>(ld_val<W>(vals + i * W), c.nk); };
+    // ---- null share and the vote
+    uint32_t nulls = 0;
+    Val<W> vk = val_zero<W>();
+    uint32_t vn = 0;
+    for (uint64_t i = t; i < N; i += WG) {
+        if (!vv.get(i)) nulls++;
+        const Val<W> x = keyof(i);
+        if (vn == 0) {
+            vk = x;
+            vn = 1;
+        } else if (bits_eq<W>(vk, x)) {
+            vn++;
+        } else {
+            vn--;
+        }
+    }
+    const uint32_t null_count = wg_sum32(nulls, s_w);
+    const bool top_is_null = (double)null_count / (double)N >= 0.9;
+    Val<W> topk = val_zero<W>();
+    Val<W> top = val_zero<W>();
+    if (!top_is_null) {
+        s_key[t] = vk;
+        s_cnt[t] = vn;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                const Val<W> c0 = s_key[t], c1 = s_key[t + stride];
+                const uint32_t n0 = s_cnt[t], n1 = s_cnt[t + stride];
+                if (n1) {
+                    if (n0 == 0) {
+                        s_key[t] = c1;
+                        s_cnt[t] = n1;
+                    } else if (bits_eq<W>(c0, c1)) {
+                        s_cnt[t] = n0 + n1;
+                    } else if (n1 > n0) {
+                        s_key[t] = c1;
+                        s_cnt[t] = n1 - n0;
+                    } else {
+                        s_cnt[t] = n0 - n1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        topk = s_key[0];
+        __syncthreads();
+        // its count and first occurrence (the value written is the first slot's raw bits)
+        uint32_t mine = 0;
+        unsigned long long first = ~0ull;
+        for (uint64_t i = t; i < N; i += WG)
+            if (bits_eq<W>(keyof(i), topk)) {
+                mine++;
+                if (first == ~0ull) first = i;
+            }
+        const uint32_t mc = wg_sum32(mine, s_w);
+        if (t == 0) s_first[0] = ~0ull;
+        __syncthreads();
+        if (first != ~0ull) atomicMin(&s_first[0], first);
+        __syncthreads();
+        if ((uint64_t)mc * 2 <= N) {  // no majority: the exact arg-max needs full counts (host-forced Freq only)
+            if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
+            return;
+        }
+        top = ld_val<W>(vals + s_first[0] * W);
+        __syncthreads();
+    }
+    auto is_exc = [&](uint64_t i) { return vv.get(i) && (top_is_null || !bits_eq<W>(keyof(i), topk)); };
+    uint8_t* ex = a.scratch + p.ex_off;
+    uint32_t rb_size, n_ex;
+    if (t == 0) st_val<W>(blk + 9, top);
+    freq_roaring(N, blk + 9 + W + 4, blk + 9 + W, sA, s_w, s_card, is_exc,
+                 [&](uint64_t row, uint32_t k) { st_val<W>(ex + (uint64_t)k * W, ld_val<W>(vals + row * W)); }, rb_size, n_ex);
     // ---- the virtual page that carries the exceptions through the second wave
     if (t == 0) {
         EncCol vc = c;
@@ -2802,17 +2812,151 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
     }
 }
 
+// Binary / Utf8 Freq page (binary/freq.rs:44-101): u64 top_len | top | u32 rb_size | Roaring | per exception
+// `u64 len | bytes` (plain, no nested block) — written completely here.  The top value is the majority value
+// over ALL slots (binary/mod.rs:265-291 counts null slots too), empty when >= 90 % of the rows are null.
+template <class O>
+__device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, uint32_t* lds) {
+    const int t = threadIdx.x;
+    const uint64_t N = p.rows;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    uint32_t* sA = lds;
+    uint32_t* s_w = lds + SIDX_WORDS;
+    uint32_t* s_card = s_w + 8;
+    uint32_t* s_vote = s_card + FREQ_MAX_CONTAINERS;  // 2 * WG + 4
+    uint8_t* slot = page_slot(a, c, p);
+    uint64_t pos = 0;
+    if (c.nullable) {
+        uint8_t* bits = def_header(slot, N);
+        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
+        pos = def_section_bytes(N);
+    }
+    uint8_t* blk = slot + pos;
+    if ((N + 65535) / 65536 > FREQ_MAX_CONTAINERS) {
+        if (t == 0) raise(a.status, SB_ERR_NYI, page, 540);
+        return;
+    }
+    const BinKeys<O> bk{c.offsets + p.row0 * sizeof(O), c.values, vv};
+    uint32_t nulls = 0;
+    for (uint64_t i = t; i < N; i += WG) nulls += vv.get(i) ? 0u : 1u;
+    const uint32_t null_count = wg_sum32(nulls, s_w);
+    const bool top_is_null = (double)null_count / (double)N >= 0.9;
+    uint32_t cand = 0;
+    uint64_t tb = 0, te = 0;
+    if (!top_is_null) {
+        uint32_t cd = SEL_EMPTY, cnt = 0;
+        for (uint64_t i = t; i < N; i += WG) {
+            if (cnt == 0) {
+                cd = (uint32_t)i;
+                cnt = 1;
+            } else if (bk.eq(cd, i)) {
+                cnt++;
+            } else {
+                cnt--;
+            }
+        }
+        s_vote[t] = cd;
+        s_vote[WG + t] = cnt;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                const uint32_t c0 = s_vote[t], n0 = s_vote[WG + t], c1 = s_vote[t + stride], n1 = s_vote[WG + t + stride];
+                uint32_t cc = c0, n = n0;
+                if (n1) {
+                    if (n0 == 0) {
+                        cc = c1;
+                        n = n1;
+                    } else if (bk.eq(c0, c1)) {
+                        n = n0 + n1;
+                    } else if (n1 > n0) {
+                        cc = c1;
+                        n = n1 - n0;
+                    } else {
+                        n = n0 - n1;
+                    }
+                }
+                s_vote[t] = cc;
+                s_vote[WG + t] = n;
+            }
+            __syncthreads();
+        }
+        const bool have = s_vote[WG] != 0;
+        cand = s_vote[0];
+        __syncthreads();
+        uint32_t mine = 0;
+        if (have)
+            for (uint64_t i = t; i < N; i += WG) mine += bk.eq(cand, i) ? 1u : 0u;
+        const uint32_t mc = wg_sum32(mine, s_w);
+        if ((uint64_t)mc * 2 <= N) {  // no majority: the exact arg-max needs full counts (host-forced Freq only)
+            if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
+            return;
+        }
+        tb = bk.beg(cand);
+        te = bk.beg((uint64_t)cand + 1);
+    }
+    const uint64_t top_len = te - tb;
+    if (t == 0) stu64(blk + 9, top_len);
+    wg_copy(blk + 17, c.values + tb, top_len);
+    auto is_exc = [&](uint64_t i) { return vv.get(i) && (top_is_null || !bk.eq(cand, i)); };
+    uint32_t rb_size, n_ex;
+    uint8_t* rb = blk + 9 + 8 + top_len + 4;
+    freq_roaring(N, rb, rb - 4, sA, s_w, s_card, is_exc, [](uint64_t, uint32_t) {}, rb_size, n_ex);
+    // exception records, in row order: position = scan of (8 + len) over the exception rows
+    uint8_t* rec = rb + rb_size;
+    uint64_t carry = 0;
+    for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
+        const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, N - cb);
+        __syncthreads();
+        for (uint32_t r = t; r < TILE_ROWS; r += WG) {
+            uint32_t len = 0;
+            if (r < n && is_exc(cb + r)) len = (uint32_t)(bk.beg(cb + r + 1) - bk.beg(cb + r)) + 8;
+            sA[sidx((int)r)] = len;
+        }
+        __syncthreads();
+        const uint32_t tot = tile_incl_scan(sA, s_w);
+        for (uint32_t r = t; r < n; r += WG) {
+            const uint32_t endb = sA[sidx((int)r)];
+            const uint32_t prev = r ? sA[sidx((int)r - 1)] : 0;
+            if (endb == prev) continue;
+            const uint64_t b = bk.beg(cb + r), len = endb - prev - 8;
+            uint8_t* d = rec + carry + prev;
+            stu64(d, len);
+            for (uint64_t q = 0; q < len; q++) d[8 + q] = c.values[b + q];
+        }
+        carry += tot;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint64_t body = 8 + top_len + 4 + rb_size + carry;
+        put_hdr9(blk, SB_CODEC_FREQ, (uint32_t)body, (uint32_t)c.values_len);  // binary/mod.rs:83-88
+        EncOut o;
+        o.length = pos + 9 + body;
+        o.out_off = 0;
+        o.slot = slot;
+        o.codec = SB_CODEC_FREQ;
+        o.pad = 2;  // complete: k_enc_freq_finish has nothing to append
+        a.outs[page] = o;
+    }
+}
+
 __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a, EncCol* cols_rw, EncPage* pages_rw) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[SIDX_WORDS + 8 + FREQ_MAX_CONTAINERS + 3 * WG + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SIDX_WORDS + 8 + FREQ_MAX_CONTAINERS + 4 + WG + 8 + 8 * WG];
     if (*a.freq_count == 0) return;
   for (uint32_t page = blockIdx.x; page < a.n_pages; page += gridDim.x) {
     __syncthreads();
     const EncPage p = get_page(a, page);
     if (codec_of(a, p, page) != SB_CODEC_FREQ) continue;
     const EncCol c = get_col(a, p.col);
-    if (c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY || c.ptype == SB_TYPE_NULL ||
-        c.width > 8 || p.rows == 0) {
-        if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 542);  // binary / 128-bit Freq pages: oracle only
+    if (c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_NULL || p.rows == 0) {
+        if (threadIdx.x == 0) raise(a.status, SB_ERR_OUT_OF_SPEC, page, 542);  // no Freq for booleans upstream
+        continue;
+    }
+    if (c.ptype == SB_TYPE_BINARY) {
+        freq_prep_bin<int32_t>(a, c, p, page, lds);
+        continue;
+    }
+    if (c.ptype == SB_TYPE_LARGE_BINARY) {
+        freq_prep_bin<int64_t>(a, c, p, page, lds);
         continue;
     }
     switch (c.width) {
@@ -2825,8 +2969,14 @@ __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a, EncCol* c
         case 4:
             freq_prep_page<4>(a, cols_rw, pages_rw, c, p, page, lds);
             break;
-        default:
+        case 8:
             freq_prep_page<8>(a, cols_rw, pages_rw, c, p, page, lds);
+            break;
+        case 16:
+            freq_prep_page<16>(a, cols_rw, pages_rw, c, p, page, lds);
+            break;
+        default:
+            freq_prep_page<32>(a, cols_rw, pages_rw, c, p, page, lds);
             break;
     }
   }
@@ -2903,13 +3053,13 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
             blen = emit_prim_page<W, SB_CODEC_ONEVALUE>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
             break;
         case SB_CODEC_BITPACKING:
-            blen = emit_prim_page<W, SB_CODEC_BITPACKING>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            if constexpr (W == 4) blen = emit_prim_page<W, SB_CODEC_BITPACKING>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
             break;
         case SB_CODEC_DELTA_BITPACKING:
-            blen = emit_prim_page<W, SB_CODEC_DELTA_BITPACKING>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            if constexpr (W == 4) blen = emit_prim_page<W, SB_CODEC_DELTA_BITPACKING>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
             break;
         case SB_CODEC_PATAS:
-            blen = emit_prim_page<W, SB_CODEC_PATAS>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+            if constexpr (W == 4 || W == 8) blen = emit_prim_page<W, SB_CODEC_PATAS>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
             break;
         default:
             if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 545);
@@ -2923,7 +3073,9 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
 // a few hundred workgroups walk all virtual pages: a batch without Freq pages costs a short launch
 template <int W>
 __global__ void __launch_bounds__(WG) k_enc_nested(EncodeArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * SIDX_WORDS];
+    // three tile arrays for the emitters; the selector lays its hash set, misc words and sample area over them
+    constexpr int SEL_WORDS = SEL_LDS_SLOTS + 2 * WG + 16 + (SAMPLE_CAP * (W + 1) + 16 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SEL_WORDS > 3 * SIDX_WORDS ? SEL_WORDS : 3 * SIDX_WORDS];
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_misc2[2];
     if (*a.freq_count == 0) return;
@@ -2939,7 +3091,7 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
     const EncPage p = get_page(a, page);
     if (codec_of(a, p, page) != SB_CODEC_FREQ) return;
     const EncOut o = a.outs[page];
-    if (o.codec != SB_CODEC_FREQ || o.length == 0) return;  // prep raised
+    if (o.codec != SB_CODEC_FREQ || o.length == 0 || o.pad == 2) return;  // prep raised / binary page already complete
     const EncOut vo = a.outs[a.n_pages + page];
     const EncCol c = get_col(a, p.col);
     if (vo.length == 0) {
@@ -3290,15 +3442,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (host_codec == SB_CODEC_FREQ)
         for (uint64_t i = 0; i < n; i++) {
             const int32_t t = cols[i].physical_type;
-            if (t == SB_TYPE_BOOLEAN || t == SB_TYPE_NULL || enc_is_binary(t) || enc_type_width(t) > 8)
-                return ctx->fail(SB_ERR_NYI, "Freq pages of binary / 128-bit / boolean columns have no device encoder");
+            if (t == SB_TYPE_BOOLEAN || t == SB_TYPE_NULL)
+                return ctx->fail(SB_ERR_OUT_OF_SPEC, "Unknown compression codec Freq for boolean");
         }
     // Freq pages (chosen or forced) send their exceptions through a second wave of the same kernels
     bool freq_possible = false;
     if (host_codec == SB_CODEC_FREQ || (adaptive && !((forb >> SB_CODEC_FREQ) & 1)))
         for (uint64_t i = 0; i < n; i++) {
             const int32_t t = cols[i].physical_type;
-            freq_possible |= t != SB_TYPE_BOOLEAN && t != SB_TYPE_NULL && !enc_is_binary(t) && enc_type_width(t) <= 8;
+            freq_possible |= t != SB_TYPE_BOOLEAN && t != SB_TYPE_NULL;
         }
 
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
@@ -3414,7 +3566,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 p.slot_off = scratch_off;
                 scratch_off += align_up(slot_fixed_bytes(c.physical_type, c.is_nullable, N), 16);
                 any_compact = true;
-                if (freq_possible && !bin && c.physical_type != SB_TYPE_BOOLEAN && d.width <= 8) {
+                if (freq_possible && !bin && c.physical_type != SB_TYPE_BOOLEAN) {
                     // a Freq page also holds the Roaring bitmap (<= 8 KiB + 8 B per 64 Ki rows, + header)
                     scratch_off += align_up(N / 8 + 16 * (N / 65536 + 1) + 8192 + 64, 16);
                     p.slot_cap = scratch_off - p.slot_off;
@@ -3600,9 +3752,13 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             k_enc_freq_prep<<<(uint32_t)std::min<uint64_t>(P, 1024), WG, 0, s>>>(a, (EncCol*)(tb + o_vcols), (EncPage*)(tb + o_vpages));
         }
         for (int kd : kinds) {
-            if (kd != 1 && kd != 2 && kd != 4 && kd != 8) continue;
+            if (kd != 1 && kd != 2 && kd != 4 && kd != 8 && kd != 16 && kd != 32) continue;
             KScope k(ctx, K_ENC_FREQ);
-            if (kd == 1)
+            if (kd == 16)
+                k_enc_nested<16><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
+            else if (kd == 32)
+                k_enc_nested<32><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
+            else if (kd == 1)
                 k_enc_nested<1><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
             else if (kd == 2)
                 k_enc_nested<2><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);

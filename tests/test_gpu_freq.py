@@ -102,3 +102,77 @@ def test_adaptive_selection_with_nothing_forbidden(gpu_ctx):
         for ratio in (1.2, 2.0):
             seen |= set(sel_check(gpu_ctx, col, max_page_size=128 * 100, ratio=ratio, forbidden=()).tolist())
     assert S.FREQ in seen and len(seen) >= 2, seen
+
+
+# ---- binary / Utf8 Freq pages (binary/freq.rs:44-145) and 128- / 256-bit integers
+def sparse_bin(rows, p_exc, seed, null_density=None, large=False, top=b"the-common-value", exc_uniq=500, maxlen=20):
+    rng = np.random.default_rng(seed)
+    exc = rng.random(rows) < p_exc
+    vocab = [(b"x%d-" % i) * int(rng.integers(0, maxlen // 3 + 1)) for i in range(exc_uniq)]
+    pick = rng.integers(0, exc_uniq, rows)
+    items = [vocab[pick[i]] if exc[i] else top for i in range(rows)]
+    lens = np.fromiter((len(b) for b in items), np.int64, rows)
+    offs = np.zeros(rows + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"".join(items), np.uint8).copy() if rows else np.zeros(0, np.uint8)
+    validity = gen.make_validity(rng, rows, null_density)
+    return dict(ptype=S.T_BIN64 if large else S.T_BIN32, nullable=validity is not None, rows=rows, values=data,
+                validity=validity, offsets=offs.astype(np.int64 if large else np.int32))
+
+
+def sparse_wide(ptype, rows, p_exc, seed, null_density=None):
+    rng = np.random.default_rng(seed)
+    w = S.WIDTH[ptype] // 8
+    vals = np.zeros((rows, w), np.int64)
+    vals[:, 0] = 1000
+    vals[:, -1] = 5
+    exc = rng.random(rows) < p_exc
+    vals[exc, 0] = rng.integers(300, 100000, int(exc.sum()))
+    vals[exc, -1] = -rng.integers(0, 3, int(exc.sum()))
+    validity = gen.make_validity(rng, rows, null_density)
+    return dict(ptype=ptype, nullable=validity is not None, rows=rows, values=vals.reshape(-1), validity=validity, offsets=None)
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_binary_freq_decode(gpu_ctx, large):
+    check(gpu_ctx, sparse_bin(20_000, 0.05, 41, large=large), max_page_size=4096, force_codec=S.FREQ)
+    check(gpu_ctx, sparse_bin(20_000, 0.05, 42, null_density=0.1, large=large), max_page_size=5000, force_codec=S.FREQ)
+    check(gpu_ctx, sparse_bin(9_000, 0.0, 43, large=large), max_page_size=3000, force_codec=S.FREQ)      # no exceptions
+    check(gpu_ctx, sparse_bin(9_000, 0.04, 44, top=b"", large=large), max_page_size=3000, force_codec=S.FREQ)  # empty top value
+    check(gpu_ctx, sparse_bin(30_000, 0.5, 45, null_density=0.95, large=large), max_page_size=8192, force_codec=S.FREQ)  # top "is null"
+    check(gpu_ctx, sparse_bin(140_000, 0.08, 46, large=large), max_page_size=70_000, force_codec=S.FREQ)  # bitmap + array containers
+    check(gpu_ctx, sparse_bin(5_000, 0.07, 47, maxlen=900, exc_uniq=40, large=large), max_page_size=2500, force_codec=S.FREQ)  # long exceptions
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_binary_freq_encode_matches_oracle(gpu_ctx, large):
+    from tests.test_gpu_encode import check as enc_check
+    enc_check(gpu_ctx, sparse_bin(20_000, 0.05, 51, large=large), max_page_size=4096, force_codec=S.FREQ)
+    enc_check(gpu_ctx, sparse_bin(20_000, 0.05, 52, null_density=0.1, large=large), max_page_size=5000, force_codec=S.FREQ)
+    enc_check(gpu_ctx, sparse_bin(9_000, 0.0, 53, large=large), max_page_size=3000, force_codec=S.FREQ)
+    enc_check(gpu_ctx, sparse_bin(9_000, 0.04, 54, top=b"", large=large), max_page_size=3000, force_codec=S.FREQ)
+    enc_check(gpu_ctx, sparse_bin(30_000, 0.5, 55, null_density=0.95, large=large), max_page_size=8192, force_codec=S.FREQ)
+    enc_check(gpu_ctx, sparse_bin(140_000, 0.08, 56, large=large), max_page_size=70_000, force_codec=S.FREQ)
+    enc_check(gpu_ctx, sparse_bin(5_000, 0.07, 57, maxlen=900, exc_uniq=40, large=large), max_page_size=2500, force_codec=S.FREQ)
+
+
+def test_binary_adaptive_picks_freq(gpu_ctx):
+    """a Utf8 column that is mostly one string: choose_compressor takes Freq (binary/freq.rs:147-169)"""
+    from tests.test_gpu_select import check as sel_check
+    seen = set()
+    for col in (sparse_bin(128 * 300, 0.03, 61), sparse_bin(128 * 300, 0.04, 62, null_density=0.05, top=b""),
+                sparse_bin(128 * 300, 0.5, 63, null_density=0.93)):
+        seen |= set(sel_check(gpu_ctx, col, max_page_size=128 * 100, ratio=2.0, forbidden=()).tolist())
+    assert S.FREQ in seen, seen
+
+
+@pytest.mark.parametrize("ptype", [S.T_I128, S.T_I256])
+def test_wide_integer_freq(gpu_ctx, ptype):
+    from tests.test_gpu_encode import check as enc_check
+    from tests.test_gpu_select import check as sel_check
+    for col, ps in ((sparse_wide(ptype, 20_000, 0.05, 71), 4096), (sparse_wide(ptype, 20_000, 0.05, 72, null_density=0.1), 5000),
+                    (sparse_wide(ptype, 70_000, 0.08, 73), 70_000)):
+        check(gpu_ctx, col, max_page_size=ps, force_codec=S.FREQ)
+        enc_check(gpu_ctx, col, max_page_size=ps, force_codec=S.FREQ)
+    seen = set(sel_check(gpu_ctx, sparse_wide(ptype, 128 * 300, 0.03, 74), max_page_size=128 * 100, ratio=2.0, forbidden=()).tolist())
+    assert S.FREQ in seen, seen

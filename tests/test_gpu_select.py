@@ -79,7 +79,8 @@ def test_binary(gpu_ctx, large):
 
 
 def test_unsupported_choice_is_loud(gpu_ctx):
-    # binary Freq pages have no device encoder: the call fails loudly (NYI) instead of writing something else
+    # a forced Freq page without a majority value has no device encoder (the exact arg-max needs full counts):
+    # the call fails loudly (NYI) instead of writing something else
     from strawboat_amd._native import NativeError
     with pytest.raises(NativeError) as e:
         gpu_encode(gpu_ctx, gen.binary(8192, uniq=40, seed=5), force_codec=S.FREQ)

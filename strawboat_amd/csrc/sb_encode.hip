@@ -1123,15 +1123,208 @@ __device__ uint32_t lz4_compress_lane(const uint8_t* src, uint32_t n, uint8_t* d
     }
     return (uint32_t)(op - dst);
 }
-// one wave compresses one block: the table (4096 words of LDS) is cleared by all lanes, lane 0 parses
+// One wave compresses one block with the SAME parse, 64 probe positions at a time.
+// The greedy search examines positions q_0, q_1, ... whose spacing follows the skip schedule
+// (step = searchMatchNb++ >> 6) until one of them finds a 4-byte match through the hash table; every
+// examined position is inserted.  Nothing in that depends on the outcome of earlier probes of the same
+// search except the table contents, so lane l takes probe 64 b + l of batch b: it hashes its position,
+// reads the table, and sees the insertions of the lower lanes of its own batch through a match-any over
+// the hash bits (the latest lower lane with the same hash supersedes the table value).  The first lane
+// with a match wins; lanes up to it commit their insertions (per hash the highest such lane), the
+// others commit nothing.  The position tested right after a match (`ip` with literal length 0,
+// LZ4_compress_generic's _next_match tail) is probe 0 of the next search's first batch.
+// Match extension and literal copies are wave-wide.
+__device__ __forceinline__ uint32_t lz4_hash_bits(uint64_t bytes, bool by_u16) {
+    if (by_u16) return ((uint32_t)bytes * 2654435761u) >> (32 - 13);
+    return (uint32_t)(((bytes << 24) * 889523592379ull) >> (64 - 12));
+}
+__device__ __forceinline__ uint64_t lz4_ld8_safe(const uint8_t* src, uint32_t pos, uint32_t n) {
+    if (pos + 8 <= n) return ldu64(src + pos);
+    uint64_t v = 0;
+    for (uint32_t b = 0; pos + b < n && b < 8; b++) v |= (uint64_t)src[pos + b] << (8 * b);
+    return v;
+}
+__device__ __forceinline__ void wave_copy_bytes(uint8_t* dst, const uint8_t* src, uint32_t len) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t body = len & ~7u;
+    for (uint32_t i = lane * 8; i < body; i += 512) stu64(dst + i, ldu64(src + i));
+    if (lane < (len & 7u)) dst[body + lane] = src[body + lane];
+}
+// probe number -> position for a search whose first regular probe is at p0 (q_0 = p0, q_{k+1} = q_k + step_k,
+// step_0 = 1, step_k = (63 + k) >> 6)
+__device__ __forceinline__ uint32_t lz4_probe_pos(uint32_t p0, uint32_t k) {
+    if (k == 0) return p0;
+    const uint32_t f = (k - 1) >> 6, r = (k - 1) & 63;
+    return p0 + 1 + 32 * f * (f + 1) + r * (f + 1);
+}
 __device__ uint32_t lz4_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* tab4096) {
-    const int lane = threadIdx.x & 63;
-    for (int i = lane; i < 4096; i += 64) tab4096[i] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t size = 0;
-    if (lane == 0) size = lz4_compress_lane(src, n, dst, tab4096);
-    return (uint32_t)__shfl((int)size, 0, 64);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const bool by_u16 = n < 65536u + 11u;  // LZ4_64Klimit
+    const int hbits = by_u16 ? 13 : 12;
+    uint16_t* tab16 = (uint16_t*)tab4096;
+    if (by_u16)
+        for (uint32_t i = lane; i < 8192; i += 64) tab16[i] = 0;
+    else
+        for (uint32_t i = lane; i < 4096; i += 64) tab4096[i] = 0;
+    auto tab_get = [&](uint32_t h) { return by_u16 ? (uint32_t)tab16[h] : tab4096[h]; };
+    auto tab_put = [&](uint32_t h, uint32_t v) {
+        if (by_u16)
+            tab16[h] = (uint16_t)v;
+        else
+            tab4096[h] = v;
+    };
+    uint32_t op = 0, anchor = 0;
+    if (n >= 13) {
+        const uint32_t mfl1 = n - 11;        // mflimitPlusOne
+        const uint32_t matchlimit = n - 5;
+        uint32_t ip = 1;                     // first position to examine
+        uint32_t preput = 0;                 // position inserted before the search starts
+        bool special = false;                // probe 0 = the position right after a match
+        for (;;) {
+            // ------------------------------------------------ search
+            uint32_t mpos = 0;
+            bool have = false;
+            for (uint32_t b = 0;; b++) {
+                const uint32_t idx = 64 * b + lane;
+                uint32_t q, qn;
+                bool valid;
+                if (special) {
+                    if (idx == 0) {
+                        q = ip;
+                        qn = ip;
+                        valid = true;
+                    } else {
+                        q = lz4_probe_pos(ip + 1, idx - 1);
+                        qn = lz4_probe_pos(ip + 1, idx);
+                        valid = qn <= mfl1;
+                    }
+                } else {
+                    q = lz4_probe_pos(ip, idx);
+                    qn = lz4_probe_pos(ip, idx + 1);
+                    valid = qn <= mfl1;
+                }
+                const uint64_t vmask = __ballot(valid);  // a prefix of the lanes
+                const uint64_t data = valid ? ldu64(src + q) : 0;
+                if (b == 0) {  // every lane computes the same insertion; one writes it
+                    const uint32_t hp = lz4_hash_bits(ldu64(src + preput), by_u16);
+                    if (lane == 0) tab_put(hp, preput);
+                }
+                const uint32_t h = lz4_hash_bits(data, by_u16);
+                const uint32_t v = valid ? tab_get(h) : 0;
+                // lanes with my hash (valid ones only)
+                uint64_t peers = vmask;
+                for (int bit = 0; bit < hbits; bit++) {
+                    const bool mine = (h >> bit) & 1;
+                    const uint64_t m = __ballot(mine);
+                    peers &= mine ? m : ~m;
+                }
+                const uint64_t lower = peers & below;
+                const int prev = lower ? 63 - __clzll((long long)lower) : 0;
+                const uint32_t qprev = (uint32_t)__shfl((int)q, prev, 64);
+                const uint32_t m = lower ? qprev : v;
+                const bool cand = valid && (by_u16 || m + 65535u >= q);
+                const bool found = cand && ldu32(src + m) == (uint32_t)data;
+                const uint64_t fm = __ballot(found);
+                const int kf = fm ? __ffsll((long long)fm) - 1 : 63;
+                const uint64_t upto = kf == 63 ? ~0ull : ((2ull << kf) - 1);
+                // commit: per hash the highest probing lane that really ran
+                if (valid && (lane <= (uint32_t)kf) && !(peers & ~below & ~(1ull << lane) & upto)) tab_put(h, q);
+                if (fm) {
+                    ip = (uint32_t)__shfl((int)q, kf, 64);
+                    mpos = (uint32_t)__shfl((int)m, kf, 64);
+                    have = true;
+                    break;
+                }
+                if (vmask != ~0ull) break;  // ran into the end of the block
+            }
+            if (!have) break;
+            // ------------------------------------------------ catch up (ip > anchor only for regular probes)
+            while (ip > anchor && mpos > 0) {
+                const uint32_t room = min(ip - anchor, mpos);
+                const bool eq = lane < room && src[ip - 1 - lane] == src[mpos - 1 - lane];
+                const uint64_t ne = ~__ballot(eq);
+                const uint32_t back = ne ? (uint32_t)(__ffsll((long long)ne) - 1) : 64;
+                ip -= back;
+                mpos -= back;
+                if (back < 64) break;
+            }
+            // ------------------------------------------------ literals
+            const uint32_t lit = ip - anchor;
+            const uint32_t tok = op++;
+            uint32_t tokv;
+            if (lit >= 15) {
+                tokv = 15u << 4;
+                const uint32_t rest = lit - 15, n255 = rest / 255;
+                for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
+                if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
+                op += n255 + 1;
+            } else {
+                tokv = lit << 4;
+            }
+            wave_copy_bytes(dst + op, src + anchor, lit);
+            op += lit;
+            // ------------------------------------------------ match
+            {
+                const uint32_t off = ip - mpos;
+                if (lane == 0) {
+                    dst[op] = (uint8_t)off;
+                    dst[op + 1] = (uint8_t)(off >> 8);
+                }
+                op += 2;
+                uint32_t mc = 0;
+                for (;;) {  // LZ4_count(ip + 4, match + 4, matchlimit), 512 bytes per round
+                    const uint32_t a0 = ip + 4 + mc + 8 * lane;
+                    uint64_t d = ~0ull;
+                    if (a0 < matchlimit) {
+                        d = lz4_ld8_safe(src, a0, n) ^ lz4_ld8_safe(src, mpos + 4 + mc + 8 * lane, n);
+                        const uint32_t room = matchlimit - a0;
+                        if (room < 8) d |= ~0ull << (8 * room);
+                    }
+                    const uint64_t nz = __ballot(d != 0);
+                    if (nz) {
+                        const int fl = __ffsll((long long)nz) - 1;
+                        const uint64_t dl = (uint64_t)__shfl((long long)d, fl, 64);
+                        mc += 8 * fl + (uint32_t)((__ffsll((long long)dl) - 1) >> 3);
+                        break;
+                    }
+                    mc += 512;
+                }
+                ip += mc + 4;
+                if (mc >= 15) {
+                    tokv += 15;
+                    const uint32_t rest = mc - 15, n255 = rest / 255;
+                    for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
+                    if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
+                    op += n255 + 1;
+                } else {
+                    tokv += mc;
+                }
+                if (lane == 0) dst[tok] = (uint8_t)tokv;
+            }
+            anchor = ip;
+            if (ip >= mfl1) break;
+            preput = ip - 2;
+            special = true;
+        }
+    }
+    {  // last literals
+        const uint32_t last = n - anchor;
+        if (last >= 15) {
+            const uint32_t rest = last - 15, n255 = rest / 255;
+            if (lane == 0) dst[op] = 15u << 4;
+            op++;
+            for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
+            if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
+            op += n255 + 1;
+        } else {
+            if (lane == 0) dst[op] = (uint8_t)(last << 4);
+            op++;
+        }
+        wave_copy_bytes(dst + op, src + anchor, last);
+        op += last;
+    }
+    return op;
 }
 
 __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);

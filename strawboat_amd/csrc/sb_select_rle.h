@@ -134,7 +134,7 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
         if (!mine) vw.mask = 0;
         // the row before my first one (lane 0 of a wave: fetched, it belongs to another wave or chunk)
         Val<W> pvrow = shfl_val<W>(v[K - 1], (lane + 63) & 63);
-        if (lane == 0) pvrow = getv(cb + r0 > 0 ? cb + r0 - 1 : 0);
+        if (lane == 0) pvrow = getv(cb + r0 > 0 ? min(cb + r0 - 1, N - 1) : 0);  // (waves past the end of a short chunk stay in range)
         const bool has_prev_row = cb + r0 > 0;
         const uint32_t m = vw.word();
         // ---- one walk over my rows: selector statistics and RLE boundaries share the canonical keys

@@ -98,3 +98,26 @@ def test_rle_chosen_after_the_speculation_stopped(gpu_ctx):
     v = np.concatenate([np.arange(3000), np.repeat(np.arange(50), 1000)]).astype(np.int64)
     col = dict(ptype=S.T_I64, nullable=False, rows=v.size, values=v, validity=None, offsets=None)
     check(gpu_ctx, col, ratio=1.5, forbidden=(S.DICT,))
+
+
+def test_inputs_at_the_end_of_an_allocation(gpu_ctx):
+    """pages whose last 4096-row chunk is short, values placed flush against the end of their device
+    allocation: the kernels must not read past the column (a stray prefetch there is a GPU fault)"""
+    import torch
+    from strawboat_amd import write
+    from strawboat_amd.types import WriteOptions
+    rng = np.random.default_rng(9)
+    seg = 20 << 20  # a whole allocator segment of its own
+    for ptype, npt, rows in ((S.T_I32, np.int32, 4224), (S.T_I64, np.int64, 12416), (S.T_F64, np.float64, 16896)):
+        w = np.dtype(npt).itemsize
+        buf = torch.zeros(seg, dtype=torch.uint8, device=gpu_ctx.torch_device)
+        v = rng.integers(0, 1000, rows).astype(npt)
+        view = buf[seg - rows * w:]
+        view.copy_(torch.from_numpy(v.view(np.uint8)))
+        col = dict(ptype=ptype, nullable=False, rows=rows, values=v, validity=None, offsets=None)
+        want_pages, want_metas = gen.oracle_write(col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+        opts = WriteOptions(max_page_size=65536, default_compression=S.LZ4, default_compress_ratio=2.0)
+        enc = write.encode_columns(gpu_ctx, [write.DeviceColumn(ptype, False, rows, view)], opts)
+        gpu_ctx.synchronize()
+        assert np.array_equal(enc[0].pages_numpy(), want_pages)
+        del buf

@@ -1695,8 +1695,12 @@ __device__ uint32_t distinct_count(Ops ops, uint64_t N, uint32_t limit, const Se
 template <class Ops>
 __device__ uint32_t majority_count(Ops ops, uint64_t N, uint32_t* s_a /* 2*WG + 4 words */) {
     const int t = threadIdx.x;
-    uint32_t cand = SEL_EMPTY, cnt = 0;
-    for (uint64_t i = t; i < N; i += WG) {
+    // (candidates are always rows of the page — row 0 while a thread has none — so that a comparison the
+    // compiler hoists above the count checks cannot read outside the column)
+    uint32_t cand = 0, cnt = 0;
+    for (uint64_t base = 0; base < N; base += WG) {  // (uniform trip count, rows guarded inside)
+        const uint64_t i = base + (uint64_t)t;
+        if (i >= N) continue;
         if (cnt == 0) {
             cand = (uint32_t)i;
             cnt = 1;
@@ -1735,7 +1739,10 @@ __device__ uint32_t majority_count(Ops ops, uint64_t N, uint32_t* s_a /* 2*WG + 
     __syncthreads();
     if (c == SEL_EMPTY) return 0;
     uint32_t mine = 0;
-    for (uint64_t i = t; i < N; i += WG) mine += ops.eq(c, i) ? 1 : 0;
+    for (uint64_t base = 0; base < N; base += WG) {
+        const uint64_t i = base + (uint64_t)t;
+        if (i < N && ops.eq(c, i)) mine++;
+    }
     return wg_sum32(mine, s_a + 2 * WG);
 }
 
@@ -2265,6 +2272,16 @@ __device__ uint32_t choose_bin(const BinKeys<O>& bk, uint64_t N, uint64_t values
     return result;
 }
 
+// Blocks go to XCD blockIdx % 8.  Pages at the same position of their column (every column's short last page,
+// whose u32 indices fall to LZ4 and take 100x longer than a bit-packed page) are a fixed stride apart: with a
+// power-of-two page count per column they would all run on ONE XCD.  Rotate each group of 8 blocks by a hash
+// of the group number.
+__device__ __forceinline__ uint32_t spread_block(uint32_t b, uint32_t nblocks) {
+    const uint32_t g = b >> 3;
+    if (((g + 1) << 3) > nblocks) return b;
+    return (g << 3) | ((b + ((g * 0x9E3779B1u) >> 29)) & 7);
+}
+
 // ------------------------------------------------------------------------------ page kernels
 struct PageCtx {
     const EncCol* c;
@@ -2506,7 +2523,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     // sample area, also the streaming scratch of choose_prim: 1 KB validity words + 4 x 128 keys
     constexpr int SMP = SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16, STR = 1024 + 4 * 96 * (KIND == 8 ? 8 : 4) + 4 * 96;
     __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SMP > STR ? SMP : STR];
-    const uint32_t page = blockIdx.x + a.page_base;
+    const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     if (p.codec != CODEC_ON_DEVICE) return;
     const EncCol c = get_col(a, p.col);
@@ -2627,7 +2644,7 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * LW];
     uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
     __shared__ uint32_t s_w[4];
-    const uint32_t page = blockIdx.x + a.page_base;
+    const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     if (codec_of(a, p, page) != CODEC) return;
     if constexpr (CODEC == SB_CODEC_RLE) {
@@ -2896,7 +2913,9 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
     uint32_t nulls = 0;
     Val<W> vk = val_zero<W>();
     uint32_t vn = 0;
-    for (uint64_t i = t; i < N; i += WG) {
+    for (uint64_t base = 0; base < N; base += WG) {
+        const uint64_t i = base + (uint64_t)t;
+        if (i >= N) continue;
         if (!vv.get(i)) nulls++;
         const Val<W> x = keyof(i);
         if (vn == 0) {
@@ -2941,11 +2960,13 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
         // its count and first occurrence (the value written is the first slot's raw bits)
         uint32_t mine = 0;
         unsigned long long first = ~0ull;
-        for (uint64_t i = t; i < N; i += WG)
-            if (bits_eq<W>(keyof(i), topk)) {
+        for (uint64_t base = 0; base < N; base += WG) {
+            const uint64_t i = base + (uint64_t)t;
+            if (i < N && bits_eq<W>(keyof(i), topk)) {
                 mine++;
                 if (first == ~0ull) first = i;
             }
+        }
         const uint32_t mc = wg_sum32(mine, s_w);
         if (t == 0) s_first[0] = ~0ull;
         __syncthreads();
@@ -3037,8 +3058,10 @@ __device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPag
     uint32_t cand = 0;
     uint64_t tb = 0, te = 0;
     if (!top_is_null) {
-        uint32_t cd = SEL_EMPTY, cnt = 0;
-        for (uint64_t i = t; i < N; i += WG) {
+        uint32_t cd = 0, cnt = 0;  // (always a row of the page, see majority_count)
+        for (uint64_t base = 0; base < N; base += WG) {
+            const uint64_t i = base + (uint64_t)t;
+            if (i >= N) continue;
             if (cnt == 0) {
                 cd = (uint32_t)i;
                 cnt = 1;
@@ -3078,7 +3101,10 @@ __device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPag
         __syncthreads();
         uint32_t mine = 0;
         if (have)
-            for (uint64_t i = t; i < N; i += WG) mine += bk.eq(cand, i) ? 1u : 0u;
+            for (uint64_t base = 0; base < N; base += WG) {
+                const uint64_t i = base + (uint64_t)t;
+                if (i < N && bk.eq(cand, i)) mine++;
+            }
         const uint32_t mc = wg_sum32(mine, s_w);
         if ((uint64_t)mc * 2 <= N) {  // no majority: the exact arg-max needs full counts (host-forced Freq only)
             if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
@@ -3321,7 +3347,7 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
 __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     __shared__ uint32_t tab[4096];
     __shared__ uint32_t s_sz;
-    const uint32_t page = blockIdx.x + a.page_base;
+    const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     const int32_t bc = codec_of(a, p, page);
     if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD && bc != SB_CODEC_SNAPPY) return;
@@ -3651,7 +3677,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         sb_column_write& c = cols[i];
         if (c.physical_type < 0 || c.physical_type > SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "bad physical_type");
         if (c.rows == 0) return ctx->fail(SB_ERR_OUT_OF_SPEC, "encode_chunk on an empty chunk panics upstream");
-        if (c.physical_type != SB_TYPE_NULL && !c.values) return ctx->fail(SB_ERR_INVALID, "values is null");
+        if (c.physical_type != SB_TYPE_NULL && !c.values && !(enc_is_binary(c.physical_type) && c.values_len == 0))
+            return ctx->fail(SB_ERR_INVALID, "values is null");  // (a binary column of empty strings has no value bytes)
         if (enc_is_binary(c.physical_type) && !c.offsets) return ctx->fail(SB_ERR_INVALID, "offsets is null");
         const uint64_t ps = page_size_of(c.rows, opts);
         const uint64_t np = c.page_rows ? c.n_pages_in : (c.rows + ps - 1) / ps;

@@ -121,3 +121,23 @@ def test_inputs_at_the_end_of_an_allocation(gpu_ctx):
         gpu_ctx.synchronize()
         assert np.array_equal(enc[0].pages_numpy(), want_pages)
         del buf
+
+
+@pytest.mark.parametrize("rows", [1, 2, 63, 129, 255, 256])
+def test_pages_smaller_than_a_workgroup(gpu_ctx, rows):
+    """fewer rows than threads, every codec a candidate: the majority vote of the Freq ratio (wide integers,
+    binary) must only look at rows of the page"""
+    for col in (gen.prim(S.T_I128, rows, uniq=300, seed=rows), gen.prim(S.T_I256, rows, uniq=300, seed=rows + 1),
+                gen.prim(S.T_I64, rows, uniq=300, seed=rows + 2), gen.prim(S.T_F64, rows, uniq=3, null_density=0.2, seed=rows + 3),
+                gen.binary(rows, uniq=40, seed=rows + 4), gen.binary(rows, uniq=2, null_density=0.3, large=True, seed=rows + 5),
+                gen.boolean(rows, seed=rows + 6)):
+        check(gpu_ctx, col, ratio=2.0, forbidden=())
+        check(gpu_ctx, col, ratio=1.1, default_compression=S.LZ4, forbidden=())
+
+
+def test_binary_column_of_empty_strings(gpu_ctx):
+    for rows in (1, 300):
+        col = gen.binary(rows, uniq=1, maxlen=0)
+        assert col["values"].size == 0
+        check(gpu_ctx, col, ratio=2.0, forbidden=())
+        check(gpu_ctx, col)

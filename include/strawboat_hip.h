@@ -121,10 +121,11 @@ typedef struct sb_column_read {
     uint64_t pages_len;
     const sb_page_meta* metas; /* HOST: ColumnMeta.pages */
     uint64_t n_pages;
-    /* outputs (DEVICE).  Capacities in bytes. */
-    void* values;            /* primitives: rows*w; boolean: ceil(rows/8) bitmap; binary: value bytes */
+    /* outputs (DEVICE).  Capacities in bytes; bitmaps are written in 32-bit words, so their buffers are
+     * 4-byte aligned with a capacity of 4*ceil(rows/32) (SB_ERR_INVALID otherwise). */
+    void* values;            /* primitives: rows*w; boolean: ceil(rows/8) bitmap bytes; binary: value bytes */
     uint64_t values_capacity;
-    uint8_t* validity;       /* ceil(rows/8) bytes, LSB-first; required iff is_nullable */
+    uint8_t* validity;       /* ceil(rows/8) bitmap bytes, LSB-first; required iff is_nullable */
     uint64_t validity_capacity;
     void* offsets;           /* binary: (rows+1) offsets of i32/i64 */
     uint64_t offsets_capacity;

@@ -275,6 +275,27 @@ int32_t sb_file_reader_read_pages(sb_file_reader* r, uint64_t col, uint64_t firs
                                   uint8_t* dst, uint64_t capacity, uint64_t* bytes_read);
 void sb_file_reader_close(sb_file_reader* r);
 
+/* ------------------------------------------------------------------ page inspector (host only)
+ * Replaces stat::stat_simple / stat_body / stat_dict_body / stat_freq_body (src/stat.rs:61-152): the
+ * block structure of one page without decoding it.  `out` receives a chain: out[0] is the page's block,
+ * out[k + 1] the block nested in out[k] (the u32 indices of a Dict block, the exceptions of a primitive
+ * Freq block), PageInfo / DictPageBody / FreqPageBody flattened. */
+typedef struct sb_page_info {
+    int32_t codec;                   /* SB_CODEC_*: PageBody variant */
+    int32_t has_validity_size;       /* PageInfo.validity_size is Some (nullable field, out[0] only) */
+    uint32_t validity_size;          /* as upstream reports it: the u32 FOLLOWING the def-level section, i.e. the
+                                        first 4 bytes of the block header (src/stat.rs:72-76), not the section's size */
+    uint32_t compressed_size;
+    uint32_t uncompressed_size;
+    uint32_t unique_num;             /* Dict: DictPageBody.unique_num */
+    uint32_t exceptions_bitmap_size; /* Freq: FreqPageBody.exceptions_bitmap_size */
+    int32_t has_nested;              /* the next entry of `out` describes this block's nested block */
+} sb_page_info;
+/* Returns SB_OK and the chain length in *n_out (<= capacity); SB_ERR_IO when the page is shorter than
+ * its headers say (upstream: slice panic), SB_ERR_OUT_OF_SPEC for an unknown codec id. */
+int32_t sb_stat_page(const uint8_t* page, uint64_t length, int32_t physical_type, int32_t is_nullable,
+                     sb_page_info* out, uint32_t capacity, uint32_t* n_out);
+
 /* ------------------------------------------------------------------ measurement
  * Optional per-kernel timing with HIP events recorded on the context's stream around every
  * kernel launch (used by bench.py for the roofline figure).  Totals are accumulated at

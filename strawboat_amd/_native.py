@@ -20,7 +20,7 @@ EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize"
            "sb_nested_read_levels", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
            "sb_file_writer_write_column", "sb_file_writer_finish", "sb_file_writer_close", "sb_file_reader_open",
            "sb_file_reader_n_columns", "sb_file_reader_column", "sb_file_reader_schema", "sb_file_reader_read_pages",
-           "sb_file_reader_close")
+           "sb_file_reader_close", "sb_stat_page")
 
 
 class PageMetaC(C.Structure):
@@ -66,6 +66,12 @@ class NestedLevelOutC(C.Structure):
     _fields_ = [("offsets", C.c_void_p), ("validity", C.c_void_p), ("offsets_capacity", C.c_uint64),
                 ("validity_capacity", C.c_uint64), ("length", C.c_uint64), ("kind", C.c_int32),
                 ("is_nullable", C.c_int32)]
+
+
+class PageInfoC(C.Structure):
+    _fields_ = [("codec", C.c_int32), ("has_validity_size", C.c_int32), ("validity_size", C.c_uint32),
+                ("compressed_size", C.c_uint32), ("uncompressed_size", C.c_uint32), ("unique_num", C.c_uint32),
+                ("exceptions_bitmap_size", C.c_uint32), ("has_nested", C.c_int32)]
 
 
 class KernelStatC(C.Structure):
@@ -149,5 +155,8 @@ def load():
     L.sb_file_reader_read_pages.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                             C.POINTER(C.c_uint64)]
     L.sb_file_reader_close.argtypes = [C.c_void_p]
+    L.sb_stat_page.restype = C.c_int32
+    L.sb_stat_page.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(PageInfoC), C.c_uint32,
+                               C.POINTER(C.c_uint32)]
     _lib = L
     return L

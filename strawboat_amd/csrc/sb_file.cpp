@@ -239,3 +239,98 @@ void sb_file_reader_close(sb_file_reader* r) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- page inspector
+// stat::stat_simple and friends (src/stat.rs:61-152): walk the block headers of one page.
+namespace {
+uint32_t stat_width(int32_t t) {
+    switch (t) {
+        case SB_TYPE_INT8: case SB_TYPE_UINT8: return 1;
+        case SB_TYPE_INT16: case SB_TYPE_UINT16: return 2;
+        case SB_TYPE_INT32: case SB_TYPE_UINT32: case SB_TYPE_FLOAT32: return 4;
+        case SB_TYPE_INT64: case SB_TYPE_UINT64: case SB_TYPE_FLOAT64: return 8;
+        case SB_TYPE_INT128: return 16;
+        case SB_TYPE_INT256: return 32;
+        default: return 0;
+    }
+}
+uint32_t rd32(const uint8_t* p) {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+// stat_body (src/stat.rs:82-113); returns 0 or an error code, appends to out
+int32_t stat_block(const uint8_t*& cur, const uint8_t* end, int32_t ptype, sb_page_info* out, uint32_t cap, uint32_t& n) {
+    if (n >= cap) return SB_ERR_INVALID;
+    if (end - cur < 9) return SB_ERR_IO;
+    const uint32_t me0 = n;
+    sb_page_info& pi = out[n++];
+    memset(&pi, 0, sizeof pi);
+    const uint32_t codec = cur[0];
+    pi.compressed_size = rd32(cur + 1);
+    pi.uncompressed_size = rd32(cur + 5);
+    if (!(codec <= 3 || (codec >= 10 && codec <= 16))) return SB_ERR_OUT_OF_SPEC;  // Compression::from_codec
+    pi.codec = (int32_t)codec;
+    cur += 9;
+    const uint8_t* body = cur;
+    const bool is_bin = ptype == SB_TYPE_BINARY || ptype == SB_TYPE_LARGE_BINARY;
+    if (codec == SB_CODEC_DICT) {  // stat_dict_body (:145-152): nested indices block, then u32 unique_num
+        const uint8_t* q = body;
+        pi.has_nested = 1;
+        const uint32_t me = n - 1;
+        const int32_t rc = stat_block(q, end, ptype, out, cap, n);
+        if (rc) return rc;
+        if (end - q < 4) return SB_ERR_IO;
+        out[me].unique_num = rd32(q);
+    } else if (codec == SB_CODEC_FREQ) {  // stat_freq_body (:115-143)
+        const uint8_t* q = body;
+        if (is_bin) {
+            if (end - q < 8) return SB_ERR_IO;
+            uint64_t len;
+            memcpy(&len, q, 8);
+            if ((uint64_t)(end - q) - 8 < len || (uint64_t)(end - q) - 8 - len < 4) return SB_ERR_IO;
+            pi.exceptions_bitmap_size = rd32(q + 8 + len);
+        } else {
+            const uint32_t w = stat_width(ptype);
+            if (!w) return SB_ERR_OUT_OF_SPEC;  // unreachable!("type not supported") upstream
+            if ((uint64_t)(end - q) < (uint64_t)w + 4) return SB_ERR_IO;
+            const uint32_t bm = rd32(q + w);
+            if ((uint64_t)(end - q) - w - 4 < bm) return SB_ERR_IO;
+            q += w + 4 + bm;
+            const uint32_t me = n - 1;
+            out[me].exceptions_bitmap_size = bm;
+            out[me].has_nested = 1;
+            const int32_t rc = stat_block(q, end, ptype, out, cap, n);
+            if (rc) return rc;
+        }
+    }
+    const uint32_t csize = out[me0].compressed_size;
+    if ((uint64_t)(end - body) < csize) return SB_ERR_IO;  // `*buffer = &buffer[compressed_size..]` panics upstream
+    cur = body + csize;
+    return SB_OK;
+}
+}  // namespace
+
+extern "C" int32_t sb_stat_page(const uint8_t* page, uint64_t length, int32_t physical_type, int32_t is_nullable,
+                                sb_page_info* out, uint32_t capacity, uint32_t* n_out) {
+    if (!page || !out || !n_out || capacity == 0) return SB_ERR_INVALID;
+    const uint8_t* cur = page;
+    const uint8_t* end = page + length;
+    int32_t has_vs = 0;
+    uint32_t vs = 0;
+    if (is_nullable) {  // stat_simple (:72-77)
+        if (length < 4) return SB_ERR_IO;
+        const uint32_t def_len = rd32(cur);
+        if (length - 4 < def_len || length - 4 - def_len < 4) return SB_ERR_IO;
+        cur += 4 + def_len;
+        vs = rd32(cur);
+        has_vs = 1;
+    }
+    uint32_t n = 0;
+    const int32_t rc = stat_block(cur, end, physical_type, out, capacity, n);
+    if (rc) return rc;
+    out[0].has_validity_size = has_vs;
+    out[0].validity_size = vs;
+    *n_out = n;
+    return SB_OK;
+}

@@ -16,7 +16,7 @@ static const char* const KERNEL_NAMES[K_COUNT] = {"k_parse", "k_inflate", "k_pla
                                                   "k_expand", "k_expand_binary", "k_enc_emit_tiles",
                                                   "k_enc_emit_pages<RLE>", "k_enc_layout", "k_enc_compact", "k_enc_select", "k_enc_emit_lz4",
                                                   "k_enc_emit_pages<Dict>", "k_enc_emit_pages<OneValue>",
-                                                  "k_enc_emit_pages<Bitpacking>", "k_expand_rle", "k_enc_emit_pages<Patas>", "k_enc_freq_prep/finish"};
+                                                  "k_enc_emit_pages<Bitpacking>", "k_expand_rle", "k_enc_emit_pages<Patas>", "k_enc_freq_prep/finish", "k_enc_select_rle"};
 
 int32_t check_hip(sb_ctx* ctx, hipError_t e, const char* what) {
     if (e == hipSuccess) return SB_OK;

@@ -2515,6 +2515,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
 
 // codec choice per page (adaptive mode): one workgroup per page, one instance per KIND
 #include "sb_select_rle.h"
+#include "sb_select_runs.h"
 
 template <int KIND>
 __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
@@ -2585,6 +2586,7 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
     const EncCol c = a.cols[p.col];
     if (c.ptype == SB_TYPE_NULL || c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY) return;
     if (c.width != (uint32_t)KIND || (c.fkind != 0) != (FK != 0)) return;
+    if (a.codecs[page] != CODEC_PENDING) return;  // k_enc_select_runs (launched before) took the page
     const uint64_t N = p.rows;
     SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
     SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
@@ -2597,6 +2599,45 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
     bool kept = false;
     if (N > 0) codec = select_rle_page<KIND, FK>(a, c, p, page, so, sc, s_cnt2, &kept);
     if (threadIdx.x == 0) {
+        a.codecs[page] = (int32_t)codec;
+        if (!has_device_encoder(codec))
+            raise(a.status, SB_ERR_NYI, page, 700 + codec);
+        else if (codec == SB_CODEC_FREQ)
+            atomicAdd(a.freq_count, 1u);
+    }
+}
+
+// The same selection + speculative RLE with one raw run per lane (sb_select_runs.h); pages whose runs are
+// too short are left to k_enc_select_rle (CODEC_PENDING).
+template <int KIND, int FK>
+__global__ void __launch_bounds__(WG, 4) k_enc_select_runs(EncodeArgs a) {
+    __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
+    __shared__ uint32_t s_misc[2 * WG + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * (KIND + 1) + 16];
+    __shared__ uint32_t s_cnt2[2];
+    static_assert(SAMPLE_CAP * (KIND + 1) + 16 >= 2 * (RUNS_CAP + 8) + (WG * 16 / 32 + 32) * 4 + 8 * KIND, "run list must fit the sample area");
+    const uint32_t page = blockIdx.x;
+    const EncPage p = a.pages[page];
+    if (p.codec != CODEC_ON_DEVICE) return;
+    const EncCol c = a.cols[p.col];
+    if (c.ptype == SB_TYPE_NULL || c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY) return;
+    if (c.width != (uint32_t)KIND || (c.fkind != 0) != (FK != 0)) return;
+    const uint64_t N = p.rows;
+    SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
+    SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
+    if (sc.gtab) {  // the Dict aux area starts with a table of pow2 >= 2N slots
+        uint64_t M = 64;
+        while (M < 2 * N) M <<= 1;
+        sc.gslots = M;
+    }
+    uint32_t codec = so.default_codec;
+    bool kept = false, fallback = false;
+    if (N > 0) codec = select_runs_page<KIND, FK>(a, c, p, page, so, sc, s_cnt2, &kept, &fallback);
+    if (threadIdx.x == 0) {
+        if (fallback) {
+            a.codecs[page] = CODEC_PENDING;
+            return;
+        }
         a.codecs[page] = (int32_t)codec;
         if (!has_device_encoder(codec))
             raise(a.status, SB_ERR_NYI, page, 700 + codec);
@@ -3900,15 +3941,30 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                             any_f |= hc[i].fkind != 0;
                             any_i |= hc[i].fkind == 0;
                         }
+                    // lane = raw run first; pages with runs too short for that go through the lane = row kernel
                     if (any_f) {
-                        KScope k(ctx, K_ENC_SELECT);
+                        {
+                            KScope k(ctx, K_ENC_SELECT);
+                            if (kd == 4)
+                                k_enc_select_runs<4, 1><<<(uint32_t)P, WG, 0, s>>>(aa);
+                            else
+                                k_enc_select_runs<8, 2><<<(uint32_t)P, WG, 0, s>>>(aa);
+                        }
+                        KScope k(ctx, K_ENC_SELECT_ROWS);
                         if (kd == 4)
                             k_enc_select_rle<4, 1><<<(uint32_t)P, WG, 0, s>>>(aa);
                         else
                             k_enc_select_rle<8, 2><<<(uint32_t)P, WG, 0, s>>>(aa);
                     }
                     if (any_i) {
-                        KScope k(ctx, K_ENC_SELECT);
+                        {
+                            KScope k(ctx, K_ENC_SELECT);
+                            if (kd == 4)
+                                k_enc_select_runs<4, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
+                            else
+                                k_enc_select_runs<8, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
+                        }
+                        KScope k(ctx, K_ENC_SELECT_ROWS);
                         if (kd == 4)
                             k_enc_select_rle<4, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
                         else

@@ -30,7 +30,7 @@ struct Pending {  // results to hand back to the caller's structs at synchronize
 enum KernelId {
     K_PARSE, K_INFLATE_A, K_PLAN, K_COLSCAN, K_INFLATE_B, K_EXPAND, K_EXPAND_BIN,
     K_ENC_TILES, K_ENC_PAGES, K_ENC_LAYOUT, K_ENC_COMPACT, K_ENC_SELECT, K_ENC_LZ4,
-    K_ENC_PAGES_DICT, K_ENC_PAGES_ONEVALUE, K_ENC_PAGES_BP, K_EXPAND_RLE, K_ENC_PAGES_PATAS, K_ENC_FREQ, K_COUNT
+    K_ENC_PAGES_DICT, K_ENC_PAGES_ONEVALUE, K_ENC_PAGES_BP, K_EXPAND_RLE, K_ENC_PAGES_PATAS, K_ENC_FREQ, K_ENC_SELECT_ROWS, K_COUNT
 };
 struct ProfSpan {
     int id;

@@ -135,11 +135,17 @@ __device__ unsigned long long* g_tl;
     do {                                                                                             \
         if (g_tl && blockIdx.x == 100 && threadIdx.x == 0) g_tl[512 + (p)] = __builtin_readcyclecounter(); \
     } while (0)
+// per-chunk stamps of chunk XTL_CHUNK (workgroup 100, thread 0): g_tl[600 + p]
+#define XTL(p)                                                                                                        \
+    do {                                                                                                              \
+        if (g_tl && blockIdx.x == 100 && threadIdx.x == 0 && cb == 8 * 4096) g_tl[600 + (p)] = __builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define TL_INIT
 #define TL(p)
 #define TL_NEXT
 #define STL(p)
+#define XTL(p)
 #endif
 
 // ------------------------------------------------------------------------------ small helpers
@@ -2612,10 +2618,15 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
 template <int KIND, int FK>
 __global__ void __launch_bounds__(WG, 4) k_enc_select_runs(EncodeArgs a) {
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
-    __shared__ uint32_t s_misc[2 * WG + 16];
-    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * (KIND + 1) + 16];
+    // the sample area and the misc words are one pool: the run list and the run values of the streaming loop use
+    // both (they are free until decide_prim runs)
+    constexpr int SMP_BYTES = (SAMPLE_CAP * (KIND + 1) + 16 + 15) / 16 * 16, MISC_BYTES = (2 * WG + 16) * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t pool[SMP_BYTES + MISC_BYTES];
+    uint8_t* sample_mem = pool;
+    uint32_t* s_misc = (uint32_t*)(pool + SMP_BYTES);
     __shared__ uint32_t s_cnt2[2];
-    static_assert(SAMPLE_CAP * (KIND + 1) + 16 >= 2 * (RUNS_CAP + 8) + (WG * 16 / 32 + 32) * 4 + 8 * KIND, "run list must fit the sample area");
+    static_assert(SMP_BYTES + MISC_BYTES >= 2 * (RUNS_CAP + 8) + (WG * 16 / 32 + 32) * 4 + 8 * KIND + (RUNS_CAP + 1) * KIND,
+                  "run list and run values must fit the pool");
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
     if (p.codec != CODEC_ON_DEVICE) return;

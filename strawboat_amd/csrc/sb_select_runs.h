@@ -13,11 +13,15 @@
 // where the bits change are compacted into an LDS list, and a second step handles one raw RUN per
 // lane.  For pages with runs of ~32 rows that is 1/32 of the old per-row work.
 //
-// A chunk (4096 rows) with more than RUNS_CAP raw runs (runs shorter than 4 rows on average) makes
+// The next chunk's rows are requested as soon as the comparison has consumed the current ones (same
+// registers), and the run values travel through LDS, so neither load latency sits on the per-chunk
+// critical path.
+//
+// A chunk (4096 rows) with more than RUNS_CAP raw runs (runs shorter than ~6 rows on average) makes
 // the page FALL BACK to select_rle_page (k_enc_select_rle runs after this kernel and takes the pages
 // marked CODEC_PENDING): lane = run pays off only when there are runs.
 constexpr int32_t CODEC_PENDING = -100;
-constexpr uint32_t RUNS_CAP = 1024;
+constexpr uint32_t RUNS_CAP = 640;
 
 template <int W, int FK>
 __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, const SelectOpts& o,
@@ -61,11 +65,13 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
         s_kcnt = 0;
         s_ksent = 0;
     }
-    // LDS (inside the sample area, free until decide_prim draws the samples)
-    uint16_t* runs = (uint16_t*)sc.sample_mem;                        // RUNS_CAP + 2 chunk-relative run starts
-    uint32_t* s_vb = (uint32_t*)(sc.sample_mem + 2 * (RUNS_CAP + 8));  // CHUNK / 32 validity words of the chunk
-    uint32_t* s_x = s_vb + CHUNK / 32;                                 // 2 parities x 16 words of wave records
-    Val<W>* s_lastk = (Val<W>*)(s_x + 32);                             // 2 parities x 4 keys
+    // LDS: sc.sample_mem and sc.s_misc are one contiguous pool here (k_enc_select_runs), free until decide_prim
+    uint16_t* runs = (uint16_t*)sc.sample_mem;                         // RUNS_CAP + 2 chunk-relative run starts
+    uint32_t* s_vb = (uint32_t*)(sc.sample_mem + 2 * (RUNS_CAP + 8));   // CHUNK / 32 validity words of the chunk
+    uint32_t* s_x = s_vb + CHUNK / 32;                                  // 2 parities x 16 words of wave records
+    Val<W>* s_lastk = (Val<W>*)(s_x + 32);                              // 2 parities x 4 keys
+    Val<W>* rvals = s_lastk + 8;                                        // RUNS_CAP + 1 raw values: [0] = the row before
+                                                                        // the chunk, [1 + r] = value of run r
     __syncthreads();
     // ---- RLE state (speculative)
     bool spec = !forbidden(SB_CODEC_RLE);
@@ -83,12 +89,13 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     };
     uint32_t par = 0;
-    for (uint64_t cb = 0; cb < N; cb += CHUNK) {
+    // rows of one chunk (thread = K consecutive rows), the row before a wave's first row, and a validity word
+    Val<W> v[K];
+    Val<W> pv0 = val_zero<W>();
+    uint32_t vword = 0;
+    auto request = [&](uint64_t cb) {
         const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
         const uint32_t r0 = (uint32_t)t * K;
-        const uint32_t mine = r0 < n ? min((uint32_t)K, n - r0) : 0u;
-        // ---- step 1: where do the bits change?
-        Val<W> v[K];
         if (r0 + K <= n) {
             constexpr int NV = K * W / 16;
             u32x4 q[NV];
@@ -99,19 +106,32 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
 #pragma unroll
             for (int j = 0; j < K; j++) v[j] = getv(cb + (r0 + j < n ? r0 + j : n - 1));
         }
+        if (lane == 0) pv0 = getv(cb + r0 > 0 ? min(cb + r0 - 1, N - 1) : 0);
+        vword = 0xFFFFFFFFu;
+        if (t < (int)(CHUNK / 32) && (uint32_t)t * 32 < n && vv.bits) vword = bits32(vv.bits, vv.off + cb + (uint32_t)t * 32, vtotal);
+    };
+    STL(0);
+    for (uint64_t cb = 0; cb < N; cb += CHUNK) {
+        XTL(0);
+        request(cb);
+        const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
+        const uint32_t r0 = (uint32_t)t * K;
+        const uint32_t mine = r0 < n ? min((uint32_t)K, n - r0) : 0u;
+        // ---- step 1: where do the bits change?
         if (t < (int)(CHUNK / 32)) {  // the chunk's validity words (null count rides along)
             const uint32_t b0 = (uint32_t)t * 32;
             uint32_t word = 0;
             if (b0 < n) {
                 const uint32_t nb = min(32u, n - b0);
                 const uint32_t m = nb >= 32 ? 0xFFFFFFFFu : (1u << nb) - 1;
-                word = (vv.bits ? bits32(vv.bits, vv.off + cb + b0, vtotal) : 0xFFFFFFFFu) & m;
+                word = vword & m;
                 nulls += nb - (uint32_t)__popc(word);
             }
             s_vb[t] = word;
         }
         Val<W> pvrow = shfl_val<W>(v[K - 1], (lane + 63) & 63);
-        if (lane == 0) pvrow = getv(cb + r0 > 0 ? min(cb + r0 - 1, N - 1) : 0);
+        if (lane == 0) pvrow = pv0;
+        if (t == 0) rvals[0] = pvrow;
         uint32_t rbm = 0;
         {
             Val<W> pr = pvrow;
@@ -124,11 +144,13 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
                                      // chunk before may hold its first valid row here)
             rbm &= mine >= (uint32_t)K ? 0xFFFFu : ((1u << mine) - 1);
         }
+        XTL(1);
         uint32_t* s_rc = s_x + par * 16 + 12;  // [4] raw runs starting in each wave
         const uint32_t cnt1 = (uint32_t)__popc(rbm);
         const uint32_t incl1 = wave_incl_scan(cnt1);
         if (lane == 63) s_rc[w] = incl1;
         lds_barrier();
+        XTL(2);
         const uint32_t total = s_rc[0] + s_rc[1] + s_rc[2] + s_rc[3];
         if (total > RUNS_CAP) {  // short runs: lane = run does not pay, the row-level kernel takes the page
             *fallback = true;
@@ -138,28 +160,32 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
             uint32_t at = incl1 - cnt1;
             for (int pw = 0; pw < 3; pw++)
                 if (pw < w) at += s_rc[pw];
-            while (rbm) {
-                const int j = __ffs((int)rbm) - 1;
-                rbm &= rbm - 1;
-                runs[at++] = (uint16_t)(r0 + (uint32_t)j);
-            }
+#pragma unroll
+            for (int j = 0; j < K; j++)
+                if ((rbm >> j) & 1) {
+                    runs[at] = (uint16_t)(r0 + (uint32_t)j);
+                    rvals[1 + at] = v[j];
+                    at++;
+                }
             if (t == 0) runs[total] = (uint16_t)n;  // (n <= 4096 fits)
         }
+        XTL(3);
         lds_barrier();
+        XTL(4);
         // ---- step 2: one raw run per lane
         for (uint32_t rb = 0; rb < total; rb += WG, par ^= 1) {
             const uint32_t r = rb + (uint32_t)t;
             const bool act = r < total;
             const uint32_t start = act ? runs[r] : 0, end = act ? runs[r + 1] : 0;
             const uint64_t row = cb + start;
-            const Val<W> val = getv(act ? row : 0);
+            const Val<W> val = rvals[act ? 1 + r : 0];
             const Val<W> kk = stat_key<W>(val, nk);
             if (act) {
                 if (!bits_eq<W>(kk, k0)) f_neq0 = 1;
                 if (!is_float) {
                     if (int_lt<W>(tmax, val, nk)) tmax = val;
                     if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(val, nk) < 0) f_neg = 1;
-                    if (W == 4 && row > 0 && int_lt<W>(val, getv(row - 1), nk)) f_unsorted = 1;
+                    if (W == 4 && row > 0 && int_lt<W>(val, rvals[r], nk)) f_unsorted = 1;  // rvals[r]: the row before
                 }
                 if (want_vote) {  // Boyer-Moore with the run length as weight (== feeding its rows one by one)
                     const uint64_t x = k64(kk);
@@ -195,6 +221,7 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
                     }
                 }
             }
+            XTL(5);
             if (!spec) continue;
             // first valid row of my run (chunk relative), -1 if it has none
             int fv = -1;
@@ -222,7 +249,9 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
                 s_has[w] = has_w;
                 s_last[w] = last_w;
             }
+            XTL(6);
             lds_barrier();
+            XTL(7);
             bool chas = have;
             Val<W> cval = last;
             for (int pw = 0; pw < 3; pw++)
@@ -246,7 +275,9 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
                 s_cnt[w] = cnt_w;
                 s_blast[w] = bmk ? blast_w : 0;
             }
+            XTL(8);
             lds_barrier();
+            XTL(9);
             uint32_t base = nrec;
             uint64_t start_prev = run_start;
             for (int pw = 0; pw < 3; pw++)
@@ -269,11 +300,13 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
                 if (s_blast[pw]) run_start = cb + s_blast[pw] - 1;
             }
         }
+        XTL(10);
         if (!spec) lds_barrier();  // (the run list and the validity words are rewritten by the next chunk)
         // runs shorter than 4 rows on average: RLE is unlikely to be chosen, stop paying for it
         if ((uint64_t)nrec * 4 > cb + n + 256) spec = false;
     }
     __syncthreads();  // every wave's keys are in the set before its size is read
+    STL(1);
     PrimPartials<W> pp{f_neq0, f_unsorted, f_neg, nulls, tmax, vote_k, vote_n};
     const uint32_t s_k = want_set ? s_kcnt : 0u, s_s = want_set ? s_ksent : 0u;
     SamplePre<W> none;

@@ -5,8 +5,8 @@
 #include <random>
 using namespace sb;
 
-int main() {
-    const uint64_t P = 4096, N = 65536;
+int main(int argc, char** argv) {
+    const uint64_t P = (uint64_t)(argc > 1 ? atoi(argv[1]) : 4096), N = 65536;
     std::vector<uint64_t> h(P * N);
     std::vector<uint8_t> hv(P * N / 8);
     std::mt19937_64 rng(42);

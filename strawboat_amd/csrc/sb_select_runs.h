@@ -160,13 +160,17 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
             uint32_t at = incl1 - cnt1;
             for (int pw = 0; pw < 3; pw++)
                 if (pw < w) at += s_rc[pw];
+            while (rbm) {  // (a handful of iterations: the value is picked with a select chain, not 16 guarded stores)
+                const int j = __ffs((int)rbm) - 1;
+                rbm &= rbm - 1;
+                Val<W> x = v[0];
 #pragma unroll
-            for (int j = 0; j < K; j++)
-                if ((rbm >> j) & 1) {
-                    runs[at] = (uint16_t)(r0 + (uint32_t)j);
-                    rvals[1 + at] = v[j];
-                    at++;
-                }
+                for (int q = 1; q < K; q++)
+                    if (j == q) x = v[q];
+                runs[at] = (uint16_t)(r0 + (uint32_t)j);
+                rvals[1 + at] = x;
+                at++;
+            }
             if (t == 0) runs[total] = (uint16_t)n;  // (n <= 4096 fits)
         }
         XTL(3);

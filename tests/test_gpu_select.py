@@ -141,3 +141,51 @@ def test_binary_column_of_empty_strings(gpu_ctx):
         assert col["values"].size == 0
         check(gpu_ctx, col, ratio=2.0, forbidden=())
         check(gpu_ctx, col)
+
+
+def test_run_level_kernel_shapes(gpu_ctx):
+    """the lane = raw run kernel (sb_select_runs.h): null blocks around the 4096-row chunk seams, runs whose
+    bits differ but whose keys are equal (+0 / -0, NaN payloads), a page that falls back to the row-level
+    kernel half way, leading / trailing nulls, one long run"""
+    rng = np.random.default_rng(77)
+    N = 3 * 65536 + 5000
+
+    def col_of(vals, valid_bool, ptype):
+        validity = None if valid_bool is None else gen.pack_bits(valid_bool)
+        return dict(ptype=ptype, nullable=validity is not None, rows=vals.size, values=vals, validity=validity, offsets=None)
+
+    # null blocks that straddle chunk seams, values changing exactly at / next to the seams
+    v = np.repeat(rng.integers(0, 50, N // 37 + 1), 37)[:N].astype(np.float64)
+    ok = np.ones(N, bool)
+    for seam in range(4096, N, 4096):
+        a, b = seam - int(rng.integers(0, 9)), seam + int(rng.integers(0, 9))
+        ok[a:b] = False
+        if seam % 8192 == 0:
+            v[seam - 1:seam + 40] = 1000.0 + seam     # a raw run that starts on the last row of a chunk
+    check(gpu_ctx, col_of(v, ok, S.T_F64), max_page_size=65536, ratio=1.5, forbidden=())
+    check(gpu_ctx, col_of(v.astype(np.int64), ok, S.T_I64), max_page_size=65536, ratio=1.5, forbidden=())
+    check(gpu_ctx, col_of(v.astype(np.int32), ok, S.T_I32), max_page_size=65536, ratio=1.5, forbidden=())
+    check(gpu_ctx, col_of(v.astype(np.float32), None, S.T_F32), max_page_size=65536, ratio=1.5, forbidden=())
+    # equal keys with different bits: blocks of +0.0 / -0.0 and of NaNs with different payloads
+    z = np.zeros(N, np.float64)
+    z[(np.arange(N) // 16) % 2 == 1] = -0.0
+    nan_bits = np.where((np.arange(N) // 24) % 2 == 0, 0x7FF8000000000000, 0xFFF8000000000123).astype(np.uint64)
+    z2 = np.where((np.arange(N) // 3000) % 2 == 0, z, nan_bits.view(np.float64))
+    okz = rng.random(N) < 0.9
+    check(gpu_ctx, col_of(z2, okz, S.T_F64), max_page_size=65536, ratio=1.5, forbidden=())
+    # half of a page in long runs, the other half random: the page leaves the run-level kernel half way
+    h = np.concatenate([np.repeat(rng.integers(0, 9, 1024), 32), rng.integers(0, 1 << 40, 32768)]).astype(np.int64)
+    check(gpu_ctx, col_of(h, rng.random(h.size) < 0.95, S.T_I64), max_page_size=65536, ratio=1.2, forbidden=())
+    # leading and trailing nulls, an all-null page, one run
+    w = np.full(2 * 65536, 7.5)
+    okw = np.ones(w.size, bool)
+    okw[:5000] = False
+    okw[60000:70000] = False
+    okw[-3:] = False
+    check(gpu_ctx, col_of(w, okw, S.T_F64), max_page_size=65536, ratio=1.5, forbidden=())
+    check(gpu_ctx, col_of(np.arange(70000, dtype=np.float64) // 1000, np.zeros(70000, bool), S.T_F64), max_page_size=65536, ratio=1.5, forbidden=())
+    # sorted / unsorted / negative 4-byte integers in runs (Bitpacking and DeltaBitpacking eligibility)
+    for arr in (np.repeat(np.arange(2048), 64), np.repeat(np.arange(2048)[::-1], 64), np.repeat(np.arange(-5, 2043), 64),
+                np.repeat(np.r_[np.arange(1000), 999, np.arange(1000, 2047)], 64)):
+        check(gpu_ctx, col_of(arr.astype(np.int32), None, S.T_I32), max_page_size=65536, ratio=1.05, forbidden=())
+        check(gpu_ctx, col_of(arr.astype(np.uint32), None, S.T_U32), max_page_size=65536, ratio=1.05, forbidden=())

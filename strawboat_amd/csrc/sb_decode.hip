@@ -1448,9 +1448,10 @@ __device__ __forceinline__ uint32_t xcd_tile_index() {
 // short: the tile task carries the column index and, for RLE pages, the tile's run range (k_plan),
 // which lets the three descriptors, the validity word and the run starts be fetched in two steps;
 // only the gather of the run values follows.
-constexpr uint32_t TILES_PER_WG = 4;  // a workgroup takes 4 entries of the tile list, one after the other: the
-                                      // grid is sized by the host's upper bound, and entries that do not exist
-                                      // (pages expanded by k_expand_rle) should not each cost a workgroup launch
+constexpr uint32_t TILE_GRID = 4096;  // the tile kernels walk the compact tile list with a grid of at most this many
+                                      // workgroups: the host only knows an upper bound of the list's length, and
+                                      // entries that do not exist (pages expanded by k_expand_rle) should not each
+                                      // cost a workgroup launch
 __device__ void expand_tile(const DecodeArgs& a, uint32_t ti, uint32_t* s_a, uint32_t* s_w) {
     static_assert(TILE_ROWS / 32 <= WG, "one validity word per thread");
     DTL(0);
@@ -1503,9 +1504,7 @@ __global__ void __launch_bounds__(WG) k_expand(DecodeArgs a) {
     __shared__ uint32_t s_a[SIDX_WORDS];
     __shared__ uint32_t s_w[4];
     const uint32_t count = a.job_counts[2];
-    for (uint32_t q = 0; q < TILES_PER_WG; q++) {
-        const uint32_t ti = blockIdx.x * TILES_PER_WG + q;
-        if (ti >= count) return;
+    for (uint32_t ti = blockIdx.x; ti < count; ti += gridDim.x) {
         expand_tile(a, ti, s_a, s_w);
         __syncthreads();
     }
@@ -1687,9 +1686,7 @@ __global__ void __launch_bounds__(WG) k_expand_binary(DecodeArgs a) {
     __shared__ uint32_t s_len[SIDX_WORDS];
     __shared__ uint32_t s_w[4];
     const uint32_t count = a.job_counts[2];
-    for (uint32_t q = 0; q < TILES_PER_WG; q++) {
-        const uint32_t ti = blockIdx.x * TILES_PER_WG + q;
-        if (ti >= count) return;
+    for (uint32_t ti = blockIdx.x; ti < count; ti += gridDim.x) {
         expand_binary_tile(a, ti, s_a, s_len, s_w);
         __syncthreads();
     }
@@ -1750,11 +1747,11 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     if (a.n_tiles && any_prim) {
         KScope k(ctx, K_EXPAND);
-        k_expand<<<(a.n_tiles + TILES_PER_WG - 1) / TILES_PER_WG, WG, 0, s>>>(a);
+        k_expand<<<min(a.n_tiles, TILE_GRID), WG, 0, s>>>(a);
     }
     if (a.n_tiles && any_binary) {
         KScope k(ctx, K_EXPAND_BIN);
-        k_expand_binary<<<(a.n_tiles + TILES_PER_WG - 1) / TILES_PER_WG, WG, 0, s>>>(a);
+        k_expand_binary<<<min(a.n_tiles, TILE_GRID), WG, 0, s>>>(a);
     }
 }
 

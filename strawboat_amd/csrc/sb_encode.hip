@@ -3262,8 +3262,14 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
     uint32_t& s_sz = s_misc2[0];
     uint32_t& s_codec = s_misc2[1];
     uint32_t *sA = lds, *sB = lds + SIDX_WORDS, *sC = lds + 2 * SIDX_WORDS;
+    {  // the table entry of a virtual page is only valid when k_enc_freq_prep wrote it for its real page
+        const uint32_t q = page - a.n_pages;
+        const EncPage rp = a.pages[q];
+        if (codec_of(a, rp, q) != SB_CODEC_FREQ) return;
+        const EncOut ro = a.outs[q];
+        if (ro.length == 0 || ro.codec != SB_CODEC_FREQ || ro.pad == 2) return;  // prep raised / binary page (no nested block)
+    }
     const EncPage p = get_page(a, page);
-    if (p.codec < CODEC_ON_DEVICE) return;  // no Freq page here
     const EncCol c = get_col(a, p.col);
     if (c.width != (uint32_t)W) return;
     const uint64_t N = p.rows;
@@ -3924,10 +3930,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.page_base = 0;
     a.nested_force = opts->force_index_codec;
     a.freq_count = (uint32_t*)(tb + o_freqcnt);
-    (void)hipMemsetAsync(a.freq_count, host_codec == SB_CODEC_FREQ ? 1 : 0, 4, s);  // forced: every page is a Freq page
-
-    (void)hipMemsetAsync(a.outs, 0, 2 * P * sizeof(EncOut), s);
-    if (freq_possible) (void)hipMemsetAsync(tb + o_vpages, 0xFE, P * sizeof(EncPage), s);  // codec < -1: entry not in use
+    // one memset: page outputs (length 0 = not emitted), results, device-chosen codecs, the Freq page counter
+    (void)hipMemsetAsync(tb + o_outs, 0, o_vcols - o_outs, s);
+    if (host_codec == SB_CODEC_FREQ) (void)hipMemsetAsync(a.freq_count, 1, 4, s);  // forced: every page is a Freq page (non-zero)
     auto kind_of = [](const EncCol& d) {
         return d.ptype == SB_TYPE_BOOLEAN ? 0 : d.ptype == SB_TYPE_BINARY ? -4 : d.ptype == SB_TYPE_LARGE_BINARY ? -8 : (int)d.width;
     };

@@ -1,4 +1,4 @@
-"""Corrupted-page cases shared by scripts/fuzz_decode.py and tests/test_gpu_robustness.py: oracle-written
+"""Corrupted-page cases shared by tests/probes/fuzz_decode.py and tests/test_gpu_robustness.py: oracle-written
 pages of every codec / column family, and the mutations applied to them (byte flips, size fields,
 truncation).  The reference panics or errors on such input; the device must report a
 status — never fault, never hang."""

@@ -1,9 +1,9 @@
 """Out-of-range probe (development): every input buffer of an encode call sits flush against the end of a
 device allocation of its own, so a read past the column is a GPU fault instead of a silent stray load.
-    python scripts/edge_alloc.py <first case> <last case>"""
+    python tests/probes/edge_alloc.py <first case> <last case>"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import strawboat_amd as sb
 from strawboat_amd import read, write
 from strawboat_amd.types import WriteOptions

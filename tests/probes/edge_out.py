@@ -1,9 +1,9 @@
 """Out-of-range WRITE probe (development): decode into output buffers of exactly the documented capacity,
 each followed by a guard zone that must stay untouched.
-    python scripts/edge_out.py"""
+    python tests/probes/edge_out.py"""
 import os, sys, types
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import strawboat_amd as sb
 from strawboat_amd import read
 from strawboat_amd.types import PhysicalType

@@ -1,9 +1,9 @@
 """Decoder robustness probe (development): oracle-written pages with random byte flips / truncations are
 decoded on the device; any status is fine, a GPU fault or a hang is not.  One case per process:
-    for i in $(seq 0 62); do timeout 300 python scripts/fuzz_decode.py $i 150 || echo "CASE $i FAILED"; done"""
+    for i in $(seq 0 62); do timeout 300 python tests/probes/fuzz_decode.py $i 150 || echo "CASE $i FAILED"; done"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import strawboat_amd as sb
 from strawboat_amd import read
 from strawboat_amd._native import NativeError

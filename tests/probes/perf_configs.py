@@ -2,7 +2,7 @@
 one GPU, inputs resident in HBM (development probe; numbers quoted in DESIGN.md)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 import strawboat_amd as sb
 from strawboat_amd import read, write

@@ -1,7 +1,7 @@
 """Quick decode throughput probe (development aid, not the contract bench)."""
 import sys, time
 import numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sbo as S
 from tests import gen
 import strawboat_amd as sb

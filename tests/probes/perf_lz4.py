@@ -1,7 +1,7 @@
 """LZ4 block encoder / decoder probe (development): time per block for a few byte patterns."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import strawboat_amd as sb
 from strawboat_amd import read, write
 from strawboat_amd.types import Compression as C, WriteOptions

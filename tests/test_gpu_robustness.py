@@ -1,7 +1,7 @@
 """Corrupted pages never take the device down: every codec / column family, a few mutations each
 (byte flips, size fields set to extreme values, truncated last page).  Any status is acceptable —
 the reference itself panics or errors on such input — a GPU fault or a hang is not.
-scripts/fuzz_decode.py runs the same cases with many more trials."""
+tests/probes/fuzz_decode.py runs the same cases with many more trials."""
 import numpy as np
 import pytest
 

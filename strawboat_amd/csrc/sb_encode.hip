@@ -1490,9 +1490,13 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const uint32_t mask = (uint32_t)(M - 1);
-    // phase 1: insert; the slot of a key ends up holding the smallest row that carries it
+    // phase 1: insert; the slot of a key ends up holding the smallest row that carries it.  The slot a row
+    // landed in is remembered (in F), so that phase 2 does not hash and compare the key a second time.
     for (uint64_t i = t; i < N; i += WG) {
-        if (!ko.keyed(i)) continue;
+        if (!ko.keyed(i)) {
+            F[i] = EMPTY;
+            continue;
+        }
         uint32_t h = ko.hash(i) & mask;
         for (;;) {
             uint32_t cur = table_load(&table[h]);
@@ -1507,24 +1511,14 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
             }
             h = (h + 1) & mask;
         }
+        F[i] = h;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-    // phase 2: F[i] = first row of row i's key
+    // phase 2: F[i] = first row of row i's key (a key never leaves its slot)
     for (uint64_t i = t; i < N; i += WG) {
-        if (!ko.keyed(i)) {
-            F[i] = EMPTY;
-            continue;
-        }
-        uint32_t h = ko.hash(i) & mask;
-        for (;;) {
-            const uint32_t cur = table_load(&table[h]);
-            if (cur == (uint32_t)i || ko.eq(cur, i)) {
-                F[i] = cur;
-                break;
-            }
-            h = (h + 1) & mask;
-        }
+        const uint32_t h = F[i];
+        if (h != EMPTY) F[i] = table_load(&table[h]);
     }
     __syncthreads();
     // phase 3: dictionary ids in first-occurrence order (rank of first rows), chunked scan

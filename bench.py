@@ -7,11 +7,12 @@ produced back (pages -> Arrow buffers), through the C ABI of libstrawboat_hip.so
 
 Workload at N=1 (BASELINE.json configs[1], "C2"): columns of 1 M-row nullable Float64,
 64 Ki-row pages, value = float(k) with k piecewise constant (run length ~ Geometric(mean 32),
-k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (default 256 =
-256 M rows, 2.08 GB of Arrow bytes, 4096 pages): far beyond the 256 MB Infinity Cache
+k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (default 512 =
+512 M rows, 4.16 GB of Arrow bytes, 8192 pages): far beyond the 256 MB Infinity Cache
 (SURVEY.md §8d), and enough pages that the one-workgroup-per-page kernels run several rounds per
 CU instead of exactly one (with 64 columns = 1024 pages = 4 per CU every phase of every workgroup
-runs in lockstep and the fixed ~0.1 ms of small kernels and launch gaps weighs 20 %).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
+runs in lockstep and the fixed ~0.15 ms of small kernels and launch gaps weighs 20 %; at 256 columns it
+still weighs 10 %, at 512 columns 6 %).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
 page is chosen on the device by the reference's selector (it picks RLE for this data: sampled
 ratio ~14 vs Dict 7.6 vs Patas < 4; the CPU oracle agrees, tests/test_oracle_golden.py).  Nothing is in
 forbidden_compressions: every codec of the reference is a candidate, as with its default options.
@@ -55,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--columns", type=int, default=256, help="1 M-row columns per GPU in one batch")
+    ap.add_argument("--columns", type=int, default=512, help="1 M-row columns per GPU in one batch")
     ap.add_argument("--codec", default="adaptive", choices=["adaptive", "rle", "none", "dict"],
                     help="adaptive = default_compress_ratio 2.0, codec chosen per page on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -49,8 +49,18 @@ def physical_type(dt):
 
 
 def _is_list(dt):
+    """List, LargeList and Map: a Map is a list of a non-nullable `entries` struct (arrow2 to_nested treats
+    DataType::Map like List, src/read/array/map.rs rebuilds it from the same offsets)"""
     t = _pa().types
-    return t.is_list(dt) or t.is_large_list(dt)
+    return t.is_list(dt) or t.is_large_list(dt) or t.is_map(dt)
+
+
+def _value_field(dt):
+    """the child field of a list-like type"""
+    pa = _pa()
+    if pa.types.is_map(dt):
+        return pa.field("entries", pa.struct([dt.key_field, dt.item_field]), nullable=False)
+    return dt.value_field
 
 
 def _buf(b, start=0, length=None):
@@ -87,7 +97,7 @@ def to_leaves(field, arr, chain=None) -> List[_Leaf]:
             offs = offs - offs[0]
         chain.append(dict(kind=NE.LARGE_LIST if w == 8 else NE.LIST, is_optional=field.nullable, length=n,
                           validity=validity, validity_off=off, offsets=np.ascontiguousarray(offs)))
-        return to_leaves(dt.value_field, child.slice(0, int(offs[-1]) if n else 0), chain)
+        return to_leaves(_value_field(dt), child.slice(0, int(offs[-1]) if n else 0), chain)
     if pa.types.is_struct(dt):
         chain.append(dict(kind=NE.STRUCT, is_optional=field.nullable, length=n, validity=validity, validity_off=off,
                           offsets=None))
@@ -267,7 +277,7 @@ def _leaf_fields(field, chain=None):
     dt = field.type
     if _is_list(dt):
         chain.append((NE.LARGE_LIST if pa.types.is_large_list(dt) else NE.LIST, field.nullable))
-        return _leaf_fields(dt.value_field, chain)
+        return _leaf_fields(_value_field(dt), chain)
     if pa.types.is_struct(dt):
         chain.append((NE.STRUCT, field.nullable))
         out = []
@@ -307,7 +317,7 @@ def _assemble(field, leaves, depth):
     pa = _pa()
     dt = field.type
     if _is_list(dt):
-        child, st = _assemble(dt.value_field, leaves, depth + 1)
+        child, st = _assemble(_value_field(dt), leaves, depth + 1)
         n = st.lengths[depth]
         offs = st.offsets_numpy(depth)
         offs = offs.astype(np.int64 if pa.types.is_large_list(dt) else np.int32)

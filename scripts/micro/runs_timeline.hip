@@ -50,6 +50,15 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> t(4096);
     hipMemcpy(t.data(), tl, 8 * 4096, hipMemcpyDeviceToHost);
     printf("  page loop %llu ticks, decide %llu ticks (100 MHz ticks: x10 ns)\n", t[512 + 1] - t[512 + 0], t[512 + 10] - t[512 + 1]);
+    {
+        const char* sn[11] = {"loop start", "loop end", "reduce", "OneValue", "Freq", "Dict", "Patas", "RLE", "-", "-", "end"};
+        for (int p = 2; p <= 10; p++) {
+            if (!t[512 + p]) continue;
+            int q = p - 1;
+            while (q > 1 && !t[512 + q]) q--;
+            printf("    decide: %-10s +%llu\n", sn[p], t[512 + p] - t[512 + q]);
+        }
+    }
     const char* nm[11] = {"top", "loads+compare", "barrier A", "run list", "barrier B", "stats", "fv+ballots", "barrier 1", "carries", "barrier 2", "records"};
     for (int p = 1; p <= 10; p++) printf("  %-14s +%llu\n", nm[p], t[600 + p] - t[600 + p - 1]);
     return 0;

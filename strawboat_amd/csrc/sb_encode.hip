@@ -3474,9 +3474,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
 }
 
 // pages with codec None: (page, tile) parallel plain copies
-__global__ void __launch_bounds__(WG) k_enc_emit_tiles(EncodeArgs a) {
-    const uint32_t page = blockIdx.x + a.page_base;
-    const uint32_t tile = blockIdx.y;
+__device__ void emit_tile(const EncodeArgs& a, uint32_t page, uint32_t tile) {
     const EncPage p = get_page(a, page);
     if (p.codec < CODEC_ON_DEVICE) return;  // table entry not in use
     const EncCol c = get_col(a, p.col);
@@ -3556,6 +3554,22 @@ __global__ void __launch_bounds__(WG) k_enc_emit_tiles(EncodeArgs a) {
             EncOut o{pos + 9 + N * w, 0, slot, SB_CODEC_NONE, 0};
             a.outs[page] = o;
         }
+    }
+}
+
+// grid = (pages, T): a workgroup takes the tiles blockIdx.y, blockIdx.y + T, ... of its page.  With the codec
+// known on the host T = tiles per page (every tile its own workgroup); in adaptive mode, where few pages stay
+// plain, T = 1: one workgroup per page finds out that there is nothing to do, not one per tile.
+__global__ void __launch_bounds__(WG) k_enc_emit_tiles(EncodeArgs a, uint32_t max_tiles) {
+    const uint32_t page = blockIdx.x + a.page_base;
+    if (gridDim.y < max_tiles) {  // (adaptive) look at the page before walking its tiles
+        const EncPage p = get_page(a, page);
+        if (p.codec < CODEC_ON_DEVICE) return;
+        if (get_col(a, p.col).ptype != SB_TYPE_NULL && codec_of(a, p, page) != SB_CODEC_NONE) return;
+    }
+    for (uint32_t tile = blockIdx.y; tile < max_tiles; tile += gridDim.y) {
+        emit_tile(a, page, tile);
+        __syncthreads();
     }
 }
 
@@ -3990,7 +4004,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const bool basic_comp = dc == SB_CODEC_LZ4 || dc == SB_CODEC_ZSTD || dc == SB_CODEC_SNAPPY;
         if (nested ? (wave_adaptive ? dc == SB_CODEC_NONE : wave_codec == SB_CODEC_NONE) : any_tiles) {
             KScope k(ctx, K_ENC_TILES);
-            k_enc_emit_tiles<<<dim3((uint32_t)P, (uint32_t)max_tiles), WG, 0, s>>>(aa);
+            k_enc_emit_tiles<<<dim3((uint32_t)P, wave_adaptive ? 1u : (uint32_t)max_tiles), WG, 0, s>>>(aa, (uint32_t)max_tiles);
         }
         if (nested ? (wave_adaptive ? basic_comp : (wave_codec >= 1 && wave_codec <= 3)) : any_lz4) {
             KScope k(ctx, K_ENC_LZ4);

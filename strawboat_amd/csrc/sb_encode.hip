@@ -3607,10 +3607,12 @@ __global__ void __launch_bounds__(WG) k_enc_compact(EncodeArgs a) {
     if (blockIdx.y == 0 && p.head_bytes && c.heads)  // the page's head (nested level section)
         wg_copy(c.out + o.out_off - p.head_bytes, c.heads + p.head_off, p.head_bytes);
     if (p.direct) return;
-    const uint64_t b0 = (uint64_t)blockIdx.y * COMPACT_CHUNK;
-    if (b0 >= o.length) return;
-    const uint64_t n = min((uint64_t)COMPACT_CHUNK, o.length - b0);
-    wg_copy(c.out + o.out_off + b0, o.slot + b0, n);
+    // gridDim.y workgroups share the page's 64 KiB chunks (the grid is sized for the worst-case slot; most pages
+    // are far smaller, so the host keeps gridDim.y small when there are many pages)
+    for (uint64_t b0 = (uint64_t)blockIdx.y * COMPACT_CHUNK; b0 < o.length; b0 += (uint64_t)gridDim.y * COMPACT_CHUNK) {
+        const uint64_t n = min((uint64_t)COMPACT_CHUNK, o.length - b0);
+        wg_copy(c.out + o.out_off + b0, o.slot + b0, n);
+    }
 }
 
 }  // namespace sb
@@ -4076,7 +4078,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     }
     if (any_compact) {
         KScope k(ctx, K_ENC_COMPACT);
-        k_enc_compact<<<dim3((uint32_t)P, (uint32_t)max_chunks), WG, 0, s>>>(a);
+        k_enc_compact<<<dim3((uint32_t)P, (uint32_t)std::min<uint64_t>(max_chunks, std::max<uint64_t>(1, 8192 / P))), WG, 0, s>>>(a);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return check_hip(ctx, e, "encode launch");

@@ -983,153 +983,8 @@ __device__ uint64_t enc_bp(GetU32 getv, uint64_t N, bool delta, uint8_t* dst, ui
 // ------------------------------------------------------------------------------ LZ4 block encode
 // Byte-exact restatement of LZ4_compress_default (liblz4 1.9.x: greedy parse, one hash probe per
 // position, skip acceleration 1) — what lz4::block::compress_to_buffer(src, None, false, dst) runs
-// (reference call site src/compression/basic.rs:108-120).  The parse is inherently serial (every
-// probe sees the table as left by all earlier positions), so one lane walks the block; the 16 KB
-// hash table lives in LDS, and a CU runs as many blocks as its LDS holds.  Parallelism comes from
-// the number of blocks (pages x sub-blocks) in flight, not from within a block.
-__device__ __forceinline__ uint32_t lz4_hash(const uint8_t* p, bool by_u16) {
-    if (by_u16) return (ldu32(p) * 2654435761u) >> (32 - 13);
-    return (uint32_t)(((ldu64(p) << 24) * 889523592379ull) >> (64 - 12));
-}
-__device__ __forceinline__ uint32_t lz4_tab_get(const void* tab, uint32_t h, bool by_u16) {
-    return by_u16 ? (uint32_t)((const uint16_t*)tab)[h] : ((const uint32_t*)tab)[h];
-}
-__device__ __forceinline__ void lz4_tab_put(void* tab, uint32_t h, uint32_t v, bool by_u16) {
-    if (by_u16)
-        ((uint16_t*)tab)[h] = (uint16_t)v;
-    else
-        ((uint32_t*)tab)[h] = v;
-}
-__device__ __forceinline__ uint32_t lz4_count(const uint8_t* ip, const uint8_t* match, const uint8_t* limit) {
-    const uint8_t* s = ip;
-    while (ip + 8 <= limit) {
-        const uint64_t d = ldu64(ip) ^ ldu64(match);
-        if (d) return (uint32_t)(ip - s) + (uint32_t)((__ffsll((long long)d) - 1) >> 3);
-        ip += 8;
-        match += 8;
-    }
-    while (ip < limit && *ip == *match) {
-        ip++;
-        match++;
-    }
-    return (uint32_t)(ip - s);
-}
-// executed by ONE lane; `tab` = 16 KB of LDS (zeroed by the caller)
-__device__ uint32_t lz4_compress_lane(const uint8_t* src, uint32_t n, uint8_t* dst, void* tab) {
-    const bool by_u16 = n < 65536u + 11u;  // LZ4_64Klimit
-    const uint8_t* ip = src;
-    const uint8_t* anchor = src;
-    const uint8_t* iend = src + n;
-    const uint8_t* mflimitPlusOne = iend - 12 + 1;
-    const uint8_t* matchlimit = iend - 5;
-    uint8_t* op = dst;
-    if (n >= 13) {
-        lz4_tab_put(tab, lz4_hash(ip, by_u16), 0, by_u16);
-        ip++;
-        uint32_t forwardH = lz4_hash(ip, by_u16);
-        for (;;) {
-            const uint8_t* match;
-            uint8_t* token;
-            {
-                const uint8_t* forwardIp = ip;
-                int step = 1, searchMatchNb = 1 << 6;
-                bool done = false;
-                for (;;) {
-                    const uint32_t h = forwardH;
-                    const uint32_t current = (uint32_t)(forwardIp - src);
-                    const uint32_t matchIndex = lz4_tab_get(tab, h, by_u16);
-                    ip = forwardIp;
-                    forwardIp += step;
-                    step = (searchMatchNb++ >> 6);
-                    if (forwardIp > mflimitPlusOne) {
-                        done = true;
-                        break;
-                    }
-                    match = src + matchIndex;
-                    forwardH = lz4_hash(forwardIp, by_u16);
-                    lz4_tab_put(tab, h, current, by_u16);
-                    if (!by_u16 && matchIndex + 65535u < current) continue;
-                    if (ldu32(match) == ldu32(ip)) break;
-                }
-                if (done) break;
-            }
-            while (ip > anchor && match > src && ip[-1] == match[-1]) {
-                ip--;
-                match--;
-            }
-            {
-                const uint32_t litLength = (uint32_t)(ip - anchor);
-                token = op++;
-                if (litLength >= 15) {
-                    int len = (int)(litLength - 15);
-                    *token = 15 << 4;
-                    for (; len >= 255; len -= 255) *op++ = 255;
-                    *op++ = (uint8_t)len;
-                } else {
-                    *token = (uint8_t)(litLength << 4);
-                }
-                uint32_t k = 0;
-                for (; k + 8 <= litLength; k += 8) stu64(op + k, ldu64(anchor + k));
-                for (; k < litLength; k++) op[k] = anchor[k];
-                op += litLength;
-            }
-            bool end_of_chunk = false;
-            for (;;) {
-                const uint32_t off = (uint32_t)(ip - match);
-                op[0] = (uint8_t)off;
-                op[1] = (uint8_t)(off >> 8);
-                op += 2;
-                uint32_t matchCode = lz4_count(ip + 4, match + 4, matchlimit);
-                ip += matchCode + 4;
-                if (matchCode >= 15) {
-                    *token += 15;
-                    matchCode -= 15;
-                    while (matchCode >= 255) {
-                        *op++ = 255;
-                        matchCode -= 255;
-                    }
-                    *op++ = (uint8_t)matchCode;
-                } else {
-                    *token += (uint8_t)matchCode;
-                }
-                anchor = ip;
-                if (ip >= mflimitPlusOne) {
-                    end_of_chunk = true;
-                    break;
-                }
-                lz4_tab_put(tab, lz4_hash(ip - 2, by_u16), (uint32_t)(ip - 2 - src), by_u16);
-                const uint32_t h = lz4_hash(ip, by_u16);
-                const uint32_t current = (uint32_t)(ip - src);
-                const uint32_t matchIndex = lz4_tab_get(tab, h, by_u16);
-                match = src + matchIndex;
-                lz4_tab_put(tab, h, current, by_u16);
-                if ((by_u16 || matchIndex + 65535u >= current) && ldu32(match) == ldu32(ip)) {
-                    token = op++;
-                    *token = 0;
-                    continue;
-                }
-                break;
-            }
-            if (end_of_chunk) break;
-            forwardH = lz4_hash(++ip, by_u16);
-        }
-    }
-    {
-        const uint32_t lastRun = (uint32_t)(iend - anchor);
-        if (lastRun >= 15) {
-            uint32_t acc = lastRun - 15;
-            *op++ = 15 << 4;
-            for (; acc >= 255; acc -= 255) *op++ = 255;
-            *op++ = (uint8_t)acc;
-        } else {
-            *op++ = (uint8_t)(lastRun << 4);
-        }
-        for (uint32_t k = 0; k < lastRun; k++) op[k] = anchor[k];
-        op += lastRun;
-    }
-    return (uint32_t)(op - dst);
-}
-// One wave compresses one block with the SAME parse, 64 probe positions at a time.
+// (reference call site src/compression/basic.rs:108-120).  The 16 KB hash table lives in LDS.
+// One wave compresses one block with that parse, 64 probe positions at a time.
 // The greedy search examines positions q_0, q_1, ... whose spacing follows the skip schedule
 // (step = searchMatchNb++ >> 6) until one of them finds a 4-byte match through the hash table; every
 // examined position is inserted.  Nothing in that depends on the outcome of earlier probes of the same

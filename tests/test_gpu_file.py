@@ -42,10 +42,9 @@ def test_table_round_trip(gpu_ctx, tmp_path, opt):
     from strawboat_amd.types import Compression as C
     t = make_table(5000)
     wo = dict(none=WriteOptions(max_page_size=1000),
-              adaptive=WriteOptions(max_page_size=1024, default_compress_ratio=2.0, forbidden_compressions=[C.FREQ]),
+              adaptive=WriteOptions(max_page_size=1024, default_compress_ratio=2.0),
               lz4=WriteOptions(max_page_size=2048, default_compression=C.LZ4),
-              zstd_adaptive=WriteOptions(max_page_size=4096, default_compression=C.ZSTD, default_compress_ratio=1.5,
-                                         forbidden_compressions=[C.FREQ]))[opt]
+              zstd_adaptive=WriteOptions(max_page_size=4096, default_compression=C.ZSTD, default_compress_ratio=1.5))[opt]
     path = tmp_path / "t.sb"
     with F.NativeWriter(gpu_ctx, path, t.schema, wo) as w:
         w.start()

@@ -53,3 +53,10 @@ bench("i32 BP", i32, max_page_size=65536, force_codec=S.BITPACK)
 i32s = gen.prim(S.T_I32, 128 * 7808, uniq=1 << 20, sorted_=True)
 bench("i32 DeltaBP", i32s, max_page_size=65536, force_codec=S.DELTABP)
 bench("C2 f64 LZ4", c2, reps=3, max_page_size=65536, default_compression=S.LZ4)
+bench("C2 f64 Zstd (libzstd level 3)", c2, reps=3, max_page_size=65536, default_compression=S.ZSTD)
+bench("C2 f64 Snappy", c2, reps=3, max_page_size=65536, default_compression=S.SNAPPY)
+rnd = gen.prim(S.T_I64, ROWS, uniq=1 << 40)
+bench("random i64 Zstd", rnd, reps=3, max_page_size=65536, default_compression=S.ZSTD)
+txt = gen.binary(ROWS, uniq=5000, zipf=1.3, maxlen=24)
+bench("utf8 zipf Zstd", txt, reps=3, max_page_size=65536, default_compression=S.ZSTD)
+bench("utf8 zipf LZ4", txt, reps=3, max_page_size=65536, default_compression=S.LZ4)

@@ -2782,6 +2782,54 @@ __device__ void freq_roaring(uint64_t N, uint8_t* rb, uint8_t* size_field, uint3
     n_ex_out = n_ex;
 }
 
+// The exact top value of a Freq page that has no majority value (only reachable with force_codec; the vote above
+// covers every page choose_compressor can send here): first-occurrence dictionary ids for ALL slots (null slots
+// count, integer/mod.rs:211), a count per id, arg-max with ties going to the earliest first occurrence (the
+// oracle's deterministic stand-in for the reference's HashMap order).  Returns the row of the top value's first
+// occurrence, EMPTY if the page has no Dict work area.
+template <int W>
+struct FreqKeys {  // every slot carries a key; equality of the statistics (canonical float keys)
+    const uint8_t* vals;
+    uint32_t nk;
+    __device__ __forceinline__ bool keyed(uint64_t) const { return true; }
+    __device__ __forceinline__ Val<W> key(uint64_t i) const { return stat_key<W>(ld_val<W>(vals + i * W), nk); }
+    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return stat_hash<W>(key(i)); }
+    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return bits_eq<W>(key(a), key(b)); }
+};
+template <class KeyOps>
+__device__ uint32_t freq_exact_top(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t aux_words, uint32_t* sA, uint32_t* sB, uint32_t* s_w,
+                                   Status* st, uint32_t page) {
+    const int t = threadIdx.x;
+    if (!aux || !aux_words) return EMPTY;
+    uint32_t *idx, *firsts;
+    const uint32_t D = dict_build(ko, N, aux, aux_words, &idx, &firsts, sA, sB, s_w, st, page);
+    if (D == EMPTY) return EMPTY;
+    uint64_t M = 64;
+    while (M < 2 * N) M <<= 1;
+    uint32_t* cnt = aux + M;  // the builder's F array (one word per row) is free again
+    for (uint32_t i = t; i < D; i += WG) cnt[i] = 0;
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    for (uint64_t i = t; i < N; i += WG) atomicAdd(&cnt[idx[i]], 1u);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    unsigned long long best = 0;  // count << 32 | ~id: highest count, then the smallest id (= earliest first occurrence)
+    for (uint32_t i = t; i < D; i += WG) {
+        const unsigned long long c = ((unsigned long long)table_load(&cnt[i]) << 32) | (0xFFFFFFFFu - i);
+        if (c > best) best = c;
+    }
+    unsigned long long* red = (unsigned long long*)sA;
+    red[t] = best;
+    __syncthreads();
+    for (int stride = WG / 2; stride > 0; stride >>= 1) {
+        if (t < stride && red[t + stride] > red[t]) red[t] = red[t + stride];
+        __syncthreads();
+    }
+    const uint32_t id = 0xFFFFFFFFu - (uint32_t)red[0];
+    __syncthreads();
+    return firsts[id];
+}
+
 template <int W>
 __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pages_rw, const EncCol& c, const EncPage& p,
                                uint32_t page, uint32_t* lds) {
@@ -2873,11 +2921,20 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
         __syncthreads();
         if (first != ~0ull) atomicMin(&s_first[0], first);
         __syncthreads();
-        if ((uint64_t)mc * 2 <= N) {  // no majority: the exact arg-max needs full counts (host-forced Freq only)
-            if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
-            return;
+        uint64_t top_row = s_first[0];
+        __syncthreads();
+        if ((uint64_t)mc * 2 <= N) {  // no majority (host-forced Freq only): exact counts
+            uint32_t* sB = s_card + FREQ_MAX_CONTAINERS;  // a second tile array over the vote scratch (no longer needed)
+            const uint32_t r = freq_exact_top(FreqKeys<W>{vals, c.nk}, N, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr,
+                                              p.aux_bytes / 4, sA, sB, s_w, a.status, page);
+            if (r == EMPTY) {
+                if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
+                return;
+            }
+            top_row = r;
+            topk = keyof(top_row);
         }
-        top = ld_val<W>(vals + s_first[0] * W);
+        top = ld_val<W>(vals + top_row * W);
         __syncthreads();
     }
     auto is_exc = [&](uint64_t i) { return vv.get(i) && (top_is_null || !bits_eq<W>(keyof(i), topk)); };
@@ -3007,9 +3064,16 @@ __device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPag
                 if (i < N && bk.eq(cand, i)) mine++;
             }
         const uint32_t mc = wg_sum32(mine, s_w);
-        if ((uint64_t)mc * 2 <= N) {  // no majority: the exact arg-max needs full counts (host-forced Freq only)
-            if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
-            return;
+        if ((uint64_t)mc * 2 <= N) {  // no majority (host-forced Freq only): exact counts over all slots
+            uint32_t* sB = s_card + FREQ_MAX_CONTAINERS;
+            const BinKeys<O> all{c.offsets + p.row0 * sizeof(O), c.values, ValidView{nullptr, 0}};
+            const uint32_t r = freq_exact_top(all, N, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, p.aux_bytes / 4, sA, sB,
+                                              s_w, a.status, page);
+            if (r == EMPTY) {
+                if (t == 0) raise(a.status, SB_ERR_NYI, page, 541);
+                return;
+            }
+            cand = r;
         }
         tb = bk.beg(cand);
         te = bk.beg((uint64_t)cand + 1);
@@ -3060,7 +3124,9 @@ __device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPag
 }
 
 __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a, EncCol* cols_rw, EncPage* pages_rw) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[SIDX_WORDS + 8 + FREQ_MAX_CONTAINERS + 4 + WG + 8 + 8 * WG];
+    // tile array | s_w | container counts | vote scratch (a second tile array in the exact-count path)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SIDX_WORDS + 8 + FREQ_MAX_CONTAINERS + SIDX_WORDS + 16];
+    static_assert(SIDX_WORDS + 16 >= 4 + WG + 8 + 8 * WG, "vote scratch");
     if (*a.freq_count == 0) return;
   for (uint32_t page = blockIdx.x; page < a.n_pages; page += gridDim.x) {
     __syncthreads();
@@ -3719,7 +3785,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     scratch_off += align_up(slot_fixed_bytes(c.physical_type, 0, N), 16);
                 }
             }
-            if (codec == SB_CODEC_DICT || (adaptive && !((forb >> SB_CODEC_DICT) & 1) && c.physical_type != SB_TYPE_BOOLEAN &&
+            if (codec == SB_CODEC_DICT || codec == SB_CODEC_FREQ ||  // (forced Freq: exact counts when no value has a majority)
+                (adaptive && !((forb >> SB_CODEC_DICT) & 1) && c.physical_type != SB_TYPE_BOOLEAN &&
                                            c.physical_type != SB_TYPE_NULL)) {
                 uint64_t M = 64;
                 while (M < 2 * N) M <<= 1;

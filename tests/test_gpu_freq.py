@@ -176,3 +176,22 @@ def test_wide_integer_freq(gpu_ctx, ptype):
         enc_check(gpu_ctx, col, max_page_size=ps, force_codec=S.FREQ)
     seen = set(sel_check(gpu_ctx, sparse_wide(ptype, 128 * 300, 0.03, 74), max_page_size=128 * 100, ratio=2.0, forbidden=()).tolist())
     assert S.FREQ in seen, seen
+
+
+def test_forced_freq_without_a_majority_value(gpu_ctx):
+    """force_codec = Freq on pages where no value holds half of the rows (unreachable for choose_compressor): the
+    top value is the exact arg-max of the counts over all slots, ties going to the earliest first occurrence"""
+    from tests.test_gpu_encode import check as enc_check
+    for ptype in (S.T_U8, S.T_I16, S.T_I32, S.T_I64, S.T_F32, S.T_F64, S.T_I128, S.T_I256):
+        enc_check(gpu_ctx, gen.prim(ptype, 9000, uniq=7, null_density=0.2, seed=3), max_page_size=3000, force_codec=S.FREQ)
+        enc_check(gpu_ctx, gen.prim(ptype, 5000, uniq=100 if ptype == S.T_U8 else 3000, seed=4), max_page_size=2500, force_codec=S.FREQ)
+    # ties: every value exactly twice -> the value that occurs first wins
+    v = np.tile(np.arange(500, dtype=np.int64), 2)[np.random.default_rng(5).permutation(1000)]
+    enc_check(gpu_ctx, dict(ptype=S.T_I64, nullable=False, rows=1000, values=v, validity=None, offsets=None), force_codec=S.FREQ)
+    # floats: -0.0 / +0.0 and NaNs with different payloads count as one value
+    f = np.array([0.0, -0.0, 1.0, np.nan, 2.0, -0.0] * 200, np.float64)
+    f.view(np.uint64)[3::12] = 0xFFF8000000000001
+    enc_check(gpu_ctx, dict(ptype=S.T_F64, nullable=False, rows=f.size, values=f, validity=None, offsets=None), force_codec=S.FREQ)
+    for large in (False, True):
+        enc_check(gpu_ctx, gen.binary(8192, uniq=40, seed=5, large=large), max_page_size=4096, force_codec=S.FREQ)
+        enc_check(gpu_ctx, gen.binary(6000, uniq=9, null_density=0.3, seed=6, large=large), max_page_size=2000, force_codec=S.FREQ)

@@ -79,12 +79,11 @@ def test_binary(gpu_ctx, large):
 
 
 def test_unsupported_choice_is_loud(gpu_ctx):
-    # a forced Freq page without a majority value has no device encoder (the exact arg-max needs full counts):
-    # the call fails loudly (NYI) instead of writing something else
+    # a codec the column family does not have fails loudly instead of writing something else
     from strawboat_amd._native import NativeError
     with pytest.raises(NativeError) as e:
-        gpu_encode(gpu_ctx, gen.binary(8192, uniq=40, seed=5), force_codec=S.FREQ)
-    assert e.value.code == -4
+        gpu_encode(gpu_ctx, gen.boolean(8192, seed=5), force_codec=S.FREQ)   # "Unknown compression codec Freq for boolean"
+    assert e.value.code == -1
 
 
 def test_rle_chosen_after_the_speculation_stopped(gpu_ctx):

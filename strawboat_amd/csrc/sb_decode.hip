@@ -265,8 +265,56 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             if (N % 128 != 0) FAIL(SB_ERR_OUT_OF_SPEC, 29);
         } else if (ic == SB_CODEC_ONEVALUE) {
             if (d.icsize < 4) FAIL(SB_ERR_IO, 30);
+        } else if (ic == SB_CODEC_FREQ) {
+            // The u32 indices as a Freq block: top[4] | u32 rb_size | Roaring | BLOCK<u32 exceptions> (integer/freq.rs:71-83).
+            // The reference writes this for a column that is mostly one value but may not use Freq itself (integers whose
+            // maximum is below 256, freq.rs:146).  k_plan materialises the N indices in the inflate area; the exceptions
+            // block cannot be Dict or Freq again (both forbidden by then) and is taken as plain / inflated / one-value.
+            if (d.icsize < 8) FAIL(SB_ERR_IO, 45);
+            const uint8_t* fend = d.ibody + d.icsize;
+            const uint32_t rb_size = ldu32(d.ibody + 4);
+            const uint8_t* rb = d.ibody + 8;
+            if ((uint64_t)(fend - rb) < (uint64_t)rb_size + 9) FAIL(SB_ERR_IO, 46);
+            if (rb_size < 8) FAIL(SB_ERR_EXTERNAL, 47);
+            const uint32_t cookie = ldu32(rb);
+            uint32_t nc, hp;
+            if ((cookie & 0xFFFF) == 12347) {
+                nc = (cookie >> 16) + 1;
+                hp = 4 + (nc + 7) / 8;
+            } else if (cookie == 12346) {
+                nc = ldu32(rb + 4);
+                hp = 8;
+            } else {
+                FAIL(SB_ERR_EXTERNAL, 48);
+            }
+            if (nc > 65536 || (uint64_t)hp + 4ull * nc > rb_size) FAIL(SB_ERR_EXTERNAL, 49);
+            uint64_t card = 0;
+            for (uint32_t k = 0; k < nc; k++) card += (uint64_t)ldu16(rb + hp + 4 * k + 2) + 1;
+            if (card > N) FAIL(SB_ERR_OUT_OF_SPEC, 50);
+            const uint8_t* eh = rb + rb_size;
+            const uint32_t ec = eh[0], ecsize = ldu32(eh + 1);
+            const uint8_t* ebody = eh + 9;
+            if ((uint64_t)(fend - ebody) < ecsize) FAIL(SB_ERR_IO, 51);
+            d.vbody = rb;
+            d.vcsize = rb_size;
+            d.vusize = (uint32_t)card;
+            d.pad = (uint8_t)ec;
+            if (ec == SB_CODEC_NONE) {
+                if (ecsize != card * 4) FAIL(SB_ERR_OUT_OF_SPEC, 52);
+                d.src = ebody;
+            } else if (is_basic(ec)) {
+                uint8_t* exd = infl + ((N * 4 + 15) & ~(uint64_t)15);
+                push_job(a.jobs_a, a.job_counts, ebody, ecsize, exd, (uint32_t)(card * 4), ec, p);
+                d.src = exd;
+            } else if (ec == SB_CODEC_ONEVALUE) {
+                if (ecsize < 4) FAIL(SB_ERR_IO, 53);
+                d.src = ebody;
+            } else {
+                FAIL(ec == SB_CODEC_RLE || ec == SB_CODEC_BITPACKING || ec == SB_CODEC_DELTA_BITPACKING ? SB_ERR_NYI : SB_ERR_OUT_OF_SPEC, 54);
+            }
+            d.isrc = infl;
         } else if (ic != SB_CODEC_RLE) {
-            FAIL(ic == SB_CODEC_FREQ || ic == SB_CODEC_DICT ? SB_ERR_NYI : SB_ERR_OUT_OF_SPEC, 31);
+            FAIL(SB_ERR_OUT_OF_SPEC, 31);  // Dict inside Dict is never written (integer/dict.rs:60-62)
         }
         const uint8_t* q = d.ibody + d.icsize;
         d.dict_n = ldu32(q);
@@ -1058,7 +1106,32 @@ __global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
             changed = true;
         }
     } else if (d.codec == SB_CODEC_DICT) {
-        const uint32_t ic = d.icodec;
+        uint32_t ic = d.icodec;
+        if (ic == SB_CODEC_FREQ) {  // indices = top everywhere, exceptions scattered by the Roaring bitmap (see k_parse)
+            uint32_t* idx = (uint32_t*)(a.scratch + t.infl_off);
+            const uint32_t top = ldu32(d.ibody);
+            const uint32_t E = d.vusize;
+            const uint8_t* ex = d.src;
+            const bool one = d.pad == SB_CODEC_ONEVALUE;
+            for (uint64_t i = threadIdx.x; i < N; i += WG) idx[i] = top;
+            __syncthreads();
+            const uint64_t cum = roaring_walk(d.vbody, d.vcsize, s_a, s_w, [&](uint64_t row, uint64_t k) {
+                if (row >= N || k >= E) {
+                    raise(a.status, SB_ERR_OUT_OF_SPEC, p, 226);  // exception index out of bounds
+                    return;
+                }
+                idx[row] = one ? ldu32(ex) : ldu32(ex + 4 * k);
+            });
+            __syncthreads();
+            if (cum != E) {
+                if (threadIdx.x == 0) raise(a.status, SB_ERR_EXTERNAL, p, 225);  // malformed RoaringBitmap
+                d.ok = 0;
+            }
+            d.icodec = SB_CODEC_NONE;
+            d.isrc = (const uint8_t*)idx;
+            ic = SB_CODEC_NONE;
+            changed = true;
+        }
         if (ic == SB_CODEC_RLE) {
             uint32_t R = plan_rle(d.ibody, (uint32_t)(page_end - d.ibody), 8, N, aux, aux_cap, s_a, s_w64, a.status, p);
             if (R == 0xFFFFFFFFu) d.ok = 0;

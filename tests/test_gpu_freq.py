@@ -195,3 +195,31 @@ def test_forced_freq_without_a_majority_value(gpu_ctx):
     for large in (False, True):
         enc_check(gpu_ctx, gen.binary(8192, uniq=40, seed=5, large=large), max_page_size=4096, force_codec=S.FREQ)
         enc_check(gpu_ctx, gen.binary(6000, uniq=9, null_density=0.3, seed=6, large=large), max_page_size=2000, force_codec=S.FREQ)
+
+
+def test_dict_pages_with_freq_indices(gpu_ctx):
+    """integers that are mostly one value but whose maximum is below 256 may not use Freq themselves (freq.rs:146):
+    choose_compressor takes Dict, and the u32 indices — mostly index 0, more than 256 distinct — become a nested
+    Freq block.  The reference writes such pages; they decode on the device"""
+    rng = np.random.default_rng(1)
+    for ptype, npt in ((S.T_I64, np.int64), (S.T_I32, np.int32)):
+        n = 3 * 8192
+        v = np.full(n, -5, npt)
+        exc = rng.random(n) < 0.06
+        v[exc] = -rng.integers(10, 2000, int(exc.sum())).astype(npt)
+        col = dict(ptype=ptype, nullable=False, rows=n, values=v, validity=None, offsets=None)
+        seen = set()
+        for opt in (dict(ratio=2.0), dict(ratio=2.0, default_compression=S.LZ4), dict(ratio=2.0, default_compression=S.ZSTD)):
+            pages, metas = check(gpu_ctx, col, max_page_size=8192, forbidden=(S.RLE,), **opt)
+            codecs, inner = S.stat_column(ptype, False, pages, metas)
+            seen |= set(zip(codecs.tolist(), inner.tolist()))
+        assert (S.DICT, S.FREQ) in seen, seen
+    # one distinct exception index -> the exceptions block is OneValue: forced Dict over { -5 x many, 300 other values once
+    # each at the start (ids 1..300), then one value repeated }
+    v = np.concatenate([[-5], -np.arange(10, 310), np.full(8192 - 301, -5)]).astype(np.int64)
+    v[400::97] = -309
+    check(gpu_ctx, dict(ptype=S.T_I64, nullable=False, rows=v.size, values=v, validity=None, offsets=None), force_codec=S.DICT, ratio=1.5)
+    # binary: forced Dict, nested selection on the indices
+    b = sparse_bin(20_000, 0.05, 91, exc_uniq=600)
+    pages, metas = check(gpu_ctx, b, max_page_size=20000, force_codec=S.DICT, ratio=2.0, forbidden=(S.RLE,))
+    assert S.FREQ in set(S.stat_column(b["ptype"], b["nullable"], pages, metas)[1].tolist())

@@ -121,6 +121,7 @@ __device__ __forceinline__ bool has_device_encoder(uint32_t codec) {
 }
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr uint64_t DICT_FREQ_PENDING = ~0ull;  // emit_prim_page<Dict>: the page waits for the Freq kernels (EncOut.pad = 3)
 constexpr uint32_t COMPACT_CHUNK = 64 * 1024;
 
 #ifdef SB_RLE_TIMELINE  // scripts/micro/rle_timeline.hip: s_memtime stamps of one workgroup's phases
@@ -2232,6 +2233,24 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
                                          ValidView{nullptr, 0}, N, NK_UNSIGNED, so, sc);
             __syncthreads();
         }
+        if (ic == SB_CODEC_FREQ) {
+            // u32 indices that are mostly one value (the column may not use Freq itself: integers with a maximum
+            // below 256, freq.rs:146): the index block is a Freq block with its own nested exceptions block.  The
+            // Freq kernels finish the page (k_enc_freq_prep -> k_enc_nested<4> -> k_enc_freq_finish); this kernel
+            // leaves them the index array and the first rows of the dictionary entries.
+            if (p.vaux_bytes < 32 || !p.vslot_off) {
+                if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 502);
+                return 0;
+            }
+            if (threadIdx.x == 0) {
+                unsigned long long* rec = (unsigned long long*)(a.scratch + p.vaux_off);
+                rec[0] = (unsigned long long)(uintptr_t)idx;
+                rec[1] = (unsigned long long)(uintptr_t)firsts;
+                rec[2] = D;
+                atomicAdd(a.freq_count, 1u);
+            }
+            return DICT_FREQ_PENDING;
+        }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
         if (ib == 0) return 0;
         uint8_t* q = blk + 9 + ib;
@@ -2585,11 +2604,11 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
         blen = emit_prim_page<KIND, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
     if (threadIdx.x == 0) {
         EncOut o;
-        o.length = blen ? pos + blen : 0;
+        o.length = blen == DICT_FREQ_PENDING ? 1 : (blen ? pos + blen : 0);
         o.out_off = 0;
         o.slot = slot;
         o.codec = (uint32_t)CODEC;
-        o.pad = 0;
+        o.pad = blen == DICT_FREQ_PENDING ? 3 : 0;
         a.outs[page] = o;
     }
 }
@@ -2832,7 +2851,10 @@ __device__ uint32_t freq_exact_top(KeyOps ko, uint64_t N, uint32_t* aux, uint64_
 
 template <int W>
 __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pages_rw, const EncCol& c, const EncPage& p,
-                               uint32_t page, uint32_t* lds) {
+                               uint32_t page, uint32_t* lds, uint8_t* dict_slot = nullptr, uint64_t dict_pos = 0,
+                               uint64_t ex_cap = ~0ull) {
+    // dict_slot != nullptr: `c` / `p` describe the u32 index array of a Dict page whose real slot is dict_slot and
+    // whose Dict block starts at dict_pos; the Freq block written here is the index block of that page
     const int t = threadIdx.x, lane = t & 63;
     const uint64_t N = p.rows;
     const uint8_t* vals = c.values + p.row0 * W;
@@ -2942,7 +2964,13 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
     uint32_t rb_size, n_ex;
     if (t == 0) st_val<W>(blk + 9, top);
     freq_roaring(N, blk + 9 + W + 4, blk + 9 + W, sA, s_w, s_card, is_exc,
-                 [&](uint64_t row, uint32_t k) { st_val<W>(ex + (uint64_t)k * W, ld_val<W>(vals + row * W)); }, rb_size, n_ex);
+                 [&](uint64_t row, uint32_t k) {
+                     if (((uint64_t)k + 1) * W <= ex_cap) st_val<W>(ex + (uint64_t)k * W, ld_val<W>(vals + row * W));
+                 }, rb_size, n_ex);
+    if ((uint64_t)n_ex * W > ex_cap) {  // (only a forced nested Freq on data without a dominant index gets here)
+        if (t == 0) raise(a.status, SB_ERR_NYI, page, 546);
+        return;
+    }
     // ---- the virtual page that carries the exceptions through the second wave
     if (t == 0) {
         EncCol vc = c;
@@ -2980,6 +3008,12 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
         o.slot = slot;
         o.codec = SB_CODEC_FREQ;
         o.pad = 0;
+        if (dict_slot) {  // the page stays a Dict page in waiting; its length so far counts from the real slot
+            o.length += dict_pos + 9;
+            o.slot = dict_slot;
+            o.codec = SB_CODEC_DICT;
+            o.pad = 3;
+        }
         a.outs[page] = o;
     }
 }
@@ -3131,7 +3165,36 @@ __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a, EncCol* c
   for (uint32_t page = blockIdx.x; page < a.n_pages; page += gridDim.x) {
     __syncthreads();
     const EncPage p = get_page(a, page);
-    if (codec_of(a, p, page) != SB_CODEC_FREQ) continue;
+    const int32_t pcodec = codec_of(a, p, page);
+    if (pcodec == SB_CODEC_DICT) {  // a Dict page whose u32 indices are to be a Freq block (emit_prim_page<Dict>)
+        const EncOut o0 = a.outs[page];
+        if (o0.codec != SB_CODEC_DICT || o0.pad != 3) continue;
+        const EncCol c = get_col(a, p.col);
+        const unsigned long long* rec = (const unsigned long long*)(a.scratch + p.vaux_off);
+        EncCol ic = c;   // the index array as a column of its own
+        ic.values = (const uint8_t*)(uintptr_t)rec[0];
+        ic.validity = nullptr;
+        ic.validity_bit_offset = 0;
+        ic.nullable = 0;
+        ic.width = 4;
+        ic.ptype = SB_TYPE_UINT32;
+        ic.fkind = 0;
+        ic.nk = NK_UNSIGNED;
+        ic.rows = p.rows;
+        EncPage ip = p;
+        const uint64_t dpos = c.nullable ? def_section_bytes(p.rows) : 0;
+        uint8_t* dslot = page_slot(a, c, p);
+        ip.row0 = 0;
+        ip.direct = 0;
+        ip.slot_off = (uint64_t)(dslot + dpos + 9 - a.scratch);
+        ip.depth = p.depth + 1;                              // compress_integer::<u32> inside Dict (dict.rs:60-62)
+        ip.forb_extra = p.forb_extra | (1u << SB_CODEC_DICT);
+        ip.aux_bytes = 0;
+        ip.vaux_bytes = 0;                                   // (the area holds the record read above)
+        freq_prep_page<4>(a, cols_rw, pages_rw, ic, ip, page, lds, dslot, dpos, p.rows * c.width);
+        continue;
+    }
+    if (pcodec != SB_CODEC_FREQ) continue;
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_NULL || p.rows == 0) {
         if (threadIdx.x == 0) raise(a.status, SB_ERR_OUT_OF_SPEC, page, 542);  // no Freq for booleans upstream
@@ -3180,9 +3243,14 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
     {  // the table entry of a virtual page is only valid when k_enc_freq_prep wrote it for its real page
         const uint32_t q = page - a.n_pages;
         const EncPage rp = a.pages[q];
-        if (codec_of(a, rp, q) != SB_CODEC_FREQ) return;
+        const int32_t rc = codec_of(a, rp, q);
         const EncOut ro = a.outs[q];
-        if (ro.length == 0 || ro.codec != SB_CODEC_FREQ || ro.pad == 2) return;  // prep raised / binary page (no nested block)
+        if (rc == SB_CODEC_DICT) {  // Freq-coded indices of a Dict page: valid once prep has written past the headers
+            if (ro.codec != SB_CODEC_DICT || ro.pad != 3 || ro.length <= 1) return;
+        } else {
+            if (rc != SB_CODEC_FREQ) return;
+            if (ro.length == 0 || ro.codec != SB_CODEC_FREQ || ro.pad == 2) return;  // prep raised / binary page (no nested block)
+        }
     }
     const EncPage p = get_page(a, page);
     const EncCol c = get_col(a, p.col);
@@ -3281,7 +3349,48 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
     if (*a.freq_count == 0) return;
     const uint32_t page = blockIdx.x;
     const EncPage p = get_page(a, page);
-    if (codec_of(a, p, page) != SB_CODEC_FREQ) return;
+    const int32_t pcodec = codec_of(a, p, page);
+    if (pcodec == SB_CODEC_DICT) {  // Dict page with Freq-coded indices: exceptions block, then `u32 D | entries`, then both headers
+        const EncOut o = a.outs[page];
+        if (o.codec != SB_CODEC_DICT || o.pad != 3) return;
+        const EncOut vo = a.outs[a.n_pages + page];
+        const EncCol c = get_col(a, p.col);
+        const unsigned long long* rec = (const unsigned long long*)(a.scratch + p.vaux_off);
+        const uint32_t* firsts = (const uint32_t*)(uintptr_t)rec[1];
+        const uint32_t D = (uint32_t)rec[2];
+        const uint32_t W = c.width;
+        const uint64_t total = o.length + vo.length + 4 + (uint64_t)D * W;
+        if (o.length <= 1 || vo.length == 0 || (p.slot_cap && total > p.slot_cap)) {
+            if (threadIdx.x == 0) {
+                raise(a.status, SB_ERR_NYI, page, 547);
+                EncOut z = o;
+                z.length = 0;
+                z.pad = 0;
+                a.outs[page] = z;
+            }
+            return;
+        }
+        wg_copy(o.slot + o.length, vo.slot, vo.length);
+        uint8_t* q = o.slot + o.length + vo.length;
+        const uint8_t* vals = c.values + p.row0 * W;
+        const bool lead_null = c.validity && !bit_at(c.validity, c.validity_bit_offset + p.row0);
+        for (uint32_t k = threadIdx.x; k < D; k += WG) {
+            const uint32_t r = firsts[k];
+            for (uint32_t b = 0; b < W; b++) q[4 + (uint64_t)k * W + b] = (r == 0 && lead_null) ? (uint8_t)0 : vals[(uint64_t)r * W + b];  // dict.rs:46-50
+        }
+        if (threadIdx.x == 0) {
+            stu32(q, D);
+            const uint64_t pos = c.nullable ? def_section_bytes(p.rows) : 0;
+            put_hdr9(o.slot + pos + 9, SB_CODEC_FREQ, (uint32_t)(o.length + vo.length - pos - 18), (uint32_t)(p.rows * 4));
+            put_hdr9(o.slot + pos, SB_CODEC_DICT, (uint32_t)(total - pos - 9), (uint32_t)(p.rows * W));
+            EncOut z = o;
+            z.length = total;
+            z.pad = 0;
+            a.outs[page] = z;
+        }
+        return;
+    }
+    if (pcodec != SB_CODEC_FREQ) return;
     const EncOut o = a.outs[page];
     if (o.codec != SB_CODEC_FREQ || o.length == 0 || o.pad == 2) return;  // prep raised / binary page already complete
     const EncOut vo = a.outs[a.n_pages + page];
@@ -3974,6 +4083,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         {
             KScope k(ctx, K_ENC_FREQ);
             k_enc_freq_prep<<<(uint32_t)std::min<uint64_t>(P, 1024), WG, 0, s>>>(a, (EncCol*)(tb + o_vcols), (EncPage*)(tb + o_vpages));
+        }
+        bool has4 = false, wide = false;
+        for (int kd : kinds) {
+            has4 |= kd == 4;
+            wide |= kd == 2 || kd == 8 || kd == 16 || kd == 32;
+        }
+        if (!has4 && wide && adaptive && !((forb >> SB_CODEC_DICT) & 1)) {  // Freq-coded u32 indices of Dict pages
+            KScope k(ctx, K_ENC_FREQ);
+            k_enc_nested<4><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
         }
         for (int kd : kinds) {
             if (kd != 1 && kd != 2 && kd != 4 && kd != 8 && kd != 16 && kd != 32) continue;

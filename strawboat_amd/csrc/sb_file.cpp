@@ -278,7 +278,9 @@ int32_t stat_block(const uint8_t*& cur, const uint8_t* end, int32_t ptype, sb_pa
         const uint8_t* q = body;
         pi.has_nested = 1;
         const uint32_t me = n - 1;
-        const int32_t rc = stat_block(q, end, ptype, out, cap, n);
+        // (the indices are a compress_integer::<u32> block: a nested Freq block inside has a 4-byte top value.
+        // Upstream passes the column's type down, src/stat.rs:146, and misreads such a page.)
+        const int32_t rc = stat_block(q, end, SB_TYPE_UINT32, out, cap, n);
         if (rc) return rc;
         if (end - q < 4) return SB_ERR_IO;
         out[me].unique_num = rd32(q);

@@ -223,3 +223,28 @@ def test_dict_pages_with_freq_indices(gpu_ctx):
     b = sparse_bin(20_000, 0.05, 91, exc_uniq=600)
     pages, metas = check(gpu_ctx, b, max_page_size=20000, force_codec=S.DICT, ratio=2.0, forbidden=(S.RLE,))
     assert S.FREQ in set(S.stat_column(b["ptype"], b["nullable"], pages, metas)[1].tolist())
+
+
+def test_dict_pages_with_freq_indices_encode(gpu_ctx):
+    """the same pages written on the device: Dict block = Freq block over the u32 indices (top index, Roaring bitmap,
+    nested exceptions block chosen on the device) + dictionary, byte-equal to the oracle"""
+    from tests.test_gpu_select import check as sel_check
+    rng = np.random.default_rng(1)
+    for ptype, npt in ((S.T_I64, np.int64), (S.T_I32, np.int32)):
+        n = 3 * 8192
+        v = np.full(n, -5, npt)
+        exc = rng.random(n) < 0.06
+        v[exc] = -rng.integers(10, 2000, int(exc.sum())).astype(npt)
+        for validity in (None, gen.make_validity(rng, n, 0.02)):
+            col = dict(ptype=ptype, nullable=validity is not None, rows=n, values=v, validity=validity, offsets=None)
+            seen = set()
+            for opt in (dict(ratio=2.0), dict(ratio=2.0, default_compression=S.LZ4), dict(ratio=1.2)):
+                codecs = sel_check(gpu_ctx, col, max_page_size=8192, forbidden=(S.RLE,), **opt)
+                seen |= set(codecs.tolist())
+            assert S.DICT in seen
+    # a leading null (the dictionary's first entry is T::default()) and f64 values
+    g = np.where(rng.random(8192) < 0.07, -rng.integers(10, 3000, 8192).astype(np.float64), -5.0)
+    valid = np.ones(8192, bool)
+    valid[0] = False
+    sel_check(gpu_ctx, dict(ptype=S.T_F64, nullable=True, rows=8192, values=g, validity=gen.pack_bits(valid), offsets=None),
+              ratio=2.0, forbidden=(S.RLE,))

@@ -309,8 +309,11 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             } else if (ec == SB_CODEC_ONEVALUE) {
                 if (ecsize < 4) FAIL(SB_ERR_IO, 53);
                 d.src = ebody;
+            } else if (ec == SB_CODEC_RLE || ec == SB_CODEC_BITPACKING || ec == SB_CODEC_DELTA_BITPACKING) {
+                if (ec != SB_CODEC_RLE && card % 128 != 0) FAIL(SB_ERR_OUT_OF_SPEC, 55);  // whole blocks only (bp.rs:72-84)
+                d.src = ebody;  // k_plan expands the block into the inflate area first
             } else {
-                FAIL(ec == SB_CODEC_RLE || ec == SB_CODEC_BITPACKING || ec == SB_CODEC_DELTA_BITPACKING ? SB_ERR_NYI : SB_ERR_OUT_OF_SPEC, 54);
+                FAIL(SB_ERR_OUT_OF_SPEC, 54);
             }
             d.isrc = infl;
         } else if (ic != SB_CODEC_RLE) {
@@ -1113,6 +1116,34 @@ __global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
             const uint32_t E = d.vusize;
             const uint8_t* ex = d.src;
             const bool one = d.pad == SB_CODEC_ONEVALUE;
+            const uint32_t ec = d.pad;
+            if ((ec == SB_CODEC_RLE || ec == SB_CODEC_BITPACKING || ec == SB_CODEC_DELTA_BITPACKING) && E) {
+                // exceptions coded with RLE / bit-packing: expand them to a plain u32 array behind the index array
+                const uint8_t* eh = d.vbody + d.vcsize;
+                const uint32_t ecsize = ldu32(eh + 1);
+                uint32_t* plain = (uint32_t*)(a.scratch + t.infl_off + ((N * 4 + 15) & ~(uint64_t)15));
+                uint32_t runs = 0;
+                bool okx = true;
+                if (ec == SB_CODEC_RLE) {
+                    runs = plan_rle(ex, ecsize, 8, E, aux, aux_cap, s_a, s_w64, a.status, p);
+                    okx = runs != 0xFFFFFFFFu;
+                } else {
+                    okx = plan_bp(ex, ecsize, E, ec == SB_CODEC_DELTA_BITPACKING, aux, s_win, s_a, s_w, a.status, p);
+                }
+                if (okx) {
+                    const U32Stream es{ex, aux, ec, runs, E};
+                    for (uint32_t tl = 0; tl * TILE_ROWS < E; tl++) {
+                        const uint32_t rows = min((uint32_t)TILE_ROWS, E - tl * TILE_ROWS);
+                        __syncthreads();
+                        u32_tile_to_lds(es, tl, rows, s_a, s_w);
+                        for (uint32_t i = threadIdx.x; i < rows; i += WG) plain[tl * TILE_ROWS + i] = s_a[sidx((int)i)];
+                    }
+                    __syncthreads();
+                    ex = (const uint8_t*)plain;
+                } else {
+                    d.ok = 0;
+                }
+            }
             for (uint64_t i = threadIdx.x; i < N; i += WG) idx[i] = top;
             __syncthreads();
             const uint64_t cum = roaring_walk(d.vbody, d.vcsize, s_a, s_w, [&](uint64_t row, uint64_t k) {
@@ -1123,7 +1154,7 @@ __global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
                 idx[row] = one ? ldu32(ex) : ldu32(ex + 4 * k);
             });
             __syncthreads();
-            if (cum != E) {
+            if (cum != E && d.ok) {
                 if (threadIdx.x == 0) raise(a.status, SB_ERR_EXTERNAL, p, 225);  // malformed RoaringBitmap
                 d.ok = 0;
             }

@@ -32,6 +32,24 @@ for codec in (S.NONE, S.LZ4, S.RLE, S.ONEVALUE):
 
 
 
+def _dominant(npt, ptype, seed, ascending=False):
+    rng = np.random.default_rng(seed)
+    v = np.full(8192, -5, npt)
+    if ascending:   # exactly 256 exceptions with ascending ids: (Delta)Bitpacking exceptions block
+        v[np.sort(rng.choice(np.arange(1, 8192), 256, replace=False))] = -(np.arange(256) + 10)
+    else:
+        exc = rng.random(8192) < 0.06
+        v[exc] = -rng.integers(10, 2000, int(exc.sum())).astype(npt)
+    return dict(ptype=ptype, nullable=False, rows=8192, values=v, validity=None, offsets=None)
+
+
+# Dict pages whose u32 indices are a nested Freq block (plain / LZ4 / bit-packed exceptions)
+for dc in (S.NONE, S.LZ4):
+    CASES.append(("i64 dict(freq idx) default %d" % dc, lambda dc=dc: (_dominant(np.int64, S.T_I64, 5),
+                                                                        dict(ratio=2.0, forbidden=(S.RLE,), default_compression=dc))))
+CASES.append(("i64 dict(freq idx, dbp exceptions)", lambda: (_dominant(np.int64, S.T_I64, 6, ascending=True), dict(ratio=2.0, forbidden=(S.RLE,)))))
+
+
 def mutate(rng, pages, metas, t):
     """the t-th mutation of (pages, metas): returns (pages', metas')"""
     pg = pages.copy()

@@ -219,6 +219,15 @@ def test_dict_pages_with_freq_indices(gpu_ctx):
     v = np.concatenate([[-5], -np.arange(10, 310), np.full(8192 - 301, -5)]).astype(np.int64)
     v[400::97] = -309
     check(gpu_ctx, dict(ptype=S.T_I64, nullable=False, rows=v.size, values=v, validity=None, offsets=None), force_codec=S.DICT, ratio=1.5)
+    # exactly 256 exceptions with ascending ids: the exceptions block is (Delta)Bitpacking
+    v = np.full(8192, -5, np.int64)
+    v[np.sort(np.random.default_rng(3).choice(np.arange(1, 8192), 256, replace=False))] = -(np.arange(256) + 10)
+    for opt in (dict(ratio=2.0), dict(ratio=2.0, default_compression=S.LZ4)):
+        pages, metas = check(gpu_ctx, dict(ptype=S.T_I64, nullable=False, rows=8192, values=v, validity=None, offsets=None),
+                             forbidden=(S.RLE,), **opt)
+        from strawboat_amd import stat
+        q = stat.stat_page(pages, S.T_I64, False)
+        assert (q.codec, q.body.indices.codec, q.body.indices.body.exceptions.codec) == (S.DICT, S.FREQ, S.DELTABP)
     # binary: forced Dict, nested selection on the indices
     b = sparse_bin(20_000, 0.05, 91, exc_uniq=600)
     pages, metas = check(gpu_ctx, b, max_page_size=20000, force_codec=S.DICT, ratio=2.0, forbidden=(S.RLE,))

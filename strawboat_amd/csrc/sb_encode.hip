@@ -4085,10 +4085,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             k_enc_freq_prep<<<(uint32_t)std::min<uint64_t>(P, 1024), WG, 0, s>>>(a, (EncCol*)(tb + o_vcols), (EncPage*)(tb + o_vpages));
         }
         bool has4 = false, wide = false;
-        for (int kd : kinds) {
-            has4 |= kd == 4;
-            wide |= kd == 2 || kd == 8 || kd == 16 || kd == 32;
-        }
+        for (int kd : kinds) has4 |= kd == 4;
+        for (uint64_t i = 0; i < n; i++)  // only integers get there: a mostly-one-value float column takes Freq itself
+            wide |= hc[i].fkind == 0 && hc[i].ptype != SB_TYPE_BOOLEAN && hc[i].ptype != SB_TYPE_NULL && !enc_is_binary(hc[i].ptype) &&
+                    (hc[i].width == 2 || hc[i].width >= 8);
         if (!has4 && wide && adaptive && !((forb >> SB_CODEC_DICT) & 1)) {  // Freq-coded u32 indices of Dict pages
             KScope k(ctx, K_ENC_FREQ);
             k_enc_nested<4><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     EncodeArgs a;
     memset(&a, 0, sizeof a);
     a.cols = dc; a.pages = dp; a.outs = outs; a.scratch = scratch; a.status = st; a.codecs = codecs; a.ratio = 2.0; a.has_ratio = 1;
-    a.forbidden = 0; a.n_pages = P; a.n_cols = 1; a.default_compression = 0; a.freq_count = fc; a.nested_force = -1;
+    a.forbidden = 0; a.n_pages = P; a.n_cols = 1; a.default_compression = 0; a.freq_count = fc; a.nested_force = -1; { uint32_t* cc; hipMalloc(&cc, 128); hipMemset(cc, 0, 128); a.codec_counts = cc; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; i++) k_enc_select_runs<8, 2><<<P, WG>>>(a);
     hipEventRecord(e0);

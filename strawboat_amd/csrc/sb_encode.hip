@@ -99,6 +99,10 @@ struct EncodeArgs {
     const EncCol* vcols;  // virtual columns / pages of Freq exceptions: entries n_cols.. / n_pages.. (device-written)
     const EncPage* vpages;
     uint32_t* freq_count;  // pages that chose Freq in this call (the Freq kernels return at once when 0)
+    uint32_t* codec_counts;  // [32] adaptive mode: pages per chosen codec ([31]: left to the row-level selector); an emit
+                             // kernel whose codec nobody chose returns before it looks at a page
+    uint32_t use_counts;     // this launch may trust codec_counts (adaptive wave over real pages)
+    uint32_t null_cols;      // the batch holds Null columns (their empty pages are recorded by k_enc_emit_tiles)
     uint32_t page_base;   // first table entry this launch works on (0: pages, n_pages: virtual pages)
     int32_t nested_force; // force_index_codec: the codec forced on nested blocks (-1: none)
 };
@@ -2438,6 +2442,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     }
     if (threadIdx.x == 0) {
         a.codecs[page] = (int32_t)codec;
+        atomicAdd(&a.codec_counts[codec & 31], 1u);
         if (!has_device_encoder(codec))
             raise(a.status, SB_ERR_NYI, page, 700 + codec);
         else if (codec == SB_CODEC_FREQ && page < a.n_pages)
@@ -2454,6 +2459,7 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
     __shared__ uint32_t s_misc[2 * WG + 16];
     __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * (KIND + 1) + 16];
     __shared__ uint32_t s_cnt2[2];
+    if (a.codec_counts[31] == 0) return;  // k_enc_select_runs (launched before) took every page
     const uint32_t page = blockIdx.x;
     const EncPage p = a.pages[page];
     if (p.codec != CODEC_ON_DEVICE) return;
@@ -2474,6 +2480,7 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
     if (N > 0) codec = select_rle_page<KIND, FK>(a, c, p, page, so, sc, s_cnt2, &kept);
     if (threadIdx.x == 0) {
         a.codecs[page] = (int32_t)codec;
+        if (!kept) atomicAdd(&a.codec_counts[codec & 31], 1u);  // (kept: the RLE page is already written)
         if (!has_device_encoder(codec))
             raise(a.status, SB_ERR_NYI, page, 700 + codec);
         else if (codec == SB_CODEC_FREQ)
@@ -2515,9 +2522,11 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_runs(EncodeArgs a) {
     if (threadIdx.x == 0) {
         if (fallback) {
             a.codecs[page] = CODEC_PENDING;
+            atomicAdd(&a.codec_counts[31], 1u);
             return;
         }
         a.codecs[page] = (int32_t)codec;
+        if (!kept) atomicAdd(&a.codec_counts[codec & 31], 1u);  // (kept: the RLE page is already written)
         if (!has_device_encoder(codec))
             raise(a.status, SB_ERR_NYI, page, 700 + codec);
         else if (codec == SB_CODEC_FREQ)
@@ -2564,6 +2573,7 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * LW];
     uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
     __shared__ uint32_t s_w[4];
+    if (a.use_counts && a.codec_counts[CODEC] == 0) return;  // adaptive batch without a page of this codec
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     if (codec_of(a, p, page) != CODEC) return;
@@ -3429,6 +3439,7 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
 __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     __shared__ uint32_t tab[4096];
     __shared__ uint32_t s_sz;
+    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] + a.codec_counts[SB_CODEC_ZSTD] + a.codec_counts[SB_CODEC_SNAPPY] == 0) return;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     const int32_t bc = codec_of(a, p, page);
@@ -3591,6 +3602,7 @@ __device__ void emit_tile(const EncodeArgs& a, uint32_t page, uint32_t tile) {
 // known on the host T = tiles per page (every tile its own workgroup); in adaptive mode, where few pages stay
 // plain, T = 1: one workgroup per page finds out that there is nothing to do, not one per tile.
 __global__ void __launch_bounds__(WG) k_enc_emit_tiles(EncodeArgs a, uint32_t max_tiles) {
+    if (a.use_counts && a.codec_counts[SB_CODEC_NONE] == 0 && !a.null_cols) return;
     const uint32_t page = blockIdx.x + a.page_base;
     if (gridDim.y < max_tiles) {  // (adaptive) look at the page before walking its tiles
         const EncPage p = get_page(a, page);
@@ -3813,7 +3825,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     const size_t o_codecs = off;
     off = align_up(off + 2 * P * sizeof(int32_t), 64);
     const size_t o_freqcnt = off;
-    off = align_up(off + 64, 64);
+    off = align_up(off + 64 + 32 * sizeof(uint32_t), 64);  // freq_count | codec_counts[32]
     const size_t o_vcols = off;
     off = align_up(off + (freq_possible ? P : 0) * sizeof(EncCol), 64);
     const size_t o_vpages = off;
@@ -3971,6 +3983,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.page_base = 0;
     a.nested_force = opts->force_index_codec;
     a.freq_count = (uint32_t*)(tb + o_freqcnt);
+    a.codec_counts = (uint32_t*)(tb + o_freqcnt + 64);
+    a.use_counts = 0;
+    a.null_cols = 0;
+    for (uint64_t i = 0; i < n; i++) a.null_cols |= cols[i].physical_type == SB_TYPE_NULL ? 1u : 0u;
     // one memset: page outputs (length 0 = not emitted), results, device-chosen codecs, the Freq page counter
     (void)hipMemsetAsync(tb + o_outs, 0, o_vcols - o_outs, s);
     if (host_codec == SB_CODEC_FREQ) (void)hipMemsetAsync(a.freq_count, 1, 4, s);  // forced: every page is a Freq page (non-zero)
@@ -3987,7 +4003,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     }
     // One wave of select + emit kernels over the table entries [aa.page_base, aa.page_base + P).
     // wave_adaptive: codecs are chosen on the device; wave_codec: the one codec otherwise (-1: several possible).
-    auto run_wave = [&](const EncodeArgs& aa, bool wave_adaptive, int32_t wave_codec, bool nested) -> int32_t {
+    auto run_wave = [&](const EncodeArgs& aa_in, bool wave_adaptive, int32_t wave_codec, bool nested) -> int32_t {
+        EncodeArgs aa = aa_in;
+        aa.use_counts = wave_adaptive && !nested ? 1u : 0u;
         if (wave_adaptive) {
             for (int kd : kinds) {
                 if (nested && (kd <= 0 || kd > 8)) continue;

@@ -330,6 +330,18 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
     // Tile tasks for k_expand / k_expand_binary, appended to a compact list (job_counts[2] entries):
     // pages that a page-level kernel expands (k_expand_rle) contribute none, so a batch of RLE pages
     // does not launch tens of thousands of workgroups that only find out they have nothing to do.
+    // pages that k_plan / k_expand_rle have work for: those kernels return at once when there are none
+    // (one atomic per wave: thousands of pages adding to one word serialise)
+    {
+        const bool by_page = rle_by_page(c, d);
+        const bool plan = !by_page && (is_binary(c.ptype) || codec == SB_CODEC_DICT || codec == SB_CODEC_RLE ||
+                                       codec == SB_CODEC_BITPACKING || codec == SB_CODEC_DELTA_BITPACKING);
+        const uint64_t mb = __ballot(by_page), mp = __ballot(plan), act = __ballot(true);
+        if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)act) - 1)) {
+            if (mb) atomicAdd(&a.job_counts[4], (uint32_t)__popcll(mb));
+            if (mp) atomicAdd(&a.job_counts[3], (uint32_t)__popcll(mp));
+        }
+    }
     if (!rle_by_page(c, d) && ntiles) {
         const uint32_t base = atomicAdd(&a.job_counts[2], ntiles);
         d.tile_base = base;
@@ -1073,6 +1085,7 @@ __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, cons
 }
 
 __global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
+    if (a.job_counts[3] == 0) return;  // no page of this call needs a plan (k_parse counts them)
     const uint32_t p = blockIdx.x;
     __shared__ uint32_t s_a[SIDX_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t s_win[BP_WINDOW];
@@ -1747,6 +1760,7 @@ __global__ void __launch_bounds__(WG) k_expand_rle(DecodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_vals[RLE_CHUNK * 8];
     __shared__ uint32_t s_w[4];
     __shared__ uint64_t s_w64[4];
+    if (a.job_counts[4] == 0) return;  // no RLE page of <= 8-byte values in this call
     const uint32_t p = blockIdx.x;
     const PageDesc d = a.descs[p];
     const PageTask t = a.tasks[p];
@@ -1824,7 +1838,7 @@ void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, cons
 
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 3 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 5 * sizeof(uint32_t), s);
     {
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
@@ -1861,7 +1875,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
 
 void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 3 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 5 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);

@@ -3623,17 +3623,32 @@ __global__ void k_enc_layout(EncodeArgs a, const uint64_t* res_off) {
     uint64_t* res = a.results + res_off[ci];
     uint64_t off = 0;
     bool bad = false;
-    for (uint32_t k = 0; k < c.n_pages; k++) {
-        const uint32_t pg = c.first_page + k;
-        EncOut o = a.outs[pg];
-        if (o.length == 0 && c.ptype != SB_TYPE_NULL) bad = true;
-        const uint64_t head = a.pages[pg].head_bytes;
-        o.out_off = off + head;  // the block goes behind the page's head
-        a.outs[pg] = o;
-        res[k] = head + o.length;
-        res[c.n_pages + k] = a.pages[pg].rows;
-        if (a.pages[pg].direct && a.pages[pg].direct_off != off) bad = true;
-        off += head + o.length;
+    constexpr uint32_t G = 8;  // pages fetched together: the running offset is the only thing that is sequential
+    for (uint32_t k0 = 0; k0 < c.n_pages; k0 += G) {
+        EncOut o[G];
+        uint64_t head[G], rows[G], doff[G];
+        uint32_t dir[G];
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) {
+            const uint32_t pg = c.first_page + min(k0 + j, c.n_pages - 1);
+            o[j] = a.outs[pg];
+            head[j] = a.pages[pg].head_bytes;
+            rows[j] = a.pages[pg].rows;
+            dir[j] = a.pages[pg].direct;
+            doff[j] = a.pages[pg].direct_off;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) {
+            const uint32_t k = k0 + j;
+            if (k >= c.n_pages) break;
+            if (o[j].length == 0 && c.ptype != SB_TYPE_NULL) bad = true;
+            o[j].out_off = off + head[j];  // the block goes behind the page's head
+            a.outs[c.first_page + k] = o[j];
+            res[k] = head[j] + o[j].length;
+            res[c.n_pages + k] = rows[j];
+            if (dir[j] && doff[j] != off) bad = true;
+            off += head[j] + o[j].length;
+        }
     }
     res[2 * c.n_pages] = off;
     if (off > c.out_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 600);

@@ -181,21 +181,36 @@ __device__ __forceinline__ bool sample_row(uint64_t N, uint64_t seed, uint32_t d
     return true;
 }
 
-// fill the LDS sample for trial `trial`
+// fill the LDS sample for trial `trial`: the rows of a thread (up to 3) are computed first and their validity bits and
+// values requested together, so the gather exposes one memory round trip, not one per row
 template <int W, class GetVal, class Valid>
 __device__ void load_sample(GetVal getv, Valid valid, uint64_t N, uint64_t seed, uint32_t depth, uint32_t trial,
                             Sample<W>& s) {
     const bool whole = N / SAMPLE_COUNT <= SAMPLE_SIZE;
     s.whole = whole;
     s.n = whole ? (uint32_t)N : SAMPLE_ROWS;
-    for (uint32_t k = threadIdx.x; k < s.n; k += WG) {
-        uint64_t row;
-        sample_row(N, seed, depth, trial, k, row);
-        const bool v = valid(row);
-        Val<W> x = getv(row);
-        if (!whole && !v) __builtin_memset(&x, 0, sizeof(x));  // MutablePrimitiveArray pushes T::default()
-        s.val[k] = x;
-        s.valid[k] = v ? 1 : 0;
+    constexpr int R = (SAMPLE_CAP + WG - 1) / WG;
+    uint64_t row[R];
+    Val<W> x[R];
+    bool v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t k = threadIdx.x + (uint32_t)r * WG;
+        row[r] = 0;
+        if (k < s.n) sample_row(N, seed, depth, trial, k, row[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        x[r] = getv(row[r]);
+        v[r] = valid(row[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t k = threadIdx.x + (uint32_t)r * WG;
+        if (k >= s.n) continue;
+        if (!whole && !v[r]) __builtin_memset(&x[r], 0, sizeof(x[r]));  // MutablePrimitiveArray pushes T::default()
+        s.val[k] = x[r];
+        s.valid[k] = v[r] ? 1 : 0;
     }
     __syncthreads();
 }

@@ -1702,7 +1702,8 @@ __device__ void expand_rle_page(const ColDesc& c, const PageTask& t, const PageD
             if (start[j] < N && start[j] + cnt[j] > N) raise(st, SB_ERR_OUT_OF_SPEC, page, 202);
         for (uint64_t tile_lo = S0 / TILE_ROWS * TILE_ROWS; tile_lo < S1; tile_lo += TILE_ROWS) {
             const uint64_t lo = max(S0, tile_lo), hi = min(S1, tile_lo + TILE_ROWS);
-            for (int i = tid; i < SIDX_WORDS; i += WG) s_flag[i] = 0;
+            static_assert(SIDX_WORDS % 4 == 0, "16-byte clears");
+            for (int i = tid; i < SIDX_WORDS / 4; i += WG) ((u32x4*)s_flag)[i] = u32x4{0, 0, 0, 0};
             // A = (runs of the chunk that start at or before row lo) - 1: the run covering row lo
             uint32_t le = 0;
 #pragma unroll
@@ -1756,7 +1757,7 @@ __device__ void page_copy_bits(uint8_t* dst_bm, uint64_t dst_bit0, const uint8_t
 }
 
 __global__ void __launch_bounds__(WG) k_expand_rle(DecodeArgs a) {
-    __shared__ uint32_t s_flag[SIDX_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_flag[SIDX_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t s_vals[RLE_CHUNK * 8];
     __shared__ uint32_t s_w[4];
     __shared__ uint64_t s_w64[4];

@@ -2351,6 +2351,20 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
                                          ValidView{nullptr, 0}, N, NK_UNSIGNED, so, sc);
             __syncthreads();
         }
+        if (ic == SB_CODEC_FREQ) {  // as in emit_prim_page<Dict>: the Freq kernels write the index block and the entries
+            if (p.vaux_bytes < 32 || !p.vslot_off) {
+                if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 502);
+                return 0;
+            }
+            if (threadIdx.x == 0) {
+                unsigned long long* rec = (unsigned long long*)(a.scratch + p.vaux_off);
+                rec[0] = (unsigned long long)(uintptr_t)idx;
+                rec[1] = (unsigned long long)(uintptr_t)firsts;
+                rec[2] = D;
+                atomicAdd(a.freq_count, 1u);
+            }
+            return DICT_FREQ_PENDING;
+        }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
         if (ib == 0) return 0;
         uint8_t* q = blk + 9 + ib;
@@ -3201,7 +3215,8 @@ __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a, EncCol* c
         ip.forb_extra = p.forb_extra | (1u << SB_CODEC_DICT);
         ip.aux_bytes = 0;
         ip.vaux_bytes = 0;                                   // (the area holds the record read above)
-        freq_prep_page<4>(a, cols_rw, pages_rw, ic, ip, page, lds, dslot, dpos, p.rows * c.width);
+        const bool cbin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;  // (exception area: rows/2 + 1 indices)
+        freq_prep_page<4>(a, cols_rw, pages_rw, ic, ip, page, lds, dslot, dpos, cbin ? (p.rows / 2 + 1) * 4 : p.rows * c.width);
         continue;
     }
     if (pcodec != SB_CODEC_FREQ) continue;
@@ -3356,6 +3371,8 @@ __global__ void __launch_bounds__(WG) k_enc_nested(EncodeArgs a) {
 }
 
 __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
+    __shared__ uint32_t s_ent[SIDX_WORDS];  // entry positions of a binary dictionary
+    __shared__ uint32_t s_w[4];
     if (*a.freq_count == 0) return;
     const uint32_t page = blockIdx.x;
     const EncPage p = get_page(a, page);
@@ -3382,6 +3399,47 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
         }
         wg_copy(o.slot + o.length, vo.slot, vo.length);
         uint8_t* q = o.slot + o.length + vo.length;
+        if (c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY) {
+            // entries `u64 len | bytes` in dictionary order (binary/dict.rs:55-93), positions = scan of (8 + len)
+            const uint32_t ow = c.ptype == SB_TYPE_BINARY ? 4u : 8u;
+            const uint8_t* offs = c.offsets + p.row0 * ow;
+            auto beg = [=](uint64_t i) { return ow == 4 ? (uint64_t)ldu32(offs + i * 4) : ldu64(offs + i * 8); };
+            uint64_t epos = 0;
+            for (uint32_t kb = 0; kb < D; kb += TILE_ROWS) {
+                const uint32_t n = min((uint32_t)TILE_ROWS, D - kb);
+                for (uint32_t i = threadIdx.x; i < TILE_ROWS; i += WG) {
+                    uint32_t len = 0;
+                    if (i < n) {
+                        const uint64_t r = firsts[kb + i];
+                        len = (uint32_t)(beg(r + 1) - beg(r)) + 8;
+                    }
+                    s_ent[sidx((int)i)] = len;
+                }
+                __syncthreads();
+                const uint32_t tot = tile_incl_scan(s_ent, s_w);
+                for (uint32_t i = threadIdx.x; i < n; i += WG) {
+                    const uint64_t r = firsts[kb + i];
+                    const uint64_t b = beg(r), e = beg(r + 1);
+                    uint8_t* d = q + 4 + epos + s_ent[sidx((int)i)] - (e - b) - 8;
+                    stu64(d, e - b);
+                    for (uint64_t k = 0; k < e - b; k++) d[8 + k] = c.values[b + k];
+                }
+                epos += tot;
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                stu32(q, D);
+                const uint64_t pos = c.nullable ? def_section_bytes(p.rows) : 0;
+                const uint64_t btotal = o.length + vo.length + 4 + epos;
+                put_hdr9(o.slot + pos + 9, SB_CODEC_FREQ, (uint32_t)(o.length + vo.length - pos - 18), (uint32_t)(p.rows * 4));
+                put_hdr9(o.slot + pos, SB_CODEC_DICT, (uint32_t)(btotal - pos - 9), (uint32_t)c.values_len);  // binary/mod.rs:88
+                EncOut z = o;
+                z.length = btotal;
+                z.pad = 0;
+                a.outs[page] = z;
+            }
+            return;
+        }
         const uint8_t* vals = c.values + p.row0 * W;
         const bool lead_null = c.validity && !bit_at(c.validity, c.validity_bit_offset + p.row0);
         for (uint32_t k = threadIdx.x; k < D; k += WG) {
@@ -3791,7 +3849,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
     // Freq pages (chosen or forced) send their exceptions through a second wave of the same kernels
     bool freq_possible = false;
-    if (host_codec == SB_CODEC_FREQ || (adaptive && !((forb >> SB_CODEC_FREQ) & 1)))
+    const bool dict_freq = host_codec == SB_CODEC_DICT &&  // a forced Dict page whose u32 indices may become a Freq block
+                           (opts->force_index_codec == SB_CODEC_FREQ ||
+                            (opts->force_index_codec < 0 && opts->has_default_compress_ratio && !((forb >> SB_CODEC_FREQ) & 1)));
+    if (host_codec == SB_CODEC_FREQ || dict_freq || (adaptive && !((forb >> SB_CODEC_FREQ) & 1)))
         for (uint64_t i = 0; i < n; i++) {
             const int32_t t = cols[i].physical_type;
             freq_possible |= t != SB_TYPE_BOOLEAN && t != SB_TYPE_NULL;
@@ -3919,6 +3980,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     scratch_off += align_up(N * d.width + 64, 16);
                     p.vslot_off = scratch_off;  // slot of the exceptions block (a non-nullable page of <= N rows)
                     scratch_off += align_up(slot_fixed_bytes(c.physical_type, 0, N), 16);
+                } else if (freq_possible && bin && !((forb >> SB_CODEC_DICT) & 1) && (adaptive || codec == SB_CODEC_DICT)) {
+                    // a binary Dict page with Freq-coded indices: < N/2 + 1 exception indices and their block
+                    // (placed after all slots, below: a binary column's slots share one region with its value bytes)
+                    p.ex_off = ~0ull;
+                    p.vaux_bytes = 64;  // the idx / firsts / D record of the Dict page
                 }
             }
             if (codec == SB_CODEC_DICT || codec == SB_CODEC_FREQ ||  // (forced Freq: exact counts when no value has a majority)
@@ -3965,6 +4031,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             scratch_off = align_up(scratch_off, 16);
             hp[q].vaux_off = scratch_off;
             scratch_off += hp[q].vaux_bytes;
+        }
+        if (hp[q].ex_off == ~0ull) {  // binary Dict page with Freq-coded indices: exception indices and their block
+            const uint64_t nh = hp[q].rows / 2 + 1;
+            scratch_off = align_up(scratch_off, 16);
+            hp[q].ex_off = scratch_off;
+            scratch_off += align_up(nh * 4 + 64, 16);
+            hp[q].vslot_off = scratch_off;
+            scratch_off += align_up(slot_fixed_bytes(SB_TYPE_UINT32, 0, nh), 16);
         }
         if (!hp[q].direct) {
             const EncCol& d = hc[hp[q].col];
@@ -4120,9 +4194,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         bool has4 = false, wide = false;
         for (int kd : kinds) has4 |= kd == 4;
         for (uint64_t i = 0; i < n; i++)  // only integers get there: a mostly-one-value float column takes Freq itself
-            wide |= hc[i].fkind == 0 && hc[i].ptype != SB_TYPE_BOOLEAN && hc[i].ptype != SB_TYPE_NULL && !enc_is_binary(hc[i].ptype) &&
-                    (hc[i].width == 2 || hc[i].width >= 8);
-        if (!has4 && wide && adaptive && !((forb >> SB_CODEC_DICT) & 1)) {  // Freq-coded u32 indices of Dict pages
+            wide |= (hc[i].fkind == 0 || dict_freq) && hc[i].ptype != SB_TYPE_BOOLEAN && hc[i].ptype != SB_TYPE_NULL && !enc_is_binary(hc[i].ptype) &&
+                    (hc[i].width <= 2 || hc[i].width >= 8);
+        for (uint64_t i = 0; i < n; i++) wide |= enc_is_binary(hc[i].ptype);
+        if (!has4 && wide && (adaptive || dict_freq) && !((forb >> SB_CODEC_DICT) & 1)) {  // Freq-coded u32 indices of Dict pages
             KScope k(ctx, K_ENC_FREQ);
             k_enc_nested<4><<<(uint32_t)std::min<uint64_t>(P, 512), WG, 0, s>>>(a);
         }

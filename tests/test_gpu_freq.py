@@ -257,3 +257,34 @@ def test_dict_pages_with_freq_indices_encode(gpu_ctx):
     valid[0] = False
     sel_check(gpu_ctx, dict(ptype=S.T_F64, nullable=True, rows=8192, values=g, validity=gen.pack_bits(valid), offsets=None),
               ratio=2.0, forbidden=(S.RLE,))
+
+
+def test_binary_and_forced_dict_pages_with_freq_indices_encode(gpu_ctx):
+    """Dict pages whose u32 indices are a Freq block, written on the device for Binary / Utf8 columns (entries
+    `u64 len | bytes`, binary/dict.rs:55-93) and for a *forced* Dict codec (nested selection, or Freq forced on the
+    indices): byte-equal to the oracle"""
+    from tests.test_gpu_encode import check as enc_check
+    for large in (False, True):
+        for nd in (None, 0.03):
+            b = sparse_bin(20_000, 0.05, 91, exc_uniq=600, large=large, null_density=nd)
+            for opt in (dict(force_codec=S.DICT, ratio=2.0, forbidden=(S.RLE,)), dict(force_codec=S.DICT, force_index_codec=S.FREQ),
+                        dict(force_codec=S.DICT, force_index_codec=S.FREQ, default_compression=S.LZ4)):
+                enc_check(gpu_ctx, b, max_page_size=8192, **opt)
+                pages, metas = gen.oracle_write(b, max_page_size=8192, **opt)
+                assert S.FREQ in set(S.stat_column(b["ptype"], b["nullable"], pages, metas)[1].tolist()), opt
+    # empty strings as the top value and as exceptions, one page shorter than the others
+    e = sparse_bin(9_000, 0.06, 92, exc_uniq=700, top=b"", maxlen=9)
+    enc_check(gpu_ctx, e, max_page_size=4096, force_codec=S.DICT, force_index_codec=S.FREQ)
+    # primitives of every width under a forced Dict
+    rng = np.random.default_rng(7)
+    for ptype, npt in ((S.T_I64, np.int64), (S.T_I32, np.int32), (S.T_I16, np.int16), (S.T_F64, np.float64)):
+        n = 2 * 8192
+        v = np.full(n, -5, npt)
+        exc = rng.random(n) < 0.06
+        v[exc] = (-rng.integers(10, 2000, int(exc.sum()))).astype(npt)
+        col = dict(ptype=ptype, nullable=False, rows=n, values=v, validity=None, offsets=None)
+        for opt in (dict(force_codec=S.DICT, force_index_codec=S.FREQ), dict(force_codec=S.DICT, ratio=2.0, forbidden=(S.RLE,))):
+            enc_check(gpu_ctx, col, max_page_size=8192, **opt)
+            pages, metas = gen.oracle_write(col, max_page_size=8192, **opt)
+            if "force_index_codec" in opt:
+                assert set(S.stat_column(ptype, False, pages, metas)[1].tolist()) == {S.FREQ}

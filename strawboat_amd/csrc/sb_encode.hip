@@ -2735,7 +2735,7 @@ __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t*
 // Roaring portable serialization of the exception rows of one page (format note above):
 // header + containers at `rb`, its byte size also stored at `size_field`; on_exc(row, k) is called for
 // the k-th exception.  All threads of the workgroup call this.
-constexpr uint32_t FREQ_MAX_CONTAINERS = 64;  // pages of up to 4 Mi rows
+constexpr uint32_t FREQ_MAX_CONTAINERS = 1024;  // pages of up to 64 Mi rows (4 KiB of LDS for the cardinalities)
 template <class IsExc, class OnExc>
 __device__ void freq_roaring(uint64_t N, uint8_t* rb, uint8_t* size_field, uint32_t* sA, uint32_t* s_w, uint32_t* s_card,
                              IsExc is_exc, OnExc on_exc, uint32_t& rb_size_out, uint32_t& n_ex_out) {

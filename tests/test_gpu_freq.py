@@ -288,3 +288,22 @@ def test_binary_and_forced_dict_pages_with_freq_indices_encode(gpu_ctx):
             pages, metas = gen.oracle_write(col, max_page_size=8192, **opt)
             if "force_index_codec" in opt:
                 assert set(S.stat_column(ptype, False, pages, metas)[1].tolist()) == {S.FREQ}
+
+
+def test_freq_pages_of_more_than_four_mi_rows(gpu_ctx):
+    """without max_page_size a column is ONE page (write/common.rs: page size = rows): 4.3 M rows are 66 Roaring
+    containers, bitmap and array containers mixed"""
+    from tests.test_gpu_encode import check as enc_check
+    from tests.test_gpu_select import check as sel_check
+    c = sparse(S.T_I64, 4_300_000, 0.03, 5)
+    c["values"][70_000:140_000:3] = 999    # one dense (bitmap) container
+    c["values"][200_000:262_144] = 7       # one empty container
+    enc_check(gpu_ctx, c, force_codec=S.FREQ)
+    check(gpu_ctx, c, force_codec=S.FREQ)
+    assert set(sel_check(gpu_ctx, c, ratio=2.0, forbidden=()).tolist()) == {S.FREQ}
+    n = sparse(S.T_I32, 4_200_000, 0.02, 6, null_density=0.05)
+    enc_check(gpu_ctx, n, force_codec=S.FREQ)
+    check(gpu_ctx, n, force_codec=S.FREQ)
+    b = sparse_bin(4_300_000, 0.03, 6)
+    enc_check(gpu_ctx, b, force_codec=S.FREQ)
+    check(gpu_ctx, b, force_codec=S.FREQ)

@@ -145,6 +145,7 @@ void sb_ctx_destroy(sb_ctx* ctx) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     for (void* p : ctx->temp_dev) (void)hipFree(p);
+    ctx->stage_release();
     for (auto& sp : ctx->spans) {
         (void)hipEventDestroy(sp.a);
         (void)hipEventDestroy(sp.b);
@@ -291,14 +292,16 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     }
     ctx->pending.clear();
     for (auto& cb : ctx->copybacks) {
-        if (rc == SB_OK && cb.n) {
-            hipError_t ce = hipMemcpy(cb.host, cb.dev, cb.n, hipMemcpyDeviceToHost);
+        const size_t nb = cb.used ? (size_t)std::min<uint64_t>(cb.n, *cb.used) : cb.n;
+        if (rc == SB_OK && nb) {
+            hipError_t ce = hipMemcpy(cb.host, cb.dev, nb, hipMemcpyDeviceToHost);
             if (ce != hipSuccess) rc = check_hip(ctx, ce, "copy back");
         }
     }
     ctx->copybacks.clear();
     for (void* p : ctx->temp_dev) (void)hipFree(p);
     ctx->temp_dev.clear();
+    ctx->stage_rewind();
     ctx->sticky = 0;
     return rc;
 }
@@ -404,9 +407,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             auto alloc = [&](size_t bytes, uint8_t** out) -> bool {
                 *out = nullptr;
                 if (!bytes) return true;
-                if (hipMalloc((void**)out, bytes + 64) != hipSuccess) return false;
-                ctx->temp_dev.push_back(*out);
-                return true;
+                return (*out = ctx->stage_alloc(bytes)) != nullptr;
             };
             if (!alloc(c.pages_len, &dev_pages[i])) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(pages) failed");
             if (c.pages_len &&

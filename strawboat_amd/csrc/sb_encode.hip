@@ -3809,9 +3809,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         auto stage_in = [&](const void* host, size_t bytes, const uint8_t** out) -> bool {
             *out = nullptr;
             if (!host || !bytes) return true;
-            uint8_t* d = nullptr;
-            if (hipMalloc((void**)&d, bytes + 64) != hipSuccess) return false;
-            ctx->temp_dev.push_back(d);
+            uint8_t* d = ctx->stage_alloc(bytes);
+            if (!d) return false;
             *out = d;
             return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
         };
@@ -3825,10 +3824,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 !stage_in(enc_is_binary(c.physical_type) ? c.offsets : nullptr, (size_t)((c.rows + 1) * w), &doff[i]))
                 return ctx->fail(SB_ERR_EXTERNAL, "staging of host buffers failed");
             if (c.out_capacity) {
-                if (hipMalloc((void**)&dout[i], c.out_capacity + 64) != hipSuccess)
+                if (!(dout[i] = ctx->stage_alloc(c.out_capacity)))
                     return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(out_pages) failed");
-                ctx->temp_dev.push_back(dout[i]);
-                ctx->copybacks.push_back({c.out_pages, dout[i], (size_t)c.out_capacity});
+                ctx->copybacks.push_back({c.out_pages, dout[i], (size_t)c.out_capacity, &cols[i].out_len});
             }
         }
     }

@@ -1,6 +1,7 @@
 // strawboat-hip: host-side context (workspace, staging ring, error plumbing).
 #pragma once
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "sb_common.h"
@@ -63,9 +64,49 @@ struct sb_ctx {
         void* host;
         const void* dev;
         size_t n;
+        const uint64_t* used = nullptr;  // when set: only the first min(n, *used) bytes are copied (pages: out_len)
     };
     std::vector<Copyback> copybacks;
     std::vector<void*> temp_dev;  // device temporaries to free at synchronize
+    // SB_MEM_HOST staging areas: carved out of chunks that stay allocated (hipMalloc / hipFree per buffer and call
+    // cost more than the PCIe copies); every carve-out lives until the next synchronize, which rewinds the chunks
+    struct StageChunk {
+        uint8_t* p;
+        size_t cap, used;
+    };
+    std::vector<StageChunk> stage_chunks;
+    size_t stage_hint = 0;  // capacity of the set of chunks that was last merged
+    uint8_t* stage_alloc(size_t bytes) {
+        bytes = (bytes + 64 + 255) & ~(size_t)255;
+        for (auto& c : stage_chunks)
+            if (c.cap - c.used >= bytes) {
+                uint8_t* r = c.p + c.used;
+                c.used += bytes;
+                return r;
+            }
+        size_t total = 0;
+        for (auto& c : stage_chunks) total += c.cap;
+        const size_t cap = std::max<size_t>(std::max<size_t>(bytes, stage_hint), std::max<size_t>(total, (size_t)256 << 20));  // doubling growth
+        uint8_t* p = nullptr;
+        if (hipMalloc((void**)&p, cap) != hipSuccess) return nullptr;
+        stage_chunks.push_back({p, cap, bytes});
+        return p;
+    }
+    void stage_rewind() {  // after the stream has drained: one chunk of the total size replaces a fragmented set
+        if (stage_chunks.size() > 2) {
+            stage_hint = 0;
+            for (auto& c : stage_chunks) {
+                stage_hint += c.cap;
+                (void)hipFree(c.p);
+            }
+            stage_chunks.clear();
+        }
+        for (auto& c : stage_chunks) c.used = 0;
+    }
+    void stage_release() {
+        for (auto& c : stage_chunks) (void)hipFree(c.p);
+        stage_chunks.clear();
+    }
     // Freq pages logged by the decode calls since the last synchronize: [u32 count | pad][FreqEntry...]
     struct FreqLog {
         uint8_t* dev = nullptr;

@@ -549,7 +549,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             if (c.is_nullable && c.rows) ctx->copybacks.push_back({c.validity, dev_validity[i], (size_t)((c.rows + 7) / 8)});
             if (is_binary_t(c.physical_type)) {
                 ctx->copybacks.push_back({c.offsets, dev_offsets[i], (size_t)((c.rows + 1) * w)});
-                ctx->copybacks.push_back({c.values, dev_values[i], (size_t)c.values_capacity});
+                ctx->copybacks.push_back({c.values, dev_values[i], (size_t)c.values_capacity, &cols[i].values_len});  // (set just before, from `pending`)
             } else if (c.physical_type == SB_TYPE_BOOLEAN) {
                 ctx->copybacks.push_back({c.values, dev_values[i], (size_t)((c.rows + 7) / 8)});
             } else if (c.physical_type != SB_TYPE_NULL) {

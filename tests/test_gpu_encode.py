@@ -203,3 +203,50 @@ def test_host_memory_boundary(gpu_ctx):
     gpu_ctx._check(lib.sb_read_columns(h, cr, 1, N.SB_MEM_HOST))
     gpu_ctx.synchronize()
     assert np.array_equal(v_out, want["values"]) and np.array_equal(b_out[:(col["rows"] + 7) // 8], want["validity"])
+
+
+def test_host_memory_boundary_binary(gpu_ctx):
+    """SB_MEM_HOST for a Utf8 column: host page bytes in, host offsets / values out; only `values_len` bytes of the
+    values buffer and `out_len` bytes of a page buffer are written back"""
+    import ctypes as C
+    from strawboat_amd import _native as N
+    from strawboat_amd.types import WriteOptions
+    from strawboat_amd.write import options_c
+    col = gen.binary(30_000, uniq=300, null_density=0.1, seed=3)
+    want_pages, want_metas = gen.oracle_write(col, max_page_size=8192, ratio=2.0)
+    want = gen.oracle_read(col, want_pages, want_metas)
+    lib, h = gpu_ctx._lib, gpu_ctx._h
+    # write: host Arrow buffers -> host page bytes
+    oc = options_c(WriteOptions(max_page_size=8192, default_compress_ratio=2.0))
+    npg = C.c_uint64()
+    bound = lib.sb_write_bound(col["ptype"], 1, col["rows"], col["values"].size, C.byref(oc), C.byref(npg))
+    out = np.full(bound, 0xA5, np.uint8)
+    metas = (N.PageMetaC * npg.value)()
+    cw = (N.ColumnWriteC * 1)()
+    cw[0].physical_type, cw[0].is_nullable, cw[0].rows = col["ptype"], 1, col["rows"]
+    cw[0].values, cw[0].values_len = col["values"].ctypes.data, col["values"].size
+    cw[0].validity, cw[0].offsets = col["validity"].ctypes.data, col["offsets"].ctypes.data
+    cw[0].out_pages, cw[0].out_capacity = out.ctypes.data, out.size
+    cw[0].out_metas, cw[0].n_pages_capacity = metas, npg.value
+    gpu_ctx._check(lib.sb_write_columns(h, cw, 1, C.byref(oc), N.SB_MEM_HOST))
+    gpu_ctx.synchronize()
+    assert cw[0].out_len == want_pages.size and np.array_equal(out[:cw[0].out_len], want_pages)
+    assert (out[cw[0].out_len:] == 0xA5).all()
+    # read back into host buffers with spare capacity
+    m = np.ascontiguousarray(want_metas)
+    cap = want["values"].size + 4096
+    v_out = np.full(cap, 0x5A, np.uint8)
+    o_out = np.zeros((col["rows"] + 1) * 4, np.uint8)
+    b_out = np.zeros((col["rows"] + 31) // 32 * 4, np.uint8)
+    cr = (N.ColumnReadC * 1)()
+    cr[0].physical_type, cr[0].is_nullable = col["ptype"], 1
+    cr[0].pages, cr[0].pages_len = out.ctypes.data, int(cw[0].out_len)
+    cr[0].metas, cr[0].n_pages = m.ctypes.data_as(C.POINTER(N.PageMetaC)), m.shape[0]
+    cr[0].values, cr[0].values_capacity = v_out.ctypes.data, v_out.size
+    cr[0].validity, cr[0].validity_capacity = b_out.ctypes.data, b_out.size
+    cr[0].offsets, cr[0].offsets_capacity = o_out.ctypes.data, o_out.size
+    gpu_ctx._check(lib.sb_read_columns(h, cr, 1, N.SB_MEM_HOST))
+    gpu_ctx.synchronize()
+    assert cr[0].values_len == want["values"].size
+    assert np.array_equal(v_out[:cr[0].values_len], want["values"]) and (v_out[cr[0].values_len:] == 0x5A).all()
+    assert np.array_equal(o_out, want["offsets"]) and np.array_equal(b_out[:(col["rows"] + 7) // 8], want["validity"])

@@ -5,17 +5,21 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
 resident in HBM: encode the batch (Arrow buffers -> strawboat pages) and decode the pages it
 produced back (pages -> Arrow buffers), through the C ABI of libstrawboat_hip.so.
 
-Workload at N=1 (BASELINE.json configs[1], "C2"): columns of 1 M-row nullable Float64,
+Headline workload at N=1 (BASELINE.json configs[1], "C2"): columns of 1 M-row nullable Float64,
 64 Ki-row pages, value = float(k) with k piecewise constant (run length ~ Geometric(mean 32),
 k uniform in [0,256)), 10 % nulls.  The batch is `--columns` such columns (default 512 =
 512 M rows, 4.16 GB of Arrow bytes, 8192 pages): far beyond the 256 MB Infinity Cache
 (SURVEY.md §8d), and enough pages that the one-workgroup-per-page kernels run several rounds per
-CU instead of exactly one (with 64 columns = 1024 pages = 4 per CU every phase of every workgroup
-runs in lockstep and the fixed ~0.15 ms of small kernels and launch gaps weighs 20 %; at 256 columns it
-still weighs 10 %, at 512 columns 6 %).  Default mode "adaptive": default_compress_ratio = 2.0 and the codec of every
-page is chosen on the device by the reference's selector (it picks RLE for this data: sampled
-ratio ~14 vs Dict 7.6 vs Patas < 4; the CPU oracle agrees, tests/test_oracle_golden.py).  Nothing is in
+CU.  Mode "adaptive": default_compress_ratio = 2.0 and the codec of every page is chosen on the
+device by the reference's selector (RLE for this data; the CPU oracle agrees).  Nothing is in
 forbidden_compressions: every codec of the reference is a candidate, as with its default options.
+
+`configs` (same JSON line, N=1 only): every other BASELINE.json configuration and the reference's
+own bench shapes (benches/write_strawboat.rs:30-67), each with encode / decode GB/s of Arrow bytes,
+the fraction of the HBM roofline its algorithmic bytes reach per direction, the kernel that
+dominates each direction, and the CPU restatement timed on this box (1 thread and all cores).
+C2 is the FRIENDLIEST configuration (16x compressible runs); the LZ4 / Dict / nested ones are
+one to two orders of magnitude slower per Arrow byte — read `configs`, not only `value`.
 
 Multi-GPU (torchrun, one rank per GPU): every rank owns its own `--columns` columns (weak
 scaling, pages of independent columns shard with no data-path collective); the only collective
@@ -27,6 +31,7 @@ import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -34,21 +39,342 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import workloads as W  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 ROWS = 1_000_000
 PAGE = 65536
+METRIC = "encode+decode GB/s (uncompressed Arrow bytes) per GPU; 1/2/4/8-GPU scaling"
 
 
 def gen_c2_column(seed, rows=ROWS):
-    rng = np.random.default_rng(seed)
-    nrun = rows // 16 + 64
-    lens = rng.geometric(1.0 / 32.0, nrun)
-    while lens.sum() < rows:
-        lens = np.concatenate([lens, rng.geometric(1.0 / 32.0, nrun)])
-    k = rng.integers(0, 256, lens.size)
-    vals = np.repeat(k, lens)[:rows].astype(np.float64)
-    valid = np.packbits(rng.random(rows) < 0.9, bitorder="little")
-    return vals, valid
+    return W.c2_values(seed, rows)
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def gen_parallel(fn, seeds):
+    with ThreadPoolExecutor(max_workers=min(16, host_cores())) as ex:
+        return list(ex.map(fn, seeds))
+
+
+def cpu_baseline(cols, sbo_opts, arrow_bytes, sample_desc, rep_for_all_cores=True):
+    """CPU restatement (oracle) over the (column, page) items of `cols`: 1 thread — how the reference runs —
+    and page-parallel over all host cores.  Bounded: the sample is sized by the caller."""
+    from oracle import sbo
+    cores = host_cores()
+    tw, tr, _ = sbo.time_pages_mt(cols, sbo_opts, threads=1, iters=2)
+    one = {"value": round(2.0 * arrow_bytes / (tw + tr) / 1e9, 3), "encode": round(arrow_bytes / tw / 1e9, 3),
+           "decode": round(arrow_bytes / tr / 1e9, 3)}
+    rep = 1
+    if rep_for_all_cores:
+        ps = sbo_opts.max_page_size or max(c["rows"] for c in cols)
+        pages = sum((c["rows"] + ps - 1) // ps for c in cols)
+        rep = max(1, -(-4 * cores // max(pages, 1)))   # >= 4 work items per core
+        rep = min(rep, 64)
+    twm, trm, _ = sbo.time_pages_mt(cols * rep, sbo_opts, threads=cores, iters=2)
+    allc = {"value": round(2.0 * arrow_bytes * rep / (twm + trm) / 1e9, 3), "encode": round(arrow_bytes * rep / twm / 1e9, 3),
+            "decode": round(arrow_bytes * rep / trm / 1e9, 3), "cores": cores, "sample_replicas": rep}
+    return {"value": one["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": sample_desc,
+            "one_thread": one, "all_cores": allc, "cpu_model": cpu_model(),
+            "note": "C++ restatement of sundy-li/strawboat's algorithm (oracle/), not the Rust binary; its LZ4 / Zstd / "
+                    "Snappy are the oracle's own implementations, not liblz4 / libzstd"}
+
+
+class GpuHarness:
+    def __init__(self, ctx):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.dev = ctx.torch_device
+
+    def up(self, a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a)
+        return self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.dev)
+
+    def dcol(self, col):
+        from strawboat_amd import write
+        return write.DeviceColumn(col["ptype"], col["nullable"], col["rows"], self.up(col["values"]),
+                                  self.up(col["validity"]), self.up(col["offsets"]))
+
+    def check_round_trip(self, col, dec):
+        """decoded buffers == the Arrow buffers they came from (null slots of primitives excepted: RLE / Dict / Freq
+        pages do not keep them, like the reference)"""
+        torch = self.torch
+        n = col["rows"]
+        if col["nullable"] and col["validity"] is not None:
+            assert np.array_equal(dec.validity_numpy(), col["validity"][:(n + 7) // 8]), "validity round trip failed"
+        if col["offsets"] is not None:
+            go, gv = dec.offsets_numpy().view(np.int32).astype(np.int64), dec.values_numpy()
+            ro, rv = col["offsets"].astype(np.int64), col["values"]
+            if col["validity"] is None:
+                assert np.array_equal(go, ro) and np.array_equal(gv, rv), "binary round trip failed"
+                return
+            m = np.unpackbits(col["validity"], bitorder="little")[:n].astype(bool)   # null slots: Dict pages repeat a neighbour
+            assert np.array_equal((go[1:] - go[:-1])[m], (ro[1:] - ro[:-1])[m]), "string lengths round trip failed"
+            rows = np.flatnonzero(m)[::max(1, int(m.sum()) // 2000)]
+            for r in rows:
+                assert np.array_equal(gv[go[r]:go[r + 1]], rv[ro[r]:ro[r + 1]]), "string bytes round trip failed (row %d)" % r
+            return
+        if col["ptype"] == W.T_BOOL:
+            got = np.unpackbits(dec.values_numpy(), bitorder="little")[:n]
+            ref = np.unpackbits(col["values"], bitorder="little")[:n]
+        else:
+            got = dec.values_numpy().view(col["values"].dtype)
+            ref = col["values"]
+        if col["validity"] is not None:
+            m = np.unpackbits(col["validity"], bitorder="little")[:n].astype(bool)
+            got, ref = got[m], ref[m]
+        assert np.array_equal(got.view(np.uint8), np.ascontiguousarray(ref).view(np.uint8)), "value round trip failed"
+        del torch
+
+    def measure_flat(self, cols, opts, reps=5, check=1):
+        """encode / decode of a batch of flat columns: ms per direction (HIP events on the context's stream), Arrow and
+        page bytes, per-kernel HIP-event times of one profiled pass"""
+        from strawboat_amd import read, write
+        torch, ctx = self.torch, self.ctx
+        dc = [self.dcol(c) for c in cols]
+        U = sum(W.arrow_bytes(c) for c in cols)
+        enc = write.encode_columns(ctx, dc, opts)
+        ctx.synchronize()
+        pages = [read.ColumnPages(c["ptype"], c["nullable"], e.pages, e.metas_array()) for c, e in zip(cols, enc)]
+        dec = read.batch_read_columns(ctx, pages)
+        ctx.synchronize()
+        for i in range(min(check, len(cols))):
+            self.check_round_trip(cols[i], dec[i])
+        pb = sum(e.length for e in enc)
+        npages = sum(e.n_pages for e in enc)
+        wb, rb = write.WriteBatch(ctx, dc, opts, out=enc), read.ReadBatch(ctx, pages, out=dec)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        wb.enqueue()
+        rb.enqueue()
+        ctx.synchronize()
+        with torch.cuda.stream(ctx.torch_stream):
+            ev[0].record()
+            for _ in range(reps):
+                wb.enqueue()
+            ev[1].record()
+            for _ in range(reps):
+                rb.enqueue()
+            ev[2].record()
+        ctx.synchronize()
+        te, td = ev[0].elapsed_time(ev[1]) / reps, ev[1].elapsed_time(ev[2]) / reps
+        ctx.profile(True)
+        wb.enqueue()
+        rb.enqueue()
+        ctx.synchronize()
+        st = ctx.profile_read()
+        ctx.profile(False)
+        return dict(U=U, page_bytes=pb, n_pages=npages, enc_ms=te, dec_ms=td, kernels=st, enc=enc)
+
+
+def direction_summary(U, pb, ms, kernels, encode):
+    """GB/s of Arrow bytes, fraction of the HBM roofline reached by the direction's algorithmic bytes
+    (A_enc = Arrow bytes read + page bytes written, A_dec = page bytes read + Arrow bytes written),
+    and the kernel that dominates the direction"""
+    ks = {k: v for k, v in kernels.items() if k.startswith("k_enc") == encode}
+    tot = sum(v[1] for v in ks.values()) or 1.0
+    top = max(ks.items(), key=lambda kv: kv[1][1]) if ks else (None, (0, 0.0))
+    A = U + pb
+    return {"GBps": round(U / ms / 1e6, 1), "ms": round(ms, 3), "frac_hbm": round(A / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "top_kernel": top[0], "top_kernel_ms": round(top[1][1], 3), "top_kernel_share": round(top[1][1] / tot, 3)}
+
+
+def config_entry(name, res, cpu, extra=None):
+    U, pb = res["U"], res["page_bytes"]
+    e = {"arrow_MB": round(U / 1e6, 1), "page_MB": round(pb / 1e6, 1), "pages": res["n_pages"],
+         "encdec_GBps": round(2.0 * U / (res["enc_ms"] + res["dec_ms"]) / 1e6, 1),
+         "encode": direction_summary(U, pb, res["enc_ms"], res["kernels"], True),
+         "decode": direction_summary(U, pb, res["dec_ms"], res["kernels"], False),
+         "cpu_baseline": cpu}
+    if extra:
+        e.update(extra)
+    return e
+
+
+def sbo_options(opts):
+    from oracle import sbo
+    return sbo.make_options(default_compression=opts.default_compression, ratio=opts.default_compress_ratio,
+                            max_page_size=opts.max_page_size, forbidden=tuple(opts.forbidden_compressions),
+                            force_codec=opts.force_codec, force_index_codec=opts.force_index_codec,
+                            rng_seed=opts.rng_seed)
+
+
+def page_codecs(col, enc):
+    """codec ids of a column's pages (page inspector, strawboat_amd.stat)"""
+    from strawboat_amd import stat
+    from strawboat_amd.types import Compression
+    ids = set()
+    pages = enc.pages_numpy()
+    off = 0
+    for m in enc.metas:
+        info = stat.stat_page(pages[off:off + m.length], col["ptype"], col["nullable"])
+        chain = []
+        while info is not None:
+            chain.append(Compression.NAMES.get(info.codec, str(info.codec)))
+            info = info.body.indices or info.body.exceptions
+        ids.add(">".join(chain))
+        off += m.length
+    return sorted(ids)
+
+
+def run_configs(h, only, cpu_on, log):
+    """every BASELINE.json configuration but the headline, and the reference's bench shapes, on one GPU"""
+    from strawboat_amd.types import Compression as C, WriteOptions
+    out = {}
+
+    def want(k):
+        return only is None or k in only
+
+    def flat(key, desc, cols, opts, cpu_cols, reps=5, codecs=True):
+        t0 = time.time()
+        res = h.measure_flat(cols, opts, reps=reps)
+        cpu = None
+        if cpu_on:
+            cu = sum(W.arrow_bytes(c) for c in cpu_cols)
+            cpu = cpu_baseline(cpu_cols, sbo_options(opts), cu,
+                               "%d column(s) x %d rows of this configuration, encode+decode" % (len(cpu_cols), cpu_cols[0]["rows"]))
+        extra = {"workload": desc}
+        if codecs:
+            try:
+                extra["codecs_of_column_0"] = page_codecs(cols[0], res["enc"][0])
+            except Exception as e:  # the inspector is informative only
+                extra["codecs_of_column_0"] = "n/a (%s)" % type(e).__name__
+        out[key] = config_entry(key, res, cpu, extra)
+        log("%s: encode %.1f GB/s, decode %.1f GB/s (%.1f s)" % (key, out[key]["encode"]["GBps"], out[key]["decode"]["GBps"], time.time() - t0))
+
+    if want("c1"):
+        cols = gen_parallel(W.c1_int64, range(42, 42 + 128))
+        flat("c1", "C1: 128 x 1M-row non-nullable Int64, one page per column, no compression (the north-star "
+                   "'1 M-row primitive-page decode' shape)", cols, WriteOptions(), cols[:2], reps=10)
+    if want("c3") or want("c3_lz4"):
+        cols = gen_parallel(lambda s: W.zipf_utf8(ROWS, s), range(42, 42 + 64))
+        if want("c3"):
+            flat("c3", "C3: 64 x 1M-row Utf8 (zipf 1.1 over 10 000 words of 4..24 B), 64Ki-row pages, LZ4 default, ratio 2.0 "
+                       "-> Dict pages with Bitpacking / LZ4 indices", cols,
+                 WriteOptions(max_page_size=PAGE, default_compression=C.LZ4, default_compress_ratio=2.0), cols[:1], reps=3)
+        if want("c3_lz4"):
+            flat("c3_lz4", "C3': the same columns, Basic(LZ4) pages (offsets block + values block), ratio None", cols,
+                 WriteOptions(max_page_size=PAGE, default_compression=C.LZ4), cols[:1], reps=3)
+        del cols
+    if want("c4"):
+        named = W.c4_columns(10_000_000)
+        cols = [c for _, c in named]
+        opts = WriteOptions(max_page_size=PAGE, default_compression=C.LZ4, default_compress_ratio=2.0)
+        cpu_cols = [dict(c, rows=ROWS, values=(c["values"][:ROWS] if c["offsets"] is None and c["ptype"] != W.T_BOOL else c["values"]),
+                         offsets=None if c["offsets"] is None else c["offsets"][:ROWS + 1]) for c in cols[::2]]
+        for c in cpu_cols:
+            if c["offsets"] is not None:
+                c["values"] = c["values"][:int(c["offsets"][-1])]
+        flat("c4", "C4: the 8-column mixed schema {Int32 x2, Float64 x2, Utf8 x2, Boolean x2} x 10 M rows (153 pages per "
+                   "column), LZ4 default, ratio 2.0, all 8 columns on this GPU; CPU sample = the first 1 M rows of one column "
+                   "per type", cols, opts, cpu_cols, reps=3, codecs=False)
+        per = {}
+        for (nm, c) in named[::2]:
+            r = h.measure_flat([c], opts, reps=3, check=0)
+            per[nm.split("_")[0]] = {"encode_GBps": round(r["U"] / r["enc_ms"] / 1e6, 1), "decode_GBps": round(r["U"] / r["dec_ms"] / 1e6, 1),
+                                     "codecs": page_codecs(c, r["enc"][0])}
+        out["c4"]["per_column_type"] = per
+        del named, cols
+    if want("c5"):
+        out["c5"] = run_c5(h, cpu_on)
+        log("c5: encode %.2f GB/s, decode %.2f GB/s" % (out["c5"]["encode"]["GBps"], out["c5"]["decode"]["GBps"]))
+    if want("continuity"):
+        o = WriteOptions(max_page_size=8192, default_compression=C.LZ4)
+        cont = {}
+        for nm, fn, B in (("bool", W.cont_bool, 512), ("utf8", W.cont_utf8, 128), ("i64", W.cont_i64, 128)):
+            cols = gen_parallel(lambda s: fn(1 << 20, s), range(42, 42 + B))
+            res = h.measure_flat(cols, o, reps=3)
+            cpu = None
+            if cpu_on:
+                cpu = cpu_baseline(cols[:1], sbo_options(o), W.arrow_bytes(cols[0]), "1 column x 2^20 rows, encode+decode")
+            e = config_entry(nm, res, cpu, {"workload": "%d x 2^20-row %s columns, nullable field, LZ4, page 8192, ratio None "
+                                                        "(benches/write_strawboat.rs:30-67), batched" % (B, nm)})
+            lat = {}
+            for p in range(10, 21, 2):   # the reference's own sizes, one column per call: wall ms per write (criterion's unit)
+                c1 = fn(1 << p, 42)
+                r = h.measure_flat([c1], o, reps=5, check=1)
+                lat["2^%d" % p] = {"write_ms": round(r["enc_ms"], 3), "read_ms": round(r["dec_ms"], 3)}
+            e["single_column_latency"] = lat
+            cont[nm] = e
+            log("continuity %s: encode %.1f GB/s, decode %.1f GB/s" % (nm, e["encode"]["GBps"], e["decode"]["GBps"]))
+            del cols
+        out["continuity"] = cont
+    return out
+
+
+def run_c5(h, cpu_on):
+    """C5: 1 M-row List<Struct<Int64,Utf8>>, Zstd default, ratio None: 2 leaf columns x 16 pages through the nested
+    API (level sections on the device + leaf blocks through the flat path).  The calls are synchronous per leaf
+    column, so this is wall time."""
+    from strawboat_amd import nested
+    from strawboat_amd.read import ColumnPages
+    from strawboat_amd.types import Compression as C, WriteOptions
+    ctx = h.ctx
+    la, a, lb, b = W.c5_nested()
+    opts = WriteOptions(max_page_size=PAGE, default_compression=C.ZSTD)
+
+    def dlevels(levels):
+        return [nested.NestedLevel(lv["kind"], bool(lv["is_optional"]), lv["length"], h.up(lv.get("validity")), h.up(lv.get("offsets")))
+                for lv in levels]
+    items = [(dlevels(la), h.dcol(a), a, la), (dlevels(lb), h.dcol(b), b, lb)]
+    for _, dc, _, _ in items:
+        dc.is_nullable = False
+    rows = la[0]["length"]
+    U = W.arrow_bytes(a) + W.arrow_bytes(b) + 2 * ((rows + 1) * 4 + (rows + 7) // 8)   # leaves + list offsets / validity per leaf path
+    encs = [nested.write_nested(ctx, dl, dc, opts) for dl, dc, _, _ in items]      # warm-up + outputs
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        encs = [nested.write_nested(ctx, dl, dc, opts) for dl, dc, _, _ in items]
+    te = (time.perf_counter() - t0) / reps * 1e3
+    cps = [ColumnPages(c["ptype"], False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (_, _, c, _) in zip(encs, items)]
+    kinds = [[lv["kind"] for lv in lv_] for _, _, _, lv_ in items]
+    opt = [[bool(lv["is_optional"]) for lv in lv_] for _, _, _, lv_ in items]
+    arrs = [nested.read_nested(ctx, cp, k, o) for cp, k, o in zip(cps, kinds, opt)]
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        arrs = [nested.read_nested(ctx, cp, k, o) for cp, k, o in zip(cps, kinds, opt)]
+    td = (time.perf_counter() - t0) / reps * 1e3
+    # round trip: list offsets and leaf buffers
+    assert np.array_equal(arrs[0].offsets_numpy(0), la[0]["offsets"].astype(np.int64)), "C5 list offsets round trip failed"
+    assert np.array_equal(arrs[1].leaf.values_numpy(), b["values"]), "C5 Utf8 leaf round trip failed"
+    m = np.unpackbits(a["validity"], bitorder="little")[:a["rows"]].astype(bool)
+    assert np.array_equal(arrs[0].leaf.values_numpy().view(np.int64)[m], a["values"][m]), "C5 Int64 leaf round trip failed"
+    ctx.profile(True)
+    [nested.write_nested(ctx, dl, dc, opts) for dl, dc, _, _ in items]
+    [nested.read_nested(ctx, cp, k, o) for cp, k, o in zip(cps, kinds, opt)]
+    st = ctx.profile_read()
+    ctx.profile(False)
+    pb = sum(e.length for e in encs)
+    res = dict(U=U, page_bytes=pb, n_pages=sum(e.n_pages for e in encs), enc_ms=te, dec_ms=td, kernels=st)
+    cpu = None
+    if cpu_on:   # leaf blocks only (the level arithmetic has no page-parallel CPU leg in the oracle)
+        from oracle import sbo
+        o = sbo.make_options(default_compression=sbo.ZSTD, max_page_size=PAGE)
+        cpu = cpu_baseline([dict(a, nullable=False), dict(b, nullable=False)], o, W.arrow_bytes(a) + W.arrow_bytes(b),
+                           "the two leaf columns as flat non-nullable columns (leaf blocks only, no level sections); the oracle's "
+                           "Zstd encoder is store-only")
+    return config_entry("c5", res, cpu, {"workload": "C5: 1 M-row List<Struct<Int64,Utf8>> (list length U{0,1,2}, 10 % null lists, leaves 20 % "
+                                                     "null), 64Ki-row pages, Zstd default, ratio None; 2 leaf columns x 16 pages; synchronous nested "
+                                                     "API, wall time incl. host work"})
 
 
 def main():
@@ -60,6 +386,9 @@ def main():
     ap.add_argument("--codec", default="adaptive", choices=["adaptive", "rle", "none", "dict"],
                     help="adaptive = default_compress_ratio 2.0, codec chosen per page on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sweep over the other configurations")
+    ap.add_argument("--only", default=None, help="comma list of configs (c1,c3,c3_lz4,c4,c5,continuity): run ONLY these, "
+                                                 "without the headline (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -79,8 +408,17 @@ def main():
     from strawboat_amd import read, write
     from strawboat_amd.types import Compression, PhysicalType, WriteOptions
 
+    def log(msg):
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
     dev = torch.device("cuda", local_rank)
     ctx = sb.Context(local_rank)
+    harness = GpuHarness(ctx)
+    if args.only:
+        res = run_configs(harness, set(args.only.split(",")), not args.no_cpu_baseline, log)
+        print(json.dumps({"metric": METRIC, "configs": res, "hbm_peak_GBps": HBM_PEAK_GBS}))
+        return
+
     B = args.columns
     codec = {"adaptive": -1, "rle": Compression.RLE, "none": Compression.NONE, "dict": Compression.DICT}[args.codec]
     if codec < 0:   # the reference's adaptive mode with its default options: nothing forbidden
@@ -89,16 +427,12 @@ def main():
     else:
         opts = WriteOptions(max_page_size=PAGE, force_codec=codec)
 
-    # ---- synthetic batch, resident in HBM before the timed region
-    cols = []
-    host0 = None
-    for b in range(B):
-        vals, valid = gen_c2_column(42 + 1000 * rank + b)
-        if b == 0:
-            host0 = (vals, valid)
-        cols.append(write.DeviceColumn(PhysicalType.FLOAT64, True, ROWS,
-                                       torch.from_numpy(vals.view(np.uint8)).to(dev),
-                                       torch.from_numpy(valid).to(dev)))
+    # ---- synthetic batch, resident in HBM before the timed region (every column from its own seed)
+    gen = gen_parallel(gen_c2_column, [42 + 1000 * rank + b for b in range(B)])
+    host0 = gen[0]
+    cols = [write.DeviceColumn(PhysicalType.FLOAT64, True, ROWS, torch.from_numpy(v.view(np.uint8)).to(dev),
+                               torch.from_numpy(m).to(dev)) for v, m in gen]
+    del gen
     torch.cuda.synchronize()
     U_col = ROWS * 8 + (ROWS + 7) // 8          # uncompressed Arrow bytes of one column
     U = U_col * B
@@ -163,34 +497,37 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: algorithmic bytes / HIP-event time
-        A = {"k_expand": page_bytes + U,            # A_dec = page bytes read + Arrow bytes written
-             "k_expand_rle": page_bytes + U,
-             "k_enc_emit_pages": U + page_bytes,    # A_enc = Arrow bytes read + page bytes written
-             "k_enc_emit_tiles": U + page_bytes,
-             "k_enc_select": U + page_bytes}        # fused selection + RLE: Arrow bytes read once, pages written
+        Abytes = {"k_expand": page_bytes + U,            # A_dec = page bytes read + Arrow bytes written
+                  "k_expand_rle": page_bytes + U,
+                  "k_enc_emit_pages": U + page_bytes,    # A_enc = Arrow bytes read + page bytes written
+                  "k_enc_emit_tiles": U + page_bytes,
+                  "k_enc_select_runs": U + page_bytes,   # fused selection + RLE: Arrow bytes read once, pages written
+                  "k_enc_select_rle": U + page_bytes,
+                  "k_enc_select": U + page_bytes}
         base = lambda k: k.split("<")[0]
-        dom = max((k for k in stats if base(k) in A), key=lambda k: stats[k][1], default=None)
+        dom = max((k for k in stats if base(k) in Abytes), key=lambda k: stats[k][1], default=None)
         roof = None
         if dom:
             n, tot = stats[dom]
             avg_ms = tot / n
-            A = {k: A[base(k)] for k in stats if base(k) in A}
-            achieved = A[dom] / (avg_ms * 1e-3) / 1e9
+            achieved = Abytes[base(dom)] / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_kernel_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": A[dom]}
+                    "avg_kernel_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": Abytes[base(dom)]}
         kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / v[0], 4)} for k, v in stats.items()}
         # HBM traffic of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate passes of this same command; summary committed under profiles/)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if roof and pmc["config"] == {"workload": "C2", "columns_per_gpu": B, "codec": args.codec}:
-                cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0].startswith(dom.split("<")[0])]
-                if cand:
-                    roof["traffic"] = max(cand)   # several template instances share a name: the one that did the work
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC, per launch, gfx950 FETCH_SIZE x2 correction)"
-        except (OSError, KeyError, ValueError):
-            pass
+        for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
+                if roof and pmc["config"] == {"workload": "C2", "columns_per_gpu": B, "codec": args.codec}:
+                    cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0].startswith(dom.split("<")[0])]
+                    if cand:
+                        roof["traffic"] = max(cand)   # several template instances share a name: the one that did the work
+                        roof["traffic_source"] = "profiles/%s (PMC, per launch, gfx950 FETCH_SIZE x2 correction)" % pf
+                        break
+            except (OSError, KeyError, ValueError):
+                pass
 
         cpu = None
         if not args.no_cpu_baseline:
@@ -199,13 +536,16 @@ def main():
                 o = sbo.make_options(max_page_size=PAGE, ratio=2.0, forbidden=())
             else:
                 o = sbo.make_options(max_page_size=PAGE, force_codec=codec)
-            tw, tr = sbo.time_roundtrip(sbo.T_F64, True, ROWS, host0[0], validity=host0[1], options=o, iters=3)
-            cpu = {"value": round(2.0 * U_col / (tw + tr) / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-                   "sample": "1 column (1 M rows, 16 pages) of the same workload, encode+decode, best of 3, "
-                             "single thread (the reference is single-threaded); C++ restatement, not the Rust binary",
-                   "encode_s": round(tw, 4), "decode_s": round(tr, 4)}
+            c0 = dict(ptype=sbo.T_F64, nullable=True, rows=ROWS, values=host0[0], validity=host0[1], offsets=None)
+            cpu = cpu_baseline([c0], o, U_col, "1 column (1 M rows, 16 pages) of the same workload, encode+decode, best of 2; the all-cores "
+                                               "leg runs replicas of it page-parallel over std::threads")
+        configs = None
+        if world == 1 and not args.no_configs:
+            del wbatch, rbatch, enc, dec, pages, cols
+            torch.cuda.empty_cache()
+            configs = run_configs(harness, None, not args.no_cpu_baseline, log)
         out = {
-            "metric": "encode+decode GB/s (uncompressed Arrow bytes) per GPU; 1/2/4/8-GPU scaling",
+            "metric": METRIC,
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 bit patterns (integer/bit work, no arithmetic)",
@@ -214,8 +554,9 @@ def main():
                                    "inputs resident in HBM" % (B, args.codec),
                        "columns_per_gpu": B, "rows_per_column": ROWS, "page_rows": PAGE,
                        "arrow_bytes_per_step": U, "page_bytes_per_step": page_bytes,
-                       "parallelism": "pages of independent columns sharded across %d GPU(s)" % world},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+                       "parallelism": "pages of independent columns sharded across %d GPU(s)" % world,
+                       "note": "C2 is the most compressible configuration (RLE, 16x): see `configs` for the others"},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "configs": configs,
         }
         print(json.dumps(out))
     if world > 1:

@@ -89,9 +89,16 @@ typedef struct sb_write_options {
     uint32_t forbidden_compressions;   /* bit (1u << codec id) set = forbidden */
     int32_t force_codec;               /* -1 = choose; else the page codec */
     int32_t force_index_codec;         /* -1 = choose; else codec of Dict indices / Freq exceptions */
-    int32_t reserved;
+    uint32_t flags;                    /* SB_WRITE_* bits, 0 = defaults */
     uint64_t rng_seed;                 /* column-level seed; page p uses mix64(seed ^ p*K) */
 } sb_write_options;
+
+/* sb_write_options.flags.
+ * SB_WRITE_LZ4_EXACT: LZ4 blocks byte-identical to liblz4's LZ4_compress_default (what the reference's lz4 crate calls,
+ * src/compression/basic.rs:108-120) — the serial greedy parse, ~10x slower on the device.  Default: a parallel
+ * parse that emits a format-valid block every LZ4 decoder (hence the reference) reads back to the same bytes;
+ * compressed-byte identity is library-version dependent upstream (no lockfile) and not part of the page layout. */
+#define SB_WRITE_LZ4_EXACT 1u
 
 typedef struct sb_ctx sb_ctx;
 

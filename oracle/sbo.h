@@ -157,6 +157,7 @@ void write_column(const ColumnIn& col, const WriteOptions& opts, std::vector<uin
                   std::vector<PageMeta>& metas);
 // write::write for one already-sliced page (src/write/serialize.rs:36-132)
 void write_page(const ColumnIn& page, const WriteOptions& opts, std::vector<uint8_t>& out);
+size_t type_width(int32_t ptype);
 // batch_read::read_simple (src/read/batch_read.rs:27-64) → read_integer & co
 void read_column(int32_t ptype, bool nullable, const uint8_t* pages, uint64_t pages_len,
                  const PageMeta* metas, uint64_t n_pages, ColumnOut& out);

@@ -56,6 +56,8 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.sbo_write_column.restype = C.c_void_p
         L.sbo_write_column.argtypes = [C.POINTER(_ColumnIn), C.POINTER(_Options), C.c_char_p, C.c_size_t]
+        L.sbo_write_page.restype = C.c_void_p
+        L.sbo_write_page.argtypes = [C.POINTER(_ColumnIn), C.POINTER(_Options), C.c_char_p, C.c_size_t]
         for name in ("sbo_written_len", "sbo_written_npages", "sbo_read_rows", "sbo_read_values_len",
                      "sbo_read_validity_len", "sbo_read_offsets_len"):
             getattr(L, name).restype = C.c_uint64
@@ -93,6 +95,9 @@ def lib():
         L.sbo_time_roundtrip.restype = C.c_int32
         L.sbo_time_roundtrip.argtypes = [C.POINTER(_ColumnIn), C.POINTER(_Options), C.c_int32, C.c_void_p,
                                          C.c_char_p, C.c_size_t]
+        L.sbo_time_pages_mt.restype = C.c_int32
+        L.sbo_time_pages_mt.argtypes = [C.POINTER(_ColumnIn), C.c_uint64, C.POINTER(_Options), C.c_int32, C.c_int32,
+                                        C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -167,6 +172,32 @@ def write_column(ptype, nullable, rows, values=None, validity=None, offsets=None
     return data, metas
 
 
+def write_page(ptype, nullable, rows, values=None, validity=None, offsets=None, options=None,
+               values_bit_offset=0, validity_bit_offset=0):
+    """write::write_simple for ONE page (rows may be 0: the leaf block of a nested page without leaf slots)."""
+    L = lib()
+    keep = []
+    if rows == 0:
+        values = np.zeros(8, np.uint8) if values is None or np.asarray(values).size == 0 else values
+        if ptype in (T_BIN32, T_BIN64) and (offsets is None or np.asarray(offsets).size == 0):
+            offsets = np.zeros(1, np.int32 if ptype == T_BIN32 else np.int64)
+    c = _column_in(ptype, nullable, rows, values, validity, offsets, values_bit_offset, validity_bit_offset, keep)
+    if rows == 0 and ptype in (T_BIN32, T_BIN64):
+        c.values_len = 0
+    o = options if options is not None else make_options()
+    err = C.create_string_buffer(512)
+    h = L.sbo_write_page(C.byref(c), C.byref(o), err, 512)
+    if not h:
+        raise OracleError(err.value.decode())
+    try:
+        n = L.sbo_written_len(h)
+        data = np.ctypeslib.as_array(C.cast(L.sbo_written_data(h), C.POINTER(C.c_uint8)), (n,)).copy() \
+            if n else np.zeros(0, np.uint8)
+    finally:
+        L.sbo_written_free(h)
+    return data
+
+
 def read_column(ptype, nullable, pages, metas):
     """batch_read::read_simple for one leaf column -> dict(rows, values, validity, offsets) of u8 arrays."""
     L = lib()
@@ -237,6 +268,24 @@ def time_roundtrip(ptype, nullable, rows, values=None, validity=None, offsets=No
     if L.sbo_time_roundtrip(C.byref(c), C.byref(o), iters, _ptr(out2), err, 512) != 0:
         raise OracleError(err.value.decode())
     return float(out2[0]), float(out2[1])
+
+
+def time_pages_mt(columns, options=None, threads=1, iters=2):
+    """CPU baseline over the (column, page) items of `columns` (dicts: ptype, nullable, rows, values, validity,
+    offsets) with `threads` std::threads: (seconds to encode, seconds to decode, page bytes)."""
+    L = lib()
+    keep = []
+    arr = (_ColumnIn * len(columns))()
+    for i, col in enumerate(columns):
+        arr[i] = _column_in(col["ptype"], col["nullable"], col["rows"], col["values"], col.get("validity"),
+                            col.get("offsets"), 0, 0, keep)
+    o = options if options is not None else make_options()
+    out2 = np.zeros(2, np.float64)
+    nbytes = C.c_uint64(0)
+    err = C.create_string_buffer(512)
+    if L.sbo_time_pages_mt(arr, len(columns), C.byref(o), int(threads), int(iters), _ptr(out2), C.byref(nbytes), err, 512) != 0:
+        raise OracleError(err.value.decode())
+    return float(out2[0]), float(out2[1]), int(nbytes.value)
 
 
 # ---------------------------------------------------------------- nested (Dremel) level sections

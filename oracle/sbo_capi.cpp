@@ -1,5 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see sbo.h).  C ABI for ctypes (oracle/sbo.py).
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 
@@ -75,6 +80,26 @@ void* sbo_write_column(const sbo_column_in* c, const sbo_options* o, char* err, 
     sbo_written* w = new sbo_written();
     try {
         write_column(to_col(c), to_opts(o), w->bytes, w->metas);
+        return w;
+    } catch (const std::exception& e) {
+        set_err(err, errcap, e.what());
+        delete w;
+        return nullptr;
+    }
+}
+// One page through write::write_simple, rows may be 0: the leaf BLOCK of a nested page whose lists are all
+// empty / null.  write_nested (write/serialize.rs:134-198) still runs compress_* on the empty leaf slice:
+// every Extend codec's ratio is 0 or NaN on empty statistics, so the block is Basic(default_compression)
+// over zero bytes (hdr9 + the codec's encoding of an empty input).  A forced codec (this build's knob,
+// absent upstream) is not applied to an empty page.
+void* sbo_write_page(const sbo_column_in* c, const sbo_options* o, char* err, size_t errcap) {
+    sbo_written* w = new sbo_written();
+    try {
+        ColumnIn col = to_col(c);
+        WriteOptions wo = to_opts(o);
+        if (col.rows == 0) wo.force_codec = -1;
+        write_page(col, wo, w->bytes);
+        w->metas.push_back(PageMeta{(uint64_t)w->bytes.size(), col.rows});
         return w;
     } catch (const std::exception& e) {
         set_err(err, errcap, e.what());
@@ -215,6 +240,101 @@ int32_t sbo_time_roundtrip(const sbo_column_in* c, const sbo_options* o, int32_t
         }
         out2[0] = best_w;
         out2[1] = best_r;
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, errcap, e.what());
+        return -1;
+    }
+}
+
+// Page-parallel CPU baseline (leg 2): the (column, page) work items of `n_cols` columns are
+// pulled by `threads` std::threads from one atomic counter.  Phase 1 encodes every page (write_page on the
+// page's slice, the body of encode_chunk's loop), phase 2 decodes every page back (read_column on the
+// one-page column).  out2 = wall seconds of (encode phase, decode phase), best of `iters`;
+// out_bytes = page bytes produced.  threads = 1 is the single-threaded leg over the same items.
+int32_t sbo_time_pages_mt(const sbo_column_in* cols, uint64_t n_cols, const sbo_options* o, int32_t threads,
+                          int32_t iters, double* out2, uint64_t* out_bytes, char* err, size_t errcap) {
+    struct Item {
+        ColumnIn page;
+        WriteOptions opts;
+        std::vector<uint8_t> bytes;
+        PageMeta meta;
+    };
+    try {
+        WriteOptions w = to_opts(o);
+        std::vector<Item> items;
+        for (uint64_t ci = 0; ci < n_cols; ci++) {
+            ColumnIn col = to_col(&cols[ci]);
+            if (col.rows == 0) continue;
+            const uint64_t ps = w.max_page_size ? std::min<uint64_t>(w.max_page_size, col.rows) : col.rows;
+            const size_t wd = type_width(col.ptype);
+            uint64_t k = 0;
+            for (uint64_t off = 0; off < col.rows; off += ps, k++) {
+                Item it;
+                it.page = col;
+                it.page.rows = off + ps > col.rows ? col.rows - off : ps;
+                if (col.validity) it.page.validity_bit_offset = col.validity_bit_offset + off;
+                if (col.ptype == T_BOOL)
+                    it.page.values_bit_offset = col.values_bit_offset + off;
+                else if (col.ptype == T_BIN32)
+                    it.page.offsets = col.offsets + off * 4;
+                else if (col.ptype == T_BIN64)
+                    it.page.offsets = col.offsets + off * 8;
+                else
+                    it.page.values = col.values + off * wd;
+                it.opts = w;
+                it.opts.rng_seed = mix64(w.rng_seed ^ (k * 0xD6E8FEB86659FD93ull));
+                it.meta.num_values = it.page.rows;
+                it.meta.length = 0;
+                items.push_back(std::move(it));
+            }
+        }
+        if (threads < 1) threads = 1;
+        std::string first_error;
+        std::mutex mu;
+        auto run_phase = [&](bool encode) {
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                try {
+                    for (;;) {
+                        const size_t i = next.fetch_add(1);
+                        if (i >= items.size()) break;
+                        Item& it = items[i];
+                        if (encode) {
+                            it.bytes.clear();
+                            write_page(it.page, it.opts, it.bytes);
+                            it.meta.length = it.bytes.size();
+                        } else {
+                            ColumnOut out;
+                            read_column(it.page.ptype, it.page.nullable, it.bytes.data(), it.bytes.size(), &it.meta, 1, out);
+                        }
+                    }
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> g(mu);
+                    if (first_error.empty()) first_error = e.what();
+                }
+            };
+            auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> th;
+            for (int t = 1; t < threads; t++) th.emplace_back(worker);
+            worker();
+            for (auto& t : th) t.join();
+            return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        };
+        double best_w = 1e30, best_r = 1e30;
+        for (int it = 0; it < iters; it++) {
+            best_w = std::min(best_w, run_phase(true));
+            best_r = std::min(best_r, run_phase(false));
+        }
+        if (!first_error.empty()) {
+            set_err(err, errcap, first_error.c_str());
+            return -1;
+        }
+        uint64_t total = 0;
+        for (auto& it : items) total += it.bytes.size();
+        out2[0] = best_w;
+        out2[1] = best_r;
+        if (out_bytes) *out_bytes = total;
         return 0;
     } catch (const std::exception& e) {
         set_err(err, errcap, e.what());

@@ -1339,7 +1339,7 @@ static void read_validity(Reader& r, size_t length, BitBuilder& b) {
 }
 
 // ============================================================ page / column drivers
-static size_t type_width(int32_t t) {
+size_t type_width(int32_t t) {
     switch (t) {
         case T_I8:
         case T_U8:

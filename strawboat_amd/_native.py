@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libstrawboat_hip.so")
 SB_OK = 0
 SB_ERR_OUT_OF_SPEC, SB_ERR_EXTERNAL, SB_ERR_IO, SB_ERR_NYI, SB_ERR_INVALID = -1, -2, -3, -4, -5
 SB_MEM_DEVICE, SB_MEM_HOST = 0, 1
+SB_WRITE_LZ4_EXACT = 1
 
 # every symbol include/strawboat_hip.h declares
 EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
@@ -31,7 +32,7 @@ class WriteOptionsC(C.Structure):
     _fields_ = [("default_compression", C.c_int32), ("has_default_compress_ratio", C.c_int32),
                 ("default_compress_ratio", C.c_double), ("max_page_size", C.c_uint64),
                 ("forbidden_compressions", C.c_uint32), ("force_codec", C.c_int32),
-                ("force_index_codec", C.c_int32), ("reserved", C.c_int32), ("rng_seed", C.c_uint64)]
+                ("force_index_codec", C.c_int32), ("flags", C.c_uint32), ("rng_seed", C.c_uint64)]
 
 
 class ColumnReadC(C.Structure):

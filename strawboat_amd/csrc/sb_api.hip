@@ -12,6 +12,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
 void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len);
 void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, const uint64_t* ex_off, const uint8_t* ex_base);
 
+// names as rocprofv3 prints them (template instances are registered by name at their launch sites)
 static const char* const KERNEL_NAMES[K_COUNT] = {"k_parse", "k_inflate", "k_plan", "k_colscan", "k_inflate(values)",
                                                   "k_expand", "k_expand_binary", "k_enc_emit_tiles",
                                                   "k_enc_emit_pages<RLE>", "k_enc_layout", "k_enc_compact", "k_enc_select", "k_enc_emit_lz4",
@@ -48,6 +49,16 @@ StageSlot* acquire_slot(sb_ctx* ctx, size_t need) {
         (void)hipEventSynchronize(s.done);
         s.in_flight = false;
     }
+    // Results of earlier calls that were read back into this slot and not yet handed to their callers
+    // (more than NSLOTS calls since the last synchronize): move them to heap storage owned by the
+    // Pending entry before the slot is rewritten or freed.
+    if (s.host)
+        for (auto& p : ctx->pending) {
+            if (p.host < s.host || p.host >= s.host + s.cap) continue;
+            const size_t nb = p.kind == Pending::READ_COL ? 8 : (size_t)(2 * p.n + 1) * 8;
+            ctx->rescued.emplace_back(p.host, p.host + nb);
+            p.host = ctx->rescued.back().data();
+        }
     if (s.cap < need) {
         if (s.host) (void)hipHostFree(s.host);
         size_t cap = need + need / 4 + 4096;
@@ -117,6 +128,7 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return SB_ERR_EXTERNAL;
     sb_ctx* ctx = new sb_ctx();
     ctx->device = device;
+    for (int i = 0; i < K_COUNT; i++) ctx->prof_id(KERNEL_NAMES[i]);
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {
@@ -262,12 +274,20 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
     }
     if (rc == SB_OK) rc = freq_second_pass(ctx);
+    if (rc != SB_OK) {
+        // a failed interval: its Freq records point into buffers the caller may reuse — drop them all
+        for (auto& log : ctx->freq_logs) {
+            log.reserved = 0;
+            (void)hipMemsetAsync(log.dev, 0, 16, ctx->stream);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     for (auto& s : ctx->slots) s.in_flight = false;
     for (auto& sp : ctx->spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-            ctx->prof_ms[sp.id] += ms;
-            ctx->prof_n[sp.id] += 1;
+            ctx->prof[sp.id].ms += ms;
+            ctx->prof[sp.id].n += 1;
         }
         ctx->free_events.push_back(sp.a);
         ctx->free_events.push_back(sp.b);
@@ -291,6 +311,7 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         }
     }
     ctx->pending.clear();
+    ctx->rescued.clear();
     for (auto& cb : ctx->copybacks) {
         const size_t nb = cb.used ? (size_t)std::min<uint64_t>(cb.n, *cb.used) : cb.n;
         if (rc == SB_OK && nb) {
@@ -310,9 +331,9 @@ int32_t sb_ctx_profile(sb_ctx* ctx, int32_t enable) {
     if (!ctx) return SB_ERR_INVALID;
     int32_t rc = sb_ctx_synchronize(ctx);
     ctx->profile = enable != 0;
-    for (int i = 0; i < K_COUNT; i++) {
-        ctx->prof_ms[i] = 0;
-        ctx->prof_n[i] = 0;
+    for (auto& e : ctx->prof) {
+        e.ms = 0;
+        e.n = 0;
     }
     return rc;
 }
@@ -320,11 +341,11 @@ int32_t sb_ctx_profile(sb_ctx* ctx, int32_t enable) {
 uint32_t sb_ctx_profile_read(sb_ctx* ctx, sb_kernel_stat* out, uint32_t cap) {
     if (!ctx) return 0;
     uint32_t n = 0;
-    for (int i = 0; i < K_COUNT && n < cap; i++) {
-        if (!ctx->prof_n[i]) continue;
-        out[n].name = KERNEL_NAMES[i];
-        out[n].launches = ctx->prof_n[i];
-        out[n].total_ms = ctx->prof_ms[i];
+    for (size_t i = 0; i < ctx->prof.size() && n < cap; i++) {
+        if (!ctx->prof[i].n) continue;
+        out[n].name = ctx->prof[i].name.c_str();
+        out[n].launches = ctx->prof[i].n;
+        out[n].total_ms = ctx->prof[i].ms;
         n++;
     }
     return n;

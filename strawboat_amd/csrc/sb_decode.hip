@@ -20,6 +20,7 @@
 // LDS for the per-tile scans, wave64 shuffles for the scan carries.
 #include "sb_host.h"
 #include "sb_zstd.h"
+#include "sb_lz4.h"
 
 namespace sb {
 
@@ -609,7 +610,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
         if (j.codec == SB_CODEC_LZ4) {
-            lz4_inflate_wave(j, st);
+            // k_inflate_lz4 owns the LZ4 blocks
         } else if (j.codec == SB_CODEC_ZSTD) {
             zstd_inflate_wave(j.src, j.csize, j.dst, j.out_len, &wk, zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE);
             if (threadIdx.x == 0 && wk.err) raise(st, SB_ERR_EXTERNAL, j.page, 120 + (uint32_t)wk.err);
@@ -621,6 +622,20 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
         } else if (threadIdx.x == 0) {
             raise(st, SB_ERR_OUT_OF_SPEC, j.page, 110);
         }
+    }
+}
+
+// LZ4 blocks: one wave per block from a pool of waves that loops over the job queue (sb_lz4.h: compressed
+// bytes and an 8 KiB output window in LDS, speculative 64-position token parse, matches batched)
+constexpr uint32_t LZ4_POOL = 4096;
+__global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, const uint32_t* count, Status* st) {
+    __shared__ Lz4DecLds lds;
+    const uint32_t njobs = *count;
+    for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+        const InflateJob j = jobs[job];
+        if (j.codec != SB_CODEC_LZ4) continue;
+        const uint32_t e = lz4_inflate_block(j.src, j.csize, j.dst, j.out_len, lds);
+        if (e && threadIdx.x == 0) raise(st, SB_ERR_EXTERNAL, j.page, e);
     }
 }
 
@@ -1250,9 +1265,14 @@ __global__ void k_colscan(DecodeArgs a, uint64_t* col_values_len) {
         d.val_base = vbase;
         // page 0's offsets are taken verbatim (incl. offsets[0]); later pages add the running last offset
         d.off_base = obase;
+        // a page whose value bytes do not fit the caller's buffer is not expanded at all (the tile kernels
+        // skip !ok pages): nothing is written past values_cap, the column's values_len is still reported
+        const bool fits = vbase + d.val_bytes <= c.values_cap;
+        const bool was_ok = d.ok;
+        if (!fits) d.ok = 0;
         a.descs[p] = d;
-        if (!d.ok) continue;
-        if (is_basic(d.codec) && d.codec != SB_CODEC_NONE && vbase + d.vusize <= c.values_cap)
+        if (!was_ok) continue;
+        if (fits && is_basic(d.codec) && d.codec != SB_CODEC_NONE)
             push_job(a.jobs_b, a.job_counts + 1, d.vbody, d.vcsize, c.values + vbase, d.vusize, d.codec, p);
         vbase += d.val_bytes;
         obase += d.off_last;
@@ -1849,6 +1869,10 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
     }
     {
+        KScope k(ctx, "k_inflate_lz4");
+        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+    }
+    {
         KScope k(ctx, K_PLAN);
         k_plan<<<a.n_pages, WG, 0, s>>>(a);
     }
@@ -1859,6 +1883,8 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
         k_inflate<<<min(a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
+        KScope k2(ctx, "k_inflate_lz4(values)");
+        k_inflate_lz4<<<min(a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
     }
     if (any_prim) {
         KScope k(ctx, K_EXPAND_RLE);
@@ -1879,6 +1905,7 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     (void)hipMemsetAsync(a.job_counts, 0, 5 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
+    k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
 }

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "sb_host.h"
+#include "sb_lz4.h"
 
 namespace sb {
 
@@ -105,6 +106,7 @@ struct EncodeArgs {
     uint32_t null_cols;      // the batch holds Null columns (their empty pages are recorded by k_enc_emit_tiles)
     uint32_t page_base;   // first table entry this launch works on (0: pages, n_pages: virtual pages)
     int32_t nested_force; // force_index_codec: the codec forced on nested blocks (-1: none)
+    uint32_t flags;       // sb_write_options.flags (SB_WRITE_LZ4_EXACT)
 };
 
 __device__ __forceinline__ EncPage get_page(const EncodeArgs& a, uint32_t i) {
@@ -1193,6 +1195,13 @@ __device__ uint32_t lz4_compress_wave(const uint8_t* src, uint32_t n, uint8_t* d
     return op;
 }
 
+// LZ4 block of one page sub-buffer, executed by one wave.  Default: the parallel format-valid encoder (sb_lz4.h);
+// SB_WRITE_LZ4_EXACT: the serial greedy parse above, byte-identical to LZ4_compress_default.
+__device__ __forceinline__ uint32_t lz4_compress_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* ws16k, uint32_t flags) {
+    if (flags & SB_WRITE_LZ4_EXACT) return lz4_compress_wave(src, n, dst, ws16k);
+    return lz4_compress_wave_fast(src, n, dst, ws16k);
+}
+
 __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);
 // Snappy raw stream made of one literal element (uvarint length | literal tag + length | bytes): what
 // snap::raw::Decoder (basic.rs:99-106) and sb's own decoder read back; no matching is attempted.
@@ -1228,7 +1237,7 @@ __device__ uint32_t snappy_store_wg(const uint8_t* src, uint32_t n, uint8_t* dst
 // ------------------------------------------------------------------------------ u32 blocks (nested)
 // compress_integer::<u32> of an index array without validity: hdr9 + body.  Returns bytes written.
 __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec, uint8_t* dst, uint32_t* sA,
-                                  uint32_t* sB, uint32_t* sC, uint32_t* s_w, Status* st, uint32_t page) {
+                                  uint32_t* sB, uint32_t* sC, uint32_t* s_w, Status* st, uint32_t page, uint32_t flags) {
     auto getu = [=](uint64_t i) { return idx[i]; };
     auto getv = [=](uint64_t i) {
         Val<4> v;
@@ -1260,7 +1269,7 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
         case SB_CODEC_LZ4: {  // Basic(Lz4) over the raw index bytes (integer/mod.rs:55-58)
             __syncthreads();
             uint32_t sz = 0;
-            if (threadIdx.x < 64) sz = lz4_compress_wave((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, sA);
+            if (threadIdx.x < 64) sz = lz4_compress_block((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, sA, flags);
             __syncthreads();
             if (threadIdx.x == 0) s_w[0] = sz;
             __syncthreads();
@@ -2255,7 +2264,7 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
             }
             return DICT_FREQ_PENDING;
         }
-        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
+        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags);
         if (ib == 0) return 0;
         uint8_t* q = blk + 9 + ib;
         if (threadIdx.x == 0) stu32(q, D);
@@ -2365,7 +2374,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             }
             return DICT_FREQ_PENDING;
         }
-        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page);
+        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags);
         if (ib == 0) return 0;
         uint8_t* q = blk + 9 + ib;
         if (threadIdx.x == 0) stu32(q, D);
@@ -3319,7 +3328,7 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
                 sz = snappy_store_wg(vals, (uint32_t)(N * W), blk + 9);
             } else {
                 uint32_t z = 0;
-                if (threadIdx.x < 64) z = lz4_compress_wave(vals, (uint32_t)(N * W), blk + 9, sA);
+                if (threadIdx.x < 64) z = lz4_compress_block(vals, (uint32_t)(N * W), blk + 9, sA, a.flags);
                 if (threadIdx.x == 0) s_sz = z;
                 __syncthreads();
                 sz = s_sz;
@@ -3520,7 +3529,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
         if (bc == SB_CODEC_ZSTD) return zstd_store_frame_wg(src, n, dst, tab);
         if (bc == SB_CODEC_SNAPPY) return snappy_store_wg(src, n, dst);
         uint32_t sz = 0;
-        if (threadIdx.x < 64) sz = lz4_compress_wave(src, n, dst, tab);
+        if (threadIdx.x < 64) sz = lz4_compress_block(src, n, dst, tab, a.flags);
         if (threadIdx.x == 0) s_sz = sz;
         __syncthreads();
         return s_sz;
@@ -3802,35 +3811,6 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (n == 0) return SB_OK;
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    // SB_MEM_HOST: the caller holds host Arrow buffers (the reference's shape); stage them over PCIe
-    std::vector<const uint8_t*> dv(n, nullptr), dval(n, nullptr), doff(n, nullptr);
-    std::vector<uint8_t*> dout(n, nullptr);
-    if (mem == SB_MEM_HOST) {
-        auto stage_in = [&](const void* host, size_t bytes, const uint8_t** out) -> bool {
-            *out = nullptr;
-            if (!host || !bytes) return true;
-            uint8_t* d = ctx->stage_alloc(bytes);
-            if (!d) return false;
-            *out = d;
-            return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
-        };
-        for (uint64_t i = 0; i < n; i++) {
-            const sb_column_write& c = cols[i];
-            const uint32_t w = enc_type_width(c.physical_type);
-            size_t vbytes = c.physical_type == SB_TYPE_BOOLEAN ? (size_t)((c.values_bit_offset + c.rows + 7) / 8)
-                            : enc_is_binary(c.physical_type) ? (size_t)c.values_len : (size_t)(c.rows * w);
-            if (!stage_in(c.values, vbytes, &dv[i]) ||
-                !stage_in(c.validity, (size_t)((c.validity_bit_offset + c.rows + 7) / 8), &dval[i]) ||
-                !stage_in(enc_is_binary(c.physical_type) ? c.offsets : nullptr, (size_t)((c.rows + 1) * w), &doff[i]))
-                return ctx->fail(SB_ERR_EXTERNAL, "staging of host buffers failed");
-            if (c.out_capacity) {
-                if (!(dout[i] = ctx->stage_alloc(c.out_capacity)))
-                    return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(out_pages) failed");
-                ctx->copybacks.push_back({c.out_pages, dout[i], (size_t)c.out_capacity, &cols[i].out_len});
-            }
-        }
-    }
-
     // codec known on the host? (forced, or default_compress_ratio == None => Basic(default))
     int32_t host_codec = -1;
     if (opts->force_codec >= 0 && !((opts->forbidden_compressions >> opts->force_codec) & 1))
@@ -3860,8 +3840,12 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     for (uint64_t i = 0; i < n; i++) {
         sb_column_write& c = cols[i];
         if (c.physical_type < 0 || c.physical_type > SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "bad physical_type");
-        if (c.rows == 0) return ctx->fail(SB_ERR_OUT_OF_SPEC, "encode_chunk on an empty chunk panics upstream");
-        if (c.physical_type != SB_TYPE_NULL && !c.values && !(enc_is_binary(c.physical_type) && c.values_len == 0))
+        // a flat column of zero rows: encode_chunk panics upstream (common.rs:54-58 divides by the page size).  A
+        // nested leaf with explicit paging may hold zero leaf slots (every list empty or null): write_nested
+        // compresses an empty leaf block per page.
+        if (c.rows == 0 && !(c.page_rows && c.n_pages_in))
+            return ctx->fail(SB_ERR_OUT_OF_SPEC, "encode_chunk on an empty chunk panics upstream");
+        if (c.rows && c.physical_type != SB_TYPE_NULL && !c.values && !(enc_is_binary(c.physical_type) && c.values_len == 0))
             return ctx->fail(SB_ERR_INVALID, "values is null");  // (a binary column of empty strings has no value bytes)
         if (enc_is_binary(c.physical_type) && !c.offsets) return ctx->fail(SB_ERR_INVALID, "offsets is null");
         const uint64_t ps = page_size_of(c.rows, opts);
@@ -3882,6 +3866,41 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
     }
     if (P >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many pages in one call");
+
+    // SB_MEM_HOST: the caller holds host Arrow buffers (the reference's shape); stage them over PCIe
+    std::vector<const uint8_t*> dv(n, nullptr), dval(n, nullptr), doff(n, nullptr), dheads(n, nullptr);
+    std::vector<uint8_t*> dout(n, nullptr);
+    if (mem == SB_MEM_HOST) {
+        auto stage_in = [&](const void* host, size_t bytes, const uint8_t** out) -> bool {
+            *out = nullptr;
+            if (!host || !bytes) return true;
+            uint8_t* d = ctx->stage_alloc(bytes);
+            if (!d) return false;
+            *out = d;
+            return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+        };
+        for (uint64_t i = 0; i < n; i++) {
+            const sb_column_write& c = cols[i];
+            const uint32_t w = enc_type_width(c.physical_type);
+            size_t vbytes = c.physical_type == SB_TYPE_BOOLEAN ? (size_t)((c.values_bit_offset + c.rows + 7) / 8)
+                            : enc_is_binary(c.physical_type) ? (size_t)c.values_len : (size_t)(c.rows * w);
+            if (!stage_in(c.values, vbytes, &dv[i]) ||
+                !stage_in(c.validity, (size_t)((c.validity_bit_offset + c.rows + 7) / 8), &dval[i]) ||
+                !stage_in(enc_is_binary(c.physical_type) ? c.offsets : nullptr, (size_t)((c.rows + 1) * w), &doff[i]))
+                return ctx->fail(SB_ERR_EXTERNAL, "staging of host buffers failed");
+            if (c.page_heads && c.page_head_bytes) {  // nested level sections travel like every other DEVICE buffer
+                size_t hb = 0;
+                for (uint64_t q = 0; q < c.n_pages_in; q++) hb += (size_t)c.page_head_bytes[q];
+                if (!stage_in(c.page_heads, hb, &dheads[i])) return ctx->fail(SB_ERR_EXTERNAL, "staging of host buffers failed");
+            }
+            if (c.out_capacity) {
+                if (!(dout[i] = ctx->stage_alloc(c.out_capacity)))
+                    return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(out_pages) failed");
+                ctx->copybacks.push_back({c.out_pages, dout[i], (size_t)c.out_capacity, &cols[i].out_len});
+            }
+        }
+    }
+
 
     size_t off = 0;
     const size_t o_cols = off;
@@ -3923,7 +3942,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         d.validity = mem == SB_MEM_HOST ? dval[i] : c.validity;
         d.offsets = mem == SB_MEM_HOST ? doff[i] : (const uint8_t*)c.offsets;
         d.out = mem == SB_MEM_HOST ? dout[i] : c.out_pages;
-        d.heads = c.page_heads;
+        d.heads = mem == SB_MEM_HOST ? dheads[i] : c.page_heads;
         d.values_bit_offset = c.values_bit_offset;
         d.values_len = c.values_len;
         d.validity_bit_offset = c.validity_bit_offset;
@@ -4069,6 +4088,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.vpages = (const EncPage*)(tb + o_vpages);
     a.page_base = 0;
     a.nested_force = opts->force_index_codec;
+    a.flags = opts->flags;
     a.freq_count = (uint32_t*)(tb + o_freqcnt);
     a.codec_counts = (uint32_t*)(tb + o_freqcnt + 64);
     a.use_counts = 0;
@@ -4106,13 +4126,13 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     // lane = raw run first; pages with runs too short for that go through the lane = row kernel
                     if (any_f) {
                         {
-                            KScope k(ctx, K_ENC_SELECT);
+                            KScope k(ctx, kd == 4 ? "k_enc_select_runs<4, 1>" : "k_enc_select_runs<8, 2>");
                             if (kd == 4)
                                 k_enc_select_runs<4, 1><<<(uint32_t)P, WG, 0, s>>>(aa);
                             else
                                 k_enc_select_runs<8, 2><<<(uint32_t)P, WG, 0, s>>>(aa);
                         }
-                        KScope k(ctx, K_ENC_SELECT_ROWS);
+                        KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 1>" : "k_enc_select_rle<8, 2>");
                         if (kd == 4)
                             k_enc_select_rle<4, 1><<<(uint32_t)P, WG, 0, s>>>(aa);
                         else
@@ -4120,13 +4140,13 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     }
                     if (any_i) {
                         {
-                            KScope k(ctx, K_ENC_SELECT);
+                            KScope k(ctx, kd == 4 ? "k_enc_select_runs<4, 0>" : "k_enc_select_runs<8, 0>");
                             if (kd == 4)
                                 k_enc_select_runs<4, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
                             else
                                 k_enc_select_runs<8, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
                         }
-                        KScope k(ctx, K_ENC_SELECT_ROWS);
+                        KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 0>" : "k_enc_select_rle<8, 0>");
                         if (kd == 4)
                             k_enc_select_rle<4, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
                         else
@@ -4134,7 +4154,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     }
                     continue;
                 }
-                KScope k(ctx, K_ENC_SELECT);
+                char nm[48];
+                snprintf(nm, sizeof nm, "k_enc_select<%d>", kd);
+                KScope k(ctx, nm);
                 enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(aa);
             }
         }
@@ -4169,8 +4191,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     }
                     EncPageKernel kf = enc_page_kernel(kd, cd);
                     if (!kf) continue;
-                    KScope k(ctx, cd == SB_CODEC_RLE ? K_ENC_PAGES : cd == SB_CODEC_DICT ? K_ENC_PAGES_DICT
-                                    : cd == SB_CODEC_ONEVALUE ? K_ENC_PAGES_ONEVALUE : cd == SB_CODEC_PATAS ? K_ENC_PAGES_PATAS : K_ENC_PAGES_BP);
+                    char nm[48];
+                    snprintf(nm, sizeof nm, "k_enc_emit_pages<%d, %d>", kd, (int)cd);
+                    KScope k(ctx, nm);
                     kf<<<(uint32_t)P, WG, 0, s>>>(aa);
                 }
                 if (!nested && !wave_adaptive && wave_codec != SB_CODEC_NONE && wave_codec != SB_CODEC_FREQ && wave_codec > 3 &&

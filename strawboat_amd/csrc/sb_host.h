@@ -2,6 +2,7 @@
 #pragma once
 #include <string>
 #include <algorithm>
+#include <deque>
 #include <vector>
 
 #include "sb_common.h"
@@ -59,6 +60,7 @@ struct sb_ctx {
     int next_slot = 0;
 
     std::vector<sb::Pending> pending;
+    std::deque<std::vector<uint8_t>> rescued;  // readbacks moved out of a recycled staging slot (acquire_slot)
     // SB_MEM_HOST copies to hand back after the stream drains: (host dst, device src, bytes)
     struct Copyback {
         void* host;
@@ -121,8 +123,20 @@ struct sb_ctx {
     bool profile = false;
     std::vector<sb::ProfSpan> spans;
     std::vector<hipEvent_t> free_events;
-    double prof_ms[sb::K_COUNT] = {0};
-    uint64_t prof_n[sb::K_COUNT] = {0};
+    struct ProfEntry {
+        std::string name;  // the kernel's name as rocprofv3 prints it, without "void sb::" and the argument list
+        double ms = 0;
+        uint64_t n = 0;
+    };
+    std::vector<ProfEntry> prof;  // [0, K_COUNT): the KernelId entries; template instances are added by name
+    int prof_id(const char* name) {
+        for (size_t i = 0; i < prof.size(); i++)
+            if (prof[i].name == name) return (int)i;
+        ProfEntry e;
+        e.name = name;
+        prof.push_back(e);
+        return (int)prof.size() - 1;
+    }
 
     int32_t fail(int32_t code, const std::string& msg) {
         last_error = msg;
@@ -136,6 +150,7 @@ namespace sb {
 struct KScope {
     sb_ctx* ctx;
     ProfSpan sp;
+    KScope(sb_ctx* c, const char* name) : KScope(c, c->profile ? c->prof_id(name) : 0) {}
     KScope(sb_ctx* c, int id) : ctx(c) {
         if (!ctx->profile) return;
         sp.id = id;

@@ -59,3 +59,4 @@ class WriteOptions:
     force_codec: int = -1
     force_index_codec: int = -1
     rng_seed: int = 42
+    lz4_exact: bool = False   # SB_WRITE_LZ4_EXACT: LZ4 blocks byte-identical to LZ4_compress_default (slow serial parse)

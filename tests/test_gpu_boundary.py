@@ -1,0 +1,143 @@
+"""Boundary behaviour of the C ABI that the parity tests do not reach:
+  * more enqueued calls than the staging ring has slots before ONE synchronize (results of the early
+    calls must not be overwritten by the later ones);
+  * a binary column decoded into a values buffer that is too small: an error, values_len still
+    reported, and nothing written past values_capacity;
+  * a failed synchronize interval that held Freq pages does not leak its records into the next one.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(ctx, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(ctx.torch_device)
+
+
+def _dcol(ctx, col):
+    from strawboat_amd import write
+    return write.DeviceColumn(col["ptype"], col["nullable"], col["rows"], _dev(ctx, col["values"]),
+                              None if col["validity"] is None else _dev(ctx, col["validity"]),
+                              None if col["offsets"] is None else _dev(ctx, col["offsets"]))
+
+
+def test_many_calls_before_one_synchronize(gpu_ctx):
+    """20 distinct encode calls and 20 distinct decode calls, one synchronize each: every call gets its OWN
+    metas / lengths back (the pinned staging ring has 8 slots)."""
+    from strawboat_amd import read, write
+    from strawboat_amd.types import WriteOptions
+    cols, encs, wants = [], [], []
+    for k in range(20):
+        rows = 3000 + 517 * k
+        col = gen.prim(S.T_I32 if k % 2 else S.T_I64, rows, uniq=5 + 40 * k, null_density=0.1 if k % 3 else None,
+                       seed=100 + k, runs=8 if k % 4 == 0 else None)
+        cols.append(col)
+        ps = 500 + 37 * k
+        wants.append(gen.oracle_write(col, max_page_size=ps, ratio=2.0))
+        encs.append(write.encode_columns(gpu_ctx, [_dcol(gpu_ctx, col)], WriteOptions(max_page_size=ps, default_compress_ratio=2.0))[0])
+    gpu_ctx.synchronize()
+    for k in range(20):
+        assert np.array_equal(encs[k].metas_array(), wants[k][1]), "call %d: metas of another call" % k
+        assert np.array_equal(encs[k].pages_numpy(), wants[k][0]), "call %d" % k
+    outs = []
+    bins = [gen.binary(2000 + 301 * k, uniq=20 + 11 * k, null_density=0.2, seed=k) for k in range(20)]
+    pages = [gen.oracle_write(b, max_page_size=700 + k, ratio=2.0) for k, b in enumerate(bins)]
+    sizes = []
+    for k in range(20):
+        want = gen.oracle_read(bins[k], *pages[k])
+        sizes.append(want["values"].size)
+        cp = read.ColumnPages(bins[k]["ptype"], True, _dev(gpu_ctx, pages[k][0]), pages[k][1])
+        outs.append((read.batch_read_columns(gpu_ctx, [cp], values_capacity=[want["values"].size + 64])[0], want))
+    gpu_ctx.synchronize()
+    for k, (got, want) in enumerate(outs):
+        assert got.values_len == sizes[k], "call %d: values_len of another call" % k
+        assert np.array_equal(got.values_numpy(), want["values"]), k
+        assert np.array_equal(got.offsets_numpy().view(np.int32), want["offsets"].view(np.int32)), k
+
+
+@pytest.mark.parametrize("codec", [S.ONEVALUE, S.DICT, S.NONE, S.LZ4, S.FREQ])
+def test_undersized_values_capacity_is_not_overrun(gpu_ctx, codec):
+    """binary pages that expand beyond the caller's values buffer (a OneValue / Dict page expands far
+    beyond 4x its page bytes): SB_ERR_INVALID, the real size in values_len, the guard bytes untouched"""
+    import torch
+    from strawboat_amd import _native as N
+    from strawboat_amd import read
+    rows = 20000
+    if codec == S.ONEVALUE:
+        col = gen.binary(rows, uniq=1, seed=3, minlen=40, maxlen=40)
+    elif codec == S.FREQ:
+        col = gen.binary(rows, uniq=30, seed=3, minlen=30, maxlen=40)
+        # mostly one value
+        idx = np.zeros(rows, np.int64)
+        idx[::50] = 1
+        o = col["offsets"].astype(np.int64)
+        lens = (o[1:] - o[:-1])
+        first = col["values"][o[0]:o[1]].copy()
+        second = col["values"][o[1]:o[2]].copy()
+        parts = [second if i else first for i in idx]
+        col["values"] = np.concatenate(parts)
+        col["offsets"] = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int32)
+        del lens
+    else:
+        col = gen.binary(rows, uniq=16, seed=3, minlen=30, maxlen=40)
+    pages, metas = gen.oracle_write(col, max_page_size=4096, force_codec=codec)
+    want = gen.oracle_read(col, pages, metas)
+    need = want["values"].size
+    cap = need // 3
+    buf = torch.full((need + 4096,), 0xAB, dtype=torch.uint8, device=gpu_ctx.torch_device)
+    cp = read.ColumnPages(col["ptype"], col["nullable"], _dev(gpu_ctx, pages), metas)
+    batch = read.ReadBatch(gpu_ctx, [cp], values_capacity=[need])
+    c = batch._arr[0]
+    c.values = C.c_void_p(buf.data_ptr())
+    c.values_capacity = cap
+    batch.enqueue()
+    with pytest.raises(N.NativeError) as ei:
+        gpu_ctx.synchronize()
+    assert ei.value.code == N.SB_ERR_INVALID
+    assert int(c.values_len) == need          # the caller can retry with the right size
+    tail = buf[cap:].cpu().numpy()
+    assert (tail == 0xAB).all(), "%d bytes written past values_capacity" % int((tail != 0xAB).sum())
+    # retry with the reported size
+    c.values_capacity = need
+    batch.enqueue()
+    gpu_ctx.synchronize()
+    assert np.array_equal(buf[:need].cpu().numpy(), want["values"])
+
+
+def test_freq_records_of_a_failed_interval_are_dropped(gpu_ctx):
+    """interval 1: a Freq column + a corrupt column -> error at synchronize.  interval 2: another Freq column
+    decodes correctly (the first interval's FreqEntry records, which point into freed buffers, are gone)."""
+    import torch
+    from strawboat_amd import _native as N
+    from strawboat_amd import read
+    def freq_col(seed, rows):
+        rng = np.random.default_rng(seed)
+        v = np.full(rows, 1000 + seed, np.int64)
+        k = rng.choice(rows, rows // 50, replace=False)
+        v[k] = rng.integers(300, 100000, k.size)
+        return dict(ptype=S.T_I64, nullable=False, rows=rows, values=v, validity=None, offsets=None)
+    a = freq_col(1, 30000)
+    pa, ma = gen.oracle_write(a, max_page_size=4096, force_codec=S.FREQ)
+    bad = gen.prim(S.T_I32, 5000, seed=9)
+    pb, mb = gen.oracle_write(bad, max_page_size=1000, force_codec=S.NONE)
+    pb = pb.copy()
+    pb[0] = 99  # unknown codec id
+    ta = _dev(gpu_ctx, pa)
+    read.batch_read_columns(gpu_ctx, [read.ColumnPages(S.T_I64, False, ta, ma)])
+    read.batch_read_columns(gpu_ctx, [read.ColumnPages(S.T_I32, False, _dev(gpu_ctx, pb), mb)])
+    with pytest.raises(N.NativeError):
+        gpu_ctx.synchronize()
+    del ta
+    torch.cuda.empty_cache()
+    for seed in (2, 3):
+        b = freq_col(seed, 20000 + seed)
+        p2, m2 = gen.oracle_write(b, max_page_size=4096, force_codec=S.FREQ)
+        got = read.read_simple(gpu_ctx, read.ColumnPages(S.T_I64, False, _dev(gpu_ctx, p2), m2))
+        assert np.array_equal(got.values_numpy().view(np.int64), b["values"])

@@ -14,6 +14,7 @@ import pytest
 from oracle import sbo as S
 from tests import gen
 from tests.test_gpu_decode import gpu_decode
+import workloads
 from tests.test_gpu_encode import gpu_encode
 
 pytestmark = pytest.mark.gpu
@@ -39,15 +40,7 @@ def encode_matches_oracle_and_round_trips(ctx, col, **opt):
 
 
 def zipf_utf8(rows, seed, null_density=None):
-    rng = np.random.default_rng(seed)
-    vocab = [("w%d" % k).ljust(int(rng.integers(4, 25)), "x").encode() for k in range(10_000)]
-    rank = np.minimum(rng.zipf(1.1, rows), 10_000) - 1
-    lens = np.array([len(v) for v in vocab], np.int64)[rank]
-    offs = np.zeros(rows + 1, np.int64)
-    np.cumsum(lens, out=offs[1:])
-    data = np.frombuffer(b"".join(vocab[i] for i in rank), np.uint8).copy()
-    validity = gen.make_validity(rng, rows, null_density)
-    return dict(ptype=S.T_BIN32, nullable=True, rows=rows, values=data, validity=validity, offsets=offs.astype(np.int32))
+    return workloads.zipf_utf8(rows, seed, null_density)
 
 
 def test_c1_int64_one_page_no_compression(gpu_ctx):

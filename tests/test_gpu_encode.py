@@ -28,7 +28,8 @@ def gpu_encode(ctx, col, **opt):
     wo = WriteOptions(default_compression=opt.get("default_compression", 0),
                       default_compress_ratio=opt.get("ratio"), max_page_size=opt.get("max_page_size"),
                       forbidden_compressions=list(opt.get("forbidden", ())), force_codec=opt.get("force_codec", -1),
-                      force_index_codec=opt.get("force_index_codec", -1), rng_seed=opt.get("rng_seed", 42))
+                      force_index_codec=opt.get("force_index_codec", -1), rng_seed=opt.get("rng_seed", 42),
+                      lz4_exact=True)   # byte parity with the oracle (== liblz4) needs the exact parse
     return write.write(ctx, to_device_column(ctx, col), wo)
 
 

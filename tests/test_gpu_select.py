@@ -115,7 +115,7 @@ def test_inputs_at_the_end_of_an_allocation(gpu_ctx):
         view.copy_(torch.from_numpy(v.view(np.uint8)))
         col = dict(ptype=ptype, nullable=False, rows=rows, values=v, validity=None, offsets=None)
         want_pages, want_metas = gen.oracle_write(col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
-        opts = WriteOptions(max_page_size=65536, default_compression=S.LZ4, default_compress_ratio=2.0)
+        opts = WriteOptions(max_page_size=65536, default_compression=S.LZ4, default_compress_ratio=2.0, lz4_exact=True)
         enc = write.encode_columns(gpu_ctx, [write.DeviceColumn(ptype, False, rows, view)], opts)
         gpu_ctx.synchronize()
         assert np.array_equal(enc[0].pages_numpy(), want_pages)

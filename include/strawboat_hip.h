@@ -282,6 +282,55 @@ int32_t sb_file_reader_read_pages(sb_file_reader* r, uint64_t col, uint64_t firs
                                   uint8_t* dst, uint64_t capacity, uint64_t* bytes_read);
 void sb_file_reader_close(sb_file_reader* r);
 
+/* ------------------------------------------------------------------ schema bytes of the footer (host only)
+ * NativeWriter::finish stores arrow2's schema_to_bytes(&schema, &default_ipc_fields(..)) (src/write/writer.rs:137-139):
+ * the bare Arrow IPC Message flatbuffer with a Schema header (version V5, little endian, body_length 0); infer_schema
+ * feeds it to deserialize_schema (src/read/reader.rs:227-241).  These two calls write / read that flatbuffer without
+ * another Arrow implementation.  A schema is passed as its fields flattened in PRE-ORDER: every entry is followed by
+ * its n_children children (List / LargeList / FixedSizeList: the item field; Struct: its fields; Map: the non-null
+ * "entries" struct with the key and value fields).  type_id is the `Type` union tag of Schema.fbs. */
+#define SB_ARROW_NULL 1
+#define SB_ARROW_INT 2              /* bit_width 8/16/32/64, is_signed */
+#define SB_ARROW_FLOATING_POINT 3   /* precision: 0 half, 1 single, 2 double */
+#define SB_ARROW_BINARY 4
+#define SB_ARROW_UTF8 5
+#define SB_ARROW_BOOL 6
+#define SB_ARROW_DECIMAL 7          /* precision, scale, bit_width 128 / 256 */
+#define SB_ARROW_DATE 8             /* unit: 0 day (Date32), 1 millisecond (Date64) */
+#define SB_ARROW_TIME 9             /* unit (TimeUnit), bit_width 32 / 64 */
+#define SB_ARROW_TIMESTAMP 10       /* unit: 0 s, 1 ms, 2 us, 3 ns; timezone or NULL */
+#define SB_ARROW_INTERVAL 11        /* unit: 0 year_month, 1 day_time, 2 month_day_nano */
+#define SB_ARROW_LIST 12
+#define SB_ARROW_STRUCT 13
+#define SB_ARROW_FIXED_SIZE_BINARY 15 /* bit_width = byte width */
+#define SB_ARROW_FIXED_SIZE_LIST 16   /* bit_width = list size */
+#define SB_ARROW_MAP 17             /* is_signed = keys_sorted */
+#define SB_ARROW_DURATION 18        /* unit (TimeUnit) */
+#define SB_ARROW_LARGE_BINARY 19
+#define SB_ARROW_LARGE_UTF8 20
+#define SB_ARROW_LARGE_LIST 21
+typedef struct sb_schema_field {
+    const char* name;     /* UTF-8, NUL terminated */
+    const char* timezone; /* Timestamp only; NULL = none */
+    int32_t type_id;      /* SB_ARROW_* */
+    int32_t nullable;
+    int32_t n_children;
+    int32_t bit_width;
+    int32_t is_signed;
+    int32_t precision;
+    int32_t scale;
+    int32_t unit;
+} sb_schema_field;
+const char* sb_schema_last_error(void);
+/* metadata: 2 * n_metadata strings (key, value, key, value ...) of Schema.custom_metadata, or NULL.  *len returns the
+ * size of the flatbuffer (also when `capacity` is too small: SB_ERR_INVALID, call again). */
+int32_t sb_schema_to_bytes(const sb_schema_field* fields, uint64_t n_fields, uint64_t n_top, const char* const* metadata,
+                           uint64_t n_metadata, uint8_t* out, uint64_t capacity, uint64_t* len);
+/* Parses schema bytes written by this library, arrow2 or any other Arrow implementation.  Field names / timezones are
+ * copied into `strings`; the out[].name pointers point there.  *n_fields / *strings_len return the sizes needed. */
+int32_t sb_schema_from_bytes(const uint8_t* bytes, uint64_t len, sb_schema_field* out, uint64_t capacity, uint64_t* n_fields,
+                             uint64_t* n_top, char* strings, uint64_t strings_capacity, uint64_t* strings_len);
+
 /* ------------------------------------------------------------------ page inspector (host only)
  * Replaces stat::stat_simple / stat_body / stat_dict_body / stat_freq_body (src/stat.rs:61-152): the
  * block structure of one page without decoding it.  `out` receives a chain: out[0] is the page's block,

@@ -21,7 +21,7 @@ EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize"
            "sb_nested_read_levels", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
            "sb_file_writer_write_column", "sb_file_writer_finish", "sb_file_writer_close", "sb_file_reader_open",
            "sb_file_reader_n_columns", "sb_file_reader_column", "sb_file_reader_schema", "sb_file_reader_read_pages",
-           "sb_file_reader_close", "sb_stat_page")
+           "sb_file_reader_close", "sb_stat_page", "sb_schema_last_error", "sb_schema_to_bytes", "sb_schema_from_bytes")
 
 
 class PageMetaC(C.Structure):
@@ -73,6 +73,12 @@ class PageInfoC(C.Structure):
     _fields_ = [("codec", C.c_int32), ("has_validity_size", C.c_int32), ("validity_size", C.c_uint32),
                 ("compressed_size", C.c_uint32), ("uncompressed_size", C.c_uint32), ("unique_num", C.c_uint32),
                 ("exceptions_bitmap_size", C.c_uint32), ("has_nested", C.c_int32)]
+
+
+class SchemaFieldC(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("timezone", C.c_char_p), ("type_id", C.c_int32), ("nullable", C.c_int32),
+                ("n_children", C.c_int32), ("bit_width", C.c_int32), ("is_signed", C.c_int32), ("precision", C.c_int32),
+                ("scale", C.c_int32), ("unit", C.c_int32)]
 
 
 class KernelStatC(C.Structure):
@@ -159,5 +165,12 @@ def load():
     L.sb_stat_page.restype = C.c_int32
     L.sb_stat_page.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(PageInfoC), C.c_uint32,
                                C.POINTER(C.c_uint32)]
+    L.sb_schema_last_error.restype = C.c_char_p
+    L.sb_schema_to_bytes.restype = C.c_int32
+    L.sb_schema_to_bytes.argtypes = [C.POINTER(SchemaFieldC), C.c_uint64, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint64,
+                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sb_schema_from_bytes.restype = C.c_int32
+    L.sb_schema_from_bytes.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(SchemaFieldC), C.c_uint64, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = L
     return L

@@ -1199,7 +1199,7 @@ __device__ uint32_t lz4_compress_wave(const uint8_t* src, uint32_t n, uint8_t* d
 // SB_WRITE_LZ4_EXACT: the serial greedy parse above, byte-identical to LZ4_compress_default.
 __device__ __forceinline__ uint32_t lz4_compress_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* ws16k, uint32_t flags) {
     if (flags & SB_WRITE_LZ4_EXACT) return lz4_compress_wave(src, n, dst, ws16k);
-    return lz4_compress_wave_fast(src, n, dst, ws16k);
+    return lz4_compress_wave_fast<11, 13>(src, n, dst, *reinterpret_cast<Lz4EncLds<11, 13>*>(ws16k));
 }
 
 __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);
@@ -3504,7 +3504,12 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
 // pages whose codec is LZ4 (CommonCompression::Lz4 as the default, or chosen by the selector):
 // def levels + hdr9 + one LZ4 block (binary: offsets block + values block), one workgroup per page
 __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
-    __shared__ uint32_t tab[4096];
+    // one LDS area: the 16 KiB the Zstd / Snappy / exact-LZ4 paths use, or the parallel LZ4 matcher's table + 16 KiB ring
+    __shared__ union {
+        uint32_t tab[4096];
+        Lz4EncLds<12, 13> lz;
+    } sh;
+    uint32_t* const tab = sh.tab;
     __shared__ uint32_t s_sz;
     if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] + a.codec_counts[SB_CODEC_ZSTD] + a.codec_counts[SB_CODEC_SNAPPY] == 0) return;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
@@ -3529,7 +3534,8 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
         if (bc == SB_CODEC_ZSTD) return zstd_store_frame_wg(src, n, dst, tab);
         if (bc == SB_CODEC_SNAPPY) return snappy_store_wg(src, n, dst);
         uint32_t sz = 0;
-        if (threadIdx.x < 64) sz = lz4_compress_block(src, n, dst, tab, a.flags);
+        if (threadIdx.x < 64)
+            sz = (a.flags & SB_WRITE_LZ4_EXACT) ? lz4_compress_wave(src, n, dst, tab) : lz4_compress_wave_fast<12, 13>(src, n, dst, sh.lz);
         if (threadIdx.x == 0) s_sz = sz;
         __syncthreads();
         return s_sz;

@@ -32,6 +32,19 @@
 #pragma once
 #include "sb_common.h"
 
+// phase timing for scripts/micro/lz4_probe.hip (compiled out of the library)
+#ifdef SB_LZ4_PROFILE
+#define LZP_BEGIN unsigned long long lzp_acc[24] = {0}; unsigned long long lzp_t = __builtin_readcyclecounter();
+#define LZP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); lzp_acc[i] += n_ - lzp_t; lzp_t = n_; } while (0)
+#define LZP_CNT(i, v) do { lzp_acc[i] += (v); } while (0)
+#define LZP_END do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 24; i_++) g_prof[i_] += lzp_acc[i_]; } while (0)
+#else
+#define LZP_BEGIN
+#define LZP(i)
+#define LZP_CNT(i, v)
+#define LZP_END
+#endif
+
 namespace sb {
 
 // compiler + LDS ordering point inside one wave (ds operations of a wave execute in order)
@@ -50,6 +63,20 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 // lane l of a vector takes the wave-uniform `val` (v_cmp + v_cndmask; this clang has no v_writelane builtin)
 __device__ __forceinline__ uint32_t wrlane(uint32_t val, uint32_t l, uint32_t old) {
     return (threadIdx.x & 63) == l ? val : old;
+}
+// wave64 inclusive add-scan with DPP (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31
+// across rows — the gfx9 recipe): six VALU instructions, no LDS crossbar
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // set bits of m below my lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 __device__ __forceinline__ uint32_t div255(uint32_t x) { return (uint32_t)(((uint64_t)x * 0x80808081ull) >> 39); }
 
@@ -77,15 +104,37 @@ __device__ __forceinline__ void wave_copy_g2g(uint8_t* dst, const uint8_t* src, 
     if (lane < n - done) dst[done + lane] = ldu8(src + done + lane);
 }
 
+// 8 bytes at byte index x of a dword array in LDS whose length is a power of two (wm = dwords - 1): three aligned
+// dword reads issued together + two v_alignbyte, one LDS round trip instead of eight
+__device__ __forceinline__ uint64_t lds_rd8_ring(const uint32_t* a, uint32_t x, uint32_t wm) {
+    const uint32_t w = x >> 2;
+    const uint32_t d0 = a[w & wm], d1 = a[(w + 1) & wm], d2 = a[(w + 2) & wm];
+    return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, x & 3) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, x & 3) << 32);
+}
+__device__ __forceinline__ uint64_t lds_rd8(const uint32_t* a, uint32_t x) {  // no wrap; a[] has 8 bytes of slack
+    const uint32_t w = x >> 2;
+    const uint32_t d0 = a[w], d1 = a[w + 1], d2 = a[w + 2];
+    return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, x & 3) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, x & 3) << 32);
+}
+// the low nb (<= 8) bytes of v to ring bytes [x, x + nb)
+__device__ __forceinline__ void lds_wr_bytes(uint8_t* ring, uint32_t rm, uint32_t x, uint64_t v, uint32_t nb) {
+#pragma unroll
+    for (uint32_t b = 0; b < 8; b++)
+        if (b < nb) ring[(x + b) & rm] = (uint8_t)(v >> (8 * b));
+}
+
 // ------------------------------------------------------------------------------------------------ decode
 constexpr uint32_t LZD_IB = 2048;        // compressed bytes staged in LDS
 constexpr uint32_t LZD_SHORT_LIT = 300;  // literals up to here are copied from the staged input
 constexpr uint32_t LZD_MARGIN = 64 + 3 + LZD_SHORT_LIT + 2 + 3 + 16;  // window + extensions + literal + offset + extensions
-constexpr uint32_t LZD_ST = 8192;        // output staging window (bytes)
-constexpr uint32_t LZD_MB = 128;         // matches per batch
+// (a lone wave is latency bound — ~8 cycles per dependent instruction — so throughput comes from waves per SIMD: the
+// LDS footprint is kept near 12 KiB per wave, 12 waves per CU)
+constexpr uint32_t LZD_RING = 8192;      // output ring (bytes): the current batch and at least 4 KiB of history
+constexpr uint32_t LZD_BATCH = 4096;     // output bytes per batch
+constexpr uint32_t LZD_MB = 320;         // matches per batch
 struct Lz4DecLds {
-    __attribute__((aligned(16))) uint8_t ib[LZD_IB + 16];
-    __attribute__((aligned(16))) uint8_t st[LZD_ST + 16];
+    __attribute__((aligned(16))) uint8_t ib[LZD_IB + 32];
+    __attribute__((aligned(16))) uint8_t ring[LZD_RING];
     uint32_t m_dst[LZD_MB];  // match destination (output position)
     uint32_t m_len[LZD_MB];
     uint16_t m_off[LZD_MB];
@@ -110,20 +159,27 @@ __device__ __forceinline__ uint32_t lz4_ext_sum(const uint8_t* src, uint32_t x, 
 
 // Decode one LZ4 block (executed by ONE wave64).  Returns 0, or a non-zero tag on a malformed stream
 // (LZ4_decompress_safe < 0 upstream => Error::External).
+//
+// Positions: `op` counts output bytes; g = op + a0 with a0 = dst & 15, so that g % 16 is the byte's place in its
+// 16-byte line in HBM.  Output byte g lives at ring[g % LZD_RING] until it is overwritten LZD_RING bytes later.
+// fl = g-position up to which the ring has been written to HBM (whole 16-byte groups).
 __device__ uint32_t lz4_inflate_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out_len, Lz4DecLds& L) {
     const uint32_t lane = threadIdx.x & 63;
     if (n == 0) return out_len != 0 ? 100u : 0u;
-    // g-space: G = output position + a0, so that G % 16 == address % 16 (aligned 16-byte flushes)
     const uint32_t a0 = (uint32_t)((uintptr_t)dst & 15);
     uint8_t* gbase = dst - a0;
-    uint32_t S0 = 0;          // g-position of st[0] (multiple of 16)
-    uint32_t op = 0;          // output position (bytes produced so far, incl. staged)
+    constexpr uint32_t RM = LZD_RING - 1;
+    uint32_t op = 0;          // output position (bytes produced so far, incl. the ring-only part)
+    uint32_t fl = 0;          // g-positions below fl are in HBM
+    uint32_t ring_lo = 0;     // g-positions below ring_lo are NOT in the ring (after a straight HBM -> HBM sequence)
+    uint32_t bstart = 0;      // op at the start of the current batch
     uint32_t ip = 0;          // input position
     uint32_t ibase = 0;       // ib holds src[ibase, ibase + ibn), ibase a multiple of 16
     uint32_t ibn = 0;
     uint32_t nm = 0;          // matches recorded in the current batch
     uint32_t err = 0;
     bool done = false;
+    LZP_BEGIN
 
     auto refill = [&](uint32_t from) {
         ibase = from & ~15u;
@@ -138,95 +194,136 @@ __device__ uint32_t lz4_inflate_block(const uint8_t* src, uint32_t n, uint8_t* d
         }
         wave_sync();
     };
-    // staging -> HBM: g-positions [S0, g_end).  final: everything; otherwise whole 16-byte groups, the partial last
-    // group stays at the front of the window.  Bytes below a0 (in front of dst) are never written.
-    auto flush = [&](uint32_t g_end, bool final) {
+    // ring -> HBM: g-positions [fl, g_end).  Whole 16-byte groups with aligned stores; `all` also writes the partial
+    // last group (byte by byte; a later flush rewrites it from the ring).  Bytes below a0 are never written.
+    auto flush = [&](uint32_t g_end, bool all) {
         wave_sync();
-        const uint32_t full_end = final ? g_end : (g_end & ~15u);
-        uint32_t g = S0;
-        if (g < a0) {  // (S0 == 0) the first group starts in front of dst
-            const uint32_t e = min(16u, full_end);
-            if (lane >= a0 && lane < e) gbase[lane] = L.st[lane];
-            g = min(16u, max(full_end, S0));
+        const uint32_t full_end = g_end & ~15u;
+        uint32_t g = fl;
+        if (g < full_end && g < a0) {  // (fl == 0) the first group starts in front of dst: its bytes one by one
+            if (lane >= a0 && lane < 16) gbase[lane] = L.ring[lane];
+            g = 16;
         }
         const uint32_t ng = full_end > g ? (full_end - g) >> 4 : 0;
-        for (uint32_t k = lane; k < ng; k += 64) stu128(gbase + g + 16 * k, *(const u32x4*)(L.st + (g - S0) + 16 * k));
-        g += ng << 4;
-        if (final && g < g_end && lane < g_end - g) gbase[g + lane] = L.st[g - S0 + lane];
-        if (!final && full_end > S0) {
-            const uint32_t keep = g_end - full_end;
-            const uint32_t v = lane < keep ? (uint32_t)L.st[full_end - S0 + lane] : 0u;
-            wave_sync();
-            if (lane < keep) L.st[lane] = (uint8_t)v;
-            S0 = full_end;
+        for (uint32_t k = lane; k < ng; k += 64) {
+            const uint32_t gg = g + 16 * k;
+            stu128(gbase + gg, *(const u32x4*)(L.ring + (gg & RM)));
         }
+        if (all) {  // the partial last group
+            const uint32_t x = full_end + lane;
+            if (x < g_end && x >= a0) gbase[x] = L.ring[x & RM];
+        }
+        if (full_end > fl) fl = full_end;
         wave_sync();
     };
     // the matches recorded in L.m_* (in sequence order), then flush
-    auto run_batch = [&](bool final) {
+    auto run_batch = [&](bool all) {
+        const uint32_t g_op = op + a0;
+        LZP(4);
+        LZP_CNT(18, 1);
         if (nm) {
-            wave_stores_visible();  // earlier flushes must have landed before far sources are read back
-            const uint32_t o_flushed = S0 > a0 ? S0 - a0 : 0;  // output positions below this are in HBM
-            uint64_t near_m[2] = {0, 0};
+            // g-positions >= ring_min are in the ring now and stay there until the batch is complete
+            const uint32_t ring_min = max(ring_lo, g_op > LZD_RING ? g_op - LZD_RING : 0u);
+            bool waited = false;
             for (uint32_t k0 = 0; k0 < nm; k0 += 64) {
                 const uint32_t k = k0 + lane;
-                bool near = false;
-                if (k < nm) {
-                    const uint32_t d = L.m_dst[k], ml = L.m_len[k], off = L.m_off[k];
-                    const uint32_t s = d - off;
-                    if (s + min(ml, off) <= o_flushed) {  // far: the source bytes are in HBM
-                        uint8_t* w = L.st + (d + a0 - S0);
-                        if (off >= 16 && s + ((ml + 15) & ~15u) <= o_flushed) {
-                            for (uint32_t i = 0; i < ml; i += 16) {
-                                const u32x4 v = ldu128(dst + s + i);
-                                uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-                                const uint32_t nb = min(16u, ml - i);
-                                for (uint32_t b = 0; b < nb; b++) {
-                                    w[i + b] = (uint8_t)lo;
-                                    lo = (lo >> 8) | (hi << 56);
-                                    hi >>= 8;
-                                }
+                const bool have = k < nm;
+                uint32_t d = 0, ml = 0, off = 1;
+                if (have) { d = L.m_dst[k] + a0; ml = L.m_len[k]; off = L.m_off[k]; }
+                const uint32_t s = d - off;                    // g-position of the source
+                const uint32_t send = s + min(ml, off);        // every source byte lies in [s, send)
+                const bool in_ring = have && s >= ring_min;
+                const bool far = have && !in_ring && send <= fl;   // all source bytes are in HBM
+                const bool mixed = have && !in_ring && !far;       // straddles: serial path below
+                // ---- far matches: HBM -> ring, lane per match (one store->load wait per batch)
+                if (__ballot(far || mixed) && !waited) {
+                    wave_stores_visible();
+                    waited = true;
+                }
+                if (far) {
+                    if (off >= 16 && s + ((ml + 15) & ~15u) <= fl) {
+                        for (uint32_t i = 0; i < ml; i += 16) {
+                            const u32x4 v = ldu128(gbase + s + i);
+                            uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                            const uint32_t nb = min(16u, ml - i);
+                            for (uint32_t b = 0; b < nb; b++) {
+                                L.ring[(d + i + b) & RM] = (uint8_t)lo;
+                                lo = (lo >> 8) | (hi << 56);
+                                hi >>= 8;
                             }
-                        } else {
-                            for (uint32_t i = 0; i < ml; i++) w[i] = ldu8(dst + s + (off >= ml ? i : i % off));
                         }
                     } else {
-                        near = true;
-                    }
-                }
-                near_m[k0 >> 6] = __ballot(near);
-            }
-            wave_sync();
-            // near matches in sequence order, the wave copies one match at a time (LDS -> LDS)
-            for (uint32_t half = 0; half < 2; half++) {
-                uint64_t m = near_m[half];
-                while (m) {
-                    const uint32_t k = (uint32_t)__builtin_ctzll(m) + half * 64;
-                    m &= m - 1;
-                    const uint32_t d = L.m_dst[k], ml = L.m_len[k], off = L.m_off[k];
-                    const uint32_t s = d - off;
-                    const bool mixed = s < o_flushed;  // the source straddles the flushed / staged boundary
-                    const bool periodic = off < 64 && off < ml;  // then every byte comes from [s, s + off), all below d
-                    for (uint32_t i0 = 0; i0 < ml; i0 += 64) {
-                        const uint32_t i = i0 + lane;
-                        if (i < ml) {
-                            const uint32_t sp = s + (periodic ? i % off : i);
-                            uint8_t v;
-                            if (mixed && sp < o_flushed) v = ldu8(dst + sp); else v = L.st[sp + a0 - S0];
-                            L.st[d + i + a0 - S0] = v;
+                        for (uint32_t i = 0, j = 0; i < ml; i++) {
+                            L.ring[(d + i) & RM] = ldu8(gbase + s + j);
+                            if (++j == off) j = 0;
                         }
-                        wave_sync();
                     }
                 }
+                wave_sync();
+                LZP(5);
+                LZP_CNT(20, __popcll(__ballot(far)));
+                LZP_CNT(21, __popcll(__ballot(in_ring)));
+                // ---- ring matches of this chunk in sequence order, the wave copies one match at a time: lane i moves byte i
+                // (a lone wave pays ~8 cycles per dependent instruction and ~20 per taken branch, so the loop body is
+                // kept to three v_readlane, one LDS read and one LDS write; matches of up to 64 bytes take one pass)
+                uint64_t rem = __ballot(in_ring || mixed);
+                const uint64_t mixed_m = __ballot(mixed);
+                while (rem) {
+                    const uint32_t first = (uint32_t)__builtin_ctzll(rem);
+                    rem &= rem - 1;
+                    const uint32_t fd = rdlane(d, first), fml = rdlane(ml, first), foff = rdlane(off, first);
+                    const uint32_t fs = fd - foff;
+                    if (__builtin_expect(fml <= 64 && foff >= fml && !((mixed_m >> first) & 1), 1)) {   // the common shape: one pass
+                        if (lane < fml) L.ring[(fd + lane) & RM] = L.ring[(fs + lane) & RM];
+                        LZP_CNT(19, 1);
+                        continue;
+                    }
+                    if (__builtin_expect((mixed_m >> first) & 1, 0)) {  // byte source chosen per byte
+                        const bool periodic = foff < 64 && foff < fml;
+                        for (uint32_t i0 = 0; i0 < fml; i0 += 64) {
+                            const uint32_t i = i0 + lane;
+                            if (i < fml) {
+                                const uint32_t sp = fs + (periodic ? i % foff : i);
+                                const uint8_t v = sp < fl ? ldu8(gbase + sp) : L.ring[sp & RM];
+                                L.ring[(fd + i) & RM] = v;
+                            }
+                            wave_sync();
+                        }
+                        continue;
+                    }
+                    if (foff >= 64 || foff >= fml) {          // no lane reads a byte of this pass's writes
+                        for (uint32_t i0 = 0; i0 < fml; i0 += 64) {
+                            const uint32_t i = i0 + lane;
+                            if (i < fml) L.ring[(fd + i) & RM] = L.ring[(fs + i) & RM];
+                        }
+                    } else {                                  // short period: every byte comes from [fs, fs + foff)
+                        const uint32_t j0 = lane % foff, step = 64 % foff;
+                        uint32_t j = j0;
+                        for (uint32_t i0 = 0; i0 < fml; i0 += 64) {
+                            const uint32_t i = i0 + lane;
+                            if (i < fml) L.ring[(fd + i) & RM] = L.ring[(fs + j) & RM];
+                            j += step;
+                            if (j >= foff) j -= foff;
+                        }
+                    }
+                    LZP_CNT(19, 1);
+                }
+                wave_sync();
+                LZP(6);
             }
             nm = 0;
         }
-        flush(op + a0, final);
+        flush(g_op, all);
+        bstart = op;
+        LZP(7);
     };
 
     refill(0);
     while (!done && !err) {
+        LZP(4);
         if (ip + LZD_MARGIN > ibase + ibn && ibase + ibn < n) refill(ip);
+        LZP(0);
+        LZP_CNT(16, 1);
         // ---- speculative parse: lane l assumes a sequence starts at ip + l
         const uint32_t p = ip + lane;
         uint32_t lit = 0, ml = 0, off = 0, nxt = 0, flags = 0;  // flags: 1 = big (serial path), 2 = last sequence, 4 = invalid
@@ -265,44 +362,62 @@ __device__ uint32_t lz4_inflate_block(const uint8_t* src, uint32_t n, uint8_t* d
         }
         // ---- walk the chain of real sequence starts (wave-uniform): accepted lanes get their output position and,
         // for matches, their slot in the batch
+        LZP(1);
         const uint32_t tot = lit + ml;                   // output bytes of my sequence
+        // (the loop is the serial part of the parse: one v_readlane, the mask update and ONE taken branch per sequence;
+        // everything that can be computed per lane afterwards is)
+        const uint32_t comb = (flags & 5) ? 0x1000u | flags : ((flags & 2) ? 0x2000u : nxt - ip);   // (nxt - ip < 0x1000)
         uint64_t M = 0;
-        uint32_t cur = 0, acc = 0, cnt_m = 0, stop = 0;  // stop: 1 = batch full, 2 = big, 3 = last, 4 = bad
-        uint32_t my_op = 0, my_k = 0;
-        const uint32_t room = LZD_ST - (op + a0 - S0);   // staging bytes left
-        while (cur < 64) {
-            const uint32_t f = rdlane(flags, cur);
-            if (f & 4) { stop = 4; break; }
-            if (f & 1) { stop = 2; break; }
-            const uint32_t t = rdlane(tot, cur);
-            if (acc + t > room || nm + cnt_m >= LZD_MB) { stop = 1; break; }
+        uint32_t cur = 0, code = 0;
+        do {
+            const uint32_t v = rdlane(comb, cur);
+            if (v >= 0x1000) { code = v; break; }
             M |= 1ull << cur;
-            my_op = wrlane(op + acc, cur, my_op);
-            my_k = wrlane(nm + cnt_m, cur, my_k);
-            acc += t;
-            if (f & 2) { stop = 3; break; }
-            cnt_m++;
-            cur = rdlane(nxt, cur) - ip;
+            cur = v;
+        } while (cur < 64);
+        uint32_t stop = 0;                               // 1 = batch full, 2 = big, 3 = last, 4 = bad
+        if (code & 0x2000) { stop = 3; M |= 1ull << cur; }
+        else if (code & 4) stop = 4;
+        else if (code & 1) stop = 2;
+        // output positions and batch slots of the accepted lanes; cut the window where the batch is full
+        const uint32_t room = LZD_BATCH - (op - bstart);   // output bytes the batch still takes
+        bool mine = (M >> lane) & 1;
+        uint32_t incl = wave_scan_dpp(mine ? tot : 0u);
+        uint32_t rank = lane_rank(M);
+        const uint64_t over = __ballot(mine && (incl > room || nm + rank >= LZD_MB));
+        if (over) {
+            const uint32_t c = (uint32_t)__builtin_ctzll(over);
+            M &= (1ull << c) - 1;
+            mine = (M >> lane) & 1;
+            stop = 1;
+            cur = c;
         }
-        const bool mine = (M >> lane) & 1;
+        const uint32_t my_op = op + incl - tot, my_k = nm + rank;
+        const uint32_t cnt_all = (uint32_t)__popcll(M);
+        const uint32_t cnt_m = cnt_all - ((stop == 3) ? 1u : 0u);
+        const uint32_t acc = cnt_all ? rdlane(incl, 63u - (uint32_t)__builtin_clzll(M)) : 0u;
+        LZP(2);
+        LZP_CNT(17, cnt_m);
         bool bad = false;
         if (mine) {
             if (my_op + tot > out_len) bad = true;
             if (!(flags & 2) && (off == 0 || off > my_op + lit)) bad = true;
         }
         if (__ballot(bad)) { err = 103; break; }
-        {   // literals: staged input -> staging window; per lane up to 32 bytes, longer ones wave-wide
-            const uint32_t wpos = my_op + a0 - S0, rpos = q - ibase;
+        {   // literals: staged input -> ring; per lane up to 32 bytes, longer ones wave-wide
+            const uint32_t wpos = my_op + a0, rpos = q - ibase;
             const uint32_t nl = mine ? min(lit, 32u) : 0u;
-            for (uint32_t i = 0; i < nl; i++) L.st[wpos + i] = L.ib[rpos + i];
+            for (uint32_t i = 0; i < nl; i += 8)
+                lds_wr_bytes(L.ring, RM, wpos + i, lds_rd8((const uint32_t*)L.ib, rpos + i), nl - i);
             uint64_t lm = __ballot(mine && lit > 32);
             while (lm) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(lm);
                 lm &= lm - 1;
                 const uint32_t w2 = rdlane(wpos, l), r2 = rdlane(rpos, l), n2 = rdlane(lit, l);
-                for (uint32_t i = 32 + lane; i < n2; i += 64) L.st[w2 + i] = L.ib[r2 + i];
+                for (uint32_t i = 32 + lane; i < n2; i += 64) L.ring[(w2 + i) & RM] = L.ib[r2 + i];
             }
         }
+        LZP(3);
         if (mine && !(flags & 2)) {
             L.m_dst[my_k] = my_op + lit;
             L.m_len[my_k] = ml;
@@ -322,11 +437,10 @@ __device__ uint32_t lz4_inflate_block(const uint8_t* src, uint32_t n, uint8_t* d
             break;
         }
         ip += cur;                            // position of the sequence that did not fit / is big
-        run_batch(false);
+        run_batch(stop == 2);
         if (stop != 2) continue;
-        // ---- one big sequence, wave-serial: long literal run and / or long match, straight HBM -> HBM.
-        // The window holds only the < 16 carried bytes: write them out for good, restart the window afterwards.
-        flush(op + a0, true);
+        // ---- one big sequence, wave-serial: long literal run and / or long match, straight HBM -> HBM
+        // (run_batch(true) has written every byte produced so far)
         uint32_t x = ip;
         const uint32_t t = ldu8(src + x);
         x++;
@@ -360,52 +474,61 @@ __device__ uint32_t lz4_inflate_block(const uint8_t* src, uint32_t n, uint8_t* d
             }
             op += bm;
         }
-        // restart the staging window at the new output position: the partial 16-byte group below it is read back
-        // so that the next aligned flush rewrites the same bytes
+        // restart the ring at the new output position: nothing below is in the ring any more; the partial 16-byte
+        // group below op is read back so that the next aligned flush rewrites the same bytes
         wave_stores_visible();
-        S0 = (op + a0) & ~15u;
+        fl = (op + a0) & ~15u;
+        ring_lo = fl;
+        bstart = op;
         {
-            const uint32_t keep = (op + a0) - S0;
-            if (lane < keep && S0 + lane >= a0) L.st[lane] = ldu8(gbase + S0 + lane);
+            const uint32_t keep = (op + a0) - fl;
+            if (lane < keep && fl + lane >= a0) L.ring[(fl + lane) & RM] = ldu8(gbase + fl + lane);
         }
         wave_sync();
         ip = x;
+        LZP(8);
     }
+    if (!err && done) run_batch(true);
+    LZP_END;
     if (err) return err;
     if (!done) return 101;
-    run_batch(true);
     if (op != out_len) return 107;
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ encode
-// Workspace: 16 KiB of LDS (the callers' uint32_t[4096]).
-constexpr uint32_t LZE_HASH_BITS = 12;
-constexpr uint32_t LZE_WIN = 4096;       // input window kept in LDS: src[wb, wb + wn), wn <= LZE_WIN + 80
-constexpr uint32_t LZE_OUT = 3072;       // output staging
-constexpr uint32_t LZE_CAP = 64;         // per-lane match extension per step; longer matches extend wave-wide
+// The matcher looks back only as far as its LDS ring reaches (HB hash bits, 2^RB ring bytes): on zipf text 8 KiB of
+// history costs ~7 % of liblz4's ratio, 14 KiB ~5 % — and every probe, candidate check and match extension is an LDS
+// access, no HBM round trip inside a step.  Only matches longer than LZE_CAP are extended against HBM, wave-wide.
+constexpr uint32_t LZE_OUT = 2048;       // output staging
+constexpr uint32_t LZE_CAP = 32;         // per-lane match extension per step; longer matches extend wave-wide
 constexpr uint32_t LZE_LIT_LANE = 48;    // sequences with more literals than this are emitted wave-wide, one by one
+constexpr uint32_t LZE_AHEAD = 2048;     // input loaded this far beyond the step's first position
+template <int HB, int RB>
 struct Lz4EncLds {
-    uint16_t tab[1u << LZE_HASH_BITS];                          // 8 KiB: position & 0xFFFF of the last occurrence
-    __attribute__((aligned(16))) uint32_t win[(LZE_WIN + 96) / 4];  // ~4 KiB
-    __attribute__((aligned(16))) uint8_t out[LZE_OUT + 32];     // ~3 KiB
+    uint16_t tab[1u << HB];                                     // position & 0xFFFF of the last occurrence of a hash
+    __attribute__((aligned(16))) uint32_t ring[(1u << RB) / 4]; // input byte x lives at ring byte x % 2^RB
+    __attribute__((aligned(16))) uint8_t out[LZE_OUT + 32];
 };
-static_assert(sizeof(Lz4EncLds) <= 16384, "the callers pass a 16 KiB workspace");
 
 __device__ __forceinline__ uint32_t lz4_bound(uint32_t n) { return n + n / 255 + 16; }
 
 // Compress src[0, n) into dst (capacity >= lz4_bound(n)); executed by ONE wave64; returns the block size.
-__device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* ws) {
-    Lz4EncLds& L = *reinterpret_cast<Lz4EncLds*>(ws);
+template <int HB, int RB>
+__device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
+    constexpr uint32_t R = 1u << RB, RWM = R / 4 - 1;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t outp = 0;        // bytes already written to dst
     uint32_t on = 0;          // bytes staged in L.out
+    LZP_BEGIN
     auto flush_out = [&]() {
+        LZP(3);
         wave_sync();
         for (uint32_t k = lane; k < on; k += 64) dst[outp + k] = L.out[k];
         outp += on;
         on = 0;
         wave_sync();
+        LZP(4);
     };
     // token + literal-length extension for one sequence written by lane 0 straight to dst; returns its size
     auto put_head = [&](uint32_t lit, uint32_t mcode) -> uint32_t {
@@ -431,138 +554,188 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
         emit_last(0);
         return outp;
     }
-    for (uint32_t i = lane; i < (1u << LZE_HASH_BITS); i += 64) L.tab[i] = 0xFFFF;
+    for (uint32_t i = lane; i < (1u << HB); i += 64) L.tab[i] = 0xFFFF;
     const uint32_t mflimit = n - 12;      // a match may start at positions <= mflimit
     const uint32_t matchlimit = n - 5;    // and must end at or before this position
     uint32_t anchor = 0, base = 0, stride = 1;
-    uint32_t wb = 0, wn = 0;              // window: L.win holds src[wb, wb + wn)
-    auto load_window = [&](uint32_t from) {
-        wb = from & ~15u;
-        wn = min(LZE_WIN + 80u, n - wb);
+    uint32_t hi = 0;                      // input loaded into the ring up to here (multiple of 1024, or >= n)
+    auto fill = [&](uint32_t upto) {      // 1 KiB per instruction, 16-byte loads
         wave_sync();
-        uint8_t* w8 = (uint8_t*)L.win;
-        for (uint32_t k = lane * 16; k < wn; k += 64 * 16) {
-            if (wb + k + 16 <= n) *(u32x4*)(w8 + k) = ldu128(src + wb + k);
-            else for (uint32_t b = 0; b < 16; b++) w8[k + b] = wb + k + b < n ? ldu8(src + wb + k + b) : (uint8_t)0;
+        while (hi < n && hi < upto) {
+            const uint32_t x = hi + 16 * lane;
+            u32x4 v = {0, 0, 0, 0};
+            if (x + 16 <= n) {
+                v = ldu128(src + x);
+            } else if (x < n) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t b = 0; x + b < n; b++) w[b >> 2] |= (uint32_t)ldu8(src + x + b) << ((b & 3) * 8);
+                v = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            *(u32x4*)(L.ring + ((x & (R - 1)) >> 2)) = v;
+            hi += 1024;
         }
         wave_sync();
     };
-    load_window(0);
-    // 4 bytes at position x: from the window (two aligned dwords + v_alignbyte) when inside, else from HBM
-    auto win4 = [&](uint32_t x) -> uint32_t {
-        const uint32_t y = x - wb;
-        return __builtin_amdgcn_alignbyte(L.win[(y >> 2) + 1], L.win[y >> 2], y & 3);
+    auto rd4 = [&](uint32_t x) -> uint32_t {
+        const uint32_t w = (x >> 2) & RWM;
+        return __builtin_amdgcn_alignbyte(L.ring[(w + 1) & RWM], L.ring[w], x & 3);
     };
-    auto in_win = [&](uint32_t x, uint32_t len) -> bool { return x >= wb && x + len + 4 <= wb + wn; };  // (+4: the second dword)
-    auto ld4 = [&](uint32_t x) -> uint32_t { return in_win(x, 4) ? win4(x) : ldu32(src + x); };
+    auto rd8 = [&](uint32_t x) -> uint64_t {
+        const uint32_t w = (x >> 2) & RWM;
+        const uint32_t a = L.ring[w], b = L.ring[(w + 1) & RWM], c = L.ring[(w + 2) & RWM];
+        return (uint64_t)__builtin_amdgcn_alignbyte(b, a, x & 3) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, x & 3) << 32);
+    };
 
     while (base <= mflimit) {
-        {   // the step's positions and LZE_CAP + 16 bytes of look-ahead must be in the window
-            const uint32_t need = base + 63 * stride + LZE_CAP + 24;
-            if (need > wb + wn && wb + wn < n) load_window(base >= 1024 ? base - 1024 : 0);  // keep 1 KiB of history
-        }
+        LZP(3);
+        fill(base + LZE_AHEAD);
+        LZP(0);
+        LZP_CNT(16, 1);
+        const uint32_t lo_valid = hi > R ? hi - R : 0;   // positions below are no longer in the ring
         const uint32_t p = base + lane * stride;
-        const bool act = p <= mflimit && in_win(p, 4);   // (a step wider than the window probes only its front part)
+        // a probe needs its LZE_CAP + 16 bytes of look-ahead in the ring (a step spread wider probes only its front part)
+        const bool act = p <= mflimit && (p + LZE_CAP + 16 <= hi || hi >= n);
         uint32_t cand = 0, mlen = 0;
+        bool open = false;    // the extension stopped at LZE_CAP, not at a mismatch
         if (act) {
-            const uint32_t v4 = win4(p);
-            const uint32_t h = (v4 * 2654435761u) >> (32 - LZE_HASH_BITS);
+            // round trip 1: the eight dwords that hold bytes [p - 8, p + 20); t[k] = the 4 bytes at p - 8 + 4k
+            const uint32_t w0 = (p - 8) >> 2, q = p & 3;
+            uint32_t D[8], t[7];
+#pragma unroll
+            for (int k = 0; k < 8; k++) D[k] = L.ring[(w0 + k) & RWM];
+#pragma unroll
+            for (int k = 0; k < 7; k++) t[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], q);
+            const uint32_t v4 = t[2];
+            // round trip 2: the hash table
+            const uint32_t h = (v4 * 2654435761u) >> (32 - HB);
             const uint32_t e = L.tab[h];
             L.tab[h] = (uint16_t)(p & 0xFFFF);
-            // candidate from the table: the last position with this hash (mod 64 Ki), if inside the 64 KiB reach
-            uint32_t c = (p & ~0xFFFFu) | e;
-            if (c >= p) c -= 0x10000u;                       // (wraps above p when there is no such position)
-            bool ok = e != 0xFFFF && c < p && p - c <= 65535u;
-            uint32_t have = 0;                               // matching bytes known so far
-            if (ok) {
-                if (in_win(c, 16) && in_win(p, 16)) {
-                    ok = win4(c) == v4;
-                    if (ok) have = 4;
-                } else if (c + 16 <= n && in_win(p, 16)) {  // one round trip: 16 candidate bytes
-                    const u32x4 cv = ldu128(src + c);
-                    ok = cv.x == v4;
-                    if (ok) {
-                        have = 4;
-                        uint32_t d;
-                        if ((d = cv.y ^ win4(p + 4)) != 0) have = 4 + (__builtin_ctz(d) >> 3);
-                        else if ((d = cv.z ^ win4(p + 8)) != 0) have = 8 + (__builtin_ctz(d) >> 3);
-                        else if ((d = cv.w ^ win4(p + 12)) != 0) have = 12 + (__builtin_ctz(d) >> 3);
-                        else have = 16;
-                        if (have < 16) have |= 0x80000000u;  // mismatch found: final
-                    }
-                } else {
-                    ok = ldu32(src + c) == v4;
-                    if (ok) have = 4;
-                }
+            uint32_t c = 0;
+            bool ok = false;
+            if (stride == 1) {   // the periods columnar data repeats with (positions of this very step are not in the table
+                                 // yet, and the nearest candidate gives the longest runs): 8, 4, 2, 1 bytes back
+                if (p >= 8 && t[0] == v4) { c = p - 8; ok = true; }
+                else if (p >= 4 && t[1] == v4) { c = p - 4; ok = true; }
+                else if (p >= 2 && ((t[1] >> 16) | (t[2] << 16)) == v4) { c = p - 2; ok = true; }
+                else if (p >= 1 && ((t[1] >> 24) | (t[2] << 8)) == v4) { c = p - 1; ok = true; }
             }
-            if (!ok && stride == 1) {   // the periods columnar data repeats with (positions of this very step are not in
-                                        // the table yet): 8, 4, 2, 1 bytes back
-                if (p >= wb + 8 && win4(p - 8) == v4) { c = p - 8; ok = true; }
-                else if (p >= wb + 4 && win4(p - 4) == v4) { c = p - 4; ok = true; }
-                else if (p >= wb + 2 && win4(p - 2) == v4) { c = p - 2; ok = true; }
-                else if (p >= wb + 1 && win4(p - 1) == v4) { c = p - 1; ok = true; }
-                if (ok) have = 4;
+            if (!ok && e != 0xFFFF) {   // the last position with this hash (mod 64 Ki), if it is still in the ring
+                c = (p & ~0xFFFFu) | e;
+                if (c >= p) c -= 0x10000u;                   // (wraps above p when there is no such position)
+                ok = c < p && c >= lo_valid;
+            }
+            if (ok) {
+                // round trip 3: 16 candidate bytes against the 16 bytes at p
+                const uint32_t cw = c >> 2, cq = c & 3;
+                uint32_t E[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) E[k] = L.ring[(cw + k) & RWM];
+                uint32_t d;
+                if ((d = __builtin_amdgcn_alignbyte(E[1], E[0], cq) ^ v4) != 0) ok = false;
+                else if ((d = __builtin_amdgcn_alignbyte(E[2], E[1], cq) ^ t[3]) != 0) mlen = 4 + (__builtin_ctz(d) >> 3);
+                else if ((d = __builtin_amdgcn_alignbyte(E[3], E[2], cq) ^ t[4]) != 0) mlen = 8 + (__builtin_ctz(d) >> 3);
+                else if ((d = __builtin_amdgcn_alignbyte(E[4], E[3], cq) ^ t[5]) != 0) mlen = 12 + (__builtin_ctz(d) >> 3);
+                else { mlen = 16; open = true; }
             }
             if (ok) {
                 cand = c;
                 const uint32_t room = matchlimit - p;        // longest match allowed here (>= 7)
-                bool final = (have & 0x80000000u) != 0;
-                mlen = have & 0x7FFFFFFFu;
-                while (!final && mlen < LZE_CAP && mlen + 4 <= room) {
-                    const uint32_t d = ld4(c + mlen) ^ ld4(p + mlen);
-                    if (d) { mlen += __builtin_ctz(d) >> 3; final = true; } else mlen += 4;
+                while (open && mlen < LZE_CAP) {             // further round trips: 8 bytes each
+                    const uint64_t d = rd8(c + mlen) ^ rd8(p + mlen);
+                    if (d) { mlen += (uint32_t)__builtin_ctzll(d) >> 3; open = false; break; }
+                    mlen += 8;
                 }
-                if (!final && mlen < LZE_CAP) {              // fewer than 4 bytes of room left: byte by byte
-                    while (mlen < room && ldu8(src + c + mlen) == ldu8(src + p + mlen)) mlen++;
-                }
-                if (mlen > room) mlen = room;
+                if (mlen >= room) { mlen = room; open = false; }
+            } else {
+                mlen = 0;
+                open = false;
             }
         }
         const uint64_t mm = __ballot(mlen >= 4);
+        LZP(1);
         if (!mm) {
             base += 64 * stride;
-            stride++;
+            if (stride < 24) stride++;
             continue;
         }
-        // ---- greedy left-to-right selection of non-overlapping matches of this step (wave-uniform walk).  Chosen lanes
-        // get the start of their literals, the offset of their sequence in the staging buffer and its size.
-        uint64_t C = 0, big = 0;
+        // ---- greedy left-to-right selection of non-overlapping matches of this step.  Lazy matching first, per lane: a
+        // match steps aside when one of the next three positions starts a match that is longer by more than the
+        // distance.  Then the serial part — a wave-uniform walk over the match mask — is one v_readlane and one taken
+        // branch per chosen sequence; literal starts, sizes and staging offsets are computed per lane afterwards.
+        uint64_t msel = mm;
+        if (stride == 1) {
+            const uint32_t m1 = __shfl_down(mlen, 1, 64), m2 = __shfl_down(mlen, 2, 64), m3 = __shfl_down(mlen, 3, 64);
+            const bool dom = mlen >= 4 && ((lane < 63 && m1 > mlen + 1) || (lane < 62 && m2 > mlen + 2) || (lane < 61 && m3 > mlen + 3));
+            msel &= ~__ballot(dom);
+        }
+        const uint32_t mcomb = mlen | (open ? 0x80000000u : 0u);
+        uint64_t C = 0;
         uint32_t covered = anchor;            // everything below is emitted or pending as literals of the next sequence
-        uint32_t lit_start_v = 0, out_off_v = 0, run = 0;
-        uint32_t first_lane = 0;
-        for (;;) {
-            // lanes whose position is >= covered form a suffix: first lane = ceil((covered - base) / stride)
-            first_lane = covered > base ? (covered - base + stride - 1) / stride : 0;
-            if (first_lane >= 64) break;
-            const uint64_t m = (mm >> first_lane) << first_lane;
-            if (!m) break;
-            const uint32_t l = (uint32_t)__builtin_ctzll(m);
-            const uint32_t pl = base + l * stride;
-            uint32_t ml_l = rdlane(mlen, l);
-            if (ml_l >= LZE_CAP) {   // extend wave-wide, 64 x 4 bytes per step
-                const uint32_t c = rdlane(cand, l);
-                for (;;) {
-                    const uint32_t x = ml_l + 4 * lane;
-                    bool eq = pl + x + 4 <= matchlimit;
-                    if (eq) eq = ldu32(src + c + x) == ldu32(src + pl + x);
-                    const uint64_t ne = __ballot(!eq);
-                    const uint32_t take = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;
-                    ml_l += 4 * take;
-                    if (ne) break;
-                }
-                while (pl + ml_l < matchlimit && ldu8(src + c + ml_l) == ldu8(src + pl + ml_l)) ml_l++;  // < 4 steps
-                mlen = wrlane(ml_l, l, mlen);
+        // wave-wide extension of the match at lane l (position pl) beyond its per-lane part, 64 x 4 bytes per step from HBM
+        auto extend = [&](uint32_t l, uint32_t pl, uint32_t ml_l) -> uint32_t {
+            const uint32_t c = rdlane(cand, l);
+            for (;;) {
+                const uint32_t x = ml_l + 4 * lane;
+                bool eq = pl + x + 4 <= matchlimit;
+                if (eq) eq = ldu32(src + c + x) == ldu32(src + pl + x);
+                const uint64_t ne = __ballot(!eq);
+                const uint32_t take = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;
+                ml_l += 4 * take;
+                if (ne) break;
             }
-            const uint32_t lit = pl - covered, mcode = ml_l - 4;
-            const uint32_t sz = 1 + (lit >= 15 ? 1 + div255(lit - 15) : 0) + lit + 2 + (mcode >= 15 ? 1 + div255(mcode - 15) : 0);
-            C |= 1ull << l;
-            if (lit > LZE_LIT_LANE) big |= 1ull << l;
-            lit_start_v = wrlane(covered, l, lit_start_v);
-            out_off_v = wrlane(run, l, out_off_v);
-            run += sz;
-            covered = pl + ml_l;
+            while (pl + ml_l < matchlimit && ldu8(src + c + ml_l) == ldu8(src + pl + ml_l)) ml_l++;  // < 4 steps
+            mlen = wrlane(ml_l, l, mlen);
+            return ml_l;
+        };
+        if (stride == 1) {
+            uint32_t rel = 0;                 // (anchor <= base: the first lane is free)
+            do {
+                const uint64_t m = (msel >> rel) << rel;
+                if (!m) break;
+                const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                const uint32_t v = rdlane(mcomb, l);
+                uint32_t ml_l = v & 0x7FFFFFFFu;
+                if (__builtin_expect(v >> 31, 0)) ml_l = extend(l, base + l, ml_l);
+                C |= 1ull << l;
+                rel = l + ml_l;
+            } while (rel < 64);
+            if (C) covered = base + rel;
+        } else {
+            for (;;) {
+                // lanes whose position is >= covered form a suffix: first lane = ceil((covered - base) / stride)
+                const uint32_t first_lane = covered <= base ? 0u : (covered - base + stride - 1) / stride;
+                if (first_lane >= 64) break;
+                const uint64_t m = (msel >> first_lane) << first_lane;
+                if (!m) break;
+                const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                const uint32_t v = rdlane(mcomb, l);
+                uint32_t ml_l = v & 0x7FFFFFFFu;
+                const uint32_t pl = base + l * stride;
+                if (v >> 31) ml_l = extend(l, pl, ml_l);
+                C |= 1ull << l;
+                covered = pl + ml_l;
+            }
         }
         const bool chosen = (C >> lane) & 1;
+        uint32_t lit_start_v = anchor;
+        {
+            const uint64_t below = C & ((1ull << lane) - 1);
+            const uint32_t prevl = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+            const uint32_t pe = __shfl(p + mlen, prevl, 64);     // end of the previous chosen match
+            if (below) lit_start_v = pe;
+        }
+        uint32_t sz = 0;
+        if (chosen) {
+            const uint32_t lit = p - lit_start_v, mcode = mlen - 4;
+            sz = 1 + (lit >= 15 ? 1 + div255(lit - 15) : 0) + lit + 2 + (mcode >= 15 ? 1 + div255(mcode - 15) : 0);
+        }
+        const uint64_t big = __ballot(chosen && p - lit_start_v > LZE_LIT_LANE);
+        const uint32_t incl_sz = wave_scan_dpp(sz);
+        const uint32_t out_off_v = incl_sz - sz;
+        const uint32_t run = rdlane(incl_sz, 63);
+        LZP(2);
+        LZP_CNT(17, __popcll(C));
+        if (big || run > LZE_OUT) LZP_CNT(18, 1);
         if (!big && run <= LZE_OUT) {
             // ---- every chosen lane writes its own sequence into the staging buffer
             if (on + run > LZE_OUT) flush_out();
@@ -576,10 +749,13 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
                     while (r >= 255) { o[k++] = 255; r -= 255; }
                     o[k++] = (uint8_t)r;
                 }
-                const uint8_t* w8 = (const uint8_t*)L.win;
-                for (uint32_t i = 0; i < lit; i++) {
-                    const uint32_t x = lit_start_v + i;
-                    o[k++] = (x >= wb && x < wb + wn) ? w8[x - wb] : ldu8(src + x);
+                for (uint32_t i = 0; i < lit; i += 8) {   // (<= 48 bytes back: in the ring)
+                    const uint64_t v = lds_rd8_ring(L.ring, (lit_start_v + i) & (R - 1), RWM);
+                    const uint32_t nb = min(8u, lit - i);
+#pragma unroll
+                    for (uint32_t b = 0; b < 8; b++)
+                        if (b < nb) o[k + b] = (uint8_t)(v >> (8 * b));
+                    k += nb;
                 }
                 o[k++] = (uint8_t)off;
                 o[k++] = (uint8_t)(off >> 8);
@@ -621,7 +797,10 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
         base = max(covered, base + 1);
         stride = 1;
     }
+    LZP(3);
     emit_last(anchor);
+    LZP(5);
+    LZP_END;
     return outp;
 }
 

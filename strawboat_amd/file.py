@@ -203,19 +203,7 @@ class NativeWriter:
         self.close()
 
 
-def schema_to_bytes(schema) -> bytes:
-    """The bare IPC Schema message flatbuffer (what arrow2's schema_to_bytes returns): pyarrow's
-    encapsulated message minus its 8-byte continuation + length prefix."""
-    enc = schema.serialize().to_pybytes()
-    assert enc[:4] == b"\xff\xff\xff\xff"
-    (n,) = struct.unpack_from("<i", enc, 4)
-    return enc[8:8 + n]
-
-
-def schema_from_bytes(raw: bytes):
-    pa = _pa()
-    pad = (-len(raw)) % 8
-    return pa.ipc.read_schema(pa.py_buffer(b"\xff\xff\xff\xff" + struct.pack("<i", len(raw) + pad) + raw + b"\x00" * pad))
+from .schema import schema_from_bytes, schema_to_bytes  # noqa: E402,F401  (the library's own flatbuffer writer / reader)
 
 
 class FileReader:

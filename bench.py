@@ -377,6 +377,92 @@ def run_c5(h, cpu_on):
                                                      "API, wall time incl. host work"})
 
 
+def run_c4_sharded(h, world, rank, dist, steps=3, on_device=True):
+    """C4 as BASELINE.json states it: the 8-column mixed schema x 10 M rows, (column, page-range) work items dealt to the
+    ranks by strawboat_amd.shard.plan_work_items, every rank encodes and decodes its own items with the device codecs,
+    ONE all_gather of the page metas (RCCL over xGMI).  Strong scaling: the job is fixed, value = job bytes / max-over-
+    ranks time.  Returns the entry for `configs` on rank 0 (None elsewhere)."""
+    import torch
+    from strawboat_amd import read, shard, write
+    from strawboat_amd.types import Compression as C, WriteOptions
+    ctx = h.ctx
+    rows = 10_000_000
+    npages = (rows + PAGE - 1) // PAGE
+    # per-column Arrow bytes are a function of the generator alone: every rank computes the same plan without the data
+    est = {"int32": rows * 4 + rows // 8, "float64": rows * 8 + rows // 8, "utf8": rows * 18 + rows // 8, "boolean": rows // 4}
+    names = ["int32_0", "int32_1", "float64_0", "float64_1", "utf8_0", "utf8_1", "boolean_0", "boolean_1"]
+    plan = shard.plan_work_items([(est[n.split("_")[0]], npages) for n in names], world)
+    mine = plan[rank]
+    need = sorted({it.column for it in mine})
+    full = {}
+    for ci in need:   # the columns this rank touches (seeds as in workloads.c4_columns)
+        kind, j = names[ci].split("_")
+        j = int(j)
+        if kind == "int32":
+            rng = np.random.default_rng(42 + j)
+            full[ci] = dict(ptype=W.T_I32, nullable=True, rows=rows, values=rng.integers(0, 1000, rows).astype(np.int32), validity=None, offsets=None)
+        elif kind == "float64":
+            full[ci] = W.c2_float64(52 + j, rows)
+        elif kind == "utf8":
+            full[ci] = W.zipf_utf8(rows, 62 + j, null_density=0.1)
+        else:
+            rng = np.random.default_rng(72 + j)
+            full[ci] = dict(ptype=W.T_BOOL, nullable=True, rows=rows, values=W.pack_bits(rng.random(rows) < 0.5),
+                            validity=W.pack_bits(rng.random(rows) >= 0.1), offsets=None)
+    opts = WriteOptions(max_page_size=PAGE, default_compression=C.LZ4, default_compress_ratio=2.0)
+    parts = [shard.slice_column(full[it.column], it.first_page, it.n_pages, PAGE) for it in mine]
+    U_local = sum(W.arrow_bytes(c) for c in parts)
+    dcs = []
+    for it, c in zip(mine, parts):
+        d = h.dcol(c)
+        d.first_page_index = it.first_page
+        d.column_values_len = c.get("column_values_len", 0)
+        dcs.append(d)
+    del full
+    enc = write.encode_columns(ctx, dcs, opts)
+    ctx.synchronize()
+    cps = [read.ColumnPages(c["ptype"], c["nullable"], e.pages, e.metas_array()) for c, e in zip(parts, enc)]
+    dec = read.batch_read_columns(ctx, cps)
+    ctx.synchronize()
+    if parts:
+        h.check_round_trip(parts[0], dec[0])
+    wb, rb = write.WriteBatch(ctx, dcs, opts, out=enc), read.ReadBatch(ctx, cps, out=dec)
+    cap = shard.record_capacity(plan)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wb.enqueue()
+        rb.enqueue()
+    ctx.synchronize()
+    items = [(it.column, it.first_page, e.metas_array()) for it, e in zip(mine, enc)]
+    allm = shard.gather_metas(items, len(names), capacity=cap, device=h.dev if (world > 1 and on_device) else None)
+    cm = shard.column_metas(allm)
+    barrier()
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el, float(U_local)], dtype=torch.float64, device=h.dev if on_device else "cpu")
+    if world > 1:
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        el, U = float(mx[0].item()), float(sm[1].item())
+    else:
+        U = float(U_local)
+    assert all(len(m.pages) == npages for m in cm), "every column must come back with all of its pages"
+    if rank != 0:
+        return None
+    return {"workload": "C4: 8-column mixed schema x 10 M rows, %d (column, page-range) work items over %d GPU(s), LZ4 default, ratio 2.0, "
+                        "encode+decode of every item + ONE all_gather of %d page metas" % (sum(len(s) for s in plan), world, len(names) * npages),
+            "scaling": "strong", "n_gpus": world, "steps": steps, "arrow_MB": round(U / 1e6, 1),
+            "ms_per_step": round(el / steps * 1e3, 3), "encdec_GBps": round(2.0 * U * steps / el / 1e9, 1),
+            "items_per_rank": [len(s) for s in plan], "record_capacity": cap}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,6 +473,9 @@ def main():
                     help="adaptive = default_compress_ratio 2.0, codec chosen per page on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the sweep over the other configurations")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; nccl = RCCL over xGMI (the measured configuration).  gloo lets the N > 1 path be "
+                         "exercised on a box with fewer GPUs than ranks (ranks then share devices): a functional check, not a number")
     ap.add_argument("--only", default=None, help="comma list of configs (c1,c3,c3_lz4,c4,c5,continuity): run ONLY these, "
                                                  "without the headline (profiling runs)")
     args = ap.parse_args()
@@ -399,10 +488,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback in strawboat_amd)")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible); RCCL needs one device per rank" % (rank, ndev))
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL
+        dist.init_process_group(args.backend, rank=rank, world_size=world)  # nccl == RCCL on ROCm
 
     import strawboat_amd as sb
     from strawboat_amd import read, write
@@ -473,7 +566,8 @@ def main():
     if world > 1:  # the one collective of the path: page metas of every rank (RCCL all_gather)
         from strawboat_amd import shard
         local = {rank * B + i: e.metas_array() for i, e in enumerate(enc)}
-        all_metas = shard.gather_metas(local, world * B, device=dev)
+        all_metas = shard.gather_metas(local, world * B, capacity=B * ((ROWS + PAGE - 1) // PAGE),
+                                       device=dev if args.backend == "nccl" else None)
         assert len(shard.column_metas(all_metas)) == world * B
     barrier()
     t1 = time.perf_counter()
@@ -487,9 +581,13 @@ def main():
     stats = ctx.profile_read()
     ctx.profile(False)
 
+    c4s = None
+    if world > 1 and not args.no_configs:   # the configuration BASELINE names for 8 GPUs, sharded by page ranges
+        del wbatch, rbatch
+        c4s = run_c4_sharded(harness, world, rank, dist, on_device=args.backend == "nccl")
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -540,6 +638,8 @@ def main():
             cpu = cpu_baseline([c0], o, U_col, "1 column (1 M rows, 16 pages) of the same workload, encode+decode, best of 2; the all-cores "
                                                "leg runs replicas of it page-parallel over std::threads")
         configs = None
+        if world > 1 and not args.no_configs:
+            configs = {"c4_sharded": c4s}
         if world == 1 and not args.no_configs:
             del wbatch, rbatch, enc, dec, pages, cols
             torch.cuda.empty_cache()

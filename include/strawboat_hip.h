@@ -186,6 +186,15 @@ typedef struct sb_column_write {
     const uint64_t* page_head_bytes;
     const uint8_t* page_heads;
     uint64_t n_pages_in;
+    /* index of this call's first page inside its column (0 for a whole column).  A rank that encodes pages
+     * [first, first + n) of a column (SURVEY §8e work items) passes `first`, so that the per-page sampling seeds — and
+     * hence the adaptive codec choice — are those of a single writer. */
+    uint64_t first_page_index;
+    /* binary columns: byte length of the COLUMN's whole values buffer when `values` holds only the bytes of this page
+     * range (0 = values_len).  Upstream slices arrays page by page without slicing the values buffer, so
+     * array.values().len() — which enters the selector's total_bytes (binary/mod.rs:270) and the hdr9 of Dict / Freq /
+     * OneValue pages (binary/mod.rs:88) — is the length of the whole column's buffer. */
+    uint64_t column_values_len;
 } sb_column_write;
 
 /* upper bound of the encoded size of a column, and its page count (A.4 page arithmetic) */

@@ -84,6 +84,7 @@ struct WriteOptions {
     int32_t force_codec = -1;              // top-level page codec, -1 = choose
     int32_t force_index_codec = -1;        // nested (Dict indices / Freq exceptions) codec
     uint64_t rng_seed = 42;                // page-level sampling seed
+    uint64_t page_index0 = 0;              // index of the call's first page inside its column (page-range work items)
     bool forbidden(uint8_t c) const { return (forbidden_mask >> c) & 1u; }
 };
 

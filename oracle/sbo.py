@@ -43,7 +43,7 @@ class _Options(C.Structure):
     _fields_ = [("default_compression", C.c_uint8), ("has_ratio", C.c_uint8), ("pad_", C.c_uint8 * 6),
                 ("ratio", C.c_double), ("max_page_size", C.c_uint64), ("forbidden_mask", C.c_uint32),
                 ("force_codec", C.c_int32), ("force_index_codec", C.c_int32), ("pad2_", C.c_int32),
-                ("rng_seed", C.c_uint64)]
+                ("rng_seed", C.c_uint64), ("page_index0", C.c_uint64)]
 
 
 _lib = None
@@ -118,7 +118,7 @@ def _bytes_view(a):
 
 
 def make_options(default_compression=NONE, ratio=None, max_page_size=None, forbidden=(), force_codec=-1,
-                 force_index_codec=-1, rng_seed=42):
+                 force_index_codec=-1, rng_seed=42, page_index0=0):
     o = _Options()
     o.default_compression = default_compression
     o.has_ratio = 0 if ratio is None else 1
@@ -131,6 +131,7 @@ def make_options(default_compression=NONE, ratio=None, max_page_size=None, forbi
     o.force_codec = force_codec
     o.force_index_codec = force_index_codec
     o.rng_seed = rng_seed
+    o.page_index0 = page_index0
     return o
 
 

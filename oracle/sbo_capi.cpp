@@ -37,6 +37,7 @@ struct sbo_options {
     int32_t force_index_codec;
     int32_t pad2_;
     uint64_t rng_seed;
+    uint64_t page_index0;
 };
 
 struct sbo_written {
@@ -73,6 +74,7 @@ static WriteOptions to_opts(const sbo_options* o) {
     w.force_codec = o->force_codec;
     w.force_index_codec = o->force_index_codec;
     w.rng_seed = o->rng_seed;
+    w.page_index0 = o->page_index0;
     return w;
 }
 
@@ -283,7 +285,7 @@ int32_t sbo_time_pages_mt(const sbo_column_in* cols, uint64_t n_cols, const sbo_
                 else
                     it.page.values = col.values + off * wd;
                 it.opts = w;
-                it.opts.rng_seed = mix64(w.rng_seed ^ (k * 0xD6E8FEB86659FD93ull));
+                it.opts.rng_seed = mix64(w.rng_seed ^ ((w.page_index0 + k) * 0xD6E8FEB86659FD93ull));
                 it.meta.num_values = it.page.rows;
                 it.meta.length = 0;
                 items.push_back(std::move(it));

@@ -1427,7 +1427,7 @@ void write_column(const ColumnIn& col, const WriteOptions& opts, std::vector<uin
         else
             page.values = col.values + offset * w;
         WriteOptions popts = opts;
-        popts.rng_seed = mix64(opts.rng_seed ^ (page_index * 0xD6E8FEB86659FD93ull));
+        popts.rng_seed = mix64(opts.rng_seed ^ ((opts.page_index0 + page_index) * 0xD6E8FEB86659FD93ull));
         size_t start = out.size();
         write_page(page, popts, out);
         metas.push_back(PageMeta{(uint64_t)(out.size() - start), length});

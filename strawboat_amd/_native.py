@@ -50,7 +50,7 @@ class ColumnWriteC(C.Structure):
                 ("out_pages", C.c_void_p), ("out_capacity", C.c_uint64), ("out_metas", C.POINTER(PageMetaC)),
                 ("n_pages_capacity", C.c_uint64), ("n_pages", C.c_uint64), ("out_len", C.c_uint64),
                 ("page_rows", C.c_void_p), ("page_head_bytes", C.c_void_p), ("page_heads", C.c_void_p),
-                ("n_pages_in", C.c_uint64)]
+                ("n_pages_in", C.c_uint64), ("first_page_index", C.c_uint64), ("column_values_len", C.c_uint64)]
 
 
 class NestedLevelC(C.Structure):

@@ -37,6 +37,7 @@ struct EncCol {
     uint8_t* out;
     uint64_t values_bit_offset;
     uint64_t values_len;
+    uint64_t values_len_total;  // array.values().len() of the column (== values_len unless the call holds a page range)
     uint64_t validity_bit_offset;
     uint64_t out_cap;
     uint64_t rows;
@@ -2410,7 +2411,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
     }
     __syncthreads();
     // uncompressed_size = array.values().len(): the whole shared buffer (binary/mod.rs:88)
-    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)CODEC, (uint32_t)body, (uint32_t)c.values_len);
+    if (threadIdx.x == 0) put_hdr9(blk, (uint32_t)CODEC, (uint32_t)body, (uint32_t)c.values_len_total);
     return 9 + body;
 }
 
@@ -2455,10 +2456,10 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
         codec = choose_bool(c.values, c.values_bit_offset + p.row0, vv, N, so, sc);
     } else if constexpr (KIND == -4) {
         BinKeys<int32_t> bk{c.offsets + p.row0 * 4, c.values, vv};
-        codec = choose_bin<int32_t>(bk, N, c.values_len, so, sc);
+        codec = choose_bin<int32_t>(bk, N, c.values_len_total, so, sc);
     } else if constexpr (KIND == -8) {
         BinKeys<int64_t> bk{c.offsets + p.row0 * 8, c.values, vv};
-        codec = choose_bin<int64_t>(bk, N, c.values_len, so, sc);
+        codec = choose_bin<int64_t>(bk, N, c.values_len_total, so, sc);
     } else {
         const uint8_t* vals = c.values + p.row0 * KIND;
         codec = choose_prim<KIND>([=](uint64_t i) { return ld_val<KIND>(vals + i * KIND); }, vv, N, c.nk, so, sc);
@@ -3179,7 +3180,7 @@ __device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPag
     __syncthreads();
     if (t == 0) {
         const uint64_t body = 8 + top_len + 4 + rb_size + carry;
-        put_hdr9(blk, SB_CODEC_FREQ, (uint32_t)body, (uint32_t)c.values_len);  // binary/mod.rs:83-88
+        put_hdr9(blk, SB_CODEC_FREQ, (uint32_t)body, (uint32_t)c.values_len_total);  // binary/mod.rs:83-88
         EncOut o;
         o.length = pos + 9 + body;
         o.out_off = 0;
@@ -3441,7 +3442,7 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
                 const uint64_t pos = c.nullable ? def_section_bytes(p.rows) : 0;
                 const uint64_t btotal = o.length + vo.length + 4 + epos;
                 put_hdr9(o.slot + pos + 9, SB_CODEC_FREQ, (uint32_t)(o.length + vo.length - pos - 18), (uint32_t)(p.rows * 4));
-                put_hdr9(o.slot + pos, SB_CODEC_DICT, (uint32_t)(btotal - pos - 9), (uint32_t)c.values_len);  // binary/mod.rs:88
+                put_hdr9(o.slot + pos, SB_CODEC_DICT, (uint32_t)(btotal - pos - 9), (uint32_t)c.values_len_total);  // binary/mod.rs:88
                 EncOut z = o;
                 z.length = btotal;
                 z.pad = 0;
@@ -3951,6 +3952,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         d.heads = mem == SB_MEM_HOST ? dheads[i] : c.page_heads;
         d.values_bit_offset = c.values_bit_offset;
         d.values_len = c.values_len;
+        d.values_len_total = c.column_values_len ? c.column_values_len : c.values_len;
         d.validity_bit_offset = c.validity_bit_offset;
         d.out_cap = c.out_capacity;
         d.rows = c.rows;
@@ -3983,7 +3985,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             p.col = (uint32_t)i;
             p.codec = codec;
             p.icodec = opts->force_index_codec;
-            p.seed = page_seed_of(opts->rng_seed, k);
+            p.seed = page_seed_of(opts->rng_seed, c.first_page_index + k);
             p.direct = direct ? 1 : 0;
             if (direct) {
                 p.direct_off = direct_off;

@@ -29,6 +29,8 @@ class DeviceColumn:
     offsets: Optional[object] = None    # binary: rows+1 offsets (i32 / i64) as bytes
     values_bit_offset: int = 0          # boolean
     validity_bit_offset: int = 0
+    first_page_index: int = 0           # pages [first, first + n) of a column encoded on their own (shard.WorkItem)
+    column_values_len: int = 0          # binary page ranges: byte length of the column's whole values buffer (0 = this one)
 
 
 class EncodedColumn:
@@ -117,6 +119,8 @@ class WriteBatch:
                 c.validity = _ptr(col.validity)
                 c.validity_bit_offset = col.validity_bit_offset
                 c.offsets = _ptr(col.offsets)
+                c.first_page_index = col.first_page_index
+                c.column_values_len = col.column_values_len
                 if out is not None:
                     pages, metas = out[i].pages, out[i]._metas
                 else:

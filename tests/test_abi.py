@@ -68,4 +68,4 @@ def test_struct_layouts_match_header():
     assert C.sizeof(N.PageMetaC) == 16
     assert C.sizeof(N.WriteOptionsC) == 48
     assert C.sizeof(N.ColumnReadC) == 112
-    assert C.sizeof(N.ColumnWriteC) == 144
+    assert C.sizeof(N.ColumnWriteC) == 160

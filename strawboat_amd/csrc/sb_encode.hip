@@ -74,6 +74,7 @@ struct EncPage {
     uint64_t slot_cap;    // bytes available in the page's slot (Freq pages append a block of unknown size)
     uint32_t depth;       // nesting depth of this block (sampling RNG stream; 0 = page)
     uint32_t forb_extra;  // codecs forbidden for this block in addition to the options'
+    uint64_t h64_off;     // binary pages: scratch offset of one u64 hash per row (~0: none), written by bin_hash_rows
 };
 
 struct EncOut {
@@ -1344,7 +1345,7 @@ __device__ __forceinline__ uint32_t table_load(uint32_t* p) {
 template <class KeyOps>
 __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t aux_words, uint32_t** idx_out,
                                uint32_t** firsts_out, uint32_t* sA, uint32_t* sB, uint32_t* s_w, Status* st,
-                               uint32_t page) {
+                               uint32_t page, uint32_t* lds_table = nullptr, uint32_t lds_slots = 0) {
     const int t = threadIdx.x;
     uint64_t M = 64;
     while (M < 2 * N) M <<= 1;
@@ -1352,45 +1353,70 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
         if (t == 0) raise(st, SB_ERR_INVALID, page, 510);
         return EMPTY;
     }
-    uint32_t* table = aux;
     uint32_t* F = aux + M;       // row -> first row with the same key
     uint32_t* R = F + N;         // first row -> dictionary id ; later: dict id -> first row (firsts)
     uint32_t* idx = R + N;
-    for (uint64_t i = t; i < M; i += WG) table[i] = EMPTY;
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const uint32_t mask = (uint32_t)(M - 1);
-    // phase 1: insert; the slot of a key ends up holding the smallest row that carries it.  The slot a row
-    // landed in is remembered (in F), so that phase 2 does not hash and compare the key a second time.
-    for (uint64_t i = t; i < N; i += WG) {
-        if (!ko.keyed(i)) {
-            F[i] = EMPTY;
-            continue;
-        }
-        uint32_t h = ko.hash(i) & mask;
-        for (;;) {
-            uint32_t cur = table_load(&table[h]);
-            if (cur == EMPTY) {
-                const uint32_t old = atomicCAS(&table[h], EMPTY, (uint32_t)i);
-                if (old == EMPTY) break;
-                cur = old;
+    __shared__ uint32_t s_keys;
+    // The table of first rows: in LDS while the page has few distinct keys (tier 0: every probe is an LDS access; string
+    // keys are compared through L2), in HBM otherwise (tier 1: pow2 >= 2N slots in the aux area).
+    for (int tier = (lds_table && lds_slots) ? 0 : 1; tier < 2; tier++) {
+        uint32_t* table = tier == 0 ? lds_table : aux;
+        const uint64_t slots = tier == 0 ? lds_slots : M;
+        const uint32_t cap = tier == 0 ? min(lds_slots / 8 * 5, lds_slots - (uint32_t)WG * 16 - 1) : 0xFFFFFFFFu;   // (see distinct_count)
+        for (uint64_t i = t; i < slots; i += WG) table[i] = EMPTY;
+        if (t == 0) s_keys = 0;
+        __syncthreads();
+        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t mask = (uint32_t)(slots - 1);
+        bool overflow = false;
+        // phase 1: insert; the slot of a key ends up holding the smallest row that carries it.  The slot a row
+        // landed in is remembered (in F), so that phase 2 does not hash and compare the key a second time.
+        for (uint64_t base = 0; base < N; base += (uint64_t)WG * 16) {
+            for (int j = 0; j < 16; j++) {
+                const uint64_t i = base + (uint64_t)j * WG + t;
+                if (i >= N) break;
+                if (!ko.keyed(i)) {
+                    F[i] = EMPTY;
+                    continue;
+                }
+                uint32_t h = ko.hash(i) & mask;
+                for (;;) {
+                    uint32_t cur = tier == 0 ? table[h] : table_load(&table[h]);
+                    if (cur == EMPTY) {
+                        const uint32_t old = atomicCAS(&table[h], EMPTY, (uint32_t)i);
+                        if (old == EMPTY) {
+                            if (tier == 0) atomicAdd(&s_keys, 1u);
+                            break;
+                        }
+                        cur = old;
+                    }
+                    if (cur == (uint32_t)i || ko.eq(cur, i)) {
+                        if ((uint32_t)i < cur) atomicMin(&table[h], (uint32_t)i);  // rows arrive roughly in order: rarely needed
+                        break;
+                    }
+                    h = (h + 1) & mask;
+                }
+                F[i] = h;
             }
-            if (ko.eq(cur, i)) {
-                if ((uint32_t)i < cur) atomicMin(&table[h], (uint32_t)i);  // rows arrive roughly in order: rarely needed
-                break;
+            if (tier == 0) {   // too many distinct keys for the LDS table: start over on the HBM one
+                __syncthreads();
+                if (s_keys > cap) {
+                    overflow = true;
+                    break;
+                }
             }
-            h = (h + 1) & mask;
         }
-        F[i] = h;
+        __syncthreads();
+        if (overflow) continue;
+        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        // phase 2: F[i] = first row of row i's key (a key never leaves its slot)
+        for (uint64_t i = t; i < N; i += WG) {
+            const uint32_t h = F[i];
+            if (h != EMPTY) F[i] = tier == 0 ? table[h] : table_load(&table[h]);
+        }
+        __syncthreads();
+        break;
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-    // phase 2: F[i] = first row of row i's key (a key never leaves its slot)
-    for (uint64_t i = t; i < N; i += WG) {
-        const uint32_t h = F[i];
-        if (h != EMPTY) F[i] = table_load(&table[h]);
-    }
-    __syncthreads();
     // phase 3: dictionary ids in first-occurrence order (rank of first rows), chunked scan
     uint32_t nent = 0;
     for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
@@ -1420,8 +1446,8 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
         if (lk) carry_last = (uint32_t)(cb + lk);
         __syncthreads();
     }
-    // phase 5: firsts[id] = first row (re-use the table area: it is no longer needed)
-    uint32_t* firsts = table;
+    // phase 5: firsts[id] = first row (the HBM table area: not needed any more, or never used)
+    uint32_t* firsts = aux;
     for (uint64_t i = t; i < N; i += WG)
         if (F[i] == (uint32_t)i) firsts[R[i]] = (uint32_t)i;
     __syncthreads();
@@ -1478,6 +1504,71 @@ struct BinKeys {
     }
 };
 
+// ---- binary pages: one 64-bit hash per row, computed ONCE per page in a streaming pass (four rows in flight per
+// thread), so that the selector's statistics and the dictionary build probe with 8-byte keys instead of chasing
+// offsets -> bytes for both strings of every comparison.  Statistics treat equal hashes (the length is mixed in) as
+// equal strings; the dictionary build, which decides what bytes a page holds, still compares the strings.
+__device__ __forceinline__ uint64_t bin_hash_bytes(const uint8_t* values, uint64_t b, uint64_t e, uint64_t values_len) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((e - b) * 0xD6E8FEB86659FD93ull);
+    uint64_t p = b;
+    for (; p + 8 <= e; p += 8) {
+        h = (h ^ ldu64(values + p)) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    if (p < e) {
+        uint64_t w = 0;
+        if (p + 8 <= values_len) {
+            w = ldu64(values + p) & ((1ull << (8 * (e - p))) - 1);
+        } else {
+            for (uint64_t k = 0; p + k < e; k++) w |= (uint64_t)ldu8(values + p + k) << (8 * k);
+        }
+        h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+        h ^= h >> 29;
+    }
+    h *= 0x94D049BB133111EBull;
+    return h ^ (h >> 31);
+}
+template <class O>
+__device__ void bin_hash_rows(const BinKeys<O>& bk, uint64_t N, uint64_t values_len, uint64_t* h64) {
+    constexpr int U = 4;
+    for (uint64_t base = threadIdx.x; base < N; base += (uint64_t)WG * U) {
+        uint64_t b[U], e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = base + (uint64_t)u * WG;
+            b[u] = i < N ? bk.beg(i) : 0;
+            e[u] = i < N ? bk.beg(i + 1) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = base + (uint64_t)u * WG;
+            if (i < N) h64[i] = bin_hash_bytes(bk.values, b[u], e[u], values_len);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// statistics over hashed rows (choose_bin): key equality = hash equality
+template <class O>
+struct KeyOpsBinHashed {
+    BinKeys<O> k;
+    const uint64_t* h64;
+    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return (uint32_t)(h64[i] >> 17); }
+    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return h64[a] == h64[b]; }
+    __device__ __forceinline__ uint32_t weight(uint64_t i) const { return (uint32_t)(k.beg(i + 1) - k.beg(i)) + 8; }
+};
+// dictionary build over hashed rows: the hash finds the slot and rejects different strings, the strings decide
+template <class O>
+struct BinKeysHashed {
+    BinKeys<O> k;
+    const uint64_t* h64;
+    __device__ __forceinline__ bool keyed(uint64_t i) const { return k.keyed(i); }
+    __device__ __forceinline__ uint64_t beg(uint64_t i) const { return k.beg(i); }
+    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return (uint32_t)(h64[i] >> 17); }
+    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return h64[a] == h64[b] && k.eq(a, b); }
+};
+
 // ------------------------------------------------------------------------------ adaptive selection
 }  // namespace sb
 #include "sb_select.h"
@@ -1489,6 +1580,7 @@ struct SelScratch {
     uint8_t* sample_mem; // SAMPLE_ROWS * (W + 1) bytes, 16-byte aligned
     uint32_t* gtab;      // HBM table for the distinct count (may be null)
     uint64_t gslots;
+    uint32_t lds_slots = SEL_LDS_SLOTS;  // slots of lds_tab (a power of two)
 };
 
 // row-index hash-set operations over canonical primitive keys
@@ -1510,9 +1602,11 @@ __device__ uint32_t distinct_count(Ops ops, uint64_t N, uint32_t limit, const Se
     __shared__ unsigned long long s_wsum;
     for (int tier = 0; tier < 2; tier++) {
         uint32_t* tab = tier == 0 ? sc.lds_tab : sc.gtab;
-        const uint64_t slots = tier == 0 ? SEL_LDS_SLOTS : sc.gslots;
+        const uint64_t slots = tier == 0 ? sc.lds_slots : sc.gslots;
         if (tier == 1 && (!sc.gtab || sc.gslots < 2 * N)) return limit + 1;
-        const uint32_t cap = tier == 0 ? SEL_LDS_SLOTS / 2 : 0xFFFFFFFFu;
+        // LDS tier up to a load of 5/8 — and never so full that the WG * 16 rows inserted between two checks could
+        // occupy every slot (a probe for one more key would then never find an empty one)
+        const uint32_t cap = tier == 0 ? min(sc.lds_slots / 8 * 5, sc.lds_slots - (uint32_t)WG * 16 - 1) : 0xFFFFFFFFu;
         for (uint64_t i = t; i < slots; i += WG) tab[i] = SEL_EMPTY;
         if (t == 0) {
             s_cnt = 0;
@@ -2086,14 +2180,11 @@ struct KeyOpsBin {
 };
 
 // choose_compressor for binary (binary/mod.rs:293-348)
-template <class O>
-__device__ uint32_t choose_bin(const BinKeys<O>& bk, uint64_t N, uint64_t values_len_total, const SelectOpts& o,
-                               const SelScratch& sc) {
+template <class O, class Ops>
+__device__ uint32_t choose_bin_impl(const Ops& ops, const BinKeys<O>& bk, uint64_t N, uint64_t values_len_total, const SelectOpts& o,
+                                    const SelScratch& sc) {
     auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
-    if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
-    if (!o.has_ratio || N == 0) return o.default_codec;
     uint32_t* s4 = sc.s_misc + 2 * WG;
-    KeyOpsBin<O> ops{bk};
     uint32_t f_neq0 = 0, nulls = 0;
     for (uint64_t i = threadIdx.x; i < N; i += WG) {
         if (!ops.eq(0, i)) f_neq0 = 1;
@@ -2140,6 +2231,19 @@ __device__ uint32_t choose_bin(const BinKeys<O>& bk, uint64_t N, uint64_t values
         }
     }
     return result;
+}
+// h64 (one u64 per row, or null): when present the statistics run over hashed rows (bin_hash_rows)
+template <class O>
+__device__ uint32_t choose_bin(const BinKeys<O>& bk, uint64_t N, uint64_t values_len_total, const SelectOpts& o,
+                               const SelScratch& sc, uint64_t* h64 = nullptr, uint64_t values_len = 0) {
+    auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
+    if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
+    if (!o.has_ratio || N == 0) return o.default_codec;
+    if (h64) {
+        bin_hash_rows<O>(bk, N, values_len, h64);
+        return choose_bin_impl<O>(KeyOpsBinHashed<O>{bk, h64}, bk, N, values_len_total, o, sc);
+    }
+    return choose_bin_impl<O>(KeyOpsBin<O>{bk}, bk, N, values_len_total, o, sc);
 }
 
 // Blocks go to XCD blockIdx % 8.  Pages at the same position of their column (every column's short last page,
@@ -2320,7 +2424,7 @@ __device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const E
 template <class O, int CODEC>
 __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page,
                                      uint8_t* blk, const ValidView& vv, uint32_t* sA, uint32_t* sB, uint32_t* sC,
-                                     uint32_t* s_w) {
+                                     uint32_t* s_w, uint32_t* lds_table = nullptr, uint32_t lds_slots = 0) {
     const uint64_t N = p.rows;
     const uint8_t* offs = c.offsets + p.row0 * sizeof(O);
     auto off_at = [=](uint64_t i) {
@@ -2350,7 +2454,16 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         BinKeys<O> ko{offs, c.values, vv};
         uint32_t *idx, *firsts;
         uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
-        const uint32_t D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
+        uint32_t D;
+        if (p.h64_off != ~0ull) {   // hashed rows: computed by the selector of this call, or here when the codec was forced
+            uint64_t* h64 = (uint64_t*)(a.scratch + p.h64_off);
+            if (p.codec != CODEC_ON_DEVICE) bin_hash_rows<O>(ko, N, c.values_len, h64);
+            D = dict_build(BinKeysHashed<O>{ko, h64}, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page,
+                           lds_slots > 1 ? lds_table : nullptr, lds_slots > 1 ? lds_slots : 0);
+        } else {
+            D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page,
+                           lds_slots > 1 ? lds_table : nullptr, lds_slots > 1 ? lds_slots : 0);
+        }
         if (D == EMPTY) return 0;
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
         if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
@@ -2399,7 +2512,10 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
                 const uint64_t b = ko.beg(r), e = ko.beg(r + 1);
                 uint8_t* d = q + pos + sA[sidx((int)i)] - (e - b) - 8;
                 stu64(d, e - b);
-                for (uint64_t k = 0; k < e - b; k++) d[8 + k] = c.values[b + k];
+                uint64_t k = 0;
+                for (; k + 16 <= e - b; k += 16) stu128(d + 8 + k, ldu128(c.values + b + k));   // (unaligned 16-byte moves)
+                for (; k + 8 <= e - b; k += 8) stu64(d + 8 + k, ldu64(c.values + b + k));
+                for (; k < e - b; k++) d[8 + k] = c.values[b + k];
             }
             pos += tot;
             __syncthreads();
@@ -2419,9 +2535,13 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
 #include "sb_select_rle.h"
 #include "sb_select_runs.h"
 
+// Binary pages hash strings: a probe that misses the LDS tier costs a random HBM access per row (13 GB of traffic for
+// 1.15 GB of C3 input when the table sat in HBM), so their LDS table is 16 Ki slots (~10 000 distinct strings per page).
+constexpr uint32_t BIN_LDS_SLOTS = 16384;
 template <int KIND>
 __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
-    __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
+    constexpr uint32_t LDS_SLOTS = KIND < 0 ? BIN_LDS_SLOTS : SEL_LDS_SLOTS;
+    __shared__ uint32_t lds_tab[LDS_SLOTS];
     __shared__ uint32_t s_misc[2 * WG + 16];
     // sample area, also the streaming scratch of choose_prim: 1 KB validity words + 4 x 128 keys
     constexpr int SMP = SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16, STR = 1024 + 4 * 96 * (KIND == 8 ? 8 : 4) + 4 * 96;
@@ -2446,6 +2566,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
     SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
     SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
+    sc.lds_slots = LDS_SLOTS;
     if (sc.gtab) {  // the Dict aux area starts with a table of pow2 >= 2N slots
         uint64_t M = 64;
         while (M < 2 * N) M <<= 1;
@@ -2456,10 +2577,10 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
         codec = choose_bool(c.values, c.values_bit_offset + p.row0, vv, N, so, sc);
     } else if constexpr (KIND == -4) {
         BinKeys<int32_t> bk{c.offsets + p.row0 * 4, c.values, vv};
-        codec = choose_bin<int32_t>(bk, N, c.values_len_total, so, sc);
+        codec = choose_bin<int32_t>(bk, N, c.values_len_total, so, sc, p.h64_off != ~0ull ? (uint64_t*)(a.scratch + p.h64_off) : nullptr, c.values_len);
     } else if constexpr (KIND == -8) {
         BinKeys<int64_t> bk{c.offsets + p.row0 * 8, c.values, vv};
-        codec = choose_bin<int64_t>(bk, N, c.values_len_total, so, sc);
+        codec = choose_bin<int64_t>(bk, N, c.values_len_total, so, sc, p.h64_off != ~0ull ? (uint64_t*)(a.scratch + p.h64_off) : nullptr, c.values_len);
     } else {
         const uint8_t* vals = c.values + p.row0 * KIND;
         codec = choose_prim<KIND>([=](uint64_t i) { return ld_val<KIND>(vals + i * KIND); }, vv, N, c.nk, so, sc);
@@ -2597,6 +2718,9 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * LW];
     uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
     __shared__ uint32_t s_w[4];
+    // binary Dict pages: the table of first rows sits in LDS while the page has at most ~10 000 distinct strings
+    constexpr uint32_t BIN_TABLE = (KIND < 0 && CODEC == SB_CODEC_DICT) ? BIN_LDS_SLOTS : 1;
+    __shared__ uint32_t s_bin_table[BIN_TABLE];
     if (a.use_counts && a.codec_counts[CODEC] == 0) return;  // adaptive batch without a page of this codec
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
@@ -2631,9 +2755,9 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     if constexpr (KIND == 0)
         blen = emit_bool_page<CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
     else if constexpr (KIND == -4)
-        blen = emit_binary_page<int32_t, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+        blen = emit_binary_page<int32_t, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w, s_bin_table, BIN_TABLE);
     else if constexpr (KIND == -8)
-        blen = emit_binary_page<int64_t, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
+        blen = emit_binary_page<int64_t, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w, s_bin_table, BIN_TABLE);
     else
         blen = emit_prim_page<KIND, CODEC>(a, c, p, page, blk, vv, sA, sB, sC, s_w);
     if (threadIdx.x == 0) {
@@ -4019,6 +4143,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 while (M < 2 * N) M <<= 1;
                 p.aux_bytes = (M + 3 * N) * 4;
             }
+            p.h64_off = ~0ull;
+            if (bin && p.aux_bytes && N) p.h64_off = 0;   // (placed with the aux areas below)
             if (p.vslot_off && !((forb >> SB_CODEC_DICT) & 1)) {  // the exceptions block may be a Dict block
                 uint64_t M = 64;
                 while (M < 2 * N) M <<= 1;
@@ -4051,6 +4177,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             scratch_off = align_up(scratch_off, 16);
             hp[q].aux_off = scratch_off;
             scratch_off += hp[q].aux_bytes;
+        }
+        if (hp[q].h64_off == 0) {
+            scratch_off = align_up(scratch_off, 16);
+            hp[q].h64_off = scratch_off;
+            scratch_off += hp[q].rows * 8;
         }
         if (hp[q].vaux_bytes) {
             scratch_off = align_up(scratch_off, 16);

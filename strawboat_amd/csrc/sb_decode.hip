@@ -1563,7 +1563,13 @@ __device__ void expand_binary(const ColDesc& c, const PageTask& t, const PageDes
                 const uint32_t len = ent_off[k + 1] - ent_off[k] - 8 - (k == 0 ? gap : 0);
                 const uint8_t* sp = d.dict + ent_off[k] + 8;
                 uint8_t* dp = vdst + (endb - len);
-                for (uint32_t b = 0; b < len; b++) dp[b] = sp[b];
+                uint32_t b = 0;   // unaligned 16- / 8-byte moves, then the tail
+                for (; b + 16 <= len; b += 16) stu128(dp + b, ldu128(sp + b));
+                if (b + 8 <= len) {
+                    stu64(dp + b, ldu64(sp + b));
+                    b += 8;
+                }
+                for (; b < len; b++) dp[b] = sp[b];
             }
         }
         (void)st;

@@ -1342,6 +1342,11 @@ __device__ __forceinline__ uint32_t table_load(uint32_t* p) {
 // carry a key; keyed(i) says whether row i interns a key (valid rows, and row 0 even if null).
 // Outputs idx[N] (u32) in aux and the first-occurrence rows in `firsts` (dict order).
 // Returns the number of entries.
+// key classes with a hash-only fast mode (BinKeysHashed)
+template <class T, class = void>
+struct is_hashed_keys { static constexpr bool value = false; };
+template <class T>
+struct is_hashed_keys<T, decltype((void)T::HASHED)> { static constexpr bool value = true; };
 template <class KeyOps>
 __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t aux_words, uint32_t** idx_out,
                                uint32_t** firsts_out, uint32_t* sA, uint32_t* sB, uint32_t* s_w, Status* st,
@@ -1356,7 +1361,9 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
     uint32_t* F = aux + M;       // row -> first row with the same key
     uint32_t* R = F + N;         // first row -> dictionary id ; later: dict id -> first row (firsts)
     uint32_t* idx = R + N;
-    __shared__ uint32_t s_keys;
+    __shared__ uint32_t s_keys, s_collide;
+    constexpr bool HASHED = is_hashed_keys<KeyOps>::value;
+    bool exact_mode = !HASHED;
     // The table of first rows: in LDS while the page has few distinct keys (tier 0: every probe is an LDS access; string
     // keys are compared through L2), in HBM otherwise (tier 1: pow2 >= 2N slots in the aux area).
     for (int tier = (lds_table && lds_slots) ? 0 : 1; tier < 2; tier++) {
@@ -1390,7 +1397,10 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
                         }
                         cur = old;
                     }
-                    if (cur == (uint32_t)i || ko.eq(cur, i)) {
+                    bool same;
+                    if constexpr (HASHED) same = cur == (uint32_t)i || (exact_mode ? ko.eq(cur, i) : ko.heq(cur, i));
+                    else same = cur == (uint32_t)i || ko.eq(cur, i);
+                    if (same) {
                         if ((uint32_t)i < cur) atomicMin(&table[h], (uint32_t)i);  // rows arrive roughly in order: rarely needed
                         break;
                     }
@@ -1415,6 +1425,34 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
             if (h != EMPTY) F[i] = tier == 0 ? table[h] : table_load(&table[h]);
         }
         __syncthreads();
+        if constexpr (HASHED) {
+            if (!exact_mode) {   // every row against the first row of its hash class
+                if (t == 0) s_collide = 0;
+                __syncthreads();
+                uint32_t bad = 0;
+                for (uint64_t base = t; base < N; base += (uint64_t)WG * 4) {
+                    uint32_t f[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint64_t i = base + (uint64_t)u * WG;
+                        f[u] = i < N ? F[i] : EMPTY;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint64_t i = base + (uint64_t)u * WG;
+                        if (i < N && f[u] != EMPTY && f[u] != (uint32_t)i && !ko.exact(f[u], i)) bad = 1;
+                    }
+                }
+                if (bad) atomicOr(&s_collide, 1u);
+                __syncthreads();
+                if (s_collide) {     // two different strings with one hash: the exact build on the HBM table
+                    exact_mode = true;
+                    tier = 0;        // (tier++ -> 1)
+                    __syncthreads();
+                    continue;
+                }
+            }
+        }
         break;
     }
     // phase 3: dictionary ids in first-occurrence order (rank of first rows), chunked scan
@@ -1567,6 +1605,12 @@ struct BinKeysHashed {
     __device__ __forceinline__ uint64_t beg(uint64_t i) const { return k.beg(i); }
     __device__ __forceinline__ uint32_t hash(uint64_t i) const { return (uint32_t)(h64[i] >> 17); }
     __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return h64[a] == h64[b] && k.eq(a, b); }
+    // dict_build's fast mode: classes by hash alone (no offsets -> bytes chase inside the probe loop), then ONE streaming
+    // pass checks every row against the first row of its class, four rows in flight per thread; a 64-bit collision (never
+    // seen, but it would merge two different strings) sends the page through the exact build
+    static constexpr bool HASHED = true;
+    __device__ __forceinline__ bool heq(uint64_t a, uint64_t b) const { return h64[a] == h64[b]; }
+    __device__ __forceinline__ bool exact(uint64_t a, uint64_t b) const { return k.eq(a, b); }
 };
 
 // ------------------------------------------------------------------------------ adaptive selection
@@ -2715,12 +2759,14 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     constexpr int LW = CODEC == SB_CODEC_ONEVALUE ? 256
                        : CODEC == SB_CODEC_RLE ? (int)(RleRows<(KIND > 0 ? KIND : 1)>::WORDS + 2) / 3
                                                : SIDX_WORDS;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * LW];
-    uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
-    __shared__ uint32_t s_w[4];
-    // binary Dict pages: the table of first rows sits in LDS while the page has at most ~10 000 distinct strings
+    // binary Dict pages: the table of first rows sits in LDS while the page has at most ~10 000 distinct strings.  It is
+    // dead before the scans of the build start, so it shares the 3 * LW words of sA / sB / sC.
     constexpr uint32_t BIN_TABLE = (KIND < 0 && CODEC == SB_CODEC_DICT) ? BIN_LDS_SLOTS : 1;
-    __shared__ uint32_t s_bin_table[BIN_TABLE];
+    constexpr int LDS_WORDS = 3 * LW > (int)BIN_TABLE ? 3 * LW : (int)BIN_TABLE;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_WORDS];
+    uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
+    uint32_t* const s_bin_table = lds;
+    __shared__ uint32_t s_w[4];
     if (a.use_counts && a.codec_counts[CODEC] == 0) return;  // adaptive batch without a page of this codec
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);

@@ -11,6 +11,7 @@
 #define SB_LZ4_PROFILE 1
 __device__ unsigned long long g_prof[32];
 #include "sb_lz4.h"
+#include "sb_zstd_enc.h"
 using namespace sb;
 
 __global__ void __launch_bounds__(64) k_enc(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t* sizes) {
@@ -22,6 +23,11 @@ __global__ void __launch_bounds__(64) k_dec(const uint8_t* comp, uint32_t cap, c
     __shared__ Lz4DecLds lds;
     const uint32_t e = lz4_inflate_block(comp + (size_t)blockIdx.x * cap, sizes[blockIdx.x], out + (size_t)blockIdx.x * ((n + 255) & ~255u), n, lds);
     if (threadIdx.x == 0) errs[blockIdx.x] = e;
+}
+__global__ void __launch_bounds__(64) k_zenc(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t* sizes, uint8_t* scratch) {
+    __shared__ ZEncLds lds;
+    const uint32_t sz = zstd_compress_wave(src, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK));
+    if (threadIdx.x == 0) sizes[blockIdx.x] = sz;
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 static const char* ENC[] = {"fill", "probe+cand+ext", "select", "emit", "flush_out", "last", "", ""};
@@ -67,6 +73,34 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 8; i++) tot += prof[i];
             for (int i = 0; i < 6; i++) printf("   %-16s %12llu ticks %5.1f %%\n", ENC[i], prof[i], 100.0 * prof[i] / (tot ? tot : 1));
             printf("   steps %llu, sequences %llu, big-path steps %llu\n", prof[16], prof[17], prof[18]);
+        }
+    }
+    {
+        uint8_t* d_scr;
+        uint32_t* d_zs;
+        CK(hipMalloc(&d_scr, zstd_scratch_bytes(ZE_BLOCK) * (size_t)blocks));
+        CK(hipMalloc(&d_zs, 4 * blocks));
+        uint8_t* d_z;
+        CK(hipMalloc(&d_z, (size_t)cap * blocks));
+        static const char* ZN[] = {"", "", "", "", "", "", "", "", "begin", "match", "record", "tail+visible", "literals", "sequences", "finish"};
+        for (int rep = 0; rep < 2; rep++) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof zero));
+            hipEventRecord(e0);
+            k_zenc<<<blocks, 64>>>(d_in, n, d_z, cap, d_zs, d_scr);
+            hipEventRecord(e1);
+            CK(hipDeviceSynchronize());
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            uint32_t sz;
+            CK(hipMemcpy(&sz, d_zs, 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof prof));
+            if (rep) {
+                printf("zstd encode: %u -> %u bytes, %d blocks, %.3f ms (%.1f MB/s per wave)\n", n, sz, blocks, ms, n / ms / 1e3);
+                unsigned long long tot = 0;
+                for (int i = 8; i < 15; i++) tot += prof[i];
+                for (int i = 8; i < 15; i++) printf("   %-16s %12llu ticks %5.1f %%\n", ZN[i], prof[i], 100.0 * prof[i] / (tot ? tot : 1));
+                printf("   sequences %llu, literals %llu\n", prof[16], prof[17]);
+            }
         }
     }
     for (int rep = 0; rep < 2; rep++) {

@@ -26,6 +26,7 @@
 
 #include "sb_host.h"
 #include "sb_lz4.h"
+#include "sb_zstd_enc.h"
 
 namespace sb {
 
@@ -75,6 +76,7 @@ struct EncPage {
     uint32_t depth;       // nesting depth of this block (sampling RNG stream; 0 = page)
     uint32_t forb_extra;  // codecs forbidden for this block in addition to the options'
     uint64_t h64_off;     // binary pages: scratch offset of one u64 hash per row (~0: none), written by bin_hash_rows
+    uint64_t zst_off;     // Basic(Zstd) pages: scratch of the Zstd encoder (zstd_scratch_bytes; ~0: none)
 };
 
 struct EncOut {
@@ -3679,6 +3681,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     __shared__ union {
         uint32_t tab[4096];
         Lz4EncLds<12, 13> lz;
+        ZEncLds ze;
     } sh;
     uint32_t* const tab = sh.tab;
     __shared__ uint32_t s_sz;
@@ -3702,7 +3705,14 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
     auto compress = [&](const uint8_t* src, uint32_t n, uint8_t* dst) -> uint32_t {
         __syncthreads();
-        if (bc == SB_CODEC_ZSTD) return zstd_store_frame_wg(src, n, dst, tab);
+        if (bc == SB_CODEC_ZSTD) {
+            if (p.zst_off == ~0ull) return zstd_store_frame_wg(src, n, dst, tab);
+            uint32_t zs = 0;
+            if (threadIdx.x < 64) zs = zstd_compress_wave(src, n, dst, sh.ze, a.scratch + p.zst_off);
+            if (threadIdx.x == 0) s_sz = zs;
+            __syncthreads();
+            return s_sz;
+        }
         if (bc == SB_CODEC_SNAPPY) return snappy_store_wg(src, n, dst);
         uint32_t sz = 0;
         if (threadIdx.x < 64)
@@ -4191,6 +4201,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             }
             p.h64_off = ~0ull;
             if (bin && p.aux_bytes && N) p.h64_off = 0;   // (placed with the aux areas below)
+            p.zst_off = ~0ull;
+            if (c.physical_type != SB_TYPE_NULL &&
+                (codec == SB_CODEC_ZSTD || (adaptive && opts->default_compression == SB_CODEC_ZSTD)))
+                p.zst_off = 0;
             if (p.vslot_off && !((forb >> SB_CODEC_DICT) & 1)) {  // the exceptions block may be a Dict block
                 uint64_t M = 64;
                 while (M < 2 * N) M <<= 1;
@@ -4228,6 +4242,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             scratch_off = align_up(scratch_off, 16);
             hp[q].h64_off = scratch_off;
             scratch_off += hp[q].rows * 8;
+        }
+        if (hp[q].zst_off == 0) {   // (one block is at most 128 KiB whatever the page holds)
+            scratch_off = align_up(scratch_off, 16);
+            hp[q].zst_off = scratch_off;
+            scratch_off += zstd_scratch_bytes(ZE_BLOCK);
         }
         if (hp[q].vaux_bytes) {
             scratch_off = align_up(scratch_off, 16);

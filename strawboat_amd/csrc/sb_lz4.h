@@ -513,6 +513,208 @@ struct Lz4EncLds {
 
 __device__ __forceinline__ uint32_t lz4_bound(uint32_t n) { return n + n / 255 + 16; }
 
+// The matcher, shared by the LZ4 and the Zstd encoder: hash table + input ring in LDS, one step = 64 probe positions.
+// next() runs steps until one finds matches and leaves, per lane, the position p, the match (cand, mlen) and — for the
+// lanes chosen by the greedy / lazy selection (mask C) — nothing else to decide: the caller emits the sequences
+// [lit_start .. p) + match and calls advance().  A chunk [c0, c1) bounds the sequences (matches end at or before
+// c1 - tail_lits, start at or before c1 - min_tail); the history in the ring and the table carries over between chunks.
+template <int HB, int RB>
+struct LzMatcher {
+    static constexpr uint32_t R = 1u << RB, RWM = R / 4 - 1;
+    Lz4EncLds<HB, RB>& L;
+    const uint8_t* src;
+    uint32_t n;                            // bytes of the whole input
+    uint32_t hi = 0;                       // input loaded into the ring up to here (multiple of 1024, or >= n)
+    uint32_t anchor = 0, base = 0, stride = 1;
+    uint32_t mflimit = 0, matchlimit = 0;  // a match may start at positions <= mflimit and must end at or before matchlimit
+    // results of next()
+    uint64_t C = 0;
+    uint32_t p = 0, mlen = 0, cand = 0, covered = 0;
+    unsigned long long* prof = nullptr;
+
+    __device__ LzMatcher(Lz4EncLds<HB, RB>& l, const uint8_t* s, uint32_t nn) : L(l), src(s), n(nn) {}
+    __device__ void init() {
+        const uint32_t lane = threadIdx.x & 63;
+        for (uint32_t i = lane; i < (1u << HB); i += 64) L.tab[i] = 0xFFFF;
+        wave_sync();
+    }
+    __device__ void begin_chunk(uint32_t c0, uint32_t mfl, uint32_t mtl) {
+        anchor = base = c0;
+        stride = 1;
+        mflimit = mfl;
+        matchlimit = mtl;
+    }
+    __device__ void advance() {
+        anchor = covered;
+        base = max(covered, base + 1);
+        stride = 1;
+    }
+    __device__ __forceinline__ uint32_t rd4(uint32_t x) const {
+        const uint32_t w = (x >> 2) & RWM;
+        return __builtin_amdgcn_alignbyte(L.ring[(w + 1) & RWM], L.ring[w], x & 3);
+    }
+    __device__ __forceinline__ uint64_t rd8(uint32_t x) const {
+        const uint32_t w = (x >> 2) & RWM;
+        const uint32_t a = L.ring[w], b = L.ring[(w + 1) & RWM], c = L.ring[(w + 2) & RWM];
+        return (uint64_t)__builtin_amdgcn_alignbyte(b, a, x & 3) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, x & 3) << 32);
+    }
+    __device__ void fill(uint32_t upto) {      // 1 KiB per instruction, 16-byte loads
+        const uint32_t lane = threadIdx.x & 63;
+        wave_sync();
+        while (hi < n && hi < upto) {
+            const uint32_t x = hi + 16 * lane;
+            u32x4 v = {0, 0, 0, 0};
+            if (x + 16 <= n) {
+                v = ldu128(src + x);
+            } else if (x < n) {
+                uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                for (uint32_t b = 0; x + b < n; b++) {
+                    const uint32_t bv = (uint32_t)ldu8(src + x + b) << ((b & 3) * 8);
+                    if (b < 4) w0 |= bv; else if (b < 8) w1 |= bv; else if (b < 12) w2 |= bv; else w3 |= bv;
+                }
+                v = u32x4{w0, w1, w2, w3};
+            }
+            *(u32x4*)(L.ring + ((x & (R - 1)) >> 2)) = v;
+            hi += 1024;
+        }
+        wave_sync();
+    }
+    // true: a step with chosen matches is ready; false: the chunk is exhausted (anchor = start of its trailing literals)
+    __device__ bool next() {
+        const uint32_t lane = threadIdx.x & 63;
+        while (base <= mflimit) {
+            fill(base + LZE_AHEAD);
+            const uint32_t lo_valid = hi > R ? hi - R : 0;   // positions below are no longer in the ring
+            p = base + lane * stride;
+            // a probe needs its LZE_CAP + 16 bytes of look-ahead in the ring (a step spread wider probes only its front part)
+            const bool act = p <= mflimit && (p + LZE_CAP + 16 <= hi || hi >= n);
+            cand = 0;
+            mlen = 0;
+            bool open = false;    // the extension stopped at LZE_CAP, not at a mismatch
+            if (act) {
+                // round trip 1: the eight dwords that hold bytes [p - 8, p + 20); t[k] = the 4 bytes at p - 8 + 4k
+                const uint32_t w0 = (p - 8) >> 2, q = p & 3;
+                uint32_t D[8], t[7];
+    #pragma unroll
+                for (int k = 0; k < 8; k++) D[k] = L.ring[(w0 + k) & RWM];
+    #pragma unroll
+                for (int k = 0; k < 7; k++) t[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], q);
+                const uint32_t v4 = t[2];
+                // round trip 2: the hash table
+                const uint32_t h = (v4 * 2654435761u) >> (32 - HB);
+                const uint32_t e = L.tab[h];
+                L.tab[h] = (uint16_t)(p & 0xFFFF);
+                uint32_t c = 0;
+                bool ok = false;
+                if (stride == 1) {   // the periods columnar data repeats with (positions of this very step are not in the table
+                                     // yet, and the nearest candidate gives the longest runs): 8, 4, 2, 1 bytes back
+                    if (p >= 8 && t[0] == v4) { c = p - 8; ok = true; }
+                    else if (p >= 4 && t[1] == v4) { c = p - 4; ok = true; }
+                    else if (p >= 2 && ((t[1] >> 16) | (t[2] << 16)) == v4) { c = p - 2; ok = true; }
+                    else if (p >= 1 && ((t[1] >> 24) | (t[2] << 8)) == v4) { c = p - 1; ok = true; }
+                }
+                if (!ok && e != 0xFFFF) {   // the last position with this hash (mod 64 Ki), if it is still in the ring
+                    c = (p & ~0xFFFFu) | e;
+                    if (c >= p) c -= 0x10000u;                   // (wraps above p when there is no such position)
+                    ok = c < p && c >= lo_valid;
+                }
+                if (ok) {
+                    // round trip 3: 16 candidate bytes against the 16 bytes at p
+                    const uint32_t cw = c >> 2, cq = c & 3;
+                    uint32_t E[5];
+    #pragma unroll
+                    for (int k = 0; k < 5; k++) E[k] = L.ring[(cw + k) & RWM];
+                    uint32_t d;
+                    if ((d = __builtin_amdgcn_alignbyte(E[1], E[0], cq) ^ v4) != 0) ok = false;
+                    else if ((d = __builtin_amdgcn_alignbyte(E[2], E[1], cq) ^ t[3]) != 0) mlen = 4 + (__builtin_ctz(d) >> 3);
+                    else if ((d = __builtin_amdgcn_alignbyte(E[3], E[2], cq) ^ t[4]) != 0) mlen = 8 + (__builtin_ctz(d) >> 3);
+                    else if ((d = __builtin_amdgcn_alignbyte(E[4], E[3], cq) ^ t[5]) != 0) mlen = 12 + (__builtin_ctz(d) >> 3);
+                    else { mlen = 16; open = true; }
+                }
+                if (ok) {
+                    cand = c;
+                    const uint32_t room = matchlimit - p;        // longest match allowed here (>= 7)
+                    while (open && mlen < LZE_CAP) {             // further round trips: 8 bytes each
+                        const uint64_t d = rd8(c + mlen) ^ rd8(p + mlen);
+                        if (d) { mlen += (uint32_t)__builtin_ctzll(d) >> 3; open = false; break; }
+                        mlen += 8;
+                    }
+                    if (mlen >= room) { mlen = room; open = false; }
+                } else {
+                    mlen = 0;
+                    open = false;
+                }
+            }
+            const uint64_t mm = __ballot(mlen >= 4);
+            if (!mm) {
+                base += 64 * stride;
+                if (stride < 24) stride++;
+                continue;
+            }
+            // ---- greedy left-to-right selection of non-overlapping matches of this step.  Lazy matching first, per lane: a
+            // match steps aside when one of the next three positions starts a match that is longer by more than the
+            // distance.  Then the serial part — a wave-uniform walk over the match mask — is one v_readlane and one taken
+            // branch per chosen sequence; literal starts, sizes and staging offsets are computed per lane afterwards.
+            uint64_t msel = mm;
+            if (stride == 1) {
+                const uint32_t m1 = __shfl_down(mlen, 1, 64), m2 = __shfl_down(mlen, 2, 64), m3 = __shfl_down(mlen, 3, 64);
+                const bool dom = mlen >= 4 && ((lane < 63 && m1 > mlen + 1) || (lane < 62 && m2 > mlen + 2) || (lane < 61 && m3 > mlen + 3));
+                msel &= ~__ballot(dom);
+            }
+            const uint32_t mcomb = mlen | (open ? 0x80000000u : 0u);
+            C = 0;
+            covered = anchor;            // everything below is emitted or pending as literals of the next sequence
+            // wave-wide extension of the match at lane l (position pl) beyond its per-lane part, 64 x 4 bytes per step from HBM
+            auto extend = [&](uint32_t l, uint32_t pl, uint32_t ml_l) -> uint32_t {
+                const uint32_t c = rdlane(cand, l);
+                for (;;) {
+                    const uint32_t x = ml_l + 4 * lane;
+                    bool eq = pl + x + 4 <= matchlimit;
+                    if (eq) eq = ldu32(src + c + x) == ldu32(src + pl + x);
+                    const uint64_t ne = __ballot(!eq);
+                    const uint32_t take = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;
+                    ml_l += 4 * take;
+                    if (ne) break;
+                }
+                while (pl + ml_l < matchlimit && ldu8(src + c + ml_l) == ldu8(src + pl + ml_l)) ml_l++;  // < 4 steps
+                mlen = wrlane(ml_l, l, mlen);
+                return ml_l;
+            };
+            if (stride == 1) {
+                uint32_t rel = 0;                 // (anchor <= base: the first lane is free)
+                do {
+                    const uint64_t m = (msel >> rel) << rel;
+                    if (!m) break;
+                    const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                    const uint32_t v = rdlane(mcomb, l);
+                    uint32_t ml_l = v & 0x7FFFFFFFu;
+                    if (__builtin_expect(v >> 31, 0)) ml_l = extend(l, base + l, ml_l);
+                    C |= 1ull << l;
+                    rel = l + ml_l;
+                } while (rel < 64);
+                if (C) covered = base + rel;
+            } else {
+                for (;;) {
+                    // lanes whose position is >= covered form a suffix: first lane = ceil((covered - base) / stride)
+                    const uint32_t first_lane = covered <= base ? 0u : (covered - base + stride - 1) / stride;
+                    if (first_lane >= 64) break;
+                    const uint64_t m = (msel >> first_lane) << first_lane;
+                    if (!m) break;
+                    const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                    const uint32_t v = rdlane(mcomb, l);
+                    uint32_t ml_l = v & 0x7FFFFFFFu;
+                    const uint32_t pl = base + l * stride;
+                    if (v >> 31) ml_l = extend(l, pl, ml_l);
+                    C |= 1ull << l;
+                    covered = pl + ml_l;
+                }
+            }
+            return true;
+        }
+        return false;
+    }
+};
+
 // Compress src[0, n) into dst (capacity >= lz4_bound(n)); executed by ONE wave64; returns the block size.
 template <int HB, int RB>
 __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
@@ -554,193 +756,35 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
         emit_last(0);
         return outp;
     }
-    for (uint32_t i = lane; i < (1u << HB); i += 64) L.tab[i] = 0xFFFF;
-    const uint32_t mflimit = n - 12;      // a match may start at positions <= mflimit
-    const uint32_t matchlimit = n - 5;    // and must end at or before this position
-    uint32_t anchor = 0, base = 0, stride = 1;
-    uint32_t hi = 0;                      // input loaded into the ring up to here (multiple of 1024, or >= n)
-    auto fill = [&](uint32_t upto) {      // 1 KiB per instruction, 16-byte loads
-        wave_sync();
-        while (hi < n && hi < upto) {
-            const uint32_t x = hi + 16 * lane;
-            u32x4 v = {0, 0, 0, 0};
-            if (x + 16 <= n) {
-                v = ldu128(src + x);
-            } else if (x < n) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t b = 0; x + b < n; b++) w[b >> 2] |= (uint32_t)ldu8(src + x + b) << ((b & 3) * 8);
-                v = u32x4{w[0], w[1], w[2], w[3]};
-            }
-            *(u32x4*)(L.ring + ((x & (R - 1)) >> 2)) = v;
-            hi += 1024;
-        }
-        wave_sync();
-    };
-    auto rd4 = [&](uint32_t x) -> uint32_t {
-        const uint32_t w = (x >> 2) & RWM;
-        return __builtin_amdgcn_alignbyte(L.ring[(w + 1) & RWM], L.ring[w], x & 3);
-    };
-    auto rd8 = [&](uint32_t x) -> uint64_t {
-        const uint32_t w = (x >> 2) & RWM;
-        const uint32_t a = L.ring[w], b = L.ring[(w + 1) & RWM], c = L.ring[(w + 2) & RWM];
-        return (uint64_t)__builtin_amdgcn_alignbyte(b, a, x & 3) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, x & 3) << 32);
-    };
-
-    while (base <= mflimit) {
-        LZP(3);
-        fill(base + LZE_AHEAD);
-        LZP(0);
-        LZP_CNT(16, 1);
-        const uint32_t lo_valid = hi > R ? hi - R : 0;   // positions below are no longer in the ring
-        const uint32_t p = base + lane * stride;
-        // a probe needs its LZE_CAP + 16 bytes of look-ahead in the ring (a step spread wider probes only its front part)
-        const bool act = p <= mflimit && (p + LZE_CAP + 16 <= hi || hi >= n);
-        uint32_t cand = 0, mlen = 0;
-        bool open = false;    // the extension stopped at LZE_CAP, not at a mismatch
-        if (act) {
-            // round trip 1: the eight dwords that hold bytes [p - 8, p + 20); t[k] = the 4 bytes at p - 8 + 4k
-            const uint32_t w0 = (p - 8) >> 2, q = p & 3;
-            uint32_t D[8], t[7];
-#pragma unroll
-            for (int k = 0; k < 8; k++) D[k] = L.ring[(w0 + k) & RWM];
-#pragma unroll
-            for (int k = 0; k < 7; k++) t[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], q);
-            const uint32_t v4 = t[2];
-            // round trip 2: the hash table
-            const uint32_t h = (v4 * 2654435761u) >> (32 - HB);
-            const uint32_t e = L.tab[h];
-            L.tab[h] = (uint16_t)(p & 0xFFFF);
-            uint32_t c = 0;
-            bool ok = false;
-            if (stride == 1) {   // the periods columnar data repeats with (positions of this very step are not in the table
-                                 // yet, and the nearest candidate gives the longest runs): 8, 4, 2, 1 bytes back
-                if (p >= 8 && t[0] == v4) { c = p - 8; ok = true; }
-                else if (p >= 4 && t[1] == v4) { c = p - 4; ok = true; }
-                else if (p >= 2 && ((t[1] >> 16) | (t[2] << 16)) == v4) { c = p - 2; ok = true; }
-                else if (p >= 1 && ((t[1] >> 24) | (t[2] << 8)) == v4) { c = p - 1; ok = true; }
-            }
-            if (!ok && e != 0xFFFF) {   // the last position with this hash (mod 64 Ki), if it is still in the ring
-                c = (p & ~0xFFFFu) | e;
-                if (c >= p) c -= 0x10000u;                   // (wraps above p when there is no such position)
-                ok = c < p && c >= lo_valid;
-            }
-            if (ok) {
-                // round trip 3: 16 candidate bytes against the 16 bytes at p
-                const uint32_t cw = c >> 2, cq = c & 3;
-                uint32_t E[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) E[k] = L.ring[(cw + k) & RWM];
-                uint32_t d;
-                if ((d = __builtin_amdgcn_alignbyte(E[1], E[0], cq) ^ v4) != 0) ok = false;
-                else if ((d = __builtin_amdgcn_alignbyte(E[2], E[1], cq) ^ t[3]) != 0) mlen = 4 + (__builtin_ctz(d) >> 3);
-                else if ((d = __builtin_amdgcn_alignbyte(E[3], E[2], cq) ^ t[4]) != 0) mlen = 8 + (__builtin_ctz(d) >> 3);
-                else if ((d = __builtin_amdgcn_alignbyte(E[4], E[3], cq) ^ t[5]) != 0) mlen = 12 + (__builtin_ctz(d) >> 3);
-                else { mlen = 16; open = true; }
-            }
-            if (ok) {
-                cand = c;
-                const uint32_t room = matchlimit - p;        // longest match allowed here (>= 7)
-                while (open && mlen < LZE_CAP) {             // further round trips: 8 bytes each
-                    const uint64_t d = rd8(c + mlen) ^ rd8(p + mlen);
-                    if (d) { mlen += (uint32_t)__builtin_ctzll(d) >> 3; open = false; break; }
-                    mlen += 8;
-                }
-                if (mlen >= room) { mlen = room; open = false; }
-            } else {
-                mlen = 0;
-                open = false;
-            }
-        }
-        const uint64_t mm = __ballot(mlen >= 4);
-        LZP(1);
-        if (!mm) {
-            base += 64 * stride;
-            if (stride < 24) stride++;
-            continue;
-        }
-        // ---- greedy left-to-right selection of non-overlapping matches of this step.  Lazy matching first, per lane: a
-        // match steps aside when one of the next three positions starts a match that is longer by more than the
-        // distance.  Then the serial part — a wave-uniform walk over the match mask — is one v_readlane and one taken
-        // branch per chosen sequence; literal starts, sizes and staging offsets are computed per lane afterwards.
-        uint64_t msel = mm;
-        if (stride == 1) {
-            const uint32_t m1 = __shfl_down(mlen, 1, 64), m2 = __shfl_down(mlen, 2, 64), m3 = __shfl_down(mlen, 3, 64);
-            const bool dom = mlen >= 4 && ((lane < 63 && m1 > mlen + 1) || (lane < 62 && m2 > mlen + 2) || (lane < 61 && m3 > mlen + 3));
-            msel &= ~__ballot(dom);
-        }
-        const uint32_t mcomb = mlen | (open ? 0x80000000u : 0u);
-        uint64_t C = 0;
-        uint32_t covered = anchor;            // everything below is emitted or pending as literals of the next sequence
-        // wave-wide extension of the match at lane l (position pl) beyond its per-lane part, 64 x 4 bytes per step from HBM
-        auto extend = [&](uint32_t l, uint32_t pl, uint32_t ml_l) -> uint32_t {
-            const uint32_t c = rdlane(cand, l);
-            for (;;) {
-                const uint32_t x = ml_l + 4 * lane;
-                bool eq = pl + x + 4 <= matchlimit;
-                if (eq) eq = ldu32(src + c + x) == ldu32(src + pl + x);
-                const uint64_t ne = __ballot(!eq);
-                const uint32_t take = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;
-                ml_l += 4 * take;
-                if (ne) break;
-            }
-            while (pl + ml_l < matchlimit && ldu8(src + c + ml_l) == ldu8(src + pl + ml_l)) ml_l++;  // < 4 steps
-            mlen = wrlane(ml_l, l, mlen);
-            return ml_l;
-        };
-        if (stride == 1) {
-            uint32_t rel = 0;                 // (anchor <= base: the first lane is free)
-            do {
-                const uint64_t m = (msel >> rel) << rel;
-                if (!m) break;
-                const uint32_t l = (uint32_t)__builtin_ctzll(m);
-                const uint32_t v = rdlane(mcomb, l);
-                uint32_t ml_l = v & 0x7FFFFFFFu;
-                if (__builtin_expect(v >> 31, 0)) ml_l = extend(l, base + l, ml_l);
-                C |= 1ull << l;
-                rel = l + ml_l;
-            } while (rel < 64);
-            if (C) covered = base + rel;
-        } else {
-            for (;;) {
-                // lanes whose position is >= covered form a suffix: first lane = ceil((covered - base) / stride)
-                const uint32_t first_lane = covered <= base ? 0u : (covered - base + stride - 1) / stride;
-                if (first_lane >= 64) break;
-                const uint64_t m = (msel >> first_lane) << first_lane;
-                if (!m) break;
-                const uint32_t l = (uint32_t)__builtin_ctzll(m);
-                const uint32_t v = rdlane(mcomb, l);
-                uint32_t ml_l = v & 0x7FFFFFFFu;
-                const uint32_t pl = base + l * stride;
-                if (v >> 31) ml_l = extend(l, pl, ml_l);
-                C |= 1ull << l;
-                covered = pl + ml_l;
-            }
-        }
-        const bool chosen = (C >> lane) & 1;
-        uint32_t lit_start_v = anchor;
+    LzMatcher<HB, RB> mt(L, src, n);
+    mt.init();
+    mt.begin_chunk(0, n - 12, n - 5);     // LZ4: the last match starts >= 12 bytes before the end, the last 5 bytes are literals
+    while (mt.next()) {
+        const bool chosen = (mt.C >> lane) & 1;
+        uint32_t lit_start_v = mt.anchor;
         {
-            const uint64_t below = C & ((1ull << lane) - 1);
+            const uint64_t below = mt.C & ((1ull << lane) - 1);
             const uint32_t prevl = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-            const uint32_t pe = __shfl(p + mlen, prevl, 64);     // end of the previous chosen match
+            const uint32_t pe = __shfl(mt.p + mt.mlen, prevl, 64);     // end of the previous chosen match
             if (below) lit_start_v = pe;
         }
         uint32_t sz = 0;
         if (chosen) {
-            const uint32_t lit = p - lit_start_v, mcode = mlen - 4;
+            const uint32_t lit = mt.p - lit_start_v, mcode = mt.mlen - 4;
             sz = 1 + (lit >= 15 ? 1 + div255(lit - 15) : 0) + lit + 2 + (mcode >= 15 ? 1 + div255(mcode - 15) : 0);
         }
-        const uint64_t big = __ballot(chosen && p - lit_start_v > LZE_LIT_LANE);
+        const uint64_t big = __ballot(chosen && mt.p - lit_start_v > LZE_LIT_LANE);
         const uint32_t incl_sz = wave_scan_dpp(sz);
         const uint32_t out_off_v = incl_sz - sz;
         const uint32_t run = rdlane(incl_sz, 63);
         LZP(2);
-        LZP_CNT(17, __popcll(C));
+        LZP_CNT(17, __popcll(mt.C));
         if (big || run > LZE_OUT) LZP_CNT(18, 1);
         if (!big && run <= LZE_OUT) {
             // ---- every chosen lane writes its own sequence into the staging buffer
             if (on + run > LZE_OUT) flush_out();
             if (chosen) {
-                const uint32_t lit = p - lit_start_v, mcode = mlen - 4, off = p - cand;
+                const uint32_t lit = mt.p - lit_start_v, mcode = mt.mlen - 4, off = mt.p - mt.cand;
                 uint8_t* o = L.out + on + out_off_v;
                 uint32_t k = 0;
                 o[k++] = (uint8_t)((min(lit, 15u) << 4) | min(mcode, 15u));
@@ -770,12 +814,12 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
         } else {
             // ---- one sequence at a time, straight to dst (long literal runs)
             flush_out();
-            uint64_t m = C;
+            uint64_t m = mt.C;
             while (m) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
-                const uint32_t pl = base + l * stride;
-                const uint32_t s_ls = rdlane(lit_start_v, l), s_mc = rdlane(mlen, l) - 4, s_off = pl - rdlane(cand, l);
+                const uint32_t pl = mt.base + l * mt.stride;
+                const uint32_t s_ls = rdlane(lit_start_v, l), s_mc = rdlane(mt.mlen, l) - 4, s_off = pl - rdlane(mt.cand, l);
                 const uint32_t s_lit = pl - s_ls;
                 outp += put_head(s_lit, s_mc);
                 wave_copy_g2g(dst + outp, src + s_ls, s_lit);
@@ -793,12 +837,10 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
                 outp += 2 + (s_mc >= 15 ? 1 + div255(s_mc - 15) : 0);
             }
         }
-        anchor = covered;
-        base = max(covered, base + 1);
-        stride = 1;
+        mt.advance();
     }
     LZP(3);
-    emit_last(anchor);
+    emit_last(mt.anchor);
     LZP(5);
     LZP_END;
     return outp;

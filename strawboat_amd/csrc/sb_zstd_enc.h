@@ -1,0 +1,629 @@
+// strawboat-hip: Zstandard frame ENCODER on the device (RFC 8878), codec id 2 — replaces zstd::bulk::compress_to_buffer
+// (libzstd, level 3) at the reference call site src/compression/basic.rs:122-135.  Format-valid, not libzstd's bytes
+// (BASELINE.md §6): any Zstd decoder — the reference's, libzstd's, sb_zstd.h — reads the frame back to the input.
+//
+// One wave64 per page sub-buffer, one frame, blocks of up to 128 KiB of content:
+//   * sequences from the LDS matcher the LZ4 encoder uses (sb_lz4.h LzMatcher: 64 probe positions per step, lazy
+//     selection, history across blocks), recorded as (literal length, match length, offset) + a literal buffer in HBM;
+//   * literals: Huffman coded when the block's literals use byte values 0..128 only (the tree then fits the direct
+//     4-bit weight description; text, small integers) — lengths from a two-queue Huffman build limited to 11 bits,
+//     canonical codes as libzstd assigns them, four streams whose bits are placed lane-parallel (16 symbols per lane,
+//     prefix sums of code lengths, ds_or into an LDS window); raw literals otherwise;
+//   * sequences: FSE with the predefined distributions (RFC 8878 §3.1.1.3.2.2) — the encoding tables are built once
+//     per wave in LDS; the state chain is serial by construction and runs on lane 0;
+//   * a block that does not get smaller is stored raw.
+#pragma once
+#include "sb_lz4.h"
+
+namespace sb {
+
+constexpr uint32_t ZE_BLOCK = 128 * 1024;
+constexpr uint32_t ZE_HUF_MAXBITS = 11;
+
+struct ZeSeq {       // 8 bytes per sequence in HBM
+    uint32_t ll;
+    uint16_t ml;     // match length (>= 4)
+    uint16_t off;    // distance (1 .. 65535)
+};
+struct ZeSymTT {
+    int32_t delta_nb_bits;
+    int32_t delta_find_state;
+};
+struct ZEncLds {
+    Lz4EncLds<12, 13> lz;            // matcher; lz.out doubles as the bit window of the Huffman streams
+    uint32_t hist[256];
+    uint16_t hcode[132];
+    uint8_t hlen[132];
+    uint16_t ll_st[64], ml_st[64], of_st[32];   // FSE state tables (predefined distributions)
+    ZeSymTT ll_tt[36], ml_tt[53], of_tt[29];
+    uint16_t h_sorted[132];          // Huffman build scratch
+    uint32_t h_cnt[264];
+    int16_t h_parent[264];
+    uint32_t misc[8];
+    // one batch of sequences, prepared by all lanes for lane 0: codes + extra-bit values + the FSE transforms of the codes
+    uint32_t sq_code[64], sq_ll[64], sq_ml[64], sq_of[64];
+    ZeSymTT sq_tt[64][3];
+};
+
+__device__ const int16_t ZE_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                              2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__device__ const int16_t ZE_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                              1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__device__ const int16_t ZE_OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                              1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+__device__ const uint8_t ZE_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                           1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ const uint8_t ZE_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                           0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ const uint8_t ZE_LL_CODE[64] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 18,
+                                           19, 19, 20, 20, 20, 20, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23,
+                                           23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
+__device__ const uint8_t ZE_ML_CODE[128] = {
+    0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31,
+    32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38, 38, 38, 38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39,
+    40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41,
+    42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
+
+__device__ __forceinline__ uint32_t ze_highbit(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+__device__ __forceinline__ uint32_t ze_ll_code(uint32_t ll) { return ll > 63 ? ze_highbit(ll) + 19 : ZE_LL_CODE[ll]; }
+__device__ __forceinline__ uint32_t ze_ml_code(uint32_t mlbase) { return mlbase > 127 ? ze_highbit(mlbase) + 36 : ZE_ML_CODE[mlbase]; }
+
+// FSE_buildCTable for a normalized distribution (executed by one lane)
+__device__ inline void ze_build_ctable(const int16_t* norm, int nsym, int log, uint16_t* state_table, ZeSymTT* tt, uint8_t* spread /* 1 << log */) {
+    const int size = 1 << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    int high = size - 1;
+    int cumul[54];
+    cumul[0] = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == -1) {
+            cumul[s + 1] = cumul[s] + 1;
+            spread[high--] = (uint8_t)s;
+        } else {
+            cumul[s + 1] = cumul[s] + norm[s];
+        }
+    }
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        for (int k = 0; k < norm[s]; k++) {
+            spread[pos] = (uint8_t)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    for (int u = 0; u < size; u++) {
+        const int s = spread[u];
+        state_table[cumul[s]++] = (uint16_t)(size + u);
+    }
+    int total = 0;
+    for (int s = 0; s < nsym; s++) {
+        const int c = norm[s];
+        if (c == 0) {
+            tt[s].delta_nb_bits = ((log + 1) << 16) - (1 << log);
+            tt[s].delta_find_state = 0;
+        } else if (c == -1 || c == 1) {
+            tt[s].delta_nb_bits = (log << 16) - (1 << log);
+            tt[s].delta_find_state = total - 1;
+            total++;
+        } else {
+            const int max_bits_out = log - (int)ze_highbit((uint32_t)(c - 1));
+            const int min_state_plus = c << max_bits_out;
+            tt[s].delta_nb_bits = (max_bits_out << 16) - min_state_plus;
+            tt[s].delta_find_state = total - c;
+            total += c;
+        }
+    }
+}
+
+// forward-growing bit writer used by lane 0 (sequences section): bits are added low to high, bytes flushed to HBM
+struct ZeBits {
+    uint8_t* p;
+    uint64_t acc;
+    uint32_t nb;
+    __device__ __forceinline__ void add(uint32_t v, uint32_t n) {
+        acc |= (uint64_t)(v & ((1u << n) - 1)) << nb;   // (n <= 25)
+        nb += n;
+    }
+    __device__ __forceinline__ void flush() {   // one unaligned 8-byte store; the bytes above the whole ones are rewritten later
+        stu64(p, acc);
+        p += nb >> 3;
+        acc = (nb & ~7u) >= 64 ? 0 : acc >> (nb & ~7u);
+        nb &= 7;
+    }
+    __device__ __forceinline__ uint8_t* close() {   // end mark, then the partial byte
+        add(1, 1);
+        flush();
+        if (nb) *p++ = (uint8_t)acc;
+        return p;
+    }
+};
+
+// Huffman code lengths (<= 11 bits) and libzstd's canonical codes for the symbols with hist[s] > 0, s <= max_sym <= 128.
+// Executed by lane 0.  Returns the number of bits of the longest code, 0 if no valid tree (the caller stores raw literals).
+__device__ inline uint32_t ze_huf_build(ZEncLds& Z, uint32_t max_sym) {
+    // symbols sorted by count, ascending (insertion sort: <= 129 symbols)
+    uint32_t ns = 0;
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        Z.hlen[s] = 0;
+        if (!Z.hist[s]) continue;
+        uint32_t k = ns++;
+        while (k > 0 && Z.hist[Z.h_sorted[k - 1]] > Z.hist[s]) {
+            Z.h_sorted[k] = Z.h_sorted[k - 1];
+            k--;
+        }
+        Z.h_sorted[k] = (uint16_t)s;
+    }
+    if (ns < 2) return 0;
+    // two-queue Huffman: leaves 0..ns-1 (sorted), internal nodes ns..2ns-2
+    for (uint32_t k = 0; k < ns; k++) Z.h_cnt[k] = Z.hist[Z.h_sorted[k]];
+    uint32_t leaf = 0, inode = ns, next_i = ns;
+    auto take = [&]() -> uint32_t {
+        if (leaf < ns && (inode >= next_i || Z.h_cnt[leaf] <= Z.h_cnt[inode])) return leaf++;
+        return inode++;
+    };
+    for (uint32_t k = 0; k + 1 < ns; k++) {
+        const uint32_t a = take(), b = take();
+        Z.h_cnt[next_i] = Z.h_cnt[a] + Z.h_cnt[b];
+        Z.h_parent[a] = (int16_t)next_i;
+        Z.h_parent[b] = (int16_t)next_i;
+        next_i++;
+    }
+    const uint32_t root = next_i - 1;
+    Z.h_parent[root] = -1;
+    // depths: parents have larger indices than their children
+    for (uint32_t k = root; k-- > 0;) Z.h_cnt[k] = (Z.h_parent[k] == (int16_t)root ? 0u : Z.h_cnt[Z.h_parent[k]]) + 1;   // h_cnt now = depth
+    uint32_t maxd = 0;
+    for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
+    if (maxd > ZE_HUF_MAXBITS) {
+        // clamp, then repair the Kraft sum: K = sum 2^(11 - len) must be exactly 2^11
+        uint32_t K = 0;
+        for (uint32_t k = 0; k < ns; k++) {
+            if (Z.h_cnt[k] > ZE_HUF_MAXBITS) Z.h_cnt[k] = ZE_HUF_MAXBITS;
+            K += 1u << (ZE_HUF_MAXBITS - Z.h_cnt[k]);
+        }
+        const uint32_t full = 1u << ZE_HUF_MAXBITS;
+        // over-subscribed: lengthen the rarest symbols that are still short of 11 bits (k ascending = rarest first)
+        for (uint32_t L = ZE_HUF_MAXBITS - 1; K > full && L >= 1; L--)
+            for (uint32_t k = 0; k < ns && K > full; k++)
+                if (Z.h_cnt[k] == L) {
+                    Z.h_cnt[k] = L + 1;
+                    K -= 1u << (ZE_HUF_MAXBITS - L - 1);
+                }
+        if (K > full) return 0;
+        // under-subscribed: shorten the most frequent symbols whose step fits the deficit (k descending = most frequent)
+        uint32_t D = full - K;
+        for (uint32_t k = ns; k-- > 0 && D;) {
+            while (Z.h_cnt[k] > 1 && (1u << (ZE_HUF_MAXBITS - Z.h_cnt[k])) <= D) {
+                D -= 1u << (ZE_HUF_MAXBITS - Z.h_cnt[k]);
+                Z.h_cnt[k]--;
+            }
+        }
+        if (D) return 0;
+        maxd = 0;
+        for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
+    }
+    for (uint32_t k = 0; k < ns; k++) Z.hlen[Z.h_sorted[k]] = (uint8_t)Z.h_cnt[k];
+    // canonical codes: longest codes first (rank = number of bits), symbols of one length in symbol order
+    uint32_t code = 0;
+    for (uint32_t len = maxd; len >= 1; len--) {
+        for (uint32_t s = 0; s <= max_sym; s++)
+            if (Z.hlen[s] == len) Z.hcode[s] = (uint16_t)code++;
+        code >>= 1;
+    }
+    return maxd;
+}
+
+// One Huffman stream: symbols lits[0, m) in REVERSE order into a forward bit stream + end mark.  16 symbols per lane,
+// positions from prefix sums of the code lengths, bits OR-ed into an LDS window (Z.lz.out) tile by tile.
+// Returns the stream's size in bytes.
+__device__ inline uint32_t ze_huf_stream(ZEncLds& Z, const uint8_t* lits, uint32_t m, uint8_t* dst) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t* win = (uint32_t*)Z.lz.out;        // 2048 bytes = 512 words; a tile of 1024 symbols needs <= 11264 bits = 352 words
+    uint32_t out = 0;                            // whole bytes already written to dst
+    uint32_t carry_bits = 0, carry = 0;          // bits of the unfinished byte (< 8), kept in `carry`
+    for (uint32_t done = 0; done <= m; done += 1024) {   // (one extra round when m % 1024 == 0 writes the end mark)
+        const uint32_t tile = min(1024u, m - done);
+        for (uint32_t k = lane; k < 384; k += 64) win[k] = 0;
+        wave_sync();
+        // my symbols: reverse positions [done + 16 lane, done + 16 lane + 16) -> lits[m - 1 - r]
+        uint32_t bits = 0;
+        uint32_t lens[16], codes[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t r = done + 16 * lane + j;
+            uint32_t l = 0, c = 0;
+            if (16 * lane + j < tile) {
+                const uint32_t s = ldu8(lits + (m - 1 - r));
+                l = Z.hlen[s];
+                c = Z.hcode[s];
+            }
+            lens[j] = l;
+            codes[j] = c;
+            bits += l;
+        }
+        const uint32_t incl = wave_scan_dpp(bits);
+        uint32_t pos = carry_bits + incl - bits;
+        if (lane == 0 && carry_bits) atomicOr(&win[0], carry);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (lens[j]) {
+                const uint32_t w = pos >> 5, sh = pos & 31;
+                atomicOr(&win[w], codes[j] << sh);
+                if (sh + lens[j] > 32) atomicOr(&win[w + 1], codes[j] >> (32 - sh));
+                pos += lens[j];
+            }
+        }
+        uint32_t total = carry_bits + rdlane(incl, 63);
+        const bool last = done + tile >= m;
+        if (last) {
+            if (lane == 0) atomicOr(&win[total >> 5], 1u << (total & 31));   // end mark
+            total += 1;
+        }
+        wave_sync();
+        const uint32_t nbytes = last ? (total + 7) >> 3 : total >> 3;
+        const uint8_t* wb = (const uint8_t*)win;
+        for (uint32_t k = lane; k < nbytes; k += 64) dst[out + k] = wb[k];
+        out += nbytes;
+        carry_bits = last ? 0 : total & 7;
+        carry = carry_bits ? (uint32_t)wb[nbytes] & ((1u << carry_bits) - 1) : 0;
+        wave_sync();
+        if (last) break;
+    }
+    return out;
+}
+
+// HBM scratch of one wave: literal buffer (1x), sequence records (2x) and the compressed block under construction (3x: a
+// block that turns out larger than its content is dropped for a raw block, so it is not built in the caller's buffer)
+__host__ __device__ __forceinline__ uint64_t zstd_scratch_bytes(uint64_t n) {
+    const uint64_t b = n < ZE_BLOCK ? n : ZE_BLOCK;
+    return 6 * ((b + 15) & ~15ull) + 256;
+}
+// Compress src[0, n) into dst as one Zstd frame (capacity >= n + 3 * ceil(n / 128 KiB) + 16); executed by ONE wave64.
+// `scratch` (HBM): zstd_scratch_bytes(n).  Returns the frame size.
+__device__ uint32_t zstd_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, ZEncLds& Z, uint8_t* scratch) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t o = 0;
+    LZP_BEGIN
+    // ---- frame header: magic, single segment + frame content size (1 / 2 / 4 bytes as libzstd sizes it), no checksum
+    if (lane == 0) {
+        dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+        if (n < 256) {
+            dst[4] = 0x20;
+            dst[5] = (uint8_t)n;
+        } else if (n < 65536 + 256) {
+            dst[4] = 0x60;
+            dst[5] = (uint8_t)(n - 256);
+            dst[6] = (uint8_t)((n - 256) >> 8);
+        } else {
+            dst[4] = 0xA0;
+            for (int k = 0; k < 4; k++) dst[5 + k] = (uint8_t)(n >> (8 * k));
+        }
+    }
+    o = n < 256 ? 6 : n < 65536 + 256 ? 7 : 9;
+    if (n == 0) {   // one empty raw block, last
+        if (lane == 0) { dst[o] = 1; dst[o + 1] = 0; dst[o + 2] = 0; }
+        return o + 3;
+    }
+    // ---- FSE encoding tables of the predefined distributions (once per wave)
+    if (lane == 0) {
+        uint8_t* spread = Z.lz.out;
+        ze_build_ctable(ZE_LL_DEFAULT, 36, 6, Z.ll_st, Z.ll_tt, spread);
+        ze_build_ctable(ZE_ML_DEFAULT, 53, 6, Z.ml_st, Z.ml_tt, spread);
+        ze_build_ctable(ZE_OF_DEFAULT, 29, 5, Z.of_st, Z.of_tt, spread);
+    }
+    wave_sync();
+    const uint32_t blk_cap = min(n, ZE_BLOCK);
+    uint8_t* lits = scratch;                                   // <= blk_cap bytes
+    const uint32_t cap16 = (blk_cap + 15) & ~15u;
+    ZeSeq* seqs = (ZeSeq*)(scratch + cap16);                    // <= blk_cap / 4 records of 8 bytes
+    uint8_t* attempt = scratch + 3 * (size_t)cap16;              // the compressed block is built here
+    LzMatcher<12, 13> mt(Z.lz, src, n);
+    mt.init();
+    for (uint32_t c0 = 0; c0 < n; c0 += ZE_BLOCK) {
+        const uint32_t c1 = min(n, c0 + ZE_BLOCK), blk = c1 - c0;
+        const bool last_block = c1 == n;
+        uint32_t nseq = 0, nlit = 0;
+        uint32_t tail_from = c0;
+        if (blk >= 32) {
+            mt.begin_chunk(c0, c1 - 12, c1 - 5);
+            LZP(8);
+            while (mt.next()) {
+                LZP(9);
+                // ---- record the chosen sequences of this step: literals [lit_start, p) + match
+                const bool chosen = (mt.C >> lane) & 1;
+                uint32_t lit_start = mt.anchor;
+                {
+                    const uint64_t below = mt.C & ((1ull << lane) - 1);
+                    const uint32_t prevl = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                    const uint32_t pe = __shfl(mt.p + mt.mlen, prevl, 64);
+                    if (below) lit_start = pe;
+                }
+                const uint32_t ll = chosen ? mt.p - lit_start : 0u;
+                // a match longer than 65535 is cut (the rest is found again as the next match)
+                uint32_t ml = mt.mlen;
+                const uint64_t longm = __ballot(chosen && ml > 65535u);
+                if (longm) {   // only the first such match of the step is kept; the step ends there
+                    const uint32_t l0 = (uint32_t)__builtin_ctzll(longm);
+                    mt.C &= (2ull << l0) - 1;
+                    if (lane == l0) ml = 65535u;
+                    mt.covered = rdlane(mt.p, l0) + 65535u;
+                }
+                const bool keep = (mt.C >> lane) & 1;
+                const uint32_t myll = keep ? ll : 0u;
+                const uint32_t incl = wave_scan_dpp(myll);
+                const uint32_t k = nseq + lane_rank(mt.C);
+                if (keep) {
+                    ZeSeq r;
+                    r.ll = myll;
+                    r.ml = (uint16_t)ml;
+                    r.off = (uint16_t)(mt.p - mt.cand);
+                    seqs[k] = r;
+                    uint8_t* w = lits + nlit + (incl - myll);
+                    if (myll <= 64) {   // (at most 64 bytes back: in the matcher's ring, no HBM load)
+                        for (uint32_t i = 0; i < myll; i += 8) {
+                            const uint64_t v = lds_rd8_ring(Z.lz.ring, (lit_start + i) & (LzMatcher<12, 13>::R - 1), LzMatcher<12, 13>::RWM);
+                            if (myll - i >= 8) {
+                                stu64(w + i, v);
+                            } else {
+                                for (uint32_t b = 0; b < myll - i; b++) w[i + b] = (uint8_t)(v >> (8 * b));
+                            }
+                        }
+                    }
+                }
+                uint64_t bigl = __ballot(keep && myll > 64);
+                while (bigl) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(bigl);
+                    bigl &= bigl - 1;
+                    wave_copy_g2g(lits + nlit + rdlane(incl - myll, l), src + rdlane(lit_start, l), rdlane(myll, l));
+                }
+                nlit += rdlane(incl, 63);
+                nseq += (uint32_t)__popcll(mt.C);
+                mt.advance();
+                LZP(10);
+            }
+            tail_from = mt.anchor;
+        }
+        // trailing literals of the block
+        wave_copy_g2g(lits + nlit, src + tail_from, c1 - tail_from);
+        nlit += c1 - tail_from;
+        wave_stores_visible();   // lits / seqs are read back below
+        LZP(11);
+        LZP_CNT(16, nseq);
+        LZP_CNT(17, nlit);
+        // ---- the block: compressed if that is smaller, raw otherwise
+        uint8_t* bh = dst + o;          // 3-byte block header
+        uint8_t* body = attempt;
+        uint32_t csize = 0;
+        bool ok = (nseq > 0 || nlit > 64) && nlit / 2 + 2 * nseq < blk;   // (cheap lower bound of the compressed size)
+        if (ok) {
+            uint32_t q = 0;
+            // ---- literals section
+            for (uint32_t k = lane; k < 256; k += 64) Z.hist[k] = 0;
+            wave_sync();
+            {   // 16 bytes per lane and load (lits is 16-byte aligned scratch)
+                const uint32_t nvec = nlit >> 4;
+                for (uint32_t i = lane; i < nvec; i += 64) {
+                    const u32x4 v = ldu128(lits + 16 * (size_t)i);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        atomicAdd(&Z.hist[w[k] & 255], 1u);
+                        atomicAdd(&Z.hist[(w[k] >> 8) & 255], 1u);
+                        atomicAdd(&Z.hist[(w[k] >> 16) & 255], 1u);
+                        atomicAdd(&Z.hist[w[k] >> 24], 1u);
+                    }
+                }
+                for (uint32_t i = (nvec << 4) + lane; i < nlit; i += 64) atomicAdd(&Z.hist[ldu8(lits + i)], 1u);
+            }
+            wave_sync();
+            uint32_t maxs = 0;
+            for (uint32_t k = lane; k < 256; k += 64)
+                if (Z.hist[k]) maxs = max(maxs, k);
+            for (int d = 32; d > 0; d >>= 1) maxs = max(maxs, (uint32_t)__shfl_xor((int)maxs, d, 64));
+            uint32_t hbits = 0;
+            if (nlit >= 64 && maxs <= 128 && maxs >= 1) {
+                if (lane == 0) Z.misc[0] = ze_huf_build(Z, maxs);
+                wave_sync();
+                hbits = Z.misc[0];
+            }
+            bool huf = hbits != 0;
+            if (huf) {
+                // size estimate: the tree + the coded bits must beat raw
+                uint32_t est = 0;
+                for (uint32_t k = lane; k <= maxs; k += 64) est += Z.hist[k] * Z.hlen[k];
+                for (int d = 32; d > 0; d >>= 1) est += (uint32_t)__shfl_xor((int)est, d, 64);
+                const uint32_t coded = (est + 7) / 8 + 1 + (maxs + 1) / 2 + 16;
+                if (coded >= nlit || nlit > 262143u) huf = false;
+            }
+            if (huf) {
+                const bool four = nlit >= 256;
+                // header size: 3 bytes (sizes < 1024), 4 (< 16384), 5 (< 262144); single stream only in the 3-byte form
+                const uint32_t hsz = !four ? 3u : 5u;   // (the compressed size is not known yet: the widest form always fits)
+                uint8_t* lh = body + q;
+                uint32_t w = hsz;
+                // tree description: direct 4-bit weights of symbols 0 .. maxs - 1
+                if (lane == 0) {
+                    lh[w] = (uint8_t)(127 + maxs);
+                    for (uint32_t s = 0; s < maxs; s += 2) {
+                        const uint32_t w0 = Z.hlen[s] ? hbits + 1 - Z.hlen[s] : 0;
+                        const uint32_t w1 = (s + 1 < maxs && Z.hlen[s + 1]) ? hbits + 1 - Z.hlen[s + 1] : 0;
+                        lh[w + 1 + s / 2] = (uint8_t)((w0 << 4) | w1);
+                    }
+                }
+                w += 1 + (maxs + 1) / 2;
+                const uint32_t tree_end = w;
+                if (four) {
+                    const uint32_t seg = (nlit + 3) / 4;
+                    uint32_t ssz[4];
+                    w += 6;   // jump table
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t b0 = min(nlit, seg * j), b1 = min(nlit, seg * (j + 1));
+                        ssz[j] = ze_huf_stream(Z, lits + b0, b1 - b0, lh + w);
+                        w += ssz[j];
+                    }
+                    if (lane == 0)
+                        for (int j = 0; j < 3; j++) {
+                            lh[tree_end + 2 * j] = (uint8_t)ssz[j];
+                            lh[tree_end + 2 * j + 1] = (uint8_t)(ssz[j] >> 8);
+                        }
+                    if (ssz[0] > 65535u || ssz[1] > 65535u || ssz[2] > 65535u) huf = false;
+                } else {
+                    w += ze_huf_stream(Z, lits, nlit, lh + w);
+                }
+                const uint32_t comp = w - hsz;   // tree + jump table + streams
+                if (huf && comp < nlit && comp < 262144u) {
+                    if (lane == 0) {
+                        if (!four) {            // type 2, size format 0: 10-bit sizes, single stream
+                            const uint32_t v = 2u | (0u << 2) | (nlit << 4) | (comp << 14);
+                            lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); lh[2] = (uint8_t)(v >> 16);
+                        } else {                // type 2, size format 3: 18-bit sizes, four streams
+                            const uint64_t v = 2ull | (3ull << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22);
+                            for (int k = 0; k < 5; k++) lh[k] = (uint8_t)(v >> (8 * k));
+                        }
+                    }
+                    q += w;
+                } else {
+                    huf = false;
+                }
+            }
+            if (!huf) {   // raw literals
+                uint8_t* lh = body + q;
+                uint32_t hsz;
+                if (nlit < 32) {
+                    hsz = 1;
+                    if (lane == 0) lh[0] = (uint8_t)(nlit << 3);
+                } else if (nlit < 4096) {
+                    hsz = 2;
+                    if (lane == 0) { const uint32_t v = (nlit << 4) | (1u << 2); lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); }
+                } else {
+                    hsz = 3;
+                    if (lane == 0) { const uint32_t v = (nlit << 4) | (3u << 2); lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); lh[2] = (uint8_t)(v >> 16); }
+                }
+                wave_copy_g2g(lh + hsz, lits, nlit);
+                q += hsz + nlit;
+            }
+            LZP(12);
+            // ---- sequences section
+            uint8_t* sh = body + q;
+            uint32_t shdr;
+            if (nseq < 128) {
+                shdr = 1;
+                if (lane == 0) sh[0] = (uint8_t)nseq;
+            } else if (nseq < 0x7F00) {
+                shdr = 2;
+                if (lane == 0) { sh[0] = (uint8_t)((nseq >> 8) + 0x80); sh[1] = (uint8_t)nseq; }
+            } else {
+                shdr = 3;
+                if (lane == 0) { sh[0] = 0xFF; sh[1] = (uint8_t)(nseq - 0x7F00); sh[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+            }
+            q += shdr;
+            if (nseq) {
+                // The FSE state chain is serial (lane 0).  Everything else about a sequence — its three codes and the values of
+                // its extra bits — is prepared 64 sequences at a time by all lanes (one HBM round trip per batch instead of one
+                // per sequence), from the LAST sequence backwards.
+                ZeBits bs{sh + shdr + 1, 0, 0};
+                uint32_t s_ll = 0, s_of = 0, s_ml = 0;
+                if (lane == 0) sh[shdr] = 0;   // Symbol_Compression_Modes: predefined LL / OF / ML
+                auto init_state = [&](const uint16_t* st, const ZeSymTT* tt, uint32_t sym) -> uint32_t {
+                    const uint32_t nb = (uint32_t)(tt[sym].delta_nb_bits + (1 << 15)) >> 16;
+                    const uint32_t value = (nb << 16) - (uint32_t)tt[sym].delta_nb_bits;
+                    return st[(value >> nb) + tt[sym].delta_find_state];
+                };
+                auto enc_sym = [&](uint32_t& state, const uint16_t* st, const ZeSymTT* tt, uint32_t sym) {
+                    const uint32_t nb = (uint32_t)(state + tt[sym].delta_nb_bits) >> 16;
+                    bs.add(state, nb);
+                    state = st[(state >> nb) + tt[sym].delta_find_state];
+                };
+                for (uint32_t hi_k = nseq; hi_k > 0; hi_k -= min(hi_k, 64u)) {
+                    const uint32_t cnt = min(hi_k, 64u);
+                    if (lane < cnt) {
+                        const ZeSeq r = seqs[hi_k - 1 - lane];
+                        const uint32_t ofb = (uint32_t)r.off + 3;
+                        const uint32_t llc = ze_ll_code(r.ll), mlc = ze_ml_code((uint32_t)r.ml - 3);
+                        // (the code / bit-count tables live in HBM: looked up here, 64 at a time, not inside the serial loop)
+                        Z.sq_code[lane] = llc | (mlc << 6) | (ze_highbit(ofb) << 12) | ((uint32_t)ZE_LL_BITS[llc] << 17) | ((uint32_t)ZE_ML_BITS[mlc] << 22);
+                        Z.sq_ll[lane] = r.ll;
+                        Z.sq_ml[lane] = (uint32_t)r.ml - 3;
+                        Z.sq_of[lane] = ofb;
+                        Z.sq_tt[lane][0] = Z.of_tt[ze_highbit(ofb)];
+                        Z.sq_tt[lane][1] = Z.ml_tt[mlc];
+                        Z.sq_tt[lane][2] = Z.ll_tt[llc];
+                    }
+                    wave_sync();
+                    if (lane == 0) {
+                        for (uint32_t j = 0; j < cnt; j++) {
+                            const uint32_t code = Z.sq_code[j], llc = code & 63, mlc = (code >> 6) & 63, ofc = (code >> 12) & 31;
+                            const uint32_t llb = (code >> 17) & 31, mlb = code >> 22;
+                            if (hi_k == nseq && j == 0) {   // the last sequence initialises the three states
+                                s_ll = init_state(Z.ll_st, Z.ll_tt, llc);
+                                s_of = init_state(Z.of_st, Z.of_tt, ofc);
+                                s_ml = init_state(Z.ml_st, Z.ml_tt, mlc);
+                            } else {
+                                // the three chains are independent: their transforms arrive with one LDS round trip, their new
+                                // states with a second one
+                                const ZeSymTT t_of = Z.sq_tt[j][0], t_ml = Z.sq_tt[j][1], t_ll = Z.sq_tt[j][2];
+                                const uint32_t nb_of = (uint32_t)(s_of + t_of.delta_nb_bits) >> 16;
+                                const uint32_t nb_ml = (uint32_t)(s_ml + t_ml.delta_nb_bits) >> 16;
+                                const uint32_t nb_ll = (uint32_t)(s_ll + t_ll.delta_nb_bits) >> 16;
+                                const uint32_t n_of = Z.of_st[(s_of >> nb_of) + t_of.delta_find_state];
+                                const uint32_t n_ml = Z.ml_st[(s_ml >> nb_ml) + t_ml.delta_find_state];
+                                const uint32_t n_ll = Z.ll_st[(s_ll >> nb_ll) + t_ll.delta_find_state];
+                                bs.add(s_of, nb_of);
+                                bs.add(s_ml, nb_ml);
+                                bs.add(s_ll, nb_ll);   // (<= 5 + 6 + 6 bits on top of < 8 pending)
+                                bs.flush();
+                                s_of = n_of;
+                                s_ml = n_ml;
+                                s_ll = n_ll;
+                            }
+                            bs.add(Z.sq_ll[j], llb);
+                            bs.add(Z.sq_ml[j], mlb);   // (<= 16 + 16 bits on top of < 8 pending)
+                            bs.flush();
+                            bs.add(Z.sq_of[j], ofc);
+                            bs.flush();
+                        }
+                    }
+                    wave_sync();
+                }
+                if (lane == 0) {
+                    bs.add(s_ml, 6);
+                    bs.flush();
+                    bs.add(s_of, 5);
+                    bs.flush();
+                    bs.add(s_ll, 6);
+                    uint8_t* e = bs.close();
+                    Z.misc[1] = (uint32_t)(e - (sh + shdr));
+                }
+                wave_sync();
+                __builtin_amdgcn_s_waitcnt(0);
+                q += Z.misc[1];
+            }
+            csize = q;
+            ok = csize < blk;
+            LZP(13);
+        }
+        if (ok) {
+            if (lane == 0) {
+                const uint32_t v = (last_block ? 1u : 0u) | (2u << 1) | (csize << 3);
+                bh[0] = (uint8_t)v; bh[1] = (uint8_t)(v >> 8); bh[2] = (uint8_t)(v >> 16);
+            }
+            wave_stores_visible();
+            wave_copy_g2g(bh + 3, attempt, csize);
+            o += 3 + csize;
+        } else {   // raw block
+            body = bh + 3;
+            if (lane == 0) {
+                const uint32_t v = (last_block ? 1u : 0u) | (0u << 1) | (blk << 3);
+                bh[0] = (uint8_t)v; bh[1] = (uint8_t)(v >> 8); bh[2] = (uint8_t)(v >> 16);
+            }
+            wave_stores_visible();
+            wave_copy_g2g(body, src + c0, blk);
+            o += 3 + blk;
+        }
+        wave_stores_visible();
+        LZP(14);
+    }
+    LZP_END;
+    return o;
+}
+
+}  // namespace sb

@@ -207,7 +207,8 @@ def test_pages_without_leaf_slots(gpu_ctx, dc, ptype, ratio):
     enc = nested.write_nested(gpu_ctx, device_levels(gpu_ctx, levels), dcol,
                               WriteOptions(default_compression=dc, max_page_size=2, default_compress_ratio=ratio, lz4_exact=True))
     got = enc.pages_numpy()
-    if dc == S.SNAPPY:   # the device's Snappy streams are literal-only (valid, not the oracle's bytes): same page count / entries
+    if dc in (S.SNAPPY, S.ZSTD):   # valid Snappy / Zstd streams, not the oracle's bytes (literal-only Snappy; the device's Zstd
+        # encoder compresses, the oracle's stores): same page count / entries, and the pages decode
         assert np.array_equal(enc.metas_array()[:, 1], want_metas[:, 1])
         back = nested.read_nested(gpu_ctx, ColumnPages(ptype, False, up(gpu_ctx, got), enc.metas_array()),
                                   [lv["kind"] for lv in levels], [bool(lv["is_optional"]) for lv in levels])

@@ -496,6 +496,151 @@ __device__ uint32_t lz4_inflate_block(const uint8_t* src, uint32_t n, uint8_t* d
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ sequence executor
+// Executes decoded LZ sequences (literal length, match length, distance) whose literals sit in one contiguous HBM buffer
+// — the Zstd decoder's sequence stage (sb_zstd.h) — through the same LDS output ring as lz4_inflate_block: a batch of up
+// to 64 sequences costs one HBM round trip for its literals and at most one store->load wait for matches that reach
+// behind the ring, instead of two waits per sequence.
+constexpr uint32_t LZX_RING = 8192, LZX_BATCH = 4096;
+struct LzSeqLds {
+    __attribute__((aligned(16))) uint8_t ring[LZX_RING];
+};
+struct LzSeqExec {
+    LzSeqLds& L;
+    uint8_t* dst;
+    uint32_t a0;
+    uint8_t* gbase;
+    uint32_t fl = 0, ring_lo = 0;
+    static constexpr uint32_t RM = LZX_RING - 1;
+    __device__ LzSeqExec(LzSeqLds& l, uint8_t* d) : L(l), dst(d), a0((uint32_t)((uintptr_t)d & 15)), gbase(d - ((uintptr_t)d & 15)) {}
+    __device__ void flush(uint32_t g_end, bool all) {
+        const uint32_t lane = threadIdx.x & 63;
+        wave_sync();
+        const uint32_t full_end = g_end & ~15u;
+        uint32_t g = fl;
+        if (g < full_end && g < a0) {
+            if (lane >= a0 && lane < 16) gbase[lane] = L.ring[lane];
+            g = 16;
+        }
+        const uint32_t ng = full_end > g ? (full_end - g) >> 4 : 0;
+        for (uint32_t k = lane; k < ng; k += 64) {
+            const uint32_t gg = g + 16 * k;
+            stu128(gbase + gg, *(const u32x4*)(L.ring + (gg & RM)));
+        }
+        if (all) {
+            const uint32_t x = full_end + lane;
+            if (x < g_end && x >= a0) gbase[x] = L.ring[x & RM];
+        }
+        if (full_end > fl) fl = full_end;
+        wave_sync();
+    }
+    // after bytes were written straight to HBM up to output position op: nothing below is in the ring any more
+    __device__ void restart(uint32_t op) {
+        const uint32_t lane = threadIdx.x & 63;
+        wave_stores_visible();
+        fl = (op + a0) & ~15u;
+        ring_lo = fl;
+        const uint32_t keep = (op + a0) - fl;
+        if (lane < keep && fl + lane >= a0) L.ring[(fl + lane) & RM] = ldu8(gbase + fl + lane);
+        wave_sync();
+    }
+    // One batch: lane k < nb holds sequence k (ll, ml, off; off validated by the caller: 0 < off <= its match position).
+    // lit = the batch's literals, contiguous.  op = output position of the batch's first byte.  Returns the bytes produced.
+    __device__ uint32_t run(uint32_t nb, uint32_t ll, uint32_t ml, uint32_t off, const uint8_t* lit, uint32_t op) {
+        const uint32_t lane = threadIdx.x & 63;
+        const bool have = lane < nb;
+        const uint32_t tot = have ? ll + ml : 0u;
+        const uint32_t incl = wave_scan_dpp(tot);
+        const uint32_t total = rdlane(incl, 63);
+        const uint32_t lincl = wave_scan_dpp(have ? ll : 0u);
+        const uint32_t my_op = op + incl - tot;             // my literals start here, my match at my_op + ll
+        const uint32_t my_lit = lincl - (have ? ll : 0u);  // offset of my literals in `lit`
+        const uint64_t bigm = __ballot(have && (ll > 512 || ml > 512));
+        if (total > LZX_BATCH || bigm) {
+            // ---- oversized batch: sequence by sequence through HBM (long literal runs / long matches)
+            flush(op + a0, true);
+            uint32_t o = op;
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint32_t kl = rdlane(ll, k), km = rdlane(ml, k), ko = rdlane(off, k), kp = rdlane(my_lit, k);
+                wave_copy_g2g(dst + o, lit + kp, kl);
+                o += kl;
+                wave_stores_visible();
+                if (ko >= km) {
+                    wave_copy_g2g(dst + o, dst + o - ko, km);
+                } else if (ko >= 1024) {
+                    for (uint32_t c0 = 0; c0 < km; c0 += ko) {
+                        wave_copy_g2g(dst + o + c0, dst + o - ko + c0, min(ko, km - c0));
+                        wave_stores_visible();
+                    }
+                } else {
+                    const uint8_t* hist = dst + o - ko;
+                    for (uint32_t i = lane; i < km; i += 64) dst[o + i] = ldu8(hist + i % ko);
+                }
+                o += km;
+            }
+            restart(o);
+            return o - op;
+        }
+        const uint32_t g_end = op + total + a0;
+        // ---- literals: HBM -> ring, lane per sequence, 8 bytes per round trip
+        if (have) {
+            for (uint32_t i = 0; i < ll; i += 8) {
+                uint64_t v = 0;
+                const uint32_t nbytes = min(8u, ll - i);
+                if (nbytes == 8) {
+                    v = ldu64(lit + my_lit + i);
+                } else {
+                    for (uint32_t b = 0; b < nbytes; b++) v |= (uint64_t)ldu8(lit + my_lit + i + b) << (8 * b);
+                }
+                lds_wr_bytes(L.ring, RM, my_op + a0 + i, v, nbytes);
+            }
+        }
+        wave_sync();
+        // ---- matches
+        const uint32_t ring_min = max(ring_lo, g_end > LZX_RING ? g_end - LZX_RING : 0u);
+        const uint32_t d = my_op + ll + a0, s = d - off;
+        const uint32_t send = s + min(ml, off);
+        const bool ism = have && ml > 0;
+        const bool in_ring = ism && s >= ring_min;
+        const bool far = ism && !in_ring && send <= fl;
+        const bool mixed = ism && !in_ring && !far;
+        if (__ballot(far || mixed)) wave_stores_visible();
+        if (far) {
+            for (uint32_t i = 0, j = 0; i < ml; i++) {
+                L.ring[(d + i) & RM] = ldu8(gbase + s + j);
+                if (++j == off) j = 0;
+            }
+        }
+        wave_sync();
+        uint64_t rem = __ballot(in_ring || mixed);
+        const uint64_t mixed_m = __ballot(mixed);
+        while (rem) {
+            const uint32_t first = (uint32_t)__builtin_ctzll(rem);
+            rem &= rem - 1;
+            const uint32_t fd = rdlane(d, first), fml = rdlane(ml, first), foff = rdlane(off, first);
+            const uint32_t fs = fd - foff;
+            if (__builtin_expect(fml <= 64 && foff >= fml && !((mixed_m >> first) & 1), 1)) {
+                if (lane < fml) L.ring[(fd + lane) & RM] = L.ring[(fs + lane) & RM];
+                continue;
+            }
+            const bool mx = (mixed_m >> first) & 1;
+            const bool periodic = foff < 64 && foff < fml;
+            for (uint32_t i0 = 0; i0 < fml; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                if (i < fml) {
+                    const uint32_t sp = fs + (periodic ? i % foff : i);
+                    const uint8_t v = (mx && sp < fl) ? ldu8(gbase + sp) : L.ring[sp & RM];
+                    L.ring[(fd + i) & RM] = v;
+                }
+                wave_sync();
+            }
+        }
+        flush(g_end, false);
+        return total;
+    }
+    __device__ void finish(uint32_t op) { flush(op + a0, true); }
+};
+
 // ------------------------------------------------------------------------------------------------ encode
 // The matcher looks back only as far as its LDS ring reaches (HB hash bits, 2^RB ring bytes): on zipf text 8 KiB of
 // history costs ~7 % of liblz4's ratio, 14 KiB ~5 % — and every probe, candidate check and match extension is an LDS

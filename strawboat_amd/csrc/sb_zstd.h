@@ -10,6 +10,7 @@
 // parallelism comes from the number of pages in flight.
 #pragma once
 #include "sb_common.h"
+#include "sb_lz4.h"
 
 namespace sb {
 
@@ -31,7 +32,13 @@ struct ZWork {  // per-wave LDS workspace (~12 KB)
     uint32_t rep[3];
     int32_t err;
     uint32_t nbatch;
+    // window of the sequences bit stream (read backwards): bytes [bw_lo, bw_lo + ZBW) of it, refilled by the wave before a
+    // batch of 64 sequences (a batch consumes < 64 * 12 bytes)
+    uint32_t bw_lo;
+    __attribute__((aligned(16))) uint8_t bw[2048 + 16];
+    LzSeqLds ring;   // output ring of the sequence executor (sb_lz4.h LzSeqExec)
 };
+constexpr uint32_t ZBW = 2048;
 
 #define ZFAIL(code)         \
     do {                    \
@@ -358,6 +365,7 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         if (fcs_bytes == 2) fcs += 256;
         ip += fcs_bytes;
     }
+    LzSeqExec ex(wk->ring, dst);   // sequences run through an LDS output ring; everything else writes HBM directly
     for (;;) {  // blocks
         if (n - ip < 3) ZERR(9);
         const uint32_t bh = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
@@ -367,14 +375,16 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         const uint32_t bsize = bh >> 3;
         if (btype == 0) {
             if (n - ip < bsize || out_len - op < bsize) ZERR(10);
-            for (uint32_t i = lane; i < bsize; i += 64) dst[op + i] = src[ip + i];
+            wave_copy_g2g(dst + op, src + ip, bsize);
             ip += bsize;
             op += bsize;
+            ex.restart(op);
         } else if (btype == 1) {
             if (n - ip < 1 || out_len - op < bsize) ZERR(11);
             const uint8_t v = src[ip++];
             for (uint32_t i = lane; i < bsize; i += 64) dst[op + i] = v;
             op += bsize;
+            ex.restart(op);
         } else if (btype == 2) {
             if (bsize > 128 * 1024 || n - ip < bsize) ZERR(12);
             const uint8_t* bs = src + ip;
@@ -510,28 +520,48 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                 // lane 0 keeps the bit reader and the three FSE states; batches of 64 sequences
                 int64_t bitpos = (int64_t)(sn_ - 1) * 8 + (31 - __clz((int)sb_[sn_ - 1]));
                 uint32_t sl = 0, so = 0, sm = 0;
+                // the stream is read through an LDS window: `wp` points at the window so that wp[x] == sb_[x] for the bytes in it
+                auto refill_window = [&](int64_t bp_) {
+                    const uint32_t hi_byte = (uint32_t)min((int64_t)sn_, (bp_ >> 3) + 9);
+                    const uint32_t lo_byte = hi_byte > ZBW ? (hi_byte - ZBW) & ~15u : 0u;
+                    wsync();
+                    for (uint32_t k = lane * 16; k < ZBW + 16 && lo_byte + k < sn_; k += 64 * 16)
+                        for (uint32_t b = 0; b < 16 && lo_byte + k + b < sn_; b++) wk->bw[k + b] = sb_[lo_byte + k + b];
+                    if (lane == 0) wk->bw_lo = lo_byte;
+                    wsync();
+                };
+                refill_window(bitpos);
                 if (lane == 0) {
-                    sl = z_peek(sb_, bitpos, (int)wk->ll_log);
+                    const uint8_t* wp = wk->bw - wk->bw_lo;
+                    sl = z_peek(wp, bitpos, (int)wk->ll_log);
                     bitpos -= wk->ll_log;
-                    so = z_peek(sb_, bitpos, (int)wk->of_log);
+                    so = z_peek(wp, bitpos, (int)wk->of_log);
                     bitpos -= wk->of_log;
-                    sm = z_peek(sb_, bitpos, (int)wk->ml_log);
+                    sm = z_peek(wp, bitpos, (int)wk->ml_log);
                     bitpos -= wk->ml_log;
                 }
                 for (uint32_t done = 0; done < nseq; done += 64) {
                     const uint32_t nb = min(64u, nseq - done);
+                    {   // a batch reads at most 64 * (16 + 16 + 32 + 27) bits = 728 bytes below the current position
+                        const int64_t bp_now = __shfl(bitpos, 0, 64);
+                        const int64_t need_lo = (bp_now >> 3) - 760;
+                        if (need_lo < (int64_t)wk->bw_lo && wk->bw_lo > 0) refill_window(bp_now);
+                    }
                     if (lane == 0) {
+                        const uint8_t* wp = wk->bw - wk->bw_lo;
+                        const int64_t wbits = (int64_t)wk->bw_lo * 8;   // bits below the window read as stream bits via the shifted base
+                        (void)wbits;
                         for (uint32_t k = 0; k < nb; k++) {
                             const uint8_t ofc = wk->of[so].symbol, mlc = wk->ml[sm].symbol, llc = wk->ll[sl].symbol;
                             if (ofc > 31 || mlc > 52 || llc > 35) {
                                 wk->err = 27;
                                 break;
                             }
-                            const uint64_t ofv = ((uint64_t)1 << ofc) + z_peek(sb_, bitpos, ofc);
+                            const uint64_t ofv = ((uint64_t)1 << ofc) + z_peek(wp, bitpos, ofc);
                             bitpos -= ofc;
-                            const uint32_t mlen = Z_ML_BASE[mlc] + z_peek(sb_, bitpos, Z_ML_BITS[mlc]);
+                            const uint32_t mlen = Z_ML_BASE[mlc] + z_peek(wp, bitpos, Z_ML_BITS[mlc]);
                             bitpos -= Z_ML_BITS[mlc];
-                            const uint32_t llen = Z_LL_BASE[llc] + z_peek(sb_, bitpos, Z_LL_BITS[llc]);
+                            const uint32_t llen = Z_LL_BASE[llc] + z_peek(wp, bitpos, Z_LL_BITS[llc]);
                             bitpos -= Z_LL_BITS[llc];
                             uint32_t offset;
                             if (ofv > 3) {
@@ -557,11 +587,11 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                             }
                             if (done + k + 1 < nseq) {
                                 const uint32_t n1 = wk->ll[sl].nbits, n2 = wk->ml[sm].nbits, n3 = wk->of[so].nbits;
-                                sl = wk->ll[sl].base + z_peek(sb_, bitpos, (int)n1);
+                                sl = wk->ll[sl].base + z_peek(wp, bitpos, (int)n1);
                                 bitpos -= n1;
-                                sm = wk->ml[sm].base + z_peek(sb_, bitpos, (int)n2);
+                                sm = wk->ml[sm].base + z_peek(wp, bitpos, (int)n2);
                                 bitpos -= n2;
-                                so = wk->of[so].base + z_peek(sb_, bitpos, (int)n3);
+                                so = wk->of[so].base + z_peek(wp, bitpos, (int)n3);
                                 bitpos -= n3;
                             }
                             wk->seq[k].ll = llen;
@@ -572,27 +602,28 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                     }
                     wsync();
                     if (wk->err) return 0;
-                    // execute the batch: copies spread over the lanes, sequences in order
-                    for (uint32_t k = 0; k < nb; k++) {
-                        const uint32_t llen = wk->seq[k].ll, mlen = wk->seq[k].ml, off = wk->seq[k].off;
-                        if (lit_pos + llen > regen || out_len - op < llen + mlen || off > op + llen) ZERR(30);
-                        for (uint32_t i = lane; i < llen; i += 64) dst[op + i] = litp[lit_pos + i];
-                        op += llen;
-                        lit_pos += llen;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_s_waitcnt(0);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        const uint8_t* hist = dst + op - off;
-                        for (uint32_t i = lane; i < mlen; i += 64) dst[op + i] = hist[off >= mlen ? i : i % off];
-                        op += mlen;
+                    // execute the batch through the LDS output ring (sb_lz4.h LzSeqExec): lane k holds sequence k
+                    {
+                        const bool have = (uint32_t)lane < nb;
+                        const uint32_t llen = have ? wk->seq[lane].ll : 0u, mlen = have ? wk->seq[lane].ml : 0u;
+                        const uint32_t off = have ? wk->seq[lane].off : 1u;
+                        const uint32_t lsum = wave_scan_dpp(llen), osum = wave_scan_dpp(llen + mlen);
+                        const bool bad = have && ((uint64_t)lit_pos + lsum > regen || (uint64_t)op + osum > out_len || off == 0 ||
+                                                  off > op + osum - mlen);
+                        if (__ballot(bad)) ZERR(30);
+                        const uint32_t lit_total = rdlane(lsum, 63);
+                        op += ex.run(nb, llen, mlen, off, litp + lit_pos, op);
+                        lit_pos += lit_total;
                     }
                     wsync();
                 }
             }
             const uint32_t rest = regen - lit_pos;
             if (out_len - op < rest) ZERR(31);
+            ex.finish(op);
             for (uint32_t i = lane; i < rest; i += 64) dst[op + i] = litp[lit_pos + i];
             op += rest;
+            ex.restart(op);
             ip += bsize;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);

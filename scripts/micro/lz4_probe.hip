@@ -12,6 +12,7 @@
 __device__ unsigned long long g_prof[32];
 #include "sb_lz4.h"
 #include "sb_zstd_enc.h"
+#include "sb_zstd.h"
 using namespace sb;
 
 __global__ void __launch_bounds__(64) k_enc(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t* sizes) {
@@ -28,6 +29,12 @@ __global__ void __launch_bounds__(64) k_zenc(const uint8_t* src, uint32_t n, uin
     __shared__ ZEncLds lds;
     const uint32_t sz = zstd_compress_wave(src, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK));
     if (threadIdx.x == 0) sizes[blockIdx.x] = sz;
+}
+__global__ void __launch_bounds__(64) k_zdec(const uint8_t* comp, uint32_t cap, const uint32_t* sizes, uint8_t* out, uint32_t n, uint32_t* errs, uint8_t* zlit) {
+    __shared__ ZWork wk;
+    const uint32_t got = zstd_inflate_wave(comp + (size_t)blockIdx.x * cap, sizes[blockIdx.x], out + (size_t)blockIdx.x * ((n + 255) & ~255u), n, &wk,
+                                           zlit + (size_t)blockIdx.x * (128 * 1024 + 64));
+    if (threadIdx.x == 0) errs[blockIdx.x] = wk.err ? (uint32_t)wk.err : (got == n ? 0u : 999u);
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 static const char* ENC[] = {"fill", "probe+cand+ext", "select", "emit", "flush_out", "last", "", ""};
@@ -100,6 +107,30 @@ int main(int argc, char** argv) {
                 for (int i = 8; i < 15; i++) tot += prof[i];
                 for (int i = 8; i < 15; i++) printf("   %-16s %12llu ticks %5.1f %%\n", ZN[i], prof[i], 100.0 * prof[i] / (tot ? tot : 1));
                 printf("   sequences %llu, literals %llu\n", prof[16], prof[17]);
+            }
+        }
+        uint8_t* d_zlit;
+        CK(hipMalloc(&d_zlit, (size_t)(128 * 1024 + 64) * blocks));
+        static const char* DN[] = {"rest", "literals", "seq tables", "seq decode", "seq execute"};
+        for (int rep = 0; rep < 2; rep++) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof zero));
+            CK(hipMemset(d_out, 0xEE, (size_t)ostride * blocks));
+            hipEventRecord(e0);
+            k_zdec<<<blocks, 64>>>(d_z, cap, d_zs, d_out, n, d_errs, d_zlit);
+            hipEventRecord(e1);
+            CK(hipDeviceSynchronize());
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            CK(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof prof));
+            if (rep) {
+                std::vector<uint8_t> out(n);
+                uint32_t err;
+                CK(hipMemcpy(&err, d_errs, 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(out.data(), d_out, n, hipMemcpyDeviceToHost));
+                printf("zstd decode: err %u, %s, %.3f ms (%.1f MB/s per wave)\n", err, memcmp(out.data(), in.data(), n) ? "MISMATCH" : "round trip ok", ms, n / ms / 1e3);
+                unsigned long long tot = 0;
+                for (int i = 19; i < 24; i++) tot += prof[i];
+                for (int i = 19; i < 24; i++) printf("   %-16s %12llu ticks %5.1f %%\n", DN[i - 19], prof[i], 100.0 * prof[i] / (tot ? tot : 1));
             }
         }
     }

@@ -37,6 +37,8 @@ struct ZWork {  // per-wave LDS workspace (~12 KB)
     uint32_t bw_lo;
     __attribute__((aligned(16))) uint8_t bw[2048 + 16];
     LzSeqLds ring;   // output ring of the sequence executor (sb_lz4.h LzSeqExec)
+    uint32_t t_llbase[36], t_mlbase[53];   // baseline / extra-bit tables (copies of the __constant__ ones: the serial
+    uint8_t t_llbits[36], t_mlbits[53];    // sequence loop reads them with LDS latency, not a scalar-cache miss each)
 };
 constexpr uint32_t ZBW = 2048;
 
@@ -243,15 +245,47 @@ __device__ inline uint32_t z_huf_read(ZWork* wk, const uint8_t* src, uint32_t n)
     return used;
 }
 
-// one Huffman stream (executed by one lane); returns false on error
+// one Huffman stream (executed by one lane); returns false on error.  The stream is read backwards through a 128-bit
+// register window refilled with one unaligned 16-byte load every ~10 symbols (a byte-wise peek per symbol costs an HBM /
+// L2 round trip per symbol).
 __device__ inline bool z_huf_stream(const ZWork* wk, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out) {
     if (n == 0 || src[n - 1] == 0) return false;
     int64_t bitpos = (int64_t)(n - 1) * 8 + (31 - __clz((int)src[n - 1]));
     const int mb = (int)wk->huf_bits;
+    if (n < 16) {   // short stream: the byte-wise reader
+        for (uint32_t i = 0; i < out; i++) {
+            const uint32_t idx = z_peek(src, bitpos, mb);
+            dst[i] = wk->hsym[idx];
+            bitpos -= wk->hlen[idx];
+        }
+        return bitpos == 0;
+    }
+    int64_t wbase = -1;          // bit index of the window's lowest bit (a multiple of 8); -1 = nothing loaded
+    uint64_t lo = 0, hi = 0;
     for (uint32_t i = 0; i < out; i++) {
-        const uint32_t idx = z_peek(src, bitpos, mb);
+        int64_t from = bitpos - mb;                 // lowest bit of the peek (may be < 0 at the very start of the stream)
+        const int64_t need = from < 0 ? 0 : from;
+        if (wbase < 0 || need < wbase) {
+            int64_t b = (bitpos >> 3) - 15;          // window = bytes [b, b + 16): its top reaches the current position
+            if (b < 0) b = 0;
+            if (b > (int64_t)n - 16) b = (int64_t)n - 16;
+            const u32x4 v = ldu128(src + b);
+            lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            wbase = b * 8;
+        }
+        uint32_t idx;
+        if (from >= 0) {
+            const uint32_t rel = (uint32_t)(from - wbase);
+            const uint64_t w = rel >= 64 ? hi >> (rel - 64) : (rel ? (lo >> rel) | (hi << (64 - rel)) : lo);
+            idx = (uint32_t)w & ((1u << mb) - 1);
+        } else {                                     // fewer than mb bits left: the missing low bits read as 0
+            const uint32_t avail = (uint32_t)bitpos;
+            idx = avail ? (((uint32_t)lo & ((1u << avail) - 1)) << (uint32_t)(-from)) : 0u;   // (wbase == 0 here)
+        }
         dst[i] = wk->hsym[idx];
         bitpos -= wk->hlen[idx];
+        if (bitpos < 0) return false;
     }
     return bitpos == 0;
 }
@@ -322,8 +356,17 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         wk->rep[1] = 4;
         wk->rep[2] = 8;
     }
+    for (int i = lane; i < 53; i += 64) {
+        wk->t_mlbase[i] = Z_ML_BASE[i];
+        wk->t_mlbits[i] = Z_ML_BITS[i];
+        if (i < 36) {
+            wk->t_llbase[i] = Z_LL_BASE[i];
+            wk->t_llbits[i] = Z_LL_BITS[i];
+        }
+    }
     wsync();
     uint32_t ip = 0, op = 0;
+    LZP_BEGIN
 #define ZERR(c)                        \
     do {                               \
         if (lane == 0) wk->err = (c);  \
@@ -492,6 +535,7 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                 }
             }
             uint32_t lit_pos = 0;
+            LZP(20);
             if (nseq > 0) {
                 if (lane == 0) {
                     const uint8_t modes = bs[bp];
@@ -531,6 +575,7 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                     wsync();
                 };
                 refill_window(bitpos);
+                LZP(21);
                 if (lane == 0) {
                     const uint8_t* wp = wk->bw - wk->bw_lo;
                     sl = z_peek(wp, bitpos, (int)wk->ll_log);
@@ -551,56 +596,87 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                         const uint8_t* wp = wk->bw - wk->bw_lo;
                         const int64_t wbits = (int64_t)wk->bw_lo * 8;   // bits below the window read as stream bits via the shifted base
                         (void)wbits;
+                        uint32_t r0 = wk->rep[0], r1 = wk->rep[1], r2 = wk->rep[2];
+                        const uint32_t* w32 = (const uint32_t*)wk->bw;
                         for (uint32_t k = 0; k < nb; k++) {
-                            const uint8_t ofc = wk->of[so].symbol, mlc = wk->ml[sm].symbol, llc = wk->ll[sl].symbol;
+                            // round trip 1: the three FSE entries of the current states + 160 bits of the stream below bitpos
+                            const uint32_t e_of = *(const uint32_t*)&wk->of[so], e_ml = *(const uint32_t*)&wk->ml[sm], e_ll = *(const uint32_t*)&wk->ll[sl];
+                            // the 64 stream bits below bitpos, top aligned (bit 63 = stream bit bitpos - 1): three aligned dwords of
+                            // the LDS window + a funnel shift; a take() is then two shifts
+                            auto load_top = [&]() -> uint64_t {
+                                const int64_t lo = bitpos - 64;
+                                const int64_t rel = (lo < 0 ? 0 : lo) - (int64_t)wk->bw_lo * 8;
+                                if (rel < 0) {           // (malformed stream / stale window: never on a valid one)
+                                    wk->err = 29;
+                                    return 0ull;
+                                }
+                                const uint32_t idx = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31;
+                                const uint32_t d0 = w32[idx], d1 = w32[idx + 1], d2 = w32[idx + 2];
+                                uint64_t v = (((uint64_t)d1 << 32) | d0) >> sh;
+                                if (sh) v |= (uint64_t)d2 << (64 - sh);
+                                if (lo < 0) v = bitpos > 0 ? v << (uint32_t)(-lo) : 0ull;   // fewer than 64 bits left: low bits read as 0
+                                return v;
+                            };
+                            uint64_t C = load_top();
+                            auto take = [&](uint32_t nbits) -> uint32_t {
+                                if (nbits == 0) return 0u;
+                                const uint32_t v = (uint32_t)(C >> (64 - nbits));
+                                C <<= nbits;
+                                bitpos -= nbits;
+                                return v;
+                            };
+                            const uint32_t ofc = e_of & 255, mlc = e_ml & 255, llc = e_ll & 255;
                             if (ofc > 31 || mlc > 52 || llc > 35) {
                                 wk->err = 27;
                                 break;
                             }
-                            const uint64_t ofv = ((uint64_t)1 << ofc) + z_peek(wp, bitpos, ofc);
-                            bitpos -= ofc;
-                            const uint32_t mlen = Z_ML_BASE[mlc] + z_peek(wp, bitpos, Z_ML_BITS[mlc]);
-                            bitpos -= Z_ML_BITS[mlc];
-                            const uint32_t llen = Z_LL_BASE[llc] + z_peek(wp, bitpos, Z_LL_BITS[llc]);
-                            bitpos -= Z_LL_BITS[llc];
+                            // round trip 2: baselines and extra-bit counts of the two length codes
+                            const uint32_t mlbits = wk->t_mlbits[mlc], llbits = wk->t_llbits[llc];
+                            const uint32_t mlbase = wk->t_mlbase[mlc], llbase = wk->t_llbase[llc];
+                            const uint64_t ofv = ((uint64_t)1 << ofc) + take(ofc);
+                            const uint32_t mlen = mlbase + take(mlbits);
+                            const uint32_t llen = llbase + take(llbits);
                             uint32_t offset;
                             if (ofv > 3) {
                                 offset = (uint32_t)(ofv - 3);
-                                wk->rep[2] = wk->rep[1];
-                                wk->rep[1] = wk->rep[0];
-                                wk->rep[0] = offset;
+                                r2 = r1;
+                                r1 = r0;
+                                r0 = offset;
                             } else {
                                 uint32_t idx = (uint32_t)ofv - 1;
                                 if (llen == 0) idx++;
                                 if (idx == 0) {
-                                    offset = wk->rep[0];
+                                    offset = r0;
                                 } else {
-                                    offset = idx < 3 ? wk->rep[idx] : wk->rep[0] - 1;
+                                    offset = idx == 1 ? r1 : idx == 2 ? r2 : r0 - 1;
                                     if (offset == 0) {
                                         wk->err = 28;
                                         break;
                                     }
-                                    if (idx > 1) wk->rep[2] = wk->rep[1];
-                                    wk->rep[1] = wk->rep[0];
-                                    wk->rep[0] = offset;
+                                    if (idx > 1) r2 = r1;
+                                    r1 = r0;
+                                    r0 = offset;
                                 }
                             }
-                            if (done + k + 1 < nseq) {
-                                const uint32_t n1 = wk->ll[sl].nbits, n2 = wk->ml[sm].nbits, n3 = wk->of[so].nbits;
-                                sl = wk->ll[sl].base + z_peek(wp, bitpos, (int)n1);
-                                bitpos -= n1;
-                                sm = wk->ml[sm].base + z_peek(wp, bitpos, (int)n2);
-                                bitpos -= n2;
-                                so = wk->of[so].base + z_peek(wp, bitpos, (int)n3);
-                                bitpos -= n3;
+                            if (done + k + 1 < nseq) {   // new states: LL, ML, OF (entry = symbol | nbits << 8 | base << 16)
+                                C = load_top();          // (offset + length bits may have used up to 63 of the 64)
+                                sl = (e_ll >> 16) + take((e_ll >> 8) & 255);
+                                sm = (e_ml >> 16) + take((e_ml >> 8) & 255);
+                                so = (e_of >> 16) + take((e_of >> 8) & 255);
                             }
+                            if (bitpos < 0) wk->err = 29;
+                            if (wk->err) break;
                             wk->seq[k].ll = llen;
                             wk->seq[k].ml = mlen;
                             wk->seq[k].off = offset;
                         }
+                        wk->rep[0] = r0;
+                        wk->rep[1] = r1;
+                        wk->rep[2] = r2;
                         if (done + nb == nseq && !wk->err && bitpos != 0) wk->err = 29;
                     }
                     wsync();
+                    LZP(22);
                     if (wk->err) return 0;
                     // execute the batch through the LDS output ring (sb_lz4.h LzSeqExec): lane k holds sequence k
                     {
@@ -614,6 +690,7 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                         const uint32_t lit_total = rdlane(lsum, 63);
                         op += ex.run(nb, llen, mlen, off, litp + lit_pos, op);
                         lit_pos += lit_total;
+                        LZP(23);
                     }
                     wsync();
                 }
@@ -633,6 +710,8 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         }
         if (last) break;
     }
+    LZP(19);
+    LZP_END;
     if (checksum) ip += 4;
     if (fcs_bytes && fcs != op) ZERR(33);
     if (op != out_len) ZERR(34);

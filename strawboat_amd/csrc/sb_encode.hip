@@ -21,6 +21,7 @@
 // Pages whose size is known up front (None / OneValue of fixed-width types) are written straight
 // to their final position ("direct"), everything else goes through a worst-case sized slot.
 #include <cstring>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -3676,12 +3677,16 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
 
 // pages whose codec is LZ4 (CommonCompression::Lz4 as the default, or chosen by the selector):
 // def levels + hdr9 + one LZ4 block (binary: offsets block + values block), one workgroup per page
+// Two instances: ZSTD = false handles LZ4 / Snappy pages (and Zstd pages without encoder scratch: stored frames), ZSTD =
+// true the pages that go through the Zstd encoder — its Huffman / FSE stages need ~160 VGPRs, which would cut the
+// LZ4 instance from 6 to 3 workgroups per CU.
+template <bool ZSTD>
 __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
-    // one LDS area: the 16 KiB the Zstd / Snappy / exact-LZ4 paths use, or the parallel LZ4 matcher's table + 16 KiB ring
+    // one LDS area: the 16 KiB the stored-Zstd / Snappy / exact-LZ4 paths use, or the matcher's table + ring (+ Zstd entropy tables)
     __shared__ union {
         uint32_t tab[4096];
         Lz4EncLds<12, 13> lz;
-        ZEncLds ze;
+        typename std::conditional<ZSTD, ZEncLds, uint32_t>::type ze;
     } sh;
     uint32_t* const tab = sh.tab;
     __shared__ uint32_t s_sz;
@@ -3690,6 +3695,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     const EncPage p = get_page(a, page);
     const int32_t bc = codec_of(a, p, page);
     if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD && bc != SB_CODEC_SNAPPY) return;
+    if (ZSTD != (bc == SB_CODEC_ZSTD && p.zst_off != ~0ull)) return;   // the other instance's page
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     uint8_t* slot = page_slot(a, c, p);
@@ -3705,13 +3711,14 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     const bool is_bin = c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY;
     auto compress = [&](const uint8_t* src, uint32_t n, uint8_t* dst) -> uint32_t {
         __syncthreads();
-        if (bc == SB_CODEC_ZSTD) {
-            if (p.zst_off == ~0ull) return zstd_store_frame_wg(src, n, dst, tab);
+        if constexpr (ZSTD) {
             uint32_t zs = 0;
             if (threadIdx.x < 64) zs = zstd_compress_wave(src, n, dst, sh.ze, a.scratch + p.zst_off);
             if (threadIdx.x == 0) s_sz = zs;
             __syncthreads();
             return s_sz;
+        } else {
+            if (bc == SB_CODEC_ZSTD) return zstd_store_frame_wg(src, n, dst, tab);
         }
         if (bc == SB_CODEC_SNAPPY) return snappy_store_wg(src, n, dst);
         uint32_t sz = 0;
@@ -4372,7 +4379,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
         if (nested ? (wave_adaptive ? basic_comp : (wave_codec >= 1 && wave_codec <= 3)) : any_lz4) {
             KScope k(ctx, K_ENC_LZ4);
-            k_enc_emit_lz4<<<(uint32_t)P, WG, 0, s>>>(aa);
+            k_enc_emit_lz4<false><<<(uint32_t)P, WG, 0, s>>>(aa);
+            if (dc == SB_CODEC_ZSTD || wave_codec == SB_CODEC_ZSTD) {   // (virtual pages inherit their page's encoder scratch)
+                KScope kz(ctx, "k_enc_emit_lz4<true>");
+                k_enc_emit_lz4<true><<<(uint32_t)P, WG, 0, s>>>(aa);
+            }
         }
         if (nested || any_pages) {
             // one kernel instance per (kind, codec) that can occur in the batch

@@ -112,7 +112,17 @@ struct EncodeArgs {
     uint32_t page_base;   // first table entry this launch works on (0: pages, n_pages: virtual pages)
     int32_t nested_force; // force_index_codec: the codec forced on nested blocks (-1: none)
     uint32_t flags;       // sb_write_options.flags (SB_WRITE_LZ4_EXACT)
+    // LZ4 blocks longer than one chunk are compressed chunk by chunk, one wave each (k_enc_lz4_plan / _chunks / _stitch)
+    struct LzChunkPlan* lzc_plan;   // per page (nullptr: every LZ4 page goes through k_enc_emit_lz4)
+    struct LzChunkDesc* lzc_list;   // the chunks of this call, in the order the pages reserved them
+    uint32_t* lzc_count;
+    uint8_t* lzc_pool;              // one slot of LZC_SLOT bytes per chunk
+    uint32_t lzc_cap;
 };
+constexpr uint32_t LZC_CH = 65536;                                         // chunk bytes (a multiple of 1024)
+constexpr uint32_t LZC_SLOT = (16 + LZC_CH + LZC_CH / 255 + 16 + 15) / 16 * 16;   // u32 size | u32 tail anchor | 8 pad | sequences
+struct LzChunkPlan { uint32_t base, n_a, n_b, pad; };   // chunks [base, base + n_a) = first block, then n_b of a binary page's values block
+struct LzChunkDesc { uint32_t page, idx; };             // idx: chunk of its block; bit 31: the values block
 
 __device__ __forceinline__ EncPage get_page(const EncodeArgs& a, uint32_t i) {
     return i < a.n_pages ? a.pages[i] : a.vpages[i - a.n_pages];
@@ -2682,8 +2692,11 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
 
 // The same selection + speculative RLE with one raw run per lane (sb_select_runs.h); pages whose runs are
 // too short are left to k_enc_select_rle (CODEC_PENDING).
+#ifndef SB_RUNS_OCC
+#define SB_RUNS_OCC 4
+#endif
 template <int KIND, int FK>
-__global__ void __launch_bounds__(WG, 4) k_enc_select_runs(EncodeArgs a) {
+__global__ void __launch_bounds__(WG, SB_RUNS_OCC) k_enc_select_runs(EncodeArgs a) {
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
     // the sample area and the misc words are one pool: the run list and the run values of the streaming loop use
     // both (they are free until decide_prim runs)
@@ -3680,12 +3693,53 @@ __global__ void __launch_bounds__(WG) k_enc_freq_finish(EncodeArgs a) {
 // Two instances: ZSTD = false handles LZ4 / Snappy pages (and Zstd pages without encoder scratch: stored frames), ZSTD =
 // true the pages that go through the Zstd encoder — its Huffman / FSE stages need ~160 VGPRs, which would cut the
 // LZ4 instance from 6 to 3 workgroups per CU.
+#ifndef SB_LZ4_HB
+#define SB_LZ4_HB 12
+#endif
+// the block(s) a Basic page compresses: bitmap bytes / re-based offsets / values (first block), a binary page's value bytes
+struct LzBlocks {
+    const uint8_t *src_a, *src_b;
+    uint32_t n_a, n_b;
+    uint64_t first;     // binary: offsets[row0]
+    bool stage_a;       // the first block is built in the page's staging area (p.aux_off)
+};
+__device__ __forceinline__ LzBlocks lz4_page_blocks(const EncodeArgs& a, const EncCol& c, const EncPage& p) {
+    LzBlocks b{nullptr, nullptr, 0, 0, 0, false};
+    const uint64_t N = p.rows;
+    uint8_t* stage = a.scratch + p.aux_off;
+    if (c.ptype == SB_TYPE_BOOLEAN) {
+        const uint64_t boff = c.values_bit_offset + p.row0;
+        b.stage_a = (boff & 7) != 0;
+        b.src_a = b.stage_a ? stage : c.values + (boff >> 3);
+        b.n_a = (uint32_t)((N + 7) / 8);
+    } else if (c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY) {
+        const uint32_t ow = c.width;
+        const uint8_t* offs = c.offsets + p.row0 * ow;
+        b.first = ow == 4 ? (uint64_t)ldu32(offs) : ldu64(offs);
+        const uint64_t last = ow == 4 ? (uint64_t)ldu32(offs + N * 4) : ldu64(offs + N * 8);
+        b.stage_a = true;
+        b.src_a = stage;
+        b.n_a = (uint32_t)((N + 1) * ow);
+        b.src_b = c.values + b.first;
+        b.n_b = (uint32_t)(last - b.first);
+    } else {
+        b.src_a = c.values + p.row0 * c.width;
+        b.n_a = (uint32_t)(N * c.width);
+    }
+    return b;
+}
+// chunk by chunk (k_enc_lz4_plan / _chunks / _stitch) or as one block by one wave (k_enc_emit_lz4)?  A pure function of
+// the page, so that every kernel decides alike.
+__device__ __forceinline__ bool lz4_page_chunked(const EncodeArgs& a, int32_t bc, uint32_t page, const LzBlocks& b) {
+    return a.lzc_plan && page < a.n_pages && bc == SB_CODEC_LZ4 && !(a.flags & SB_WRITE_LZ4_EXACT) && max(b.n_a, b.n_b) > LZC_CH;
+}
+
 template <bool ZSTD>
 __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     // one LDS area: the 16 KiB the stored-Zstd / Snappy / exact-LZ4 paths use, or the matcher's table + ring (+ Zstd entropy tables)
     __shared__ union {
         uint32_t tab[4096];
-        Lz4EncLds<12, 13> lz;
+        Lz4EncLds<SB_LZ4_HB, 13> lz;
         typename std::conditional<ZSTD, ZEncLds, uint32_t>::type ze;
     } sh;
     uint32_t* const tab = sh.tab;
@@ -3698,6 +3752,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     if (ZSTD != (bc == SB_CODEC_ZSTD && p.zst_off != ~0ull)) return;   // the other instance's page
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
+    if (!ZSTD && a.lzc_plan && lz4_page_chunked(a, bc, page, lz4_page_blocks(a, c, p))) return;   // compressed chunk by chunk
     uint8_t* slot = page_slot(a, c, p);
     const uint64_t N = p.rows;
     uint64_t pos = 0;
@@ -3723,7 +3778,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
         if (bc == SB_CODEC_SNAPPY) return snappy_store_wg(src, n, dst);
         uint32_t sz = 0;
         if (threadIdx.x < 64)
-            sz = (a.flags & SB_WRITE_LZ4_EXACT) ? lz4_compress_wave(src, n, dst, tab) : lz4_compress_wave_fast<12, 13>(src, n, dst, sh.lz);
+            sz = (a.flags & SB_WRITE_LZ4_EXACT) ? lz4_compress_wave(src, n, dst, tab) : lz4_compress_wave_fast<SB_LZ4_HB, 13>(src, n, dst, sh.lz);
         if (threadIdx.x == 0) s_sz = sz;
         __syncthreads();
         return s_sz;
@@ -3771,6 +3826,200 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     }
     if (threadIdx.x == 0) {
         EncOut o{length, 0, slot, (uint32_t)bc, 0};
+        a.outs[page] = o;
+    }
+}
+
+// ---- LZ4 blocks of more than one chunk (64 KiB): a page is one LZ4 block per buffer in the format, and one wave per block
+// leaves a 1 MiB page to a single latency-bound wave while the rest of the chip idles.  The block is cut into chunks
+// compressed independently (no match crosses a chunk border, so the output is a valid block whatever the order), one
+// wave per chunk, into a pool slot each; the stitch pass joins them: a chunk's trailing literals — which no sequence
+// holds — become part of the next chunk's first sequence, whose token and length bytes are rewritten.
+// plan: def levels + staged first block + the chunk list (one workgroup per page).
+__global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
+    __shared__ uint32_t s_base;
+    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] == 0) return;
+    const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
+    const EncPage p = get_page(a, page);
+    const int32_t bc = codec_of(a, p, page);
+    if (bc != SB_CODEC_LZ4) return;
+    const EncCol c = get_col(a, p.col);
+    if (c.ptype == SB_TYPE_NULL) return;
+    const LzBlocks b = lz4_page_blocks(a, c, p);
+    if (!lz4_page_chunked(a, bc, page, b)) return;
+    const uint64_t N = p.rows;
+    if (c.nullable) {
+        uint8_t* bits = def_header(page_slot(a, c, p), N);
+        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
+    }
+    uint8_t* stage = a.scratch + p.aux_off;
+    if (c.ptype == SB_TYPE_BOOLEAN) {
+        if (b.stage_a) {   // bitmap re-packed from bit 0 (boolean/mod.rs:44-54)
+            const uint64_t boff = c.values_bit_offset + p.row0, total_bits = c.values_bit_offset + c.rows;
+            for (uint64_t i = threadIdx.x; i < b.n_a; i += WG) {
+                uint32_t w = bits32(c.values, boff + i * 8, total_bits);
+                const uint64_t nb = min((uint64_t)8, N - i * 8);
+                if (nb < 8) w &= (1u << nb) - 1;
+                stage[i] = (uint8_t)w;
+            }
+        }
+    } else if (b.src_b) {  // offsets re-based to 0 (binary/mod.rs:45-55)
+        const uint32_t ow = c.width;
+        const uint8_t* offs = c.offsets + p.row0 * ow;
+        for (uint64_t i = threadIdx.x; i <= N; i += WG) {
+            if (ow == 4)
+                stu32(stage + i * 4, (uint32_t)(ldu32(offs + i * 4) - b.first));
+            else
+                stu64(stage + i * 8, ldu64(offs + i * 8) - b.first);
+        }
+    }
+    const uint32_t na = (b.n_a + LZC_CH - 1) / LZC_CH, nb = (b.n_b + LZC_CH - 1) / LZC_CH;
+    if (threadIdx.x == 0) {
+        uint32_t base = atomicAdd(a.lzc_count, na + nb);
+        if (base + na + nb > a.lzc_cap) {   // (offsets that run past values_len)
+            raise(a.status, SB_ERR_INVALID, page, 560);
+            base = ~0u;
+        } else {
+            a.lzc_plan[page] = LzChunkPlan{base, na, nb, 0};
+        }
+        s_base = base;
+    }
+    __syncthreads();
+    if (s_base == ~0u) return;
+    for (uint32_t i = threadIdx.x; i < na + nb; i += WG) a.lzc_list[s_base + i] = LzChunkDesc{page, i < na ? i : (0x80000000u | (i - na))};
+}
+
+// chunks: one wave per chunk, sequences into the chunk's pool slot
+__global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
+    __shared__ Lz4EncLds<SB_LZ4_HB, 13> L;
+    const uint32_t total = min(*a.lzc_count, a.lzc_cap);
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        const LzChunkDesc d = a.lzc_list[i];
+        const EncPage p = get_page(a, d.page);
+        const EncCol c = get_col(a, p.col);
+        const LzBlocks b = lz4_page_blocks(a, c, p);
+        const bool second = d.idx >> 31;
+        const uint8_t* src = second ? b.src_b : b.src_a;
+        const uint32_t n = second ? b.n_b : b.n_a;
+        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * LZC_CH, c1 = min(n, c0 + LZC_CH);
+        uint8_t* slot = a.lzc_pool + (uint64_t)i * LZC_SLOT;
+        uint32_t anchor = c0;
+        wave_sync();
+        const uint32_t len = lz4_compress_range<SB_LZ4_HB, 13, true>(src, n, c0, c1, slot + 16, L, &anchor);
+        if (threadIdx.x == 0) {
+            stu32(slot, len);
+            stu32(slot + 4, anchor);
+        }
+    }
+}
+
+// joins the chunks [chunk0, chunk0 + nch) of the block src[0, n) at dst; returns the block size.  sh: 5 * WG + 8 words.
+__device__ uint32_t lz4_stitch_block(const EncodeArgs& a, const uint8_t* src, uint32_t n, uint32_t chunk0, uint32_t nch, uint8_t* dst,
+                                     uint32_t* sh) {
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t *s_off = sh, *s_cs = sh + WG, *s_ll = sh + 2 * WG, *s_e1 = sh + 3 * WG, *s_len = sh + 4 * WG, *s_w = sh + 5 * WG;
+    uint32_t run_base = 0;    // bytes of the block written by the chunks before this batch
+    uint32_t run_carry = 0;   // where the literals begin that no sequence holds yet
+    for (uint32_t b0 = 0; b0 < nch; b0 += WG) {
+        const uint32_t k = b0 + t;
+        const uint8_t* slot = a.lzc_pool + (uint64_t)(chunk0 + (k < nch ? k : 0)) * LZC_SLOT;
+        uint32_t len = 0, anchor = 0, ll = 0, e1 = 0;
+        if (k < nch) {
+            len = ldu32(slot);
+            anchor = ldu32(slot + 4);
+        }
+        if (len) {  // literal length of the chunk's first sequence
+            ll = slot[16] >> 4;
+            if (ll == 15)
+                for (;;) {
+                    const uint32_t x = slot[17 + e1];
+                    e1++;
+                    ll += x;
+                    if (x != 255) break;
+                }
+        }
+        // literals pending when chunk k begins start at the tail anchor of the last chunk before it that holds a sequence
+        uint32_t inc = len ? anchor : 0;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc = max(inc, o);
+        }
+        uint32_t exc = __shfl_up(inc, 1, 64);
+        if (lane == 0) exc = 0;
+        if (lane == 63) s_w[4 + w] = inc;
+        __syncthreads();
+        uint32_t cs = max(run_carry, exc);
+        for (uint32_t q = 0; q < WG / 64; q++)
+            if (q < w) cs = max(cs, s_w[4 + q]);
+        const uint32_t carry = len ? k * LZC_CH - cs : 0;
+        const uint32_t size = len ? (carry ? lz4_head_bytes(carry + ll) - 1 + carry + len - e1 : len) : 0;
+        const uint32_t isum = wave_scan_dpp(size);
+        if (lane == 63) s_w[w] = isum;
+        __syncthreads();
+        uint32_t at = run_base + isum - size;
+        for (uint32_t q = 0; q < WG / 64; q++)
+            if (q < w) at += s_w[q];
+        s_off[t] = at;
+        s_cs[t] = cs;
+        s_ll[t] = ll;
+        s_e1[t] = e1;
+        s_len[t] = len;
+        uint32_t tot = 0, bmax = 0;
+        for (uint32_t q = 0; q < WG / 64; q++) {
+            tot += s_w[q];
+            bmax = max(bmax, s_w[4 + q]);
+        }
+        __syncthreads();
+        run_base += tot;
+        run_carry = max(run_carry, bmax);
+        const uint32_t cnt = min((uint32_t)WG, nch - b0);
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t len_j = s_len[j];
+            if (!len_j) continue;
+            const uint8_t* sl = a.lzc_pool + (uint64_t)(chunk0 + b0 + j) * LZC_SLOT + 16;
+            uint8_t* d = dst + s_off[j];
+            const uint32_t carry_j = (b0 + j) * LZC_CH - s_cs[j];
+            if (!carry_j) {
+                wg_copy(d, sl, len_j);
+                continue;
+            }
+            const uint32_t ll_j = s_ll[j], e1_j = s_e1[j], nl = carry_j + ll_j, hb = lz4_head_bytes(nl);
+            if (t == 0) lz4_put_head(d, nl, sl[0] & 15u);
+            wg_copy(d + hb, src + s_cs[j], nl);
+            wg_copy(d + hb + nl, sl + 1 + e1_j + ll_j, len_j - 1 - e1_j - ll_j);
+        }
+        __syncthreads();
+    }
+    const uint32_t lit = n - run_carry, hb = lz4_head_bytes(lit);   // the literals-only last sequence
+    if (t == 0) lz4_put_head(dst + run_base, lit, 0);
+    wg_copy(dst + run_base + hb, src + run_carry, lit);
+    return run_base + hb + lit;
+}
+
+__global__ void __launch_bounds__(WG) k_enc_lz4_stitch(EncodeArgs a) {
+    __shared__ uint32_t sh[5 * WG + 8];
+    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] == 0) return;
+    const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
+    const LzChunkPlan pl = a.lzc_plan[page];
+    if (pl.n_a + pl.n_b == 0) return;
+    const EncPage p = get_page(a, page);
+    const EncCol c = get_col(a, p.col);
+    const LzBlocks b = lz4_page_blocks(a, c, p);
+    uint8_t* slot = page_slot(a, c, p);
+    const uint64_t N = p.rows;
+    const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
+    uint8_t* blk = slot + pos;
+    const uint32_t s1 = lz4_stitch_block(a, b.src_a, b.n_a, pl.base, pl.n_a, blk + 9, sh);
+    if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
+    uint64_t length = pos + 9 + s1;
+    if (b.src_b) {
+        uint8_t* b2 = blk + 9 + s1;
+        const uint32_t s2 = lz4_stitch_block(a, b.src_b, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh);
+        if (threadIdx.x == 0) put_hdr9(b2, SB_CODEC_LZ4, s2, b.n_b);
+        length += 9 + s2;
+    }
+    if (threadIdx.x == 0) {
+        EncOut o{length, 0, slot, SB_CODEC_LZ4, 0};
         a.outs[page] = o;
     }
 }
@@ -4031,6 +4280,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
 
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
+    // LZ4 blocks of more than LZC_CH bytes are compressed chunk by chunk (flat pages, the matcher that is free to choose)
+    const bool lz_possible = !(opts->flags & SB_WRITE_LZ4_EXACT) &&
+                             (host_codec == SB_CODEC_LZ4 || (adaptive && opts->default_compression == SB_CODEC_LZ4));
+    uint64_t lz_cap = 0;
+    bool lz_any = false;
     for (uint64_t i = 0; i < n; i++) {
         sb_column_write& c = cols[i];
         if (c.physical_type < 0 || c.physical_type > SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "bad physical_type");
@@ -4058,7 +4312,27 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 for (uint64_t q = 0; q < np; q++) mx = std::max<uint64_t>(mx, c.page_rows[q]);
             max_tiles = std::max<uint64_t>(max_tiles, (mx + TILE_ROWS - 1) / TILE_ROWS);
         }
+        if (lz_possible && c.physical_type != SB_TYPE_NULL) {   // upper bound of the LZ4 chunks this column can ask for
+            const bool bin = enc_is_binary(c.physical_type);
+            const uint64_t w = enc_type_width(c.physical_type);
+            auto first_block = [&](uint64_t N) {
+                return c.physical_type == SB_TYPE_BOOLEAN ? (N + 7) / 8 : bin ? (N + 1) * w : N * w;
+            };
+            for (uint64_t q = 0, r = 0; q < np; q++) {
+                const uint64_t N = c.page_rows ? c.page_rows[q] : std::min<uint64_t>(ps, c.rows - r);
+                r += N;
+                const uint64_t fb = first_block(N);
+                lz_cap += (fb + LZC_CH - 1) / LZC_CH;
+                lz_any |= fb > LZC_CH;
+            }
+            if (bin) {
+                lz_cap += c.values_len / LZC_CH + np + 1;
+                lz_any |= c.values_len > LZC_CH;
+            }
+        }
     }
+    if (!lz_any) lz_cap = 0;
+    if (lz_cap >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many LZ4 chunks in one call");
     if (P >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many pages in one call");
 
     // SB_MEM_HOST: the caller holds host Arrow buffers (the reference's shape); stage them over PCIe
@@ -4113,10 +4387,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     off = align_up(off + 2 * P * sizeof(int32_t), 64);
     const size_t o_freqcnt = off;
     off = align_up(off + 64 + 32 * sizeof(uint32_t), 64);  // freq_count | codec_counts[32]
+    const size_t o_lzplan = off;                             // (inside the region zeroed per call: count | per-page plans)
+    off = align_up(off + (lz_cap ? 64 + P * sizeof(LzChunkPlan) : 0), 64);
     const size_t o_vcols = off;
     off = align_up(off + (freq_possible ? P : 0) * sizeof(EncCol), 64);
     const size_t o_vpages = off;
     off = align_up(off + (freq_possible ? P : 0) * sizeof(EncPage), 64);
+    const size_t o_lzlist = off;
+    off = align_up(off + lz_cap * sizeof(LzChunkDesc), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
     StageSlot* slot = acquire_slot(ctx, upload_bytes + results_words * sizeof(uint64_t));
@@ -4275,6 +4553,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             max_chunks = std::max<uint64_t>(max_chunks, (cap + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
         }
     }
+    scratch_off = align_up(scratch_off, 16);
+    const size_t lz_pool_off = scratch_off;
+    scratch_off += (size_t)lz_cap * LZC_SLOT;
     if (!ensure(ctx, ctx->scratch, scratch_off + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(scratch) failed");
 
     uint8_t* tb = ctx->tables.p;
@@ -4300,6 +4581,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.page_base = 0;
     a.nested_force = opts->force_index_codec;
     a.flags = opts->flags;
+    a.lzc_plan = lz_cap ? (LzChunkPlan*)(tb + o_lzplan + 64) : nullptr;
+    a.lzc_count = (uint32_t*)(tb + o_lzplan);
+    a.lzc_list = (LzChunkDesc*)(tb + o_lzlist);
+    a.lzc_pool = ctx->scratch.p + lz_pool_off;
+    a.lzc_cap = (uint32_t)lz_cap;
     a.freq_count = (uint32_t*)(tb + o_freqcnt);
     a.codec_counts = (uint32_t*)(tb + o_freqcnt + 64);
     a.use_counts = 0;
@@ -4378,6 +4664,18 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             k_enc_emit_tiles<<<dim3((uint32_t)P, wave_adaptive ? 1u : (uint32_t)max_tiles), WG, 0, s>>>(aa, (uint32_t)max_tiles);
         }
         if (nested ? (wave_adaptive ? basic_comp : (wave_codec >= 1 && wave_codec <= 3)) : any_lz4) {
+            if (!nested && aa.lzc_plan) {   // blocks of more than one chunk: one wave per chunk, then joined
+                {
+                    KScope k(ctx, "k_enc_lz4_plan");
+                    k_enc_lz4_plan<<<(uint32_t)P, WG, 0, s>>>(aa);
+                }
+                {
+                    KScope k(ctx, "k_enc_lz4_chunks");
+                    k_enc_lz4_chunks<<<(uint32_t)std::min<uint64_t>(aa.lzc_cap, 1u << 20), 64, 0, s>>>(aa);
+                }
+                KScope k(ctx, "k_enc_lz4_stitch");
+                k_enc_lz4_stitch<<<(uint32_t)P, WG, 0, s>>>(aa);
+            }
             KScope k(ctx, K_ENC_LZ4);
             k_enc_emit_lz4<false><<<(uint32_t)P, WG, 0, s>>>(aa);
             if (dc == SB_CODEC_ZSTD || wave_codec == SB_CODEC_ZSTD) {   // (virtual pages inherit their page's encoder scratch)

@@ -670,6 +670,7 @@ struct LzMatcher {
     const uint8_t* src;
     uint32_t n;                            // bytes of the whole input
     uint32_t hi = 0;                       // input loaded into the ring up to here (multiple of 1024, or >= n)
+    uint32_t lo0 = 0;                      // lowest input position the ring ever held (chunks compressed on their own start late)
     uint32_t anchor = 0, base = 0, stride = 1;
     uint32_t mflimit = 0, matchlimit = 0;  // a match may start at positions <= mflimit and must end at or before matchlimit
     // results of next()
@@ -688,6 +689,18 @@ struct LzMatcher {
         stride = 1;
         mflimit = mfl;
         matchlimit = mtl;
+    }
+    // A chunk compressed by a wave of its own (c0 % 1024 == 0): the 5 KiB of input before it — what the ring of a wave
+    // that had compressed them would still hold — are loaded and entered into the table, so matches reach back over the
+    // chunk border as they do inside a chunk (the input is all there; only the OUTPUT of the chunks is independent).
+    __device__ void begin_alone(uint32_t c0, uint32_t mfl, uint32_t mtl) {
+        const uint32_t lane = threadIdx.x & 63;
+        hi = lo0 = c0 >= 5120 ? c0 - 5120 : 0;
+        begin_chunk(c0, mfl, mtl);
+        if (c0 == 0) return;
+        fill(c0 + 1024);
+        for (uint32_t x = lo0 + lane; x < c0; x += 64) L.tab[(rd4(x) * 2654435761u) >> (32 - HB)] = (uint16_t)(x & 0xFFFF);
+        wave_sync();
     }
     __device__ void advance() {
         anchor = covered;
@@ -729,7 +742,7 @@ struct LzMatcher {
         const uint32_t lane = threadIdx.x & 63;
         while (base <= mflimit) {
             fill(base + LZE_AHEAD);
-            const uint32_t lo_valid = hi > R ? hi - R : 0;   // positions below are no longer in the ring
+            const uint32_t lo_valid = max(hi > R ? hi - R : 0, lo0);   // positions below are not in the ring
             p = base + lane * stride;
             // a probe needs its LZE_CAP + 16 bytes of look-ahead in the ring (a step spread wider probes only its front part)
             const bool act = p <= mflimit && (p + LZE_CAP + 16 <= hi || hi >= n);
@@ -753,10 +766,10 @@ struct LzMatcher {
                 bool ok = false;
                 if (stride == 1) {   // the periods columnar data repeats with (positions of this very step are not in the table
                                      // yet, and the nearest candidate gives the longest runs): 8, 4, 2, 1 bytes back
-                    if (p >= 8 && t[0] == v4) { c = p - 8; ok = true; }
-                    else if (p >= 4 && t[1] == v4) { c = p - 4; ok = true; }
-                    else if (p >= 2 && ((t[1] >> 16) | (t[2] << 16)) == v4) { c = p - 2; ok = true; }
-                    else if (p >= 1 && ((t[1] >> 24) | (t[2] << 8)) == v4) { c = p - 1; ok = true; }
+                    if (p >= lo0 + 8 && t[0] == v4) { c = p - 8; ok = true; }
+                    else if (p >= lo0 + 4 && t[1] == v4) { c = p - 4; ok = true; }
+                    else if (p >= lo0 + 2 && ((t[1] >> 16) | (t[2] << 16)) == v4) { c = p - 2; ok = true; }
+                    else if (p >= lo0 + 1 && ((t[1] >> 24) | (t[2] << 8)) == v4) { c = p - 1; ok = true; }
                 }
                 if (!ok && e != 0xFFFF) {   // the last position with this hash (mod 64 Ki), if it is still in the ring
                     c = (p & ~0xFFFFu) | e;
@@ -860,9 +873,13 @@ struct LzMatcher {
     }
 };
 
-// Compress src[0, n) into dst (capacity >= lz4_bound(n)); executed by ONE wave64; returns the block size.
-template <int HB, int RB>
-__device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
+// The sequences of src[c0, c1) — a whole block (c0 = 0, c1 = n) or one chunk of it compressed on its own (ALONE: no
+// match reaches below c0 or beyond c1) — written to dst; executed by ONE wave64.  Returns their size; *tail_anchor =
+// where the literals begin that no sequence holds (they open the next chunk's first sequence, or close the block).
+// LZ4's end-of-block rules hold for every chunk: the last match starts >= 12 bytes before n, the last 5 bytes are literals.
+template <int HB, int RB, bool ALONE>
+__device__ uint32_t lz4_compress_range(const uint8_t* src, uint32_t n, uint32_t c0, uint32_t c1, uint8_t* dst, Lz4EncLds<HB, RB>& L,
+                                       uint32_t* tail_anchor) {
     constexpr uint32_t R = 1u << RB, RWM = R / 4 - 1;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t outp = 0;        // bytes already written to dst
@@ -890,20 +907,14 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
         }
         return 1 + (lit >= 15 ? 1 + div255(lit - 15) : 0);
     };
-    auto emit_last = [&](uint32_t anchor) {  // the literals-only last sequence
-        const uint32_t lit = n - anchor;
-        flush_out();
-        outp += put_head(lit, 0);
-        wave_copy_g2g(dst + outp, src + anchor, lit);
-        outp += lit;
-    };
-    if (n < 13) {  // LZ4_minLength = mflimit + 1: no match possible
-        emit_last(0);
-        return outp;
-    }
+    *tail_anchor = c0;
+    if (n < 13 || c0 + 12 > n) return 0;   // LZ4_minLength = mflimit + 1: no match possible
     LzMatcher<HB, RB> mt(L, src, n);
     mt.init();
-    mt.begin_chunk(0, n - 12, n - 5);     // LZ4: the last match starts >= 12 bytes before the end, the last 5 bytes are literals
+    if (ALONE)
+        mt.begin_alone(c0, min(c1 - 4, n - 12), min(c1, n - 5));
+    else
+        mt.begin_chunk(c0, n - 12, n - 5);
     while (mt.next()) {
         const bool chosen = (mt.C >> lane) & 1;
         uint32_t lit_start_v = mt.anchor;
@@ -985,10 +996,37 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
         mt.advance();
     }
     LZP(3);
-    emit_last(mt.anchor);
+    flush_out();
+    *tail_anchor = mt.anchor;
     LZP(5);
     LZP_END;
     return outp;
+}
+
+// token + literal-length extension of a sequence with `lit` literals and match code `mcode`, by one lane; returns the size
+__device__ __forceinline__ uint32_t lz4_put_head(uint8_t* o, uint32_t lit, uint32_t mcode) {
+    uint32_t k = 0;
+    o[k++] = (uint8_t)((min(lit, 15u) << 4) | min(mcode, 15u));
+    if (lit >= 15) {
+        uint32_t r = lit - 15;
+        while (r >= 255) { o[k++] = 255; r -= 255; }
+        o[k++] = (uint8_t)r;
+    }
+    return k;
+}
+__device__ __forceinline__ uint32_t lz4_head_bytes(uint32_t lit) { return 1 + (lit >= 15 ? 1 + div255(lit - 15) : 0); }
+
+// Compress src[0, n) into dst (capacity >= lz4_bound(n)); executed by ONE wave64; returns the block size.
+template <int HB, int RB>
+__device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t anchor = 0;
+    uint32_t outp = lz4_compress_range<HB, RB, false>(src, n, 0, n, dst, L, &anchor);
+    const uint32_t lit = n - anchor;     // the literals-only last sequence
+    if (lane == 0) lz4_put_head(dst + outp, lit, 0);
+    outp += lz4_head_bytes(lit);
+    wave_copy_g2g(dst + outp, src + anchor, lit);
+    return outp + lit;
 }
 
 }  // namespace sb

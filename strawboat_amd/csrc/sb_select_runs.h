@@ -13,9 +13,10 @@
 // where the bits change are compacted into an LDS list, and a second step handles one raw RUN per
 // lane.  For pages with runs of ~32 rows that is 1/32 of the old per-row work.
 //
-// The next chunk's rows are requested as soon as the comparison has consumed the current ones (same
-// registers), and the run values travel through LDS, so neither load latency sits on the per-chunk
-// critical path.
+// The run values travel through LDS.  A chunk's rows are requested at the top of its iteration: requesting the next
+// chunk before step 2 (measured, round 2) keeps 32 more VGPRs live across step 2, which either spills at 4 waves /
+// SIMD (1.58 ms on C2 instead of 1.10) or drops the kernel to 3 waves / SIMD (1.33 ms) — the other three
+// workgroups of the CU are what hides the load latency.
 //
 // A chunk (4096 rows) with more than RUNS_CAP raw runs (runs shorter than ~6 rows on average) makes
 // the page FALL BACK to select_rle_page (k_enc_select_rle runs after this kernel and takes the pages

@@ -264,3 +264,78 @@ def test_binary_and_boolean_and_nested_blocks_fast_path(gpu_ctx):
                               S.stat_column(col["ptype"], col["nullable"], wp, wm)[0])
         back = device_read(gpu_ctx, col, pages, metas)    # device decode of the device's pages
         assert np.array_equal(back.values_numpy(), want["values"])
+
+
+def _liblz4_check(pages, off, length, data_bytes):
+    """liblz4 (through pyarrow) must accept the block at pages[off + 9 : off + length] and give data_bytes"""
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return
+    out = pa.Codec("lz4_raw").decompress(bytes(pages[off + 9:off + int(length)]), decompressed_size=len(data_bytes), asbytes=True)
+    assert out == data_bytes
+
+
+@pytest.mark.parametrize("kind", ["zeros", "text", "random", "runs"])
+@pytest.mark.parametrize("n", [65536 + 1, 65536 + 4, 65536 + 5, 65536 + 11, 65536 + 12, 65536 + 13, 65536 + 100,
+                               2 * 65536, 2 * 65536 + 7, 5 * 65536 - 3, 1_000_003])
+def test_chunked_blocks_end_rules(gpu_ctx, kind, n):
+    """blocks of more than one 64 KiB chunk are compressed chunk by chunk and joined (k_enc_lz4_plan/_chunks/_stitch):
+    the joined block must be one valid LZ4 block — liblz4's LZ4_decompress_safe enforces the end-of-block rules (last
+    5 bytes literals, last match >= 12 bytes before the end) — whatever the size of the last chunk"""
+    rng = np.random.default_rng(n % 1000)
+    if kind == "zeros":
+        data = np.zeros(n, np.uint8)
+    elif kind == "text":
+        words = [b"w%d" % i + b"y" * (i % 7) for i in range(200)]
+        data = np.frombuffer(b"".join(words[i] for i in rng.zipf(1.3, n // 3) % 200)[:n].ljust(n, b"."), np.uint8)
+    elif kind == "random":
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+    else:
+        data = np.repeat(rng.integers(0, 256, n // 40 + 1, dtype=np.uint8), 40)[:n]
+    col = bytes_column(data)
+    enc = device_write(gpu_ctx, col, max_page_size=None)
+    pages, metas = enc.pages_numpy(), enc.metas_array()
+    assert metas.shape[0] == 1 and int(metas[0, 1]) == n
+    assert pages[0] == S.LZ4 and int.from_bytes(bytes(pages[1:5]), "little") == int(metas[0, 0]) - 9
+    _liblz4_check(pages, 0, metas[0, 0], bytes(data))
+    got = gen.oracle_read(col, pages, metas)
+    assert np.array_equal(got["values"], data)
+    back = device_read(gpu_ctx, col, pages, metas)
+    assert np.array_equal(back.values_numpy(), data)
+    if kind != "random":
+        want_pages, _ = gen.oracle_write(col, max_page_size=None, default_compression=S.LZ4)
+        assert pages.size <= 1.25 * want_pages.size + 64 * (n // 65536 + 1), (pages.size, want_pages.size)
+
+
+def test_chunked_binary_boolean_nullable_pages(gpu_ctx):
+    """every flat page shape with a block of more than one chunk: binary (offsets block and values block, i32 and i64
+    offsets, nullable), boolean with a bit offset inside the column, wide primitives; adaptive mode with LZ4 as default"""
+    from strawboat_amd import write
+    from strawboat_amd.types import WriteOptions
+    cases = ((gen.binary(120_000, uniq=5000, null_density=0.1, zipf=1.2, maxlen=40), dict(max_page_size=50_000)),
+             (gen.binary(40_000, uniq=40_000, large=True, minlen=10, maxlen=30), dict(max_page_size=None)),
+             (gen.boolean(2_000_003, null_density=0.2, runs=5), dict(max_page_size=700_001)),
+             (gen.prim(S.T_I64, 200_000, uniq=1 << 40, null_density=0.3), dict(max_page_size=None)),
+             (gen.prim(S.T_I32, 300_000, uniq=1 << 30), dict(max_page_size=100_000, default_compress_ratio=50.0)))
+    for col, kw in cases:
+        dc = write.DeviceColumn(col["ptype"], col["nullable"], col["rows"], up(gpu_ctx, col["values"]),
+                                None if col["validity"] is None else up(gpu_ctx, col["validity"]),
+                                None if col["offsets"] is None else up(gpu_ctx, col["offsets"]))
+        enc = write.write(gpu_ctx, dc, WriteOptions(default_compression=S.LZ4, **kw))
+        pages, metas = enc.pages_numpy(), enc.metas_array()
+        okw = dict(kw)
+        if "default_compress_ratio" in okw:
+            okw["ratio"] = okw.pop("default_compress_ratio")
+        wp, wm = gen.oracle_write(col, default_compression=S.LZ4, **okw)
+        assert np.array_equal(metas[:, 1], wm[:, 1])
+        want = gen.oracle_read(col, wp, wm)
+        got = gen.oracle_read(col, pages, metas)
+        for k in ("values", "validity", "offsets"):
+            assert np.array_equal(got[k], want[k]), k
+        assert np.array_equal(S.stat_column(col["ptype"], col["nullable"], pages, metas)[0],
+                              S.stat_column(col["ptype"], col["nullable"], wp, wm)[0])
+        back = device_read(gpu_ctx, col, pages, metas)
+        assert np.array_equal(back.values_numpy(), want["values"])
+        # (the matcher's history is its 8 KiB LDS ring, liblz4's is 64 KiB: a vocabulary of 5000 strings costs ~45 %)
+        assert pages.size <= 1.6 * wp.size + 4096

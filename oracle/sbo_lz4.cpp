@@ -6,8 +6,8 @@
 // = LZ4_compress_default, no size prefix).  The algorithm itself lives in liblz4 (C,
 // bundled by lz4-sys; `lz4 = "1.23.1"`, Cargo.toml:23), which is not under
 // /root/reference; this file restates the published block format and liblz4 1.9.x's
-// greedy single-probe hash parser from its documentation.  tests/test_oracle_lz4.py
-// cross-checks both directions against the system liblz4 (1.9.3) when present.
+// greedy single-probe hash parser from its documentation.  tests/test_oracle_blocks.py
+// pins both directions against bytes liblz4 1.9.3 produced (tests/golden/blocks/, generator committed).
 #include <cstring>
 
 #include "sbo.h"

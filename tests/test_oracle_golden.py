@@ -97,11 +97,11 @@ def test_stat_rs_codec_choice_one_value():
 
 
 def test_c2_adaptive_choice_is_rle():
-    """bench.py's C2 data: the reference's selector (ratio 2.0) prefers RLE (sampled ratio ~14) over
-    Dict (7.6); Patas/Freq excluded like in the bench (not on the GPU path yet)."""
+    """bench.py's C2 data with the bench's options (the reference's defaults: ratio 2.0, NOTHING forbidden): the
+    selector prefers RLE (sampled ratio ~14) over Dict (7.6), Freq and Patas."""
     import bench
     vals, valid = bench.gen_c2_column(42)
-    opts = S.make_options(default_compression=S.LZ4, ratio=2.0, max_page_size=65536, forbidden=(S.FREQ, S.PATAS))
+    opts = S.make_options(default_compression=S.LZ4, ratio=2.0, max_page_size=65536)
     data, metas = S.write_column(S.T_F64, True, vals.size, vals, validity=valid, options=opts)
     codecs, _ = S.stat_column(S.T_F64, True, data, metas)
     assert (codecs == S.RLE).all()

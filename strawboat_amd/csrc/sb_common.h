@@ -161,6 +161,43 @@ __device__ __forceinline__ uint64_t ldu64(const uint8_t* p) {
     __builtin_memcpy(&v, (gcptr)p, 8);
     return v;
 }
+// aligned u32 / u64 accesses to HBM through generic pointers (workspace arrays handed around as plain pointers): the
+// cast makes them global_load / global_store — a flat access also counts on lgkmcnt, so every wait for an LDS result
+// would wait for the outstanding HBM accesses too and nothing overlaps
+typedef __attribute__((address_space(1))) const uint32_t* gc32p;
+typedef __attribute__((address_space(1))) uint32_t* g32p;
+typedef __attribute__((address_space(1))) const uint64_t* gc64p;
+typedef __attribute__((address_space(1))) uint64_t* g64p;
+typedef __attribute__((address_space(3))) uint32_t* l32p;
+__device__ __forceinline__ uint32_t gld32(const uint32_t* p) { return *(gc32p)p; }
+__device__ __forceinline__ void gst32(uint32_t* p, uint32_t v) { *(g32p)p = v; }
+__device__ __forceinline__ uint64_t gld64(const uint64_t* p) { return *(gc64p)p; }
+__device__ __forceinline__ void gst64(uint64_t* p, uint64_t v) { *(g64p)p = v; }
+// A table of u32 slots that lives in LDS or in HBM (chosen at run time): every access names its address space.
+struct SlotTable {
+    uint32_t* p;
+    bool in_lds;
+    __device__ __forceinline__ uint32_t ld(uint32_t h) const {
+        return in_lds ? *((l32p)p + h) : __hip_atomic_load((g32p)p + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void st(uint32_t h, uint32_t v) const {
+        if (in_lds) *((l32p)p + h) = v;
+        else *((g32p)p + h) = v;
+    }
+    // returns the value found (== cmp: the slot now holds val)
+    __device__ __forceinline__ uint32_t cas(uint32_t h, uint32_t cmp, uint32_t val) const {
+        uint32_t e = cmp;
+        if (in_lds)
+            __hip_atomic_compare_exchange_strong((l32p)p + h, &e, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+            __hip_atomic_compare_exchange_strong((g32p)p + h, &e, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return e;
+    }
+    __device__ __forceinline__ void amin(uint32_t h, uint32_t v) const {
+        if (in_lds) __hip_atomic_fetch_min((l32p)p + h, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_min((g32p)p + h, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
 __device__ __forceinline__ void stu32(uint8_t* p, uint32_t v) { __builtin_memcpy((gptr)p, &v, 4); }
 __device__ __forceinline__ void stu64(uint8_t* p, uint64_t v) { __builtin_memcpy((gptr)p, &v, 8); }
 

@@ -1371,6 +1371,7 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
         if (t == 0) raise(st, SB_ERR_INVALID, page, 510);
         return EMPTY;
     }
+    // (workspace arrays in HBM: gld32 / gst32 — see sb_common.h — keep them off the LDS counter)
     uint32_t* F = aux + M;       // row -> first row with the same key
     uint32_t* R = F + N;         // first row -> dictionary id ; later: dict id -> first row (firsts)
     uint32_t* idx = R + N;
@@ -1380,10 +1381,10 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
     // The table of first rows: in LDS while the page has few distinct keys (tier 0: every probe is an LDS access; string
     // keys are compared through L2), in HBM otherwise (tier 1: pow2 >= 2N slots in the aux area).
     for (int tier = (lds_table && lds_slots) ? 0 : 1; tier < 2; tier++) {
-        uint32_t* table = tier == 0 ? lds_table : aux;
+        const SlotTable table{tier == 0 ? lds_table : aux, tier == 0};
         const uint64_t slots = tier == 0 ? lds_slots : M;
         const uint32_t cap = tier == 0 ? min(lds_slots / 8 * 5, lds_slots - (uint32_t)WG * 16 - 1) : 0xFFFFFFFFu;   // (see distinct_count)
-        for (uint64_t i = t; i < slots; i += WG) table[i] = EMPTY;
+        for (uint64_t i = t; i < slots; i += WG) table.st((uint32_t)i, EMPTY);
         if (t == 0) s_keys = 0;
         __syncthreads();
         if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1392,34 +1393,57 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
         // phase 1: insert; the slot of a key ends up holding the smallest row that carries it.  The slot a row
         // landed in is remembered (in F), so that phase 2 does not hash and compare the key a second time.
         for (uint64_t base = 0; base < N; base += (uint64_t)WG * 16) {
-            for (int j = 0; j < 16; j++) {
-                const uint64_t i = base + (uint64_t)j * WG + t;
-                if (i >= N) break;
-                if (!ko.keyed(i)) {
-                    F[i] = EMPTY;
-                    continue;
+            // eight rows in flight per thread, probed in rounds (see distinct_count)
+            for (int j0 = 0; j0 < 16; j0 += 8) {
+                uint64_t iu[8];
+                uint32_t hu[8], cu[8];
+                uint32_t pend = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    iu[u] = base + (uint64_t)(j0 + u) * WG + t;
+                    const bool in = iu[u] < N;
+                    if (!in) iu[u] = 0;
+                    if (in) {
+                        if (ko.keyed(iu[u])) pend |= 1u << u;
+                        else gst32(F + iu[u], EMPTY);
+                    }
+                    hu[u] = ko.hash(iu[u]) & mask;
                 }
-                uint32_t h = ko.hash(i) & mask;
-                for (;;) {
-                    uint32_t cur = tier == 0 ? table[h] : table_load(&table[h]);
-                    if (cur == EMPTY) {
-                        const uint32_t old = atomicCAS(&table[h], EMPTY, (uint32_t)i);
+                while (pend) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if ((pend >> u) & 1) cu[u] = table.ld(hu[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (!((pend >> u) & 1) || cu[u] != EMPTY) continue;
+                        const uint32_t old = table.cas(hu[u], EMPTY, (uint32_t)iu[u]);
                         if (old == EMPTY) {
                             if (tier == 0) atomicAdd(&s_keys, 1u);
-                            break;
+                            gst32(F + iu[u], hu[u]);
+                            pend &= ~(1u << u);
+                        } else {
+                            cu[u] = old;
                         }
-                        cur = old;
                     }
-                    bool same;
-                    if constexpr (HASHED) same = cur == (uint32_t)i || (exact_mode ? ko.eq(cur, i) : ko.heq(cur, i));
-                    else same = cur == (uint32_t)i || ko.eq(cur, i);
-                    if (same) {
-                        if ((uint32_t)i < cur) atomicMin(&table[h], (uint32_t)i);  // rows arrive roughly in order: rarely needed
-                        break;
+                    bool same[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t cr = ((pend >> u) & 1) ? cu[u] : (uint32_t)iu[u];
+                        if constexpr (HASHED) same[u] = cr == (uint32_t)iu[u] || (exact_mode ? ko.eq(cr, iu[u]) : ko.heq(cr, iu[u]));
+                        else same[u] = cr == (uint32_t)iu[u] || ko.eq(cr, iu[u]);
                     }
-                    h = (h + 1) & mask;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (!((pend >> u) & 1)) continue;
+                        if (same[u]) {
+                            if ((uint32_t)iu[u] < cu[u]) table.amin(hu[u], (uint32_t)iu[u]);  // rows arrive roughly in order: rarely needed
+                            gst32(F + iu[u], hu[u]);
+                            pend &= ~(1u << u);
+                        } else {
+                            hu[u] = (hu[u] + 1) & mask;
+                        }
+                    }
                 }
-                F[i] = h;
             }
             if (tier == 0) {   // too many distinct keys for the LDS table: start over on the HBM one
                 __syncthreads();
@@ -1430,31 +1454,32 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
             }
         }
         __syncthreads();
+        STL(21);
         if (overflow) continue;
         if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // phase 2: F[i] = first row of row i's key (a key never leaves its slot)
         for (uint64_t i = t; i < N; i += WG) {
-            const uint32_t h = F[i];
-            if (h != EMPTY) F[i] = tier == 0 ? table[h] : table_load(&table[h]);
+            const uint32_t h = gld32(F + i);
+            if (h != EMPTY) gst32(F + i, table.ld(h));
         }
         __syncthreads();
+        STL(22);
         if constexpr (HASHED) {
             if (!exact_mode) {   // every row against the first row of its hash class
                 if (t == 0) s_collide = 0;
                 __syncthreads();
                 uint32_t bad = 0;
-                for (uint64_t base = t; base < N; base += (uint64_t)WG * 4) {
-                    uint32_t f[4];
+                constexpr int VU = 8;    // rows in flight per thread: the pass is a chain of dependent random accesses
+                for (uint64_t base = t; base < N; base += (uint64_t)WG * VU) {
+                    uint32_t f[VU];
+                    uint64_t row[VU];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint64_t i = base + (uint64_t)u * WG;
-                        f[u] = i < N ? F[i] : EMPTY;
+                    for (int u = 0; u < VU; u++) {
+                        row[u] = base + (uint64_t)u * WG;
+                        f[u] = row[u] < N ? gld32(F + row[u]) : EMPTY;
+                        if (f[u] == (uint32_t)row[u]) f[u] = EMPTY;   // a first row needs no check
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint64_t i = base + (uint64_t)u * WG;
-                        if (i < N && f[u] != EMPTY && f[u] != (uint32_t)i && !ko.exact(f[u], i)) bad = 1;
-                    }
+                    if (!ko.template exact_batch<VU>(f, row)) bad = 1;
                 }
                 if (bad) atomicOr(&s_collide, 1u);
                 __syncthreads();
@@ -1468,40 +1493,47 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
         }
         break;
     }
-    // phase 3: dictionary ids in first-occurrence order (rank of first rows), chunked scan
+    STL(23);
+    // phase 3: dictionary ids in first-occurrence order (rank of first rows), chunked scan; firsts[id] = the first row
+    // (the HBM table area: not needed any more, or never used)
+    uint32_t* firsts = aux;
     uint32_t nent = 0;
     for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
         const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, N - cb);
-        for (uint32_t i = t; i < TILE_ROWS; i += WG) sA[sidx((int)i)] = (i < n && F[cb + i] == (uint32_t)(cb + i)) ? 1 : 0;
+        for (uint32_t i = t; i < TILE_ROWS; i += WG) sA[sidx((int)i)] = (i < n && gld32(F + cb + i) == (uint32_t)(cb + i)) ? 1 : 0;
         __syncthreads();
         const uint32_t tot = tile_incl_scan(sA, s_w);
-        for (uint32_t i = t; i < n; i += WG)
-            if (F[cb + i] == (uint32_t)(cb + i)) R[cb + i] = nent + sA[sidx((int)i)] - 1;
+        for (uint32_t i = t; i < n; i += WG) {
+            const uint32_t inc = sA[sidx((int)i)], prev = i ? sA[sidx((int)i - 1)] : 0;
+            if (inc != prev) {   // a first row
+                gst32(R + cb + i, nent + inc - 1);
+                gst32(firsts + nent + inc - 1, (uint32_t)(cb + i));
+            }
+        }
         nent += tot;
         __syncthreads();
     }
     __syncthreads();
+    STL(24);
     // phase 4: idx[i] = id of the key of the last keyed row <= i (nulls repeat the previous index)
     uint32_t carry_last = 0;  // (last keyed row)+1 seen in earlier chunks; row 0 is always keyed
     for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
         const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, N - cb);
-        for (uint32_t i = t; i < TILE_ROWS; i += WG) sB[sidx((int)i)] = (i < n && F[cb + i] != EMPTY) ? i + 1 : 0;
+        for (uint32_t i = t; i < TILE_ROWS; i += WG) sB[sidx((int)i)] = (i < n && gld32(F + cb + i) != EMPTY) ? i + 1 : 0;
         __syncthreads();
         tile_incl_scan_max(sB, s_w);
         for (uint32_t i = t; i < n; i += WG) {
             const uint32_t lk = sB[sidx((int)i)];
             const uint64_t row = lk ? cb + lk - 1 : (uint64_t)carry_last - 1;
-            idx[cb + i] = R[F[row]];
+            gst32(idx + cb + i, gld32(R + gld32(F + row)));
         }
         const uint32_t lk = sB[sidx((int)n - 1)];
         if (lk) carry_last = (uint32_t)(cb + lk);
         __syncthreads();
     }
-    // phase 5: firsts[id] = first row (the HBM table area: not needed any more, or never used)
-    uint32_t* firsts = aux;
-    for (uint64_t i = t; i < N; i += WG)
-        if (F[i] == (uint32_t)i) firsts[R[i]] = (uint32_t)i;
+    STL(25);
     __syncthreads();
+    STL(26);
     *idx_out = idx;
     *firsts_out = firsts;
     return nent;
@@ -1530,16 +1562,15 @@ struct BinKeys {
     ValidView vv;
     __device__ __forceinline__ bool keyed(uint64_t i) const { return i == 0 || vv.get(i); }
     __device__ __forceinline__ uint64_t beg(uint64_t i) const {
-        O o;
-        __builtin_memcpy(&o, offs + i * sizeof(O), sizeof(O));
-        return (uint64_t)o;
+        if constexpr (sizeof(O) == 4) return (uint64_t)(O)ldu32(offs + i * 4);
+        else return (uint64_t)(O)ldu64(offs + i * 8);
     }
     __device__ __forceinline__ uint32_t hash(uint64_t i) const {
         const uint64_t b = beg(i), e = beg(i + 1);
         uint64_t h = 0xcbf29ce484222325ull ^ (e - b);
         uint64_t p = b;
         for (; p + 8 <= e; p += 8) h = (h ^ ldu64(values + p)) * 0x100000001b3ull + (h >> 29);
-        for (; p < e; p++) h = (h ^ values[p]) * 0x100000001b3ull;
+        for (; p < e; p++) h = (h ^ ldu8(values + p)) * 0x100000001b3ull;
         return hash64(h);
     }
     __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const {
@@ -1550,7 +1581,7 @@ struct BinKeys {
         for (; k + 8 <= n; k += 8)
             if (ldu64(values + ab + k) != ldu64(values + bb + k)) return false;
         for (; k < n; k++)
-            if (values[ab + k] != values[bb + k]) return false;
+            if (ldu8(values + ab + k) != ldu8(values + bb + k)) return false;
         return true;
     }
 };
@@ -1579,6 +1610,72 @@ __device__ __forceinline__ uint64_t bin_hash_bytes(const uint8_t* values, uint64
     h *= 0x94D049BB133111EBull;
     return h ^ (h >> 31);
 }
+// the same hash over a string staged in LDS (`l`: dword array with 8 bytes of slack) at byte b .. e
+__device__ __forceinline__ uint64_t lds3_rd8(l32p a, uint32_t x) {   // 8 bytes at byte x of an LDS dword array (8 bytes of slack)
+    const uint32_t w = x >> 2;
+    const uint32_t d0 = a[w], d1 = a[w + 1], d2 = a[w + 2];
+    return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, x & 3) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, x & 3) << 32);
+}
+__device__ __forceinline__ uint64_t bin_hash_lds(l32p l, uint32_t b, uint32_t e) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)(e - b) * 0xD6E8FEB86659FD93ull);
+    uint32_t p = b;
+    for (; p + 8 <= e; p += 8) {
+        h = (h ^ lds3_rd8(l, p)) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    if (p < e) {
+        const uint64_t w = lds3_rd8(l, p) & ((1ull << (8 * (e - p))) - 1);
+        h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+        h ^= h >> 29;
+    }
+    h *= 0x94D049BB133111EBull;
+    return h ^ (h >> 31);
+}
+// bin_hash_rows through LDS: the value bytes of a page are one contiguous range, so instead of every thread chasing
+// offsets -> bytes (3-4 dependent HBM round trips per 4 rows, 0.49 ms per 64 Ki-row page) the workgroup streams the
+// bytes of a tile of rows into LDS with coalesced 16-byte loads and hashes from there (two round trips per ~3000 rows).
+template <class O>
+__device__ void bin_hash_rows_staged(const BinKeys<O>& bk, uint64_t N, uint64_t values_len, uint64_t* h64, uint32_t* lds, uint32_t lds_bytes) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t cap = lds_bytes - 16;
+    uint64_t r0 = 0;
+    while (r0 < N) {
+        uint64_t R = min((uint64_t)4096, N - r0);
+        const uint64_t b0 = bk.beg(r0);
+        uint64_t nb = bk.beg(r0 + R) - b0;
+        while (nb > cap && R > 1) {      // (uniform: rows of more than ~15 bytes on average)
+            R >>= 1;
+            nb = bk.beg(r0 + R) - b0;
+        }
+        if (nb > cap) {                  // one row larger than the staging area: straight from HBM
+            if (t == 0) gst64(h64 + r0, bin_hash_bytes(bk.values, b0, b0 + nb, values_len));
+            r0 += 1;
+            continue;
+        }
+        __syncthreads();
+        for (uint64_t x = (uint64_t)t * 16; x < nb; x += (uint64_t)WG * 16) {
+            u32x4 v;
+            if (b0 + x + 16 <= values_len) {
+                v = ldu128(bk.values + b0 + x);
+            } else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t q = 0; q < 16 && b0 + x + q < values_len; q++) w[q >> 2] |= (uint32_t)ldu8(bk.values + b0 + x + q) << (8 * (q & 3));
+                v = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            l32p d = (l32p)lds + (x >> 2);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        for (uint64_t r = r0 + t; r < r0 + R; r += WG) {
+            const uint32_t b = (uint32_t)(bk.beg(r) - b0), e = (uint32_t)(bk.beg(r + 1) - b0);
+            gst64(h64 + r, bin_hash_lds((l32p)lds, b, e));
+        }
+        r0 += R;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 template <class O>
 __device__ void bin_hash_rows(const BinKeys<O>& bk, uint64_t N, uint64_t values_len, uint64_t* h64) {
     constexpr int U = 4;
@@ -1593,7 +1690,7 @@ __device__ void bin_hash_rows(const BinKeys<O>& bk, uint64_t N, uint64_t values_
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint64_t i = base + (uint64_t)u * WG;
-            if (i < N) h64[i] = bin_hash_bytes(bk.values, b[u], e[u], values_len);
+            if (i < N) gst64(h64 + i, bin_hash_bytes(bk.values, b[u], e[u], values_len));
         }
     }
     __syncthreads();
@@ -1605,10 +1702,16 @@ template <class O>
 struct KeyOpsBinHashed {
     BinKeys<O> k;
     const uint64_t* h64;
-    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return (uint32_t)(h64[i] >> 17); }
-    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return h64[a] == h64[b]; }
+    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return (uint32_t)(gld64(h64 + i) >> 17); }
+    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return gld64(h64 + a) == gld64(h64 + b); }
     __device__ __forceinline__ uint32_t weight(uint64_t i) const { return (uint32_t)(k.beg(i + 1) - k.beg(i)) + 8; }
+    // eq(a, b) == (key64(a) == key64(b)): lets a pass keep the key it compares against in a register
+    __device__ __forceinline__ uint64_t key64(uint64_t i) const { return gld64(h64 + i); }
 };
+template <class T, class = void>
+struct has_key64 { static constexpr bool value = false; };
+template <class T>
+struct has_key64<T, decltype((void)&T::key64)> { static constexpr bool value = true; };
 // dictionary build over hashed rows: the hash finds the slot and rejects different strings, the strings decide
 template <class O>
 struct BinKeysHashed {
@@ -1616,14 +1719,50 @@ struct BinKeysHashed {
     const uint64_t* h64;
     __device__ __forceinline__ bool keyed(uint64_t i) const { return k.keyed(i); }
     __device__ __forceinline__ uint64_t beg(uint64_t i) const { return k.beg(i); }
-    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return (uint32_t)(h64[i] >> 17); }
-    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return h64[a] == h64[b] && k.eq(a, b); }
+    __device__ __forceinline__ uint32_t hash(uint64_t i) const { return (uint32_t)(gld64(h64 + i) >> 17); }
+    __device__ __forceinline__ bool eq(uint64_t a, uint64_t b) const { return gld64(h64 + a) == gld64(h64 + b) && k.eq(a, b); }
     // dict_build's fast mode: classes by hash alone (no offsets -> bytes chase inside the probe loop), then ONE streaming
     // pass checks every row against the first row of its class, four rows in flight per thread; a 64-bit collision (never
     // seen, but it would merge two different strings) sends the page through the exact build
     static constexpr bool HASHED = true;
-    __device__ __forceinline__ bool heq(uint64_t a, uint64_t b) const { return h64[a] == h64[b]; }
+    __device__ __forceinline__ bool heq(uint64_t a, uint64_t b) const { return gld64(h64 + a) == gld64(h64 + b); }
     __device__ __forceinline__ bool exact(uint64_t a, uint64_t b) const { return k.eq(a, b); }
+    uint64_t values_len = 0;   // bytes readable behind k.values (0: exact_batch takes the slow path)
+    // row[u] against row f[u] (EMPTY: nothing to check) for U rows at once: three rounds of independent accesses —
+    // offsets, then the first 24 bytes of both strings with byte masks — instead of U chains of eq()'s early-exit loop.
+    // Strings longer than 24 bytes or within 24 bytes of the buffer's end take eq().
+    template <int U>
+    __device__ __forceinline__ bool exact_batch(const uint32_t (&f)[U], const uint64_t (&row)[U]) const {
+        uint64_t bi[U], bf[U], n[U];
+        bool ok = true, fast[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool need = f[u] != 0xFFFFFFFFu;
+            const uint64_t r = need ? row[u] : 0, g = need ? f[u] : 0;
+            bi[u] = k.beg(r);
+            bf[u] = k.beg(g);
+            n[u] = k.beg(r + 1) - bi[u];
+            const uint64_t nf = k.beg(g + 1) - bf[u];
+            if (need && nf != n[u]) ok = false;
+            fast[u] = need && n[u] <= 24 && bi[u] + 24 <= values_len && bf[u] + 24 <= values_len;
+            if (need && !fast[u] && nf == n[u] && !k.eq(g, r)) ok = false;
+        }
+        uint64_t x = 0;
+        if (values_len < 24) return ok;   // (no fast row: nothing below may touch the buffer)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint8_t* pi = k.values + (fast[u] ? bi[u] : 0);
+            const uint8_t* pf = k.values + (fast[u] ? bf[u] : 0);
+#pragma unroll
+            for (int w = 0; w < 3; w++) {
+                const uint64_t d = ldu64(pi + 8 * w) ^ ldu64(pf + 8 * w);
+                const uint64_t have = n[u] > (uint64_t)(8 * w) ? n[u] - 8 * w : 0;   // bytes of this word that belong to the string
+                const uint64_t m = have >= 8 ? ~0ull : ((1ull << (8 * have)) - 1);
+                if (fast[u]) x |= d & m;
+            }
+        }
+        return ok && x == 0;
+    }
 };
 
 // ------------------------------------------------------------------------------ adaptive selection
@@ -1658,13 +1797,13 @@ __device__ uint32_t distinct_count(Ops ops, uint64_t N, uint32_t limit, const Se
     __shared__ uint32_t s_cnt;
     __shared__ unsigned long long s_wsum;
     for (int tier = 0; tier < 2; tier++) {
-        uint32_t* tab = tier == 0 ? sc.lds_tab : sc.gtab;
+        const SlotTable tab{tier == 0 ? sc.lds_tab : sc.gtab, tier == 0};
         const uint64_t slots = tier == 0 ? sc.lds_slots : sc.gslots;
         if (tier == 1 && (!sc.gtab || sc.gslots < 2 * N)) return limit + 1;
         // LDS tier up to a load of 5/8 — and never so full that the WG * 16 rows inserted between two checks could
         // occupy every slot (a probe for one more key would then never find an empty one)
         const uint32_t cap = tier == 0 ? min(sc.lds_slots / 8 * 5, sc.lds_slots - (uint32_t)WG * 16 - 1) : 0xFFFFFFFFu;
-        for (uint64_t i = t; i < slots; i += WG) tab[i] = SEL_EMPTY;
+        for (uint64_t i = t; i < slots; i += WG) tab.st((uint32_t)i, SEL_EMPTY);
         if (t == 0) {
             s_cnt = 0;
             s_wsum = 0;
@@ -1674,25 +1813,47 @@ __device__ uint32_t distinct_count(Ops ops, uint64_t N, uint32_t limit, const Se
         const uint32_t mask = (uint32_t)(slots - 1);
         bool overflow = false;
         for (uint64_t base = 0; base < N; base += WG * 16) {
-            for (int j = 0; j < 16; j++) {
-                const uint64_t i = base + (uint64_t)j * WG + t;
-                if (i >= N) break;
-                uint32_t h = ops.hash(i) & mask;
-                for (;;) {
-                    uint32_t cur = tier == 0 ? tab[h]
-                                             : __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cur == SEL_EMPTY) {
-                        const uint32_t old = atomicCAS(&tab[h], SEL_EMPTY, (uint32_t)i);
+            // Eight rows in flight per thread, probed in rounds: a key comparison is a dependent chain (table slot -> the
+            // slot's row -> its key in HBM), so every round issues the slot reads of all unsettled rows together, then their
+            // key comparisons together; a row leaves when it finds its key or claims an empty slot, the others step to
+            // their next slot.  (One row at a time costs the chain's latency per row: 0.6 ms per 64 Ki-row page.)
+            for (int j0 = 0; j0 < 16; j0 += 8) {
+                uint64_t iu[8];
+                uint32_t hu[8], cu[8];
+                uint32_t pend = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    iu[u] = base + (uint64_t)(j0 + u) * WG + t;
+                    if (iu[u] < N) pend |= 1u << u;
+                    else iu[u] = 0;
+                    hu[u] = ops.hash(iu[u]) & mask;
+                }
+                while (pend) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if ((pend >> u) & 1) cu[u] = tab.ld(hu[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (!((pend >> u) & 1) || cu[u] != SEL_EMPTY) continue;
+                        const uint32_t old = tab.cas(hu[u], SEL_EMPTY, (uint32_t)iu[u]);
                         if (old == SEL_EMPTY) {
                             atomicAdd(&s_cnt, 1u);
-                            const uint32_t wgt = ops.weight(i);
+                            const uint32_t wgt = ops.weight(iu[u]);
                             if (wgt) atomicAdd(&s_wsum, (unsigned long long)wgt);
-                            break;
+                            pend &= ~(1u << u);
+                        } else {
+                            cu[u] = old;
                         }
-                        cur = old;
                     }
-                    if (cur == (uint32_t)i || ops.eq(cur, i)) break;
-                    h = (h + 1) & mask;
+                    bool same[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) same[u] = ops.eq(((pend >> u) & 1) ? cu[u] : (uint32_t)iu[u], iu[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (!((pend >> u) & 1)) continue;
+                        if (same[u]) pend &= ~(1u << u);
+                        else hu[u] = (hu[u] + 1) & mask;
+                    }
                 }
             }
             __syncthreads();
@@ -1719,16 +1880,44 @@ __device__ uint32_t majority_count(Ops ops, uint64_t N, uint32_t* s_a /* 2*WG + 
     // (candidates are always rows of the page — row 0 while a thread has none — so that a comparison the
     // compiler hoists above the count checks cannot read outside the column)
     uint32_t cand = 0, cnt = 0;
-    for (uint64_t base = 0; base < N; base += WG) {  // (uniform trip count, rows guarded inside)
-        const uint64_t i = base + (uint64_t)t;
-        if (i >= N) continue;
-        if (cnt == 0) {
-            cand = (uint32_t)i;
-            cnt = 1;
-        } else if (ops.eq(cand, i)) {
-            cnt++;
-        } else {
-            cnt--;
+    if constexpr (has_key64<Ops>::value) {
+        // the candidate's key stays in a register and the rows' keys stream in, eight loads in flight (with eq() every
+        // step is a dependent load of the candidate's key: 0.24 ms per 64 Ki-row page)
+        uint64_t ck = 0;
+        for (uint64_t base = 0; base < N; base += (uint64_t)WG * 8) {
+            uint64_t kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG + t;
+                kv[u] = ops.key64(i < N ? i : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG + t;
+                if (i >= N) continue;
+                if (cnt == 0) {
+                    cand = (uint32_t)i;
+                    ck = kv[u];
+                    cnt = 1;
+                } else if (kv[u] == ck) {
+                    cnt++;
+                } else {
+                    cnt--;
+                }
+            }
+        }
+    } else {
+        for (uint64_t base = 0; base < N; base += WG) {  // (uniform trip count, rows guarded inside)
+            const uint64_t i = base + (uint64_t)t;
+            if (i >= N) continue;
+            if (cnt == 0) {
+                cand = (uint32_t)i;
+                cnt = 1;
+            } else if (ops.eq(cand, i)) {
+                cnt++;
+            } else {
+                cnt--;
+            }
         }
     }
     s_a[t] = cand;
@@ -1760,9 +1949,24 @@ __device__ uint32_t majority_count(Ops ops, uint64_t N, uint32_t* s_a /* 2*WG + 
     __syncthreads();
     if (c == SEL_EMPTY) return 0;
     uint32_t mine = 0;
-    for (uint64_t base = 0; base < N; base += WG) {
-        const uint64_t i = base + (uint64_t)t;
-        if (i < N && ops.eq(c, i)) mine++;
+    if constexpr (has_key64<Ops>::value) {
+        const uint64_t ck = ops.key64(c);
+        for (uint64_t base = 0; base < N; base += (uint64_t)WG * 8) {
+            uint64_t kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG + t;
+                kv[u] = ops.key64(i < N ? i : c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (base + (uint64_t)u * WG + t < N && kv[u] == ck) mine++;
+        }
+    } else {
+        for (uint64_t base = 0; base < N; base += WG) {
+            const uint64_t i = base + (uint64_t)t;
+            if (i < N && ops.eq(c, i)) mine++;
+        }
     }
     return wg_sum32(mine, s_a + 2 * WG);
 }
@@ -2243,12 +2447,34 @@ __device__ uint32_t choose_bin_impl(const Ops& ops, const BinKeys<O>& bk, uint64
     auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
     uint32_t* s4 = sc.s_misc + 2 * WG;
     uint32_t f_neq0 = 0, nulls = 0;
-    for (uint64_t i = threadIdx.x; i < N; i += WG) {
-        if (!ops.eq(0, i)) f_neq0 = 1;
-        if (!bk.vv.get(i)) nulls++;
+    if constexpr (has_key64<Ops>::value) {   // keys streamed eight loads at a time; nulls from the validity words
+        const uint64_t k0 = ops.key64(0);
+        for (uint64_t base = threadIdx.x; base < N; base += (uint64_t)WG * 8) {
+            uint64_t kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG;
+                kv[u] = ops.key64(i < N ? i : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (kv[u] != k0) f_neq0 = 1;
+        }
+        if (bk.vv.bits)
+            for (uint64_t w = threadIdx.x; w * 32 < N; w += WG) {
+                const uint32_t nb = (uint32_t)min((uint64_t)32, N - w * 32);
+                const uint32_t word = bits32(bk.vv.bits, bk.vv.off + w * 32, bk.vv.off + N) & (nb >= 32 ? 0xFFFFFFFFu : (1u << nb) - 1);
+                nulls += nb - (uint32_t)__popc(word);
+            }
+    } else {
+        for (uint64_t i = threadIdx.x; i < N; i += WG) {
+            if (!ops.eq(0, i)) f_neq0 = 1;
+            if (!bk.vv.get(i)) nulls++;
+        }
     }
     const bool all_equal = !wg_or32(f_neq0, s4);
     const uint32_t null_count = wg_sum32(nulls, s4);
+    STL(42);
     const double tuple_count = (double)N;
     const double total_bytes = (double)(values_len_total + (N + 1) * sizeof(O));
     double max_ratio = o.ratio;
@@ -2269,11 +2495,13 @@ __device__ uint32_t choose_bin_impl(const Ops& ops, const BinKeys<O>& bk, uint64
                     if ((double)mc / tuple_count >= 0.9) r = (double)(N - 1);
                 }
             }
+            STL(43);
         } else {  // binary/dict.rs:43-53
             if (N >= 3) {
                 const uint32_t limit = (uint32_t)((N - 1) / 3);
                 uint64_t tus = 0;
                 const uint32_t uq = distinct_count(ops, N, limit, sc, &tus);
+                STL(44);
                 if ((uint64_t)uq * 3 < N) {
                     uint64_t after = tus + N * (uint64_t)(bits_needed(uq) / 8);
                     after += N * 2 / 128;
@@ -2297,8 +2525,15 @@ __device__ uint32_t choose_bin(const BinKeys<O>& bk, uint64_t N, uint64_t values
     if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
     if (!o.has_ratio || N == 0) return o.default_codec;
     if (h64) {
-        bin_hash_rows<O>(bk, N, values_len, h64);
-        return choose_bin_impl<O>(KeyOpsBinHashed<O>{bk, h64}, bk, N, values_len_total, o, sc);
+        STL(40);
+        if (sc.lds_slots >= 4096)   // (the table is not in use yet: its LDS stages the value bytes)
+            bin_hash_rows_staged<O>(bk, N, values_len, h64, sc.lds_tab, sc.lds_slots * 4);
+        else
+            bin_hash_rows<O>(bk, N, values_len, h64);
+        STL(41);
+        const uint32_t r = choose_bin_impl<O>(KeyOpsBinHashed<O>{bk, h64}, bk, N, values_len_total, o, sc);
+        STL(45);
+        return r;
     }
     return choose_bin_impl<O>(KeyOpsBin<O>{bk}, bk, N, values_len_total, o, sc);
 }
@@ -2512,10 +2747,16 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         uint32_t *idx, *firsts;
         uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
         uint32_t D;
+        STL(20);
         if (p.h64_off != ~0ull) {   // hashed rows: computed by the selector of this call, or here when the codec was forced
             uint64_t* h64 = (uint64_t*)(a.scratch + p.h64_off);
-            if (p.codec != CODEC_ON_DEVICE) bin_hash_rows<O>(ko, N, c.values_len, h64);
-            D = dict_build(BinKeysHashed<O>{ko, h64}, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page,
+            if (p.codec != CODEC_ON_DEVICE) {
+                if (lds_slots >= 4096)
+                    bin_hash_rows_staged<O>(ko, N, c.values_len, h64, lds_table, lds_slots * 4);
+                else
+                    bin_hash_rows<O>(ko, N, c.values_len, h64);
+            }
+            D = dict_build(BinKeysHashed<O>{ko, h64, c.values_len}, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page,
                            lds_slots > 1 ? lds_table : nullptr, lds_slots > 1 ? lds_slots : 0);
         } else {
             D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page,
@@ -2527,10 +2768,11 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             SelectOpts so{a.ratio, 1u, a.forbidden | p.forb_extra | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, p.depth + 1};
             SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
             const uint32_t* ip = idx;
-            ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = ip[i]; return v; },
+            ic = (int32_t)choose_prim<4>([=](uint64_t i) { Val<4> v; v.x = gld32(ip + i); return v; },
                                          ValidView{nullptr, 0}, N, NK_UNSIGNED, so, sc);
             __syncthreads();
         }
+        STL(30);
         if (ic == SB_CODEC_FREQ) {  // as in emit_prim_page<Dict>: the Freq kernels write the index block and the entries
             if (p.vaux_bytes < 32 || !p.vslot_off) {
                 if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 502);
@@ -2547,6 +2789,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags);
         if (ib == 0) return 0;
+        STL(31);
         uint8_t* q = blk + 9 + ib;
         if (threadIdx.x == 0) stu32(q, D);
         q += 4;
@@ -2557,7 +2800,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             for (uint32_t i = threadIdx.x; i < TILE_ROWS; i += WG) {
                 uint32_t len = 0;
                 if (i < n) {
-                    const uint64_t r = firsts[kb + i];
+                    const uint64_t r = gld32(firsts + kb + i);
                     len = (uint32_t)(ko.beg(r + 1) - ko.beg(r)) + 8;
                 }
                 sA[sidx((int)i)] = len;
@@ -2565,18 +2808,19 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             __syncthreads();
             const uint32_t tot = tile_incl_scan(sA, s_w);
             for (uint32_t i = threadIdx.x; i < n; i += WG) {
-                const uint64_t r = firsts[kb + i];
+                const uint64_t r = gld32(firsts + kb + i);
                 const uint64_t b = ko.beg(r), e = ko.beg(r + 1);
                 uint8_t* d = q + pos + sA[sidx((int)i)] - (e - b) - 8;
                 stu64(d, e - b);
                 uint64_t k = 0;
                 for (; k + 16 <= e - b; k += 16) stu128(d + 8 + k, ldu128(c.values + b + k));   // (unaligned 16-byte moves)
                 for (; k + 8 <= e - b; k += 8) stu64(d + 8 + k, ldu64(c.values + b + k));
-                for (; k < e - b; k++) d[8 + k] = c.values[b + k];
+                for (; k < e - b; k++) *(gptr)(d + 8 + k) = ldu8(c.values + b + k);
             }
             pos += tot;
             __syncthreads();
         }
+        STL(32);
         body = ib + 4 + pos;
     } else {
         if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 540);

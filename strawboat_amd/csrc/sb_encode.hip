@@ -1217,6 +1217,16 @@ __device__ __forceinline__ uint32_t lz4_compress_block(const uint8_t* src, uint3
     return lz4_compress_wave_fast<11, 13>(src, n, dst, *reinterpret_cast<Lz4EncLds<11, 13>*>(ws16k));
 }
 
+// Snappy stream of one page sub-buffer: the LZ4 matcher with Snappy's element syntax (sb_lz4.h), one wave of the
+// workgroup; ws16k: 16 KiB of LDS; s_out: one LDS word for the size.  All threads of the workgroup call it.
+__device__ __forceinline__ uint32_t snappy_compress_block_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* ws16k, uint32_t* s_out) {
+    __syncthreads();
+    uint32_t sz = 0;
+    if (threadIdx.x < 64) sz = snappy_compress_wave<11, 13>(src, n, dst, *reinterpret_cast<Lz4EncLds<11, 13>*>(ws16k));
+    if (threadIdx.x == 0) *s_out = sz;
+    __syncthreads();
+    return *s_out;
+}
 __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);
 // Snappy raw stream made of one literal element (uvarint length | literal tag + length | bytes): what
 // snap::raw::Decoder (basic.rs:99-106) and sb's own decoder read back; no matching is attempted.
@@ -1278,8 +1288,7 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
             body = zstd_store_frame_wg((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, s_w);
             break;
         case SB_CODEC_SNAPPY:
-            __syncthreads();
-            body = snappy_store_wg((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9);
+            body = snappy_compress_block_wg((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, sA, s_w);
             break;
         case SB_CODEC_LZ4: {  // Basic(Lz4) over the raw index bytes (integer/mod.rs:55-58)
             __syncthreads();
@@ -3756,7 +3765,7 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
             if (codec == SB_CODEC_ZSTD) {
                 sz = zstd_store_frame_wg(vals, (uint32_t)(N * W), blk + 9, s_w);
             } else if (codec == SB_CODEC_SNAPPY) {
-                sz = snappy_store_wg(vals, (uint32_t)(N * W), blk + 9);
+                sz = snappy_compress_block_wg(vals, (uint32_t)(N * W), blk + 9, sA, &s_sz);
             } else {
                 uint32_t z = 0;
                 if (threadIdx.x < 64) z = lz4_compress_block(vals, (uint32_t)(N * W), blk + 9, sA, a.flags);
@@ -4019,10 +4028,9 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
         } else {
             if (bc == SB_CODEC_ZSTD) return zstd_store_frame_wg(src, n, dst, tab);
         }
-        if (bc == SB_CODEC_SNAPPY) return snappy_store_wg(src, n, dst);
         uint32_t sz = 0;
         if (threadIdx.x < 64)
-            sz = (a.flags & SB_WRITE_LZ4_EXACT) ? lz4_compress_wave(src, n, dst, tab) : lz4_compress_wave_fast<SB_LZ4_HB, 13>(src, n, dst, sh.lz);
+            sz = bc == SB_CODEC_SNAPPY ? snappy_compress_wave<SB_LZ4_HB, 13>(src, n, dst, sh.lz) : (a.flags & SB_WRITE_LZ4_EXACT) ? lz4_compress_wave(src, n, dst, tab) : lz4_compress_wave_fast<SB_LZ4_HB, 13>(src, n, dst, sh.lz);
         if (threadIdx.x == 0) s_sz = sz;
         __syncthreads();
         return s_sz;

@@ -1029,4 +1029,156 @@ __device__ uint32_t lz4_compress_wave_fast(const uint8_t* src, uint32_t n, uint8
     return outp + lit;
 }
 
+
+// ------------------------------------------------------------------------------------------------ Snappy encode
+// Raw Snappy stream (what snap::raw::Encoder emits and snap::raw::Decoder / any Snappy library reads; reference call
+// sites src/compression/basic.rs:137-152 / :99-106): uvarint(uncompressed length), then literal and copy elements.
+// The parse is the LZ4 matcher's (64 probe positions per step over the LDS ring); only the element syntax differs:
+//   literal: tag (len-1) << 2 for len <= 60, else tag (59 + nb) << 2 followed by nb little-endian bytes of len-1
+//   copy1  : len 4..11, offset < 2048: ((off >> 8) << 5) | ((len - 4) << 2) | 1, off & 0xFF
+//   copy2  : len 1..64: ((len - 1) << 2) | 2, off lo, off hi      (longer matches: several copies)
+__device__ __forceinline__ uint32_t snappy_lit_head(uint32_t lit) {   // bytes of a literal element's tag (lit >= 1)
+    const uint32_t m = lit - 1;
+    return m < 60 ? 1u : m < (1u << 8) ? 2u : m < (1u << 16) ? 3u : m < (1u << 24) ? 4u : 5u;
+}
+template <class P>
+__device__ __forceinline__ uint32_t snappy_put_lit_head(P o, uint32_t lit) {
+    const uint32_t m = lit - 1;
+    if (m < 60) {
+        o[0] = (uint8_t)(m << 2);
+        return 1;
+    }
+    const uint32_t nb = m < (1u << 8) ? 1u : m < (1u << 16) ? 2u : m < (1u << 24) ? 3u : 4u;
+    o[0] = (uint8_t)((59 + nb) << 2);
+    for (uint32_t k = 0; k < nb; k++) o[1 + k] = (uint8_t)(m >> (8 * k));
+    return 1 + nb;
+}
+// the copy elements of one match: full 64-byte copies first (60 when 65..67 bytes remain, so that the rest is >= 4)
+__device__ __forceinline__ uint32_t snappy_copy_bytes(uint32_t ml, uint32_t off) {
+    uint32_t sz = 0;
+    while (ml >= 68) { sz += 3; ml -= 64; }
+    if (ml > 64) { sz += 3; ml -= 60; }
+    return sz + ((ml < 12 && off < 2048) ? 2u : 3u);
+}
+template <class P>
+__device__ __forceinline__ uint32_t snappy_put_copies(P o, uint32_t ml, uint32_t off) {
+    uint32_t k = 0;
+    while (ml >= 68) {
+        o[k++] = (uint8_t)((63u << 2) | 2u); o[k++] = (uint8_t)off; o[k++] = (uint8_t)(off >> 8);
+        ml -= 64;
+    }
+    if (ml > 64) {
+        o[k++] = (uint8_t)((59u << 2) | 2u); o[k++] = (uint8_t)off; o[k++] = (uint8_t)(off >> 8);
+        ml -= 60;
+    }
+    if (ml < 12 && off < 2048) {
+        o[k++] = (uint8_t)(((off >> 8) << 5) | ((ml - 4) << 2) | 1u); o[k++] = (uint8_t)off;
+    } else {
+        o[k++] = (uint8_t)(((ml - 1) << 2) | 2u); o[k++] = (uint8_t)off; o[k++] = (uint8_t)(off >> 8);
+    }
+    return k;
+}
+
+// Compress src[0, n) into dst (capacity >= 32 + n + n / 6); executed by ONE wave64; returns the stream size.
+template <int HB, int RB>
+__device__ uint32_t snappy_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
+    constexpr uint32_t R = 1u << RB, RWM = R / 4 - 1;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t outp = 0, on = 0;
+    {
+        uint32_t v = n;
+        while (v >= 0x80) {
+            if (lane == 0) dst[outp] = (uint8_t)(v | 0x80);
+            v >>= 7;
+            outp++;
+        }
+        if (lane == 0) dst[outp] = (uint8_t)v;
+        outp++;
+    }
+    auto flush_out = [&]() {
+        wave_sync();
+        for (uint32_t k = lane; k < on; k += 64) dst[outp + k] = L.out[k];
+        outp += on;
+        on = 0;
+        wave_sync();
+    };
+    auto put_literal = [&](uint32_t from, uint32_t lit) {   // wave-wide literal element straight to dst
+        if (!lit) return;
+        if (lane == 0) snappy_put_lit_head(dst + outp, lit);
+        outp += snappy_lit_head(lit);
+        wave_copy_g2g(dst + outp, src + from, lit);
+        outp += lit;
+    };
+    uint32_t anchor = 0;
+    if (n >= 16) {
+        LzMatcher<HB, RB> mt(L, src, n);
+        mt.init();
+        mt.begin_chunk(0, n - 4, n);
+        while (mt.next()) {
+            const bool chosen = (mt.C >> lane) & 1;
+            uint32_t lit_start_v = mt.anchor;
+            {
+                const uint64_t below = mt.C & ((1ull << lane) - 1);
+                const uint32_t prevl = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                const uint32_t pe = __shfl(mt.p + mt.mlen, prevl, 64);
+                if (below) lit_start_v = pe;
+            }
+            const uint32_t lit = mt.p - lit_start_v, off = mt.p - mt.cand;
+            uint32_t sz = 0;
+            if (chosen) sz = (lit ? snappy_lit_head(lit) + lit : 0u) + snappy_copy_bytes(mt.mlen, off);
+            const uint64_t big = __ballot(chosen && (lit > LZE_LIT_LANE || mt.mlen > 256));
+            const uint32_t incl_sz = wave_scan_dpp(sz);
+            const uint32_t out_off_v = incl_sz - sz;
+            const uint32_t run = rdlane(incl_sz, 63);
+            if (!big && run <= LZE_OUT) {
+                if (on + run > LZE_OUT) flush_out();
+                if (chosen) {
+                    uint8_t* o = L.out + on + out_off_v;
+                    uint32_t k = 0;
+                    if (lit) {
+                        k = snappy_put_lit_head(o, lit);
+                        for (uint32_t i = 0; i < lit; i += 8) {   // (<= 48 bytes back: in the ring)
+                            const uint64_t v = lds_rd8_ring(L.ring, (lit_start_v + i) & (R - 1), RWM);
+                            const uint32_t nb = min(8u, lit - i);
+#pragma unroll
+                            for (uint32_t b = 0; b < 8; b++)
+                                if (b < nb) o[k + b] = (uint8_t)(v >> (8 * b));
+                            k += nb;
+                        }
+                    }
+                    snappy_put_copies(o + k, mt.mlen, off);
+                }
+                on += run;
+                wave_sync();
+            } else {
+                flush_out();
+                uint64_t m = mt.C;
+                while (m) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t pl = mt.base + l * mt.stride;
+                    const uint32_t s_ls = rdlane(lit_start_v, l), s_ml = rdlane(mt.mlen, l), s_off = pl - rdlane(mt.cand, l);
+                    put_literal(s_ls, pl - s_ls);
+                    // copies: the 64-byte ones lane-parallel, the tail by lane 0
+                    const uint32_t full = (s_ml - 4) / 64;   // 64-byte copies that leave a rest of 4..67 bytes
+                    const uint32_t rest = s_ml - 64 * full;
+                    for (uint32_t k = lane; k < full; k += 64) {
+                        uint8_t* o = dst + outp + 3 * k;
+                        o[0] = (uint8_t)((63u << 2) | 2u); o[1] = (uint8_t)s_off; o[2] = (uint8_t)(s_off >> 8);
+                    }
+                    outp += 3 * full;
+                    if (lane == 0) snappy_put_copies(dst + outp, rest, s_off);
+                    outp += snappy_copy_bytes(rest, s_off);
+                }
+            }
+            mt.advance();
+        }
+        anchor = mt.anchor;
+    }
+    flush_out();
+    put_literal(anchor, n - anchor);
+    wave_stores_visible();
+    return outp;
+}
+
 }  // namespace sb

@@ -1,8 +1,9 @@
 """GPU parity for Snappy pages (codec id 3, src/compression/basic.rs:99-106,137-152).
 Decode: pages are built from the oracle's None pages by re-compressing every block with the real
 libsnappy (through pyarrow), so the device decoder sees genuine copy-1/2/4 elements; the result must
-equal the oracle's decode.  Encode: the device writes literal-only Snappy streams — format-valid
-(libsnappy and the oracle read them back), not byte-identical to the `snap` crate (unpinned upstream)."""
+equal the oracle's decode.  Encode: the device's Snappy streams come from the LZ4 matcher with Snappy's element
+syntax (strawboat_amd/csrc/sb_lz4.h snappy_compress_wave) — format-valid (libsnappy, the oracle and the device read
+them back) and compressed, not byte-identical to the `snap` crate (unpinned upstream)."""
 import numpy as np
 import pytest
 
@@ -87,3 +88,58 @@ def test_snappy_encode_is_readable(gpu_ctx):
     csize = int.from_bytes(page[1:5], "little")
     raw = pa.Codec("snappy").decompress(page[9:9 + csize], decompressed_size=8000, asbytes=True)
     assert raw == col["values"].tobytes()
+
+
+def _shapes():
+    from tests.test_gpu_lz4 import SHAPES
+    return SHAPES
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _shapes()])
+@pytest.mark.parametrize("page", [None, 8192])
+def test_snappy_encoder_compresses(gpu_ctx, name, page):
+    """every block shape of the LZ4 encoder tests: libsnappy (pyarrow) decodes each page's stream to the input, the oracle
+    and the device decode the pages, and the stream is not much larger than the oracle's greedy Snappy matcher's"""
+    pa = pytest.importorskip("pyarrow")
+    data = dict(_shapes())[name]
+    if data.size == 0:
+        pytest.skip("encode_chunk on an empty chunk panics upstream")
+    col = dict(ptype=S.T_U8, nullable=False, rows=int(data.size), values=np.ascontiguousarray(data, np.uint8), validity=None, offsets=None)
+    enc = gpu_encode(gpu_ctx, col, max_page_size=page, default_compression=S.SNAPPY)
+    pages, metas = enc.pages_numpy(), enc.metas_array()
+    want_pages, want_metas = gen.oracle_write(col, max_page_size=page, default_compression=S.SNAPPY)
+    assert np.array_equal(metas[:, 1], want_metas[:, 1])
+    off = total = 0
+    for length, rows in metas:
+        assert pages[off] == S.SNAPPY and int.from_bytes(bytes(pages[off + 5:off + 9]), "little") == rows
+        assert int.from_bytes(bytes(pages[off + 1:off + 5]), "little") == length - 9
+        out = pa.Codec("snappy").decompress(bytes(pages[off + 9:off + int(length)]), decompressed_size=int(rows), asbytes=True)
+        assert out == bytes(data[total:total + int(rows)]), "libsnappy decodes the device's stream to something else"
+        off += int(length)
+        total += int(rows)
+    got = gen.oracle_read(col, pages, metas)
+    assert np.array_equal(got["values"], data)
+    back = gpu_decode(gpu_ctx, col, pages, metas)
+    assert np.array_equal(back.values_numpy(), data)
+    if data.size >= 4096:
+        assert pages.size <= 1.3 * want_pages.size + 64 * metas.shape[0], (pages.size, want_pages.size)
+
+
+def test_snappy_index_blocks_and_binary(gpu_ctx):
+    """Snappy as the default under the adaptive selector: Dict pages whose u32 indices become Snappy blocks, binary Basic
+    pages (offsets block + values block), nested exception blocks"""
+    for col, kw in ((gen.prim(S.T_I64, 40_000, uniq=300, runs=2), dict(max_page_size=5000, ratio=2.0)),
+                    (gen.binary(30_000, uniq=300, null_density=0.1, zipf=1.3), dict(max_page_size=4096)),
+                    (gen.prim(S.T_F64, 30_000, uniq=100, runs=5), dict(max_page_size=8192, force_codec=S.DICT, force_index_codec=S.SNAPPY))):
+        enc = gpu_encode(gpu_ctx, col, default_compression=S.SNAPPY, **kw)
+        pages, metas = enc.pages_numpy(), enc.metas_array()
+        wp, wm = gen.oracle_write(col, default_compression=S.SNAPPY, **kw)
+        want = gen.oracle_read(col, wp, wm)
+        got = gen.oracle_read(col, pages, metas)
+        for k in ("values", "validity", "offsets"):
+            assert np.array_equal(got[k], want[k]), k
+        assert np.array_equal(S.stat_column(col["ptype"], col["nullable"], pages, metas)[0],
+                              S.stat_column(col["ptype"], col["nullable"], wp, wm)[0])
+        back = gpu_decode(gpu_ctx, col, pages, metas)
+        assert np.array_equal(back.values_numpy(), want["values"])
+        assert pages.size <= 1.3 * wp.size + 64 * metas.shape[0]

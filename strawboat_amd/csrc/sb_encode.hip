@@ -118,7 +118,11 @@ struct EncodeArgs {
     uint32_t* lzc_count;
     uint8_t* lzc_pool;              // one slot of LZC_SLOT bytes per chunk
     uint32_t lzc_cap;
+    uint32_t lzc_chunk;             // chunk bytes of this call: LZC_CH (LZ4) or ZPAR_CH (Zstd blocks, one wave each)
+    uint8_t* zpar_scratch;          // Zstd: encoder scratch of the chunk waves (ZPAR_WAVES x zstd_scratch_bytes(ZPAR_CH))
 };
+constexpr uint32_t ZPAR_CH = 32768;      // a Zstd frame's blocks when they are compressed by waves of their own
+constexpr uint32_t ZPAR_WAVES = 2048;
 constexpr uint32_t LZC_CH = 65536;                                         // chunk bytes (a multiple of 1024)
 constexpr uint32_t LZC_SLOT = (16 + LZC_CH + LZC_CH / 255 + 16 + 15) / 16 * 16;   // u32 size | u32 tail anchor | 8 pad | sequences
 struct LzChunkPlan { uint32_t base, n_a, n_b, pad; };   // chunks [base, base + n_a) = first block, then n_b of a binary page's values block
@@ -3983,8 +3987,10 @@ __device__ __forceinline__ LzBlocks lz4_page_blocks(const EncodeArgs& a, const E
 }
 // chunk by chunk (k_enc_lz4_plan / _chunks / _stitch) or as one block by one wave (k_enc_emit_lz4)?  A pure function of
 // the page, so that every kernel decides alike.
-__device__ __forceinline__ bool lz4_page_chunked(const EncodeArgs& a, int32_t bc, uint32_t page, const LzBlocks& b) {
-    return a.lzc_plan && page < a.n_pages && bc == SB_CODEC_LZ4 && !(a.flags & SB_WRITE_LZ4_EXACT) && max(b.n_a, b.n_b) > LZC_CH;
+__device__ __forceinline__ bool lz4_page_chunked(const EncodeArgs& a, int32_t bc, uint32_t page, const LzBlocks& b, uint64_t zst_off = ~0ull) {
+    if (!a.lzc_plan || page >= a.n_pages || max(b.n_a, b.n_b) <= a.lzc_chunk) return false;
+    if (bc == SB_CODEC_LZ4) return !(a.flags & SB_WRITE_LZ4_EXACT) && a.lzc_chunk == LZC_CH;
+    return bc == SB_CODEC_ZSTD && a.zpar_scratch && zst_off != ~0ull && a.lzc_chunk == ZPAR_CH;
 }
 
 template <bool ZSTD>
@@ -4005,7 +4011,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
     if (ZSTD != (bc == SB_CODEC_ZSTD && p.zst_off != ~0ull)) return;   // the other instance's page
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
-    if (!ZSTD && a.lzc_plan && lz4_page_chunked(a, bc, page, lz4_page_blocks(a, c, p))) return;   // compressed chunk by chunk
+    if (a.lzc_plan && lz4_page_chunked(a, bc, page, lz4_page_blocks(a, c, p), p.zst_off)) return;   // compressed chunk by chunk
     uint8_t* slot = page_slot(a, c, p);
     const uint64_t N = p.rows;
     uint64_t pos = 0;
@@ -4090,15 +4096,15 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
 // plan: def levels + staged first block + the chunk list (one workgroup per page).
 __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
     __shared__ uint32_t s_base;
-    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] == 0) return;
+    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] + a.codec_counts[SB_CODEC_ZSTD] == 0) return;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     const int32_t bc = codec_of(a, p, page);
-    if (bc != SB_CODEC_LZ4) return;
+    if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD) return;
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     const LzBlocks b = lz4_page_blocks(a, c, p);
-    if (!lz4_page_chunked(a, bc, page, b)) return;
+    if (!lz4_page_chunked(a, bc, page, b, p.zst_off)) return;
     const uint64_t N = p.rows;
     if (c.nullable) {
         uint8_t* bits = def_header(page_slot(a, c, p), N);
@@ -4125,7 +4131,7 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
                 stu64(stage + i * 8, ldu64(offs + i * 8) - b.first);
         }
     }
-    const uint32_t na = (b.n_a + LZC_CH - 1) / LZC_CH, nb = (b.n_b + LZC_CH - 1) / LZC_CH;
+    const uint32_t na = (b.n_a + a.lzc_chunk - 1) / a.lzc_chunk, nb = (b.n_b + a.lzc_chunk - 1) / a.lzc_chunk;
     if (threadIdx.x == 0) {
         uint32_t base = atomicAdd(a.lzc_count, na + nb);
         if (base + na + nb > a.lzc_cap) {   // (offsets that run past values_len)
@@ -4149,6 +4155,7 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
 #endif
 __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
     __shared__ Lz4EncLds<SB_LZC_HB, 13> L;
+    if (a.lzc_chunk != LZC_CH) return;   // (a call's chunks are all LZ4 chunks or all Zstd blocks)
     const uint32_t total = min(*a.lzc_count, a.lzc_cap);
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
         const LzChunkDesc d = a.lzc_list[i];
@@ -4168,6 +4175,63 @@ __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
             stu32(slot + 4, anchor);
         }
     }
+}
+
+// Zstd: the same plan, with the frame's BLOCKS (32 KiB) as chunks — a frame is a header followed by self-delimiting
+// blocks, and this encoder's blocks carry no state into each other, so they are compressed by waves of their own (the
+// serial part of a block, its FSE state chain, is what bounds a wave; 16 waves per 512 KiB page instead of one).
+__global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
+    __shared__ ZEncLds Z;
+    if (a.lzc_chunk != ZPAR_CH) return;
+    const uint32_t total = min(*a.lzc_count, a.lzc_cap);
+    uint8_t* scratch = a.zpar_scratch + (uint64_t)blockIdx.x * zstd_scratch_bytes(ZPAR_CH);
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        const LzChunkDesc d = a.lzc_list[i];
+        const EncPage p = get_page(a, d.page);
+        const EncCol c = get_col(a, p.col);
+        const LzBlocks b = lz4_page_blocks(a, c, p);
+        const bool second = d.idx >> 31;
+        const uint8_t* src = second ? b.src_b : b.src_a;
+        const uint32_t n = second ? b.n_b : b.n_a;
+        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * ZPAR_CH, c1 = min(n, c0 + ZPAR_CH);
+        uint8_t* slot = a.lzc_pool + (uint64_t)i * LZC_SLOT;
+        wave_sync();
+        const uint32_t len = zstd_compress_block_alone(src, n, c0, c1, slot + 16, Z, scratch, ZPAR_CH);
+        if (threadIdx.x == 0) stu32(slot, len);
+        wave_stores_visible();
+    }
+}
+
+// frame header + the blocks [chunk0, chunk0 + nch) of src[0, n) back to back; returns the frame size.  sh: 2 * WG + 8 words.
+__device__ uint32_t zstd_stitch_frame(const EncodeArgs& a, uint32_t n, uint32_t chunk0, uint32_t nch, uint8_t* dst, uint32_t* sh) {
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t *s_off = sh, *s_len = sh + WG, *s_w = sh + 2 * WG;
+    if (t == 0) ze_frame_header(dst, n);
+    uint32_t run = ze_frame_header_bytes(n);
+    if (nch == 0) {   // an empty buffer: one empty raw block, last
+        if (t == 0) { dst[run] = 1; dst[run + 1] = 0; dst[run + 2] = 0; }
+        return run + 3;
+    }
+    for (uint32_t b0 = 0; b0 < nch; b0 += WG) {
+        const uint32_t k = b0 + t;
+        const uint32_t len = k < nch ? ldu32(a.lzc_pool + (uint64_t)(chunk0 + k) * LZC_SLOT) : 0u;
+        const uint32_t isum = wave_scan_dpp(len);
+        if (lane == 63) s_w[w] = isum;
+        __syncthreads();
+        uint32_t at = run + isum - len;
+        for (uint32_t q = 0; q < WG / 64; q++)
+            if (q < w) at += s_w[q];
+        s_off[t] = at;
+        s_len[t] = len;
+        uint32_t tot = 0;
+        for (uint32_t q = 0; q < WG / 64; q++) tot += s_w[q];
+        __syncthreads();
+        run += tot;
+        const uint32_t cnt = min((uint32_t)WG, nch - b0);
+        for (uint32_t j = 0; j < cnt; j++) wg_copy(dst + s_off[j], a.lzc_pool + (uint64_t)(chunk0 + b0 + j) * LZC_SLOT + 16, s_len[j]);
+        __syncthreads();
+    }
+    return run;
 }
 
 // joins the chunks [chunk0, chunk0 + nch) of the block src[0, n) at dst; returns the block size.  sh: 5 * WG + 8 words.
@@ -4255,28 +4319,32 @@ __device__ uint32_t lz4_stitch_block(const EncodeArgs& a, const uint8_t* src, ui
 
 __global__ void __launch_bounds__(WG) k_enc_lz4_stitch(EncodeArgs a) {
     __shared__ uint32_t sh[5 * WG + 8];
-    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] == 0) return;
+    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] + a.codec_counts[SB_CODEC_ZSTD] == 0) return;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const LzChunkPlan pl = a.lzc_plan[page];
     if (pl.n_a + pl.n_b == 0) return;
     const EncPage p = get_page(a, page);
     const EncCol c = get_col(a, p.col);
     const LzBlocks b = lz4_page_blocks(a, c, p);
+    const bool zstd = a.lzc_chunk == ZPAR_CH;
+    const uint32_t codec = zstd ? SB_CODEC_ZSTD : SB_CODEC_LZ4;
     uint8_t* slot = page_slot(a, c, p);
     const uint64_t N = p.rows;
     const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
     uint8_t* blk = slot + pos;
-    const uint32_t s1 = lz4_stitch_block(a, b.src_a, b.n_a, pl.base, pl.n_a, blk + 9, sh);
-    if (threadIdx.x == 0) put_hdr9(blk, SB_CODEC_LZ4, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
+    const uint32_t s1 = zstd ? zstd_stitch_frame(a, b.n_a, pl.base, pl.n_a, blk + 9, sh)
+                             : lz4_stitch_block(a, b.src_a, b.n_a, pl.base, pl.n_a, blk + 9, sh);
+    if (threadIdx.x == 0) put_hdr9(blk, codec, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
     uint64_t length = pos + 9 + s1;
     if (b.src_b) {
         uint8_t* b2 = blk + 9 + s1;
-        const uint32_t s2 = lz4_stitch_block(a, b.src_b, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh);
-        if (threadIdx.x == 0) put_hdr9(b2, SB_CODEC_LZ4, s2, b.n_b);
+        const uint32_t s2 = zstd ? zstd_stitch_frame(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh)
+                                 : lz4_stitch_block(a, b.src_b, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh);
+        if (threadIdx.x == 0) put_hdr9(b2, codec, s2, b.n_b);
         length += 9 + s2;
     }
     if (threadIdx.x == 0) {
-        EncOut o{length, 0, slot, SB_CODEC_LZ4, 0};
+        EncOut o{length, 0, slot, codec, 0};
         a.outs[page] = o;
     }
 }
@@ -4538,8 +4606,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
 
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
     // LZ4 blocks of more than LZC_CH bytes are compressed chunk by chunk (flat pages, the matcher that is free to choose)
-    const bool lz_possible = !(opts->flags & SB_WRITE_LZ4_EXACT) &&
-                             (host_codec == SB_CODEC_LZ4 || (adaptive && opts->default_compression == SB_CODEC_LZ4));
+    const bool zs_possible = host_codec == SB_CODEC_ZSTD || (adaptive && opts->default_compression == SB_CODEC_ZSTD);
+    const bool lz_possible = zs_possible || (!(opts->flags & SB_WRITE_LZ4_EXACT) &&
+                             (host_codec == SB_CODEC_LZ4 || (adaptive && opts->default_compression == SB_CODEC_LZ4)));
+    const uint64_t lz_chunk = zs_possible ? ZPAR_CH : LZC_CH;
     uint64_t lz_cap = 0;
     bool lz_any = false;
     for (uint64_t i = 0; i < n; i++) {
@@ -4579,12 +4649,12 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 const uint64_t N = c.page_rows ? c.page_rows[q] : std::min<uint64_t>(ps, c.rows - r);
                 r += N;
                 const uint64_t fb = first_block(N);
-                lz_cap += (fb + LZC_CH - 1) / LZC_CH;
-                lz_any |= fb > LZC_CH;
+                lz_cap += (fb + lz_chunk - 1) / lz_chunk;
+                lz_any |= fb > lz_chunk;
             }
             if (bin) {
-                lz_cap += c.values_len / LZC_CH + np + 1;
-                lz_any |= c.values_len > LZC_CH;
+                lz_cap += c.values_len / lz_chunk + np + 1;
+                lz_any |= c.values_len > lz_chunk;
             }
         }
     }
@@ -4813,6 +4883,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     scratch_off = align_up(scratch_off, 16);
     const size_t lz_pool_off = scratch_off;
     scratch_off += (size_t)lz_cap * LZC_SLOT;
+    const size_t zpar_off = scratch_off;
+    const uint32_t zpar_waves = (uint32_t)std::min<uint64_t>(lz_cap, ZPAR_WAVES);
+    if (lz_cap && zs_possible) scratch_off += (size_t)zpar_waves * zstd_scratch_bytes(ZPAR_CH);
     if (!ensure(ctx, ctx->scratch, scratch_off + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(scratch) failed");
 
     uint8_t* tb = ctx->tables.p;
@@ -4843,6 +4916,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.lzc_list = (LzChunkDesc*)(tb + o_lzlist);
     a.lzc_pool = ctx->scratch.p + lz_pool_off;
     a.lzc_cap = (uint32_t)lz_cap;
+    a.lzc_chunk = (uint32_t)lz_chunk;
+    a.zpar_scratch = lz_cap && zs_possible ? ctx->scratch.p + zpar_off : nullptr;
     a.freq_count = (uint32_t*)(tb + o_freqcnt);
     a.codec_counts = (uint32_t*)(tb + o_freqcnt + 64);
     a.use_counts = 0;
@@ -4926,7 +5001,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     KScope k(ctx, "k_enc_lz4_plan");
                     k_enc_lz4_plan<<<(uint32_t)P, WG, 0, s>>>(aa);
                 }
-                {
+                if (aa.zpar_scratch) {
+                    KScope k(ctx, "k_enc_zstd_chunks");
+                    k_enc_zstd_chunks<<<zpar_waves, 64, 0, s>>>(aa);
+                } else {
                     KScope k(ctx, "k_enc_lz4_chunks");
                     k_enc_lz4_chunks<<<(uint32_t)std::min<uint64_t>(aa.lzc_cap, 1u << 20), 64, 0, s>>>(aa);
                 }

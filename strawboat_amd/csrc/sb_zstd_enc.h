@@ -277,353 +277,382 @@ __host__ __device__ __forceinline__ uint64_t zstd_scratch_bytes(uint64_t n) {
     const uint64_t b = n < ZE_BLOCK ? n : ZE_BLOCK;
     return 6 * ((b + 15) & ~15ull) + 256;
 }
-// Compress src[0, n) into dst as one Zstd frame (capacity >= n + 3 * ceil(n / 128 KiB) + 16); executed by ONE wave64.
-// `scratch` (HBM): zstd_scratch_bytes(n).  Returns the frame size.
-__device__ uint32_t zstd_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, ZEncLds& Z, uint8_t* scratch) {
+// One block of a frame: src[c0, c1) of the input src[0, n) -> 3-byte header + content at bh; returns its size.  The matcher
+// carries its history from the blocks before (ALONE = false, one wave walks the frame) or loads it itself (ALONE = true:
+// the blocks of a frame are compressed by waves of their own and concatenated — a frame's blocks are self-delimiting, and
+// this encoder's blocks never depend on each other's entropy tables or repeat offsets).  `scratch`: zstd_scratch_bytes(cap).
+template <bool ALONE, class MT>
+__device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32_t c1, bool last_block, uint8_t* bh, ZEncLds& Z,
+                             uint8_t* scratch, uint32_t blk_cap, MT& mt) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t o = 0;
+    const uint32_t blk = c1 - c0;
+    uint8_t* lits = scratch;                                   // <= blk_cap bytes
+    const uint32_t cap16 = (blk_cap + 15) & ~15u;
+    ZeSeq* seqs = (ZeSeq*)(scratch + cap16);                    // <= blk_cap / 4 records of 8 bytes
+    uint8_t* attempt = scratch + 3 * (size_t)cap16;              // the compressed block is built here
+    uint32_t total = 0;
     LZP_BEGIN
-    // ---- frame header: magic, single segment + frame content size (1 / 2 / 4 bytes as libzstd sizes it), no checksum
-    if (lane == 0) {
-        dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
-        if (n < 256) {
-            dst[4] = 0x20;
-            dst[5] = (uint8_t)n;
-        } else if (n < 65536 + 256) {
-            dst[4] = 0x60;
-            dst[5] = (uint8_t)(n - 256);
-            dst[6] = (uint8_t)((n - 256) >> 8);
-        } else {
-            dst[4] = 0xA0;
-            for (int k = 0; k < 4; k++) dst[5 + k] = (uint8_t)(n >> (8 * k));
+    uint32_t nseq = 0, nlit = 0;
+    uint32_t tail_from = c0;
+    if (blk >= 32) {
+        if (ALONE)
+            mt.begin_alone(c0, c1 - 12, c1 - 5);
+        else
+            mt.begin_chunk(c0, c1 - 12, c1 - 5);
+        LZP(8);
+        while (mt.next()) {
+            LZP(9);
+            // ---- record the chosen sequences of this step: literals [lit_start, p) + match
+            const bool chosen = (mt.C >> lane) & 1;
+            uint32_t lit_start = mt.anchor;
+            {
+                const uint64_t below = mt.C & ((1ull << lane) - 1);
+                const uint32_t prevl = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                const uint32_t pe = __shfl(mt.p + mt.mlen, prevl, 64);
+                if (below) lit_start = pe;
+            }
+            const uint32_t ll = chosen ? mt.p - lit_start : 0u;
+            // a match longer than 65535 is cut (the rest is found again as the next match)
+            uint32_t ml = mt.mlen;
+            const uint64_t longm = __ballot(chosen && ml > 65535u);
+            if (longm) {   // only the first such match of the step is kept; the step ends there
+                const uint32_t l0 = (uint32_t)__builtin_ctzll(longm);
+                mt.C &= (2ull << l0) - 1;
+                if (lane == l0) ml = 65535u;
+                mt.covered = rdlane(mt.p, l0) + 65535u;
+            }
+            const bool keep = (mt.C >> lane) & 1;
+            const uint32_t myll = keep ? ll : 0u;
+            const uint32_t incl = wave_scan_dpp(myll);
+            const uint32_t k = nseq + lane_rank(mt.C);
+            if (keep) {
+                ZeSeq r;
+                r.ll = myll;
+                r.ml = (uint16_t)ml;
+                r.off = (uint16_t)(mt.p - mt.cand);
+                seqs[k] = r;
+                uint8_t* w = lits + nlit + (incl - myll);
+                if (myll <= 64) {   // (at most 64 bytes back: in the matcher's ring, no HBM load)
+                    for (uint32_t i = 0; i < myll; i += 8) {
+                        const uint64_t v = lds_rd8_ring(Z.lz.ring, (lit_start + i) & (LzMatcher<12, 13>::R - 1), LzMatcher<12, 13>::RWM);
+                        if (myll - i >= 8) {
+                            stu64(w + i, v);
+                        } else {
+                            for (uint32_t b = 0; b < myll - i; b++) w[i + b] = (uint8_t)(v >> (8 * b));
+                        }
+                    }
+                }
+            }
+            uint64_t bigl = __ballot(keep && myll > 64);
+            while (bigl) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(bigl);
+                bigl &= bigl - 1;
+                wave_copy_g2g(lits + nlit + rdlane(incl - myll, l), src + rdlane(lit_start, l), rdlane(myll, l));
+            }
+            nlit += rdlane(incl, 63);
+            nseq += (uint32_t)__popcll(mt.C);
+            mt.advance();
+            LZP(10);
         }
+        tail_from = mt.anchor;
     }
-    o = n < 256 ? 6 : n < 65536 + 256 ? 7 : 9;
-    if (n == 0) {   // one empty raw block, last
-        if (lane == 0) { dst[o] = 1; dst[o + 1] = 0; dst[o + 2] = 0; }
-        return o + 3;
+    // trailing literals of the block
+    wave_copy_g2g(lits + nlit, src + tail_from, c1 - tail_from);
+    nlit += c1 - tail_from;
+    wave_stores_visible();   // lits / seqs are read back below
+    LZP(11);
+    LZP_CNT(16, nseq);
+    LZP_CNT(17, nlit);
+    // ---- the block: compressed if that is smaller, raw otherwise
+    uint8_t* body = attempt;
+    uint32_t csize = 0;
+    bool ok = (nseq > 0 || nlit > 64) && nlit / 2 + 2 * nseq < blk;   // (cheap lower bound of the compressed size)
+    if (ok) {
+        uint32_t q = 0;
+        // ---- literals section
+        for (uint32_t k = lane; k < 256; k += 64) Z.hist[k] = 0;
+        wave_sync();
+        {   // 16 bytes per lane and load (lits is 16-byte aligned scratch)
+            const uint32_t nvec = nlit >> 4;
+            for (uint32_t i = lane; i < nvec; i += 64) {
+                const u32x4 v = ldu128(lits + 16 * (size_t)i);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    atomicAdd(&Z.hist[w[k] & 255], 1u);
+                    atomicAdd(&Z.hist[(w[k] >> 8) & 255], 1u);
+                    atomicAdd(&Z.hist[(w[k] >> 16) & 255], 1u);
+                    atomicAdd(&Z.hist[w[k] >> 24], 1u);
+                }
+            }
+            for (uint32_t i = (nvec << 4) + lane; i < nlit; i += 64) atomicAdd(&Z.hist[ldu8(lits + i)], 1u);
+        }
+        wave_sync();
+        uint32_t maxs = 0;
+        for (uint32_t k = lane; k < 256; k += 64)
+            if (Z.hist[k]) maxs = max(maxs, k);
+        for (int d = 32; d > 0; d >>= 1) maxs = max(maxs, (uint32_t)__shfl_xor((int)maxs, d, 64));
+        uint32_t hbits = 0;
+        if (nlit >= 64 && maxs <= 128 && maxs >= 1) {
+            if (lane == 0) Z.misc[0] = ze_huf_build(Z, maxs);
+            wave_sync();
+            hbits = Z.misc[0];
+        }
+        bool huf = hbits != 0;
+        if (huf) {
+            // size estimate: the tree + the coded bits must beat raw
+            uint32_t est = 0;
+            for (uint32_t k = lane; k <= maxs; k += 64) est += Z.hist[k] * Z.hlen[k];
+            for (int d = 32; d > 0; d >>= 1) est += (uint32_t)__shfl_xor((int)est, d, 64);
+            const uint32_t coded = (est + 7) / 8 + 1 + (maxs + 1) / 2 + 16;
+            if (coded >= nlit || nlit > 262143u) huf = false;
+        }
+        if (huf) {
+            const bool four = nlit >= 256;
+            // header size: 3 bytes (sizes < 1024), 4 (< 16384), 5 (< 262144); single stream only in the 3-byte form
+            const uint32_t hsz = !four ? 3u : 5u;   // (the compressed size is not known yet: the widest form always fits)
+            uint8_t* lh = body + q;
+            uint32_t w = hsz;
+            // tree description: direct 4-bit weights of symbols 0 .. maxs - 1
+            if (lane == 0) {
+                lh[w] = (uint8_t)(127 + maxs);
+                for (uint32_t s = 0; s < maxs; s += 2) {
+                    const uint32_t w0 = Z.hlen[s] ? hbits + 1 - Z.hlen[s] : 0;
+                    const uint32_t w1 = (s + 1 < maxs && Z.hlen[s + 1]) ? hbits + 1 - Z.hlen[s + 1] : 0;
+                    lh[w + 1 + s / 2] = (uint8_t)((w0 << 4) | w1);
+                }
+            }
+            w += 1 + (maxs + 1) / 2;
+            const uint32_t tree_end = w;
+            if (four) {
+                const uint32_t seg = (nlit + 3) / 4;
+                uint32_t ssz[4];
+                w += 6;   // jump table
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t b0 = min(nlit, seg * j), b1 = min(nlit, seg * (j + 1));
+                    ssz[j] = ze_huf_stream(Z, lits + b0, b1 - b0, lh + w);
+                    w += ssz[j];
+                }
+                if (lane == 0)
+                    for (int j = 0; j < 3; j++) {
+                        lh[tree_end + 2 * j] = (uint8_t)ssz[j];
+                        lh[tree_end + 2 * j + 1] = (uint8_t)(ssz[j] >> 8);
+                    }
+                if (ssz[0] > 65535u || ssz[1] > 65535u || ssz[2] > 65535u) huf = false;
+            } else {
+                w += ze_huf_stream(Z, lits, nlit, lh + w);
+            }
+            const uint32_t comp = w - hsz;   // tree + jump table + streams
+            if (huf && comp < nlit && comp < 262144u) {
+                if (lane == 0) {
+                    if (!four) {            // type 2, size format 0: 10-bit sizes, single stream
+                        const uint32_t v = 2u | (0u << 2) | (nlit << 4) | (comp << 14);
+                        lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); lh[2] = (uint8_t)(v >> 16);
+                    } else {                // type 2, size format 3: 18-bit sizes, four streams
+                        const uint64_t v = 2ull | (3ull << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22);
+                        for (int k = 0; k < 5; k++) lh[k] = (uint8_t)(v >> (8 * k));
+                    }
+                }
+                q += w;
+            } else {
+                huf = false;
+            }
+        }
+        if (!huf) {   // raw literals
+            uint8_t* lh = body + q;
+            uint32_t hsz;
+            if (nlit < 32) {
+                hsz = 1;
+                if (lane == 0) lh[0] = (uint8_t)(nlit << 3);
+            } else if (nlit < 4096) {
+                hsz = 2;
+                if (lane == 0) { const uint32_t v = (nlit << 4) | (1u << 2); lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); }
+            } else {
+                hsz = 3;
+                if (lane == 0) { const uint32_t v = (nlit << 4) | (3u << 2); lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); lh[2] = (uint8_t)(v >> 16); }
+            }
+            wave_copy_g2g(lh + hsz, lits, nlit);
+            q += hsz + nlit;
+        }
+        LZP(12);
+        // ---- sequences section
+        uint8_t* sh = body + q;
+        uint32_t shdr;
+        if (nseq < 128) {
+            shdr = 1;
+            if (lane == 0) sh[0] = (uint8_t)nseq;
+        } else if (nseq < 0x7F00) {
+            shdr = 2;
+            if (lane == 0) { sh[0] = (uint8_t)((nseq >> 8) + 0x80); sh[1] = (uint8_t)nseq; }
+        } else {
+            shdr = 3;
+            if (lane == 0) { sh[0] = 0xFF; sh[1] = (uint8_t)(nseq - 0x7F00); sh[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+        }
+        q += shdr;
+        if (nseq) {
+            // The FSE state chain is serial (lane 0).  Everything else about a sequence — its three codes and the values of
+            // its extra bits — is prepared 64 sequences at a time by all lanes (one HBM round trip per batch instead of one
+            // per sequence), from the LAST sequence backwards.
+            ZeBits bs{sh + shdr + 1, 0, 0};
+            uint32_t s_ll = 0, s_of = 0, s_ml = 0;
+            if (lane == 0) sh[shdr] = 0;   // Symbol_Compression_Modes: predefined LL / OF / ML
+            auto init_state = [&](const uint16_t* st, const ZeSymTT* tt, uint32_t sym) -> uint32_t {
+                const uint32_t nb = (uint32_t)(tt[sym].delta_nb_bits + (1 << 15)) >> 16;
+                const uint32_t value = (nb << 16) - (uint32_t)tt[sym].delta_nb_bits;
+                return st[(value >> nb) + tt[sym].delta_find_state];
+            };
+            auto enc_sym = [&](uint32_t& state, const uint16_t* st, const ZeSymTT* tt, uint32_t sym) {
+                const uint32_t nb = (uint32_t)(state + tt[sym].delta_nb_bits) >> 16;
+                bs.add(state, nb);
+                state = st[(state >> nb) + tt[sym].delta_find_state];
+            };
+            for (uint32_t hi_k = nseq; hi_k > 0; hi_k -= min(hi_k, 64u)) {
+                const uint32_t cnt = min(hi_k, 64u);
+                if (lane < cnt) {
+                    const ZeSeq r = seqs[hi_k - 1 - lane];
+                    const uint32_t ofb = (uint32_t)r.off + 3;
+                    const uint32_t llc = ze_ll_code(r.ll), mlc = ze_ml_code((uint32_t)r.ml - 3);
+                    // (the code / bit-count tables live in HBM: looked up here, 64 at a time, not inside the serial loop)
+                    Z.sq_code[lane] = llc | (mlc << 6) | (ze_highbit(ofb) << 12) | ((uint32_t)ZE_LL_BITS[llc] << 17) | ((uint32_t)ZE_ML_BITS[mlc] << 22);
+                    Z.sq_ll[lane] = r.ll;
+                    Z.sq_ml[lane] = (uint32_t)r.ml - 3;
+                    Z.sq_of[lane] = ofb;
+                    Z.sq_tt[lane][0] = Z.of_tt[ze_highbit(ofb)];
+                    Z.sq_tt[lane][1] = Z.ml_tt[mlc];
+                    Z.sq_tt[lane][2] = Z.ll_tt[llc];
+                }
+                wave_sync();
+                if (lane == 0) {
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const uint32_t code = Z.sq_code[j], llc = code & 63, mlc = (code >> 6) & 63, ofc = (code >> 12) & 31;
+                        const uint32_t llb = (code >> 17) & 31, mlb = code >> 22;
+                        if (hi_k == nseq && j == 0) {   // the last sequence initialises the three states
+                            s_ll = init_state(Z.ll_st, Z.ll_tt, llc);
+                            s_of = init_state(Z.of_st, Z.of_tt, ofc);
+                            s_ml = init_state(Z.ml_st, Z.ml_tt, mlc);
+                        } else {
+                            // the three chains are independent: their transforms arrive with one LDS round trip, their new
+                            // states with a second one
+                            const ZeSymTT t_of = Z.sq_tt[j][0], t_ml = Z.sq_tt[j][1], t_ll = Z.sq_tt[j][2];
+                            const uint32_t nb_of = (uint32_t)(s_of + t_of.delta_nb_bits) >> 16;
+                            const uint32_t nb_ml = (uint32_t)(s_ml + t_ml.delta_nb_bits) >> 16;
+                            const uint32_t nb_ll = (uint32_t)(s_ll + t_ll.delta_nb_bits) >> 16;
+                            const uint32_t n_of = Z.of_st[(s_of >> nb_of) + t_of.delta_find_state];
+                            const uint32_t n_ml = Z.ml_st[(s_ml >> nb_ml) + t_ml.delta_find_state];
+                            const uint32_t n_ll = Z.ll_st[(s_ll >> nb_ll) + t_ll.delta_find_state];
+                            bs.add(s_of, nb_of);
+                            bs.add(s_ml, nb_ml);
+                            bs.add(s_ll, nb_ll);   // (<= 5 + 6 + 6 bits on top of < 8 pending)
+                            bs.flush();
+                            s_of = n_of;
+                            s_ml = n_ml;
+                            s_ll = n_ll;
+                        }
+                        bs.add(Z.sq_ll[j], llb);
+                        bs.add(Z.sq_ml[j], mlb);   // (<= 16 + 16 bits on top of < 8 pending)
+                        bs.flush();
+                        bs.add(Z.sq_of[j], ofc);
+                        bs.flush();
+                    }
+                }
+                wave_sync();
+            }
+            if (lane == 0) {
+                bs.add(s_ml, 6);
+                bs.flush();
+                bs.add(s_of, 5);
+                bs.flush();
+                bs.add(s_ll, 6);
+                uint8_t* e = bs.close();
+                Z.misc[1] = (uint32_t)(e - (sh + shdr));
+            }
+            wave_sync();
+            __builtin_amdgcn_s_waitcnt(0);
+            q += Z.misc[1];
+        }
+        csize = q;
+        ok = csize < blk;
+        LZP(13);
     }
-    // ---- FSE encoding tables of the predefined distributions (once per wave)
-    if (lane == 0) {
+    if (ok) {
+        if (lane == 0) {
+            const uint32_t v = (last_block ? 1u : 0u) | (2u << 1) | (csize << 3);
+            bh[0] = (uint8_t)v; bh[1] = (uint8_t)(v >> 8); bh[2] = (uint8_t)(v >> 16);
+        }
+        wave_stores_visible();
+        wave_copy_g2g(bh + 3, attempt, csize);
+        total = 3 + csize;
+    } else {   // raw block
+        body = bh + 3;
+        if (lane == 0) {
+            const uint32_t v = (last_block ? 1u : 0u) | (0u << 1) | (blk << 3);
+            bh[0] = (uint8_t)v; bh[1] = (uint8_t)(v >> 8); bh[2] = (uint8_t)(v >> 16);
+        }
+        wave_stores_visible();
+        wave_copy_g2g(body, src + c0, blk);
+        total = 3 + blk;
+    }
+    wave_stores_visible();
+    LZP(14);
+    LZP_END;
+    return total;
+}
+
+__device__ __forceinline__ uint32_t ze_frame_header(uint8_t* dst, uint32_t n) {   // by one lane; returns the header size
+    dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+    if (n < 256) {
+        dst[4] = 0x20;
+        dst[5] = (uint8_t)n;
+    } else if (n < 65536 + 256) {
+        dst[4] = 0x60;
+        dst[5] = (uint8_t)(n - 256);
+        dst[6] = (uint8_t)((n - 256) >> 8);
+    } else {
+        dst[4] = 0xA0;
+        for (int k = 0; k < 4; k++) dst[5 + k] = (uint8_t)(n >> (8 * k));
+    }
+    return n < 256 ? 6u : n < 65536 + 256 ? 7u : 9u;
+}
+__device__ __forceinline__ uint32_t ze_frame_header_bytes(uint32_t n) { return n < 256 ? 6u : n < 65536 + 256 ? 7u : 9u; }
+__device__ __forceinline__ void ze_tables(ZEncLds& Z) {   // FSE encoding tables of the predefined distributions (once per wave)
+    if ((threadIdx.x & 63) == 0) {
         uint8_t* spread = Z.lz.out;
         ze_build_ctable(ZE_LL_DEFAULT, 36, 6, Z.ll_st, Z.ll_tt, spread);
         ze_build_ctable(ZE_ML_DEFAULT, 53, 6, Z.ml_st, Z.ml_tt, spread);
         ze_build_ctable(ZE_OF_DEFAULT, 29, 5, Z.of_st, Z.of_tt, spread);
     }
     wave_sync();
+}
+
+// Compress src[0, n) into dst as one Zstd frame (capacity >= n + 3 * ceil(n / 128 KiB) + 16); executed by ONE wave64.
+// `scratch` (HBM): zstd_scratch_bytes(n).  Returns the frame size.
+__device__ uint32_t zstd_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, ZEncLds& Z, uint8_t* scratch) {
+    const uint32_t lane = threadIdx.x & 63;
+    // ---- frame header: magic, single segment + frame content size (1 / 2 / 4 bytes as libzstd sizes it), no checksum
+    if (lane == 0) ze_frame_header(dst, n);
+    uint32_t o = ze_frame_header_bytes(n);
+    if (n == 0) {   // one empty raw block, last
+        if (lane == 0) { dst[o] = 1; dst[o + 1] = 0; dst[o + 2] = 0; }
+        return o + 3;
+    }
+    ze_tables(Z);
     const uint32_t blk_cap = min(n, ZE_BLOCK);
-    uint8_t* lits = scratch;                                   // <= blk_cap bytes
-    const uint32_t cap16 = (blk_cap + 15) & ~15u;
-    ZeSeq* seqs = (ZeSeq*)(scratch + cap16);                    // <= blk_cap / 4 records of 8 bytes
-    uint8_t* attempt = scratch + 3 * (size_t)cap16;              // the compressed block is built here
     LzMatcher<12, 13> mt(Z.lz, src, n);
     mt.init();
     for (uint32_t c0 = 0; c0 < n; c0 += ZE_BLOCK) {
-        const uint32_t c1 = min(n, c0 + ZE_BLOCK), blk = c1 - c0;
-        const bool last_block = c1 == n;
-        uint32_t nseq = 0, nlit = 0;
-        uint32_t tail_from = c0;
-        if (blk >= 32) {
-            mt.begin_chunk(c0, c1 - 12, c1 - 5);
-            LZP(8);
-            while (mt.next()) {
-                LZP(9);
-                // ---- record the chosen sequences of this step: literals [lit_start, p) + match
-                const bool chosen = (mt.C >> lane) & 1;
-                uint32_t lit_start = mt.anchor;
-                {
-                    const uint64_t below = mt.C & ((1ull << lane) - 1);
-                    const uint32_t prevl = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-                    const uint32_t pe = __shfl(mt.p + mt.mlen, prevl, 64);
-                    if (below) lit_start = pe;
-                }
-                const uint32_t ll = chosen ? mt.p - lit_start : 0u;
-                // a match longer than 65535 is cut (the rest is found again as the next match)
-                uint32_t ml = mt.mlen;
-                const uint64_t longm = __ballot(chosen && ml > 65535u);
-                if (longm) {   // only the first such match of the step is kept; the step ends there
-                    const uint32_t l0 = (uint32_t)__builtin_ctzll(longm);
-                    mt.C &= (2ull << l0) - 1;
-                    if (lane == l0) ml = 65535u;
-                    mt.covered = rdlane(mt.p, l0) + 65535u;
-                }
-                const bool keep = (mt.C >> lane) & 1;
-                const uint32_t myll = keep ? ll : 0u;
-                const uint32_t incl = wave_scan_dpp(myll);
-                const uint32_t k = nseq + lane_rank(mt.C);
-                if (keep) {
-                    ZeSeq r;
-                    r.ll = myll;
-                    r.ml = (uint16_t)ml;
-                    r.off = (uint16_t)(mt.p - mt.cand);
-                    seqs[k] = r;
-                    uint8_t* w = lits + nlit + (incl - myll);
-                    if (myll <= 64) {   // (at most 64 bytes back: in the matcher's ring, no HBM load)
-                        for (uint32_t i = 0; i < myll; i += 8) {
-                            const uint64_t v = lds_rd8_ring(Z.lz.ring, (lit_start + i) & (LzMatcher<12, 13>::R - 1), LzMatcher<12, 13>::RWM);
-                            if (myll - i >= 8) {
-                                stu64(w + i, v);
-                            } else {
-                                for (uint32_t b = 0; b < myll - i; b++) w[i + b] = (uint8_t)(v >> (8 * b));
-                            }
-                        }
-                    }
-                }
-                uint64_t bigl = __ballot(keep && myll > 64);
-                while (bigl) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(bigl);
-                    bigl &= bigl - 1;
-                    wave_copy_g2g(lits + nlit + rdlane(incl - myll, l), src + rdlane(lit_start, l), rdlane(myll, l));
-                }
-                nlit += rdlane(incl, 63);
-                nseq += (uint32_t)__popcll(mt.C);
-                mt.advance();
-                LZP(10);
-            }
-            tail_from = mt.anchor;
-        }
-        // trailing literals of the block
-        wave_copy_g2g(lits + nlit, src + tail_from, c1 - tail_from);
-        nlit += c1 - tail_from;
-        wave_stores_visible();   // lits / seqs are read back below
-        LZP(11);
-        LZP_CNT(16, nseq);
-        LZP_CNT(17, nlit);
-        // ---- the block: compressed if that is smaller, raw otherwise
-        uint8_t* bh = dst + o;          // 3-byte block header
-        uint8_t* body = attempt;
-        uint32_t csize = 0;
-        bool ok = (nseq > 0 || nlit > 64) && nlit / 2 + 2 * nseq < blk;   // (cheap lower bound of the compressed size)
-        if (ok) {
-            uint32_t q = 0;
-            // ---- literals section
-            for (uint32_t k = lane; k < 256; k += 64) Z.hist[k] = 0;
-            wave_sync();
-            {   // 16 bytes per lane and load (lits is 16-byte aligned scratch)
-                const uint32_t nvec = nlit >> 4;
-                for (uint32_t i = lane; i < nvec; i += 64) {
-                    const u32x4 v = ldu128(lits + 16 * (size_t)i);
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        atomicAdd(&Z.hist[w[k] & 255], 1u);
-                        atomicAdd(&Z.hist[(w[k] >> 8) & 255], 1u);
-                        atomicAdd(&Z.hist[(w[k] >> 16) & 255], 1u);
-                        atomicAdd(&Z.hist[w[k] >> 24], 1u);
-                    }
-                }
-                for (uint32_t i = (nvec << 4) + lane; i < nlit; i += 64) atomicAdd(&Z.hist[ldu8(lits + i)], 1u);
-            }
-            wave_sync();
-            uint32_t maxs = 0;
-            for (uint32_t k = lane; k < 256; k += 64)
-                if (Z.hist[k]) maxs = max(maxs, k);
-            for (int d = 32; d > 0; d >>= 1) maxs = max(maxs, (uint32_t)__shfl_xor((int)maxs, d, 64));
-            uint32_t hbits = 0;
-            if (nlit >= 64 && maxs <= 128 && maxs >= 1) {
-                if (lane == 0) Z.misc[0] = ze_huf_build(Z, maxs);
-                wave_sync();
-                hbits = Z.misc[0];
-            }
-            bool huf = hbits != 0;
-            if (huf) {
-                // size estimate: the tree + the coded bits must beat raw
-                uint32_t est = 0;
-                for (uint32_t k = lane; k <= maxs; k += 64) est += Z.hist[k] * Z.hlen[k];
-                for (int d = 32; d > 0; d >>= 1) est += (uint32_t)__shfl_xor((int)est, d, 64);
-                const uint32_t coded = (est + 7) / 8 + 1 + (maxs + 1) / 2 + 16;
-                if (coded >= nlit || nlit > 262143u) huf = false;
-            }
-            if (huf) {
-                const bool four = nlit >= 256;
-                // header size: 3 bytes (sizes < 1024), 4 (< 16384), 5 (< 262144); single stream only in the 3-byte form
-                const uint32_t hsz = !four ? 3u : 5u;   // (the compressed size is not known yet: the widest form always fits)
-                uint8_t* lh = body + q;
-                uint32_t w = hsz;
-                // tree description: direct 4-bit weights of symbols 0 .. maxs - 1
-                if (lane == 0) {
-                    lh[w] = (uint8_t)(127 + maxs);
-                    for (uint32_t s = 0; s < maxs; s += 2) {
-                        const uint32_t w0 = Z.hlen[s] ? hbits + 1 - Z.hlen[s] : 0;
-                        const uint32_t w1 = (s + 1 < maxs && Z.hlen[s + 1]) ? hbits + 1 - Z.hlen[s + 1] : 0;
-                        lh[w + 1 + s / 2] = (uint8_t)((w0 << 4) | w1);
-                    }
-                }
-                w += 1 + (maxs + 1) / 2;
-                const uint32_t tree_end = w;
-                if (four) {
-                    const uint32_t seg = (nlit + 3) / 4;
-                    uint32_t ssz[4];
-                    w += 6;   // jump table
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t b0 = min(nlit, seg * j), b1 = min(nlit, seg * (j + 1));
-                        ssz[j] = ze_huf_stream(Z, lits + b0, b1 - b0, lh + w);
-                        w += ssz[j];
-                    }
-                    if (lane == 0)
-                        for (int j = 0; j < 3; j++) {
-                            lh[tree_end + 2 * j] = (uint8_t)ssz[j];
-                            lh[tree_end + 2 * j + 1] = (uint8_t)(ssz[j] >> 8);
-                        }
-                    if (ssz[0] > 65535u || ssz[1] > 65535u || ssz[2] > 65535u) huf = false;
-                } else {
-                    w += ze_huf_stream(Z, lits, nlit, lh + w);
-                }
-                const uint32_t comp = w - hsz;   // tree + jump table + streams
-                if (huf && comp < nlit && comp < 262144u) {
-                    if (lane == 0) {
-                        if (!four) {            // type 2, size format 0: 10-bit sizes, single stream
-                            const uint32_t v = 2u | (0u << 2) | (nlit << 4) | (comp << 14);
-                            lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); lh[2] = (uint8_t)(v >> 16);
-                        } else {                // type 2, size format 3: 18-bit sizes, four streams
-                            const uint64_t v = 2ull | (3ull << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22);
-                            for (int k = 0; k < 5; k++) lh[k] = (uint8_t)(v >> (8 * k));
-                        }
-                    }
-                    q += w;
-                } else {
-                    huf = false;
-                }
-            }
-            if (!huf) {   // raw literals
-                uint8_t* lh = body + q;
-                uint32_t hsz;
-                if (nlit < 32) {
-                    hsz = 1;
-                    if (lane == 0) lh[0] = (uint8_t)(nlit << 3);
-                } else if (nlit < 4096) {
-                    hsz = 2;
-                    if (lane == 0) { const uint32_t v = (nlit << 4) | (1u << 2); lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); }
-                } else {
-                    hsz = 3;
-                    if (lane == 0) { const uint32_t v = (nlit << 4) | (3u << 2); lh[0] = (uint8_t)v; lh[1] = (uint8_t)(v >> 8); lh[2] = (uint8_t)(v >> 16); }
-                }
-                wave_copy_g2g(lh + hsz, lits, nlit);
-                q += hsz + nlit;
-            }
-            LZP(12);
-            // ---- sequences section
-            uint8_t* sh = body + q;
-            uint32_t shdr;
-            if (nseq < 128) {
-                shdr = 1;
-                if (lane == 0) sh[0] = (uint8_t)nseq;
-            } else if (nseq < 0x7F00) {
-                shdr = 2;
-                if (lane == 0) { sh[0] = (uint8_t)((nseq >> 8) + 0x80); sh[1] = (uint8_t)nseq; }
-            } else {
-                shdr = 3;
-                if (lane == 0) { sh[0] = 0xFF; sh[1] = (uint8_t)(nseq - 0x7F00); sh[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
-            }
-            q += shdr;
-            if (nseq) {
-                // The FSE state chain is serial (lane 0).  Everything else about a sequence — its three codes and the values of
-                // its extra bits — is prepared 64 sequences at a time by all lanes (one HBM round trip per batch instead of one
-                // per sequence), from the LAST sequence backwards.
-                ZeBits bs{sh + shdr + 1, 0, 0};
-                uint32_t s_ll = 0, s_of = 0, s_ml = 0;
-                if (lane == 0) sh[shdr] = 0;   // Symbol_Compression_Modes: predefined LL / OF / ML
-                auto init_state = [&](const uint16_t* st, const ZeSymTT* tt, uint32_t sym) -> uint32_t {
-                    const uint32_t nb = (uint32_t)(tt[sym].delta_nb_bits + (1 << 15)) >> 16;
-                    const uint32_t value = (nb << 16) - (uint32_t)tt[sym].delta_nb_bits;
-                    return st[(value >> nb) + tt[sym].delta_find_state];
-                };
-                auto enc_sym = [&](uint32_t& state, const uint16_t* st, const ZeSymTT* tt, uint32_t sym) {
-                    const uint32_t nb = (uint32_t)(state + tt[sym].delta_nb_bits) >> 16;
-                    bs.add(state, nb);
-                    state = st[(state >> nb) + tt[sym].delta_find_state];
-                };
-                for (uint32_t hi_k = nseq; hi_k > 0; hi_k -= min(hi_k, 64u)) {
-                    const uint32_t cnt = min(hi_k, 64u);
-                    if (lane < cnt) {
-                        const ZeSeq r = seqs[hi_k - 1 - lane];
-                        const uint32_t ofb = (uint32_t)r.off + 3;
-                        const uint32_t llc = ze_ll_code(r.ll), mlc = ze_ml_code((uint32_t)r.ml - 3);
-                        // (the code / bit-count tables live in HBM: looked up here, 64 at a time, not inside the serial loop)
-                        Z.sq_code[lane] = llc | (mlc << 6) | (ze_highbit(ofb) << 12) | ((uint32_t)ZE_LL_BITS[llc] << 17) | ((uint32_t)ZE_ML_BITS[mlc] << 22);
-                        Z.sq_ll[lane] = r.ll;
-                        Z.sq_ml[lane] = (uint32_t)r.ml - 3;
-                        Z.sq_of[lane] = ofb;
-                        Z.sq_tt[lane][0] = Z.of_tt[ze_highbit(ofb)];
-                        Z.sq_tt[lane][1] = Z.ml_tt[mlc];
-                        Z.sq_tt[lane][2] = Z.ll_tt[llc];
-                    }
-                    wave_sync();
-                    if (lane == 0) {
-                        for (uint32_t j = 0; j < cnt; j++) {
-                            const uint32_t code = Z.sq_code[j], llc = code & 63, mlc = (code >> 6) & 63, ofc = (code >> 12) & 31;
-                            const uint32_t llb = (code >> 17) & 31, mlb = code >> 22;
-                            if (hi_k == nseq && j == 0) {   // the last sequence initialises the three states
-                                s_ll = init_state(Z.ll_st, Z.ll_tt, llc);
-                                s_of = init_state(Z.of_st, Z.of_tt, ofc);
-                                s_ml = init_state(Z.ml_st, Z.ml_tt, mlc);
-                            } else {
-                                // the three chains are independent: their transforms arrive with one LDS round trip, their new
-                                // states with a second one
-                                const ZeSymTT t_of = Z.sq_tt[j][0], t_ml = Z.sq_tt[j][1], t_ll = Z.sq_tt[j][2];
-                                const uint32_t nb_of = (uint32_t)(s_of + t_of.delta_nb_bits) >> 16;
-                                const uint32_t nb_ml = (uint32_t)(s_ml + t_ml.delta_nb_bits) >> 16;
-                                const uint32_t nb_ll = (uint32_t)(s_ll + t_ll.delta_nb_bits) >> 16;
-                                const uint32_t n_of = Z.of_st[(s_of >> nb_of) + t_of.delta_find_state];
-                                const uint32_t n_ml = Z.ml_st[(s_ml >> nb_ml) + t_ml.delta_find_state];
-                                const uint32_t n_ll = Z.ll_st[(s_ll >> nb_ll) + t_ll.delta_find_state];
-                                bs.add(s_of, nb_of);
-                                bs.add(s_ml, nb_ml);
-                                bs.add(s_ll, nb_ll);   // (<= 5 + 6 + 6 bits on top of < 8 pending)
-                                bs.flush();
-                                s_of = n_of;
-                                s_ml = n_ml;
-                                s_ll = n_ll;
-                            }
-                            bs.add(Z.sq_ll[j], llb);
-                            bs.add(Z.sq_ml[j], mlb);   // (<= 16 + 16 bits on top of < 8 pending)
-                            bs.flush();
-                            bs.add(Z.sq_of[j], ofc);
-                            bs.flush();
-                        }
-                    }
-                    wave_sync();
-                }
-                if (lane == 0) {
-                    bs.add(s_ml, 6);
-                    bs.flush();
-                    bs.add(s_of, 5);
-                    bs.flush();
-                    bs.add(s_ll, 6);
-                    uint8_t* e = bs.close();
-                    Z.misc[1] = (uint32_t)(e - (sh + shdr));
-                }
-                wave_sync();
-                __builtin_amdgcn_s_waitcnt(0);
-                q += Z.misc[1];
-            }
-            csize = q;
-            ok = csize < blk;
-            LZP(13);
-        }
-        if (ok) {
-            if (lane == 0) {
-                const uint32_t v = (last_block ? 1u : 0u) | (2u << 1) | (csize << 3);
-                bh[0] = (uint8_t)v; bh[1] = (uint8_t)(v >> 8); bh[2] = (uint8_t)(v >> 16);
-            }
-            wave_stores_visible();
-            wave_copy_g2g(bh + 3, attempt, csize);
-            o += 3 + csize;
-        } else {   // raw block
-            body = bh + 3;
-            if (lane == 0) {
-                const uint32_t v = (last_block ? 1u : 0u) | (0u << 1) | (blk << 3);
-                bh[0] = (uint8_t)v; bh[1] = (uint8_t)(v >> 8); bh[2] = (uint8_t)(v >> 16);
-            }
-            wave_stores_visible();
-            wave_copy_g2g(body, src + c0, blk);
-            o += 3 + blk;
-        }
-        wave_stores_visible();
-        LZP(14);
+        const uint32_t c1 = min(n, c0 + ZE_BLOCK);
+        o += ze_block<false>(src, n, c0, c1, c1 == n, dst + o, Z, scratch, blk_cap, mt);
     }
-    LZP_END;
     return o;
+}
+
+// One block [c0, c1) of the frame of src[0, n) compressed by a wave of its own (see ze_block) into `out`; returns its size.
+__device__ uint32_t zstd_compress_block_alone(const uint8_t* src, uint32_t n, uint32_t c0, uint32_t c1, uint8_t* out, ZEncLds& Z,
+                                              uint8_t* scratch, uint32_t blk_cap) {
+    ze_tables(Z);
+    LzMatcher<12, 13> mt(Z.lz, src, n);
+    mt.init();
+    return ze_block<true>(src, n, c0, c1, c1 == n, out, Z, scratch, blk_cap, mt);
 }
 
 }  // namespace sb

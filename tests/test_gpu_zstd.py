@@ -180,3 +180,34 @@ def test_zstd_ratio_on_golden_blocks(gpu_ctx):
     by = {n: (r, c, z) for n, r, c, z in rows}
     for n in ("abcd_x500", "i32_runs", "low_entropy_8k", "zipf_words", "zeros_70k", "f64_small_set"):
         assert by[n][1] < 0.75 * by[n][0], (n, by[n])
+
+
+@pytest.mark.parametrize("kind", ["zeros", "text", "random"])
+@pytest.mark.parametrize("n", [32768 + 1, 32768 + 31, 32768 + 32, 2 * 32768, 2 * 32768 + 5, 5 * 32768 - 3, 300_007])
+def test_zstd_frames_of_parallel_blocks(gpu_ctx, kind, n):
+    """buffers of more than one 32 KiB block: the frame's blocks are compressed by waves of their own (k_enc_zstd_chunks) and
+    concatenated behind one frame header; libzstd, the oracle and the device must read the frame back, whatever the size of
+    the last block"""
+    pa = pytest.importorskip("pyarrow")
+    from tests.test_gpu_encode import gpu_encode
+    rng = np.random.default_rng(n % 997)
+    if kind == "zeros":
+        data = np.zeros(n, np.uint8)
+    elif kind == "text":
+        words = [b"w%d" % i + b"y" * (i % 7) for i in range(200)]
+        data = np.frombuffer(b"".join(words[i] for i in rng.zipf(1.3, n // 3) % 200)[:n].ljust(n, b"."), np.uint8)
+    else:
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+    col = dict(ptype=S.T_U8, nullable=False, rows=n, values=data, validity=None, offsets=None)
+    enc = gpu_encode(gpu_ctx, col, default_compression=S.ZSTD)
+    pages, metas = enc.pages_numpy(), enc.metas_array()
+    assert metas.shape[0] == 1 and pages[0] == S.ZSTD
+    csize = int.from_bytes(bytes(pages[1:5]), "little")
+    assert csize == int(metas[0, 0]) - 9
+    raw = pa.Codec("zstd").decompress(bytes(pages[9:9 + csize]), decompressed_size=n).to_pybytes()
+    assert raw == bytes(data)
+    assert np.array_equal(gen.oracle_read(col, pages, metas)["values"], data)
+    assert np.array_equal(gpu_decode(gpu_ctx, col, pages, metas).values_numpy(), data)
+    assert csize <= n + 16 + 3 * (n // 32768 + 1)
+    if kind != "random":
+        assert csize < 0.5 * n

@@ -529,6 +529,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     }
     uint64_t* d_vlen = (uint64_t*)(tb + o_vlen);
 
+    a.sizes_only = sizes_only ? 1u : 0u;
     if (sizes_only) {
         if (P) launch_parse_sizes(ctx, a, d_vlen);
     } else {

@@ -130,6 +130,7 @@ struct DecodeArgs {
     uint32_t* freq_count;
     uint32_t freq_cap;
     uint32_t no_freq;      // second pass: an exceptions block never holds a Freq block (freq.rs:78-79)
+    uint32_t sizes_only;   // sb_read_columns_sizes: only what values_len depends on is inflated (nested index blocks)
 };
 
 }  // namespace sb

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
         if (codec == SB_CODEC_NONE) {
             if (d.csize != nbytes) FAIL(SB_ERR_OUT_OF_SPEC, 11);
         } else if (is_basic(codec)) {
-            push_job(a.jobs_a, a.job_counts, d.body, d.csize, infl, (uint32_t)nbytes, codec, p);
+            if (!a.sizes_only) push_job(a.jobs_a, a.job_counts, d.body, d.csize, infl, (uint32_t)nbytes, codec, p);
             d.src = infl;
         } else if (codec == SB_CODEC_ONEVALUE) {
             if (d.csize < 1) FAIL(SB_ERR_OUT_OF_SPEC, 12);
@@ -138,8 +138,8 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             const uint64_t obytes = (N + 1) * ow;
             if (codec == SB_CODEC_NONE) {
                 if (d.csize != obytes) FAIL(SB_ERR_OUT_OF_SPEC, 14);
-            } else {
-                push_job(a.jobs_a, a.job_counts, d.body, d.csize, infl, (uint32_t)obytes, codec, p);
+            } else {   // (the sizing pass reads the page's value bytes from the second header below: no need for the offsets)
+                if (!a.sizes_only) push_job(a.jobs_a, a.job_counts, d.body, d.csize, infl, (uint32_t)obytes, codec, p);
                 d.src = infl;
             }
             const uint8_t* h2 = d.body + d.csize;
@@ -185,8 +185,8 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             if (d.csize != N * w) FAIL(SB_ERR_OUT_OF_SPEC, 21);
         } else if (is_basic(codec)) {
             // inflate straight into the column's values buffer (integer/mod.rs:97-107)
-            push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec,
-                     p);
+            if (!a.sizes_only)
+                push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
             d.src = nullptr;  // nothing left for expand
         } else if (codec == SB_CODEC_ONEVALUE) {
             if (d.csize < w) FAIL(SB_ERR_IO, 22);
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
         } else if (codec == SB_CODEC_PATAS) {
             if (c.ptype == SB_TYPE_FLOAT32) FAIL(SB_ERR_NYI, 26);   // f32 Patas decode is broken upstream
             if (c.ptype != SB_TYPE_FLOAT64) FAIL(SB_ERR_OUT_OF_SPEC, 27);  // "Unknown compression codec Patas for integer"
-            push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
+            if (!a.sizes_only) push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
             d.src = nullptr;
         } else if (codec == SB_CODEC_FREQ) {  // top[w] | u32 rb_size | roaring | BLOCK<T exceptions>  (freq.rs:71-83)
             if (a.no_freq) FAIL(SB_ERR_OUT_OF_SPEC, 28);

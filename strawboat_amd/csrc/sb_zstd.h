@@ -39,6 +39,9 @@ struct ZWork {  // per-wave LDS workspace (~12 KB)
     LzSeqLds ring;   // output ring of the sequence executor (sb_lz4.h LzSeqExec)
     uint32_t t_llbase[36], t_mlbase[53];   // baseline / extra-bit tables (copies of the __constant__ ones: the serial
     uint8_t t_llbits[36], t_mlbits[53];    // sequence loop reads them with LDS latency, not a scalar-cache miss each)
+    // per FSE state: extra-bit count | baseline << 8 of the state's length code, so that the serial loop gets them with the
+    // state's entry in ONE LDS round trip (code -> table was a dependent second one)
+    uint32_t xll[512], xml[512];
 };
 constexpr uint32_t ZBW = 2048;
 
@@ -557,6 +560,23 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                 }
                 wsync();
                 if (wk->err) return 0;
+                {   // extras per state (all lanes); a state whose symbol is outside the code range makes the block invalid
+                    bool bad = false;
+                    for (uint32_t st = lane; st < (1u << wk->ll_log); st += 64) {
+                        const uint32_t c = wk->ll[st].symbol;
+                        if (c > 35) { bad = true; continue; }
+                        wk->xll[st] = (uint32_t)wk->t_llbits[c] | (wk->t_llbase[c] << 8);
+                    }
+                    for (uint32_t st = lane; st < (1u << wk->ml_log); st += 64) {
+                        const uint32_t c = wk->ml[st].symbol;
+                        if (c > 52) { bad = true; continue; }
+                        wk->xml[st] = (uint32_t)wk->t_mlbits[c] | (wk->t_mlbase[c] << 8);
+                    }
+                    for (uint32_t st = lane; st < (1u << wk->of_log); st += 64)
+                        if (wk->of[st].symbol > 31) bad = true;
+                    if (__ballot(bad)) ZERR(27);
+                    wsync();
+                }
                 bp = wk->nbatch;
                 const uint8_t* sb_ = bs + bp;
                 const uint32_t sn_ = bsize - bp;
@@ -576,42 +596,49 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                 };
                 refill_window(bitpos);
                 LZP(21);
-                if (lane == 0) {
+                // The sequence loop is a serial chain (three FSE states and one bit position), so it runs WAVE-UNIFORM: every
+                // lane computes the same values, the LDS reads go through v_readfirstlane, and the whole chain is scalar
+                // instructions (a lane-0-only loop is the same chain on the vector unit: ~4x the cycles per step).  Lane k
+                // keeps sequence k of the batch in registers: no LDS staging between decode and execute.
+                auto rfl = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                {
                     const uint8_t* wp = wk->bw - wk->bw_lo;
-                    sl = z_peek(wp, bitpos, (int)wk->ll_log);
-                    bitpos -= wk->ll_log;
-                    so = z_peek(wp, bitpos, (int)wk->of_log);
-                    bitpos -= wk->of_log;
-                    sm = z_peek(wp, bitpos, (int)wk->ml_log);
-                    bitpos -= wk->ml_log;
+                    const uint32_t lll = rfl(wk->ll_log), ofl = rfl(wk->of_log), mll = rfl(wk->ml_log);
+                    sl = rfl(z_peek(wp, bitpos, (int)lll));
+                    bitpos -= lll;
+                    so = rfl(z_peek(wp, bitpos, (int)ofl));
+                    bitpos -= ofl;
+                    sm = rfl(z_peek(wp, bitpos, (int)mll));
+                    bitpos -= mll;
                 }
+                uint32_t r0 = rfl(wk->rep[0]), r1 = rfl(wk->rep[1]), r2 = rfl(wk->rep[2]);
                 for (uint32_t done = 0; done < nseq; done += 64) {
                     const uint32_t nb = min(64u, nseq - done);
                     {   // a batch reads at most 64 * (16 + 16 + 32 + 27) bits = 728 bytes below the current position
-                        const int64_t bp_now = __shfl(bitpos, 0, 64);
-                        const int64_t need_lo = (bp_now >> 3) - 760;
-                        if (need_lo < (int64_t)wk->bw_lo && wk->bw_lo > 0) refill_window(bp_now);
+                        const int64_t need_lo = (bitpos >> 3) - 760;
+                        if (need_lo < (int64_t)wk->bw_lo && wk->bw_lo > 0) refill_window(bitpos);
                     }
-                    if (lane == 0) {
-                        const uint8_t* wp = wk->bw - wk->bw_lo;
-                        const int64_t wbits = (int64_t)wk->bw_lo * 8;   // bits below the window read as stream bits via the shifted base
-                        (void)wbits;
-                        uint32_t r0 = wk->rep[0], r1 = wk->rep[1], r2 = wk->rep[2];
+                    uint32_t my_ll = 0, my_ml = 0, my_off = 1;
+                    int32_t err = 0;
+                    {
                         const uint32_t* w32 = (const uint32_t*)wk->bw;
+                        const int64_t win_lo_bits = (int64_t)rfl(wk->bw_lo) * 8;
                         for (uint32_t k = 0; k < nb; k++) {
-                            // round trip 1: the three FSE entries of the current states + 160 bits of the stream below bitpos
-                            const uint32_t e_of = *(const uint32_t*)&wk->of[so], e_ml = *(const uint32_t*)&wk->ml[sm], e_ll = *(const uint32_t*)&wk->ll[sl];
-                            // the 64 stream bits below bitpos, top aligned (bit 63 = stream bit bitpos - 1): three aligned dwords of
-                            // the LDS window + a funnel shift; a take() is then two shifts
+                            // ONE LDS round trip per sequence: the three FSE entries of the current states, the extras of the two
+                            // length codes (per state: xll / xml) and the 64 stream bits below bitpos (three aligned dwords of
+                            // the window + a funnel shift; a take() is then two shifts)
+                            const uint32_t e_of = rfl(*(const uint32_t*)&wk->of[so]), e_ml = rfl(*(const uint32_t*)&wk->ml[sm]),
+                                           e_ll = rfl(*(const uint32_t*)&wk->ll[sl]);
+                            const uint32_t x_ml = rfl(wk->xml[sm]), x_ll = rfl(wk->xll[sl]);
                             auto load_top = [&]() -> uint64_t {
                                 const int64_t lo = bitpos - 64;
-                                const int64_t rel = (lo < 0 ? 0 : lo) - (int64_t)wk->bw_lo * 8;
+                                const int64_t rel = (lo < 0 ? 0 : lo) - win_lo_bits;
                                 if (rel < 0) {           // (malformed stream / stale window: never on a valid one)
-                                    wk->err = 29;
+                                    err = 29;
                                     return 0ull;
                                 }
                                 const uint32_t idx = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31;
-                                const uint32_t d0 = w32[idx], d1 = w32[idx + 1], d2 = w32[idx + 2];
+                                const uint32_t d0 = rfl(w32[idx]), d1 = rfl(w32[idx + 1]), d2 = rfl(w32[idx + 2]);
                                 uint64_t v = (((uint64_t)d1 << 32) | d0) >> sh;
                                 if (sh) v |= (uint64_t)d2 << (64 - sh);
                                 if (lo < 0) v = bitpos > 0 ? v << (uint32_t)(-lo) : 0ull;   // fewer than 64 bits left: low bits read as 0
@@ -625,14 +652,9 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                                 bitpos -= nbits;
                                 return v;
                             };
-                            const uint32_t ofc = e_of & 255, mlc = e_ml & 255, llc = e_ll & 255;
-                            if (ofc > 31 || mlc > 52 || llc > 35) {
-                                wk->err = 27;
-                                break;
-                            }
-                            // round trip 2: baselines and extra-bit counts of the two length codes
-                            const uint32_t mlbits = wk->t_mlbits[mlc], llbits = wk->t_llbits[llc];
-                            const uint32_t mlbase = wk->t_mlbase[mlc], llbase = wk->t_llbase[llc];
+                            const uint32_t ofc = e_of & 255;
+                            const uint32_t mlbits = x_ml & 255, llbits = x_ll & 255;
+                            const uint32_t mlbase = x_ml >> 8, llbase = x_ll >> 8;
                             const uint64_t ofv = ((uint64_t)1 << ofc) + take(ofc);
                             const uint32_t mlen = mlbase + take(mlbits);
                             const uint32_t llen = llbase + take(llbits);
@@ -650,7 +672,7 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                                 } else {
                                     offset = idx == 1 ? r1 : idx == 2 ? r2 : r0 - 1;
                                     if (offset == 0) {
-                                        wk->err = 28;
+                                        err = 28;
                                         break;
                                     }
                                     if (idx > 1) r2 = r1;
@@ -659,30 +681,31 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                                 }
                             }
                             if (done + k + 1 < nseq) {   // new states: LL, ML, OF (entry = symbol | nbits << 8 | base << 16)
-                                C = load_top();          // (offset + length bits may have used up to 63 of the 64)
-                                sl = (e_ll >> 16) + take((e_ll >> 8) & 255);
-                                sm = (e_ml >> 16) + take((e_ml >> 8) & 255);
-                                so = (e_of >> 16) + take((e_of >> 8) & 255);
+                                const uint32_t nl = (e_ll >> 8) & 255, nm = (e_ml >> 8) & 255, no = (e_of >> 8) & 255;
+                                // the container still holds 64 - (offset + length bits) stream bits: reload only when the state bits
+                                // do not fit any more (offsets beyond 2^20 or long extra-bit runs)
+                                if (ofc + mlbits + llbits + nl + nm + no > 64) C = load_top();
+                                sl = (e_ll >> 16) + take(nl);
+                                sm = (e_ml >> 16) + take(nm);
+                                so = (e_of >> 16) + take(no);
                             }
-                            if (bitpos < 0) wk->err = 29;
-                            if (wk->err) break;
-                            wk->seq[k].ll = llen;
-                            wk->seq[k].ml = mlen;
-                            wk->seq[k].off = offset;
+                            if (bitpos < 0) err = 29;
+                            if (err) break;
+                            if ((uint32_t)lane == k) {   // lane k keeps sequence k
+                                my_ll = llen;
+                                my_ml = mlen;
+                                my_off = offset;
+                            }
                         }
-                        wk->rep[0] = r0;
-                        wk->rep[1] = r1;
-                        wk->rep[2] = r2;
-                        if (done + nb == nseq && !wk->err && bitpos != 0) wk->err = 29;
+                        if (done + nb == nseq && !err && bitpos != 0) err = 29;
                     }
-                    wsync();
                     LZP(22);
-                    if (wk->err) return 0;
+                    if (err) ZERR(err);
                     // execute the batch through the LDS output ring (sb_lz4.h LzSeqExec): lane k holds sequence k
                     {
                         const bool have = (uint32_t)lane < nb;
-                        const uint32_t llen = have ? wk->seq[lane].ll : 0u, mlen = have ? wk->seq[lane].ml : 0u;
-                        const uint32_t off = have ? wk->seq[lane].off : 1u;
+                        const uint32_t llen = have ? my_ll : 0u, mlen = have ? my_ml : 0u;
+                        const uint32_t off = have ? my_off : 1u;
                         const uint32_t lsum = wave_scan_dpp(llen), osum = wave_scan_dpp(llen + mlen);
                         const bool bad = have && ((uint64_t)lit_pos + lsum > regen || (uint64_t)op + osum > out_len || off == 0 ||
                                                   off > op + osum - mlen);
@@ -694,6 +717,12 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
                     }
                     wsync();
                 }
+                if (lane == 0) {   // the repeat offsets carry into the next block
+                    wk->rep[0] = r0;
+                    wk->rep[1] = r1;
+                    wk->rep[2] = r2;
+                }
+                wsync();
             }
             const uint32_t rest = regen - lit_pos;
             if (out_len - op < rest) ZERR(31);

@@ -103,50 +103,64 @@ class NestedEncodedColumn(EncodedColumn):
                         dtype=np.uint64).reshape(-1, 2)
 
 
-def write_nested(ctx, levels: Sequence[NestedLevel], leaf: DeviceColumn, options: WriteOptions) -> NestedEncodedColumn:
-    """Encode one nested leaf column (synchronous).  `leaf` holds the leaf array's buffers
-    (leaf.rows = levels[-1].length; its validity is the leaf validity, also referenced by
-    levels[-1].validity); options.max_page_size counts TOP-LEVEL rows like upstream."""
+def write_nested_leaves(ctx, items, options: WriteOptions) -> List[NestedEncodedColumn]:
+    """Encode the leaf columns of one nested array together (synchronous): `items` = [(levels, leaf), ...] — what
+    NativeWriter::encode_chunk's loop over the leaves of an array does (src/write/common.rs:60-116), with the level
+    sections of every leaf written first and the leaf BLOCKs of all leaves in ONE sb_write_columns call, so that the
+    pages of all leaves are in flight together.  For each item leaf.rows = levels[-1].length; its validity is the leaf
+    validity, also referenced by levels[-1].validity; options.max_page_size counts TOP-LEVEL rows like upstream."""
     import torch
-    rows = levels[0].length
-    lv = write_levels(ctx, levels, rows, options.max_page_size)
-    if int(lv.leaf_start[0]) != 0:
-        raise ValueError("leaf slice must start at 0")
+    n = len(items)
     oc = options_c(options)
     oc.max_page_size = 0
-    arr = (N.ColumnWriteC * 1)()
-    c = arr[0]
-    c.physical_type = leaf.physical_type
-    c.is_nullable = 0  # the def levels carry the validity; the BLOCK has no def section
-    total_leaf = int(lv.leaf_count.sum())
-    c.rows = total_leaf
-    c.values = _ptr(leaf.values)
-    c.values_bit_offset = leaf.values_bit_offset
-    c.values_len = leaf.values.numel() if leaf.values is not None else 0
-    c.validity = _ptr(leaf.validity)
-    c.validity_bit_offset = leaf.validity_bit_offset
-    c.offsets = _ptr(leaf.offsets)
-    vlen = c.values_len if PhysicalType.is_binary(leaf.physical_type) else 0
-    npg = C.c_uint64(0)
-    bound = int(ctx._lib.sb_write_bound(leaf.physical_type, 0, max(total_leaf, 1), vlen, C.byref(oc), C.byref(npg)))
-    bound += lv.n_pages * 512 + int(lv.level_bytes.sum())
-    with torch.cuda.stream(ctx.torch_stream):
-        pages = torch.empty(bound, dtype=torch.uint8, device=ctx.torch_device)
-    metas = (N.PageMetaC * lv.n_pages)()
-    c.out_pages = _ptr(pages)
-    c.out_capacity = pages.numel()
-    c.out_metas = metas
-    c.n_pages_capacity = lv.n_pages
-    page_rows = np.ascontiguousarray(lv.leaf_count, dtype=np.uint64)
-    heads = np.ascontiguousarray(lv.level_bytes, dtype=np.uint64)
-    c.page_rows = page_rows.ctypes.data_as(C.c_void_p)
-    c.page_head_bytes = heads.ctypes.data_as(C.c_void_p)
-    c.page_heads = _ptr(lv.sections)
-    c.n_pages_in = lv.n_pages
-    ctx._keep.append((arr, oc, page_rows, heads, lv, leaf, pages, metas))
-    ctx._check(ctx._lib.sb_write_columns(ctx._h, arr, 1, C.byref(oc), N.SB_MEM_DEVICE))
+    arr = (N.ColumnWriteC * max(n, 1))()
+    keep, lvs, outs = [], [], []
+    for k, (levels, leaf) in enumerate(items):
+        rows = levels[0].length
+        lv = write_levels(ctx, levels, rows, options.max_page_size)
+        if int(lv.leaf_start[0]) != 0:
+            raise ValueError("leaf slice must start at 0")
+        c = arr[k]
+        c.physical_type = leaf.physical_type
+        c.is_nullable = 0  # the def levels carry the validity; the BLOCK has no def section
+        total_leaf = int(lv.leaf_count.sum())
+        c.rows = total_leaf
+        c.values = _ptr(leaf.values)
+        c.values_bit_offset = leaf.values_bit_offset
+        c.values_len = leaf.values.numel() if leaf.values is not None else 0
+        c.validity = _ptr(leaf.validity)
+        c.validity_bit_offset = leaf.validity_bit_offset
+        c.offsets = _ptr(leaf.offsets)
+        vlen = c.values_len if PhysicalType.is_binary(leaf.physical_type) else 0
+        npg = C.c_uint64(0)
+        bound = int(ctx._lib.sb_write_bound(leaf.physical_type, 0, max(total_leaf, 1), vlen, C.byref(oc), C.byref(npg)))
+        bound += lv.n_pages * 512 + int(lv.level_bytes.sum())
+        with torch.cuda.stream(ctx.torch_stream):
+            pages = torch.empty(bound, dtype=torch.uint8, device=ctx.torch_device)
+        metas = (N.PageMetaC * lv.n_pages)()
+        c.out_pages = _ptr(pages)
+        c.out_capacity = pages.numel()
+        c.out_metas = metas
+        c.n_pages_capacity = lv.n_pages
+        page_rows = np.ascontiguousarray(lv.leaf_count, dtype=np.uint64)
+        heads = np.ascontiguousarray(lv.level_bytes, dtype=np.uint64)
+        c.page_rows = page_rows.ctypes.data_as(C.c_void_p)
+        c.page_head_bytes = heads.ctypes.data_as(C.c_void_p)
+        c.page_heads = _ptr(lv.sections)
+        c.n_pages_in = lv.n_pages
+        keep.append((page_rows, heads, lv, leaf, pages, metas))
+        lvs.append(lv)
+        outs.append((pages, metas))
+    ctx._keep.append((arr, oc, keep))
+    if n:
+        ctx._check(ctx._lib.sb_write_columns(ctx._h, arr, n, C.byref(oc), N.SB_MEM_DEVICE))
     ctx.synchronize()
-    return NestedEncodedColumn(pages, metas, c, lv.num_values)
+    return [NestedEncodedColumn(pages, metas, arr[k], lvs[k].num_values) for k, (pages, metas) in enumerate(outs)]
+
+
+def write_nested(ctx, levels: Sequence[NestedLevel], leaf: DeviceColumn, options: WriteOptions) -> NestedEncodedColumn:
+    """Encode one nested leaf column (synchronous): write_nested_leaves with one leaf."""
+    return write_nested_leaves(ctx, [(levels, leaf)], options)[0]
 
 
 class NestedArray:
@@ -163,72 +177,103 @@ class NestedArray:
         return self.validity[k][:(self.lengths[k] + 7) // 8].cpu().numpy()
 
 
-def read_nested(ctx, column: ColumnPages, kinds: Sequence[int], nullable: Sequence[bool]) -> NestedArray:
-    """read_nested_* for one leaf column (synchronous): `kinds`/`nullable` are the InitNested chain
-    root -> leaf (src/read/batch_read.rs:66-230 builds it from the schema)."""
+def read_nested_leaves(ctx, columns, kinds_list, nullable_list) -> List[NestedArray]:
+    """read_nested_* for the leaf columns of one nested array together (synchronous): per leaf the level sections are
+    decoded (offsets / validity per level, leaf validity, per page the leaf count and where its BLOCK starts), then the
+    BLOCKs of ALL leaves go through the flat decoder in one sizing call (binary leaves) and one sb_read_columns call.
+    `kinds` / `nullable` per leaf are the InitNested chain root -> leaf (src/read/batch_read.rs:66-230 builds it from
+    the schema)."""
     import torch
-    D = len(kinds)
-    metas = column.metas_array()
-    n_pages = metas.shape[0]
-    entries = int(metas[:, 1].sum()) if n_pages else 0
     dev = ctx.torch_device
-    lv = (N.NestedLevelOutC * D)()
-    offs, vals = [None] * D, [None] * D
-    vbytes = ((entries + 31) // 32) * 4
+    n = len(columns)
+    arr = (N.ColumnReadC * max(n, 1))()
+    per, keep = [], []
+    for j, (column, kinds, nullable) in enumerate(zip(columns, kinds_list, nullable_list)):
+        D = len(kinds)
+        metas = column.metas_array()
+        n_pages = metas.shape[0]
+        entries = int(metas[:, 1].sum()) if n_pages else 0
+        lv = (N.NestedLevelOutC * D)()
+        offs, vals = [None] * D, [None] * D
+        vbytes = ((entries + 31) // 32) * 4
+        with torch.cuda.stream(ctx.torch_stream):
+            for k in range(D):
+                lv[k].kind = kinds[k]
+                lv[k].is_nullable = 1 if nullable[k] else 0
+                if kinds[k] in (LIST, LARGE_LIST):
+                    offs[k] = torch.empty((entries + 1) * 8, dtype=torch.uint8, device=dev)
+                    lv[k].offsets = _ptr(offs[k])
+                    lv[k].offsets_capacity = entries + 1
+                if nullable[k] and kinds[k] != PRIMITIVE:
+                    vals[k] = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev)
+                    lv[k].validity = _ptr(vals[k])
+                    lv[k].validity_capacity = vals[k].numel()
+            leaf_validity = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev) if nullable[-1] else None
+        counts = np.zeros(max(n_pages, 1), np.uint64)
+        block_offs = np.zeros(max(n_pages, 1), np.uint64)
+        pages = column.pages
+        ctx._check(ctx._lib.sb_nested_read_levels(
+            ctx._h, _ptr(pages), pages.numel(), metas.ctypes.data_as(C.POINTER(N.PageMetaC)), n_pages, lv, D,
+            _ptr(leaf_validity), leaf_validity.numel() if leaf_validity is not None else 0,
+            counts.ctypes.data_as(C.POINTER(C.c_uint64)), block_offs.ctypes.data_as(C.POINTER(C.c_uint64))))
+        lengths = [int(lv[k].length) for k in range(D)]
+        # the leaf BLOCKs through the flat decoder
+        starts = np.concatenate([[0], np.cumsum(metas[:, 0])[:-1]]).astype(np.uint64) if n_pages else np.zeros(0, np.uint64)
+        leaf_metas = np.zeros((n_pages, 2), np.uint64)
+        leaf_metas[:, 0] = metas[:, 0] - (block_offs[:n_pages] - starts)
+        leaf_metas[:, 1] = counts[:n_pages]
+        t = column.physical_type
+        rows = int(counts[:n_pages].sum())
+        c = arr[j]
+        c.physical_type = t
+        c.is_nullable = 0
+        c.pages = _ptr(pages)
+        c.pages_len = pages.numel()
+        c.metas = leaf_metas.ctypes.data_as(C.POINTER(N.PageMetaC))
+        c.n_pages = n_pages
+        po = np.ascontiguousarray(block_offs[:n_pages])
+        c.page_offsets = po.ctypes.data_as(C.c_void_p)
+        per.append(dict(kinds=list(kinds), nullable=list(nullable), lengths=lengths, offs=offs, vals=vals, leaf_validity=leaf_validity,
+                        rows=rows, t=t))
+        keep.append((leaf_metas, po, pages, lv))
+    binary = [j for j in range(n) if PhysicalType.is_binary(per[j]["t"])]
+    if binary:   # values_len of the binary leaves: one sizing call over all of them
+        sub = (N.ColumnReadC * len(binary))()
+        for q, j in enumerate(binary):
+            C.memmove(C.byref(sub[q]), C.byref(arr[j]), C.sizeof(N.ColumnReadC))
+        ctx._check(ctx._lib.sb_read_columns_sizes(ctx._h, sub, len(binary), N.SB_MEM_DEVICE))
+        for q, j in enumerate(binary):
+            per[j]["values_len"] = int(sub[q].values_len)
+    bufs = []
     with torch.cuda.stream(ctx.torch_stream):
-        for k in range(D):
-            lv[k].kind = kinds[k]
-            lv[k].is_nullable = 1 if nullable[k] else 0
-            if kinds[k] in (LIST, LARGE_LIST):
-                offs[k] = torch.empty((entries + 1) * 8, dtype=torch.uint8, device=dev)
-                lv[k].offsets = _ptr(offs[k])
-                lv[k].offsets_capacity = entries + 1
-            if nullable[k] and kinds[k] != PRIMITIVE:
-                vals[k] = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev)
-                lv[k].validity = _ptr(vals[k])
-                lv[k].validity_capacity = vals[k].numel()
-        leaf_validity = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev) if nullable[-1] else None
-    counts = np.zeros(max(n_pages, 1), np.uint64)
-    block_offs = np.zeros(max(n_pages, 1), np.uint64)
-    pages = column.pages
-    ctx._check(ctx._lib.sb_nested_read_levels(
-        ctx._h, _ptr(pages), pages.numel(), metas.ctypes.data_as(C.POINTER(N.PageMetaC)), n_pages, lv, D,
-        _ptr(leaf_validity), leaf_validity.numel() if leaf_validity is not None else 0,
-        counts.ctypes.data_as(C.POINTER(C.c_uint64)), block_offs.ctypes.data_as(C.POINTER(C.c_uint64))))
-    lengths = [int(lv[k].length) for k in range(D)]
-    # the leaf BLOCKs through the flat decoder
-    starts = np.concatenate([[0], np.cumsum(metas[:, 0])[:-1]]).astype(np.uint64) if n_pages else np.zeros(0, np.uint64)
-    leaf_metas = np.zeros((n_pages, 2), np.uint64)
-    leaf_metas[:, 0] = metas[:, 0] - (block_offs[:n_pages] - starts)
-    leaf_metas[:, 1] = counts[:n_pages]
-    t = column.physical_type
-    rows = int(counts[:n_pages].sum())
-    arr = (N.ColumnReadC * 1)()
-    c = arr[0]
-    c.physical_type = t
-    c.is_nullable = 0
-    c.pages = _ptr(pages)
-    c.pages_len = pages.numel()
-    c.metas = leaf_metas.ctypes.data_as(C.POINTER(N.PageMetaC))
-    c.n_pages = n_pages
-    po = np.ascontiguousarray(block_offs[:n_pages])
-    c.page_offsets = po.ctypes.data_as(C.c_void_p)
-    values = offsets = None
-    with torch.cuda.stream(ctx.torch_stream):
-        if t == PhysicalType.BOOLEAN:
-            values = torch.empty(((rows + 31) // 32) * 4 + 4, dtype=torch.uint8, device=dev)
-        elif PhysicalType.is_binary(t):
-            ctx._check(ctx._lib.sb_read_columns_sizes(ctx._h, arr, 1, N.SB_MEM_DEVICE))
-            values = torch.empty(max(int(c.values_len), 1), dtype=torch.uint8, device=dev)
-            offsets = torch.empty((rows + 1) * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
-        elif t != PhysicalType.NULL:
-            values = torch.empty(max(rows * PhysicalType.WIDTH[t], 1), dtype=torch.uint8, device=dev)
-    c.values = _ptr(values)
-    c.values_capacity = values.numel() if values is not None else 0
-    c.offsets = _ptr(offsets)
-    c.offsets_capacity = offsets.numel() if offsets is not None else 0
-    ctx._keep.append((arr, leaf_metas, po, pages, values, offsets))
-    ctx._check(ctx._lib.sb_read_columns(ctx._h, arr, 1, N.SB_MEM_DEVICE))
+        for j in range(n):
+            t, rows = per[j]["t"], per[j]["rows"]
+            values = offsets = None
+            if t == PhysicalType.BOOLEAN:
+                values = torch.empty(((rows + 31) // 32) * 4 + 4, dtype=torch.uint8, device=dev)
+            elif PhysicalType.is_binary(t):
+                values = torch.empty(max(per[j]["values_len"], 1), dtype=torch.uint8, device=dev)
+                offsets = torch.empty((rows + 1) * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
+            elif t != PhysicalType.NULL:
+                values = torch.empty(max(rows * PhysicalType.WIDTH[t], 1), dtype=torch.uint8, device=dev)
+            c = arr[j]
+            c.values = _ptr(values)
+            c.values_capacity = values.numel() if values is not None else 0
+            c.offsets = _ptr(offsets)
+            c.offsets_capacity = offsets.numel() if offsets is not None else 0
+            bufs.append((values, offsets))
+    ctx._keep.append((arr, keep, bufs))
+    if n:
+        ctx._check(ctx._lib.sb_read_columns(ctx._h, arr, n, N.SB_MEM_DEVICE))
     ctx.synchronize()
-    leaf = DeviceArray(t, bool(nullable[-1]), rows, values, leaf_validity, offsets, c)
-    return NestedArray(list(kinds), list(nullable), lengths, offs, vals, leaf)
+    out = []
+    for j in range(n):
+        d = per[j]
+        leaf = DeviceArray(d["t"], bool(d["nullable"][-1]), d["rows"], bufs[j][0], d["leaf_validity"], bufs[j][1], arr[j])
+        out.append(NestedArray(d["kinds"], d["nullable"], d["lengths"], d["offs"], d["vals"], leaf))
+    return out
+
+
+def read_nested(ctx, column: ColumnPages, kinds: Sequence[int], nullable: Sequence[bool]) -> NestedArray:
+    """read_nested_* for one leaf column (synchronous): read_nested_leaves with one leaf."""
+    return read_nested_leaves(ctx, [column], [kinds], [nullable])[0]

@@ -408,7 +408,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     const size_t o_jobs_a = off;
     off = align_up(off + 2 * P * sizeof(InflateJob), 64);
     const size_t o_jobs_b = off;
-    off = align_up(off + P * sizeof(InflateJob), 64);
+    off = align_up(off + 2 * P * sizeof(InflateJob), 64);
     const size_t o_counts = off;
     off = align_up(off + 64, 64);
     const size_t o_vlen = off;
@@ -530,6 +530,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     uint64_t* d_vlen = (uint64_t*)(tb + o_vlen);
 
     a.sizes_only = sizes_only ? 1u : 0u;
+    a.defer_payloads = (!sizes_only && any_binary) ? 1u : 0u;
     if (sizes_only) {
         if (P) launch_parse_sizes(ctx, a, d_vlen);
     } else {

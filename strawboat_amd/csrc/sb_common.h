@@ -120,7 +120,7 @@ struct DecodeArgs {
     uint8_t* scratch;
     Status* status;
     InflateJob* jobs_a;  // capacity 2 * n_pages
-    InflateJob* jobs_b;  // capacity n_pages
+    InflateJob* jobs_b;  // capacity 2 * n_pages
     uint32_t* job_counts;  // [0] = queue A, [1] = queue B
     uint8_t* zlit;         // Zstd literal buffers, one per inflate wave
     uint32_t n_pages;
@@ -131,6 +131,7 @@ struct DecodeArgs {
     uint32_t freq_cap;
     uint32_t no_freq;      // second pass: an exceptions block never holds a Freq block (freq.rs:78-79)
     uint32_t sizes_only;   // sb_read_columns_sizes: only what values_len depends on is inflated (nested index blocks)
+    uint32_t defer_payloads;  // the call has binary columns (queue B runs): Basic payloads nothing waits for go there too
 };
 
 }  // namespace sb

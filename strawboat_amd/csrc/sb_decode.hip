@@ -124,7 +124,10 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
         if (codec == SB_CODEC_NONE) {
             if (d.csize != nbytes) FAIL(SB_ERR_OUT_OF_SPEC, 11);
         } else if (is_basic(codec)) {
-            if (!a.sizes_only) push_job(a.jobs_a, a.job_counts, d.body, d.csize, infl, (uint32_t)nbytes, codec, p);
+            // (payloads that no planning step reads are inflated in queue B when it runs, next to the value blocks of the
+            // binary columns, instead of in front of them: the phases of a call are serial, their jobs are not)
+            if (!a.sizes_only)
+                push_job(a.defer_payloads ? a.jobs_b : a.jobs_a, a.job_counts + (a.defer_payloads ? 1 : 0), d.body, d.csize, infl, (uint32_t)nbytes, codec, p);
             d.src = infl;
         } else if (codec == SB_CODEC_ONEVALUE) {
             if (d.csize < 1) FAIL(SB_ERR_OUT_OF_SPEC, 12);
@@ -186,7 +189,8 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
         } else if (is_basic(codec)) {
             // inflate straight into the column's values buffer (integer/mod.rs:97-107)
             if (!a.sizes_only)
-                push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
+                push_job(a.defer_payloads ? a.jobs_b : a.jobs_a, a.job_counts + (a.defer_payloads ? 1 : 0), d.body, d.csize,
+                         c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
             d.src = nullptr;  // nothing left for expand
         } else if (codec == SB_CODEC_ONEVALUE) {
             if (d.csize < w) FAIL(SB_ERR_IO, 22);
@@ -197,7 +201,9 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
         } else if (codec == SB_CODEC_PATAS) {
             if (c.ptype == SB_TYPE_FLOAT32) FAIL(SB_ERR_NYI, 26);   // f32 Patas decode is broken upstream
             if (c.ptype != SB_TYPE_FLOAT64) FAIL(SB_ERR_OUT_OF_SPEC, 27);  // "Unknown compression codec Patas for integer"
-            if (!a.sizes_only) push_job(a.jobs_a, a.job_counts, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
+            if (!a.sizes_only)
+                push_job(a.defer_payloads ? a.jobs_b : a.jobs_a, a.job_counts + (a.defer_payloads ? 1 : 0), d.body, d.csize,
+                         c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
             d.src = nullptr;
         } else if (codec == SB_CODEC_FREQ) {  // top[w] | u32 rb_size | roaring | BLOCK<T exceptions>  (freq.rs:71-83)
             if (a.no_freq) FAIL(SB_ERR_OUT_OF_SPEC, 28);
@@ -1888,9 +1894,9 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
-        k_inflate<<<min(a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
+        k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
         KScope k2(ctx, "k_inflate_lz4(values)");
-        k_inflate_lz4<<<min(a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
+        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
     }
     if (any_prim) {
         KScope k(ctx, K_EXPAND_RLE);

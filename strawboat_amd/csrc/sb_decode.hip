@@ -349,19 +349,34 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
             if (mp) atomicAdd(&a.job_counts[3], (uint32_t)__popcll(mp));
         }
     }
-    if (!rle_by_page(c, d) && ntiles) {
-        const uint32_t base = atomicAdd(&a.job_counts[2], ntiles);
-        d.tile_base = base;
-        for (uint32_t i = 0; i < ntiles; i++) {
-            TileTask tt;
-            tt.page = p;
-            tt.tile = i;
-            tt.col = t.col;
-            tt.k0 = tt.kend = tt.pad = 0;
-            a.tiles[base + i] = tt;
-        }
+    const bool need_tiles = !rle_by_page(c, d) && ntiles;
+    uint32_t tbase = 0;
+    if (need_tiles) {
+        tbase = atomicAdd(&a.job_counts[2], ntiles);
+        d.tile_base = tbase;
     }
     a.descs[p] = d;
+    // the tile entries of the wave's pages, written by the lanes of the wave together (a 1 M-row page has 245 tiles: one
+    // thread writing them one by one was 44 us of a 0.46 ms C1 decode)
+    {
+        uint64_t m = __ballot(need_tiles);
+        const uint64_t active = __ballot(true);
+        const uint32_t lane = threadIdx.x & 63, nact = (uint32_t)__popcll(active);
+        const uint32_t rank = (uint32_t)__popcll(active & ((1ull << lane) - 1));
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t b = __shfl(tbase, l, 64), nt = __shfl(ntiles, l, 64), pg = __shfl(p, l, 64), col = __shfl(t.col, l, 64);
+            for (uint32_t i = rank; i < nt; i += nact) {
+                TileTask tt;
+                tt.page = pg;
+                tt.tile = i;
+                tt.col = col;
+                tt.k0 = tt.kend = tt.pad = 0;
+                a.tiles[b + i] = tt;
+            }
+        }
+    }
 #undef FAIL
 }
 

@@ -5,7 +5,7 @@ decodes them back to the Arrow buffers they came from.
   C1  1 M-row non-nullable Int64, one page, no compression
   C3  1 M-row Utf8, zipf(1.1) over 10 000 words of length 4..24, LZ4 default, ratio 2.0 -> Dict pages
   C4  the per-GPU shard of the mixed schema: Int32 / Float64 / Utf8 / Boolean columns, 64 Ki-row pages,
-      LZ4 default, ratio 2.0 (1 M rows per column here; the 10 M-row job is the same pages x 10)
+      LZ4 default, ratio 2.0 (1 M rows per column, and the 10 M rows BASELINE.json states: 153 pages, 38 528-row tail)
   C5  1 M-row List<Struct<Int64, Utf8>>, Zstd default, whole-file round trip
 (C2 is tests/test_gpu_select.py::test_c2_adaptive and bench.py itself.)"""
 import numpy as np
@@ -75,6 +75,16 @@ def test_c4_mixed_schema_shard(gpu_ctx, kind):
         col = gen.boolean(ROWS, null_density=0.1, seed=45)
     encode_matches_oracle_and_round_trips(gpu_ctx, col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0,
                                           forbidden=NOT_ON_DEVICE)
+
+
+@pytest.mark.parametrize("name", ["int32_0", "float64_0", "utf8_0", "boolean_0"])
+def test_c4_at_the_size_baseline_states(gpu_ctx, name):
+    """C4 as BASELINE.json states it: 10 M rows per column = 153 pages, the last one of 38 528 rows (= 301 x 128: its
+    Dict indices bit-pack, unlike the 16 960-row tail of a 1 M-row column) — the columns bench.py's `c4` entry times,
+    byte for byte against the oracle."""
+    col = dict(workloads.c4_columns(10_000_000))[name]
+    codecs = encode_matches_oracle_and_round_trips(gpu_ctx, col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+    assert len(codecs) == 153
 
 
 def test_c5_nested_list_struct_zstd_file(gpu_ctx, tmp_path):

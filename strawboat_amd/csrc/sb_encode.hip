@@ -1263,10 +1263,46 @@ __device__ uint32_t snappy_store_wg(const uint8_t* src, uint32_t n, uint8_t* dst
 }
 
 
+__device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, uint32_t chunk_bytes, const uint8_t* src, uint32_t n,
+                                     uint32_t nch, uint8_t* dst, uint32_t* sh);
+// An LZ4 block inside a page kernel (the u32 indices of a Dict page whose row count is not a multiple of 128: 68 KB on the
+// 16 960-row last page of a 1 M-row column, 2 ms through one wave while the other three wait): three waves compress a
+// third of the block each into slots of `tmp` (HBM), then the workgroup joins them like k_enc_lz4_stitch does.
+// lds: 3 * sizeof(Lz4EncLds<11, 13>) bytes (reused by the join); all threads call it.  0: block too small / no room.
+constexpr uint32_t LZ3_MIN = 12 * 1024;
+__device__ uint32_t lz4_compress_block_wg3(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* lds, uint32_t lds_bytes, uint8_t* tmp,
+                                          uint64_t tmp_bytes) {
+    typedef Lz4EncLds<11, 13> L;
+    const uint32_t chunk = ((n + 2) / 3 + 1023) / 1024 * 1024;
+    const uint32_t stride = (16 + chunk + chunk / 255 + 64 + 15) / 16 * 16;
+    const uint32_t nch = (n + chunk - 1) / chunk;
+    if (n < LZ3_MIN || lds_bytes < 3 * sizeof(L) || lds_bytes < (5 * WG + 8) * 4 || tmp_bytes < (uint64_t)stride * nch) return 0;
+    __syncthreads();
+    const uint32_t w = threadIdx.x >> 6;
+    if (w < nch) {
+        L* l = reinterpret_cast<L*>(lds) + w;
+        const uint32_t c0 = w * chunk, c1 = min(n, c0 + chunk);
+        uint8_t* slot = tmp + (uint64_t)w * stride;
+        uint32_t anchor = c0;
+        const uint32_t len = lz4_compress_range<11, 13, true>(src, n, c0, c1, slot + 16, *l, &anchor);
+        if ((threadIdx.x & 63) == 0) {
+            stu32(slot, len);
+            stu32(slot + 4, anchor);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t sz = lz4_stitch_block(tmp, stride, chunk, src, n, nch, dst, lds);
+    __syncthreads();
+    return sz;
+}
+
 // ------------------------------------------------------------------------------ u32 blocks (nested)
 // compress_integer::<u32> of an index array without validity: hdr9 + body.  Returns bytes written.
 __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec, uint8_t* dst, uint32_t* sA,
-                                  uint32_t* sB, uint32_t* sC, uint32_t* s_w, Status* st, uint32_t page, uint32_t flags) {
+                                  uint32_t* sB, uint32_t* sC, uint32_t* s_w, Status* st, uint32_t page, uint32_t flags,
+                                  uint8_t* tmp = nullptr, uint64_t tmp_bytes = 0 /* HBM scratch for the three-wave LZ4 path */) {
     auto getu = [=](uint64_t i) { return idx[i]; };
     auto getv = [=](uint64_t i) {
         Val<4> v;
@@ -1296,6 +1332,15 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
             break;
         case SB_CODEC_LZ4: {  // Basic(Lz4) over the raw index bytes (integer/mod.rs:55-58)
             __syncthreads();
+            if (!(flags & SB_WRITE_LZ4_EXACT) && tmp && sB > sA && sC - sB == sB - sA) {
+                // (sA, sB, sC are one contiguous LDS area in the page kernels: 3 * LW words)
+                const uint32_t z = lz4_compress_block_wg3((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, sA,
+                                                          (uint32_t)((sC - sA) + (sC - sB)) * 4, tmp, tmp_bytes);
+                if (z) {
+                    body = z;
+                    break;
+                }
+            }
             uint32_t sz = 0;
             if (threadIdx.x < 64) sz = lz4_compress_block((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, sA, flags);
             __syncthreads();
@@ -2674,7 +2719,16 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
             }
             return DICT_FREQ_PENDING;
         }
-        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags);
+        // (HBM scratch for the three-wave LZ4 path: 2 N words of the aux area that are dead by now — the F / R arrays of
+        // dict_build, or the tail of the area when dict_build_lds put the indices at its start)
+        uint8_t* lz_tmp = nullptr;
+        {
+            uint64_t M = 64;
+            while (M < 2 * N) M <<= 1;
+            const uint64_t aux_words = p.aux_bytes / 4;
+            if (aux_words >= M + 3 * N) lz_tmp = (uint8_t*)(idx == aux ? aux + (aux_words - 2 * N) : aux + M);
+        }
+        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags, lz_tmp, 8 * N);
         if (ib == 0) return 0;
         uint8_t* q = blk + 9 + ib;
         if (threadIdx.x == 0) stu32(q, D);
@@ -2800,7 +2854,16 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             }
             return DICT_FREQ_PENDING;
         }
-        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags);
+        // (HBM scratch for the three-wave LZ4 path: 2 N words of the aux area that are dead by now — the F / R arrays of
+        // dict_build, or the tail of the area when dict_build_lds put the indices at its start)
+        uint8_t* lz_tmp = nullptr;
+        {
+            uint64_t M = 64;
+            while (M < 2 * N) M <<= 1;
+            const uint64_t aux_words = p.aux_bytes / 4;
+            if (aux_words >= M + 3 * N) lz_tmp = (uint8_t*)(idx == aux ? aux + (aux_words - 2 * N) : aux + M);
+        }
+        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags, lz_tmp, 8 * N);
         if (ib == 0) return 0;
         STL(31);
         uint8_t* q = blk + 9 + ib;
@@ -4234,16 +4297,17 @@ __device__ uint32_t zstd_stitch_frame(const EncodeArgs& a, uint32_t n, uint32_t 
     return run;
 }
 
-// joins the chunks [chunk0, chunk0 + nch) of the block src[0, n) at dst; returns the block size.  sh: 5 * WG + 8 words.
-__device__ uint32_t lz4_stitch_block(const EncodeArgs& a, const uint8_t* src, uint32_t n, uint32_t chunk0, uint32_t nch, uint8_t* dst,
-                                     uint32_t* sh) {
+// joins the nch chunks (slots of slot_stride bytes at pool: u32 size | u32 tail anchor | 8 pad | sequences) of the block
+// src[0, n) at dst; returns the block size.  sh: 5 * WG + 8 words.
+__device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, uint32_t chunk_bytes, const uint8_t* src, uint32_t n,
+                                     uint32_t nch, uint8_t* dst, uint32_t* sh) {
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t *s_off = sh, *s_cs = sh + WG, *s_ll = sh + 2 * WG, *s_e1 = sh + 3 * WG, *s_len = sh + 4 * WG, *s_w = sh + 5 * WG;
     uint32_t run_base = 0;    // bytes of the block written by the chunks before this batch
     uint32_t run_carry = 0;   // where the literals begin that no sequence holds yet
     for (uint32_t b0 = 0; b0 < nch; b0 += WG) {
         const uint32_t k = b0 + t;
-        const uint8_t* slot = a.lzc_pool + (uint64_t)(chunk0 + (k < nch ? k : 0)) * LZC_SLOT;
+        const uint8_t* slot = pool + (uint64_t)(k < nch ? k : 0) * slot_stride;
         uint32_t len = 0, anchor = 0, ll = 0, e1 = 0;
         if (k < nch) {
             len = ldu32(slot);
@@ -4272,7 +4336,7 @@ __device__ uint32_t lz4_stitch_block(const EncodeArgs& a, const uint8_t* src, ui
         uint32_t cs = max(run_carry, exc);
         for (uint32_t q = 0; q < WG / 64; q++)
             if (q < w) cs = max(cs, s_w[4 + q]);
-        const uint32_t carry = len ? k * LZC_CH - cs : 0;
+        const uint32_t carry = len ? k * chunk_bytes - cs : 0;
         const uint32_t size = len ? (carry ? lz4_head_bytes(carry + ll) - 1 + carry + len - e1 : len) : 0;
         const uint32_t isum = wave_scan_dpp(size);
         if (lane == 63) s_w[w] = isum;
@@ -4297,9 +4361,9 @@ __device__ uint32_t lz4_stitch_block(const EncodeArgs& a, const uint8_t* src, ui
         for (uint32_t j = 0; j < cnt; j++) {
             const uint32_t len_j = s_len[j];
             if (!len_j) continue;
-            const uint8_t* sl = a.lzc_pool + (uint64_t)(chunk0 + b0 + j) * LZC_SLOT + 16;
+            const uint8_t* sl = pool + (uint64_t)(b0 + j) * slot_stride + 16;
             uint8_t* d = dst + s_off[j];
-            const uint32_t carry_j = (b0 + j) * LZC_CH - s_cs[j];
+            const uint32_t carry_j = (b0 + j) * chunk_bytes - s_cs[j];
             if (!carry_j) {
                 wg_copy(d, sl, len_j);
                 continue;
@@ -4333,13 +4397,13 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_stitch(EncodeArgs a) {
     const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
     uint8_t* blk = slot + pos;
     const uint32_t s1 = zstd ? zstd_stitch_frame(a, b.n_a, pl.base, pl.n_a, blk + 9, sh)
-                             : lz4_stitch_block(a, b.src_a, b.n_a, pl.base, pl.n_a, blk + 9, sh);
+                             : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_a, b.n_a, pl.n_a, blk + 9, sh);
     if (threadIdx.x == 0) put_hdr9(blk, codec, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
     uint64_t length = pos + 9 + s1;
     if (b.src_b) {
         uint8_t* b2 = blk + 9 + s1;
         const uint32_t s2 = zstd ? zstd_stitch_frame(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh)
-                                 : lz4_stitch_block(a, b.src_b, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh);
+                                 : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_b, b.n_b, pl.n_b, b2 + 9, sh);
         if (threadIdx.x == 0) put_hdr9(b2, codec, s2, b.n_b);
         length += 9 + s2;
     }

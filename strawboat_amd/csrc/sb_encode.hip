@@ -118,7 +118,8 @@ struct EncodeArgs {
     uint32_t* lzc_count;
     uint8_t* lzc_pool;              // one slot of LZC_SLOT bytes per chunk
     uint32_t lzc_cap;
-    uint32_t lzc_chunk;             // chunk bytes of this call: LZC_CH (LZ4) or ZPAR_CH (Zstd blocks, one wave each)
+    uint32_t lzc_chunk;             // chunk bytes of this call: LZC_CH (LZ4, Snappy) or ZPAR_CH (Zstd blocks, one wave each)
+    int32_t lzc_codec;              // the Basic codec whose big blocks go chunk by chunk in this call (LZ4 / Zstd / Snappy)
     uint8_t* zpar_scratch;          // Zstd: encoder scratch of the chunk waves (ZPAR_WAVES x zstd_scratch_bytes(ZPAR_CH))
 };
 constexpr uint32_t ZPAR_CH = 32768;      // a Zstd frame's blocks when they are compressed by waves of their own
@@ -4051,9 +4052,10 @@ __device__ __forceinline__ LzBlocks lz4_page_blocks(const EncodeArgs& a, const E
 // chunk by chunk (k_enc_lz4_plan / _chunks / _stitch) or as one block by one wave (k_enc_emit_lz4)?  A pure function of
 // the page, so that every kernel decides alike.
 __device__ __forceinline__ bool lz4_page_chunked(const EncodeArgs& a, int32_t bc, uint32_t page, const LzBlocks& b, uint64_t zst_off = ~0ull) {
-    if (!a.lzc_plan || page >= a.n_pages || max(b.n_a, b.n_b) <= a.lzc_chunk) return false;
-    if (bc == SB_CODEC_LZ4) return !(a.flags & SB_WRITE_LZ4_EXACT) && a.lzc_chunk == LZC_CH;
-    return bc == SB_CODEC_ZSTD && a.zpar_scratch && zst_off != ~0ull && a.lzc_chunk == ZPAR_CH;
+    if (!a.lzc_plan || page >= a.n_pages || max(b.n_a, b.n_b) <= a.lzc_chunk || bc != a.lzc_codec) return false;
+    if (bc == SB_CODEC_LZ4) return !(a.flags & SB_WRITE_LZ4_EXACT);
+    if (bc == SB_CODEC_SNAPPY) return true;
+    return bc == SB_CODEC_ZSTD && a.zpar_scratch && zst_off != ~0ull;
 }
 
 template <bool ZSTD>
@@ -4159,11 +4161,11 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
 // plan: def levels + staged first block + the chunk list (one workgroup per page).
 __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
     __shared__ uint32_t s_base;
-    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] + a.codec_counts[SB_CODEC_ZSTD] == 0) return;
+    if (a.use_counts && a.codec_counts[a.lzc_codec & 31] == 0) return;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     const int32_t bc = codec_of(a, p, page);
-    if (bc != SB_CODEC_LZ4 && bc != SB_CODEC_ZSTD) return;
+    if (bc != a.lzc_codec) return;
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     const LzBlocks b = lz4_page_blocks(a, c, p);
@@ -4218,7 +4220,7 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
 #endif
 __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
     __shared__ Lz4EncLds<SB_LZC_HB, 13> L;
-    if (a.lzc_chunk != LZC_CH) return;   // (a call's chunks are all LZ4 chunks or all Zstd blocks)
+    if (a.lzc_codec == SB_CODEC_ZSTD) return;   // (a call's chunks are all of one codec; Zstd blocks: k_enc_zstd_chunks)
     const uint32_t total = min(*a.lzc_count, a.lzc_cap);
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
         const LzChunkDesc d = a.lzc_list[i];
@@ -4232,7 +4234,8 @@ __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
         uint8_t* slot = a.lzc_pool + (uint64_t)i * LZC_SLOT;
         uint32_t anchor = c0;
         wave_sync();
-        const uint32_t len = lz4_compress_range<SB_LZC_HB, 13, true>(src, n, c0, c1, slot + 16, L, &anchor);
+        const uint32_t len = a.lzc_codec == SB_CODEC_SNAPPY ? snappy_compress_range<SB_LZC_HB, 13, true>(src, n, c0, c1, slot + 16, L)
+                                                            : lz4_compress_range<SB_LZC_HB, 13, true>(src, n, c0, c1, slot + 16, L, &anchor);
         if (threadIdx.x == 0) {
             stu32(slot, len);
             stu32(slot + 4, anchor);
@@ -4245,7 +4248,7 @@ __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
 // serial part of a block, its FSE state chain, is what bounds a wave; 16 waves per 512 KiB page instead of one).
 __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
     __shared__ ZEncLds Z;
-    if (a.lzc_chunk != ZPAR_CH) return;
+    if (a.lzc_codec != SB_CODEC_ZSTD) return;
     const uint32_t total = min(*a.lzc_count, a.lzc_cap);
     uint8_t* scratch = a.zpar_scratch + (uint64_t)blockIdx.x * zstd_scratch_bytes(ZPAR_CH);
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
@@ -4266,14 +4269,23 @@ __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
 }
 
 // frame header + the blocks [chunk0, chunk0 + nch) of src[0, n) back to back; returns the frame size.  sh: 2 * WG + 8 words.
+// (SNAPPY: the stream's uvarint length followed by the chunks' elements — the same concatenation)
+template <bool SNAPPY>
 __device__ uint32_t zstd_stitch_frame(const EncodeArgs& a, uint32_t n, uint32_t chunk0, uint32_t nch, uint8_t* dst, uint32_t* sh) {
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t *s_off = sh, *s_len = sh + WG, *s_w = sh + 2 * WG;
-    if (t == 0) ze_frame_header(dst, n);
-    uint32_t run = ze_frame_header_bytes(n);
-    if (nch == 0) {   // an empty buffer: one empty raw block, last
-        if (t == 0) { dst[run] = 1; dst[run + 1] = 0; dst[run + 2] = 0; }
-        return run + 3;
+    uint32_t run;
+    if (SNAPPY) {
+        if (t == 0) snappy_put_preamble(dst, n);
+        run = snappy_preamble_bytes(n);
+        if (nch == 0) return run;
+    } else {
+        if (t == 0) ze_frame_header(dst, n);
+        run = ze_frame_header_bytes(n);
+        if (nch == 0) {   // an empty buffer: one empty raw block, last
+            if (t == 0) { dst[run] = 1; dst[run + 1] = 0; dst[run + 2] = 0; }
+            return run + 3;
+        }
     }
     for (uint32_t b0 = 0; b0 < nch; b0 += WG) {
         const uint32_t k = b0 + t;
@@ -4383,26 +4395,28 @@ __device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, 
 
 __global__ void __launch_bounds__(WG) k_enc_lz4_stitch(EncodeArgs a) {
     __shared__ uint32_t sh[5 * WG + 8];
-    if (a.use_counts && a.codec_counts[SB_CODEC_LZ4] + a.codec_counts[SB_CODEC_ZSTD] == 0) return;
+    if (a.use_counts && a.codec_counts[a.lzc_codec & 31] == 0) return;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const LzChunkPlan pl = a.lzc_plan[page];
     if (pl.n_a + pl.n_b == 0) return;
     const EncPage p = get_page(a, page);
     const EncCol c = get_col(a, p.col);
     const LzBlocks b = lz4_page_blocks(a, c, p);
-    const bool zstd = a.lzc_chunk == ZPAR_CH;
-    const uint32_t codec = zstd ? SB_CODEC_ZSTD : SB_CODEC_LZ4;
+    const uint32_t codec = (uint32_t)a.lzc_codec;
+    const bool zstd = codec == SB_CODEC_ZSTD, snap = codec == SB_CODEC_SNAPPY;
     uint8_t* slot = page_slot(a, c, p);
     const uint64_t N = p.rows;
     const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
     uint8_t* blk = slot + pos;
-    const uint32_t s1 = zstd ? zstd_stitch_frame(a, b.n_a, pl.base, pl.n_a, blk + 9, sh)
+    const uint32_t s1 = zstd ? zstd_stitch_frame<false>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh)
+                        : snap ? zstd_stitch_frame<true>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh)
                              : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_a, b.n_a, pl.n_a, blk + 9, sh);
     if (threadIdx.x == 0) put_hdr9(blk, codec, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
     uint64_t length = pos + 9 + s1;
     if (b.src_b) {
         uint8_t* b2 = blk + 9 + s1;
-        const uint32_t s2 = zstd ? zstd_stitch_frame(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh)
+        const uint32_t s2 = zstd ? zstd_stitch_frame<false>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh)
+                            : snap ? zstd_stitch_frame<true>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh)
                                  : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_b, b.n_b, pl.n_b, b2 + 9, sh);
         if (threadIdx.x == 0) put_hdr9(b2, codec, s2, b.n_b);
         length += 9 + s2;
@@ -4671,7 +4685,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
     // LZ4 blocks of more than LZC_CH bytes are compressed chunk by chunk (flat pages, the matcher that is free to choose)
     const bool zs_possible = host_codec == SB_CODEC_ZSTD || (adaptive && opts->default_compression == SB_CODEC_ZSTD);
-    const bool lz_possible = zs_possible || (!(opts->flags & SB_WRITE_LZ4_EXACT) &&
+    const bool sn_possible = host_codec == SB_CODEC_SNAPPY || (adaptive && opts->default_compression == SB_CODEC_SNAPPY);
+    const bool lz_possible = zs_possible || sn_possible || (!(opts->flags & SB_WRITE_LZ4_EXACT) &&
                              (host_codec == SB_CODEC_LZ4 || (adaptive && opts->default_compression == SB_CODEC_LZ4)));
     const uint64_t lz_chunk = zs_possible ? ZPAR_CH : LZC_CH;
     uint64_t lz_cap = 0;
@@ -4981,6 +4996,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.lzc_pool = ctx->scratch.p + lz_pool_off;
     a.lzc_cap = (uint32_t)lz_cap;
     a.lzc_chunk = (uint32_t)lz_chunk;
+    a.lzc_codec = zs_possible ? SB_CODEC_ZSTD : sn_possible ? SB_CODEC_SNAPPY : SB_CODEC_LZ4;
     a.zpar_scratch = lz_cap && zs_possible ? ctx->scratch.p + zpar_off : nullptr;
     a.freq_count = (uint32_t*)(tb + o_freqcnt);
     a.codec_counts = (uint32_t*)(tb + o_freqcnt + 64);

@@ -1079,22 +1079,14 @@ __device__ __forceinline__ uint32_t snappy_put_copies(P o, uint32_t ml, uint32_t
     return k;
 }
 
-// Compress src[0, n) into dst (capacity >= 32 + n + n / 6); executed by ONE wave64; returns the stream size.
-template <int HB, int RB>
-__device__ uint32_t snappy_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
+// The elements of src[c0, c1) — a whole buffer or one chunk of it compressed by a wave of its own (ALONE: matches reach
+// back over the chunk border through the pre-loaded history, copies never cross it) — incl. the literal element that
+// closes the range: Snappy elements carry no state, so the chunks' outputs concatenate to one stream.  ONE wave64.
+template <int HB, int RB, bool ALONE>
+__device__ uint32_t snappy_compress_range(const uint8_t* src, uint32_t n, uint32_t c0, uint32_t c1, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
     constexpr uint32_t R = 1u << RB, RWM = R / 4 - 1;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t outp = 0, on = 0;
-    {
-        uint32_t v = n;
-        while (v >= 0x80) {
-            if (lane == 0) dst[outp] = (uint8_t)(v | 0x80);
-            v >>= 7;
-            outp++;
-        }
-        if (lane == 0) dst[outp] = (uint8_t)v;
-        outp++;
-    }
     auto flush_out = [&]() {
         wave_sync();
         for (uint32_t k = lane; k < on; k += 64) dst[outp + k] = L.out[k];
@@ -1109,11 +1101,14 @@ __device__ uint32_t snappy_compress_wave(const uint8_t* src, uint32_t n, uint8_t
         wave_copy_g2g(dst + outp, src + from, lit);
         outp += lit;
     };
-    uint32_t anchor = 0;
-    if (n >= 16) {
+    uint32_t anchor = c0;
+    if (c1 - c0 >= 16) {
         LzMatcher<HB, RB> mt(L, src, n);
         mt.init();
-        mt.begin_chunk(0, n - 4, n);
+        if (ALONE)
+            mt.begin_alone(c0, c1 - 4, c1);
+        else
+            mt.begin_chunk(c0, c1 - 4, c1);
         while (mt.next()) {
             const bool chosen = (mt.C >> lane) & 1;
             uint32_t lit_start_v = mt.anchor;
@@ -1176,9 +1171,27 @@ __device__ uint32_t snappy_compress_wave(const uint8_t* src, uint32_t n, uint8_t
         anchor = mt.anchor;
     }
     flush_out();
-    put_literal(anchor, n - anchor);
+    put_literal(anchor, c1 - anchor);
     wave_stores_visible();
     return outp;
+}
+__device__ __forceinline__ uint32_t snappy_put_preamble(uint8_t* dst, uint32_t n) {   // uvarint(n) by one lane; returns its size
+    uint32_t o = 0, v = n;
+    while (v >= 0x80) {
+        dst[o++] = (uint8_t)(v | 0x80);
+        v >>= 7;
+    }
+    dst[o++] = (uint8_t)v;
+    return o;
+}
+__device__ __forceinline__ uint32_t snappy_preamble_bytes(uint32_t n) { return n < (1u << 7) ? 1u : n < (1u << 14) ? 2u : n < (1u << 21) ? 3u : n < (1u << 28) ? 4u : 5u; }
+
+// Compress src[0, n) into dst (capacity >= 32 + n + n / 6); executed by ONE wave64; returns the stream size.
+template <int HB, int RB>
+__device__ uint32_t snappy_compress_wave(const uint8_t* src, uint32_t n, uint8_t* dst, Lz4EncLds<HB, RB>& L) {
+    if ((threadIdx.x & 63) == 0) snappy_put_preamble(dst, n);
+    const uint32_t h = snappy_preamble_bytes(n);
+    return h + snappy_compress_range<HB, RB, false>(src, n, 0, n, dst + h, L);
 }
 
 }  // namespace sb

@@ -1233,36 +1233,6 @@ __device__ __forceinline__ uint32_t snappy_compress_block_wg(const uint8_t* src,
     return *s_out;
 }
 __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);
-// Snappy raw stream made of one literal element (uvarint length | literal tag + length | bytes): what
-// snap::raw::Decoder (basic.rs:99-106) and sb's own decoder read back; no matching is attempted.
-__device__ uint32_t snappy_store_wg(const uint8_t* src, uint32_t n, uint8_t* dst) {
-    uint32_t op = 0;
-    uint32_t v = n;
-    while (v >= 0x80) {
-        if (threadIdx.x == 0) dst[op] = (uint8_t)(v | 0x80);
-        v >>= 7;
-        op++;
-    }
-    if (threadIdx.x == 0) dst[op] = (uint8_t)v;
-    op++;
-    if (n == 0) return op;
-    const uint32_t m = n - 1;
-    if (m < 60) {
-        if (threadIdx.x == 0) dst[op] = (uint8_t)(m << 2);
-        op += 1;
-    } else {
-        const uint32_t nb = m < (1u << 8) ? 1 : m < (1u << 16) ? 2 : m < (1u << 24) ? 3 : 4;
-        if (threadIdx.x == 0) {
-            dst[op] = (uint8_t)((59 + nb) << 2);
-            for (uint32_t k = 0; k < nb; k++) dst[op + 1 + k] = (uint8_t)(m >> (8 * k));
-        }
-        op += 1 + nb;
-    }
-    wg_copy(dst + op, src, n);
-    __syncthreads();
-    return op + n;
-}
-
 
 __device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, uint32_t chunk_bytes, const uint8_t* src, uint32_t n,
                                      uint32_t nch, uint8_t* dst, uint32_t* sh);
@@ -2247,7 +2217,6 @@ __device__ uint32_t choose_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
     if (!o.has_ratio || N == 0) return o.default_codec;
     const bool is_float = nk >= NK_F32;
     auto key = [&](uint64_t i) { return stat_key<W>(getv(i), nk); };
-    uint32_t* s4 = sc.s_misc + 2 * WG;
     // ---- one streaming pass: flags, null count, typed max, Boyer-Moore vote, and (W <= 8) an LDS
     // hash set of the canonical keys for the exact distinct count Dict needs
     STL(0);
@@ -3396,7 +3365,7 @@ __device__ void freq_prep_page(const EncodeArgs& a, EncCol* cols_rw, EncPage* pa
                                uint64_t ex_cap = ~0ull) {
     // dict_slot != nullptr: `c` / `p` describe the u32 index array of a Dict page whose real slot is dict_slot and
     // whose Dict block starts at dict_pos; the Freq block written here is the index block of that page
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x;
     const uint64_t N = p.rows;
     const uint8_t* vals = c.values + p.row0 * W;
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};

@@ -36,7 +36,6 @@ __device__ uint32_t select_rle_page(const EncodeArgs& a, const EncCol& c, const 
     const uint32_t nk = c.nk;
     const bool is_float = nk >= NK_F32;
     auto getv = [=](uint64_t i) { return ld_val<W>(vals + i * W); };
-    auto valid = [&](uint64_t i) { return vv.get(i); };
     auto forbidden = [&](uint32_t cd) { return (o.forbidden >> cd) & 1u; };
     auto k64 = [&](const Val<W>& k) {
         uint64_t x = 0;

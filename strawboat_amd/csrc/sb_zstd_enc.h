@@ -501,11 +501,6 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
                 const uint32_t value = (nb << 16) - (uint32_t)tt[sym].delta_nb_bits;
                 return st[(value >> nb) + tt[sym].delta_find_state];
             };
-            auto enc_sym = [&](uint32_t& state, const uint16_t* st, const ZeSymTT* tt, uint32_t sym) {
-                const uint32_t nb = (uint32_t)(state + tt[sym].delta_nb_bits) >> 16;
-                bs.add(state, nb);
-                state = st[(state >> nb) + tt[sym].delta_find_state];
-            };
             for (uint32_t hi_k = nseq; hi_k > 0; hi_k -= min(hi_k, 64u)) {
                 const uint32_t cnt = min(hi_k, 64u);
                 if (lane < cnt) {

@@ -769,7 +769,7 @@ __device__ uint32_t plan_rle(const uint8_t* body, uint32_t csize, uint32_t rec, 
 // the header offsets and, for delta pages, the running sum at each tile start.
 // The walk is a serial pointer chase (block k+1's position depends on block k's header); the
 // body is staged through LDS in windows so each step costs an LDS read, not an HBM miss.
-constexpr int BP_WINDOW = 32 * 1024;
+constexpr int BP_WINDOW = 16 * 1024;   // (k_plan: 17 KB of tile words + this window + <= 128 VGPRs = 4 workgroups per CU)
 __device__ bool plan_bp(const uint8_t* body, uint32_t csize, uint64_t N, bool delta, uint32_t* aux,
                         uint8_t* s_win, uint32_t* s_a, uint32_t* s_w, Status* st, uint32_t page) {
     const int t = threadIdx.x;
@@ -1120,7 +1120,9 @@ __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, cons
     return true;
 }
 
-__global__ void __launch_bounds__(WG) k_plan(DecodeArgs a) {
+// 4 workgroups per CU (LDS and registers): a 64-column x 16-page batch is 1024 pages = ONE round of the chip; at 3 per CU
+// it took two, and a page's plan is a latency chain of ~1 ms whatever else runs
+__global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
     if (a.job_counts[3] == 0) return;  // no page of this call needs a plan (k_parse counts them)
     const uint32_t p = blockIdx.x;
     __shared__ uint32_t s_a[SIDX_WORDS];

@@ -411,23 +411,40 @@ def run_c4_sharded(h, world, rank, dist, steps=3, on_device=True):
             full[ci] = dict(ptype=W.T_BOOL, nullable=True, rows=rows, values=W.pack_bits(rng.random(rows) < 0.5),
                             validity=W.pack_bits(rng.random(rows) >= 0.1), offsets=None)
     opts = WriteOptions(max_page_size=PAGE, default_compression=C.LZ4, default_compress_ratio=2.0)
-    parts = [shard.slice_column(full[it.column], it.first_page, it.n_pages, PAGE) for it in mine]
-    U_local = sum(W.arrow_bytes(c) for c in parts)
-    dcs = []
-    for it, c in zip(mine, parts):
-        d = h.dcol(c)
-        d.first_page_index = it.first_page
-        d.column_values_len = c.get("column_values_len", 0)
-        dcs.append(d)
-    del full
-    enc = write.encode_columns(ctx, dcs, opts)
-    ctx.synchronize()
-    cps = [read.ColumnPages(c["ptype"], c["nullable"], e.pages, e.metas_array()) for c, e in zip(parts, enc)]
-    dec = read.batch_read_columns(ctx, cps)
-    ctx.synchronize()
-    if parts:
-        h.check_round_trip(parts[0], dec[0])
-    wb, rb = write.WriteBatch(ctx, dcs, opts, out=enc), read.ReadBatch(ctx, cps, out=dec)
+    cdev = h.dev if (world > 1 and on_device) else None
+
+    def all_ok(ok):
+        """every rank reaches this: True only if no rank failed (a rank that raised alone would leave the others waiting in
+        the next collective)"""
+        if world == 1:
+            return ok
+        f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item() > 0.5)
+
+    err = None
+    try:
+        parts = [shard.slice_column(full[it.column], it.first_page, it.n_pages, PAGE) for it in mine]
+        U_local = sum(W.arrow_bytes(c) for c in parts)
+        dcs = []
+        for it, c in zip(mine, parts):
+            d = h.dcol(c)
+            d.first_page_index = it.first_page
+            d.column_values_len = c.get("column_values_len", 0)
+            dcs.append(d)
+        del full
+        enc = write.encode_columns(ctx, dcs, opts)
+        ctx.synchronize()
+        cps = [read.ColumnPages(c["ptype"], c["nullable"], e.pages, e.metas_array()) for c, e in zip(parts, enc)]
+        dec = read.batch_read_columns(ctx, cps)
+        ctx.synchronize()
+        if parts:
+            h.check_round_trip(parts[0], dec[0])
+        wb, rb = write.WriteBatch(ctx, dcs, opts, out=enc), read.ReadBatch(ctx, cps, out=dec)
+    except Exception as e:   # reported, not fatal: the headline line must not depend on this configuration
+        err = "%s: %s" % (type(e).__name__, e)
+    if not all_ok(err is None):
+        return {"error": err or "another rank failed while preparing its work items"} if rank == 0 else None
     cap = shard.record_capacity(plan)
 
     def barrier():
@@ -436,13 +453,16 @@ def run_c4_sharded(h, world, rank, dist, steps=3, on_device=True):
         torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        wb.enqueue()
-        rb.enqueue()
-    ctx.synchronize()
-    items = [(it.column, it.first_page, e.metas_array()) for it, e in zip(mine, enc)]
-    allm = shard.gather_metas(items, len(names), capacity=cap, device=h.dev if (world > 1 and on_device) else None)
-    cm = shard.column_metas(allm)
+    items = []
+    try:
+        for _ in range(steps):
+            wb.enqueue()
+            rb.enqueue()
+        ctx.synchronize()
+        items = [(it.column, it.first_page, e.metas_array()) for it, e in zip(mine, enc)]
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, e)
+    allm = shard.gather_metas(items, len(names), capacity=cap, device=cdev)   # (every rank takes part, whatever happened above)
     barrier()
     el = time.perf_counter() - t0
     tt = torch.tensor([el, float(U_local)], dtype=torch.float64, device=h.dev if on_device else "cpu")
@@ -454,7 +474,14 @@ def run_c4_sharded(h, world, rank, dist, steps=3, on_device=True):
         el, U = float(mx[0].item()), float(sm[1].item())
     else:
         U = float(U_local)
-    assert all(len(m.pages) == npages for m in cm), "every column must come back with all of its pages"
+    if err is None:
+        try:
+            cm = shard.column_metas(allm)
+            assert all(len(m.pages) == npages for m in cm), "every column must come back with all of its pages"
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, e)
+    if not all_ok(err is None):
+        return {"error": err or "another rank failed in the timed region"} if rank == 0 else None
     if rank != 0:
         return None
     return {"workload": "C4: 8-column mixed schema x 10 M rows, %d (column, page-range) work items over %d GPU(s), LZ4 default, ratio 2.0, "
@@ -582,15 +609,18 @@ def main():
     stats = ctx.profile_read()
     ctx.profile(False)
 
-    c4s = None
-    if world > 1 and not args.no_configs:   # the configuration BASELINE names for 8 GPUs, sharded by page ranges
-        del wbatch, rbatch
-        c4s = run_c4_sharded(harness, world, rank, dist, on_device=args.backend == "nccl")
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    c4s = None
+    if world > 1 and not args.no_configs:   # the configuration BASELINE names for 8 GPUs, sharded by page ranges
+        del wbatch, rbatch
+        try:   # (its own failures are caught inside, rank-collectively; this guards what is not: the headline line comes first)
+            c4s = run_c4_sharded(harness, world, rank, dist, on_device=args.backend == "nccl")
+        except Exception as e:
+            c4s = {"error": "%s: %s" % (type(e).__name__, e)}
     ms_per_step = elapsed / args.steps * 1e3
     value = world * 2.0 * U * args.steps / elapsed / 1e9   # whole job: encode + decode bytes
 

@@ -245,3 +245,44 @@ def test_column_of_empty_lists(gpu_ctx, ptype):
                                   WriteOptions(default_compression=dc, max_page_size=300, default_compress_ratio=2.0, lz4_exact=True))
         assert np.array_equal(enc.metas_array(), want_metas)
         assert np.array_equal(enc.pages_numpy(), want_pages)
+
+
+@pytest.mark.parametrize("dc", [S.NONE, S.LZ4, S.ZSTD])
+def test_leaves_of_an_array_in_one_call(gpu_ctx, dc):
+    """write_nested_leaves / read_nested_leaves (all leaves of a nested array through ONE sb_write_columns / sb_read_columns
+    call, as encode_chunk loops over an array's leaves, src/write/common.rs:60-116): the pages of every leaf are the
+    pages the one-leaf calls write, and the batch read rebuilds the same buffers — Int64, Utf8 and Boolean leaves under
+    two different nestings"""
+    from strawboat_amd import WriteOptions, nested
+    from strawboat_amd.read import ColumnPages
+    items, singles, metas = [], [], []
+    opts = WriteOptions(max_page_size=4096, default_compression=dc)
+    for shape, ptype, seed in (("list_struct", S.T_I64, 3), ("list_struct", S.T_BIN32, 4), ("list_list", S.T_BOOL, 5)):
+        levels, rows = make_nested(shape, 20_000, seed)
+        dcol, vals, offs = _leaf_column(gpu_ctx, levels, ptype, seed + 10)
+        dl = device_levels(gpu_ctx, levels)
+        items.append((dl, dcol))
+        one = nested.write_nested(gpu_ctx, dl, dcol, opts)
+        singles.append((one.pages_numpy().copy(), one.metas_array().copy()))
+        metas.append((levels, ptype))
+    encs = nested.write_nested_leaves(gpu_ctx, items, opts)
+    assert len(encs) == 3
+    cps, kinds, nul = [], [], []
+    for e, (pages1, metas1), (levels, ptype) in zip(encs, singles, metas):
+        assert np.array_equal(e.metas_array(), metas1)
+        assert np.array_equal(e.pages_numpy(), pages1), "a leaf's pages differ between the batch and the one-leaf call"
+        cps.append(ColumnPages(ptype, False, e.pages[:e.length].contiguous(), e.metas_array()))
+        kinds.append([lv["kind"] for lv in levels])
+        nul.append([bool(lv["is_optional"]) for lv in levels])
+    arrs = nested.read_nested_leaves(gpu_ctx, cps, kinds, nul)
+    for arr, cp, k, o, (levels, ptype) in zip(arrs, cps, kinds, nul, metas):
+        one = nested.read_nested(gpu_ctx, cp, k, o)
+        assert arr.lengths == one.lengths
+        for lvl, lv in enumerate(levels):
+            if lv["kind"] in (S.K_LIST, S.K_LARGE_LIST):
+                assert np.array_equal(arr.offsets_numpy(lvl), one.offsets_numpy(lvl))
+                assert np.array_equal(arr.offsets_numpy(lvl), np.asarray(lv["offsets"]).astype(np.int64))
+        assert np.array_equal(arr.leaf.values_numpy(), one.leaf.values_numpy())
+        assert np.array_equal(arr.leaf.validity_numpy(), one.leaf.validity_numpy())
+        if ptype == S.T_BIN32:
+            assert np.array_equal(arr.leaf.offsets_numpy(), one.leaf.offsets_numpy())

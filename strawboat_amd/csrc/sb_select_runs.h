@@ -16,7 +16,9 @@
 // The run values travel through LDS.  A chunk's rows are requested at the top of its iteration: requesting the next
 // chunk before step 2 (measured, round 2) keeps 32 more VGPRs live across step 2, which either spills at 4 waves /
 // SIMD (1.58 ms on C2 instead of 1.10) or drops the kernel to 3 waves / SIMD (1.33 ms) — the other three
-// workgroups of the CU are what hides the load latency.
+// workgroups of the CU are what hides the load latency.  More workgroups per CU do not help either (measured, round 2,
+// with a 16 KiB key set so that LDS allows 6): 5 waves / SIMD (96 VGPRs, 252 B of scratch) 1.22 ms, 6 waves / SIMD
+// (80 VGPRs, 320 B of scratch) 1.38 ms, against 1.19 ms on the same box — the kernel is bound by instruction issue.
 //
 // A chunk (4096 rows) with more than RUNS_CAP raw runs (runs shorter than ~6 rows on average) makes
 // the page FALL BACK to select_rle_page (k_enc_select_rle runs after this kernel and takes the pages

@@ -59,21 +59,31 @@ for ci, (col, name) in enumerate(CASES):
             print("   oracle refuses:", e)
             continue
         o = dict(opt)
-        wo = WriteOptions(max_page_size=65536, default_compression=o.get("default_compression", S.NONE),
-                          default_compress_ratio=o.get("ratio"), forbidden_compressions=list(o.get("forbidden", ())),
-                          force_codec=o.get("force_codec", -1), force_index_codec=o.get("force_index_codec", -1))
-        dc = write.DeviceColumn(col["ptype"], col["nullable"], col["rows"], at_end(col["values"]), at_end(col["validity"]), at_end(col["offsets"]))
-        try:
-            enc = write.encode_columns(ctx, [dc], wo)
-            ctx.synchronize()
-        except NativeError as e:
-            print("   device refuses:", e)
+        lz4 = o.get("default_compression") == S.LZ4 or o.get("force_index_codec") == S.LZ4
+        for exact in ((True, False) if lz4 else (True,)):   # both LZ4 encoders: byte-exact (compared) and the parallel default
+            wo = WriteOptions(max_page_size=65536, default_compression=o.get("default_compression", S.NONE),
+                              default_compress_ratio=o.get("ratio"), forbidden_compressions=list(o.get("forbidden", ())),
+                              force_codec=o.get("force_codec", -1), force_index_codec=o.get("force_index_codec", -1), lz4_exact=exact)
+            dc = write.DeviceColumn(col["ptype"], col["nullable"], col["rows"], at_end(col["values"]), at_end(col["validity"]), at_end(col["offsets"]))
+            try:
+                enc = write.encode_columns(ctx, [dc], wo)
+                ctx.synchronize()
+            except NativeError as e:
+                print("   device refuses:", e)
+                enc = None
+                break
+            n += 1
+            if exact and opt.get("default_compression") != S.ZSTD:
+                if not np.array_equal(enc[0].pages_numpy(), want_pages):
+                    bad += 1
+                    print("   MISMATCH")
+            if exact and lz4:   # (the parallel encoder's pages are checked by the decode below)
+                got = read.read_simple(ctx, read.ColumnPages(col["ptype"], col["nullable"], at_end(enc[0].pages_numpy()), enc[0].metas_array()))
+                if not np.array_equal(got.values_numpy(), gen.oracle_read(col, want_pages, want_metas)["values"]):
+                    bad += 1
+                    print("   DECODE MISMATCH (exact)")
+        if enc is None:
             continue
-        n += 1
-        if opt.get("default_compression") != S.ZSTD:
-            if not np.array_equal(enc[0].pages_numpy(), want_pages):
-                bad += 1
-                print("   MISMATCH")
         # decode from a buffer flush against the end as well
         pages = at_end(enc[0].pages_numpy())
         got = read.read_simple(ctx, read.ColumnPages(col["ptype"], col["nullable"], pages, enc[0].metas_array()))

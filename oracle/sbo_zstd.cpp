@@ -519,7 +519,7 @@ void zstd_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t out_len)
     In in{src, src + n};
     uint8_t* op = dst;
     uint8_t* oend = dst + out_len;
-    // zstd::bulk::decompress_to_buffer decodes exactly one frame (plus skippable frames)
+    // zstd::bulk::decompress_to_buffer ends in ZSTD_decompress: any number of frames (and skippable frames) back to back
     while (in.left() >= 4) {
         uint32_t magic = in.le(4);
         if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame

@@ -395,6 +395,9 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     if (P >= 0x7FFFFFFFull || T >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many pages in one call");
 
     // ---- table layout
+    uint64_t pages_bytes = 0;
+    for (uint64_t i = 0; i < n; i++) pages_bytes += cols[i].pages_len;
+    const size_t zs_extra = (size_t)std::min<uint64_t>(1u << 20, pages_bytes / 256 + 64);
     size_t off = 0;
     const size_t o_cols = off;
     off = align_up(off + n * sizeof(ColDesc), 64);
@@ -405,10 +408,12 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     off = align_up(off + P * sizeof(PageDesc), 64);
     const size_t o_tiles = off;
     off = align_up(off + T * sizeof(TileTask), 64);
+    // queue entries: 2 per page + room for the frames of Zstd buffers that are several frames (one entry per frame)
+    const size_t job_cap = 2 * P + zs_extra;
     const size_t o_jobs_a = off;
-    off = align_up(off + 2 * P * sizeof(InflateJob), 64);
+    off = align_up(off + job_cap * sizeof(InflateJob), 64);
     const size_t o_jobs_b = off;
-    off = align_up(off + 2 * P * sizeof(InflateJob), 64);
+    off = align_up(off + job_cap * sizeof(InflateJob), 64);
     const size_t o_counts = off;
     off = align_up(off + 64, 64);
     const size_t o_vlen = off;
@@ -531,6 +536,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
 
     a.sizes_only = sizes_only ? 1u : 0u;
     a.defer_payloads = (!sizes_only && any_binary) ? 1u : 0u;
+    a.job_cap_a = a.job_cap_b = (uint32_t)job_cap;
     if (sizes_only) {
         if (P) launch_parse_sizes(ctx, a, d_vlen);
     } else {

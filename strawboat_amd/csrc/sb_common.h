@@ -119,9 +119,9 @@ struct DecodeArgs {
     TileTask* tiles;
     uint8_t* scratch;
     Status* status;
-    InflateJob* jobs_a;  // capacity 2 * n_pages
-    InflateJob* jobs_b;  // capacity 2 * n_pages
-    uint32_t* job_counts;  // [0] = queue A, [1] = queue B
+    InflateJob* jobs_a;  // capacity job_cap_a
+    InflateJob* jobs_b;  // capacity job_cap_b
+    uint32_t* job_counts;  // [0] = queue A, [1] = queue B, [2] tiles, [3] planned pages, [4] page-level RLE, [5] / [6] workgroups of k_parse / k_colscan that are done
     uint8_t* zlit;         // Zstd literal buffers, one per inflate wave
     uint32_t n_pages;
     uint32_t n_cols;
@@ -132,6 +132,7 @@ struct DecodeArgs {
     uint32_t no_freq;      // second pass: an exceptions block never holds a Freq block (freq.rs:78-79)
     uint32_t sizes_only;   // sb_read_columns_sizes: only what values_len depends on is inflated (nested index blocks)
     uint32_t defer_payloads;  // the call has binary columns (queue B runs): Basic payloads nothing waits for go there too
+    uint32_t job_cap_a, job_cap_b;  // entries of the two job queues (2 * n_pages + room for the frames of split Zstd buffers)
 };
 
 }  // namespace sb

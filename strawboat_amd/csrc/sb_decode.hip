@@ -40,6 +40,96 @@ __device__ __forceinline__ void push_job(InflateJob* q, uint32_t* cnt, const uin
     q[i] = j;
 }
 
+// ---- Zstd buffers made of several frames (what this library's encoder writes for buffers of more than 32 KiB, and what
+// ZSTD_decompress accepts from anyone): one job per frame, so that a page's frames decode on waves of their own.
+constexpr uint32_t CODEC_SPLIT = 0xFF;   // a queue entry whose frames were queued one by one (k_inflate skips it)
+// One frame at src[pos..n): its size and its content size.  false: not a plain frame with a known content size.
+__device__ inline bool zstd_frame_extent(const uint8_t* src, uint32_t n, uint32_t pos, uint32_t* fsize, uint32_t* fcs_out) {
+    if (n - pos < 6 || ldu32(src + pos) != 0xFD2FB528u) return false;
+    uint32_t ip = pos + 4;
+    const uint8_t fhd = ldu8(src + ip++);
+    const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+    if ((fhd & 0x08) || did) return false;
+    if (!single) ip += 1;
+    const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
+    if (fcs_bytes == 0 || fcs_bytes == 8 || n - ip < (uint32_t)fcs_bytes) return false;
+    uint32_t fcs = 0;
+    for (int i = 0; i < fcs_bytes; i++) fcs |= (uint32_t)ldu8(src + ip + i) << (8 * i);
+    if (fcs_bytes == 2) fcs += 256;
+    ip += fcs_bytes;
+    for (;;) {
+        if (n - ip < 3) return false;
+        const uint32_t bh = (uint32_t)ldu8(src + ip) | ((uint32_t)ldu8(src + ip + 1) << 8) | ((uint32_t)ldu8(src + ip + 2) << 16);
+        ip += 3;
+        const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3) return false;
+        const uint32_t body = btype == 1 ? 1u : bsize;
+        if (n - ip < body) return false;
+        ip += body;
+        if (bh & 1) break;
+    }
+    if (checksum) {
+        if (n - ip < 4) return false;
+        ip += 4;
+    }
+    *fsize = ip - pos;
+    *fcs_out = fcs;
+    return true;
+}
+// Executed by ONE workgroup when the queue is complete: every Zstd entry that is >= 2 well-formed frames whose content
+// sizes add up to the entry's output is replaced by one entry per frame (thread = entry; the walk reads a few bytes per
+// frame).  Anything else stays as it is and is decoded by one wave, frame after frame.
+__device__ void zstd_split_queue(InflateJob* q, uint32_t* cnt, uint32_t cap) {
+    const uint32_t n0 = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t j = threadIdx.x; j < n0 && j < cap; j += blockDim.x) {
+        const InflateJob job = q[j];
+        if (job.codec != SB_CODEC_ZSTD) continue;
+        uint32_t nf = 0, pos = 0, total = 0;
+        bool ok = true;
+        while (pos < job.csize) {
+            uint32_t fs, fc;
+            if (!zstd_frame_extent(job.src, job.csize, pos, &fs, &fc) || fc > job.out_len - total) {
+                ok = false;
+                break;
+            }
+            pos += fs;
+            total += fc;
+            nf++;
+        }
+        if (!ok || nf < 2 || total != job.out_len) continue;
+        const uint32_t base = atomicAdd(cnt, nf);
+        if (base + nf > cap) {   // no room: the entry keeps its frames
+            atomicSub(cnt, nf);
+            continue;
+        }
+        pos = 0;
+        total = 0;
+        for (uint32_t k = 0; k < nf; k++) {
+            uint32_t fs = 0, fc = 0;
+            zstd_frame_extent(job.src, job.csize, pos, &fs, &fc);
+            InflateJob f = job;
+            f.src = job.src + pos;
+            f.dst = job.dst + total;
+            f.csize = fs;
+            f.out_len = fc;
+            q[base + k] = f;
+            pos += fs;
+            total += fc;
+        }
+        q[j].codec = CODEC_SPLIT;
+    }
+}
+// true in every thread of the LAST workgroup of the grid to get here (all threads of every workgroup must call it)
+__device__ bool last_workgroup_done(uint32_t* counter) {
+    __shared__ uint32_t s_last_wg;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last_wg = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last_wg) __threadfence();
+    return s_last_wg != 0;
+}
+
 // -------------------------------------------------------------------------------- parse
 #ifdef SB_TIMELINE  // scripts/micro/expand_timeline.hip: s_memtime stamps of one tile's phases
 __device__ unsigned long long* g_dtl;
@@ -57,9 +147,7 @@ __device__ __forceinline__ bool rle_by_page(const ColDesc& c, const PageDesc& d)
            c.width <= 8;
 }
 
-__global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_pages) return;
+__device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p) {
     const PageTask t = a.tasks[p];
     const ColDesc c = a.cols[t.col];
     PageDesc d;
@@ -379,6 +467,12 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
     }
 #undef FAIL
 }
+__global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < a.n_pages) parse_page(a, p);
+    // queue A is complete when the last workgroup is done: its multi-frame Zstd entries become one entry per frame
+    if (last_workgroup_done(&a.job_counts[5])) zstd_split_queue(a.jobs_a, a.job_counts, a.job_cap_a);
+}
 
 // -------------------------------------------------------------------------------- inflate (LZ4)
 // One wave per block.  Sequences are parsed wave-uniformly (every lane walks the same token
@@ -630,8 +724,8 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
     const uint32_t njobs = *count;
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
-        if (j.codec == SB_CODEC_LZ4) {
-            // k_inflate_lz4 owns the LZ4 blocks
+        if (j.codec == SB_CODEC_LZ4 || j.codec == CODEC_SPLIT) {
+            // k_inflate_lz4 owns the LZ4 blocks; a split Zstd buffer is decoded through its frames' entries
         } else if (j.codec == SB_CODEC_ZSTD) {
             zstd_inflate_wave(j.src, j.csize, j.dst, j.out_len, &wk, zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE);
             if (threadIdx.x == 0 && wk.err) raise(st, SB_ERR_EXTERNAL, j.page, 120 + (uint32_t)wk.err);
@@ -1273,9 +1367,7 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
 // binary columns: value-byte base and offset base of each page (the running `last` of
 // decompress_binary, binary/mod.rs:121,136-144, and values.len()), queue-B inflate jobs for
 // compressed values blocks, and the column's total value bytes.
-__global__ void k_colscan(DecodeArgs a, uint64_t* col_values_len) {
-    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ci >= a.n_cols) return;
+__device__ __forceinline__ void colscan_column(const DecodeArgs& a, uint64_t* col_values_len, const uint32_t ci) {
     const ColDesc c = a.cols[ci];
     if (!is_binary(c.ptype)) {
         col_values_len[ci] = c.ptype == SB_TYPE_BOOLEAN ? (c.rows + 7) / 8 : c.rows * c.width;
@@ -1302,6 +1394,12 @@ __global__ void k_colscan(DecodeArgs a, uint64_t* col_values_len) {
     }
     col_values_len[ci] = vbase;
     if (vbase > c.values_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 300);
+}
+__global__ void k_colscan(DecodeArgs a, uint64_t* col_values_len) {
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci < a.n_cols) colscan_column(a, col_values_len, ci);
+    // queue B is complete now (k_parse's deferred payloads + the value blocks queued above): split its multi-frame entries
+    if (!a.sizes_only && last_workgroup_done(&a.job_counts[6])) zstd_split_queue(a.jobs_b, a.job_counts + 1, a.job_cap_b);
 }
 
 // -------------------------------------------------------------------------------- expand
@@ -1888,14 +1986,14 @@ void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, cons
 
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 5 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 8 * sizeof(uint32_t), s);
     {
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     }
     {
         KScope k(ctx, K_INFLATE_A);
-        k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
+        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
     }
     {
         KScope k(ctx, "k_inflate_lz4");
@@ -1911,7 +2009,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
-        k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
+        k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
         KScope k2(ctx, "k_inflate_lz4(values)");
         k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
     }
@@ -1931,9 +2029,9 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
 
 void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 5 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 8 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-    k_inflate<<<min(2 * a.n_pages, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
+    k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
     k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);

@@ -4212,9 +4212,10 @@ __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
     }
 }
 
-// Zstd: the same plan, with the frame's BLOCKS (32 KiB) as chunks — a frame is a header followed by self-delimiting
-// blocks, and this encoder's blocks carry no state into each other, so they are compressed by waves of their own (the
-// serial part of a block, its FSE state chain, is what bounds a wave; 16 waves per 512 KiB page instead of one).
+// Zstd: the same plan with 32 KiB pieces, each written as a FRAME of its own — concatenated frames are one valid
+// compressed buffer for ZSTD_decompress (what the reference calls), and they share nothing, so both directions run one
+// wave per piece (the serial part of a piece, its FSE state chain, is what bounds a wave; 16 waves per 512 KiB page
+// instead of one).  The price is the cold start of every piece: no history, a Huffman table per piece.
 __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
     __shared__ ZEncLds Z;
     if (a.lzc_codec != SB_CODEC_ZSTD) return;
@@ -4237,25 +4238,24 @@ __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
     }
 }
 
-// frame header + the blocks [chunk0, chunk0 + nch) of src[0, n) back to back; returns the frame size.  sh: 2 * WG + 8 words.
+// the frames [chunk0, chunk0 + nch) of the pieces of src[0, n) back to back; returns their size.  sh: 2 * WG + 8 words.
 // (SNAPPY: the stream's uvarint length followed by the chunks' elements — the same concatenation)
 template <bool SNAPPY>
 __device__ uint32_t zstd_stitch_frame(const EncodeArgs& a, uint32_t n, uint32_t chunk0, uint32_t nch, uint8_t* dst, uint32_t* sh) {
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t *s_off = sh, *s_len = sh + WG, *s_w = sh + 2 * WG;
-    uint32_t run;
+    uint32_t run = 0;
     if (SNAPPY) {
         if (t == 0) snappy_put_preamble(dst, n);
         run = snappy_preamble_bytes(n);
         if (nch == 0) return run;
-    } else {
-        if (t == 0) ze_frame_header(dst, n);
-        run = ze_frame_header_bytes(n);
-        if (nch == 0) {   // an empty buffer: one empty raw block, last
-            if (t == 0) { dst[run] = 1; dst[run + 1] = 0; dst[run + 2] = 0; }
-            return run + 3;
+    } else if (nch == 0) {   // an empty buffer: one frame with one empty raw block
+        if (t == 0) {
+            const uint32_t h = ze_frame_header(dst, 0);
+            dst[h] = 1; dst[h + 1] = 0; dst[h + 2] = 0;
         }
-    }
+        return ze_frame_header_bytes(0) + 3;
+    }   // (Zstd: the chunks are whole frames, nothing in front of them)
     for (uint32_t b0 = 0; b0 < nch; b0 += WG) {
         const uint32_t k = b0 + t;
         const uint32_t len = k < nch ? ldu32(a.lzc_pool + (uint64_t)(chunk0 + k) * LZC_SLOT) : 0u;

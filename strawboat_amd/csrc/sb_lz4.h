@@ -693,11 +693,12 @@ struct LzMatcher {
     // A chunk compressed by a wave of its own (c0 % 1024 == 0): the 5 KiB of input before it — what the ring of a wave
     // that had compressed them would still hold — are loaded and entered into the table, so matches reach back over the
     // chunk border as they do inside a chunk (the input is all there; only the OUTPUT of the chunks is independent).
-    __device__ void begin_alone(uint32_t c0, uint32_t mfl, uint32_t mtl) {
+    // history = false: no match may reach below c0 (the chunk becomes a Zstd frame of its own: a frame's window starts with it)
+    __device__ void begin_alone(uint32_t c0, uint32_t mfl, uint32_t mtl, bool history = true) {
         const uint32_t lane = threadIdx.x & 63;
-        hi = lo0 = c0 >= 5120 ? c0 - 5120 : 0;
+        hi = lo0 = (history && c0 >= 5120) ? c0 - 5120 : c0;
         begin_chunk(c0, mfl, mtl);
-        if (c0 == 0) return;
+        if (c0 == 0 || !history) return;
         fill(c0 + 1024);
         for (uint32_t x = lo0 + lane; x < c0; x += 64) L.tab[(rd4(x) * 2654435761u) >> (32 - HB)] = (uint16_t)(x & 0xFFFF);
         wave_sync();

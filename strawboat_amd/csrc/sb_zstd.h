@@ -352,13 +352,7 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    if (lane == 0) {
-        wk->err = 0;
-        wk->have_ll = wk->have_of = wk->have_ml = wk->have_huf = 0;
-        wk->rep[0] = 1;
-        wk->rep[1] = 4;
-        wk->rep[2] = 8;
-    }
+    if (lane == 0) wk->err = 0;
     for (int i = lane; i < 53; i += 64) {
         wk->t_mlbase[i] = Z_ML_BASE[i];
         wk->t_mlbits[i] = Z_ML_BITS[i];
@@ -376,6 +370,23 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         wsync();                       \
         return 0;                      \
     } while (0)
+    LzSeqExec ex(wk->ring, dst);   // sequences run through an LDS output ring; everything else writes HBM directly
+    // One or more frames back to back — ZSTD_decompress, which zstd::bulk::decompress_to_buffer (basic.rs:93-97) ends in,
+    // decodes "any number of frames concatenated"; this library's encoder writes the 32 KiB pieces of a large buffer as
+    // frames of their own so that they decode in parallel (k_parse queues one job per frame; a buffer whose frames were
+    // not split arrives here whole).
+    bool first_frame = true;
+    for (;;) {   // frames
+    if (lane == 0) {   // entropy tables and repeat offsets do not carry over between frames
+        wk->have_ll = wk->have_of = wk->have_ml = wk->have_huf = 0;
+        wk->rep[0] = 1;
+        wk->rep[1] = 4;
+        wk->rep[2] = 8;
+    }
+    wsync();
+    if (!first_frame) ex.restart(op);
+    first_frame = false;
+    const uint32_t frame_op0 = op;
     // frame header (all lanes, uniform)
     for (;;) {  // skippable frames
         if (n - ip < 4) ZERR(1);
@@ -411,7 +422,6 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         if (fcs_bytes == 2) fcs += 256;
         ip += fcs_bytes;
     }
-    LzSeqExec ex(wk->ring, dst);   // sequences run through an LDS output ring; everything else writes HBM directly
     for (;;) {  // blocks
         if (n - ip < 3) ZERR(9);
         const uint32_t bh = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
@@ -739,10 +749,15 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
         }
         if (last) break;
     }
+    if (checksum) {
+        if (n - ip < 4) ZERR(35);
+        ip += 4;
+    }
+    if (fcs_bytes && fcs != op - frame_op0) ZERR(33);
+    if (ip >= n) break;
+    }   // frames
     LZP(19);
     LZP_END;
-    if (checksum) ip += 4;
-    if (fcs_bytes && fcs != op) ZERR(33);
     if (op != out_len) ZERR(34);
 #undef ZERR
     return op;

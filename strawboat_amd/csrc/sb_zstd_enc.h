@@ -278,9 +278,8 @@ __host__ __device__ __forceinline__ uint64_t zstd_scratch_bytes(uint64_t n) {
     return 6 * ((b + 15) & ~15ull) + 256;
 }
 // One block of a frame: src[c0, c1) of the input src[0, n) -> 3-byte header + content at bh; returns its size.  The matcher
-// carries its history from the blocks before (ALONE = false, one wave walks the frame) or loads it itself (ALONE = true:
-// the blocks of a frame are compressed by waves of their own and concatenated — a frame's blocks are self-delimiting, and
-// this encoder's blocks never depend on each other's entropy tables or repeat offsets).  `scratch`: zstd_scratch_bytes(cap).
+// carries its history from the blocks before (ALONE = false, one wave walks the frame) or starts without any (ALONE =
+// true: the block is the only one of a frame of its own, see zstd_compress_block_alone).  `scratch`: zstd_scratch_bytes(cap).
 template <bool ALONE, class MT>
 __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32_t c1, bool last_block, uint8_t* bh, ZEncLds& Z,
                              uint8_t* scratch, uint32_t blk_cap, MT& mt) {
@@ -296,7 +295,7 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
     uint32_t tail_from = c0;
     if (blk >= 32) {
         if (ALONE)
-            mt.begin_alone(c0, c1 - 12, c1 - 5);
+            mt.begin_alone(c0, c1 - 12, c1 - 5, false);
         else
             mt.begin_chunk(c0, c1 - 12, c1 - 5);
         LZP(8);
@@ -641,13 +640,18 @@ __device__ uint32_t zstd_compress_wave(const uint8_t* src, uint32_t n, uint8_t* 
     return o;
 }
 
-// One block [c0, c1) of the frame of src[0, n) compressed by a wave of its own (see ze_block) into `out`; returns its size.
+// The piece [c0, c1) of the buffer src[0, n) as a FRAME of its own (header with the piece's size + one block), compressed
+// by a wave of its own into `out`; returns the frame's size.  A buffer's frames, back to back, are what ZSTD_decompress
+// — and with it zstd::bulk::decompress_to_buffer, src/compression/basic.rs:93-97 — reads as one buffer; frames share no
+// state (no window, tables or repeat offsets), so they are compressed AND decompressed independently, one wave each.
 __device__ uint32_t zstd_compress_block_alone(const uint8_t* src, uint32_t n, uint32_t c0, uint32_t c1, uint8_t* out, ZEncLds& Z,
                                               uint8_t* scratch, uint32_t blk_cap) {
+    if ((threadIdx.x & 63) == 0) ze_frame_header(out, c1 - c0);
+    const uint32_t h = ze_frame_header_bytes(c1 - c0);
     ze_tables(Z);
     LzMatcher<12, 13> mt(Z.lz, src, n);
     mt.init();
-    return ze_block<true>(src, n, c0, c1, c1 == n, out, Z, scratch, blk_cap, mt);
+    return h + ze_block<true>(src, n, c0, c1, true, out + h, Z, scratch, blk_cap, mt);
 }
 
 }  // namespace sb

@@ -212,3 +212,38 @@ def test_zstd_frames_of_parallel_blocks(gpu_ctx, kind, n):
     assert csize <= n + 16 + 12 * (n // 32768 + 1)     # (frame header + block header per 32 KiB piece)
     if kind != "random":
         assert csize < 0.5 * n
+
+
+def test_concatenated_libzstd_frames(gpu_ctx):
+    """a Zstd payload made of several libzstd frames back to back (valid input for ZSTD_decompress, which the reference's
+    zstd::bulk::decompress_to_buffer ends in): the device queues one job per frame when every frame states its content
+    size, and decodes the payload frame after frame on one wave otherwise; both must give the oracle's bytes"""
+    pa = pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(7)
+    data = np.repeat(rng.integers(0, 50, 40_000), rng.integers(1, 6, 40_000)).astype(np.int64)[:100_000]
+    raw = data.tobytes()
+    cuts = [0, 70_000, 70_008, 300_000, len(raw)]
+    codec = pa.Codec("zstd", compression_level=3)
+    frames = b"".join(codec.compress(raw[a:b], asbytes=True) for a, b in zip(cuts[:-1], cuts[1:]))
+    page = bytes([S.ZSTD]) + len(frames).to_bytes(4, "little") + len(raw).to_bytes(4, "little") + frames
+    pages = np.frombuffer(page, np.uint8).copy()
+    metas = np.array([[len(page), data.size]], np.uint64)
+    col = dict(ptype=S.T_I64, nullable=False, rows=data.size, values=data, validity=None, offsets=None)
+    assert np.array_equal(np.asarray(gen.oracle_read(col, pages, metas)["values"]).view(np.int64), data)
+    assert np.array_equal(gpu_decode(gpu_ctx, col, pages, metas).values_numpy().view(np.int64), data)
+    # a skippable frame in front: not split (no content size to place the frames by), decoded serially
+    skip = (0x184D2A50).to_bytes(4, "little") + (5).to_bytes(4, "little") + b"hello"
+    payload = skip + frames
+    page = bytes([S.ZSTD]) + len(payload).to_bytes(4, "little") + len(raw).to_bytes(4, "little") + payload
+    pages = np.frombuffer(page, np.uint8).copy()
+    metas = np.array([[len(page), data.size]], np.uint64)
+    assert np.array_equal(np.asarray(gen.oracle_read(col, pages, metas)["values"]).view(np.int64), data)
+    assert np.array_equal(gpu_decode(gpu_ctx, col, pages, metas).values_numpy().view(np.int64), data)
+    # a truncated last frame must be refused, not split into garbage
+    from strawboat_amd._native import NativeError
+    bad = frames[:-7]
+    page = bytes([S.ZSTD]) + len(bad).to_bytes(4, "little") + len(raw).to_bytes(4, "little") + bad
+    pages = np.frombuffer(page, np.uint8).copy()
+    metas = np.array([[len(page), data.size]], np.uint64)
+    with pytest.raises(NativeError):
+        gpu_decode(gpu_ctx, col, pages, metas)

@@ -122,7 +122,7 @@ struct EncodeArgs {
     int32_t lzc_codec;              // the Basic codec whose big blocks go chunk by chunk in this call (LZ4 / Zstd / Snappy)
     uint8_t* zpar_scratch;          // Zstd: encoder scratch of the chunk waves (ZPAR_WAVES x zstd_scratch_bytes(ZPAR_CH))
 };
-constexpr uint32_t ZPAR_CH = 32768;      // a Zstd frame's blocks when they are compressed by waves of their own
+constexpr uint32_t ZPAR_CH = 16384;      // a Zstd frame's blocks when they are compressed by waves of their own
 constexpr uint32_t ZPAR_WAVES = 2048;
 constexpr uint32_t LZC_CH = 65536;                                         // chunk bytes (a multiple of 1024)
 constexpr uint32_t LZC_SLOT = (16 + LZC_CH + LZC_CH / 255 + 16 + 15) / 16 * 16;   // u32 size | u32 tail anchor | 8 pad | sequences
@@ -4212,9 +4212,9 @@ __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
     }
 }
 
-// Zstd: the same plan with 32 KiB pieces, each written as a FRAME of its own — concatenated frames are one valid
+// Zstd: the same plan with 16 KiB pieces, each written as a FRAME of its own — concatenated frames are one valid
 // compressed buffer for ZSTD_decompress (what the reference calls), and they share nothing, so both directions run one
-// wave per piece (the serial part of a piece, its FSE state chain, is what bounds a wave; 16 waves per 512 KiB page
+// wave per piece (the serial part of a piece, its FSE state chain, is what bounds a wave; 32 waves per 512 KiB page
 // instead of one).  The price is the cold start of every piece: no history, a Huffman table per piece.
 __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
     __shared__ ZEncLds Z;

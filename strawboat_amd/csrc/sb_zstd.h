@@ -372,7 +372,7 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
     } while (0)
     LzSeqExec ex(wk->ring, dst);   // sequences run through an LDS output ring; everything else writes HBM directly
     // One or more frames back to back — ZSTD_decompress, which zstd::bulk::decompress_to_buffer (basic.rs:93-97) ends in,
-    // decodes "any number of frames concatenated"; this library's encoder writes the 32 KiB pieces of a large buffer as
+    // decodes "any number of frames concatenated"; this library's encoder writes the 16 KiB pieces of a large buffer as
     // frames of their own so that they decode in parallel (k_parse queues one job per frame; a buffer whose frames were
     // not split arrives here whole).
     bool first_frame = true;

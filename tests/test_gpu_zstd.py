@@ -149,7 +149,7 @@ def test_zstd_encode_frames(gpu_ctx, name):
                 total_u += usize if col["ptype"] != S.T_BOOL else (usize + 7) // 8
             off += int(length)
         # never larger than stored + framing; compressible shapes must actually compress
-        assert total_c <= total_u + 16 * len(metas) * 2 + 12 * (total_u // 32768 + len(metas) * 2)
+        assert total_c <= total_u + 16 * len(metas) * 2 + 12 * (total_u // 16384 + len(metas) * 2)
         if name in ("u8_constant", "utf8_zipf", "utf8_big_pages", "i32_small_values", "i64_runs"):
             assert total_c < 0.7 * total_u, (name, total_c, total_u)
 
@@ -183,9 +183,9 @@ def test_zstd_ratio_on_golden_blocks(gpu_ctx):
 
 
 @pytest.mark.parametrize("kind", ["zeros", "text", "random"])
-@pytest.mark.parametrize("n", [32768 + 1, 32768 + 31, 32768 + 32, 2 * 32768, 2 * 32768 + 5, 5 * 32768 - 3, 300_007])
+@pytest.mark.parametrize("n", [16384 + 1, 16384 + 31, 16384 + 32, 2 * 16384, 32768 + 1, 2 * 32768 + 5, 5 * 32768 - 3, 300_007])
 def test_zstd_frames_of_parallel_blocks(gpu_ctx, kind, n):
-    """buffers of more than 32 KiB: every 32 KiB piece is compressed by a wave of its own (k_enc_zstd_chunks) into a FRAME of
+    """buffers of more than 16 KiB: every 16 KiB piece is compressed by a wave of its own (k_enc_zstd_chunks) into a FRAME of
     its own, and the frames are written back to back — one valid buffer for ZSTD_decompress ("any number of frames
     concatenated"), which is what the reference's zstd::bulk::decompress_to_buffer calls; libzstd (pyarrow), the oracle and
     the device (one job per frame, or the whole buffer by one wave) must read it back, whatever the size of the last piece"""
@@ -209,7 +209,7 @@ def test_zstd_frames_of_parallel_blocks(gpu_ctx, kind, n):
     assert raw == bytes(data)
     assert np.array_equal(gen.oracle_read(col, pages, metas)["values"], data)
     assert np.array_equal(gpu_decode(gpu_ctx, col, pages, metas).values_numpy(), data)
-    assert csize <= n + 16 + 12 * (n // 32768 + 1)     # (frame header + block header per 32 KiB piece)
+    assert csize <= n + 16 + 12 * (n // 16384 + 1)     # (frame header + block header per 16 KiB piece)
     if kind != "random":
         assert csize < 0.5 * n
 

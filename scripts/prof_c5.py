@@ -1,5 +1,5 @@
 """where the wall time of the C5 nested calls goes (levels per leaf, the flat call, Python)"""
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench, workloads as W
 import strawboat_amd as sb
 from strawboat_amd import nested, write

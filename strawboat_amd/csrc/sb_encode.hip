@@ -257,37 +257,6 @@ __device__ __forceinline__ Val<W> val_zero() {
     return v;
 }
 
-// inclusive max-scan over the TILE_ROWS entries of `a` (sidx layout), in place
-__device__ __forceinline__ void tile_incl_scan_max(uint32_t* a, uint32_t* wsum) {
-    const int t = threadIdx.x;
-    uint32_t loc[ROWS_PER_THREAD];
-    uint32_t run = 0;
-#pragma unroll
-    for (int j = 0; j < ROWS_PER_THREAD; j++) {
-        run = max(run, a[sidx(t * ROWS_PER_THREAD + j)]);
-        loc[j] = run;
-    }
-    uint32_t incl = run;
-    const int lane = t & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl = max(incl, o);
-    }
-    uint32_t excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 0;
-    __syncthreads();
-    if (lane == 63) wsum[t >> 6] = incl;
-    __syncthreads();
-    const int w = t >> 6;
-    uint32_t base = excl;
-    if (w > 0) base = max(base, wsum[0]);
-    if (w > 1) base = max(base, wsum[1]);
-    if (w > 2) base = max(base, wsum[2]);
-#pragma unroll
-    for (int j = 0; j < ROWS_PER_THREAD; j++) a[sidx(t * ROWS_PER_THREAD + j)] = max(base, loc[j]);
-    __syncthreads();
-}
 
 __device__ __forceinline__ uint32_t uleb_len(uint64_t v) {
     uint32_t n = 1;

@@ -32,6 +32,8 @@ __global__ void __launch_bounds__(64) k_zenc(const uint8_t* src, uint32_t n, uin
 }
 __global__ void __launch_bounds__(64) k_zdec(const uint8_t* comp, uint32_t cap, const uint32_t* sizes, uint8_t* out, uint32_t n, uint32_t* errs, uint8_t* zlit) {
     __shared__ ZWork wk;
+    if (threadIdx.x == 0) wk.pre_built = 0;
+    __syncthreads();
     const uint32_t got = zstd_inflate_wave(comp + (size_t)blockIdx.x * cap, sizes[blockIdx.x], out + (size_t)blockIdx.x * ((n + 255) & ~255u), n, &wk,
                                            zlit + (size_t)blockIdx.x * (128 * 1024 + 64));
     if (threadIdx.x == 0) errs[blockIdx.x] = wk.err ? (uint32_t)wk.err : (got == n ? 0u : 999u);

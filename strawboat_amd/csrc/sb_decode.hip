@@ -722,6 +722,8 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
     __shared__ uint8_t s_win[64 * 10 + 8];
     __shared__ uint16_t s_pos[65];
     const uint32_t njobs = *count;
+    if (threadIdx.x == 0) wk.pre_built = 0;
+    __syncthreads();
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
         if (j.codec == SB_CODEC_LZ4 || j.codec == CODEC_SPLIT) {

@@ -42,6 +42,10 @@ struct ZWork {  // per-wave LDS workspace (~12 KB)
     // per FSE state: extra-bit count | baseline << 8 of the state's length code, so that the serial loop gets them with the
     // state's entry in ONE LDS round trip (code -> table was a dependent second one)
     uint32_t xll[512], xml[512];
+    // the tables of the predefined distributions, built once per wave (pre_built: set to 0 by the kernel before its first job):
+    // frames of 16 KiB pieces use them in every block, and building one costs lane 0 ~50 us
+    ZFse pre_ll[64], pre_of[32], pre_ml[64];
+    uint32_t pre_built;
 };
 constexpr uint32_t ZBW = 2048;
 
@@ -315,8 +319,14 @@ __device__ inline uint32_t z_seq_table(ZWork* wk, int mode, ZFse* t, uint32_t* l
                                        const int16_t* def, int def_n, int def_log, int max_sym, int max_log,
                                        const uint8_t* src, uint32_t n) {
     if (mode == 0) {
-        for (int i = 0; i < def_n; i++) wk->norm[i] = def[i];
-        if (!z_fse_build(t, wk, wk->norm, def_n, def_log)) return 0xFFFFFFFFu;
+        ZFse* pre = def_n == 36 ? wk->pre_ll : def_n == 29 ? wk->pre_of : wk->pre_ml;
+        const uint32_t bit = def_n == 36 ? 1u : def_n == 29 ? 2u : 4u;
+        if (!(wk->pre_built & bit)) {
+            for (int i = 0; i < def_n; i++) wk->norm[i] = def[i];
+            if (!z_fse_build(pre, wk, wk->norm, def_n, def_log)) return 0xFFFFFFFFu;
+            wk->pre_built |= bit;
+        }
+        for (int i = 0; i < (1 << def_log); i++) t[i] = pre[i];
         *log_out = (uint32_t)def_log;
         *have = 1;
         return 0;

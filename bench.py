@@ -22,7 +22,8 @@ C2 is the FRIENDLIEST configuration (16x compressible runs); the LZ4 / Dict / ne
 one to two orders of magnitude slower per Arrow byte — read `configs`, not only `value`.
 
 Multi-GPU (torchrun, one rank per GPU): every rank owns its own `--columns` columns (weak
-scaling, pages of independent columns shard with no data-path collective); the only collective
+scaling, pages of independent columns shard with no data-path collective; `configs.c4_sharded` / `c5_sharded`: the two
+configurations BASELINE names for 8 GPUs, work items over the N ranks, strong scaling); the only collective
 is one RCCL all_gather of the page metas at the end of the timed region (the metadata a file
 writer needs for ColumnMeta offsets).
 """
@@ -491,6 +492,102 @@ def run_c4_sharded(h, world, rank, dist, steps=3, on_device=True):
             "items_per_rank": [len(s) for s in plan], "record_capacity": cap}
 
 
+def run_c5_sharded(h, world, rank, dist, steps=3, on_device=True):
+    """C5 as SURVEY 8(e) splits it: 2 leaf columns x 16 pages = 32 (leaf, page range) work items dealt to the ranks; every
+    rank writes and reads its own items through the nested API (a page range of top-level rows is a nested column of its
+    own: same level sections, same leaf pages), ONE all_gather of the page metas.  Strong scaling, wall time of synchronous
+    calls.  Failures are handled like run_c4_sharded's."""
+    import torch
+    from strawboat_amd import nested, shard
+    from strawboat_amd.read import ColumnPages
+    from strawboat_amd.types import Compression as C, WriteOptions
+    ctx = h.ctx
+    rows = 1_000_000
+    npages = (rows + PAGE - 1) // PAGE
+    cdev = h.dev if (world > 1 and on_device) else None
+
+    def all_ok(ok):
+        if world == 1:
+            return ok
+        f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item() > 0.5)
+
+    plan = shard.plan_work_items([(rows * 9, npages), (rows * 4, npages)], world)
+    mine = plan[rank]
+    err, U_local = None, 0.0
+    try:
+        la, a, lb, b = W.c5_nested()
+        opts = WriteOptions(max_page_size=PAGE, default_compression=C.ZSTD)
+        pairs, metas_kinds = [], []
+        for it in mine:
+            levels, leaf = (la, a) if it.column == 0 else (lb, b)
+            r0, r1 = it.first_page * PAGE, min(rows, (it.first_page + it.n_pages) * PAGE)
+            lv, col = W.c5_slice(levels, leaf, r0, r1)
+            dl = [nested.NestedLevel(x["kind"], bool(x["is_optional"]), x["length"], h.up(x.get("validity")), h.up(x.get("offsets"))) for x in lv]
+            dc = h.dcol(col)
+            dc.is_nullable = False
+            pairs.append((dl, dc))
+            metas_kinds.append((col, [x["kind"] for x in lv], [bool(x["is_optional"]) for x in lv]))
+            U_local += W.arrow_bytes(col) + (r1 - r0 + 1) * 4 + (r1 - r0 + 7) // 8
+        encs = nested.write_nested_leaves(ctx, pairs, opts)
+        cps = [ColumnPages(c["ptype"], False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (c, _, _) in zip(encs, metas_kinds)]
+        arrs = nested.read_nested_leaves(ctx, cps, [k for _, k, _ in metas_kinds], [o for _, _, o in metas_kinds])
+        for arr, (c, _, _) in zip(arrs, metas_kinds):   # leaf round trip of every item
+            if c["offsets"] is None:
+                m = np.unpackbits(c["validity"], bitorder="little")[:c["rows"]].astype(bool)
+                assert np.array_equal(arr.leaf.values_numpy().view(np.int64)[m], np.asarray(c["values"])[m]), "C5 Int64 leaf round trip failed"
+            else:
+                assert np.array_equal(arr.leaf.values_numpy(), c["values"]), "C5 Utf8 leaf round trip failed"
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, e)
+    if not all_ok(err is None):
+        return {"error": err or "another rank failed while preparing its work items"} if rank == 0 else None
+    cap = shard.record_capacity(plan)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    items = []
+    try:
+        for _ in range(steps):
+            encs = nested.write_nested_leaves(ctx, pairs, opts)
+            nested.read_nested_leaves(ctx, cps, [k for _, k, _ in metas_kinds], [o for _, _, o in metas_kinds])
+        items = [(it.column, it.first_page, e.metas_array()) for it, e in zip(mine, encs)]
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, e)
+    allm = shard.gather_metas(items, 2, capacity=cap, device=cdev)
+    barrier()
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el, float(U_local)], dtype=torch.float64, device=h.dev if on_device else "cpu")
+    if world > 1:
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        el, U = float(mx[0].item()), float(sm[1].item())
+    else:
+        U = float(U_local)
+    if err is None:
+        try:
+            cm = shard.column_metas(allm)
+            assert all(len(m.pages) == npages for m in cm), "every leaf column must come back with all of its pages"
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, e)
+    if not all_ok(err is None):
+        return {"error": err or "another rank failed in the timed region"} if rank == 0 else None
+    if rank != 0:
+        return None
+    return {"workload": "C5: 1 M-row List<Struct<Int64,Utf8>>, Zstd, %d (leaf, page-range) work items over %d GPU(s), nested write + read of "
+                        "every item (synchronous calls, wall time) + ONE all_gather of %d page metas" % (sum(len(x) for x in plan), world, 2 * npages),
+            "scaling": "strong", "n_gpus": world, "steps": steps, "arrow_MB": round(U / 1e6, 1),
+            "ms_per_step": round(el / steps * 1e3, 3), "encdec_GBps": round(2.0 * U * steps / el / 1e9, 2),
+            "items_per_rank": [len(x) for x in plan], "record_capacity": cap}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -614,13 +711,17 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    c4s = None
+    c4s = c5s = None
     if world > 1 and not args.no_configs:   # the configuration BASELINE names for 8 GPUs, sharded by page ranges
         del wbatch, rbatch
         try:   # (its own failures are caught inside, rank-collectively; this guards what is not: the headline line comes first)
             c4s = run_c4_sharded(harness, world, rank, dist, on_device=args.backend == "nccl")
         except Exception as e:
             c4s = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            c5s = run_c5_sharded(harness, world, rank, dist, on_device=args.backend == "nccl")
+        except Exception as e:
+            c5s = {"error": "%s: %s" % (type(e).__name__, e)}
     ms_per_step = elapsed / args.steps * 1e3
     value = world * 2.0 * U * args.steps / elapsed / 1e9   # whole job: encode + decode bytes
 
@@ -670,7 +771,7 @@ def main():
                                                "leg runs replicas of it page-parallel over std::threads")
         configs = None
         if world > 1 and not args.no_configs:
-            configs = {"c4_sharded": c4s}
+            configs = {"c4_sharded": c4s, "c5_sharded": c5s}
         if world == 1 and not args.no_configs:
             del wbatch, rbatch, enc, dec, pages, cols
             torch.cuda.empty_cache()

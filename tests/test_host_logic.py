@@ -38,3 +38,32 @@ def test_options_mapping():
     assert o.force_codec == 10 and o.force_index_codec == -1 and o.rng_seed == 7
     o = options_c(WriteOptions())
     assert o.has_default_compress_ratio == 0 and o.max_page_size == 0
+
+
+def test_c5_page_range_slices_are_columns_of_their_own():
+    """workloads.c5_slice (what a rank holds when it owns a page range of a C5 leaf column, SURVEY 8e work items): the level
+    sections and leaf ranges the oracle writes for the pages of the slice equal those of the same pages of the whole column"""
+    import workloads as W
+    from oracle import sbo as S
+    la, a, lb, b = W.c5_nested(rows=20_000, seed=7)
+    page = 4096
+    for levels, leaf in ((la, a), (lb, b)):
+        for r0, r1 in ((0, 8192), (8192, 16384), (16384, 20_000), (4096, 20_000)):
+            lv, col = W.c5_slice(levels, leaf, r0, r1)
+            assert col["rows"] == lv[-1]["length"] == lv[1]["length"]
+            whole_leaf0 = None
+            for q0 in range(r0, r1, page):
+                ln = min(page, r1 - q0)
+                want, nv, ls, lc = S.nested_write_levels(levels, q0, ln)
+                got, nv2, ls2, lc2 = S.nested_write_levels(lv, q0 - r0, ln)
+                assert np.array_equal(got, want) and nv == nv2 and lc == lc2
+                if whole_leaf0 is None:
+                    whole_leaf0 = ls - ls2          # the slice's leaf rows are the whole column's, shifted by a constant
+                assert ls - ls2 == whole_leaf0
+            e0 = whole_leaf0
+            if leaf["offsets"] is None:
+                assert np.array_equal(col["values"], np.asarray(leaf["values"])[e0:e0 + col["rows"]])
+            else:
+                bo = np.asarray(leaf["offsets"])
+                assert np.array_equal(col["offsets"], bo[e0:e0 + col["rows"] + 1] - bo[e0])
+                assert np.array_equal(col["values"], leaf["values"][int(bo[e0]):int(bo[e0 + col["rows"]])])

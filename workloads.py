@@ -127,6 +127,31 @@ def c5_nested(rows=1_000_000, seed=42):
     return levels(a_valid), leaf_a, levels(b_valid), leaf_b
 
 
+def _bits(bm, lo, hi):
+    """bits [lo, hi) of an LSB-first bitmap, re-packed from bit 0"""
+    return pack_bits(np.unpackbits(bm, bitorder="little")[lo:hi].astype(bool))
+
+
+def c5_slice(levels, leaf, r0, r1):
+    """top-level rows [r0, r1) of one C5 leaf column (levels list -> struct -> leaf) as a column of its own: offsets
+    re-based to 0, bitmaps re-packed from bit 0 — what a rank holds when it owns a page range of the leaf column"""
+    lst, st, lf = levels
+    offs = np.asarray(lst["offsets"])
+    e0, e1 = int(offs[r0]), int(offs[r1])
+    lv = [dict(kind=lst["kind"], is_optional=lst["is_optional"], validity=_bits(lst["validity"], r0, r1),
+               offsets=(offs[r0:r1 + 1] - offs[r0]).astype(offs.dtype), length=r1 - r0),
+          dict(kind=st["kind"], is_optional=st["is_optional"], validity=None, length=e1 - e0),
+          dict(kind=lf["kind"], is_optional=lf["is_optional"], validity=_bits(lf["validity"], e0, e1), length=e1 - e0)]
+    if leaf["offsets"] is None:
+        col = dict(ptype=leaf["ptype"], nullable=leaf["nullable"], rows=e1 - e0, values=leaf["values"][e0:e1],
+                   validity=_bits(leaf["validity"], e0, e1), offsets=None)
+    else:
+        bo = np.asarray(leaf["offsets"])
+        col = dict(ptype=leaf["ptype"], nullable=leaf["nullable"], rows=e1 - e0, values=leaf["values"][int(bo[e0]):int(bo[e1])],
+                   validity=_bits(leaf["validity"], e0, e1), offsets=(bo[e0:e1 + 1] - bo[e0]).astype(bo.dtype))
+    return lv, col
+
+
 # ---- the reference's bench shapes (benches/write_strawboat.rs:53-67; arrow2 util::bench_util generators):
 # nullable field, LZ4, max_page_size 8192, default_compress_ratio None
 def cont_bool(rows, seed=42):

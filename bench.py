@@ -463,7 +463,11 @@ def run_c4_sharded(h, world, rank, dist, steps=3, on_device=True):
         items = [(it.column, it.first_page, e.metas_array()) for it, e in zip(mine, enc)]
     except Exception as e:
         err = "%s: %s" % (type(e).__name__, e)
-    allm = shard.gather_metas(items, len(names), capacity=cap, device=cdev)   # (every rank takes part, whatever happened above)
+    allm = None
+    try:   # (every rank takes part in the collective, whatever happened above; gaps / duplicates are reported after it)
+        allm = shard.gather_metas(items, len(names), capacity=cap, device=cdev, expected_pages=[npages] * len(names))
+    except ValueError as e:
+        err = err or "%s: %s" % (type(e).__name__, e)
     barrier()
     el = time.perf_counter() - t0
     tt = torch.tensor([el, float(U_local)], dtype=torch.float64, device=h.dev if on_device else "cpu")
@@ -527,6 +531,8 @@ def run_c5_sharded(h, world, rank, dist, steps=3, on_device=True):
             dl = [nested.NestedLevel(x["kind"], bool(x["is_optional"]), x["length"], h.up(x.get("validity")), h.up(x.get("offsets"))) for x in lv]
             dc = h.dcol(col)
             dc.is_nullable = False
+            dc.first_page_index = it.first_page
+            dc.column_values_len = col.get("column_values_len", 0)
             pairs.append((dl, dc))
             metas_kinds.append((col, [x["kind"] for x in lv], [bool(x["is_optional"]) for x in lv]))
             U_local += W.arrow_bytes(col) + (r1 - r0 + 1) * 4 + (r1 - r0 + 7) // 8
@@ -559,7 +565,11 @@ def run_c5_sharded(h, world, rank, dist, steps=3, on_device=True):
         items = [(it.column, it.first_page, e.metas_array()) for it, e in zip(mine, encs)]
     except Exception as e:
         err = "%s: %s" % (type(e).__name__, e)
-    allm = shard.gather_metas(items, 2, capacity=cap, device=cdev)
+    allm = None
+    try:
+        allm = shard.gather_metas(items, 2, capacity=cap, device=cdev, expected_pages=[npages, npages])
+    except ValueError as e:
+        err = err or "%s: %s" % (type(e).__name__, e)
     barrier()
     el = time.perf_counter() - t0
     tt = torch.tensor([el, float(U_local)], dtype=torch.float64, device=h.dev if on_device else "cpu")
@@ -588,6 +598,48 @@ def run_c5_sharded(h, world, rank, dist, steps=3, on_device=True):
             "items_per_rank": [len(x) for x in plan], "record_capacity": cap}
 
 
+def self_launch(n, backend):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run on 127.0.0.1) with the same arguments; rank 0 prints the JSON line.  With the RCCL backend
+    every rank needs a device of its own: fewer visible devices than ranks is an error, never a silent 1-GPU run."""
+    import socket
+    import subprocess
+    if backend == "nccl":
+        import torch
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < n:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; RCCL needs one device per rank "
+                             "(--backend gloo shares devices between ranks: a functional check, not a number)" % (n, ndev))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def config_summary(configs):
+    """one line per configuration (the driver's record keeps `config`, not `configs`): Arrow GB/s and HBM fraction per direction"""
+    out = {}
+    for k, e in (configs or {}).items():
+        if not isinstance(e, dict):
+            continue
+        if "encode" in e and "decode" in e:
+            out[k] = "enc %.1f GB/s (%.3f of HBM peak), dec %.1f GB/s (%.3f)" % (
+                e["encode"]["GBps"], e["encode"]["frac_hbm"], e["decode"]["GBps"], e["decode"]["frac_hbm"])
+        elif "encdec_GBps" in e:
+            out[k] = "enc+dec %.1f GB/s over %d GPU(s), %.3f ms per step" % (e["encdec_GBps"], e.get("n_gpus", 1), e.get("ms_per_step", 0.0))
+        elif "error" in e:
+            out[k] = "error: %s" % e["error"]
+        else:
+            sub = config_summary(e)
+            for kk, vv in sub.items():
+                out["%s.%s" % (k, kk)] = vv
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -605,10 +657,18 @@ def main():
                                                  "without the headline (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus, args.backend)   # does not return
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU (or run `python bench.py --gpus N` "
+                         "without a launcher: it starts the N ranks itself)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -747,10 +807,12 @@ def main():
         kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / v[0], 4)} for k, v in stats.items()}
         # HBM traffic of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate passes of this same command; summary committed under profiles/)
-        for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for pf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
-                if roof and pmc["config"] == {"workload": "C2", "columns_per_gpu": B, "codec": args.codec}:
+                pc = pmc["config"]
+                if roof and str(pc.get("workload", "")).lower().startswith("c2") and pc.get("columns_per_gpu", B) == B \
+                        and pc.get("codec", args.codec) == args.codec:
                     cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0].startswith(dom.split("<")[0])]
                     if cand:
                         roof["traffic"] = max(cand)   # several template instances share a name: the one that did the work
@@ -787,7 +849,8 @@ def main():
                        "columns_per_gpu": B, "rows_per_column": ROWS, "page_rows": PAGE,
                        "arrow_bytes_per_step": U, "page_bytes_per_step": page_bytes,
                        "parallelism": "pages of independent columns sharded across %d GPU(s)" % world,
-                       "note": "C2 is the most compressible configuration (RLE, 16x): see `configs` for the others"},
+                       "note": "C2 is the most compressible configuration (RLE, 16x): see `configs` / `summary` for the others",
+                       "summary": config_summary(configs)},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "configs": configs,
         }
         print(json.dumps(out))

@@ -329,6 +329,8 @@ typedef struct sb_schema_field {
     int32_t precision;
     int32_t scale;
     int32_t unit;
+    const char* metadata; /* Field.custom_metadata: n_metadata pairs packed as "key\0value\0key\0value\0..."; NULL = none */
+    uint64_t n_metadata;
 } sb_schema_field;
 const char* sb_schema_last_error(void);
 /* metadata: 2 * n_metadata strings (key, value, key, value ...) of Schema.custom_metadata, or NULL.  *len returns the
@@ -339,6 +341,10 @@ int32_t sb_schema_to_bytes(const sb_schema_field* fields, uint64_t n_fields, uin
  * copied into `strings`; the out[].name pointers point there.  *n_fields / *strings_len return the sizes needed. */
 int32_t sb_schema_from_bytes(const uint8_t* bytes, uint64_t len, sb_schema_field* out, uint64_t capacity, uint64_t* n_fields,
                              uint64_t* n_top, char* strings, uint64_t strings_capacity, uint64_t* strings_len);
+/* Schema.custom_metadata of the same bytes (arrow2's deserialize_schema keeps it, src/read/reader.rs:227-241): *n_pairs
+ * pairs packed into `strings` as "key\0value\0..." (*strings_len bytes; SB_ERR_INVALID + sizes when it does not fit). */
+int32_t sb_schema_metadata_from_bytes(const uint8_t* bytes, uint64_t len, char* strings, uint64_t strings_capacity,
+                                      uint64_t* n_pairs, uint64_t* strings_len);
 
 /* ------------------------------------------------------------------ page inspector (host only)
  * Replaces stat::stat_simple / stat_body / stat_dict_body / stat_freq_body (src/stat.rs:61-152): the

@@ -21,7 +21,8 @@ EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize"
            "sb_nested_read_levels", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
            "sb_file_writer_write_column", "sb_file_writer_finish", "sb_file_writer_close", "sb_file_reader_open",
            "sb_file_reader_n_columns", "sb_file_reader_column", "sb_file_reader_schema", "sb_file_reader_read_pages",
-           "sb_file_reader_close", "sb_stat_page", "sb_schema_last_error", "sb_schema_to_bytes", "sb_schema_from_bytes")
+           "sb_file_reader_close", "sb_stat_page", "sb_schema_last_error", "sb_schema_to_bytes", "sb_schema_from_bytes",
+           "sb_schema_metadata_from_bytes")
 
 
 class PageMetaC(C.Structure):
@@ -78,7 +79,7 @@ class PageInfoC(C.Structure):
 class SchemaFieldC(C.Structure):
     _fields_ = [("name", C.c_char_p), ("timezone", C.c_char_p), ("type_id", C.c_int32), ("nullable", C.c_int32),
                 ("n_children", C.c_int32), ("bit_width", C.c_int32), ("is_signed", C.c_int32), ("precision", C.c_int32),
-                ("scale", C.c_int32), ("unit", C.c_int32)]
+                ("scale", C.c_int32), ("unit", C.c_int32), ("metadata", C.c_void_p), ("n_metadata", C.c_uint64)]
 
 
 class KernelStatC(C.Structure):
@@ -172,5 +173,8 @@ def load():
     L.sb_schema_from_bytes.restype = C.c_int32
     L.sb_schema_from_bytes.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(SchemaFieldC), C.c_uint64, C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sb_schema_metadata_from_bytes.restype = C.c_int32
+    L.sb_schema_metadata_from_bytes.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                                C.POINTER(C.c_uint64)]
     _lib = L
     return L

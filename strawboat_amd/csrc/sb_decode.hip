@@ -80,7 +80,12 @@ __device__ inline bool zstd_frame_extent(const uint8_t* src, uint32_t n, uint32_
 // sizes add up to the entry's output is replaced by one entry per frame (thread = entry; the walk reads a few bytes per
 // frame).  Anything else stays as it is and is decoded by one wave, frame after frame.
 __device__ void zstd_split_queue(InflateJob* q, uint32_t* cnt, uint32_t cap) {
-    const uint32_t n0 = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the pre-split count is read ONCE for the workgroup: a wave that read it later would see frame entries another
+    // wave has reserved (atomicAdd below) but not yet written, and walk stale slots
+    __shared__ uint32_t s_split_n0;
+    if (threadIdx.x == 0) s_split_n0 = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t n0 = s_split_n0;
     for (uint32_t j = threadIdx.x; j < n0 && j < cap; j += blockDim.x) {
         const InflateJob job = q[j];
         if (job.codec != SB_CODEC_ZSTD) continue;

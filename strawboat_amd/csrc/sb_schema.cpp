@@ -135,7 +135,7 @@ struct Reader {
     template <class T>
     T rd(size_t p) {
         T v{};
-        if (p + sizeof(T) > n) {
+        if (p > n || n - p < sizeof(T)) {   // (no p + sizeof(T): a hostile offset may sit just below SIZE_MAX)
             ok = false;
             return v;
         }
@@ -146,7 +146,12 @@ struct Reader {
     // position of field `id` of the table at `t`, 0 when absent
     size_t field(size_t t, uint16_t id) {
         const int32_t so = rd<int32_t>(t);
-        const size_t vt = (size_t)((int64_t)t - so);
+        const int64_t vts = (int64_t)t - so;
+        if (!ok || vts < 0 || (uint64_t)vts >= n) {   // the vtable lies inside the buffer
+            ok = false;
+            return 0;
+        }
+        const size_t vt = (size_t)vts;
         const uint16_t vsz = rd<uint16_t>(vt);
         if (!ok || 4 + 2 * (size_t)id + 2 > vsz) return 0;
         const uint16_t fo = rd<uint16_t>(vt + 4 + 2 * id);
@@ -166,7 +171,7 @@ struct Reader {
         if (!p) return false;
         const size_t s = indirect(p);
         const uint32_t len = rd<uint32_t>(s);
-        if (!ok || s + 4 + (size_t)len > n) {
+        if (!ok || s > n || n - s < 4 || n - s - 4 < (size_t)len) {
             ok = false;
             return false;
         }
@@ -235,6 +240,8 @@ uint32_t write_type(Builder& fb, const sb_schema_field& f) {
     return fb.end_table();
 }
 
+uint32_t write_key_values(Builder& fb, const char* packed, uint64_t n);
+
 // writes fields[*pos] and its children (pre-order); returns the Field table
 uint32_t write_field(Builder& fb, const sb_schema_field* fields, uint64_t n, uint64_t* pos, bool* bad) {
     if (*pos >= n) {
@@ -245,10 +252,12 @@ uint32_t write_field(Builder& fb, const sb_schema_field* fields, uint64_t n, uin
     std::vector<uint32_t> kids;
     for (int32_t k = 0; k < f.n_children && !*bad; k++) kids.push_back(write_field(fb, fields, n, pos, bad));
     if (*bad) return 0;
+    const uint32_t meta = (f.n_metadata && f.metadata) ? write_key_values(fb, f.metadata, f.n_metadata) : 0;
     const uint32_t children = fb.offset_vector(kids);
     const uint32_t type = write_type(fb, f);
     const uint32_t name = fb.string(f.name ? f.name : "");
     fb.start_table();
+    fb.add_offset(F_META, meta);
     fb.add_offset(F_CHILDREN, children);
     fb.add_offset(F_TYPE, type);
     fb.add_offset(F_NAME, name);
@@ -259,11 +268,53 @@ uint32_t write_field(Builder& fb, const sb_schema_field* fields, uint64_t n, uin
 
 struct Parsed {
     std::vector<sb_schema_field> fields;
-    std::vector<std::string> names, zones;  // indices kept in the structs until the strings are copied out
+    std::vector<std::string> names, zones, metas;  // kept beside the structs until the strings are copied out
+    size_t max_fields = 0;                         // a field costs >= 8 bytes of footer: a crafted footer whose vector
+                                                   // slots all point at the same child table cannot expand beyond that
 };
 
+// [KeyValue] at field `id` of table `t` -> "key\0value\0" per pair, appended to *packed; returns the pair count
+uint64_t read_key_values(Reader& r, size_t t, uint16_t id, std::string* packed) {
+    const size_t mp = r.field(t, id);
+    const size_t mv = mp ? r.indirect(mp) : 0;
+    const uint32_t n = r.vec_len(mv);
+    if (!r.ok || (size_t)n > r.n / 4) {
+        r.ok = false;
+        return 0;
+    }
+    for (uint32_t k = 0; k < n && r.ok; k++) {
+        const size_t kv = r.vec_table(mv, k);
+        std::string key, val;
+        r.str(kv, 0, &key);
+        r.str(kv, 1, &val);
+        packed->append(key.c_str());   // (C strings on this ABI: cut at an embedded NUL)
+        packed->push_back('\0');
+        packed->append(val.c_str());
+        packed->push_back('\0');
+    }
+    return n;
+}
+
+uint32_t write_key_values(Builder& fb, const char* packed, uint64_t n) {
+    std::vector<uint32_t> kvs;
+    const char* p = packed;
+    for (uint64_t k = 0; k < n; k++) {
+        const std::string key(p);
+        p += key.size() + 1;
+        const std::string val(p);
+        p += val.size() + 1;
+        const uint32_t v = fb.string(val);
+        const uint32_t ko = fb.string(key);
+        fb.start_table();
+        fb.add_offset(1, v);
+        fb.add_offset(0, ko);
+        kvs.push_back(fb.end_table());
+    }
+    return fb.offset_vector(kvs);
+}
+
 bool read_field(Reader& r, size_t t, Parsed& out, int depth) {
-    if (depth > 64) return false;
+    if (depth > 64 || out.fields.size() >= out.max_fields) return false;
     sb_schema_field f;
     memset(&f, 0, sizeof f);
     std::string name;
@@ -319,9 +370,13 @@ bool read_field(Reader& r, size_t t, Parsed& out, int depth) {
     const uint32_t nc = r.vec_len(cv);
     if (!r.ok || nc > 4096) return false;
     f.n_children = (int32_t)nc;
+    std::string meta;
+    f.n_metadata = read_key_values(r, t, F_META, &meta);
+    if (!r.ok) return false;
     out.fields.push_back(f);
     out.names.push_back(name);
     out.zones.push_back(tz);
+    out.metas.push_back(meta);
     for (uint32_t k = 0; k < nc; k++)
         if (!read_field(r, r.vec_table(cv, k), out, depth + 1)) return false;
     return r.ok;
@@ -388,11 +443,13 @@ int32_t sb_schema_from_bytes(const uint8_t* bytes, uint64_t len, sb_schema_field
     const size_t fv = fp ? r.indirect(fp) : 0;
     const uint32_t nt = r.vec_len(fv);
     Parsed p;
+    p.max_fields = (size_t)len / 8 + 1;
     for (uint32_t k = 0; k < nt; k++)
-        if (!read_field(r, r.vec_table(fv, k), p, 0)) return sfail(SB_ERR_OUT_OF_SPEC, "schema bytes: malformed Field");
+        if (!read_field(r, r.vec_table(fv, k), p, 0))
+            return sfail(SB_ERR_OUT_OF_SPEC, "schema bytes: malformed Field (or more fields than the buffer can hold)");
     if (!r.ok) return sfail(SB_ERR_OUT_OF_SPEC, "schema bytes: offset out of bounds");
     uint64_t need = 0;
-    for (size_t i = 0; i < p.fields.size(); i++) need += p.names[i].size() + 1 + p.zones[i].size() + 1;
+    for (size_t i = 0; i < p.fields.size(); i++) need += p.names[i].size() + 1 + p.zones[i].size() + 1 + p.metas[i].size();
     *n_fields = p.fields.size();
     *n_top = nt;
     *strings_len = need;
@@ -406,7 +463,33 @@ int32_t sb_schema_from_bytes(const uint8_t* bytes, uint64_t len, sb_schema_field
         memcpy(w, p.zones[i].c_str(), p.zones[i].size() + 1);
         out[i].timezone = p.zones[i].empty() ? nullptr : w;
         w += p.zones[i].size() + 1;
+        if (out[i].n_metadata) {
+            memcpy(w, p.metas[i].data(), p.metas[i].size());
+            out[i].metadata = w;
+            w += p.metas[i].size();
+        } else {
+            out[i].metadata = nullptr;
+        }
     }
+    return SB_OK;
+}
+
+int32_t sb_schema_metadata_from_bytes(const uint8_t* bytes, uint64_t len, char* strings, uint64_t strings_capacity,
+                                      uint64_t* n_pairs, uint64_t* strings_len) {
+    if (!bytes || !n_pairs || !strings_len) return sfail(SB_ERR_INVALID, "null argument");
+    Reader r{bytes, (size_t)len};
+    const size_t msg = r.indirect(0);
+    if (!r.ok) return sfail(SB_ERR_OUT_OF_SPEC, "schema bytes: not a flatbuffer");
+    if (r.scalar<uint8_t>(msg, 1, 0) != 1) return sfail(SB_ERR_OUT_OF_SPEC, "schema bytes: the message header is not a Schema");
+    const size_t schema = r.table(msg, 2);
+    if (!schema || !r.ok) return sfail(SB_ERR_OUT_OF_SPEC, "schema bytes: no Schema table");
+    std::string packed;
+    const uint64_t n = read_key_values(r, schema, 2, &packed);
+    if (!r.ok) return sfail(SB_ERR_OUT_OF_SPEC, "schema bytes: malformed custom_metadata");
+    *n_pairs = n;
+    *strings_len = packed.size();
+    if (packed.size() > strings_capacity || (!strings && packed.size())) return sfail(SB_ERR_INVALID, "output buffer too small");
+    if (packed.size()) memcpy(strings, packed.data(), packed.size());
     return SB_OK;
 }
 

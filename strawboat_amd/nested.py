@@ -131,6 +131,10 @@ def write_nested_leaves(ctx, items, options: WriteOptions) -> List[NestedEncoded
         c.validity = _ptr(leaf.validity)
         c.validity_bit_offset = leaf.validity_bit_offset
         c.offsets = _ptr(leaf.offsets)
+        # a (leaf, page range) work item (shard.WorkItem): the sampling seed and the hdr9 / total_bytes of its pages are
+        # the single writer's (first page of the range, array.values().len() of the whole leaf column)
+        c.first_page_index = leaf.first_page_index
+        c.column_values_len = leaf.column_values_len
         vlen = c.values_len if PhysicalType.is_binary(leaf.physical_type) else 0
         npg = C.c_uint64(0)
         bound = int(ctx._lib.sb_write_bound(leaf.physical_type, 0, max(total_leaf, 1), vlen, C.byref(oc), C.byref(npg)))

@@ -25,7 +25,7 @@ def _flatten(field, out):
     pa = _pa()
     t = field.type
     e = dict(name=field.name, nullable=field.nullable, type_id=0, n_children=0, bit_width=0, is_signed=0, precision=0, scale=0,
-             unit=0, timezone=None)
+             unit=0, timezone=None, metadata=dict(field.metadata or {}))
     kids = []
     T = pa.types
     if T.is_null(t):
@@ -84,6 +84,29 @@ def _flatten(field, out):
         _flatten(k, out)
 
 
+def _pack_kv(md) -> bytes:
+    """{key: value} -> b"key\\0value\\0..." (the C ABI's packed KeyValue form)"""
+    out = b""
+    for k, v in md.items():
+        k, v = bytes(k), bytes(v)
+        if b"\0" in k or b"\0" in v:
+            raise ValueError("metadata keys / values with an embedded NUL cannot cross the C ABI")
+        out += k + b"\0" + v + b"\0"
+    return out
+
+
+def _unpack_kv(addr, n):
+    """n pairs of NUL-terminated strings starting at address `addr` -> dict"""
+    md, p = {}, addr
+    for _ in range(n):
+        k = C.string_at(p)
+        p += len(k) + 1
+        v = C.string_at(p)
+        p += len(v) + 1
+        md[k] = v
+    return md
+
+
 def schema_to_bytes(schema) -> bytes:
     """arrow2 `schema_to_bytes(&schema, &default_ipc_fields(&schema.fields))`: the bare IPC Message flatbuffer"""
     lib = N.load()
@@ -91,12 +114,17 @@ def schema_to_bytes(schema) -> bytes:
     for f in schema:
         _flatten(f, ents)
     arr = (N.SchemaFieldC * max(len(ents), 1))()
-    keep = []
+    keep, held = [], []
     for i, e in enumerate(ents):
         nm = e["name"].encode()
         tz = e["timezone"].encode() if e["timezone"] else None
         keep += [nm, tz]
         arr[i].name, arr[i].timezone = nm, tz
+        if e["metadata"]:
+            mb = C.create_string_buffer(_pack_kv(e["metadata"]))
+            keep.append(mb.raw)
+            held.append(mb)
+            arr[i].metadata, arr[i].n_metadata = C.cast(mb, C.c_void_p), len(e["metadata"])
         for k in ("type_id", "n_children", "bit_width", "is_signed", "precision", "scale", "unit"):
             setattr(arr[i], k, int(e[k]))
         arr[i].nullable = 1 if e["nullable"] else 0
@@ -168,11 +196,13 @@ def _build(ents, pos):
         t = pa.map_(ent.field(0), ent.field(1), keys_sorted=bool(e.is_signed))
     else:
         raise NotImplementedError("Arrow type tag %d" % tid)
-    return pa.field(e.name.decode(), t, nullable=bool(e.nullable)), pos
+    md = _unpack_kv(e.metadata, e.n_metadata) if e.n_metadata else None
+    return pa.field(e.name.decode(), t, nullable=bool(e.nullable), metadata=md), pos
 
 
 def schema_from_bytes(raw: bytes):
-    """arrow2 `deserialize_schema(&schema_bytes)` -> pyarrow.Schema (field names, types, nullability)"""
+    """arrow2 `deserialize_schema(&schema_bytes)` -> pyarrow.Schema (field names, types, nullability, field and schema
+    custom_metadata)"""
     pa = _pa()
     lib = N.load()
     nf, nt, sl = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
@@ -192,4 +222,16 @@ def schema_from_bytes(raw: bytes):
     for _ in range(nt.value):
         f, pos = _build(arr, pos)
         fields.append(f)
-    return pa.schema(fields)
+    np_, ml = C.c_uint64(0), C.c_uint64(0)
+    mcap = 4096
+    while True:
+        mbuf = C.create_string_buffer(mcap)
+        rc = lib.sb_schema_metadata_from_bytes(buf, len(raw), mbuf, mcap, C.byref(np_), C.byref(ml))
+        if rc == N.SB_ERR_INVALID and ml.value > mcap:
+            mcap = ml.value
+            continue
+        if rc != N.SB_OK:
+            raise N.NativeError(rc, lib.sb_schema_last_error().decode())
+        break
+    md = _unpack_kv(C.addressof(mbuf), np_.value) if np_.value else None
+    return pa.schema(fields, metadata=md)

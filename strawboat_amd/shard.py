@@ -73,11 +73,14 @@ def record_capacity(plan: Sequence[Sequence[WorkItem]]) -> int:
     return max([sum(it.n_pages for it in s) for s in plan] + [1])
 
 
-def gather_metas(local, n_columns: int, capacity: Optional[int] = None, device=None, group=None) -> List[np.ndarray]:
+def gather_metas(local, n_columns: int, capacity: Optional[int] = None, device=None, group=None,
+                 expected_pages: Optional[Sequence[int]] = None) -> List[np.ndarray]:
     """The one collective of the path.  `local`: what this rank encoded — a dict {column: metas} (whole columns) or a
     list of (column, first_page, metas) with metas = uint64 [n, 2] (length, num_values).  `capacity`: records per rank
     (record_capacity(plan)); when omitted the ranks fall back to agreeing on it first (a second, 8-byte all_gather).
-    Returns the page metas of all columns, in column and page order, on every rank."""
+    Returns the page metas of all columns, in column and page order, on every rank.  Every column's pages must arrive
+    exactly once and without gaps (page indices 0..n-1; n = expected_pages[column] when the plan's counts are passed):
+    a rank that contributed nothing or a range dealt twice raises here instead of shifting every later ColumnMeta.offset."""
     import torch
     import torch.distributed as dist
     if isinstance(local, dict):
@@ -102,11 +105,21 @@ def gather_metas(local, n_columns: int, capacity: Optional[int] = None, device=N
         rec = [tuple(r) for t in out for r in t.cpu().tolist() if r[0] >= 0]
     pages: Dict[int, Dict[int, tuple]] = {}
     for c, p, length, nv in rec:
-        pages.setdefault(c, {})[p] = (length, nv)
+        if not 0 <= c < n_columns:
+            raise ValueError("page record of column %d, but the job has %d columns" % (c, n_columns))
+        col = pages.setdefault(c, {})
+        if p in col:
+            raise ValueError("page %d of column %d arrived twice (a page range was dealt to two ranks)" % (p, c))
+        col[p] = (length, nv)
     res = []
     for c in range(n_columns):
         pp = pages.get(c, {})
-        res.append(np.array([pp[p] for p in sorted(pp)], dtype=np.uint64).reshape(-1, 2))
+        n = len(pp)
+        if expected_pages is not None and n != int(expected_pages[c]):
+            raise ValueError("column %d: %d of its %d pages arrived" % (c, n, int(expected_pages[c])))
+        if n and (min(pp) != 0 or max(pp) != n - 1):
+            raise ValueError("column %d: page indices %d..%d for %d pages (a page range is missing)" % (c, min(pp), max(pp), n))
+        res.append(np.array([pp[p] for p in range(n)], dtype=np.uint64).reshape(-1, 2))
     return res
 
 

@@ -93,3 +93,42 @@ def test_two_ranks_device_encoder(gpu_ctx):
         assert got == pages.tobytes(), "column %d" % ci
         want, _ = gen.oracle_write(cols[ci], max_page_size=PAGE, ratio=2.0)
         assert got == want.tobytes(), "column %d vs oracle" % ci
+
+
+@pytest.mark.parametrize("dc_name", ["LZ4", "ZSTD"])
+def test_nested_page_range_items_write_the_single_writers_pages(gpu_ctx, dc_name):
+    """(leaf, page range) work items through the NESTED API with an ADAPTIVE ratio: a rank that owns top-level rows
+    [r0, r1) of a C5 leaf column (workloads.c5_slice) writes, page for page, the bytes a single writer produces for the
+    whole column — the per-page sampling seed continues from first_page_index and the binary selector's total_bytes /
+    the hdr9 of Dict / Freq / OneValue pages use the whole column's values length (write_nested_leaves forwards both)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import workloads as W
+    from strawboat_amd import nested, write
+    from strawboat_amd.types import Compression, WriteOptions
+    ctx = gpu_ctx
+    page = 4096
+    rows = 30_000
+    la, a, lb, b = W.c5_nested(rows=rows, seed=11)
+    opts = WriteOptions(max_page_size=page, default_compression=getattr(Compression, dc_name), default_compress_ratio=2.0)
+
+    def up(x):
+        return None if x is None else torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1).copy()).to(ctx.torch_device)
+
+    def item(levels, col, first_page):
+        dl = [nested.NestedLevel(x["kind"], bool(x["is_optional"]), x["length"], up(x.get("validity")), up(x.get("offsets"))) for x in levels]
+        dc = write.DeviceColumn(col["ptype"], False, col["rows"], up(col["values"]), up(col["validity"]), up(col["offsets"]),
+                                first_page_index=first_page, column_values_len=col.get("column_values_len", 0))
+        return dl, dc
+    npages = (rows + page - 1) // page
+    for levels, leaf in ((la, a), (lb, b)):
+        whole = nested.write_nested_leaves(ctx, [item(levels, leaf, 0)], opts)[0]
+        wm, wp = whole.metas_array(), whole.pages_numpy()
+        assert len(wm) == npages
+        ends = np.concatenate([[0], np.cumsum(wm[:, 0].astype(np.int64))])
+        for p0, n in ((0, 3), (3, 1), (4, npages - 4)):
+            r0, r1 = p0 * page, min(rows, (p0 + n) * page)
+            lv, col = W.c5_slice(levels, leaf, r0, r1)
+            part = nested.write_nested_leaves(ctx, [item(lv, col, p0)], opts)[0]
+            assert np.array_equal(part.metas_array(), wm[p0:p0 + n]), "page sizes of pages %d..%d" % (p0, p0 + n)
+            assert np.array_equal(part.pages_numpy(), wp[ends[p0]:ends[p0 + n]]), "page bytes of pages %d..%d" % (p0, p0 + n)

@@ -30,6 +30,23 @@ def test_gather_metas_single_process():
     assert out[1].tolist() == [[20, 2], [30, 3]]
 
 
+def test_gather_metas_refuses_gaps_and_duplicates():
+    """(column, page range) work items: every page of every column exactly once, or an error — never a shorter column
+    whose later ColumnMeta offsets are silently wrong"""
+    import pytest
+    m = lambda n: np.array([[10 + k, 1] for k in range(n)], np.uint64)
+    ok = shard.gather_metas([(0, 0, m(2)), (0, 2, m(1)), (1, 0, m(1))], 2, expected_pages=[3, 1])
+    assert [len(x) for x in ok] == [3, 1]
+    with pytest.raises(ValueError, match="missing"):
+        shard.gather_metas([(0, 0, m(2)), (0, 3, m(1))], 1)                     # page 2 never arrived
+    with pytest.raises(ValueError, match="twice"):
+        shard.gather_metas([(0, 0, m(2)), (0, 1, m(2))], 1)                     # page 1 dealt twice
+    with pytest.raises(ValueError, match="of its 4 pages"):
+        shard.gather_metas([(0, 0, m(3))], 1, expected_pages=[4])               # the rank owning the tail sent nothing
+    with pytest.raises(ValueError, match="columns"):
+        shard.gather_metas([(5, 0, m(1))], 2)
+
+
 def test_options_mapping():
     o = options_c(WriteOptions(default_compression=Compression.LZ4, default_compress_ratio=2.0, max_page_size=8192,
                                forbidden_compressions=[Compression.FREQ, Compression.PATAS], force_codec=10, rng_seed=7))

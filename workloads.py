@@ -148,7 +148,8 @@ def c5_slice(levels, leaf, r0, r1):
     else:
         bo = np.asarray(leaf["offsets"])
         col = dict(ptype=leaf["ptype"], nullable=leaf["nullable"], rows=e1 - e0, values=leaf["values"][int(bo[e0]):int(bo[e1])],
-                   validity=_bits(leaf["validity"], e0, e1), offsets=(bo[e0:e1 + 1] - bo[e0]).astype(bo.dtype))
+                   validity=_bits(leaf["validity"], e0, e1), offsets=(bo[e0:e1 + 1] - bo[e0]).astype(bo.dtype),
+                   column_values_len=int(np.asarray(leaf["values"]).size))   # array.values().len() of the whole leaf column
     return lv, col
 
 

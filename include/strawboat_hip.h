@@ -240,6 +240,22 @@ int32_t sb_nested_write_levels(sb_ctx* ctx, const sb_nested_level* levels, uint3
                                uint64_t max_page_size, uint8_t* out_levels, uint64_t out_capacity,
                                sb_nested_page* pages, uint64_t n_pages_capacity, uint64_t* n_pages_out);
 
+/* The same for the leaf columns of a whole call (every leaf of every nested array of a chunk — encode_chunk's loop over
+ * the leaves, src/write/common.rs:60-116): ONE set of launches over all pages of all leaves and ONE host round trip for
+ * the page cut of the batch (32 bytes per page), instead of one per leaf column. */
+typedef struct sb_nested_levels_write {
+    const sb_nested_level* levels;  /* root -> leaf */
+    uint32_t n_levels;
+    uint32_t reserved;
+    uint64_t rows;                  /* top-level rows (levels[0].length) */
+    uint8_t* out_levels;            /* DEVICE: the level sections of the pages, back to back */
+    uint64_t out_capacity;          /* >= sb_nested_levels_bound() */
+    sb_nested_page* pages;          /* HOST, n_pages_capacity entries */
+    uint64_t n_pages_capacity;
+    uint64_t n_pages;               /* result */
+} sb_nested_levels_write;
+int32_t sb_nested_write_levels_batch(sb_ctx* ctx, sb_nested_levels_write* items, uint64_t n, uint64_t max_page_size);
+
 /* replaces read_validity_nested (src/read/read_basic.rs:65-173) over all pages of one nested leaf
  * column.  Per level the caller passes DEVICE outputs: `offsets` (lists: column-level i64 offsets,
  * elements + 1 entries) and `validity` (nullable list/struct levels: LSB-first bitmap; 4-byte
@@ -257,6 +273,21 @@ typedef struct sb_nested_level_out {
     int32_t kind;
     int32_t is_nullable;
 } sb_nested_level_out;
+/* the leaf columns of a whole call: the arguments of sb_nested_read_levels per item, one set of launches, one round trip */
+typedef struct sb_nested_levels_read {
+    const uint8_t* pages;           /* DEVICE: the column's pages back to back */
+    uint64_t pages_len;
+    const sb_page_meta* metas;      /* HOST */
+    uint64_t n_pages;
+    sb_nested_level_out* levels;    /* HOST array of n_levels entries (DEVICE outputs inside); .length returns */
+    uint32_t n_levels;
+    uint32_t reserved;
+    uint8_t* leaf_validity;         /* DEVICE or NULL */
+    uint64_t leaf_validity_capacity;
+    uint64_t* page_leaf_counts;     /* HOST, n_pages entries, or NULL */
+    uint64_t* page_block_offsets;   /* HOST, n_pages entries, or NULL */
+} sb_nested_levels_read;
+int32_t sb_nested_read_levels_batch(sb_ctx* ctx, sb_nested_levels_read* items, uint64_t n);
 int32_t sb_nested_read_levels(sb_ctx* ctx, const uint8_t* pages, uint64_t pages_len, const sb_page_meta* metas,
                               uint64_t n_pages, sb_nested_level_out* levels, uint32_t n_levels,
                               uint8_t* leaf_validity, uint64_t leaf_validity_capacity,

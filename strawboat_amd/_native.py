@@ -18,7 +18,7 @@ SB_WRITE_LZ4_EXACT = 1
 EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
            "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns",
            "sb_ctx_profile", "sb_ctx_profile_read", "sb_nested_levels_bound", "sb_nested_write_levels",
-           "sb_nested_read_levels", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
+           "sb_nested_read_levels", "sb_nested_write_levels_batch", "sb_nested_read_levels_batch", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
            "sb_file_writer_write_column", "sb_file_writer_finish", "sb_file_writer_close", "sb_file_reader_open",
            "sb_file_reader_n_columns", "sb_file_reader_column", "sb_file_reader_schema", "sb_file_reader_read_pages",
            "sb_file_reader_close", "sb_stat_page", "sb_schema_last_error", "sb_schema_to_bytes", "sb_schema_from_bytes",
@@ -68,6 +68,19 @@ class NestedLevelOutC(C.Structure):
     _fields_ = [("offsets", C.c_void_p), ("validity", C.c_void_p), ("offsets_capacity", C.c_uint64),
                 ("validity_capacity", C.c_uint64), ("length", C.c_uint64), ("kind", C.c_int32),
                 ("is_nullable", C.c_int32)]
+
+
+class NestedLevelsWriteC(C.Structure):
+    _fields_ = [("levels", C.POINTER(NestedLevelC)), ("n_levels", C.c_uint32), ("reserved", C.c_uint32), ("rows", C.c_uint64),
+                ("out_levels", C.c_void_p), ("out_capacity", C.c_uint64), ("pages", C.POINTER(NestedPageC)),
+                ("n_pages_capacity", C.c_uint64), ("n_pages", C.c_uint64)]
+
+
+class NestedLevelsReadC(C.Structure):
+    _fields_ = [("pages", C.c_void_p), ("pages_len", C.c_uint64), ("metas", C.c_void_p), ("n_pages", C.c_uint64),
+                ("levels", C.POINTER(NestedLevelOutC)), ("n_levels", C.c_uint32), ("reserved", C.c_uint32),
+                ("leaf_validity", C.c_void_p), ("leaf_validity_capacity", C.c_uint64),
+                ("page_leaf_counts", C.c_void_p), ("page_block_offsets", C.c_void_p)]
 
 
 class PageInfoC(C.Structure):
@@ -140,6 +153,10 @@ def load():
     L.sb_nested_read_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PageMetaC), C.c_uint64,
                                         C.POINTER(NestedLevelOutC), C.c_uint32, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sb_nested_write_levels_batch.restype = C.c_int32
+    L.sb_nested_write_levels_batch.argtypes = [C.c_void_p, C.POINTER(NestedLevelsWriteC), C.c_uint64, C.c_uint64]
+    L.sb_nested_read_levels_batch.restype = C.c_int32
+    L.sb_nested_read_levels_batch.argtypes = [C.c_void_p, C.POINTER(NestedLevelsReadC), C.c_uint64]
     L.sb_file_last_error.restype = C.c_char_p
     L.sb_file_writer_open.restype = C.c_int32
     L.sb_file_writer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]

@@ -68,23 +68,41 @@ class NestedLevels:
         return int(self.level_bytes.size)
 
 
+def write_levels_batch(ctx, levels_list, max_page_size: Optional[int]) -> List[NestedLevels]:
+    """write_nested_validity for every page of every leaf column of a call: ONE set of launches over all pages of all
+    leaves and ONE host round trip for the page cut (sb_nested_write_levels_batch)."""
+    import torch
+    n = len(levels_list)
+    mps = 0 if max_page_size is None else int(max_page_size)
+    items = (N.NestedLevelsWriteC * max(n, 1))()
+    keep = []
+    with torch.cuda.stream(ctx.torch_stream):
+        for k, levels in enumerate(levels_list):
+            arr = _levels_c(levels)
+            rows = levels[0].length
+            bound = int(ctx._lib.sb_nested_levels_bound(arr, len(levels), rows, mps))
+            ps = min(mps, rows) if mps else rows
+            npages = (rows + ps - 1) // ps if rows else 0
+            out = torch.empty(max(bound, 1), dtype=torch.uint8, device=ctx.torch_device)
+            pages = (N.NestedPageC * max(npages, 1))()
+            it = items[k]
+            it.levels, it.n_levels, it.rows = arr, len(levels), rows
+            it.out_levels, it.out_capacity = _ptr(out), out.numel()
+            it.pages, it.n_pages_capacity = pages, len(pages)
+            keep.append((arr, out, pages))
+    if n:
+        ctx._check(ctx._lib.sb_nested_write_levels_batch(ctx._h, items, n, mps))
+    res = []
+    for k, (arr, out, pages) in enumerate(keep):
+        info = np.frombuffer(pages, dtype=np.uint64).reshape(-1, 4)[:int(items[k].n_pages)].copy()
+        res.append(NestedLevels(out, info))
+    return res
+
+
 def write_levels(ctx, levels: Sequence[NestedLevel], rows: int, max_page_size: Optional[int]) -> NestedLevels:
     """write_nested_validity for every page of one nested leaf column (synchronous)."""
-    import torch
-    arr = _levels_c(levels)
-    mps = 0 if max_page_size is None else int(max_page_size)
-    bound = int(ctx._lib.sb_nested_levels_bound(arr, len(levels), rows, mps))
-    ps = min(mps, rows) if mps else rows
-    npages = (rows + ps - 1) // ps if rows else 0
-    with torch.cuda.stream(ctx.torch_stream):
-        out = torch.empty(max(bound, 1), dtype=torch.uint8, device=ctx.torch_device)
-    pages = (N.NestedPageC * max(npages, 1))()
-    got = C.c_uint64(0)
-    ctx._check(ctx._lib.sb_nested_write_levels(ctx._h, arr, len(levels), rows, mps, _ptr(out), out.numel(), pages,
-                                               len(pages), C.byref(got)))
-    info = np.array([[p.level_bytes, p.num_values, p.leaf_start, p.leaf_count] for p in pages[:got.value]],
-                    dtype=np.uint64).reshape(-1, 4)
-    return NestedLevels(out, info)
+    assert rows == levels[0].length
+    return write_levels_batch(ctx, [levels], max_page_size)[0]
 
 
 class NestedEncodedColumn(EncodedColumn):
@@ -115,9 +133,9 @@ def write_nested_leaves(ctx, items, options: WriteOptions) -> List[NestedEncoded
     oc.max_page_size = 0
     arr = (N.ColumnWriteC * max(n, 1))()
     keep, lvs, outs = [], [], []
+    all_lv = write_levels_batch(ctx, [levels for levels, _ in items], options.max_page_size)
     for k, (levels, leaf) in enumerate(items):
-        rows = levels[0].length
-        lv = write_levels(ctx, levels, rows, options.max_page_size)
+        lv = all_lv[k]
         if int(lv.leaf_start[0]) != 0:
             raise ValueError("leaf slice must start at 0")
         c = arr[k]
@@ -192,9 +210,11 @@ def read_nested_leaves(ctx, columns, kinds_list, nullable_list) -> List[NestedAr
     n = len(columns)
     arr = (N.ColumnReadC * max(n, 1))()
     per, keep = [], []
+    items = (N.NestedLevelsReadC * max(n, 1))()
+    prep = []
     for j, (column, kinds, nullable) in enumerate(zip(columns, kinds_list, nullable_list)):
         D = len(kinds)
-        metas = column.metas_array()
+        metas = np.ascontiguousarray(column.metas_array(), dtype=np.uint64).reshape(-1, 2)
         n_pages = metas.shape[0]
         entries = int(metas[:, 1].sum()) if n_pages else 0
         lv = (N.NestedLevelOutC * D)()
@@ -216,10 +236,20 @@ def read_nested_leaves(ctx, columns, kinds_list, nullable_list) -> List[NestedAr
         counts = np.zeros(max(n_pages, 1), np.uint64)
         block_offs = np.zeros(max(n_pages, 1), np.uint64)
         pages = column.pages
-        ctx._check(ctx._lib.sb_nested_read_levels(
-            ctx._h, _ptr(pages), pages.numel(), metas.ctypes.data_as(C.POINTER(N.PageMetaC)), n_pages, lv, D,
-            _ptr(leaf_validity), leaf_validity.numel() if leaf_validity is not None else 0,
-            counts.ctypes.data_as(C.POINTER(C.c_uint64)), block_offs.ctypes.data_as(C.POINTER(C.c_uint64))))
+        it = items[j]
+        it.pages, it.pages_len = _ptr(pages), pages.numel()
+        it.metas, it.n_pages = metas.ctypes.data_as(C.c_void_p), n_pages
+        it.levels, it.n_levels = lv, D
+        it.leaf_validity = _ptr(leaf_validity)
+        it.leaf_validity_capacity = leaf_validity.numel() if leaf_validity is not None else 0
+        it.page_leaf_counts = counts.ctypes.data_as(C.c_void_p)
+        it.page_block_offsets = block_offs.ctypes.data_as(C.c_void_p)
+        prep.append((metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages))
+    if n:   # the level sections of every leaf: one set of launches, one host round trip
+        ctx._check(ctx._lib.sb_nested_read_levels_batch(ctx._h, items, n))
+    for j, (column, kinds, nullable) in enumerate(zip(columns, kinds_list, nullable_list)):
+        metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages = prep[j]
+        D = len(kinds)
         lengths = [int(lv[k].length) for k in range(D)]
         # the leaf BLOCKs through the flat decoder
         starts = np.concatenate([[0], np.cumsum(metas[:, 0])[:-1]]).astype(np.uint64) if n_pages else np.zeros(0, np.uint64)

@@ -39,6 +39,61 @@ def encode_matches_oracle_and_round_trips(ctx, col, **opt):
     return S.stat_column(col["ptype"], col["nullable"], want_pages, want_metas)[0]
 
 
+def _chain(info):
+    """(codec, uncompressed_size, unique_num) of every block of a page, outermost first; the compressed sizes are left
+    out (they are what a different LZ4 / Zstd parse changes), and so is PageInfo.validity_size, which upstream reads from
+    the 4 bytes BEHIND the def-level section, i.e. from the hdr9 (src/stat.rs:72-77)"""
+    out = []
+    while info is not None:
+        out.append((info.codec, info.uncompressed_size, info.body.unique_num))
+        info = info.body.indices or info.body.exceptions
+    return out
+
+
+def default_encoder_parity(ctx, col, ratio_bound, **opt):
+    """The encoder bench.py times (WriteOptions without lz4_exact: parallel LZ4 matcher, chunk + stitch kernels, Zstd
+    frames per piece) under the config's own options.  Its LZ4 / Zstd bytes are format-valid streams of another parse
+    (BASELINE.md section 6), so instead of byte equality: (1) page structure equals the oracle's — page count, num_values,
+    the codec chain of every page with every hdr9 uncompressed_size / unique_num / def-level size; (2) the ORACLE decodes
+    the device's pages to what it decodes from its own; (3) the device decodes both; (4) page bytes stay within
+    `ratio_bound` x the oracle's (whose LZ4 is byte-identical to liblz4, tests/test_oracle_blocks.py).
+    Follows compress_buffer / decompress_buffer, src/compression/basic.rs:87-135."""
+    from strawboat_amd import stat
+    opt = {k: v for k, v in opt.items() if k != "forbidden" or v}
+    want_pages, want_metas = gen.oracle_write(col, **opt)
+    enc = gpu_encode(ctx, col, lz4_exact=False, **opt)
+    got_pages, got_metas = enc.pages_numpy(), enc.metas_array()
+    assert got_metas.shape == want_metas.shape, "page count"
+    assert np.array_equal(got_metas[:, 1], want_metas[:, 1]), "num_values per page"
+    gi = stat.stat_simple(got_pages, got_metas, col["ptype"], col["nullable"])
+    wi = stat.stat_simple(want_pages, want_metas, col["ptype"], col["nullable"])
+    go = wo = 0
+    for k, (g, w) in enumerate(zip(gi.pages, wi.pages)):
+        assert _chain(g) == _chain(w), "page %d: block structure %s vs the oracle's %s" % (k, _chain(g), _chain(w))
+        if col["nullable"]:   # the def-level section (u32 length + hybrid-RLE bits) byte for byte
+            dl = 4 + int(want_pages[wo:wo + 4].view(np.uint32)[0])
+            assert np.array_equal(got_pages[go:go + dl], want_pages[wo:wo + dl]), "page %d: def-level section" % k
+        go += int(got_metas[k, 0])
+        wo += int(want_metas[k, 0])
+    want = gen.oracle_read(col, want_pages, want_metas)
+    back = gen.oracle_read(col, got_pages, got_metas)           # the CPU reader reads what the device wrote
+    for key in ("values", "validity", "offsets"):
+        if want.get(key) is not None:
+            assert np.array_equal(back[key], want[key]), "oracle decode of the device's pages: %s" % key
+    for pages, metas in ((got_pages, got_metas), (want_pages, want_metas)):
+        got = gpu_decode(ctx, col, pages, metas)
+        assert got.rows == col["rows"]
+        assert np.array_equal(got.values_numpy(), want["values"])
+        if col["nullable"]:
+            assert np.array_equal(got.validity_numpy(), want["validity"])
+        if col["offsets"] is not None:
+            assert np.array_equal(got.offsets_numpy(), want["offsets"])
+    r = got_pages.size / max(want_pages.size, 1)
+    print("default encoder: %d page bytes vs %d (oracle / liblz4 parse) = %.3f x" % (got_pages.size, want_pages.size, r))
+    assert r <= ratio_bound, "page bytes %.3f x the oracle's (bound %.2f)" % (r, ratio_bound)
+    return r
+
+
 def zipf_utf8(rows, seed, null_density=None):
     return workloads.zipf_utf8(rows, seed, null_density)
 
@@ -57,6 +112,32 @@ def test_c3_utf8_zipf_dict_lz4(gpu_ctx):
     assert (codecs == S.DICT).all()
     # and the forced Basic(LZ4) variant: offsets block + values block
     encode_matches_oracle_and_round_trips(gpu_ctx, zipf_utf8(200_000, 7), max_page_size=65536, default_compression=S.LZ4)
+
+
+def test_c3_default_encoder(gpu_ctx):
+    """C3 and C3' at 1 M rows with the DEFAULT encoder (the timed path): Dict pages whose short last page carries
+    LZ4-coded indices, and Basic(LZ4) pages with 0.94 MB value blocks through the chunk + stitch kernels"""
+    col = zipf_utf8(ROWS, 42)
+    default_encoder_parity(gpu_ctx, col, 1.02, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+    default_encoder_parity(gpu_ctx, col, 1.35, max_page_size=65536, default_compression=S.LZ4)
+
+
+@pytest.mark.parametrize("name", ["int32_0", "float64_0", "utf8_0", "boolean_0"])
+def test_c4_default_encoder_at_the_size_baseline_states(gpu_ctx, name):
+    """every C4 column type at 10 M rows with the default encoder (Boolean pages are LZ4 blocks of incompressible bitmaps)"""
+    col = dict(workloads.c4_columns(10_000_000))[name]
+    default_encoder_parity(gpu_ctx, col, 1.05, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+
+
+def test_c5_leaves_default_encoder(gpu_ctx):
+    """C5's two leaf columns (Int64 with 20 % nulls, Utf8) as flat non-nullable columns, Zstd default, 1 M top-level rows'
+    worth of leaves: the Zstd frames the device writes (one per 16 KiB piece) are read by the oracle's decoder; size
+    against the oracle's STORE-ONLY frames must be below 1 (the device compresses)"""
+    la, a, lb, b = workloads.c5_nested()
+    for leaf in (a, b):
+        col = dict(leaf, nullable=False, validity=None)
+        r = default_encoder_parity(gpu_ctx, col, 1.0, max_page_size=65536, default_compression=S.ZSTD)
+        assert r < 1.0
 
 
 @pytest.mark.parametrize("kind", ["int32", "float64", "utf8", "boolean"])

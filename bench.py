@@ -321,62 +321,88 @@ def run_configs(h, only, cpu_on, log):
     return out
 
 
-def run_c5(h, cpu_on):
-    """C5: 1 M-row List<Struct<Int64,Utf8>>, Zstd default, ratio None: 2 leaf columns x 16 pages through the nested
-    API (level sections on the device per leaf + the leaf blocks of both leaves through the flat path in one call).
-    The calls are synchronous, so this is wall time."""
+def run_c5(h, cpu_on, arrays=64):
+    """C5: `arrays` x (1 M-row List<Struct<Int64,Utf8>>), Zstd default, ratio None: per array 2 leaf columns x 16 pages
+    through the nested API — the level sections of ALL leaves in one batch of launches (one host round trip for the page
+    cut), then the leaf BLOCKs of all leaves through the flat path in one call.  Wall time of the calls (they synchronise),
+    plus the one-array call as `single_array` (the round-2 shape: latency of a 22.7 MB job)."""
     from strawboat_amd import nested
     from strawboat_amd.read import ColumnPages
     from strawboat_amd.types import Compression as C, WriteOptions
     ctx = h.ctx
-    la, a, lb, b = W.c5_nested()
     opts = WriteOptions(max_page_size=PAGE, default_compression=C.ZSTD)
 
     def dlevels(levels):
         return [nested.NestedLevel(lv["kind"], bool(lv["is_optional"]), lv["length"], h.up(lv.get("validity")), h.up(lv.get("offsets")))
                 for lv in levels]
-    items = [(dlevels(la), h.dcol(a), a, la), (dlevels(lb), h.dcol(b), b, lb)]
-    for _, dc, _, _ in items:
-        dc.is_nullable = False
-    rows = la[0]["length"]
-    U = W.arrow_bytes(a) + W.arrow_bytes(b) + 2 * ((rows + 1) * 4 + (rows + 7) // 8)   # leaves + list offsets / validity per leaf path
-    pairs = [(dl, dc) for dl, dc, _, _ in items]
-    encs = nested.write_nested_leaves(ctx, pairs, opts)      # warm-up + outputs
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        encs = nested.write_nested_leaves(ctx, pairs, opts)
-    te = (time.perf_counter() - t0) / reps * 1e3
-    cps = [ColumnPages(c["ptype"], False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (_, _, c, _) in zip(encs, items)]
-    kinds = [[lv["kind"] for lv in lv_] for _, _, _, lv_ in items]
-    opt = [[bool(lv["is_optional"]) for lv in lv_] for _, _, _, lv_ in items]
-    arrs = nested.read_nested_leaves(ctx, cps, kinds, opt)
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    gen = gen_parallel(lambda s: W.c5_nested(seed=s), range(42, 42 + arrays))
+    items, U = [], 0
+    for la, a, lb, b in gen:
+        rows = la[0]["length"]
+        for lv_, leaf in ((la, a), (lb, b)):
+            dc = h.dcol(leaf)
+            dc.is_nullable = False
+            items.append((dlevels(lv_), dc, leaf, lv_))
+        U += W.arrow_bytes(a) + W.arrow_bytes(b) + 2 * ((rows + 1) * 4 + (rows + 7) // 8)   # leaves + list offsets / validity per leaf path
+    la, a, lb, b = gen[0]
+    del gen
+
+    def measure(its, reps):
+        pairs = [(dl, dc) for dl, dc, _, _ in its]
+        encs = nested.write_nested_leaves(ctx, pairs, opts)      # warm-up + outputs
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            encs = nested.write_nested_leaves(ctx, pairs, opts)
+        te = (time.perf_counter() - t0) / reps * 1e3
+        cps = [ColumnPages(c["ptype"], False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (_, _, c, _) in zip(encs, its)]
+        kinds = [[lv["kind"] for lv in lv_] for _, _, _, lv_ in its]
+        opt = [[bool(lv["is_optional"]) for lv in lv_] for _, _, _, lv_ in its]
         arrs = nested.read_nested_leaves(ctx, cps, kinds, opt)
-    td = (time.perf_counter() - t0) / reps * 1e3
-    # round trip: list offsets and leaf buffers
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            arrs = nested.read_nested_leaves(ctx, cps, kinds, opt)
+        td = (time.perf_counter() - t0) / reps * 1e3
+        return pairs, encs, cps, kinds, opt, arrs, te, td
+    pairs, encs, cps, kinds, opt, arrs, te, td = measure(items, 3)
+    # round trip: list offsets and leaf buffers of the first array
     assert np.array_equal(arrs[0].offsets_numpy(0), la[0]["offsets"].astype(np.int64)), "C5 list offsets round trip failed"
     assert np.array_equal(arrs[1].leaf.values_numpy(), b["values"]), "C5 Utf8 leaf round trip failed"
     m = np.unpackbits(a["validity"], bitorder="little")[:a["rows"]].astype(bool)
     assert np.array_equal(arrs[0].leaf.values_numpy().view(np.int64)[m], a["values"][m]), "C5 Int64 leaf round trip failed"
     ctx.profile(True)
     nested.write_nested_leaves(ctx, pairs, opts)
+    st_e = ctx.profile_read()
     nested.read_nested_leaves(ctx, cps, kinds, opt)
-    st = ctx.profile_read()
+    st_d = ctx.profile_read()
     ctx.profile(False)
     pb = sum(e.length for e in encs)
-    res = dict(U=U, page_bytes=pb, n_pages=sum(e.n_pages for e in encs), enc_ms=te, dec_ms=td, kernels=st)
+    res = dict(U=U, page_bytes=pb, n_pages=sum(e.n_pages for e in encs), enc_ms=te, dec_ms=td, kernels={})
     cpu = None
     if cpu_on:   # leaf blocks only (the level arithmetic has no page-parallel CPU leg in the oracle)
         from oracle import sbo
         o = sbo.make_options(default_compression=sbo.ZSTD, max_page_size=PAGE)
         cpu = cpu_baseline([dict(a, nullable=False), dict(b, nullable=False)], o, W.arrow_bytes(a) + W.arrow_bytes(b),
-                           "the two leaf columns as flat non-nullable columns (leaf blocks only, no level sections); the oracle's "
-                           "Zstd encoder is store-only")
-    return config_entry("c5", res, cpu, {"workload": "C5: 1 M-row List<Struct<Int64,Utf8>> (list length U{0,1,2}, 10 % null lists, leaves 20 % "
-                                                     "null), 64Ki-row pages, Zstd default, ratio None; 2 leaf columns x 16 pages through the nested API (level sections per "
-                                                     "leaf, then the BLOCKs of both leaves in one call); synchronous, wall time incl. host work"})
+                           "the two leaf columns of one array as flat non-nullable columns (leaf blocks only, no level sections); the "
+                           "oracle's Zstd encoder is store-only")
+    e = config_entry("c5", res, cpu, {"workload": "C5: %d x 1 M-row List<Struct<Int64,Utf8>> (list length U{0,1,2}, 10 %% null lists, leaves 20 %% "
+                                                  "null), 64Ki-row pages, Zstd default, ratio None; %d leaf columns x 16 pages through the nested API "
+                                                  "(level sections of all leaves in one batch, then the BLOCKs of all leaves in one call); wall "
+                                                  "time of the calls incl. their host round trips" % (arrays, 2 * arrays)})
+
+    def top(st, direction):
+        if st:
+            k, v = max(st.items(), key=lambda kv: kv[1][1])
+            tot = sum(x[1] for x in st.values()) or 1.0
+            e[direction].update(top_kernel=k, top_kernel_ms=round(v[1], 3), top_kernel_share=round(v[1] / tot, 3),
+                                kernels_ms={kk: round(vv[1], 3) for kk, vv in sorted(st.items(), key=lambda kv: -kv[1][1])[:6]})
+    top(st_e, "encode")
+    top(st_d, "decode")
+    if arrays > 1:   # the round-2 shape: one array per call
+        _, _, _, _, _, _, te1, td1 = measure(items[:2], 3)
+        U1 = W.arrow_bytes(a) + W.arrow_bytes(b) + 2 * ((la[0]["length"] + 1) * 4 + (la[0]["length"] + 7) // 8)
+        e["single_array"] = {"arrow_MB": round(U1 / 1e6, 1), "write_ms": round(te1, 3), "read_ms": round(td1, 3),
+                             "encode_GBps": round(U1 / te1 / 1e6, 2), "decode_GBps": round(U1 / td1 / 1e6, 2)}
+    return e
 
 
 def run_c4_sharded(h, world, rank, dist, steps=3, on_device=True):

@@ -168,6 +168,7 @@ void sb_ctx_destroy(sb_ctx* ctx) {
     if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
     if (ctx->staging.p) (void)hipFree(ctx->staging.p);
     if (ctx->zlit.p) (void)hipFree(ctx->zlit.p);
+    if (ctx->zrec.p) (void)hipFree(ctx->zrec.p);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -492,7 +493,12 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         if (in_off > c.pages_len) return ctx->fail(SB_ERR_IO, "sum of PageMeta.length exceeds pages_len");
     }
     if (!ensure(ctx, ctx->scratch, scratch_off + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(scratch) failed");
-    if (!ensure(ctx, ctx->zlit, (size_t)1024 * (128 * 1024 + 64))) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zlit) failed");
+    // the inflate pool's per-wave areas: a literal buffer of one block, and (calls with at least 4 queue entries per pool
+    // wave: batches) the arena of pre-decoded Zstd sequences
+    if (!ensure(ctx, ctx->zlit, (size_t)INFLATE_POOL * (128 * 1024 + 64))) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zlit) failed");
+    const bool zrec_wanted = pages_bytes >= (48ull << 20);   // (a call that can hold >= 4 x INFLATE_POOL frames of 16 KiB)
+    if (zrec_wanted && !ensure(ctx, ctx->zrec, (size_t)INFLATE_POOL * ZREC_PER_WAVE * 8))
+        return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zrec) failed");
 
     uint8_t* tb = ctx->tables.p;
     hipError_t e = hipMemcpyAsync(tb, slot->host, upload_bytes, hipMemcpyHostToDevice, s);
@@ -500,6 +506,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
 
     DecodeArgs a;
     a.zlit = ctx->zlit.p;
+    a.zrec = zrec_wanted ? (uint64_t*)ctx->zrec.p : nullptr;
     a.cols = (const ColDesc*)(tb + o_cols);
     a.tasks = (const PageTask*)(tb + o_tasks);
     a.descs = (PageDesc*)(tb + o_descs);

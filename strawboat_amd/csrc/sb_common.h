@@ -112,6 +112,10 @@ struct FreqEntry {
     uint32_t page, pad;
 };
 
+// the pool of inflate waves (k_inflate) and its per-wave areas
+constexpr uint32_t INFLATE_POOL = 2048;          // waves
+constexpr uint32_t ZREC_PER_WAVE = 128 * 1024;   // pre-decoded Zstd sequence records (8 bytes each) per pool wave
+
 struct DecodeArgs {
     const ColDesc* cols;
     const PageTask* tasks;
@@ -123,6 +127,7 @@ struct DecodeArgs {
     InflateJob* jobs_b;  // capacity job_cap_b
     uint32_t* job_counts;  // [0] = queue A, [1] = queue B, [2] tiles, [3] planned pages, [4] page-level RLE, [5] / [6] workgroups of k_parse / k_colscan that are done
     uint8_t* zlit;         // Zstd literal buffers, one per inflate wave
+    uint64_t* zrec;        // Zstd sequence records, one arena per inflate wave (k_inflate's lane-per-frame pre-decode)
     uint32_t n_pages;
     uint32_t n_cols;
     uint32_t n_tiles;

@@ -556,7 +556,6 @@ __device__ void lz4_inflate_wave(const InflateJob& j, Status* st) {
 
 // one wave per workgroup; the grid is a fixed pool of waves that loops over the job queue, so the
 // per-wave Zstd literal buffers (zlit) are a fixed pool too
-constexpr uint32_t INFLATE_POOL = 1024;
 constexpr uint32_t ZLIT_STRIDE = 128 * 1024 + 64;
 // Snappy raw format (basic.rs:99-106 -> snap::raw::Decoder [3P]): uvarint length, then literal /
 // copy elements.  Same shape as the LZ4 decoder: elements are parsed wave-uniformly, the byte
@@ -721,28 +720,89 @@ __device__ void patas_inflate_wave(const InflateJob& j, Status* st, uint8_t* s_w
     }
 }
 
+// One job of queue entries that k_inflate owns (all lanes, uniform arguments).  recs: the frame's pre-decoded sequences or null.
+__device__ __forceinline__ void inflate_one(const InflateJob& j, Status* st, ZWork& wk, uint8_t* zlit, uint8_t* s_win, uint16_t* s_pos,
+                                            const uint64_t* recs) {
+    if (j.codec == SB_CODEC_LZ4 || j.codec == CODEC_SPLIT) {
+        // k_inflate_lz4 owns the LZ4 blocks; a split Zstd buffer is decoded through its frames' entries
+    } else if (j.codec == SB_CODEC_ZSTD) {
+        zstd_inflate_wave(j.src, j.csize, j.dst, j.out_len, &wk, zlit, recs);
+        if (threadIdx.x == 0 && wk.err) raise(st, SB_ERR_EXTERNAL, j.page, 120 + (uint32_t)wk.err);
+        __syncthreads();
+    } else if (j.codec == SB_CODEC_SNAPPY) {
+        snappy_inflate_wave(j, st);
+    } else if (j.codec == SB_CODEC_PATAS) {
+        patas_inflate_wave(j, st, s_win, s_pos);
+    } else if (threadIdx.x == 0) {
+        raise(st, SB_ERR_OUT_OF_SPEC, j.page, 110);
+    }
+}
+
+// A pool of waves over the job queue.  With few jobs every wave takes one job at a time.  With many (>= 4 per wave) a wave
+// takes up to 64 consecutive jobs: the Zstd frames among them that qualify (sb_zstd.h, z_lane_frame) have their FSE
+// sequence streams decoded LANE PER FRAME into the wave's record arena first — 64 serial state chains side by side
+// instead of one after the other — and the wave then executes the jobs one by one from the records.
 __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st,
-                                                uint8_t* zlit) {
+                                                uint8_t* zlit, uint64_t* zrec) {
     __shared__ ZWork wk;
+    __shared__ ZLaneTabs zt;
     __shared__ uint8_t s_win[64 * 10 + 8];
     __shared__ uint16_t s_pos[65];
     const uint32_t njobs = *count;
+    const uint32_t lane = threadIdx.x;
     if (threadIdx.x == 0) wk.pre_built = 0;
+    uint8_t* my_lit = zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE;
+    const uint32_t B = (zrec && njobs >= 4 * gridDim.x) ? min(64u, njobs / gridDim.x) : 1u;
+    if (B > 1) {
+        for (uint32_t i = lane; i < 64; i += 64) {
+            zt.ll[i] = g_zpre.ll[i];
+            zt.ml[i] = g_zpre.ml[i];
+            zt.xll[i] = g_zpre.xll[i];
+            zt.xml[i] = g_zpre.xml[i];
+            if (i < 32) zt.of[i] = g_zpre.of[i];
+        }
+    }
     __syncthreads();
-    for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
-        const InflateJob j = jobs[job];
-        if (j.codec == SB_CODEC_LZ4 || j.codec == CODEC_SPLIT) {
-            // k_inflate_lz4 owns the LZ4 blocks; a split Zstd buffer is decoded through its frames' entries
-        } else if (j.codec == SB_CODEC_ZSTD) {
-            zstd_inflate_wave(j.src, j.csize, j.dst, j.out_len, &wk, zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE);
-            if (threadIdx.x == 0 && wk.err) raise(st, SB_ERR_EXTERNAL, j.page, 120 + (uint32_t)wk.err);
-            __syncthreads();
-        } else if (j.codec == SB_CODEC_SNAPPY) {
-            snappy_inflate_wave(j, st);
-        } else if (j.codec == SB_CODEC_PATAS) {
-            patas_inflate_wave(j, st, s_win, s_pos);
-        } else if (threadIdx.x == 0) {
-            raise(st, SB_ERR_OUT_OF_SPEC, j.page, 110);
+    if (B == 1) {
+        for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) inflate_one(jobs[job], st, wk, my_lit, s_win, s_pos, nullptr);
+        return;
+    }
+    uint64_t* arena = zrec + (uint64_t)blockIdx.x * ZREC_PER_WAVE;
+    for (uint32_t base = blockIdx.x * B; base < njobs; base += gridDim.x * B) {
+        const uint32_t nb = min(B, njobs - base);
+        InflateJob mine;
+        mine.codec = 0xFFFFFFFFu;
+        mine.src = nullptr;
+        mine.csize = mine.out_len = 0;
+        if (lane < nb) mine = jobs[base + lane];
+        const bool zs = lane < nb && mine.codec == SB_CODEC_ZSTD;
+        // phase 0 (lane per frame): how many sequences, and does the frame qualify
+        uint32_t cnt = zs ? z_lane_frame(mine.src, mine.csize, mine.out_len, zt, nullptr, 0) : ZPRE_NONE;
+        uint32_t start = 0;
+        while (start < nb) {
+            const uint32_t need = (lane >= start && cnt != ZPRE_NONE) ? cnt : 0u;
+            const uint32_t incl = wave_scan_dpp(need);
+            uint64_t over = __ballot(lane >= start && lane < nb && incl > ZREC_PER_WAVE);
+            uint32_t end = over ? (uint32_t)__builtin_ctzll(over) : nb;
+            if (end == start) {            // one frame larger than the arena: the one-wave path
+                if (lane == start) cnt = ZPRE_NONE;
+                end = start + 1;
+            }
+            // phase 1 (lane per frame): the records of frames [start, end)
+            const uint32_t my_off = incl - need;
+            bool ok = false;
+            if (lane >= start && lane < end && need)
+                ok = z_lane_frame(mine.src, mine.csize, mine.out_len, zt, arena + my_off, need) == need;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // phase 2 (the wave per job, in queue order)
+            for (uint32_t k = start; k < end; k++) {
+                const uint32_t k_ok = (uint32_t)__builtin_amdgcn_readlane((int)(ok ? 1u : 0u), (int)k);
+                const uint32_t k_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)k);
+                inflate_one(jobs[base + k], st, wk, my_lit, s_win, s_pos, k_ok ? arena + k_off : nullptr);
+            }
+            start = end;
         }
     }
 }
@@ -2000,7 +2060,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     {
         KScope k(ctx, K_INFLATE_A);
-        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
+        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
     }
     {
         KScope k(ctx, "k_inflate_lz4");
@@ -2016,7 +2076,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
-        k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit);
+        k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec);
         KScope k2(ctx, "k_inflate_lz4(values)");
         k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
     }
@@ -2038,7 +2098,7 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 8 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-    k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit);
+    k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
     k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);

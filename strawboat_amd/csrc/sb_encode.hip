@@ -2628,9 +2628,11 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
         uint32_t *idx, *firsts;
         uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
         uint32_t D = DICT_FALLBACK;
+        STL(50);
         if constexpr (W <= 8) D = dict_build_lds<W>(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA);
         if (D == DICT_FALLBACK) D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
         if (D == EMPTY) return 0;
+        STL(51);
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
         if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
             SelectOpts so{a.ratio, 1u, a.forbidden | p.forb_extra | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, p.depth + 1};
@@ -2640,6 +2642,7 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
                                          ValidView{nullptr, 0}, N, NK_UNSIGNED, so, sc);
             __syncthreads();
         }
+        STL(52);
         if (ic == SB_CODEC_FREQ) {
             // u32 indices that are mostly one value (the column may not use Freq itself: integers with a maximum
             // below 256, freq.rs:146): the index block is a Freq block with its own nested exceptions block.  The
@@ -2669,6 +2672,7 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
         }
         const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags, lz_tmp, 8 * N);
         if (ib == 0) return 0;
+        STL(53);
         uint8_t* q = blk + 9 + ib;
         if (threadIdx.x == 0) stu32(q, D);
         for (uint32_t k = threadIdx.x; k < D; k += WG) {
@@ -2676,6 +2680,7 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
             __builtin_memcpy(q + 4 + (uint64_t)k * W, &v, W);
         }
         body = ib + 4 + (uint64_t)D * W;
+        STL(54);
     } else {
         if (threadIdx.x == 0) raise(a.status, SB_ERR_NYI, page, 522);  // LZ4/Zstd/Freq/Patas encode: host path
         return 0;

@@ -52,6 +52,7 @@ struct sb_ctx {
     sb::DevBuf scratch;  // per-page aux + inflate areas, encode slots
     sb::DevBuf staging;  // device staging for SB_MEM_HOST callers
     sb::DevBuf zlit;     // Zstd literal buffers (fixed pool of inflate waves)
+    sb::DevBuf zrec;     // Zstd sequence records (one arena per inflate wave; allocated by the first batch-sized read)
     sb::Status* d_status = nullptr;
     sb::Status* h_status = nullptr;  // pinned
 

@@ -313,6 +313,319 @@ __constant__ uint32_t Z_ML_BASE[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 1
 __constant__ uint8_t Z_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                       0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 
+// ---- the decoding tables of the predefined distributions (RFC 8878 3.1.1.3.2.2), built at COMPILE time: entries packed
+// like ZFse (symbol | nbits << 8 | base << 16); xll / xml = per state the extra-bit count | baseline << 8 of its length code
+struct ZPreTables {
+    uint32_t ll[64], of[32], ml[64], xll[64], xml[64];
+};
+constexpr uint32_t zc_highbit(uint32_t v) {
+    uint32_t r = 0;
+    while (v >>= 1) r++;
+    return r;
+}
+template <int NSYM, int LOG>
+constexpr void zc_build(const int (&norm)[NSYM], uint32_t* out) {
+    constexpr int size = 1 << LOG;
+    int high = size - 1;
+    uint32_t next[NSYM] = {};
+    uint32_t sym[size] = {};
+    for (int s = 0; s < NSYM; s++) {
+        if (norm[s] == -1) {
+            sym[high--] = (uint32_t)s;
+            next[s] = 1;
+        } else {
+            next[s] = (uint32_t)norm[s];
+        }
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < NSYM; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            sym[pos] = (uint32_t)s;
+            do {
+                pos = (pos + step) & mask;
+            } while (pos > high);
+        }
+    for (int i = 0; i < size; i++) {
+        const uint32_t sy = sym[i];
+        const uint32_t ns = next[sy]++;
+        const uint32_t nb = (uint32_t)LOG - zc_highbit(ns);
+        const uint32_t base = (ns << nb) - (uint32_t)size;
+        out[i] = sy | (nb << 8) | (base << 16);
+    }
+}
+constexpr ZPreTables zc_make_pre() {
+    ZPreTables t = {};
+    constexpr int ll_norm[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+    constexpr int ml_norm[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+    constexpr int of_norm[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+    constexpr uint32_t ll_base[36] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,   10,  11,  12,  13,   14,   15,   16,   18,
+                                      20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+    constexpr uint32_t ll_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    constexpr uint32_t ml_base[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                      21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
+                                      43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+    constexpr uint32_t ml_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                      0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    zc_build<36, 6>(ll_norm, t.ll);
+    zc_build<29, 5>(of_norm, t.of);
+    zc_build<53, 6>(ml_norm, t.ml);
+    for (int i = 0; i < 64; i++) {
+        const uint32_t cl = t.ll[i] & 255, cm = t.ml[i] & 255;
+        t.xll[i] = ll_bits[cl] | (ll_base[cl] << 8);
+        t.xml[i] = ml_bits[cm] | (ml_base[cm] << 8);
+    }
+    return t;
+}
+__device__ const ZPreTables g_zpre = zc_make_pre();
+
+// ---- sequences decoded LANE PER FRAME (k_zstd_seq_lanes): the FSE state chain of a frame is serial, so a wave that owns
+// one frame spends ~900 cycles per sequence on it; 64 lanes that each own a frame run 64 chains in the same instructions.
+// A frame qualifies when every compressed block codes its sequences with the predefined tables or single-symbol (RLE)
+// tables — what this library's encoder writes for its 16 KiB frames; frames with transmitted tables (libzstd's usual
+// choice) keep the one-wave path.  Output: one 64-bit record per sequence, repeat offsets resolved,
+//     literal length (18 bits) | match length << 18 (18 bits) | offset << 36 (28 bits)
+// which zstd_inflate_wave executes instead of decoding the stream itself.
+struct ZPre {
+    uint32_t rec_off;   // first record of the frame in the record area (ZPRE_NONE: not pre-decoded)
+    uint32_t nrec;
+};
+constexpr uint32_t ZPRE_NONE = 0xFFFFFFFFu;
+struct ZLaneTabs {      // LDS copy of g_zpre
+    uint32_t ll[64], of[32], ml[64], xll[64], xml[64];
+};
+// 64 stream bits whose top bit is stream bit `bitpos - 1` (bits below the start of the stream read as 0)
+__device__ __forceinline__ uint64_t z_lane_top(const uint8_t* sb_, int32_t bitpos) {
+    const int32_t lo = bitpos - 64;
+    if (lo >= 0) {
+        const uint32_t byte0 = (uint32_t)lo >> 3, sh = (uint32_t)lo & 7;
+        uint64_t v = ldu64(sb_ + byte0) >> sh;
+        if (sh) v |= (uint64_t)ldu8(sb_ + byte0 + 8) << (64 - sh);
+        return v;
+    }
+    if (bitpos <= 0) return 0ull;
+    uint64_t v = 0;
+    const uint32_t nbytes = ((uint32_t)bitpos + 7) >> 3;
+    for (uint32_t k = 0; k < nbytes; k++) v |= (uint64_t)ldu8(sb_ + k) << (8 * k);
+    return v << (uint32_t)(-lo);
+}
+// One frame (src[0, n) must be exactly one frame with a content size of out_len) walked by ONE LANE.  recs == nullptr:
+// count the sequences and check that the frame qualifies; else write the records.  Returns the number of sequences, or
+// ZPRE_NONE when the frame does not qualify / is malformed (the one-wave decoder then reports the error).
+__device__ uint32_t z_lane_frame(const uint8_t* src, uint32_t n, uint32_t out_len, const ZLaneTabs& T, uint64_t* recs, uint32_t nrec_cap) {
+    if (n < 6 || ldu32(src) != 0xFD2FB528u) return ZPRE_NONE;
+    uint32_t ip = 4;
+    const uint8_t fhd = ldu8(src + ip++);
+    const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+    if ((fhd & 0x08) || did) return ZPRE_NONE;
+    if (!single) ip += 1;
+    const uint32_t fcs_bytes = fcs_flag == 0 ? (single ? 1u : 0u) : (1u << fcs_flag);
+    if (n - ip < fcs_bytes + 3) return ZPRE_NONE;
+    ip += fcs_bytes;
+    uint32_t total = 0, op = 0;
+    uint32_t r0 = 1, r1 = 4, r2 = 8;
+    // current tables: mode 0 = predefined (LDS), 1 = one symbol (kept here); `have` as in the one-wave decoder
+    uint32_t kind_ll = 2, kind_of = 2, kind_ml = 2, rle_ll = 0, rle_of = 0, rle_ml = 0;
+    for (;;) {
+        if (n - ip < 3) return ZPRE_NONE;
+        const uint32_t bh = (uint32_t)ldu8(src + ip) | ((uint32_t)ldu8(src + ip + 1) << 8) | ((uint32_t)ldu8(src + ip + 2) << 16);
+        ip += 3;
+        const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3) return ZPRE_NONE;
+        if (btype == 0 || btype == 1) {
+            const uint32_t body = btype == 1 ? 1u : bsize;
+            if (n - ip < body) return ZPRE_NONE;
+            ip += body;
+            op += bsize;
+        } else {
+            if (bsize > 128 * 1024 || n - ip < bsize || bsize < 2) return ZPRE_NONE;
+            const uint8_t* bs = src + ip;
+            uint32_t bp = 0;
+            const uint8_t b0 = ldu8(bs + bp++);
+            const uint32_t ltype = b0 & 3, sf = (b0 >> 2) & 3;
+            uint32_t regen = 0;
+            if (ltype == 0 || ltype == 1) {
+                if (sf == 0 || sf == 2) {
+                    regen = b0 >> 3;
+                } else if (sf == 1) {
+                    if (bsize - bp < 1) return ZPRE_NONE;
+                    regen = (b0 >> 4) | ((uint32_t)ldu8(bs + bp) << 4);
+                    bp += 1;
+                } else {
+                    if (bsize - bp < 2) return ZPRE_NONE;
+                    regen = (b0 >> 4) | ((uint32_t)ldu8(bs + bp) << 4) | ((uint32_t)ldu8(bs + bp + 1) << 12);
+                    bp += 2;
+                }
+                const uint32_t body = ltype == 0 ? regen : 1u;
+                if (bsize - bp < body) return ZPRE_NONE;
+                bp += body;
+            } else {
+                uint32_t csize;
+                if (bsize - bp < 4) return ZPRE_NONE;
+                if (sf == 0 || sf == 1) {
+                    const uint32_t v = (b0 >> 4) | ((uint32_t)ldu8(bs + bp) << 4) | ((uint32_t)ldu8(bs + bp + 1) << 12);
+                    bp += 2;
+                    regen = v & 0x3FF;
+                    csize = v >> 10;
+                } else if (sf == 2) {
+                    const uint32_t v = (b0 >> 4) | ((uint32_t)ldu8(bs + bp) << 4) | ((uint32_t)ldu8(bs + bp + 1) << 12) | ((uint32_t)ldu8(bs + bp + 2) << 20);
+                    bp += 3;
+                    regen = v & 0x3FFF;
+                    csize = v >> 14;
+                } else {
+                    const uint64_t v = (b0 >> 4) | ((uint64_t)ldu8(bs + bp) << 4) | ((uint64_t)ldu8(bs + bp + 1) << 12) |
+                                       ((uint64_t)ldu8(bs + bp + 2) << 20) | ((uint64_t)ldu8(bs + bp + 3) << 28);
+                    bp += 4;
+                    regen = (uint32_t)(v & 0x3FFFF);
+                    csize = (uint32_t)(v >> 18);
+                }
+                if (bsize - bp < csize) return ZPRE_NONE;
+                bp += csize;
+            }
+            if (bsize - bp < 1) return ZPRE_NONE;
+            uint32_t nseq;
+            {
+                const uint8_t s0 = ldu8(bs + bp++);
+                if (s0 < 128) {
+                    nseq = s0;
+                } else if (s0 < 255) {
+                    if (bsize - bp < 1) return ZPRE_NONE;
+                    nseq = ((uint32_t)(s0 - 128) << 8) + ldu8(bs + bp);
+                    bp += 1;
+                } else {
+                    if (bsize - bp < 2) return ZPRE_NONE;
+                    nseq = (uint32_t)ldu8(bs + bp) + ((uint32_t)ldu8(bs + bp + 1) << 8) + 0x7F00;
+                    bp += 2;
+                }
+            }
+            uint32_t block_out = regen;
+            if (nseq) {
+                if (bsize - bp < 1) return ZPRE_NONE;
+                const uint8_t modes = ldu8(bs + bp++);
+                if (modes & 3) return ZPRE_NONE;
+                const uint32_t m_ll = (modes >> 6) & 3, m_of = (modes >> 4) & 3, m_ml = (modes >> 2) & 3;
+                if (m_ll == 2 || m_of == 2 || m_ml == 2) return ZPRE_NONE;   // transmitted tables: the one-wave path
+                if (m_ll == 1) {
+                    if (bsize - bp < 1) return ZPRE_NONE;
+                    rle_ll = ldu8(bs + bp++);
+                    if (rle_ll > 35) return ZPRE_NONE;
+                    kind_ll = 1;
+                } else if (m_ll == 0) {
+                    kind_ll = 0;
+                } else if (kind_ll == 2) {
+                    return ZPRE_NONE;
+                }
+                if (m_of == 1) {
+                    if (bsize - bp < 1) return ZPRE_NONE;
+                    rle_of = ldu8(bs + bp++);
+                    if (rle_of > 31) return ZPRE_NONE;
+                    kind_of = 1;
+                } else if (m_of == 0) {
+                    kind_of = 0;
+                } else if (kind_of == 2) {
+                    return ZPRE_NONE;
+                }
+                if (m_ml == 1) {
+                    if (bsize - bp < 1) return ZPRE_NONE;
+                    rle_ml = ldu8(bs + bp++);
+                    if (rle_ml > 52) return ZPRE_NONE;
+                    kind_ml = 1;
+                } else if (m_ml == 0) {
+                    kind_ml = 0;
+                } else if (kind_ml == 2) {
+                    return ZPRE_NONE;
+                }
+                if (recs) {
+                    if (total + nseq > nrec_cap) return ZPRE_NONE;
+                    const uint8_t* sb_ = bs + bp;
+                    const uint32_t sn_ = bsize - bp;
+                    if (sn_ == 0) return ZPRE_NONE;
+                    const uint8_t lastb = ldu8(sb_ + sn_ - 1);
+                    if (lastb == 0) return ZPRE_NONE;
+                    int32_t bitpos = (int32_t)(sn_ - 1) * 8 + (31 - __clz((int)lastb));
+                    const uint32_t lll = kind_ll ? 0u : 6u, ofl = kind_of ? 0u : 5u, mll = kind_ml ? 0u : 6u;
+                    uint64_t C = z_lane_top(sb_, bitpos);
+                    uint32_t cbits = 64;   // valid bits left in C (top-aligned)
+                    auto take = [&](uint32_t nb) -> uint32_t {
+                        if (nb == 0) return 0u;
+                        const uint32_t v = (uint32_t)(C >> (64 - nb));
+                        C <<= nb;
+                        cbits -= nb;
+                        bitpos -= (int32_t)nb;
+                        return v;
+                    };
+                    uint32_t sl = take(lll), so = take(ofl), sm = take(mll);
+                    // single-symbol tables: the state stays 0 and the entry is the symbol with 0 bits
+                    const uint32_t fx_ll = rle_ll, fx_of = rle_of, fx_ml = rle_ml;
+                    const uint32_t fx_xll = (uint32_t)Z_LL_BITS[rle_ll] | (Z_LL_BASE[rle_ll] << 8);
+                    const uint32_t fx_xml = (uint32_t)Z_ML_BITS[rle_ml] | (Z_ML_BASE[rle_ml] << 8);
+                    for (uint32_t k = 0; k < nseq; k++) {
+                        const uint32_t e_of = kind_of ? fx_of : T.of[so], e_ml = kind_ml ? fx_ml : T.ml[sm], e_ll = kind_ll ? fx_ll : T.ll[sl];
+                        const uint32_t x_ml = kind_ml ? fx_xml : T.xml[sm], x_ll = kind_ll ? fx_xll : T.xll[sl];
+                        const uint32_t ofc = e_of & 255;
+                        if (ofc > 27) return ZPRE_NONE;    // (offsets beyond 2^28 do not fit a record)
+                        const uint32_t mlbits = x_ml & 255, llbits = x_ll & 255;
+                        if (cbits < ofc + mlbits + llbits) {
+                            C = z_lane_top(sb_, bitpos);
+                            cbits = 64;
+                        }
+                        const uint32_t ofv = (1u << ofc) + take(ofc);
+                        const uint32_t mlen = (x_ml >> 8) + take(mlbits);
+                        const uint32_t llen = (x_ll >> 8) + take(llbits);
+                        uint32_t offset;
+                        if (ofv > 3) {
+                            offset = ofv - 3;
+                            r2 = r1;
+                            r1 = r0;
+                            r0 = offset;
+                        } else {
+                            uint32_t idx = ofv - 1;
+                            if (llen == 0) idx++;
+                            if (idx == 0) {
+                                offset = r0;
+                            } else {
+                                offset = idx == 1 ? r1 : idx == 2 ? r2 : r0 - 1;
+                                if (offset == 0) return ZPRE_NONE;
+                                if (idx > 1) r2 = r1;
+                                r1 = r0;
+                                r0 = offset;
+                            }
+                        }
+                        if (llen >= (1u << 18) || mlen >= (1u << 18) || offset >= (1u << 28)) return ZPRE_NONE;
+                        if (k + 1 < nseq) {
+                            const uint32_t nl = (e_ll >> 8) & 255, nm = (e_ml >> 8) & 255, no = (e_of >> 8) & 255;
+                            if (cbits < nl + nm + no) {
+                                C = z_lane_top(sb_, bitpos);
+                                cbits = 64;
+                            }
+                            sl = (e_ll >> 16) + take(nl);
+                            sm = (e_ml >> 16) + take(nm);
+                            so = (e_of >> 16) + take(no);
+                        }
+                        if (bitpos < 0) return ZPRE_NONE;
+                        block_out += mlen;
+                        recs[total + k] = (uint64_t)llen | ((uint64_t)mlen << 18) | ((uint64_t)offset << 36);
+                    }
+                    if (bitpos != 0) return ZPRE_NONE;
+                }
+                total += nseq;
+            }
+            (void)block_out;
+            (void)op;
+            ip += bsize;
+        }
+        if (bh & 1) break;
+    }
+    if (checksum) {
+        if (n - ip < 4) return ZPRE_NONE;
+        ip += 4;
+    }
+    if (ip != n) return ZPRE_NONE;     // more than one frame: the one-wave path walks them
+    (void)out_len;
+    return total;
+}
+
 // sets one of the three sequence tables according to its compression mode; returns bytes consumed
 // from `src` (0 is a valid answer), or 0xFFFFFFFF on error
 __device__ inline uint32_t z_seq_table(ZWork* wk, int mode, ZFse* t, uint32_t* log_out, uint32_t* have,
@@ -355,7 +668,7 @@ __device__ inline uint32_t z_seq_table(ZWork* wk, int mode, ZFse* t, uint32_t* l
 // Decodes one frame.  All 64 lanes call it with identical arguments; returns bytes produced
 // (wk->err != 0 on failure).  `lit` = a 128 KiB + 32 literal buffer owned by this wave.
 __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out_len, ZWork* wk,
-                                      uint8_t* lit) {
+                                      uint8_t* lit, const uint64_t* recs = nullptr /* k_zstd_seq_lanes' records of this frame */) {
     const int lane = threadIdx.x & 63;
     auto wsync = []() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -559,7 +872,25 @@ __device__ uint32_t zstd_inflate_wave(const uint8_t* src, uint32_t n, uint8_t* d
             }
             uint32_t lit_pos = 0;
             LZP(20);
-            if (nseq > 0) {
+            if (nseq > 0 && recs) {
+                // the sequences were decoded by k_zstd_seq_lanes (lane per frame): lane k takes record k of the batch
+                for (uint32_t done = 0; done < nseq; done += 64) {
+                    const uint32_t nb = min(64u, nseq - done);
+                    const bool have = (uint32_t)lane < nb;
+                    const uint64_t r = have ? gld64(recs + done + lane) : (1ull << 36);
+                    const uint32_t llen = have ? (uint32_t)(r & 0x3FFFF) : 0u, mlen = have ? (uint32_t)((r >> 18) & 0x3FFFF) : 0u;
+                    const uint32_t off = (uint32_t)(r >> 36);
+                    const uint32_t lsum = wave_scan_dpp(llen), osum = wave_scan_dpp(llen + mlen);
+                    const bool bad = have && ((uint64_t)lit_pos + lsum > regen || (uint64_t)op + osum > out_len || off == 0 ||
+                                              off > op + osum - mlen);
+                    if (__ballot(bad)) ZERR(30);
+                    const uint32_t lit_total = rdlane(lsum, 63);
+                    op += ex.run(nb, llen, mlen, off, litp + lit_pos, op);
+                    lit_pos += lit_total;
+                    wsync();
+                }
+                recs += nseq;
+            } else if (nseq > 0) {
                 if (lane == 0) {
                     const uint8_t modes = bs[bp];
                     uint32_t q = bp + 1;

@@ -247,3 +247,29 @@ def test_concatenated_libzstd_frames(gpu_ctx):
     metas = np.array([[len(page), data.size]], np.uint64)
     with pytest.raises(NativeError):
         gpu_decode(gpu_ctx, col, pages, metas)
+
+
+def test_batch_of_frames_takes_the_lane_per_frame_sequence_decoder(gpu_ctx):
+    """A read with >= 4 frames per wave of the inflate pool (here ~10 000 frames of 16 KiB in 160 MB of Arrow bytes) decodes
+    the FSE sequence streams LANE PER FRAME before the waves execute them (k_inflate, z_lane_frame): same bytes out as the
+    one-wave path, for frames with many short sequences (small integers, runs), with long matches (constant stretches),
+    with raw literals only (random bytes) and for the two-block frames of binary pages — device decode == input ==
+    the oracle's decode of the device's pages."""
+    from tests.test_gpu_encode import gpu_encode
+    rng = np.random.default_rng(99)
+    n = 10_000_000
+    v = rng.integers(-2**40, 2**40, n)                      # 3-byte matches every 8 bytes
+    v[2_000_000:3_000_000] = rng.integers(0, 50, 1_000_000)  # small values: long zero matches + 1 literal
+    v[3_000_000:3_500_000] = 7                               # one long match per frame
+    v[3_500_000:4_000_000] = rng.integers(-2**62, 2**62, 500_000)   # incompressible: raw blocks
+    col = dict(ptype=S.T_I64, nullable=False, rows=n, values=v, validity=None, offsets=None)
+    words = gen.binary(3_000_000, uniq=500, maxlen=6, seed=5)
+    for c in (col, words):
+        enc = gpu_encode(gpu_ctx, c, lz4_exact=False, max_page_size=65536, default_compression=S.ZSTD)
+        pages, metas = enc.pages_numpy(), enc.metas_array()
+        got = gpu_decode(gpu_ctx, c, pages, metas)
+        want = gen.oracle_read(c, pages, metas)
+        assert np.array_equal(got.values_numpy(), want["values"])
+        assert np.array_equal(want["values"], np.ascontiguousarray(c["values"]).view(np.uint8))
+        if c["offsets"] is not None:
+            assert np.array_equal(got.offsets_numpy(), want["offsets"])

@@ -99,6 +99,9 @@ typedef struct sb_write_options {
  * parse that emits a format-valid block every LZ4 decoder (hence the reference) reads back to the same bytes;
  * compressed-byte identity is library-version dependent upstream (no lockfile) and not part of the page layout. */
 #define SB_WRITE_LZ4_EXACT 1u
+/* SB_WRITE_DEBUG_VERIFY_FAIL (tests only): the string check behind the adaptive binary selector's hashed key count reports a
+ * collision on every page, so that the exact re-selection and the exact dictionary build run; the bytes written are the same. */
+#define SB_WRITE_DEBUG_VERIFY_FAIL (1u << 30)
 
 typedef struct sb_ctx sb_ctx;
 

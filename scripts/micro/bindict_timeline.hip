@@ -80,28 +80,36 @@ int main(int argc, char** argv) {
     a.forbidden = 0; a.n_pages = P; a.n_cols = 1; a.default_compression = SB_CODEC_LZ4; a.freq_count = fc; a.nested_force = -1;
     { uint32_t* cc; hipMalloc(&cc, 128); hipMemset(cc, 0, 128); a.codec_counts = cc; }
     hipEvent_t e0, e1, e2; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
-    for (int i = 0; i < 2; i++) { k_enc_select<-4><<<P, WG>>>(a); k_enc_emit_pages<-4, SB_CODEC_DICT><<<P, WG>>>(a); }
+    a.pre_hashed = 1;
+    const dim3 tg((uint32_t)P, (uint32_t)((N + BH_ROWS - 1) / BH_ROWS));
+    hipEvent_t eh, ev; hipEventCreate(&eh); hipEventCreate(&ev);
+    for (int i = 0; i < 2; i++) { k_enc_bin_hash<<<tg, WG>>>(a); k_enc_select<-4><<<P, WG>>>(a); k_enc_bin_verify<<<tg, WG>>>(a); k_enc_emit_pages<-4, SB_CODEC_DICT><<<P, WG>>>(a); }
+    hipEventRecord(eh);
+    k_enc_bin_hash<<<tg, WG>>>(a);
     hipEventRecord(e0);
     k_enc_select<-4><<<P, WG>>>(a);
+    hipEventRecord(ev);
+    k_enc_bin_verify<<<tg, WG>>>(a);
     hipEventRecord(e1);
     k_enc_emit_pages<-4, SB_CODEC_DICT><<<P, WG>>>(a);
     hipEventRecord(e2); hipEventSynchronize(e2);
-    float m1, m2; hipEventElapsedTime(&m1, e0, e1); hipEventElapsedTime(&m2, e1, e2);
+    float m1, m2, mh, mv; hipEventElapsedTime(&m1, e0, ev); hipEventElapsedTime(&m2, e1, e2); hipEventElapsedTime(&mh, eh, e0); hipEventElapsedTime(&mv, ev, e1);
+    printf("k_enc_bin_hash %.3f ms, k_enc_bin_verify %.3f ms\n", mh, mv);
     Status hs; hipMemcpy(&hs, st, sizeof hs, hipMemcpyDeviceToHost);
     int32_t c100; hipMemcpy(&c100, codecs + 100, 4, hipMemcpyDeviceToHost);
     printf("k_enc_select<-4> %.3f ms, k_enc_emit_pages<-4, Dict> %.3f ms; codec of page 100: %d; status %d\n", m1, m2, c100, (int)hs.code);
     std::vector<unsigned long long> t(4096);
     hipMemcpy(t.data(), tl, 8 * 4096, hipMemcpyDeviceToHost);
     const char* nm[64] = {};
-    nm[40] = "select: start"; nm[41] = "hash rows"; nm[42] = "all-equal / nulls pass"; nm[43] = "Freq vote"; nm[44] = "distinct count"; nm[45] = "rest";
+    nm[40] = "select: start"; nm[41] = "hash rows"; nm[42] = "all-equal / nulls pass"; nm[43] = "Freq vote"; nm[44] = "distinct count"; nm[45] = "rest"; nm[46] = "handover"; nm[47] = "  tags: table init"; nm[48] = "  tags: insert + confirm"; nm[49] = "  tags: weights";
     nm[20] = "emit: start"; nm[21] = "dict phase 1 (insert)"; nm[22] = "phase 2 (first rows)"; nm[23] = "verify strings"; nm[24] = "phase 3 (ids)";
-    nm[25] = "phase 4 (idx)"; nm[26] = "phase 5 (firsts)"; nm[30] = "index selector"; nm[31] = "index block"; nm[32] = "entries";
+    nm[25] = "phase 4 (idx)"; nm[27] = "idx from hand-over"; nm[26] = "phase 5 (firsts)"; nm[30] = "index selector"; nm[31] = "index block"; nm[32] = "entries";
     unsigned long long prev = 0;
-    for (int p : {40, 41, 42, 43, 44, 45, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32}) {
+    for (int p : {40, 41, 42, 43, 47, 48, 49, 44, 45, 46, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32}) {
         const unsigned long long v = t[512 + p];
         if (!v) continue;
         if (p == 40 || p == 20) prev = v;
-        printf("  %-26s +%8.1f us\n", nm[p], (v - prev) / 100.0);
+        printf("  %-26s +%8.1f us\n", nm[p], (double)(long long)(v - prev) / 2400.0);
         prev = v;
     }
     return 0;

@@ -76,19 +76,18 @@ __device__ inline bool zstd_frame_extent(const uint8_t* src, uint32_t n, uint32_
     *fcs_out = fcs;
     return true;
 }
-// Executed by ONE workgroup when the queue is complete: every Zstd entry that is >= 2 well-formed frames whose content
-// sizes add up to the entry's output is replaced by one entry per frame (thread = entry; the walk reads a few bytes per
-// frame).  Anything else stays as it is and is decoded by one wave, frame after frame.
-__device__ void zstd_split_queue(InflateJob* q, uint32_t* cnt, uint32_t cap) {
-    // the pre-split count is read ONCE for the workgroup: a wave that read it later would see frame entries another
-    // wave has reserved (atomicAdd below) but not yet written, and walk stale slots
-    __shared__ uint32_t s_split_n0;
-    if (threadIdx.x == 0) s_split_n0 = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t n0 = s_split_n0;
-    for (uint32_t j = threadIdx.x; j < n0 && j < cap; j += blockDim.x) {
+// k_zstd_split, one thread per queue entry, launched when the queue is complete (*n0_p = its length then, recorded by the
+// last workgroup of the kernel that filled it): every Zstd entry that is >= 2 well-formed frames whose content sizes add
+// up to the entry's output is replaced by one entry per frame (the walk reads a few bytes per frame).  Anything else stays
+// as it is and is decoded by one wave, frame after frame.  Threads only look at entries below *n0_p, so the entries other
+// threads append meanwhile are never walked.
+__global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt, const uint32_t* n0_p, uint32_t cap) {
+    const uint32_t n0 = *n0_p;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n0 || j >= cap) return;
+    {
         const InflateJob job = q[j];
-        if (job.codec != SB_CODEC_ZSTD) continue;
+        if (job.codec != SB_CODEC_ZSTD) return;
         uint32_t nf = 0, pos = 0, total = 0;
         bool ok = true;
         while (pos < job.csize) {
@@ -101,11 +100,11 @@ __device__ void zstd_split_queue(InflateJob* q, uint32_t* cnt, uint32_t cap) {
             total += fc;
             nf++;
         }
-        if (!ok || nf < 2 || total != job.out_len) continue;
+        if (!ok || nf < 2 || total != job.out_len) return;
         const uint32_t base = atomicAdd(cnt, nf);
         if (base + nf > cap) {   // no room: the entry keeps its frames
             atomicSub(cnt, nf);
-            continue;
+            return;
         }
         pos = 0;
         total = 0;
@@ -475,8 +474,9 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
 __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < a.n_pages) parse_page(a, p);
-    // queue A is complete when the last workgroup is done: its multi-frame Zstd entries become one entry per frame
-    if (last_workgroup_done(&a.job_counts[5])) zstd_split_queue(a.jobs_a, a.job_counts, a.job_cap_a);
+    // queue A is complete when the last workgroup is done: its length goes to job_counts[8] for k_zstd_split
+    if (last_workgroup_done(&a.job_counts[5]) && threadIdx.x == 0)
+        a.job_counts[8] = __hip_atomic_load(&a.job_counts[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // -------------------------------------------------------------------------------- inflate (LZ4)
@@ -1466,7 +1466,8 @@ __global__ void k_colscan(DecodeArgs a, uint64_t* col_values_len) {
     const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
     if (ci < a.n_cols) colscan_column(a, col_values_len, ci);
     // queue B is complete now (k_parse's deferred payloads + the value blocks queued above): split its multi-frame entries
-    if (!a.sizes_only && last_workgroup_done(&a.job_counts[6])) zstd_split_queue(a.jobs_b, a.job_counts + 1, a.job_cap_b);
+    if (!a.sizes_only && last_workgroup_done(&a.job_counts[6]) && threadIdx.x == 0)   // queue B is complete: its length for k_zstd_split
+        a.job_counts[9] = __hip_atomic_load(&a.job_counts[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // -------------------------------------------------------------------------------- expand
@@ -2053,10 +2054,11 @@ void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, cons
 
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 8 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
     {
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
+        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a);
     }
     {
         KScope k(ctx, K_INFLATE_A);
@@ -2073,6 +2075,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     if (any_binary) {  // (without binary columns the host knows every values_len itself)
         KScope k(ctx, K_COLSCAN);
         k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
+        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.job_counts + 9, a.job_cap_b);
     }
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
@@ -2096,8 +2099,9 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
 
 void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.job_counts, 0, 8 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
+    k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a);
     k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
     k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);

@@ -121,6 +121,8 @@ struct EncodeArgs {
     uint32_t lzc_chunk;             // chunk bytes of this call: LZC_CH (LZ4, Snappy) or ZPAR_CH (Zstd blocks, one wave each)
     int32_t lzc_codec;              // the Basic codec whose big blocks go chunk by chunk in this call (LZ4 / Zstd / Snappy)
     uint8_t* zpar_scratch;          // Zstd: encoder scratch of the chunk waves (ZPAR_WAVES x zstd_scratch_bytes(ZPAR_CH))
+    uint32_t pre_hashed;            // k_enc_bin_hash ran before the selector: the h64 arrays of adaptive binary pages are filled
+    uint32_t redo;                  // k_enc_select: second pass over the binary pages k_enc_bin_verify failed (no tags, exact count)
 };
 constexpr uint32_t ZPAR_CH = 16384;      // a Zstd frame's blocks when they are compressed by waves of their own
 constexpr uint32_t ZPAR_WAVES = 2048;
@@ -911,19 +913,35 @@ template <class GetU32>
 __device__ uint64_t enc_bp(GetU32 getv, uint64_t N, bool delta, uint8_t* dst, uint32_t* sA, uint32_t* sB,
                            uint32_t* s_w) {
     const int t = threadIdx.x;
-    __shared__ uint32_t s_nb[TILE_ROWS / 128], s_off[TILE_ROWS / 128 + 1];
+    constexpr int NB = TILE_ROWS / 128, K = TILE_ROWS / WG;
+    __shared__ uint32_t s_nb[NB], s_off[NB + 1], s_woff[NB + 1];
     uint64_t out_pos = 0;
+    uint32_t carry_prev = 0;            // the value before the tile (delta variant)
+    // the next tile's values are requested before the current tile is packed: one HBM round trip per tile is hidden
+    uint32_t nxt[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint64_t i = (uint64_t)t + (uint64_t)k * WG;
+        nxt[k] = i < N ? getv(i) : 0u;
+    }
     for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
         const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, N - cb);  // multiple of 128
         const uint32_t nblk = n / 128;
-        for (uint32_t i = t; i < n; i += WG) {
-            const uint32_t v = getv(cb + i);
-            sA[sidx((int)i)] = v;
-            uint32_t dv = v;
-            if (delta) dv = v - ((cb + i) ? getv(cb + i - 1) : 0u);
-            sB[sidx((int)i)] = dv;
+#pragma unroll
+        for (int k = 0; k < K; k++) sA[sidx(t + k * (int)WG)] = nxt[k];
+        if (cb + TILE_ROWS < N) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint64_t i = cb + TILE_ROWS + (uint64_t)t + (uint64_t)k * WG;
+                nxt[k] = i < N ? getv(i) : 0u;
+            }
         }
         __syncthreads();
+        const uint32_t* src = sA;
+        if (delta) {
+            for (uint32_t i = t; i < n; i += WG) sB[sidx((int)i)] = sA[sidx((int)i)] - (i ? sA[sidx((int)i - 1)] : carry_prev);
+            src = sB;
+        }
         // num_bits per block: 8 threads per block
         {
             const uint32_t blk = t >> 3, sub = t & 7;
@@ -936,39 +954,48 @@ __device__ uint64_t enc_bp(GetU32 getv, uint64_t N, bool delta, uint8_t* dst, ui
             if (sub == 0 && blk < nblk) s_nb[blk] = acc ? 32 - __clz(acc) : 0;
         }
         __syncthreads();
-        if (t == 0) {
-            uint32_t o = 0;
-            for (uint32_t b = 0; b < nblk; b++) {
-                s_off[b] = o;
-                o += 1 + 16 * s_nb[b];
+        if (t < 64) {   // byte offset and first output word of every block (one wave scan)
+            const uint32_t nb = (uint32_t)t < nblk ? s_nb[t] : 0u;
+            const uint32_t by = (uint32_t)t < nblk ? 1 + 16 * nb : 0u;
+            const uint32_t ib = wave_incl_scan(by), iw = wave_incl_scan(4 * nb);
+            if ((uint32_t)t < nblk) {
+                s_off[t] = ib - by;
+                s_woff[t] = iw - 4 * nb;
             }
-            s_off[nblk] = o;
+            if ((uint32_t)t == nblk - 1) {
+                s_off[nblk] = ib;
+                s_woff[nblk] = iw;
+            }
         }
         __syncthreads();
-        // pack: 128 threads per block, one output word each (<= 128 words per block)
-        for (uint32_t b0 = 0; b0 < nblk; b0 += 2) {
-            const uint32_t blk = b0 + (t >> 7), wi = t & 127;
-            if (blk < nblk) {
-                const uint32_t nb = s_nb[blk];
-                uint8_t* bp = dst + out_pos + s_off[blk];
-                if (wi == 0) bp[0] = (uint8_t)nb;
-                if (wi < 4 * nb) {
-                    const uint32_t l = wi & 3, k = wi >> 2;  // word k of lane l
-                    const uint32_t lo_bit = 32 * k, hi_bit = 32 * k + 32;
-                    uint32_t word = 0;
-                    const uint32_t i0 = lo_bit / nb, i1 = min(31u, (hi_bit - 1) / nb);
-                    for (uint32_t i = i0; i <= i1; i++) {
-                        const uint32_t v = sB[sidx((int)(blk * 128 + 4 * i + l))];
-                        const uint32_t bitpos = i * nb;
-                        if (bitpos >= lo_bit)
-                            word |= v << (bitpos - lo_bit);
-                        else if (bitpos + nb > lo_bit)  // slot straddles in from the previous word
-                            word |= v >> (lo_bit - bitpos);
-                    }
-                    stu32(bp + 1 + 4 * wi, word);
-                }
+        // pack: one output word per thread and step over ALL words of the tile (a block of nb bits has 4 * nb words)
+        const uint32_t total_words = s_woff[nblk];
+        for (uint32_t j = t; j < total_words; j += WG) {
+            uint32_t lo = 0, hi = nblk;   // the block of word j: last b with s_woff[b] <= j
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_woff[mid] <= j)
+                    lo = mid;
+                else
+                    hi = mid;
             }
+            const uint32_t blk = lo, wi = j - s_woff[blk], nb = s_nb[blk];
+            const uint32_t l = wi & 3, k = wi >> 2;  // word k of lane l
+            const uint32_t lo_bit = 32 * k, hi_bit = 32 * k + 32;
+            uint32_t word = 0;
+            const uint32_t i0 = lo_bit / nb, i1 = min(31u, (hi_bit - 1) / nb);
+            for (uint32_t i = i0; i <= i1; i++) {
+                const uint32_t v = src[sidx((int)(blk * 128 + 4 * i + l))];
+                const uint32_t bitpos = i * nb;
+                if (bitpos >= lo_bit)
+                    word |= v << (bitpos - lo_bit);
+                else if (bitpos + nb > lo_bit)  // slot straddles in from the previous word
+                    word |= v >> (lo_bit - bitpos);
+            }
+            stu32(dst + out_pos + s_off[blk] + 1 + 4 * wi, word);
         }
+        if ((uint32_t)t < nblk) dst[out_pos + s_off[t]] = (uint8_t)s_nb[t];
+        carry_prev = sA[sidx((int)n - 1)];
         out_pos += s_off[nblk];
         __syncthreads();
     }
@@ -1230,9 +1257,9 @@ __device__ uint32_t lz4_compress_block_wg3(const uint8_t* src, uint32_t n, uint8
             stu32(slot + 4, anchor);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t sz = lz4_stitch_block(tmp, stride, chunk, src, n, nch, dst, lds);
     __syncthreads();
     return sz;
@@ -1385,7 +1412,10 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
         for (uint64_t i = t; i < slots; i += WG) table.st((uint32_t)i, EMPTY);
         if (t == 0) s_keys = 0;
         __syncthreads();
-        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // (fences between the phases of a page kernel are WORKGROUP scope: one workgroup owns the page and runs on one CU,
+        // whose waves share the vector L1; an agent-scope release / acquire writes back and invalidates L2 — ~100 us per
+        // fence once the chip is busy, measured on k_enc_bin_hash: 5.8 ms with, 0.5 ms without)
+        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const uint32_t mask = (uint32_t)(slots - 1);
         bool overflow = false;
         // phase 1: insert; the slot of a key ends up holding the smallest row that carries it.  The slot a row
@@ -1454,7 +1484,7 @@ __device__ uint32_t dict_build(KeyOps ko, uint64_t N, uint32_t* aux, uint64_t au
         __syncthreads();
         STL(21);
         if (overflow) continue;
-        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         // phase 2: F[i] = first row of row i's key (a key never leaves its slot)
         for (uint64_t i = t; i < N; i += WG) {
             const uint32_t h = gld32(F + i);
@@ -1633,10 +1663,11 @@ __device__ __forceinline__ uint64_t bin_hash_lds(l32p l, uint32_t b, uint32_t e)
 // offsets -> bytes (3-4 dependent HBM round trips per 4 rows, 0.49 ms per 64 Ki-row page) the workgroup streams the
 // bytes of a tile of rows into LDS with coalesced 16-byte loads and hashes from there (two round trips per ~3000 rows).
 template <class O>
-__device__ void bin_hash_rows_staged(const BinKeys<O>& bk, uint64_t N, uint64_t values_len, uint64_t* h64, uint32_t* lds, uint32_t lds_bytes) {
+__device__ void bin_hash_rows_staged(const BinKeys<O>& bk, uint64_t N, uint64_t values_len, uint64_t* h64, uint32_t* lds, uint32_t lds_bytes,
+                                     uint64_t row_begin = 0, bool read_back = true) {   // rows [row_begin, N); read_back: the caller reads h64 in this kernel
     const uint32_t t = threadIdx.x;
     const uint32_t cap = lds_bytes - 16;
-    uint64_t r0 = 0;
+    uint64_t r0 = row_begin;
     while (r0 < N) {
         uint64_t R = min((uint64_t)4096, N - r0);
         const uint64_t b0 = bk.beg(r0);
@@ -1671,8 +1702,10 @@ __device__ void bin_hash_rows_staged(const BinKeys<O>& bk, uint64_t N, uint64_t 
         r0 += R;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (read_back) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
 }
 template <class O>
 __device__ void bin_hash_rows(const BinKeys<O>& bk, uint64_t N, uint64_t values_len, uint64_t* h64) {
@@ -1692,8 +1725,8 @@ __device__ void bin_hash_rows(const BinKeys<O>& bk, uint64_t N, uint64_t values_
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 // statistics over hashed rows (choose_bin): key equality = hash equality
 template <class O>
@@ -1775,7 +1808,34 @@ struct SelScratch {
     uint32_t* gtab;      // HBM table for the distinct count (may be null)
     uint64_t gslots;
     uint32_t lds_slots = SEL_LDS_SLOTS;  // slots of lds_tab (a power of two)
+    // binary pages (hashed rows): the distinct count keeps 32-bit tags in the LDS slots (no HBM access per probe) and notes
+    // the slot of every row in slot16 (HBM) — the dictionary builder starts from there (bin_dict_handover); *tagged = 1 when
+    // the count was taken that way and the table holds the smallest row of every class
+    uint16_t* slot16 = nullptr;
+    uint32_t* tagged = nullptr;
 };
+
+// ---- hand-over of a binary page's dictionary from the selector to the builder (aux area of the page, words) -------------
+constexpr uint32_t BH_MAGIC = 0x48444231u;       // a dictionary was handed over (and the tag table counted the page's keys)
+constexpr uint32_t BH_TAGS_USED = 0x48444230u;   // the tag table counted the page's keys, the page is not a Dict page
+constexpr uint32_t SB_WRITE_DEBUG_VERIFY_FAIL_BIT = 1u << 30;   // (sb_write_options.flags, tests) k_enc_bin_verify fails every page
+constexpr uint32_t BH_W_MAGIC = 0, BH_W_D = 1, BH_W_BAD = 2, BH_W_ID16 = 16;
+constexpr uint32_t BH_SLOTS = 12288;                                  // tag slots (3/4 of BIN_LDS_SLOTS: the last quarter is the
+                                                                      // hand-over's bitmap + prefix); up to 5/8 of them hold keys
+constexpr uint32_t BH_W_REP16 = BH_W_ID16 + BH_SLOTS / 2;             // id16[BH_SLOTS] as u16
+constexpr uint32_t BH_W_FIRSTS = BH_W_REP16 + BH_SLOTS / 2;           // rep16[BH_SLOTS] as u16: smallest row of the class
+constexpr uint32_t BH_W_SLOT16 = BH_W_FIRSTS + BH_SLOTS;              // firsts[<= BH_SLOTS]
+__host__ __device__ __forceinline__ uint64_t bh_table_slots(uint64_t N) {
+    uint64_t M = 64;
+    while (M < 2 * N) M <<= 1;
+    return M;
+}
+// the fixed tables + slot16 sit in [0, M) of the aux area, the LZ4 scratch of the index block in [M, M + 2N), idx in the last N words
+__host__ __device__ __forceinline__ bool bh_fits(uint64_t N, uint64_t aux_bytes) {
+    const uint64_t M = bh_table_slots(N);
+    return N >= 2048 && N <= 65536 && BH_W_SLOT16 + (N + 1) / 2 + 4 <= M && aux_bytes / 4 >= M + 3 * N;
+}
+constexpr uint32_t SEL_TAG_FAIL = 0xFFFFFFFEu;
 
 // row-index hash-set operations over canonical primitive keys
 template <int W, class Key>
@@ -1807,7 +1867,7 @@ __device__ uint32_t distinct_count(Ops ops, uint64_t N, uint32_t limit, const Se
             s_wsum = 0;
         }
         __syncthreads();
-        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (tier == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const uint32_t mask = (uint32_t)(slots - 1);
         bool overflow = false;
         for (uint64_t base = 0; base < N; base += WG * 16) {
@@ -1869,6 +1929,204 @@ __device__ uint32_t distinct_count(Ops ops, uint64_t N, uint32_t limit, const Se
         }
     }
     return limit + 1;
+}
+
+// The distinct count of a binary page over its 64-bit row hashes with NO HBM access inside the probe loop: a slot holds a
+// 32-bit tag (hash bits 32..63; the home slot comes from bits 0..31), a probe compares tags, and the slot of every row goes
+// to sc.slot16.  Equal strings always meet in one slot (linear probing without deletions); two DIFFERENT hashes with one
+// tag that meet in a probe sequence would share a slot — about 4e-7 per 64 Ki-row page — and so would two different
+// strings with one 64-bit hash: k_enc_bin_verify compares the string of EVERY row with the smallest row of its slot
+// afterwards, and a page that fails is selected again without tags (k_enc_select's redo pass), so the count a decision
+// rests on is exact.  On return the table holds the smallest row of every class (rep16 in the aux area as well).
+__device__ __forceinline__ uint32_t bh_home(uint64_t k) { return (uint32_t)(((uint64_t)(uint32_t)k * BH_SLOTS) >> 32); }
+template <class Ops>
+__device__ uint32_t distinct_count_tags(Ops ops, uint64_t N, uint32_t limit, const SelScratch& sc, uint64_t* weight_sum, uint32_t* aux) {
+    const int t = threadIdx.x;
+    __shared__ uint32_t s_tcnt;
+    __shared__ unsigned long long s_twsum;
+    uint32_t* tab = sc.lds_tab;
+    constexpr uint32_t cap = BH_SLOTS / 8 * 5;   // (WG * 16 rows between two checks never fill the other 3/8)
+    static_assert(BH_SLOTS - BH_SLOTS / 8 * 5 > WG * 16 + 1, "a step could fill the table");
+    for (uint32_t i = t; i < BH_SLOTS; i += WG) tab[i] = SEL_EMPTY;
+    if (t == 0) {
+        s_tcnt = 0;
+        s_twsum = 0;
+    }
+    __syncthreads();
+    uint16_t* slot16 = sc.slot16;
+    STL(47);
+    constexpr int U = 16;   // rows per thread and step; the keys of the next step are requested before this step's probes
+    uint64_t kn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint64_t i = (uint64_t)u * WG + t;
+        kn[u] = ops.key64(i < N ? i : 0);
+    }
+    for (uint64_t base = 0; base < N; base += (uint64_t)WG * U) {
+        uint32_t hh[U], tg[U];
+        uint32_t pend = 0, newk = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = base + (uint64_t)u * WG + t;
+            if (i < N) pend |= 1u << u;
+            hh[u] = bh_home(kn[u]);
+            tg[u] = (uint32_t)(kn[u] >> 32);
+            if (tg[u] == SEL_EMPTY) tg[u] = 0xFFFFFFFEu;
+        }
+        const uint64_t nbase = base + (uint64_t)WG * U;
+        if (nbase < N) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = nbase + (uint64_t)u * WG + t;
+                kn[u] = ops.key64(i < N ? i : 0);
+            }
+        }
+        // probes in rounds: the slot reads of all unsettled rows are issued together
+        while (pend) {
+            uint32_t cur[U];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if ((pend >> u) & 1) cur[u] = tab[hh[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!((pend >> u) & 1)) continue;
+                uint32_t c = cur[u];
+                if (c == SEL_EMPTY) {
+                    c = atomicCAS(&tab[hh[u]], SEL_EMPTY, tg[u]);
+                    if (c == SEL_EMPTY) {
+                        newk++;
+                        c = tg[u];
+                    }
+                }
+                if (c == tg[u])
+                    pend &= ~(1u << u);
+                else
+                    hh[u] = hh[u] + 1 == BH_SLOTS ? 0u : hh[u] + 1;
+            }
+        }
+        if (newk) atomicAdd(&s_tcnt, newk);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = base + (uint64_t)u * WG + t;
+            if (i < N) *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)hh[u];
+        }
+        __syncthreads();
+        const uint32_t c = s_tcnt;
+        if (c > limit) return c;
+        if (c > cap) return SEL_TAG_FAIL;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    STL(48);
+    // the smallest row of every class (the tags are not needed any more): its length is the class's weight, the verify
+    // kernel compares every row with it, the hand-over starts from it
+    for (uint32_t i = t; i < BH_SLOTS; i += WG) tab[i] = SEL_EMPTY;
+    __syncthreads();
+    for (uint64_t base = (uint64_t)t * 2; base < N; base += (uint64_t)WG * 2 * 8) {
+        uint32_t sl[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint64_t i = base + (uint64_t)u * WG * 2;
+            sl[u] = i + 1 < N ? gld32((const uint32_t*)(slot16 + i)) : (i < N ? (uint32_t)ldu16((const uint8_t*)(slot16 + i)) | 0xFFFF0000u : 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t i = (uint32_t)(base + (uint64_t)u * WG * 2);
+            const uint32_t s0 = sl[u] & 0xFFFFu, s1 = sl[u] >> 16;
+            if (s0 != 0xFFFFu && i < tab[s0]) atomicMin(&tab[s0], i);
+            if (s1 != 0xFFFFu && i + 1 < tab[s1]) atomicMin(&tab[s1], i + 1);
+        }
+    }
+    __syncthreads();
+    unsigned long long wsum = 0;
+    uint16_t* rep16 = (uint16_t*)(aux + BH_W_REP16);
+    for (uint32_t sl = t; sl < BH_SLOTS; sl += WG * 8) {   // (eight independent offset pairs in flight)
+        uint32_t wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t q = sl + (uint32_t)u * WG;
+            const uint32_t cur = q < BH_SLOTS ? tab[q] : SEL_EMPTY;
+            wv[u] = cur != SEL_EMPTY ? ops.weight(cur) : 0u;
+            if (q < BH_SLOTS) *(__attribute__((address_space(1))) uint16_t*)(rep16 + q) = (uint16_t)cur;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) wsum += wv[u];
+    }
+    if (wsum) atomicAdd(&s_twsum, wsum);
+    __syncthreads();
+    STL(49);
+    if (weight_sum) *weight_sum = s_twsum;
+    return s_tcnt;
+}
+
+// Dictionary ids in first-occurrence order from the selector's table (see distinct_count_tags), left in the page's aux area
+// for the builder: id16[slot], firsts[id], D.  tab: BH_SLOTS words (smallest row per class); rank: 4096 words of LDS.
+template <class O>
+__device__ void bin_dict_handover(const BinKeys<O>& bk, uint64_t N, uint32_t* tab, uint32_t* rank, uint32_t* s4, uint32_t* aux) {
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint16_t* slot16 = (const uint16_t*)(aux + BH_W_SLOT16);
+    // first KEYED row per slot (row 0 and the valid rows intern keys, binary/dict.rs:55-93); without a validity bitmap
+    // that is the smallest row the table already holds
+    if (bk.vv.bits) {
+        for (uint32_t sl = t; sl < BH_SLOTS; sl += WG) tab[sl] = SEL_EMPTY;
+        __syncthreads();
+        for (uint64_t base = t; base < N; base += (uint64_t)WG * 8) {
+            uint32_t sl[8];
+            bool kd[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG;
+                sl[u] = i < N ? ldu16((const uint8_t*)(slot16 + i)) : 0u;
+                kd[u] = i < N && bk.keyed(i);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = (uint32_t)(base + (uint64_t)u * WG);
+                if (kd[u] && i < tab[sl[u]]) atomicMin(&tab[sl[u]], i);
+            }
+        }
+    }
+    for (uint32_t k = t; k < 4096; k += WG) rank[k] = 0;
+    __syncthreads();
+    // bitmap of the first rows, then the exclusive popcount prefix of its 2048 words (8 words per thread)
+    for (uint32_t sl = t; sl < BH_SLOTS; sl += WG) {
+        const uint32_t r = tab[sl];
+        if (r != SEL_EMPTY) atomicOr(&rank[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) mine += (uint32_t)__popc(rank[t * 8 + k]);
+    const uint32_t incl = wave_incl_scan(mine);
+    if (lane == 63) s4[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t pw = 0; pw < w; pw++) run += s4[pw];
+    const uint32_t D = s4[0] + s4[1] + s4[2] + s4[3];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        rank[2048 + t * 8 + k] = run;
+        run += (uint32_t)__popc(rank[t * 8 + k]);
+    }
+    __syncthreads();
+    uint16_t* id16 = (uint16_t*)(aux + BH_W_ID16);
+    uint32_t* firsts = aux + BH_W_FIRSTS;
+    for (uint32_t sl = t; sl < BH_SLOTS; sl += WG) {
+        const uint32_t r = tab[sl];
+        uint32_t id = 0xFFFFu;
+        if (r != SEL_EMPTY) {
+            id = rank[2048 + (r >> 5)] + (uint32_t)__popc(rank[r >> 5] & ((1u << (r & 31)) - 1u));
+            gst32(firsts + id, r);
+        }
+        *(__attribute__((address_space(1))) uint16_t*)(id16 + sl) = (uint16_t)id;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (t == 0) {
+        gst32(aux + BH_W_D, D);
+        gst32(aux + BH_W_BAD, 0u);
+        gst32(aux + BH_W_MAGIC, BH_MAGIC);
+    }
 }
 
 // Boyer-Moore majority candidate (row index or SEL_EMPTY) with an exact count of its key.
@@ -2497,7 +2755,15 @@ __device__ uint32_t choose_bin_impl(const Ops& ops, const BinKeys<O>& bk, uint64
             if (N >= 3) {
                 const uint32_t limit = (uint32_t)((N - 1) / 3);
                 uint64_t tus = 0;
-                const uint32_t uq = distinct_count(ops, N, limit, sc, &tus);
+                uint32_t uq = SEL_TAG_FAIL;
+                if constexpr (has_key64<Ops>::value) {
+                    if (sc.slot16 && sc.tagged && sc.lds_slots >= BH_SLOTS + 4096 && N <= 65536) {
+                        uq = distinct_count_tags(ops, N, limit, sc, &tus, sc.gtab);
+                        if (threadIdx.x == 0) *sc.tagged = uq != SEL_TAG_FAIL && uq <= limit ? 1u : 0u;
+                        __syncthreads();
+                    }
+                }
+                if (uq == SEL_TAG_FAIL) uq = distinct_count(ops, N, limit, sc, &tus);
                 STL(44);
                 if ((uint64_t)uq * 3 < N) {
                     uint64_t after = tus + N * (uint64_t)(bits_needed(uq) / 8);
@@ -2517,13 +2783,14 @@ __device__ uint32_t choose_bin_impl(const Ops& ops, const BinKeys<O>& bk, uint64
 // h64 (one u64 per row, or null): when present the statistics run over hashed rows (bin_hash_rows)
 template <class O>
 __device__ uint32_t choose_bin(const BinKeys<O>& bk, uint64_t N, uint64_t values_len_total, const SelectOpts& o,
-                               const SelScratch& sc, uint64_t* h64 = nullptr, uint64_t values_len = 0) {
+                               const SelScratch& sc, uint64_t* h64 = nullptr, uint64_t values_len = 0, bool pre_hashed = false) {
     auto forbidden = [&](uint32_t c) { return (o.forbidden >> c) & 1u; };
     if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
     if (!o.has_ratio || N == 0) return o.default_codec;
     if (h64) {
         STL(40);
-        if (sc.lds_slots >= 4096)   // (the table is not in use yet: its LDS stages the value bytes)
+        if (pre_hashed) {   // k_enc_bin_hash filled h64 for this launch
+        } else if (sc.lds_slots >= 4096)   // (the table is not in use yet: its LDS stages the value bytes)
             bin_hash_rows_staged<O>(bk, N, values_len, h64, sc.lds_tab, sc.lds_slots * 4);
         else
             bin_hash_rows<O>(bk, N, values_len, h64);
@@ -2724,6 +2991,65 @@ __device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const E
     return 9 + body;
 }
 
+// The builder's side of bin_dict_handover: the selector of this launch left id16[slot], firsts[id], D and the slot of every
+// row in the aux area; what remains is the index of every row — a keyed row takes its key's id, a null row repeats the
+// index before it (binary/dict.rs:55-93) — one streaming pass with the id table in LDS.
+template <class O>
+__device__ uint32_t bin_dict_from_handover(const BinKeys<O>& bk, uint64_t N, uint32_t* aux, uint32_t** idx_out, uint32_t** firsts_out,
+                                           uint32_t* sA, uint32_t* sB, uint32_t* lds_id16 /* BH_SLOTS / 2 words */, uint32_t* s_w) {
+    const uint32_t t = threadIdx.x;
+    const uint64_t M = bh_table_slots(N);
+    for (uint32_t k = t; k < BH_SLOTS / 2; k += WG) lds_id16[k] = gld32(aux + BH_W_ID16 + k);
+    __syncthreads();
+    const uint16_t* id16 = (const uint16_t*)lds_id16;
+    const uint16_t* slot16 = (const uint16_t*)(aux + BH_W_SLOT16);
+    uint32_t* idx = aux + M + 2 * N;
+    if (!bk.vv.bits) {   // no validity bitmap: every row is keyed, the pass is one stream (16 rows per thread in flight)
+        for (uint64_t base = (uint64_t)t * 2; base < N; base += (uint64_t)WG * 2 * 8) {
+            uint32_t sl[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG * 2;
+                sl[u] = i + 1 < N ? gld32((const uint32_t*)(slot16 + i)) : (i < N ? (uint32_t)ldu16((const uint8_t*)(slot16 + i)) : 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG * 2;
+                if (i + 1 < N) {
+                    gst64((uint64_t*)(idx + i), (uint64_t)id16[sl[u] & 0xFFFFu] | ((uint64_t)id16[sl[u] >> 16] << 32));
+                } else if (i < N) {
+                    gst32(idx + i, (uint32_t)id16[sl[u] & 0xFFFFu]);
+                }
+            }
+        }
+        __syncthreads();
+        *idx_out = idx;
+        *firsts_out = aux + BH_W_FIRSTS;
+        return gld32(aux + BH_W_D);
+    }
+    uint32_t carry_id = 0;
+    for (uint64_t cb = 0; cb < N; cb += TILE_ROWS) {
+        const uint32_t n = (uint32_t)min((uint64_t)TILE_ROWS, N - cb);
+        for (uint32_t i = t; i < TILE_ROWS; i += WG) {
+            const bool kd = i < n && bk.keyed(cb + i);
+            sB[sidx((int)i)] = kd ? i + 1 : 0;
+            sA[sidx((int)i)] = kd ? (uint32_t)id16[ldu16((const uint8_t*)(slot16 + cb + i))] : 0u;
+        }
+        __syncthreads();
+        tile_incl_scan_max(sB, s_w);
+        for (uint32_t i = t; i < n; i += WG) {
+            const uint32_t lk = sB[sidx((int)i)];
+            gst32(idx + cb + i, lk ? sA[sidx((int)lk - 1)] : carry_id);
+        }
+        const uint32_t lkl = sB[sidx((int)n - 1)];
+        if (lkl) carry_id = sA[sidx((int)lkl - 1)];
+        __syncthreads();
+    }
+    *idx_out = idx;
+    *firsts_out = aux + BH_W_FIRSTS;
+    return gld32(aux + BH_W_D);
+}
+
 template <class O, int CODEC>
 __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page,
                                      uint8_t* blk, const ValidView& vv, uint32_t* sA, uint32_t* sB, uint32_t* sC,
@@ -2759,7 +3085,13 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
         uint32_t D;
         STL(20);
-        if (p.h64_off != ~0ull) {   // hashed rows: computed by the selector of this call, or here when the codec was forced
+        // the selector of this launch built the dictionary (tables in the aux area) and k_enc_bin_verify compared the strings
+        const bool handed = p.codec == CODEC_ON_DEVICE && p.h64_off != ~0ull && lds_slots >= BH_SLOTS && bh_fits(N, p.aux_bytes) &&
+                            gld32(aux + BH_W_MAGIC) == BH_MAGIC && gld32(aux + BH_W_BAD) == 0;
+        if (handed) {
+            D = bin_dict_from_handover<O>(ko, N, aux, &idx, &firsts, sA, sB, sC, s_w);
+            STL(27);
+        } else if (p.h64_off != ~0ull) {   // hashed rows: computed by the selector of this call, or here when the codec was forced
             uint64_t* h64 = (uint64_t*)(a.scratch + p.h64_off);
             if (p.codec != CODEC_ON_DEVICE) {
                 if (lds_slots >= 4096)
@@ -2827,15 +3159,45 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             }
             __syncthreads();
             const uint32_t tot = tile_incl_scan(sA, s_w);
-            for (uint32_t i = threadIdx.x; i < n; i += WG) {
-                const uint64_t r = gld32(firsts + kb + i);
-                const uint64_t b = ko.beg(r), e = ko.beg(r + 1);
-                uint8_t* d = q + pos + sA[sidx((int)i)] - (e - b) - 8;
-                stu64(d, e - b);
-                uint64_t k = 0;
-                for (; k + 16 <= e - b; k += 16) stu128(d + 8 + k, ldu128(c.values + b + k));   // (unaligned 16-byte moves)
-                for (; k + 8 <= e - b; k += 8) stu64(d + 8 + k, ldu64(c.values + b + k));
-                for (; k < e - b; k++) *(gptr)(d + 8 + k) = ldu8(c.values + b + k);
+            for (uint32_t i0 = threadIdx.x; i0 < n; i0 += WG * 4) {   // four entries per thread in flight (first row -> offsets -> bytes)
+                uint64_t rr[4], bb[4], ee[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * WG;
+                    rr[u] = i < n ? gld32(firsts + kb + i) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    bb[u] = ko.beg(rr[u]);
+                    ee[u] = ko.beg(rr[u] + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * WG;
+                    if (i >= n) continue;
+                    const uint64_t b = bb[u], e = ee[u];
+                    uint8_t* d = q + pos + sA[sidx((int)i)] - (e - b) - 8;
+                    stu64(d, e - b);
+                    if (e - b <= 32 && b + 32 <= c.values_len) {   // the common short string: two unconditional 16-byte loads
+                        const u32x4 v0 = ldu128(c.values + b), v1 = ldu128(c.values + b + 16);
+                        uint64_t w[4] = {(uint64_t)v0.x | ((uint64_t)v0.y << 32), (uint64_t)v0.z | ((uint64_t)v0.w << 32),
+                                         (uint64_t)v1.x | ((uint64_t)v1.y << 32), (uint64_t)v1.z | ((uint64_t)v1.w << 32)};
+                        const uint32_t len = (uint32_t)(e - b), full = len >> 3;
+#pragma unroll
+                        for (uint32_t q8 = 0; q8 < 4; q8++)
+                            if (q8 < full) stu64(d + 8 + 8 * q8, w[q8]);
+                        uint64_t rest = full == 0 ? w[0] : full == 1 ? w[1] : full == 2 ? w[2] : full == 3 ? w[3] : 0ull;
+                        for (uint32_t k = full * 8; k < len; k++) {
+                            *(gptr)(d + 8 + k) = (uint8_t)rest;
+                            rest >>= 8;
+                        }
+                        continue;
+                    }
+                    uint64_t k = 0;
+                    for (; k + 16 <= e - b; k += 16) stu128(d + 8 + k, ldu128(c.values + b + k));   // (unaligned 16-byte moves)
+                    for (; k + 8 <= e - b; k += 8) stu64(d + 8 + k, ldu64(c.values + b + k));
+                    for (; k < e - b; k++) *(gptr)(d + 8 + k) = ldu8(c.values + b + k);
+                }
             }
             pos += tot;
             __syncthreads();
@@ -2859,6 +3221,81 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
 // Binary pages hash strings: a probe that misses the LDS tier costs a random HBM access per row (13 GB of traffic for
 // 1.15 GB of C3 input when the table sat in HBM), so their LDS table is 16 Ki slots (~10 000 distinct strings per page).
 constexpr uint32_t BIN_LDS_SLOTS = 16384;
+
+// The 64-bit row hashes of adaptive binary pages, TILE-parallel: hashing a page is independent work per row, and inside the
+// page kernels it was a serial chain of ~20 staged tiles per page (0.37 ms of a page's 0.93 ms in the selector even alone on
+// a CU).  One workgroup per (page, BH_ROWS rows): the tile's bytes are staged in LDS with coalesced 16-byte loads and hashed
+// from there; the selector and the dictionary builder then start from h64.
+constexpr uint32_t BH_ROWS = 2048, BH_LDS_WORDS = 10240;   // 40 KiB of staging: 4 workgroups per CU
+__global__ void __launch_bounds__(WG) k_enc_bin_hash(EncodeArgs a) {
+    __shared__ uint32_t lds[BH_LDS_WORDS];
+    const uint32_t page = blockIdx.x + a.page_base;
+    const EncPage p = get_page(a, page);
+    if (p.codec != CODEC_ON_DEVICE || p.h64_off == ~0ull) return;
+    const uint64_t r0 = (uint64_t)blockIdx.y * BH_ROWS;
+    if (r0 >= p.rows) return;
+    const EncCol c = get_col(a, p.col);
+    const uint64_t r1 = min(p.rows, r0 + BH_ROWS);
+    uint64_t* h64 = (uint64_t*)(a.scratch + p.h64_off);
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    if (c.ptype == SB_TYPE_BINARY) {
+        BinKeys<int32_t> bk{c.offsets + p.row0 * 4, c.values, vv};
+        bin_hash_rows_staged<int32_t>(bk, r1, c.values_len, h64, lds, BH_LDS_WORDS * 4, r0, false);
+    } else if (c.ptype == SB_TYPE_LARGE_BINARY) {
+        BinKeys<int64_t> bk{c.offsets + p.row0 * 8, c.values, vv};
+        bin_hash_rows_staged<int64_t>(bk, r1, c.values_len, h64, lds, BH_LDS_WORDS * 4, r0, false);
+    }
+}
+
+// Binary pages whose keys the selector counted with its tag table (distinct_count_tags): the string of EVERY row against
+// the smallest row of its slot, TILE-parallel (one workgroup per (page, BH_ROWS rows)).  Slots were formed by 32-bit tags
+// of 64-bit hashes; a slot that holds two different strings (a tag or hash collision: never seen) sets the page's BAD
+// word, and the page is selected again without tags (k_enc_select, redo pass) and built by the exact builder.
+__global__ void __launch_bounds__(WG) k_enc_bin_verify(EncodeArgs a) {
+    const uint32_t page = blockIdx.x + a.page_base;
+    const EncPage p = get_page(a, page);
+    if (p.codec != CODEC_ON_DEVICE || p.h64_off == ~0ull || !p.aux_bytes) return;
+    const uint64_t r0 = (uint64_t)blockIdx.y * BH_ROWS;
+    if (r0 >= p.rows) return;
+    uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
+    if (!bh_fits(p.rows, p.aux_bytes)) return;
+    const uint32_t magic = gld32(aux + BH_W_MAGIC);
+    if (magic != BH_MAGIC && magic != BH_TAGS_USED) return;
+    if (a.flags & SB_WRITE_DEBUG_VERIFY_FAIL_BIT) {
+        if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(aux + BH_W_BAD, 1u);
+        return;
+    }
+    const EncCol c = get_col(a, p.col);
+    const uint64_t r1 = min(p.rows, r0 + BH_ROWS);
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    const uint16_t* slot16 = (const uint16_t*)(aux + BH_W_SLOT16);
+    const uint16_t* rep16 = (const uint16_t*)(aux + BH_W_REP16);
+    const uint64_t* h64 = (const uint64_t*)(a.scratch + p.h64_off);
+    bool ok = true;
+    auto body = [&](auto keys) {
+        constexpr int VU = 8;
+        for (uint64_t base = r0 + threadIdx.x; base < r1; base += (uint64_t)WG * VU) {
+            uint32_t f[VU];
+            uint64_t row[VU];
+#pragma unroll
+            for (int u = 0; u < VU; u++) {
+                row[u] = base + (uint64_t)u * WG;
+                f[u] = EMPTY;
+                if (row[u] < r1) {
+                    f[u] = ldu16((const uint8_t*)(rep16 + ldu16((const uint8_t*)(slot16 + row[u]))));
+                    if (f[u] == (uint32_t)row[u]) f[u] = EMPTY;   // the class's own representative
+                }
+            }
+            if (!keys.template exact_batch<VU>(f, row)) ok = false;
+        }
+    };
+    if (c.ptype == SB_TYPE_BINARY)
+        body(BinKeysHashed<int32_t>{BinKeys<int32_t>{c.offsets + p.row0 * 4, c.values, vv}, h64, c.values_len});
+    else
+        body(BinKeysHashed<int64_t>{BinKeys<int64_t>{c.offsets + p.row0 * 8, c.values, vv}, h64, c.values_len});
+    if (!ok) atomicOr(aux + BH_W_BAD, 1u);
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     constexpr uint32_t LDS_SLOTS = KIND < 0 ? BIN_LDS_SLOTS : SEL_LDS_SLOTS;
@@ -2867,6 +3304,8 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     // sample area, also the streaming scratch of choose_prim: 1 KB validity words + 4 x 128 keys
     constexpr int SMP = SAMPLE_CAP * ((KIND > 0 ? KIND : 1) + 1) + 16, STR = 1024 + 4 * 96 * (KIND == 8 ? 8 : 4) + 4 * 96;
     __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SMP > STR ? SMP : STR];
+    static_assert(KIND >= 0 || LDS_SLOTS >= BH_SLOTS + 4096, "tag slots + the hand-over's bitmap and prefix share lds_tab");
+    __shared__ uint32_t s_tagged;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     if (p.codec != CODEC_ON_DEVICE) return;
@@ -2894,14 +3333,58 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
         sc.gslots = M;
     }
     uint32_t codec;
+    bool handover = false;
+    if constexpr (KIND < 0) {   // the dictionary of a Dict page is handed to the builder (bin_dict_handover) when its tables fit
+        if (threadIdx.x == 0) s_tagged = 0;
+        const bool fits = p.h64_off != ~0ull && page < a.n_pages && sc.gtab && bh_fits(N, p.aux_bytes) && !((a.forbidden >> SB_CODEC_DICT) & 1);
+        if (a.redo) {   // second pass: only the pages k_enc_bin_verify failed, counted exactly this time
+            if (!fits) return;
+            const uint32_t magic = gld32(sc.gtab + BH_W_MAGIC);
+            if ((magic != BH_MAGIC && magic != BH_TAGS_USED) || gld32(sc.gtab + BH_W_BAD) == 0) return;
+            if (threadIdx.x == 0) {   // the first pass's choice is withdrawn
+                const uint32_t old = (uint32_t)a.codecs[page];
+                atomicSub(&a.codec_counts[old & 31], 1u);
+                if (old == SB_CODEC_FREQ) atomicSub(a.freq_count, 1u);
+            }
+        } else if (fits) {
+            handover = true;
+            sc.slot16 = (uint16_t*)(sc.gtab + BH_W_SLOT16);
+            sc.tagged = &s_tagged;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && sc.gtab && p.aux_bytes >= 64) {
+            gst32(sc.gtab + BH_W_MAGIC, 0u);
+            gst32(sc.gtab + BH_W_BAD, 0u);
+        }
+        __syncthreads();
+    } else {
+        if (a.redo) return;
+    }
     if constexpr (KIND == 0) {
         codec = choose_bool(c.values, c.values_bit_offset + p.row0, vv, N, so, sc);
     } else if constexpr (KIND == -4) {
         BinKeys<int32_t> bk{c.offsets + p.row0 * 4, c.values, vv};
-        codec = choose_bin<int32_t>(bk, N, c.values_len_total, so, sc, p.h64_off != ~0ull ? (uint64_t*)(a.scratch + p.h64_off) : nullptr, c.values_len);
+        codec = choose_bin<int32_t>(bk, N, c.values_len_total, so, sc, p.h64_off != ~0ull ? (uint64_t*)(a.scratch + p.h64_off) : nullptr, c.values_len,
+                                    a.pre_hashed != 0);
+        __syncthreads();
+        if (handover && s_tagged) {
+            if (codec == SB_CODEC_DICT)
+                bin_dict_handover<int32_t>(bk, N, lds_tab, lds_tab + BH_SLOTS, s_misc, sc.gtab);
+            else if (threadIdx.x == 0)
+                gst32(sc.gtab + BH_W_MAGIC, BH_TAGS_USED);
+        }
+        STL(46);
     } else if constexpr (KIND == -8) {
         BinKeys<int64_t> bk{c.offsets + p.row0 * 8, c.values, vv};
-        codec = choose_bin<int64_t>(bk, N, c.values_len_total, so, sc, p.h64_off != ~0ull ? (uint64_t*)(a.scratch + p.h64_off) : nullptr, c.values_len);
+        codec = choose_bin<int64_t>(bk, N, c.values_len_total, so, sc, p.h64_off != ~0ull ? (uint64_t*)(a.scratch + p.h64_off) : nullptr, c.values_len,
+                                    a.pre_hashed != 0);
+        __syncthreads();
+        if (handover && s_tagged) {
+            if (codec == SB_CODEC_DICT)
+                bin_dict_handover<int64_t>(bk, N, lds_tab, lds_tab + BH_SLOTS, s_misc, sc.gtab);
+            else if (threadIdx.x == 0)
+                gst32(sc.gtab + BH_W_MAGIC, BH_TAGS_USED);
+        }
     } else {
         const uint8_t* vals = c.values + p.row0 * KIND;
         codec = choose_prim<KIND>([=](uint64_t i) { return ld_val<KIND>(vals + i * KIND); }, vv, N, c.nk, so, sc);
@@ -3042,7 +3525,10 @@ __global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODE
     // binary Dict pages: the table of first rows sits in LDS while the page has at most ~10 000 distinct strings.  It is
     // dead before the scans of the build start, so it shares the 3 * LW words of sA / sB / sC.
     constexpr uint32_t BIN_TABLE = (KIND < 0 && CODEC == SB_CODEC_DICT) ? BIN_LDS_SLOTS : 1;
-    constexpr int LDS_WORDS = 3 * LW > (int)BIN_TABLE ? 3 * LW : (int)BIN_TABLE;
+    // (a handed-over dictionary: sA, sB and behind them the id table of BH_SLOTS u16 entries, see bin_dict_from_handover)
+    constexpr int LDS_MIN = (KIND < 0 && CODEC == SB_CODEC_DICT) ? 2 * LW + (int)BH_SLOTS / 2 : 0;
+    constexpr int LDS_WORDS0 = 3 * LW > (int)BIN_TABLE ? 3 * LW : (int)BIN_TABLE;
+    constexpr int LDS_WORDS = LDS_WORDS0 > LDS_MIN ? LDS_WORDS0 : LDS_MIN;
     __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_WORDS];
     uint32_t *sA = lds, *sB = lds + LW, *sC = lds + 2 * LW;
     uint32_t* const s_bin_table = lds;
@@ -3312,10 +3798,10 @@ __device__ uint32_t freq_exact_top(KeyOps ko, uint64_t N, uint32_t* aux, uint64_
     uint32_t* cnt = aux + M;  // the builder's F array (one word per row) is free again
     for (uint32_t i = t; i < D; i += WG) cnt[i] = 0;
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     for (uint64_t i = t; i < N; i += WG) atomicAdd(&cnt[idx[i]], 1u);
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     unsigned long long best = 0;  // count << 32 | ~id: highest count, then the smallest id (= earliest first occurrence)
     for (uint32_t i = t; i < D; i += WG) {
         const unsigned long long c = ((unsigned long long)table_load(&cnt[i]) << 32) | (0xFFFFFFFFu - i);
@@ -4944,6 +5430,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     a.freq_count = (uint32_t*)(tb + o_freqcnt);
     a.codec_counts = (uint32_t*)(tb + o_freqcnt + 64);
     a.use_counts = 0;
+    a.pre_hashed = 0;
+    a.redo = 0;
     a.null_cols = 0;
     for (uint64_t i = 0; i < n; i++) a.null_cols |= cols[i].physical_type == SB_TYPE_NULL ? 1u : 0u;
     // one memset: page outputs (length 0 = not emitted), results, device-chosen codecs, the Freq page counter
@@ -4965,6 +5453,18 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     auto run_wave = [&](const EncodeArgs& aa_in, bool wave_adaptive, int32_t wave_codec, bool nested) -> int32_t {
         EncodeArgs aa = aa_in;
         aa.use_counts = wave_adaptive && !nested ? 1u : 0u;
+        aa.pre_hashed = 0;
+        aa.redo = 0;
+        if (wave_adaptive && !nested) {   // row hashes of the binary pages, tile-parallel, before their selector
+            bool any_bin = false;
+            for (int kd : kinds) any_bin |= kd < 0;
+            if (any_bin) {
+                KScope k(ctx, "k_enc_bin_hash");
+                const uint64_t max_rows = max_tiles * TILE_ROWS;
+                k_enc_bin_hash<<<dim3((uint32_t)P, (uint32_t)((max_rows + BH_ROWS - 1) / BH_ROWS)), WG, 0, s>>>(aa);
+                aa.pre_hashed = 1;
+            }
+        }
         if (wave_adaptive) {
             for (int kd : kinds) {
                 if (nested && (kd <= 0 || kd > 8)) continue;
@@ -5011,6 +5511,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 KScope k(ctx, nm);
                 enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(aa);
             }
+        }
+        if (aa.pre_hashed) {   // the dictionaries the binary selectors handed over: strings checked tile-parallel
+            KScope k(ctx, "k_enc_bin_verify");
+            const uint64_t max_rows = max_tiles * TILE_ROWS;
+            k_enc_bin_verify<<<dim3((uint32_t)P, (uint32_t)((max_rows + BH_ROWS - 1) / BH_ROWS)), WG, 0, s>>>(aa);
+            aa.redo = 1;   // pages that failed are selected again, exactly (workgroups of all other pages return at once)
+            for (int kd : kinds)
+                if (kd < 0) enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(aa);
+            aa.redo = 0;
         }
         const int32_t dc = opts->default_compression;
         const bool basic_comp = dc == SB_CODEC_LZ4 || dc == SB_CODEC_ZSTD || dc == SB_CODEC_SNAPPY;

@@ -60,3 +60,4 @@ class WriteOptions:
     force_index_codec: int = -1
     rng_seed: int = 42
     lz4_exact: bool = False   # SB_WRITE_LZ4_EXACT: LZ4 blocks byte-identical to LZ4_compress_default (slow serial parse)
+    debug_verify_fail: bool = False   # SB_WRITE_DEBUG_VERIFY_FAIL (tests): force the exact re-selection of hashed binary pages

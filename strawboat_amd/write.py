@@ -73,7 +73,7 @@ def options_c(opts: WriteOptions):
     o.force_codec = opts.force_codec
     o.force_index_codec = opts.force_index_codec
     o.rng_seed = opts.rng_seed
-    o.flags = N.SB_WRITE_LZ4_EXACT if opts.lz4_exact else 0
+    o.flags = (N.SB_WRITE_LZ4_EXACT if opts.lz4_exact else 0) | ((1 << 30) if getattr(opts, "debug_verify_fail", False) else 0)
     return o
 
 

@@ -29,6 +29,7 @@ def gpu_encode(ctx, col, **opt):
                       default_compress_ratio=opt.get("ratio"), max_page_size=opt.get("max_page_size"),
                       forbidden_compressions=list(opt.get("forbidden", ())), force_codec=opt.get("force_codec", -1),
                       force_index_codec=opt.get("force_index_codec", -1), rng_seed=opt.get("rng_seed", 42),
+                      debug_verify_fail=opt.get("debug_verify_fail", False),
                       lz4_exact=opt.get("lz4_exact", True))   # byte parity with the oracle (== liblz4) needs the exact parse;
                                                               # lz4_exact=False = the default (parallel) encoder bench.py times
     return write.write(ctx, to_device_column(ctx, col), wo)

@@ -188,3 +188,22 @@ def test_run_level_kernel_shapes(gpu_ctx):
                 np.repeat(np.r_[np.arange(1000), 999, np.arange(1000, 2047)], 64)):
         check(gpu_ctx, col_of(arr.astype(np.int32), None, S.T_I32), max_page_size=65536, ratio=1.05, forbidden=())
         check(gpu_ctx, col_of(arr.astype(np.uint32), None, S.T_U32), max_page_size=65536, ratio=1.05, forbidden=())
+
+
+@pytest.mark.parametrize("nulls", [None, 0.15])
+def test_hashed_binary_selection_redo_path(gpu_ctx, nulls):
+    """Adaptive Utf8 pages count their keys with a tag table over 64-bit row hashes and hand the dictionary to the builder;
+    a string check over every row guards it, and a page that fails is selected again exactly and built by the exact
+    builder.  SB_WRITE_DEBUG_VERIFY_FAIL makes every page fail: the bytes must still be the oracle's (Dict pages with
+    Bitpacking / LZ4 indices, a Freq-heavy column, a high-cardinality column that stays Basic)."""
+    from tests.test_gpu_encode import gpu_encode
+    cols = [gen.binary(200_000, uniq=3000, zipf=1.2, null_density=nulls, seed=11),
+            gen.binary(150_000, uniq=40, zipf=3.0, null_density=nulls, seed=12),
+            gen.binary(120_000, uniq=100_000, null_density=nulls, seed=13, maxlen=9)]
+    for col in cols:
+        opt = dict(max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+        want_pages, want_metas = gen.oracle_write(col, **opt)
+        for dbg in (False, True):
+            enc = gpu_encode(gpu_ctx, col, debug_verify_fail=dbg, **opt)
+            assert np.array_equal(enc.metas_array(), want_metas), "debug_verify_fail=%s" % dbg
+            assert np.array_equal(enc.pages_numpy(), want_pages), "debug_verify_fail=%s" % dbg

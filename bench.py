@@ -79,6 +79,7 @@ def cpu_baseline(cols, sbo_opts, arrow_bytes, sample_desc, rep_for_all_cores=Tru
     and page-parallel over all host cores.  Bounded: the sample is sized by the caller."""
     from oracle import sbo
     cores = host_cores()
+    sysc = sbo.system_codecs(True)   # Basic(LZ4 / Zstd) blocks through the box's liblz4 / libzstd (BASELINE.md section 5)
     tw, tr, _ = sbo.time_pages_mt(cols, sbo_opts, threads=1, iters=2)
     one = {"value": round(2.0 * arrow_bytes / (tw + tr) / 1e9, 3), "encode": round(arrow_bytes / tw / 1e9, 3),
            "decode": round(arrow_bytes / tr / 1e9, 3)}
@@ -91,10 +92,29 @@ def cpu_baseline(cols, sbo_opts, arrow_bytes, sample_desc, rep_for_all_cores=Tru
     twm, trm, _ = sbo.time_pages_mt(cols * rep, sbo_opts, threads=cores, iters=2)
     allc = {"value": round(2.0 * arrow_bytes * rep / (twm + trm) / 1e9, 3), "encode": round(arrow_bytes * rep / twm / 1e9, 3),
             "decode": round(arrow_bytes * rep / trm / 1e9, 3), "cores": cores, "sample_replicas": rep}
+    sbo.system_codecs(False)
     return {"value": one["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": sample_desc,
             "one_thread": one, "all_cores": allc, "cpu_model": cpu_model(),
-            "note": "C++ restatement of sundy-li/strawboat's algorithm (oracle/), not the Rust binary; its LZ4 / Zstd / "
-                    "Snappy are the oracle's own implementations, not liblz4 / libzstd"}
+            "block_codecs": {"lz4": "liblz4 %s (the box's liblz4.so.1)" % sysc["lz4"] if sysc["lz4"] else "the restatement's own LZ4 (== LZ4_compress_default bytes)",
+                             "zstd": "libzstd %s (the box's libzstd.so.1, default level)" % sysc["zstd"] if sysc["zstd"] else "the restatement's own Zstd (store-only encoder)",
+                             "snappy": "the restatement's own Snappy"},
+            "note": "C++ restatement of sundy-li/strawboat's algorithm (oracle/), not the Rust binary; Basic(LZ4 / Zstd) blocks go "
+                    "through the box's liblz4 / libzstd when they load (block_codecs says which)"}
+
+
+def reference_page_bytes(cols, sbo_opts):
+    """bytes of the pages the reference's CPU path writes for these columns: the restatement with the box's liblz4 / libzstd
+    behind Basic(LZ4 / Zstd) blocks (one LZ4 block / one Zstd frame per buffer, src/compression/basic.rs:108-135), all host
+    cores, untimed setup.  None when neither library loads."""
+    from oracle import sbo
+    sysc = sbo.system_codecs(True)
+    try:
+        if not (sysc["lz4"] or sysc["zstd"]):
+            return None, sysc
+        _, _, nbytes = sbo.time_pages_mt(cols, sbo_opts, threads=host_cores(), iters=1)
+        return nbytes, sysc
+    finally:
+        sbo.system_codecs(False)
 
 
 class GpuHarness:
@@ -186,6 +206,51 @@ class GpuHarness:
         return dict(U=U, page_bytes=pb, n_pages=npages, enc_ms=te, dec_ms=td, kernels=st, enc=enc)
 
 
+def measure_reference_pages(h, cols, sbo_opts, reps=3):
+    """decode of pages the REFERENCE's codecs wrote: the restatement with the box's liblz4 / libzstd writes the columns'
+    pages in the untimed setup (one LZ4 block / one libzstd frame per buffer, src/compression/basic.rs:108-135), the device
+    reads them back; returns None when the libraries do not load"""
+    from oracle import sbo
+    from strawboat_amd import read
+    torch, ctx = h.torch, h.ctx
+    sysc = sbo.system_codecs(True)
+    try:
+        if not (sysc["lz4"] and sysc["zstd"]):
+            return None
+
+        def one(c):
+            return sbo.write_column(c["ptype"], c["nullable"], c["rows"], c["values"], validity=c["validity"], offsets=c["offsets"], options=sbo_opts)
+        with ThreadPoolExecutor(max_workers=min(32, host_cores())) as ex:
+            written = list(ex.map(one, cols))
+    finally:
+        sbo.system_codecs(False)
+    pages = [read.ColumnPages(c["ptype"], c["nullable"], torch.from_numpy(p).to(h.dev), m) for c, (p, m) in zip(cols, written)]
+    dec = read.batch_read_columns(ctx, pages)
+    ctx.synchronize()
+    h.check_round_trip(cols[0], dec[0])
+    rb = read.ReadBatch(ctx, pages, out=dec)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    rb.enqueue()
+    ctx.synchronize()
+    with torch.cuda.stream(ctx.torch_stream):
+        ev[0].record()
+        for _ in range(reps):
+            rb.enqueue()
+        ev[1].record()
+    ctx.synchronize()
+    td = ev[0].elapsed_time(ev[1]) / reps
+    ctx.profile(True)
+    rb.enqueue()
+    ctx.synchronize()
+    st = ctx.profile_read()
+    ctx.profile(False)
+    U = sum(W.arrow_bytes(c) for c in cols)
+    pb = sum(int(p.size) for p, _ in written)
+    d = direction_summary(U, pb, td, st, False)
+    return {"arrow_MB": round(U / 1e6, 1), "page_MB": round(pb / 1e6, 1), "pages": sum(len(m) for _, m in written), "decode": d,
+            "written_by": "the restatement with liblz4 %s / libzstd %s (untimed setup)" % (sysc["lz4"], sysc["zstd"])}
+
+
 def direction_summary(U, pb, ms, kernels, encode):
     """GB/s of Arrow bytes, fraction of the HBM roofline reached by the direction's algorithmic bytes
     (A_enc = Arrow bytes read + page bytes written, A_dec = page bytes read + Arrow bytes written),
@@ -253,6 +318,12 @@ def run_configs(h, only, cpu_on, log):
             cpu = cpu_baseline(cpu_cols, sbo_options(opts), cu,
                                "%d column(s) x %d rows of this configuration, encode+decode" % (len(cpu_cols), cpu_cols[0]["rows"]))
         extra = {"workload": desc}
+        if cpu_on:   # the size the reference's own codecs (liblz4 / libzstd) give the same pages
+            rb, sysc = reference_page_bytes(cols, sbo_options(opts))
+            if rb:
+                extra["page_MB_reference_codecs"] = round(rb / 1e6, 1)
+                extra["page_bytes_vs_reference"] = round(res["page_bytes"] / rb, 4)
+                extra["reference_codecs"] = "liblz4 %s, libzstd %s" % (sysc["lz4"], sysc["zstd"])
         if codecs:
             try:
                 extra["codecs_of_column_0"] = page_codecs(cols[0], res["enc"][0])
@@ -272,8 +343,14 @@ def run_configs(h, only, cpu_on, log):
                        "-> Dict pages with Bitpacking / LZ4 indices", cols,
                  WriteOptions(max_page_size=PAGE, default_compression=C.LZ4, default_compress_ratio=2.0), cols[:1], reps=3)
         if want("c3_lz4"):
-            flat("c3_lz4", "C3': the same columns, Basic(LZ4) pages (offsets block + values block), ratio None", cols,
-                 WriteOptions(max_page_size=PAGE, default_compression=C.LZ4), cols[:1], reps=3)
+            o_lz4 = WriteOptions(max_page_size=PAGE, default_compression=C.LZ4)
+            flat("c3_lz4", "C3': the same columns, Basic(LZ4) pages (offsets block + values block), ratio None", cols, o_lz4, cols[:1], reps=3)
+            if cpu_on:
+                r = measure_reference_pages(h, cols, sbo_options(o_lz4))
+                if r:
+                    r["workload"] = "C3' pages written by liblz4 (one block per buffer, 64 KiB match window), decoded on the device"
+                    out["c3_lz4_reference_written"] = r
+                    log("c3_lz4_reference_written: decode %.1f GB/s" % r["decode"]["GBps"])
         del cols
     if want("c4"):
         named = W.c4_columns(10_000_000)
@@ -382,8 +459,7 @@ def run_c5(h, cpu_on, arrays=64):
         from oracle import sbo
         o = sbo.make_options(default_compression=sbo.ZSTD, max_page_size=PAGE)
         cpu = cpu_baseline([dict(a, nullable=False), dict(b, nullable=False)], o, W.arrow_bytes(a) + W.arrow_bytes(b),
-                           "the two leaf columns of one array as flat non-nullable columns (leaf blocks only, no level sections); the "
-                           "oracle's Zstd encoder is store-only")
+                           "the two leaf columns of one array as flat non-nullable columns (leaf blocks only, no level sections)")
     e = config_entry("c5", res, cpu, {"workload": "C5: %d x 1 M-row List<Struct<Int64,Utf8>> (list length U{0,1,2}, 10 %% null lists, leaves 20 %% "
                                                   "null), 64Ki-row pages, Zstd default, ratio None; %d leaf columns x 16 pages through the nested API "
                                                   "(level sections of all leaves in one batch, then the BLOCKs of all leaves in one call); wall "
@@ -397,6 +473,21 @@ def run_c5(h, cpu_on, arrays=64):
                                 kernels_ms={kk: round(vv[1], 3) for kk, vv in sorted(st.items(), key=lambda kv: -kv[1][1])[:6]})
     top(st_e, "encode")
     top(st_d, "decode")
+    if cpu_on:
+        from oracle import sbo
+        o = sbo.make_options(default_compression=sbo.ZSTD, max_page_size=PAGE)
+        flat_leaves = [dict(a, nullable=False, validity=None), dict(b, nullable=False, validity=None)]
+        rbytes, sysc = reference_page_bytes(flat_leaves, o)
+        if rbytes:
+            e["leaf_page_MB_reference_codecs_one_array"] = round(rbytes / 1e6, 2)
+            e["leaf_page_MB_one_array"] = round((encs[0].length + encs[1].length) / 1e6, 2)
+            e["reference_codecs"] = "libzstd %s (one frame per buffer, default level)" % sysc["zstd"]
+        # the leaf columns of all arrays written by libzstd (the reference's frames: one per page buffer), read here
+        r = measure_reference_pages(h, [dict(it[2], nullable=False, validity=None) for it in items], o)
+        if r:
+            r["workload"] = "the leaf BLOCKs of the %d arrays as flat columns, pages written by libzstd (ONE frame per page buffer: the device " \
+                            "decodes such a frame on one wave), decoded on the device" % arrays
+            e["leaf_pages_reference_written"] = r
     if arrays > 1:   # the round-2 shape: one array per call
         _, _, _, _, _, _, te1, td1 = measure(items[:2], 3)
         U1 = W.arrow_bytes(a) + W.arrow_bytes(b) + 2 * ((la[0]["length"] + 1) * 4 + (la[0]["length"] + 7) // 8)

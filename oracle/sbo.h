@@ -106,6 +106,9 @@ inline uint64_t sample_rand(uint64_t page_seed, uint32_t depth, uint32_t codec, 
 
 // ---- LZ4 block format (sbo_lz4.cpp) — third-party algorithm: liblz4 via the `lz4`
 // crate (Cargo.toml:23), call sites src/compression/basic.rs:87-91,108-120.
+// the box's liblz4 / libzstd for Basic(LZ4 / Zstd) blocks (CPU baseline leg; sbo_codecs.cpp)
+int system_codecs_enable(int on);
+int system_codec_version(int which);
 size_t lz4_compress_bound(size_t n);
 // restatement of LZ4_compress_default (greedy single-probe hash parse, liblz4 1.9.x)
 size_t lz4_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);

@@ -98,8 +98,23 @@ def lib():
         L.sbo_time_pages_mt.restype = C.c_int32
         L.sbo_time_pages_mt.argtypes = [C.POINTER(_ColumnIn), C.c_uint64, C.POINTER(_Options), C.c_int32, C.c_int32,
                                         C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        L.sbo_system_codecs.restype = C.c_int32
+        L.sbo_system_codecs.argtypes = [C.c_int32]
+        L.sbo_system_codec_version.restype = C.c_int32
+        L.sbo_system_codec_version.argtypes = [C.c_int32]
         _lib = L
     return _lib
+
+
+def system_codecs(on):
+    """Basic(LZ4 / Zstd) blocks through the box's liblz4.so.1 / libzstd.so.1 (what the reference's crates wrap) instead of
+    the restatement's own codecs — for bench.py's cpu_baseline leg.  Returns {"lz4": version or None, "zstd": ...}."""
+    L = lib()
+    m = L.sbo_system_codecs(1 if on else 0)
+
+    def ver(v):
+        return "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100)
+    return {"lz4": ver(L.sbo_system_codec_version(0)) if m & 1 else None, "zstd": ver(L.sbo_system_codec_version(1)) if m & 2 else None}
 
 
 class OracleError(RuntimeError):

@@ -213,6 +213,9 @@ void sbo_bitpack_pack(const uint32_t* in128, uint8_t nb, uint8_t* out, int32_t d
 void sbo_bitpack_unpack(const uint8_t* in, uint8_t nb, uint32_t* out128, int32_t delta, uint32_t initial) {
     bitpack4x_unpack(in, nb, out128, delta != 0, initial);
 }
+// bit 0: liblz4.so.1 in use, bit 1: libzstd.so.1 in use (bench.py's cpu_baseline leg); versions as the libraries report them
+int32_t sbo_system_codecs(int32_t on) { return system_codecs_enable(on); }
+int32_t sbo_system_codec_version(int32_t which) { return system_codec_version(which); }
 uint64_t sbo_sample_rand(uint64_t seed, uint32_t depth, uint32_t codec, uint32_t i, uint64_t n) {
     return sample_rand(seed, depth, codec, i, n);
 }

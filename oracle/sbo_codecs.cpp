@@ -15,7 +15,60 @@
 
 #include "sbo_util.h"
 
+#include <dlfcn.h>
+
 namespace sbo {
+
+// ============================================================ system block codecs (CPU baseline leg only)
+// the CPU leg links the box's liblz4 / libzstd when present — the libraries the reference's `lz4`
+// and `zstd` crates wrap (src/compression/basic.rs:87-135: LZ4_compress_default / LZ4_decompress_safe,
+// ZSTD_compress at level 0 = the default level 3 / ZSTD_decompress).  Off by default: the tests run the restatement's own
+// codecs (pinned against these very libraries in tests/test_oracle_blocks.py); bench.py's cpu_baseline switches them on.
+namespace syscodec {
+typedef int (*lz4_compress_fn)(const char*, char*, int, int);
+typedef int (*lz4_decompress_fn)(const char*, char*, int, int);
+typedef int (*lz4_version_fn)();
+typedef size_t (*zstd_compress_fn)(void*, size_t, const void*, size_t, int);
+typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*zstd_iserror_fn)(size_t);
+typedef unsigned (*zstd_version_fn)();
+static lz4_compress_fn lz4_c = nullptr;
+static lz4_decompress_fn lz4_d = nullptr;
+static zstd_compress_fn zstd_c = nullptr;
+static zstd_decompress_fn zstd_d = nullptr;
+static zstd_iserror_fn zstd_err = nullptr;
+static int lz4_ver = 0, zstd_ver = 0;
+static bool use_lz4 = false, use_zstd = false;
+// returns bit 0: liblz4 in use, bit 1: libzstd in use
+static int enable(bool on) {
+    use_lz4 = use_zstd = false;
+    if (!on) return 0;
+    if (!lz4_c) {
+        void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            lz4_c = (lz4_compress_fn)dlsym(h, "LZ4_compress_default");
+            lz4_d = (lz4_decompress_fn)dlsym(h, "LZ4_decompress_safe");
+            lz4_version_fn v = (lz4_version_fn)dlsym(h, "LZ4_versionNumber");
+            if (v) lz4_ver = v();
+        }
+    }
+    if (!zstd_c) {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            zstd_c = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
+            zstd_d = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
+            zstd_err = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+            zstd_version_fn v = (zstd_version_fn)dlsym(h, "ZSTD_versionNumber");
+            if (v) zstd_ver = (int)v();
+        }
+    }
+    use_lz4 = lz4_c && lz4_d;
+    use_zstd = zstd_c && zstd_d && zstd_err;
+    return (use_lz4 ? 1 : 0) | (use_zstd ? 2 : 0);
+}
+}  // namespace syscodec
+int system_codecs_enable(int on) { return syscodec::enable(on != 0); }
+int system_codec_version(int which) { return which == 0 ? syscodec::lz4_ver : syscodec::zstd_ver; }
 
 // ============================================================ CommonCompression
 // src/compression/basic.rs:62-84
@@ -28,14 +81,27 @@ static size_t common_compress(uint8_t codec, const uint8_t* in, size_t n, std::v
         case C_LZ4: {  // basic.rs:108-120
             size_t bound = lz4_compress_bound(n);
             out.resize(start + bound);
-            size_t sz = lz4_compress(in, n, out.data() + start, bound);
+            size_t sz;
+            if (syscodec::use_lz4 && n < 0x7E000000u) {
+                const int r = syscodec::lz4_c((const char*)in, (char*)out.data() + start, (int)n, (int)bound);
+                if (r <= 0 && n) out_of_spec("LZ4_compress_default failed");
+                sz = (size_t)r;
+            } else {
+                sz = lz4_compress(in, n, out.data() + start, bound);
+            }
             out.resize(start + sz);
             return sz;
         }
         case C_ZSTD: {  // basic.rs:122-135
-            size_t bound = zstd_compress_bound(n);
+            size_t bound = zstd_compress_bound(n) + n / 128 + 64;
             out.resize(start + bound);
-            size_t sz = zstd_compress(in, n, out.data() + start, bound);
+            size_t sz;
+            if (syscodec::use_zstd) {
+                sz = syscodec::zstd_c(out.data() + start, bound, in, n, 0);   // level 0 = the default level, as basic.rs:131
+                if (syscodec::zstd_err(sz)) out_of_spec("ZSTD_compress failed");
+            } else {
+                sz = zstd_compress(in, n, out.data() + start, bound);
+            }
             out.resize(start + sz);
             return sz;
         }
@@ -58,9 +124,18 @@ static void common_decompress(uint8_t codec, const uint8_t* in, size_t n, uint8_
             if (n) memcpy(dst, in, n);
             return;
         case C_LZ4:
+            if (syscodec::use_lz4 && n < 0x7E000000u && out_len < 0x7E000000u) {
+                if (syscodec::lz4_d((const char*)in, (char*)dst, (int)n, (int)out_len) != (int)out_len) out_of_spec("LZ4_decompress_safe failed");
+                return;
+            }
             lz4_decompress(in, n, dst, out_len);
             return;
         case C_ZSTD:
+            if (syscodec::use_zstd) {
+                const size_t r = syscodec::zstd_d(dst, out_len, in, n);
+                if (syscodec::zstd_err(r) || r != out_len) out_of_spec("ZSTD_decompress failed");
+                return;
+            }
             zstd_decompress(in, n, dst, out_len);
             return;
         case C_SNAPPY:

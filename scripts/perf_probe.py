@@ -40,7 +40,10 @@ def main():
     page = int(sys.argv[6]) if len(sys.argv) > 6 else 65536
     ctx = sb.Context(0)
     h = bench.GpuHarness(ctx)
-    cols = bench.gen_parallel(lambda s: column(kind, rows, s), range(42, 42 + ncols))
+    if kind == "c4":
+        cols = [c for _, c in W.c4_columns(rows)] * ncols
+    else:
+        cols = bench.gen_parallel(lambda s: column(kind, rows, s), range(42, 42 + ncols))
     opts = WriteOptions(max_page_size=page or None, default_compression=dc, default_compress_ratio=ratio)
     r = h.measure_flat(cols, opts, reps=3)
     U = r["U"]

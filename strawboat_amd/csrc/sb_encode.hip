@@ -1299,6 +1299,29 @@ __device__ uint64_t enc_u32_block(const uint32_t* idx, uint64_t N, int32_t codec
             break;
         case SB_CODEC_LZ4: {  // Basic(Lz4) over the raw index bytes (integer/mod.rs:55-58)
             __syncthreads();
+            if (!(flags & SB_WRITE_LZ4_EXACT)) {
+                // The u32 indices of a page whose row count is no multiple of 128 (bit-packing is not allowed then: every
+                // column's last page).  The default parse is free to choose, and a block like this
+                // is read by ONE wave whatever else the call holds — 17 000 sequences took 2 ms on both sides, longer than
+                // all other pages of a 64-column batch together.  So it is written as ONE literal run: a valid LZ4 block
+                // every decoder copies out (here: 16-byte wave copies), ~2x its compressed size on a page that is 1 / 60 of
+                // its column (C3: +1 % page bytes).  SB_WRITE_LZ4_EXACT keeps liblz4's parse.
+                const uint32_t nbytes = (uint32_t)(N * 4);
+                uint8_t* o = dst + 9;
+                uint32_t hdr = 1;
+                if (nbytes >= 15) hdr += 1 + (nbytes - 15) / 255;
+                if (threadIdx.x == 0) {
+                    o[0] = (uint8_t)((nbytes >= 15 ? 15u : nbytes) << 4);
+                    if (nbytes >= 15) {
+                        uint32_t rest = nbytes - 15, k = 1;
+                        for (; rest >= 255; rest -= 255) o[k++] = 255;
+                        o[k] = (uint8_t)rest;
+                    }
+                }
+                wg_copy(o + hdr, (const uint8_t*)idx, nbytes);
+                body = hdr + nbytes;
+                break;
+            }
             if (!(flags & SB_WRITE_LZ4_EXACT) && tmp && sB > sA && sC - sB == sB - sA) {
                 // (sA, sB, sC are one contiguous LDS area in the page kernels: 3 * LW words)
                 const uint32_t z = lz4_compress_block_wg3((const uint8_t*)idx, (uint32_t)(N * 4), dst + 9, sA,

@@ -3295,21 +3295,60 @@ __global__ void __launch_bounds__(WG) k_enc_bin_verify(EncodeArgs a) {
     const uint16_t* rep16 = (const uint16_t*)(aux + BH_W_REP16);
     const uint64_t* h64 = (const uint64_t*)(a.scratch + p.h64_off);
     bool ok = true;
+    // A divergent load costs the CU's address unit one cycle per lane, so the pass is sized in GATHERS per row: the slot's
+    // representative row (1), its offset pair with one 8-byte load (1), its first 16 bytes (1, strings of up to 16 bytes) —
+    // the row's own offsets and bytes are near-contiguous across lanes.  Longer strings take eq().
     auto body = [&](auto keys) {
+        using KT = decltype(keys);
         constexpr int VU = 8;
+        constexpr bool O32 = sizeof(keys.k.beg(0)) == 8 && std::is_same<KT, BinKeysHashed<int32_t>>::value;
+        const uint8_t* offs = keys.k.offs;
+        const uint8_t* values = keys.k.values;
+        const uint64_t vlen = c.values_len;
         for (uint64_t base = r0 + threadIdx.x; base < r1; base += (uint64_t)WG * VU) {
-            uint32_t f[VU];
-            uint64_t row[VU];
+            uint32_t g[VU];
+            uint64_t br[VU], er[VU], bg[VU], eg[VU];
+            bool need[VU];
 #pragma unroll
             for (int u = 0; u < VU; u++) {
-                row[u] = base + (uint64_t)u * WG;
-                f[u] = EMPTY;
-                if (row[u] < r1) {
-                    f[u] = ldu16((const uint8_t*)(rep16 + ldu16((const uint8_t*)(slot16 + row[u]))));
-                    if (f[u] == (uint32_t)row[u]) f[u] = EMPTY;   // the class's own representative
+                const uint64_t row = base + (uint64_t)u * WG;
+                const uint64_t rc = row < r1 ? row : r0;
+                g[u] = ldu16((const uint8_t*)(rep16 + ldu16((const uint8_t*)(slot16 + rc))));
+                need[u] = row < r1 && g[u] != (uint32_t)rc;
+                if (!need[u]) g[u] = (uint32_t)rc;
+            }
+#pragma unroll
+            for (int u = 0; u < VU; u++) {
+                const uint64_t row = base + (uint64_t)u * WG;
+                const uint64_t rc = row < r1 ? row : r0;
+                if constexpr (O32) {
+                    const uint64_t pr = ldu64(offs + rc * 4), pg = ldu64(offs + (uint64_t)g[u] * 4);
+                    br[u] = (uint32_t)pr; er[u] = pr >> 32; bg[u] = (uint32_t)pg; eg[u] = pg >> 32;
+                } else {
+                    br[u] = keys.k.beg(rc); er[u] = keys.k.beg(rc + 1); bg[u] = keys.k.beg(g[u]); eg[u] = keys.k.beg((uint64_t)g[u] + 1);
                 }
             }
-            if (!keys.template exact_batch<VU>(f, row)) ok = false;
+#pragma unroll
+            for (int u = 0; u < VU; u++) {
+                if (!need[u]) continue;
+                const uint64_t n = er[u] - br[u];
+                if (n != eg[u] - bg[u]) {
+                    ok = false;
+                    continue;
+                }
+                if (n <= 32 && br[u] + 32 <= vlen && bg[u] + 32 <= vlen) {   // two unconditional 16-byte pairs, byte masks
+                    const u32x4 a4 = ldu128(values + br[u]), b4 = ldu128(values + bg[u]);
+                    const u32x4 a5 = ldu128(values + br[u] + 16), b5 = ldu128(values + bg[u] + 16);
+                    auto msk = [](uint64_t have) -> uint64_t { return have >= 8 ? ~0ull : ((1ull << (8 * have)) - 1); };
+                    const uint64_t d0 = ((uint64_t)(a4.x ^ b4.x)) | ((uint64_t)(a4.y ^ b4.y) << 32), d1 = ((uint64_t)(a4.z ^ b4.z)) | ((uint64_t)(a4.w ^ b4.w) << 32);
+                    const uint64_t d2 = ((uint64_t)(a5.x ^ b5.x)) | ((uint64_t)(a5.y ^ b5.y) << 32), d3 = ((uint64_t)(a5.z ^ b5.z)) | ((uint64_t)(a5.w ^ b5.w) << 32);
+                    const uint64_t x = (d0 & msk(n)) | (d1 & msk(n > 8 ? n - 8 : 0)) | (d2 & msk(n > 16 ? n - 16 : 0)) | (d3 & msk(n > 24 ? n - 24 : 0));
+                    if (x) ok = false;
+                } else {
+                    const uint64_t row = base + (uint64_t)u * WG;
+                    if (!keys.k.eq(g[u], row)) ok = false;
+                }
+            }
         }
     };
     if (c.ptype == SB_TYPE_BINARY)

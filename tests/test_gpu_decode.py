@@ -159,3 +159,30 @@ def test_rle_runs_end_before_the_page_is_full(gpu_ctx):
     with pytest.raises(NativeError) as e:  # read_u32 hits EOF upstream (integer/rle.rs:128-131)
         _decode_rle_pages(gpu_ctx, S.T_I32, [_rle_page([(10, 1), (0, 2), (5, 3)], 4, np.int32)], [16])
     assert e.value.code == -3
+
+
+def test_binary_dict_entries_with_zero_bytes_and_empty_strings(gpu_ctx):
+    """k_plan finds the entries of a binary Dict page in parallel by looking for length fields (four zero bytes in front of
+    text) and verifies the chain it found; dictionaries whose strings hold zero bytes, are empty or are raw little-endian
+    integers defeat the pattern and must come out the same through the serial walk"""
+    from tests.test_gpu_encode import gpu_encode
+    rng = np.random.default_rng(17)
+    n = 150_000
+    vocab = [b"", b"\0", b"\0\0\0\0\0\0\0\0", b"a\0b", b"tail\0\0\0\0", b"\0\0\0\0head"] + \
+            [int(v).to_bytes(8, "little") for v in rng.integers(0, 1 << 20, 300)] + [("w%d" % k).encode() for k in range(200)]
+    idx = rng.integers(0, len(vocab), n)
+    lens = np.array([len(vocab[i]) for i in idx], np.int64)
+    offs = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"".join(vocab[i] for i in idx), np.uint8).copy()
+    for nulls in (None, 0.2):
+        col = dict(ptype=S.T_BIN32, nullable=nulls is not None, rows=n, values=data,
+                   validity=None if nulls is None else gen.pack_bits(rng.random(n) >= nulls), offsets=offs.astype(np.int32))
+        pages, metas = gen.oracle_write(col, max_page_size=65536, force_codec=S.DICT)
+        want = gen.oracle_read(col, pages, metas)
+        got = gpu_decode(gpu_ctx, col, pages, metas)
+        assert np.array_equal(got.values_numpy(), want["values"])
+        assert np.array_equal(got.offsets_numpy(), want["offsets"])
+        enc = gpu_encode(gpu_ctx, col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+        wp, wm = gen.oracle_write(col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+        assert np.array_equal(enc.metas_array(), wm) and np.array_equal(enc.pages_numpy(), wp)

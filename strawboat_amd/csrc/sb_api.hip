@@ -42,6 +42,33 @@ bool ensure(sb_ctx* ctx, DevBuf& b, size_t need) {
     return true;
 }
 
+bool side_streams(sb_ctx* ctx) {
+    if (ctx->side_ready) return true;
+    int lo_prio = 0, hi_prio = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+    for (int i = 0; i < sb_ctx::NSIDE; i++) {
+        // side[0] carries the longest chain of a mixed call (binary columns): highest priority, so that its workgroups are
+        // placed first when several kernels compete for the CUs
+        if (hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, i == 0 ? hi_prio : lo_prio) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) != hipSuccess) return false;
+    ctx->side_ready = true;
+    return true;
+}
+void side_fork(sb_ctx* ctx, uint32_t used_mask) {
+    (void)hipEventRecord(ctx->fork_ev, ctx->stream);
+    for (int i = 0; i < sb_ctx::NSIDE; i++)
+        if ((used_mask >> i) & 1) (void)hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0);
+}
+void side_join(sb_ctx* ctx, uint32_t used_mask) {
+    for (int i = 0; i < sb_ctx::NSIDE; i++)
+        if ((used_mask >> i) & 1) {
+            (void)hipEventRecord(ctx->join_ev[i], ctx->side[i]);
+            (void)hipStreamWaitEvent(ctx->stream, ctx->join_ev[i], 0);
+        }
+}
+
 StageSlot* acquire_slot(sb_ctx* ctx, size_t need) {
     StageSlot& s = ctx->slots[ctx->next_slot];
     ctx->next_slot = (ctx->next_slot + 1) % sb_ctx::NSLOTS;
@@ -171,6 +198,11 @@ void sb_ctx_destroy(sb_ctx* ctx) {
     if (ctx->zrec.p) (void)hipFree(ctx->zrec.p);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    for (int i = 0; i < sb_ctx::NSIDE; i++) {
+        if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
+        if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

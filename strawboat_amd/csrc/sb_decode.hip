@@ -2200,18 +2200,24 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k2(ctx, "k_inflate_lz4(values)");
         k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
     }
+    // the three expand kernels work on disjoint pages (page-level RLE, tiles of primitives, tiles of binary columns): side
+    // by side on streams of their own when the call has both kinds of columns (a mixed schema), joined before the call ends
+    const bool multi = any_prim && any_binary && a.n_tiles && !ctx->profile && side_streams(ctx);
+    hipStream_t s1 = multi ? ctx->side[0] : s, s2 = multi ? ctx->side[1] : s;
+    if (multi) side_fork(ctx, 3u);
     if (any_prim) {
         KScope k(ctx, K_EXPAND_RLE);
         k_expand_rle<<<a.n_pages, WG, 0, s>>>(a);
     }
     if (a.n_tiles && any_prim) {
         KScope k(ctx, K_EXPAND);
-        k_expand<<<min(a.n_tiles, TILE_GRID), WG, 0, s>>>(a);
+        k_expand<<<min(a.n_tiles, TILE_GRID), WG, 0, s1>>>(a);
     }
     if (a.n_tiles && any_binary) {
         KScope k(ctx, K_EXPAND_BIN);
-        k_expand_binary<<<min(a.n_tiles, TILE_GRID), WG, 0, s>>>(a);
+        k_expand_binary<<<min(a.n_tiles, TILE_GRID), WG, 0, s2>>>(a);
     }
+    if (multi) side_join(ctx, 3u);
 }
 
 void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_len) {

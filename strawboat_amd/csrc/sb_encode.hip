@@ -5517,71 +5517,150 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         aa.use_counts = wave_adaptive && !nested ? 1u : 0u;
         aa.pre_hashed = 0;
         aa.redo = 0;
-        if (wave_adaptive && !nested) {   // row hashes of the binary pages, tile-parallel, before their selector
-            bool any_bin = false;
-            for (int kd : kinds) any_bin |= kd < 0;
-            if (any_bin) {
-                KScope k(ctx, "k_enc_bin_hash");
-                const uint64_t max_rows = max_tiles * TILE_ROWS;
-                k_enc_bin_hash<<<dim3((uint32_t)P, (uint32_t)((max_rows + BH_ROWS - 1) / BH_ROWS)), WG, 0, s>>>(aa);
+        int n_bin_kinds = 0;
+        for (int kd : kinds) n_bin_kinds += kd < 0 ? 1 : 0;
+        const bool any_bin = n_bin_kinds > 0;
+        const uint64_t max_rows = max_tiles * TILE_ROWS;
+        const dim3 tile_grid((uint32_t)P, (uint32_t)((max_rows + BH_ROWS - 1) / BH_ROWS));
+        // Column kinds work on disjoint pages: in an adaptive wave over several kinds (a mixed schema: C4) every kind's chain
+        // selector -> [string check, re-selection] -> page kernels runs on a stream of its own between a fork and a join, so
+        // that a few hundred pages per kind share the chip instead of taking turns.  Not while profiling.
+        const bool multi = wave_adaptive && !nested && kinds.size() >= 2 && n_bin_kinds < (int)kinds.size() && !ctx->profile && side_streams(ctx);
+        // binary kinds (the longest chain: hash, selector, string check, dictionary pages) on the high-priority side stream,
+        // the other kinds one after the other on the call's stream; without binary columns the kinds alternate between the
+        // call's stream and a side stream.  (More streams than that only made every kernel slower: the page kernels are
+        // latency chains, and four of them sharing the CUs doubled the binary selector's time.)
+        auto stream_of = [&](size_t ki) -> hipStream_t {
+            if (!multi) return s;
+            if (n_bin_kinds) return kinds[ki] < 0 ? ctx->side[0] : s;
+            return (ki & 1) ? ctx->side[1] : s;
+        };
+        uint32_t side_mask = 0;
+        if (multi) side_mask = n_bin_kinds ? 1u : 2u;
+        if (multi && n_bin_kinds == (int)kinds.size()) side_mask = 0;   // (only binary kinds: nothing to overlap with)
+        auto launch_hash = [&](hipStream_t st) {   // row hashes of the binary pages, tile-parallel, before their selector
+            KScope k(ctx, "k_enc_bin_hash");
+            k_enc_bin_hash<<<tile_grid, WG, 0, st>>>(aa);
+        };
+        auto launch_selectors = [&](int kd, hipStream_t st) {
+            if (nested && (kd <= 0 || kd > 8)) return;
+            if (!nested && (kd == 4 || kd == 8)) {  // statistics + speculative RLE in one pass
+                bool any_f = false, any_i = false;
+                for (uint64_t i = 0; i < n; i++)
+                    if ((int)hc[i].width == kd && hc[i].ptype != SB_TYPE_BOOLEAN && !enc_is_binary(hc[i].ptype)) {
+                        any_f |= hc[i].fkind != 0;
+                        any_i |= hc[i].fkind == 0;
+                    }
+                // lane = raw run first; pages with runs too short for that go through the lane = row kernel
+                if (any_f) {
+                    {
+                        KScope k(ctx, kd == 4 ? "k_enc_select_runs<4, 1>" : "k_enc_select_runs<8, 2>");
+                        if (kd == 4)
+                            k_enc_select_runs<4, 1><<<(uint32_t)P, WG, 0, st>>>(aa);
+                        else
+                            k_enc_select_runs<8, 2><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    }
+                    KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 1>" : "k_enc_select_rle<8, 2>");
+                    if (kd == 4)
+                        k_enc_select_rle<4, 1><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    else
+                        k_enc_select_rle<8, 2><<<(uint32_t)P, WG, 0, st>>>(aa);
+                }
+                if (any_i) {
+                    {
+                        KScope k(ctx, kd == 4 ? "k_enc_select_runs<4, 0>" : "k_enc_select_runs<8, 0>");
+                        if (kd == 4)
+                            k_enc_select_runs<4, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
+                        else
+                            k_enc_select_runs<8, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    }
+                    KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 0>" : "k_enc_select_rle<8, 0>");
+                    if (kd == 4)
+                        k_enc_select_rle<4, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    else
+                        k_enc_select_rle<8, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
+                }
+                return;
+            }
+            char nm[48];
+            snprintf(nm, sizeof nm, "k_enc_select<%d>", kd);
+            KScope k(ctx, nm);
+            enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, st>>>(aa);
+        };
+        // the dictionaries the binary selectors handed over: strings checked tile-parallel, pages that failed selected again
+        // exactly (workgroups of all other pages return at once); kd_only: the one binary kind of this stream, or 0 = both
+        auto launch_verify = [&](int kd_only, hipStream_t st) {
+            {
+                KScope k(ctx, "k_enc_bin_verify");
+                k_enc_bin_verify<<<tile_grid, WG, 0, st>>>(aa);
+            }
+            aa.redo = 1;
+            for (int kd : kinds)
+                if (kd < 0 && (!kd_only || kd == kd_only)) enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, st>>>(aa);
+            aa.redo = 0;
+        };
+        auto launch_emit = [&](int kd, hipStream_t st) -> int32_t {
+            // one kernel instance per (kind, codec) that can occur in the batch
+            static const int32_t CAND[6] = {SB_CODEC_ONEVALUE, SB_CODEC_DICT, SB_CODEC_RLE, SB_CODEC_BITPACKING,
+                                            SB_CODEC_DELTA_BITPACKING, SB_CODEC_PATAS};
+            if (nested && (kd <= 0 || kd > 8)) return SB_OK;
+            for (int32_t cd : CAND) {
+                if (!wave_adaptive && cd != wave_codec) continue;
+                if (wave_adaptive) {
+                    if ((forb >> cd) & 1) continue;
+                    if ((cd == SB_CODEC_BITPACKING || cd == SB_CODEC_DELTA_BITPACKING) && kd != 4) continue;
+                    if (kd == 0 && cd == SB_CODEC_DICT) continue;
+                    if (kd < 0 && cd == SB_CODEC_RLE) continue;
+                    if (cd == SB_CODEC_PATAS) {  // candidates of float columns only (double/mod.rs:271-277)
+                        bool any_float = false;
+                        for (uint64_t i = 0; i < n; i++) any_float |= hc[i].fkind != 0 && (int)hc[i].width == kd;
+                        if (!any_float) continue;
+                    }
+                }
+                EncPageKernel kf = enc_page_kernel(kd, cd);
+                if (!kf) continue;
+                char nm[48];
+                snprintf(nm, sizeof nm, "k_enc_emit_pages<%d, %d>", kd, (int)cd);
+                KScope k(ctx, nm);
+                kf<<<(uint32_t)P, WG, 0, st>>>(aa);
+            }
+            if (!nested && !wave_adaptive && wave_codec != SB_CODEC_NONE && wave_codec != SB_CODEC_FREQ && wave_codec > 3 &&
+                !enc_page_kernel(kd, wave_codec))
+                return ctx->fail(SB_ERR_NYI, "no device encoder for this codec and column type");
+            return SB_OK;
+        };
+        const bool emit_pages_wanted = nested || any_pages;
+
+        if (multi) {
+            if (any_bin) aa.pre_hashed = 1;
+            side_fork(ctx, side_mask);
+            int32_t rc = SB_OK;
+            if (any_bin) {   // the binary chain, in order, on the high-priority side stream
+                hipStream_t st = ctx->side[0];
+                launch_hash(st);
+                for (int kd : kinds)
+                    if (kd < 0) launch_selectors(kd, st);
+                launch_verify(0, st);
+                for (int kd : kinds)
+                    if (kd < 0 && emit_pages_wanted && rc == SB_OK) rc = launch_emit(kd, st);
+            }
+            for (size_t ki = 0; ki < kinds.size() && rc == SB_OK; ki++) {
+                const int kd = kinds[ki];
+                if (kd < 0) continue;
+                hipStream_t st = stream_of(ki);
+                launch_selectors(kd, st);
+                if (emit_pages_wanted) rc = launch_emit(kd, st);
+            }
+            side_join(ctx, side_mask);
+            if (rc != SB_OK) return rc;
+        } else {
+            if (wave_adaptive && !nested && any_bin) {
+                launch_hash(s);
                 aa.pre_hashed = 1;
             }
-        }
-        if (wave_adaptive) {
-            for (int kd : kinds) {
-                if (nested && (kd <= 0 || kd > 8)) continue;
-                if (!nested && (kd == 4 || kd == 8)) {  // statistics + speculative RLE in one pass
-                    bool any_f = false, any_i = false;
-                    for (uint64_t i = 0; i < n; i++)
-                        if ((int)hc[i].width == kd && hc[i].ptype != SB_TYPE_BOOLEAN && !enc_is_binary(hc[i].ptype)) {
-                            any_f |= hc[i].fkind != 0;
-                            any_i |= hc[i].fkind == 0;
-                        }
-                    // lane = raw run first; pages with runs too short for that go through the lane = row kernel
-                    if (any_f) {
-                        {
-                            KScope k(ctx, kd == 4 ? "k_enc_select_runs<4, 1>" : "k_enc_select_runs<8, 2>");
-                            if (kd == 4)
-                                k_enc_select_runs<4, 1><<<(uint32_t)P, WG, 0, s>>>(aa);
-                            else
-                                k_enc_select_runs<8, 2><<<(uint32_t)P, WG, 0, s>>>(aa);
-                        }
-                        KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 1>" : "k_enc_select_rle<8, 2>");
-                        if (kd == 4)
-                            k_enc_select_rle<4, 1><<<(uint32_t)P, WG, 0, s>>>(aa);
-                        else
-                            k_enc_select_rle<8, 2><<<(uint32_t)P, WG, 0, s>>>(aa);
-                    }
-                    if (any_i) {
-                        {
-                            KScope k(ctx, kd == 4 ? "k_enc_select_runs<4, 0>" : "k_enc_select_runs<8, 0>");
-                            if (kd == 4)
-                                k_enc_select_runs<4, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
-                            else
-                                k_enc_select_runs<8, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
-                        }
-                        KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 0>" : "k_enc_select_rle<8, 0>");
-                        if (kd == 4)
-                            k_enc_select_rle<4, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
-                        else
-                            k_enc_select_rle<8, 0><<<(uint32_t)P, WG, 0, s>>>(aa);
-                    }
-                    continue;
-                }
-                char nm[48];
-                snprintf(nm, sizeof nm, "k_enc_select<%d>", kd);
-                KScope k(ctx, nm);
-                enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(aa);
-            }
-        }
-        if (aa.pre_hashed) {   // the dictionaries the binary selectors handed over: strings checked tile-parallel
-            KScope k(ctx, "k_enc_bin_verify");
-            const uint64_t max_rows = max_tiles * TILE_ROWS;
-            k_enc_bin_verify<<<dim3((uint32_t)P, (uint32_t)((max_rows + BH_ROWS - 1) / BH_ROWS)), WG, 0, s>>>(aa);
-            aa.redo = 1;   // pages that failed are selected again, exactly (workgroups of all other pages return at once)
-            for (int kd : kinds)
-                if (kd < 0) enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, s>>>(aa);
-            aa.redo = 0;
+            if (wave_adaptive)
+                for (int kd : kinds) launch_selectors(kd, s);
+            if (aa.pre_hashed) launch_verify(0, s);
         }
         const int32_t dc = opts->default_compression;
         const bool basic_comp = dc == SB_CODEC_LZ4 || dc == SB_CODEC_ZSTD || dc == SB_CODEC_SNAPPY;
@@ -5612,35 +5691,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 k_enc_emit_lz4<true><<<(uint32_t)P, WG, 0, s>>>(aa);
             }
         }
-        if (nested || any_pages) {
-            // one kernel instance per (kind, codec) that can occur in the batch
-            static const int32_t CAND[6] = {SB_CODEC_ONEVALUE, SB_CODEC_DICT, SB_CODEC_RLE, SB_CODEC_BITPACKING,
-                                            SB_CODEC_DELTA_BITPACKING, SB_CODEC_PATAS};
+        if (emit_pages_wanted && !multi) {
             for (int kd : kinds) {
-                if (nested && (kd <= 0 || kd > 8)) continue;
-                for (int32_t cd : CAND) {
-                    if (!wave_adaptive && cd != wave_codec) continue;
-                    if (wave_adaptive) {
-                        if ((forb >> cd) & 1) continue;
-                        if ((cd == SB_CODEC_BITPACKING || cd == SB_CODEC_DELTA_BITPACKING) && kd != 4) continue;
-                        if (kd == 0 && cd == SB_CODEC_DICT) continue;
-                        if (kd < 0 && cd == SB_CODEC_RLE) continue;
-                        if (cd == SB_CODEC_PATAS) {  // candidates of float columns only (double/mod.rs:271-277)
-                            bool any_float = false;
-                            for (uint64_t i = 0; i < n; i++) any_float |= hc[i].fkind != 0 && (int)hc[i].width == kd;
-                            if (!any_float) continue;
-                        }
-                    }
-                    EncPageKernel kf = enc_page_kernel(kd, cd);
-                    if (!kf) continue;
-                    char nm[48];
-                    snprintf(nm, sizeof nm, "k_enc_emit_pages<%d, %d>", kd, (int)cd);
-                    KScope k(ctx, nm);
-                    kf<<<(uint32_t)P, WG, 0, s>>>(aa);
-                }
-                if (!nested && !wave_adaptive && wave_codec != SB_CODEC_NONE && wave_codec != SB_CODEC_FREQ && wave_codec > 3 &&
-                    !enc_page_kernel(kd, wave_codec))
-                    return ctx->fail(SB_ERR_NYI, "no device encoder for this codec and column type");
+                const int32_t rc = launch_emit(kd, s);
+                if (rc != SB_OK) return rc;
             }
         }
         return SB_OK;

@@ -124,6 +124,13 @@ struct sb_ctx {
     bool profile = false;
     std::vector<sb::ProfSpan> spans;
     std::vector<hipEvent_t> free_events;
+    // side streams: kernels of a call that work on disjoint pages (the selector / emit chains of different column kinds, the
+    // three expand kernels of a read) run side by side between a fork and a join on `stream`; seen from outside the call is
+    // still one span of work on `stream`.  Not used while profiling (the per-kernel events bracket launches on `stream`).
+    static constexpr int NSIDE = 3;
+    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[NSIDE] = {nullptr, nullptr, nullptr};
+    bool side_ready = false;
     struct ProfEntry {
         std::string name;  // the kernel's name as rocprofv3 prints it, without "void sb::" and the argument list
         double ms = 0;
@@ -176,6 +183,11 @@ struct KScope {
     }
 };
 bool ensure(sb_ctx* ctx, DevBuf& b, size_t need);
+// side streams (created on first use); fork: they wait for everything queued on ctx->stream so far; join: ctx->stream waits
+// for the side streams listed in `used_mask`
+bool side_streams(sb_ctx* ctx);
+void side_fork(sb_ctx* ctx, uint32_t used_mask);
+void side_join(sb_ctx* ctx, uint32_t used_mask);
 StageSlot* acquire_slot(sb_ctx* ctx, size_t need);
 int32_t check_hip(sb_ctx* ctx, hipError_t e, const char* what);
 }  // namespace sb

@@ -3577,8 +3577,15 @@ static EncSelectKernel enc_select_kernel(int kind) {
 // KIND = value width 1..32 for primitives, 0 = boolean, -4 / -8 = binary with i32 / i64 offsets.
 // A monolithic kernel over all kinds needs 300 VGPRs (1 wave/SIMD); the split instances stay
 // within 4 waves/SIMD.  Pages of another kind/codec exit at once.
+// workgroups per CU the instances are compiled for (what their registers and LDS really allow: Dict pages hold a 64 KiB
+// table or the hand-over's id table, Patas needs ~200 VGPRs)
 template <int KIND, int CODEC>
-__global__ void __launch_bounds__(WG, (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_ONEVALUE) ? 4 : 3)
+constexpr int emit_pages_occupancy() {
+    return CODEC == SB_CODEC_DICT ? 2 : CODEC == SB_CODEC_PATAS ? 1 : ((CODEC == SB_CODEC_ONEVALUE || CODEC == SB_CODEC_RLE) && KIND == 32) ? 3
+           : (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_ONEVALUE) ? 4 : 3;
+}
+template <int KIND, int CODEC>
+__global__ void __launch_bounds__(WG, (emit_pages_occupancy<KIND, CODEC>()))
     k_enc_emit_pages(EncodeArgs a) {
     // RLE / OneValue only need the small per-group records; Dict and bit-packing use full tile arrays
     constexpr int LW = CODEC == SB_CODEC_ONEVALUE ? 256

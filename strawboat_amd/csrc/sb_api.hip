@@ -196,6 +196,7 @@ void sb_ctx_destroy(sb_ctx* ctx) {
     if (ctx->staging.p) (void)hipFree(ctx->staging.p);
     if (ctx->zlit.p) (void)hipFree(ctx->zlit.p);
     if (ctx->zrec.p) (void)hipFree(ctx->zrec.p);
+    if (ctx->enc_plan.pages.p) (void)hipFree(ctx->enc_plan.pages.p);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < sb_ctx::NSIDE; i++) {

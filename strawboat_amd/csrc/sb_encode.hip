@@ -5180,6 +5180,34 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             freq_possible |= t != SB_TYPE_BOOLEAN && t != SB_TYPE_NULL;
         }
 
+    // ---- plan cache: everything below that depends only on the shape of the call (sb_ctx::EncPlan)
+    uint64_t plan_key = 0xcbf29ce484222325ull;
+    {
+        auto mixk = [&](uint64_t v) { plan_key = (plan_key ^ v) * 0x100000001b3ull; plan_key ^= plan_key >> 29; };
+        mixk(n); mixk((uint64_t)mem);
+        mixk((uint64_t)opts->default_compression); mixk((uint64_t)opts->has_default_compress_ratio); mixk(opts->max_page_size);
+        mixk(opts->forbidden_compressions); mixk((uint64_t)(int64_t)opts->force_codec); mixk((uint64_t)(int64_t)opts->force_index_codec);
+        mixk(opts->flags); mixk(opts->rng_seed);
+        for (uint64_t i = 0; i < n; i++) {
+            const sb_column_write& c = cols[i];
+            mixk((uint64_t)(int64_t)c.physical_type); mixk((uint64_t)c.is_nullable); mixk(c.rows); mixk(c.values_len); mixk(c.out_capacity);
+            mixk(c.first_page_index); mixk(c.n_pages_capacity); mixk(c.page_rows ? c.n_pages_in + 1 : 0);
+            if (c.page_rows)
+                for (uint64_t q = 0; q < c.n_pages_in; q++) {
+                    mixk(c.page_rows[q]);
+                    mixk(c.page_head_bytes ? c.page_head_bytes[q] : 0);
+                }
+        }
+    }
+    sb_ctx::EncPlan& plan = ctx->enc_plan;
+    bool hit = plan.valid && plan.key == plan_key && plan.n == n;
+    if (hit) {   // (a second, independent look at the shape: the page count per column)
+        for (uint64_t i = 0; i < n && hit; i++) {
+            const uint64_t ps = page_size_of(cols[i].rows, opts);
+            const uint64_t np = cols[i].page_rows ? cols[i].n_pages_in : (cols[i].rows ? (cols[i].rows + ps - 1) / ps : 0);
+            hit = np == plan.col_pages[i];
+        }
+    }
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
     // LZ4 blocks of more than LZC_CH bytes are compressed chunk by chunk (flat pages, the matcher that is free to choose)
     const bool zs_possible = host_codec == SB_CODEC_ZSTD || (adaptive && opts->default_compression == SB_CODEC_ZSTD);
@@ -5202,14 +5230,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (enc_is_binary(c.physical_type) && !c.offsets) return ctx->fail(SB_ERR_INVALID, "offsets is null");
         const uint64_t ps = page_size_of(c.rows, opts);
         const uint64_t np = c.page_rows ? c.n_pages_in : (c.rows + ps - 1) / ps;
+        if (np > c.n_pages_capacity || !c.out_metas) return ctx->fail(SB_ERR_INVALID, "out_metas too small");
+        if (!c.out_pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "out_pages is null");
+        P += np;
+        if (hit) continue;   // (the per-page arithmetic of this shape is in the plan)
         if (c.page_rows) {
             uint64_t sum = 0;
             for (uint64_t q = 0; q < np; q++) sum += c.page_rows[q];
             if (sum != c.rows) return ctx->fail(SB_ERR_INVALID, "page_rows do not add up to rows");
         }
-        if (np > c.n_pages_capacity || !c.out_metas) return ctx->fail(SB_ERR_INVALID, "out_metas too small");
-        if (!c.out_pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "out_pages is null");
-        P += np;
         {
             uint64_t mx = ps;
             if (c.page_rows)
@@ -5236,6 +5265,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
     }
     if (!lz_any) lz_cap = 0;
+    if (hit) {
+        max_tiles = plan.max_tiles;
+        lz_cap = plan.lz_cap;
+    }
     if (lz_cap >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many LZ4 chunks in one call");
     if (P >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many pages in one call");
 
@@ -5277,8 +5310,6 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     size_t off = 0;
     const size_t o_cols = off;
     off = align_up(off + n * sizeof(EncCol), 64);
-    const size_t o_pages = off;
-    off = align_up(off + P * sizeof(EncPage), 64);
     const size_t o_resoff = off;
     off = align_up(off + n * sizeof(uint64_t), 64);
     const size_t upload_bytes = off;
@@ -5301,11 +5332,21 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     off = align_up(off + lz_cap * sizeof(LzChunkDesc), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
-    StageSlot* slot = acquire_slot(ctx, upload_bytes + results_words * sizeof(uint64_t));
+    // staging: [cols | result offsets | readback of the results | (plan miss) the page table]
+    const size_t o_hres = upload_bytes;
+    const size_t o_hpages = align_up(o_hres + results_words * sizeof(uint64_t), 64);
+    StageSlot* slot = acquire_slot(ctx, o_hpages + (hit ? 0 : P * sizeof(EncPage)) + 64);
     if (!slot) return ctx->fail(SB_ERR_EXTERNAL, "hipHostMalloc(staging) failed");
     EncCol* hc = (EncCol*)(slot->host + o_cols);
-    EncPage* hp = (EncPage*)(slot->host + o_pages);
+    EncPage* hp = hit ? nullptr : (EncPage*)(slot->host + o_hpages);
     uint64_t* hro = (uint64_t*)(slot->host + o_resoff);
+    if (!hit) {
+        plan.valid = false;
+        if (!ensure(ctx, plan.pages, P * sizeof(EncPage) + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(page table) failed");
+        plan.col_first.assign(n, 0);
+        plan.col_pages.assign(n, 0);
+        plan.hro.assign(n, 0);
+    }
 
     size_t scratch_off = 0;
     uint64_t pi = 0, res_off = 0;
@@ -5339,6 +5380,12 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const bool direct = !adaptive && !bin && (codec == SB_CODEC_NONE || codec == SB_CODEC_ONEVALUE) &&
                             c.physical_type != SB_TYPE_NULL;
         uint64_t direct_off = 0, k = 0;
+        if (hit) {
+            d.first_page = plan.col_first[i];
+            d.n_pages = plan.col_pages[i];
+            hro[i] = plan.hro[i];
+            continue;
+        }
         if (bin) scratch_off = align_up(scratch_off, 16);
         const size_t col_slot_base = scratch_off;
         uint64_t head_off = 0;
@@ -5417,11 +5464,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         (void)col_slot_base;
         d.n_pages = (uint32_t)k;
         hro[i] = res_off;
+        plan.col_first[i] = d.first_page;
+        plan.col_pages[i] = d.n_pages;
+        plan.hro[i] = res_off;
         res_off += 2 * k + 1;
         if (direct && direct_off > c.out_capacity) return ctx->fail(SB_ERR_INVALID, "out_capacity too small");
     }
     // Dict aux areas after the slots
-    for (uint64_t q = 0; q < P; q++) {
+    for (uint64_t q = 0; q < P && !hit; q++) {
         if (hp[q].aux_bytes) {
             scratch_off = align_up(scratch_off, 16);
             hp[q].aux_off = scratch_off;
@@ -5458,20 +5508,48 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
     }
     scratch_off = align_up(scratch_off, 16);
-    const size_t lz_pool_off = scratch_off;
+    size_t lz_pool_off = scratch_off;
     scratch_off += (size_t)lz_cap * LZC_SLOT;
-    const size_t zpar_off = scratch_off;
+    size_t zpar_off = scratch_off;
     const uint32_t zpar_waves = (uint32_t)std::min<uint64_t>(lz_cap, ZPAR_WAVES);
     if (lz_cap && zs_possible) scratch_off += (size_t)zpar_waves * zstd_scratch_bytes(ZPAR_CH);
+    if (hit) {
+        scratch_off = plan.scratch_total;
+        lz_pool_off = plan.lz_pool_off;
+        zpar_off = plan.zpar_off;
+        max_chunks = plan.max_chunks;
+        any_tiles = plan.any_tiles;
+        any_pages = plan.any_pages;
+        any_compact = plan.any_compact;
+        any_lz4 = plan.any_lz4;
+    }
     if (!ensure(ctx, ctx->scratch, scratch_off + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(scratch) failed");
 
     uint8_t* tb = ctx->tables.p;
     hipError_t e = hipMemcpyAsync(tb, slot->host, upload_bytes, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return check_hip(ctx, e, "table upload");
+    if (!hit) {   // the page table goes to the plan's own device buffer and stays there
+        e = hipMemcpyAsync(plan.pages.p, hp, P * sizeof(EncPage), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return check_hip(ctx, e, "page table upload");
+        plan.key = plan_key;
+        plan.n = n;
+        plan.P = P;
+        plan.max_tiles = max_tiles;
+        plan.max_chunks = max_chunks;
+        plan.lz_cap = lz_cap;
+        plan.any_tiles = any_tiles;
+        plan.any_pages = any_pages;
+        plan.any_compact = any_compact;
+        plan.any_lz4 = any_lz4;
+        plan.scratch_total = scratch_off;
+        plan.lz_pool_off = lz_pool_off;
+        plan.zpar_off = zpar_off;
+        plan.valid = true;
+    }
 
     EncodeArgs a;
     a.cols = (const EncCol*)(tb + o_cols);
-    a.pages = (const EncPage*)(tb + o_pages);
+    a.pages = (const EncPage*)plan.pages.p;
     a.outs = (EncOut*)(tb + o_outs);
     a.scratch = ctx->scratch.p;
     a.status = ctx->d_status;
@@ -5755,7 +5833,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     e = hipGetLastError();
     if (e != hipSuccess) return check_hip(ctx, e, "encode launch");
 
-    uint8_t* hres = slot->host + upload_bytes;
+    uint8_t* hres = slot->host + o_hres;
     e = hipMemcpyAsync(hres, a.results, results_words * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return check_hip(ctx, e, "metas readback");
     (void)hipEventRecord(slot->done, s);

@@ -124,6 +124,20 @@ struct sb_ctx {
     bool profile = false;
     std::vector<sb::ProfSpan> spans;
     std::vector<hipEvent_t> free_events;
+    // The page table of the last write call (sb_write_columns): page arithmetic, scratch layout and launch shape depend only
+    // on the columns' types, row counts, paging and the options — not on their buffers — so a writer that sends chunk after
+    // chunk of one schema (or a benchmark that repeats a call) re-uses the device-resident table and the plan instead of
+    // building and uploading ~170 bytes per page again (65 536 pages of 8192 booleans: 2 ms of host work per call).
+    struct EncPlan {
+        bool valid = false;
+        uint64_t key = 0, n = 0;
+        uint64_t P = 0, max_tiles = 1, max_chunks = 1, lz_cap = 0;
+        bool any_tiles = false, any_pages = false, any_compact = false, any_lz4 = false;
+        size_t scratch_total = 0, lz_pool_off = 0, zpar_off = 0;
+        std::vector<uint32_t> col_first, col_pages;
+        std::vector<uint64_t> hro;
+        sb::DevBuf pages;   // EncPage[P] on the device
+    } enc_plan;
     // side streams: kernels of a call that work on disjoint pages (the selector / emit chains of different column kinds, the
     // three expand kernels of a read) run side by side between a fork and a join on `stream`; seen from outside the call is
     // still one span of work on `stream`.  Not used while profiling (the per-kernel events bracket launches on `stream`).

@@ -3250,8 +3250,11 @@ constexpr uint32_t BIN_LDS_SLOTS = 16384;
 // a CU).  One workgroup per (page, BH_ROWS rows): the tile's bytes are staged in LDS with coalesced 16-byte loads and hashed
 // from there; the selector and the dictionary builder then start from h64.
 constexpr uint32_t BH_ROWS = 2048, BH_LDS_WORDS = 10240;   // 40 KiB of staging: 4 workgroups per CU
+#ifndef BV_ROWS_
+#define BV_ROWS_ 4096
+#endif
+constexpr uint32_t BV_ROWS = BV_ROWS_;   // rows per workgroup of k_enc_bin_verify
 __global__ void __launch_bounds__(WG) k_enc_bin_hash(EncodeArgs a) {
-    __shared__ uint32_t lds[BH_LDS_WORDS];
     const uint32_t page = blockIdx.x + a.page_base;
     const EncPage p = get_page(a, page);
     if (p.codec != CODEC_ON_DEVICE || p.h64_off == ~0ull) return;
@@ -3260,14 +3263,32 @@ __global__ void __launch_bounds__(WG) k_enc_bin_hash(EncodeArgs a) {
     const EncCol c = get_col(a, p.col);
     const uint64_t r1 = min(p.rows, r0 + BH_ROWS);
     uint64_t* h64 = (uint64_t*)(a.scratch + p.h64_off);
+    // Thread = row, eight rows in flight: the offsets of neighbouring rows are neighbours and so are their bytes (a wave's
+    // 64 strings span about a kilobyte), so the loads are near-coalesced without staging the tile in LDS — and with
+    // thousands of tiles in flight nobody waits for a round trip (staged through LDS the kernel took 0.50 ms on C3).
+    auto body = [&](auto bk) {
+        constexpr int U = 8;
+        for (uint64_t base = r0 + threadIdx.x; base < r1; base += (uint64_t)WG * U) {
+            uint64_t b[U], e[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = base + (uint64_t)u * WG;
+                const uint64_t ic = i < r1 ? i : r0;
+                b[u] = bk.beg(ic);
+                e[u] = bk.beg(ic + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = base + (uint64_t)u * WG;
+                if (i < r1) gst64(h64 + i, bin_hash_bytes(bk.values, b[u], e[u], c.values_len));
+            }
+        }
+    };
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
-    if (c.ptype == SB_TYPE_BINARY) {
-        BinKeys<int32_t> bk{c.offsets + p.row0 * 4, c.values, vv};
-        bin_hash_rows_staged<int32_t>(bk, r1, c.values_len, h64, lds, BH_LDS_WORDS * 4, r0, false);
-    } else if (c.ptype == SB_TYPE_LARGE_BINARY) {
-        BinKeys<int64_t> bk{c.offsets + p.row0 * 8, c.values, vv};
-        bin_hash_rows_staged<int64_t>(bk, r1, c.values_len, h64, lds, BH_LDS_WORDS * 4, r0, false);
-    }
+    if (c.ptype == SB_TYPE_BINARY)
+        body(BinKeys<int32_t>{c.offsets + p.row0 * 4, c.values, vv});
+    else if (c.ptype == SB_TYPE_LARGE_BINARY)
+        body(BinKeys<int64_t>{c.offsets + p.row0 * 8, c.values, vv});
 }
 
 // Binary pages whose keys the selector counted with its tag table (distinct_count_tags): the string of EVERY row against
@@ -3278,7 +3299,7 @@ __global__ void __launch_bounds__(WG) k_enc_bin_verify(EncodeArgs a) {
     const uint32_t page = blockIdx.x + a.page_base;
     const EncPage p = get_page(a, page);
     if (p.codec != CODEC_ON_DEVICE || p.h64_off == ~0ull || !p.aux_bytes) return;
-    const uint64_t r0 = (uint64_t)blockIdx.y * BH_ROWS;
+    const uint64_t r0 = (uint64_t)blockIdx.y * BV_ROWS;
     if (r0 >= p.rows) return;
     uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
     if (!bh_fits(p.rows, p.aux_bytes)) return;
@@ -3289,7 +3310,7 @@ __global__ void __launch_bounds__(WG) k_enc_bin_verify(EncodeArgs a) {
         return;
     }
     const EncCol c = get_col(a, p.col);
-    const uint64_t r1 = min(p.rows, r0 + BH_ROWS);
+    const uint64_t r1 = min(p.rows, r0 + BV_ROWS);
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
     const uint16_t* slot16 = (const uint16_t*)(aux + BH_W_SLOT16);
     const uint16_t* rep16 = (const uint16_t*)(aux + BH_W_REP16);
@@ -5677,7 +5698,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         auto launch_verify = [&](int kd_only, hipStream_t st) {
             {
                 KScope k(ctx, "k_enc_bin_verify");
-                k_enc_bin_verify<<<tile_grid, WG, 0, st>>>(aa);
+                k_enc_bin_verify<<<dim3((uint32_t)P, (uint32_t)((max_rows + BV_ROWS - 1) / BV_ROWS)), WG, 0, st>>>(aa);
             }
             aa.redo = 1;
             for (int kd : kinds)

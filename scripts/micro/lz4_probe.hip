@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(64) k_dec(const uint8_t* comp, uint32_t cap, c
 }
 __global__ void __launch_bounds__(64) k_zenc(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t* sizes, uint8_t* scratch) {
     __shared__ ZEncLds lds;
-    const uint32_t sz = zstd_compress_wave(src, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK));
+    // inputs of up to 16 KiB are compressed the way the chunk kernel does it (a frame of its own: zstd_compress_block_alone)
+    const uint32_t sz = n <= 16384 ? zstd_compress_block_alone(src, n, 0, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK), 16384)
+                                   : zstd_compress_wave(src, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK));
     if (threadIdx.x == 0) sizes[blockIdx.x] = sz;
 }
 __global__ void __launch_bounds__(64) k_zdec(const uint8_t* comp, uint32_t cap, const uint32_t* sizes, uint8_t* out, uint32_t n, uint32_t* errs, uint8_t* zlit) {

@@ -25,6 +25,8 @@ def column(kind, rows, seed):
     if kind == "bool":
         return dict(ptype=W.T_BOOL, nullable=True, rows=rows, values=W.pack_bits(rng.random(rows) < 0.5),
                     validity=W.pack_bits(rng.random(rows) >= 0.1), offsets=None)
+    if kind == "offs":   # what the offsets of short strings look like: an increasing Int32 column, steps of 2..4
+        return dict(ptype=W.T_I32, nullable=False, rows=rows, values=np.cumsum(rng.integers(2, 5, rows)).astype(np.int32), validity=None, offsets=None)
     if kind == "i64":
         return W.c1_int64(seed) if rows == 1_000_000 else dict(ptype=W.T_I64, nullable=False, rows=rows, values=rng.integers(0, 2**63 - 1, rows), validity=None, offsets=None)
     raise SystemExit("unknown kind " + kind)

@@ -748,9 +748,14 @@ __device__ __forceinline__ void inflate_one(const InflateJob& j, Status* st, ZWo
 // takes up to 64 consecutive jobs: the Zstd frames among them that qualify (sb_zstd.h, z_lane_frame) have their FSE
 // sequence streams decoded LANE PER FRAME into the wave's record arena first — 64 serial state chains side by side
 // instead of one after the other — and the wave then executes the jobs one by one from the records.
+union InflateLds {   // the one-wave decoder's workspace and the lane-per-stream Huffman phase never live at the same time
+    ZWork wk;
+    ZHufLanes hl;
+};
 __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st,
                                                 uint8_t* zlit, uint64_t* zrec) {
-    __shared__ ZWork wk;
+    __shared__ InflateLds u;
+    ZWork& wk = u.wk;
     __shared__ ZLaneTabs zt;
     __shared__ uint8_t s_win[64 * 10 + 8];
     __shared__ uint16_t s_pos[65];
@@ -779,11 +784,66 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
         InflateJob mine;
         mine.codec = 0xFFFFFFFFu;
         mine.src = nullptr;
+        mine.dst = nullptr;
         mine.csize = mine.out_len = 0;
         if (lane < nb) mine = jobs[base + lane];
         const bool zs = lane < nb && mine.codec == SB_CODEC_ZSTD;
+        // ---- phase H: literals-only frames, 16 at a time, lane per stream (sb_zstd.h)
+        ZHufFrame hf;
+        hf.ls = nullptr;
+        hf.dst = mine.dst;
+        hf.lleft = hf.regen = 0;
+        const bool lit_only = zs && z_lane_litonly(mine.src, mine.csize, mine.out_len, &hf.ls, &hf.lleft, &hf.regen);
+        uint64_t todo = __ballot(lit_only);
+        uint64_t done_m = 0;
+        if (todo) {
+            ZHufLanes& H = u.hl;
+            while (todo) {
+                // the lowest ZH_GROUP frames of `todo`: frame of lane L gets slot g = its rank
+                const uint32_t my_g = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0));
+                const bool in_group = ((todo >> lane) & 1) && my_g < ZH_GROUP;
+                const uint64_t gm = __ballot(in_group);
+                if (in_group) H.fr[my_g] = hf;
+                const uint32_t ng = (uint32_t)__popcll(gm);
+                __syncthreads();
+                if (lane < ng) z_lane_huf_table(H, lane);
+                __syncthreads();
+                bool ok = true, act = false;
+                const uint32_t g = lane >> 2, j = lane & 3;
+                if (g < ng && H.bits[g]) {
+                    act = true;
+                    const ZHufFrame f = H.fr[g];
+                    const uint8_t* q = f.ls + H.str0[g];
+                    const uint32_t left = f.lleft - H.str0[g];
+                    const uint32_t s1 = ldu16(q), s2 = ldu16(q + 2), s3 = ldu16(q + 4);
+                    const uint32_t per = (f.regen + 3) / 4;
+                    if (6 + s1 + s2 + s3 > left || per * 3 > f.regen) {
+                        ok = false;
+                    } else {
+                        const uint32_t so = j == 0 ? 0u : j == 1 ? s1 : j == 2 ? s1 + s2 : s1 + s2 + s3;
+                        const uint32_t sn = j == 0 ? s1 : j == 1 ? s2 : j == 2 ? s3 : left - 6 - s1 - s2 - s3;
+                        const uint32_t outn = j < 3 ? per : f.regen - 3 * per;
+                        ok = z_lane_huf_stream(H.tab[g], H.bits[g], q + 6 + so, sn, f.dst + j * per, outn);
+                    }
+                }
+                // a frame is done when its four streams decoded; anything else is left to the one-wave decoder (and its errors)
+                const uint64_t okm = __ballot(act && ok);
+                uint64_t grp_done = 0;
+                for (uint32_t gg = 0; gg < ng; gg++)
+                    if (((okm >> (4 * gg)) & 15) == 15) grp_done |= 1ull << gg;
+                if (in_group && ((grp_done >> my_g) & 1)) done_m |= 1ull << lane;   // (per lane; combined below)
+                todo &= ~gm;
+                __syncthreads();
+            }
+            done_m = __ballot(done_m != 0);
+            if (threadIdx.x == 0) wk.pre_built = 0;   // (the phase used ZWork's LDS)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __syncthreads();
+        }
         // phase 0 (lane per frame): how many sequences, and does the frame qualify
-        uint32_t cnt = zs ? z_lane_frame(mine.src, mine.csize, mine.out_len, zt, nullptr, 0) : ZPRE_NONE;
+        uint32_t cnt = (zs && !((done_m >> lane) & 1)) ? z_lane_frame(mine.src, mine.csize, mine.out_len, zt, nullptr, 0) : ZPRE_NONE;
         uint32_t start = 0;
         while (start < nb) {
             const uint32_t need = (lane >= start && cnt != ZPRE_NONE) ? cnt : 0u;
@@ -804,6 +864,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             // phase 2 (the wave per job, in queue order)
             for (uint32_t k = start; k < end; k++) {
+                if ((done_m >> k) & 1) continue;   // decoded in phase H
                 const uint32_t k_ok = (uint32_t)__builtin_amdgcn_readlane((int)(ok ? 1u : 0u), (int)k);
                 const uint32_t k_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)k);
                 inflate_one(jobs[base + k], st, wk, my_lit, s_win, s_pos, k_ok ? arena + k_off : nullptr);

@@ -23,7 +23,7 @@ struct ZSeq {
 };
 struct ZWork {  // per-wave LDS workspace (~12 KB)
     ZFse ll[512], of[256], ml[512];
-    uint8_t hsym[2048], hlen[2048];
+    uint16_t htab[2048];   // Huffman decoding table: symbol | code length << 8 per code of huf_bits bits
     uint8_t wts[256];
     int16_t norm[64];
     uint16_t next[64];
@@ -75,15 +75,19 @@ __device__ __forceinline__ uint32_t z_peek(const uint8_t* p, int64_t bitpos, int
     return (uint32_t)((w & ((1ull << avail) - 1)) << (int)(-lo));
 }
 
+__device__ inline bool z_fse_build2(ZFse* t, uint16_t* next, const int16_t* norm, int nsym, int log);
 __device__ inline bool z_fse_build(ZFse* t, ZWork* wk, const int16_t* norm, int nsym, int log) {
+    return z_fse_build2(t, wk->next, norm, nsym, log);
+}
+__device__ inline bool z_fse_build2(ZFse* t, uint16_t* next, const int16_t* norm, int nsym, int log) {
     const int size = 1 << log;
     int high = size - 1;
     for (int s = 0; s < nsym; s++) {
         if (norm[s] == -1) {
             t[high--].symbol = (uint8_t)s;
-            wk->next[s] = 1;
+            next[s] = 1;
         } else {
-            wk->next[s] = (uint16_t)norm[s];
+            next[s] = (uint16_t)norm[s];
         }
     }
     const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
@@ -98,7 +102,7 @@ __device__ inline bool z_fse_build(ZFse* t, ZWork* wk, const int16_t* norm, int 
     if (pos != 0) return false;
     for (int i = 0; i < size; i++) {
         const uint8_t s = t[i].symbol;
-        const uint16_t ns = wk->next[s]++;
+        const uint16_t ns = next[s]++;
         const int nb = log - (31 - __clz((int)ns));
         t[i].nbits = (uint8_t)nb;
         t[i].base = (uint16_t)(((uint32_t)ns << nb) - (uint32_t)size);
@@ -182,8 +186,7 @@ __device__ inline bool z_huf_build(ZWork* wk, int nw) {
             if (wk->wts[s] != wt) continue;
             const uint32_t span = 1u << (wt - 1);
             for (uint32_t k = 0; k < span; k++) {
-                wk->hsym[code + k] = (uint8_t)s;
-                wk->hlen[code + k] = (uint8_t)(max_bits + 1 - wt);
+                wk->htab[code + k] = (uint16_t)((uint32_t)s | ((uint32_t)(max_bits + 1 - wt) << 8));
             }
             code += span;
         }
@@ -252,49 +255,11 @@ __device__ inline uint32_t z_huf_read(ZWork* wk, const uint8_t* src, uint32_t n)
     return used;
 }
 
-// one Huffman stream (executed by one lane); returns false on error.  The stream is read backwards through a 128-bit
-// register window refilled with one unaligned 16-byte load every ~10 symbols (a byte-wise peek per symbol costs an HBM /
-// L2 round trip per symbol).
+// one Huffman stream (executed by one lane); returns false on error: z_lane_huf_stream (below) with the wave's table —
+// one table read per symbol, a register window refilled one load ahead, eight output bytes per store
+__device__ inline bool z_lane_huf_stream(const uint16_t* tab, uint32_t mb, const uint8_t* sb_, uint32_t sn, uint8_t* dst, uint32_t outn);
 __device__ inline bool z_huf_stream(const ZWork* wk, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out) {
-    if (n == 0 || src[n - 1] == 0) return false;
-    int64_t bitpos = (int64_t)(n - 1) * 8 + (31 - __clz((int)src[n - 1]));
-    const int mb = (int)wk->huf_bits;
-    if (n < 16) {   // short stream: the byte-wise reader
-        for (uint32_t i = 0; i < out; i++) {
-            const uint32_t idx = z_peek(src, bitpos, mb);
-            dst[i] = wk->hsym[idx];
-            bitpos -= wk->hlen[idx];
-        }
-        return bitpos == 0;
-    }
-    int64_t wbase = -1;          // bit index of the window's lowest bit (a multiple of 8); -1 = nothing loaded
-    uint64_t lo = 0, hi = 0;
-    for (uint32_t i = 0; i < out; i++) {
-        int64_t from = bitpos - mb;                 // lowest bit of the peek (may be < 0 at the very start of the stream)
-        const int64_t need = from < 0 ? 0 : from;
-        if (wbase < 0 || need < wbase) {
-            int64_t b = (bitpos >> 3) - 15;          // window = bytes [b, b + 16): its top reaches the current position
-            if (b < 0) b = 0;
-            if (b > (int64_t)n - 16) b = (int64_t)n - 16;
-            const u32x4 v = ldu128(src + b);
-            lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-            hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-            wbase = b * 8;
-        }
-        uint32_t idx;
-        if (from >= 0) {
-            const uint32_t rel = (uint32_t)(from - wbase);
-            const uint64_t w = rel >= 64 ? hi >> (rel - 64) : (rel ? (lo >> rel) | (hi << (64 - rel)) : lo);
-            idx = (uint32_t)w & ((1u << mb) - 1);
-        } else {                                     // fewer than mb bits left: the missing low bits read as 0
-            const uint32_t avail = (uint32_t)bitpos;
-            idx = avail ? (((uint32_t)lo & ((1u << avail) - 1)) << (uint32_t)(-from)) : 0u;   // (wbase == 0 here)
-        }
-        dst[i] = wk->hsym[idx];
-        bitpos -= wk->hlen[idx];
-        if (bitpos < 0) return false;
-    }
-    return bitpos == 0;
+    return z_lane_huf_stream(wk->htab, wk->huf_bits, src, n, dst, out);
 }
 
 __constant__ int16_t Z_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
@@ -624,6 +589,217 @@ __device__ uint32_t z_lane_frame(const uint8_t* src, uint32_t n, uint32_t out_le
     if (ip != n) return ZPRE_NONE;     // more than one frame: the one-wave path walks them
     (void)out_len;
     return total;
+}
+
+// ---- literals-only frames decoded LANE PER STREAM (k_inflate, batches): a frame whose one block is a Huffman-coded literals
+// section of four streams and no sequences — what this library's encoder writes for pieces where sequences do not pay
+// (sb_zstd_enc.h) — is four serial bit streams; on the one-wave path they occupy 4 lanes of 64 and a lane pays ~800 cycles
+// per symbol (two table reads, a byte store and an exposed refill).  Here 16 such frames are decoded together: lane 4 g + j
+// takes stream j of frame g, with the frame's table in LDS (one u16 per code: symbol | length << 8, codes of up to ZH_MAXBITS
+// bits), a 128-bit register window refilled one load ahead, and eight output bytes per store.
+constexpr uint32_t ZH_MAXBITS = 9, ZH_GROUP = 16;
+struct ZHufFrame {   // a literals-only frame (filled by the lane that owns the job)
+    const uint8_t* ls;   // literals section payload: tree description, jump table, streams
+    uint8_t* dst;
+    uint32_t lleft;      // bytes of that payload
+    uint32_t regen;      // bytes it regenerates (= the frame's content)
+};
+struct ZHufLanes {   // phase workspace (shares its LDS with ZWork)
+    uint16_t tab[ZH_GROUP][1 << ZH_MAXBITS];
+    uint8_t wts[ZH_GROUP][256];
+    ZFse fse[ZH_GROUP][64];
+    int16_t norm[ZH_GROUP][16];
+    uint16_t next[ZH_GROUP][16];
+    ZHufFrame fr[ZH_GROUP];
+    uint32_t bits[ZH_GROUP];     // code bits of frame g's table (0: not decodable here)
+    uint32_t str0[ZH_GROUP];     // offset of the jump table inside ls
+};
+// One frame src[0, n) with content out_len: is it a literals-only frame of the shape above?  (lane per frame)
+__device__ inline bool z_lane_litonly(const uint8_t* src, uint32_t n, uint32_t out_len, const uint8_t** ls, uint32_t* lleft, uint32_t* regen_out) {
+    if (n < 12 || ldu32(src) != 0xFD2FB528u) return false;
+    uint32_t ip = 4;
+    const uint8_t fhd = ldu8(src + ip++);
+    const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+    if ((fhd & 0x08) || did) return false;
+    if (!single) ip += 1;
+    const uint32_t fcs_bytes = fcs_flag == 0 ? (single ? 1u : 0u) : (1u << fcs_flag);
+    if (fcs_bytes == 0 || fcs_bytes == 8 || n - ip < fcs_bytes + 3) return false;
+    uint32_t fcs = 0;
+    for (uint32_t i = 0; i < fcs_bytes; i++) fcs |= (uint32_t)ldu8(src + ip + i) << (8 * i);
+    if (fcs_bytes == 2) fcs += 256;
+    if (fcs != out_len) return false;
+    ip += fcs_bytes;
+    const uint32_t bh = (uint32_t)ldu8(src + ip) | ((uint32_t)ldu8(src + ip + 1) << 8) | ((uint32_t)ldu8(src + ip + 2) << 16);
+    ip += 3;
+    if (!(bh & 1) || ((bh >> 1) & 3) != 2) return false;       // one block, the last, compressed
+    const uint32_t bsize = bh >> 3;
+    if (bsize > 128 * 1024 || n - ip < bsize || bsize < 8) return false;
+    if (ip + bsize + (checksum ? 4u : 0u) != n) return false;
+    const uint8_t* bs = src + ip;
+    const uint8_t b0 = ldu8(bs);
+    const uint32_t ltype = b0 & 3, sf = (b0 >> 2) & 3;
+    if (ltype != 2 || sf == 0) return false;                     // Huffman with its tree, four streams
+    uint32_t bp = 1, regen, csize;
+    if (sf == 1) {
+        const uint32_t v = (b0 >> 4) | ((uint32_t)ldu8(bs + bp) << 4) | ((uint32_t)ldu8(bs + bp + 1) << 12);
+        bp += 2;
+        regen = v & 0x3FF;
+        csize = v >> 10;
+    } else if (sf == 2) {
+        const uint32_t v = (b0 >> 4) | ((uint32_t)ldu8(bs + bp) << 4) | ((uint32_t)ldu8(bs + bp + 1) << 12) | ((uint32_t)ldu8(bs + bp + 2) << 20);
+        bp += 3;
+        regen = v & 0x3FFF;
+        csize = v >> 14;
+    } else {
+        const uint64_t v = (b0 >> 4) | ((uint64_t)ldu8(bs + bp) << 4) | ((uint64_t)ldu8(bs + bp + 1) << 12) |
+                           ((uint64_t)ldu8(bs + bp + 2) << 20) | ((uint64_t)ldu8(bs + bp + 3) << 28);
+        bp += 4;
+        regen = (uint32_t)(v & 0x3FFFF);
+        csize = (uint32_t)(v >> 18);
+    }
+    if (bsize - bp < csize + 1 || bp + csize + 1 != bsize) return false;   // the sequences section is its one byte ...
+    if (ldu8(bs + bp + csize) != 0) return false;                          // ... "no sequences"
+    if (regen != out_len || regen < 64 || csize < 16) return false;
+    *ls = bs + bp;
+    *lleft = csize;
+    *regen_out = regen;
+    return true;
+}
+// The tree of frame g (lane g < ZH_GROUP): weights (direct or FSE-coded) -> H.tab[g]; H.bits[g] = code bits or 0.
+__device__ inline void z_lane_huf_table(ZHufLanes& H, uint32_t g) {
+    const uint8_t* src = H.fr[g].ls;
+    const uint32_t n = H.fr[g].lleft;
+    H.bits[g] = 0;
+    uint8_t* wts = H.wts[g];
+    const uint8_t hb = ldu8(src);
+    int nw;
+    uint32_t used;
+    if (hb >= 128) {
+        nw = hb - 127;
+        const uint32_t bytes = (uint32_t)(nw + 1) / 2;
+        if (n < 1 + bytes) return;
+        for (int i = 0; i < nw; i++) {
+            const uint8_t b = ldu8(src + 1 + i / 2);
+            wts[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+        used = 1 + bytes;
+    } else {
+        const uint32_t clen = hb;
+        if (n < 1 + clen || clen < 2) return;
+        int nsym, log;
+        const uint32_t hsz = z_fse_header(src + 1, clen, 12, 6, H.norm[g], &nsym, &log);
+        if (!hsz || hsz >= clen) return;
+        ZFse* t = H.fse[g];
+        if (!z_fse_build2(t, H.next[g], H.norm[g], nsym, log)) return;
+        const uint8_t* bs = src + 1 + hsz;
+        const uint32_t bn = clen - hsz;
+        if (ldu8(bs + bn - 1) == 0) return;
+        int64_t bitpos = (int64_t)(bn - 1) * 8 + (31 - __clz((int)ldu8(bs + bn - 1)));
+        uint32_t s1 = z_peek(bs, bitpos, log);
+        bitpos -= log;
+        uint32_t s2 = z_peek(bs, bitpos, log);
+        bitpos -= log;
+        nw = 0;
+        for (;;) {
+            if (nw >= 254) return;
+            wts[nw++] = t[s1].symbol;
+            if (bitpos < t[s1].nbits) {
+                wts[nw++] = t[s2].symbol;
+                break;
+            }
+            {
+                const uint32_t nb = t[s1].nbits;
+                s1 = t[s1].base + z_peek(bs, bitpos, (int)nb);
+                bitpos -= nb;
+            }
+            wts[nw++] = t[s2].symbol;
+            if (bitpos < t[s2].nbits) {
+                wts[nw++] = t[s1].symbol;
+                break;
+            }
+            {
+                const uint32_t nb = t[s2].nbits;
+                s2 = t[s2].base + z_peek(bs, bitpos, (int)nb);
+                bitpos -= nb;
+            }
+        }
+        used = 1 + clen;
+    }
+    uint32_t total = 0;
+    for (int i = 0; i < nw; i++) {
+        if (wts[i] > 11) return;
+        total += wts[i] ? (1u << (wts[i] - 1)) : 0;
+    }
+    if (total == 0) return;
+    const int max_bits = 32 - __clz((int)total);
+    const uint32_t left = (1u << max_bits) - total;
+    if (left == 0 || (left & (left - 1)) || max_bits > (int)ZH_MAXBITS) return;
+    wts[nw] = (uint8_t)(32 - __clz((int)left));
+    const int nn = nw + 1;
+    // start of every weight class (codes in increasing weight, symbols of one weight in symbol order), then one pass
+    uint32_t start[12], cnt[12];
+    for (int w = 0; w < 12; w++) cnt[w] = 0;
+    for (int sy = 0; sy < nn; sy++) cnt[wts[sy]]++;
+    uint32_t code = 0;
+    for (int w = 1; w <= max_bits; w++) {
+        start[w] = code;
+        code += cnt[w] << (w - 1);
+    }
+    uint16_t* tab = H.tab[g];
+    for (int w = 1; w <= max_bits; w++) {   // (per weight: no register array indexed by a loaded value)
+        uint32_t c = start[w];
+        const uint32_t span = 1u << (w - 1);
+        const uint16_t lenbits = (uint16_t)((max_bits + 1 - w) << 8);
+        if (!cnt[w]) continue;
+        for (int sy = 0; sy < nn; sy++) {
+            if (wts[sy] != w) continue;
+            for (uint32_t k = 0; k < span; k++) tab[c + k] = (uint16_t)sy | lenbits;
+            c += span;
+        }
+    }
+    if (n < used + 6) return;
+    H.str0[g] = used;
+    H.bits[g] = (uint32_t)max_bits;
+}
+// One stream sb_[0, sn) -> outn bytes at dst, by one lane; table: 2^mb entries.  Returns false on a malformed stream.
+__device__ inline bool z_lane_huf_stream(const uint16_t* tab, uint32_t mb, const uint8_t* sb_, uint32_t sn, uint8_t* dst, uint32_t outn) {
+    if (sn == 0) return false;
+    const uint8_t lastb = ldu8(sb_ + sn - 1);
+    if (lastb == 0) return false;
+    // window: W0 = stream bits [top - 64, top), W1 = the 64 below; `used` bits of W0 are consumed (the end mark first)
+    auto load8 = [&](int32_t byte_off) -> uint64_t {   // bytes [byte_off, byte_off + 8) of the stream; below its start: 0
+        if (byte_off >= 0) return ldu64(sb_ + byte_off);
+        uint64_t v = 0;
+        for (int32_t k = byte_off < -8 ? 8 : -byte_off; k < 8; k++) v |= (uint64_t)ldu8(sb_ + byte_off + k) << (8 * k);
+        return v;
+    };
+    int32_t off = (int32_t)sn - 8;             // byte offset of W0
+    uint64_t W0 = load8(off), W1 = load8(off - 8), W2 = load8(off - 16);
+    uint32_t used = 8 - (31 - (uint32_t)__clz((int)lastb));   // bits above the end mark, and the mark itself
+    int32_t left = (int32_t)sn * 8 - (int32_t)used;           // stream bits not consumed yet
+    uint64_t acc = 0;
+    uint32_t i = 0;
+    for (; i < outn; i++) {
+        if (used >= 64) {
+            W0 = W1;
+            W1 = W2;
+            off -= 8;
+            W2 = load8(off - 16);            // (needed 128 bits from now: its latency hides behind ~20 symbols)
+            used -= 64;
+        }
+        const uint64_t top = used ? (W0 << used) | (W1 >> (64 - used)) : W0;
+        const uint32_t e = tab[(uint32_t)(top >> (64 - mb))];
+        const uint32_t len = e >> 8;
+        used += len;
+        left -= (int32_t)len;
+        acc |= (uint64_t)(e & 255) << (8 * (i & 7));
+        if ((i & 7) == 7) {
+            stu64(dst + i - 7, acc);
+            acc = 0;
+        }
+    }
+    for (uint32_t k = outn & ~7u; k < outn; k++) *(gptr)(dst + k) = (uint8_t)(acc >> (8 * (k & 7)));
+    return left == 0;
 }
 
 // sets one of the three sequence tables according to its compression mode; returns bytes consumed

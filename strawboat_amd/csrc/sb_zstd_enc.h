@@ -19,6 +19,7 @@ namespace sb {
 
 constexpr uint32_t ZE_BLOCK = 128 * 1024;
 constexpr uint32_t ZE_HUF_MAXBITS = 11;
+constexpr uint32_t ZE_LITONLY_MAXBITS = 9;   // == ZH_MAXBITS (sb_zstd.h): literals-only pieces are read lane per stream
 
 struct ZeSeq {       // 8 bytes per sequence in HBM
     uint32_t ll;
@@ -32,13 +33,18 @@ struct ZeSymTT {
 struct ZEncLds {
     Lz4EncLds<12, 13> lz;            // matcher; lz.out doubles as the bit window of the Huffman streams
     uint32_t hist[256];
-    uint16_t hcode[132];
-    uint8_t hlen[132];
+    uint16_t hcode[256];
+    uint8_t hlen[256];
     uint16_t ll_st[64], ml_st[64], of_st[32];   // FSE state tables (predefined distributions)
     ZeSymTT ll_tt[36], ml_tt[53], of_tt[29];
-    uint16_t h_sorted[132];          // Huffman build scratch
-    uint32_t h_cnt[264];
-    int16_t h_parent[264];
+    uint16_t h_sorted[256];          // Huffman build scratch
+    uint32_t h_cnt[512];
+    int16_t h_parent[512];
+    // FSE coding of the Huffman weights (alphabets of more than 128 symbols: RFC 8878 4.2.1.2)
+    uint16_t w_st[64];
+    ZeSymTT w_tt[13];
+    int16_t w_norm[13];
+    uint8_t w_val[256];
     uint32_t misc[8];
     // one batch of sequences, prepared by all lanes for lane 0: codes + extra-bit values + the FSE transforms of the codes
     uint32_t sq_code[64], sq_ll[64], sq_ml[64], sq_of[64];
@@ -212,6 +218,230 @@ __device__ inline uint32_t ze_huf_build(ZEncLds& Z, uint32_t max_sym) {
     return maxd;
 }
 
+// The same tree by the whole wave (all lanes call it, the result is uniform), for alphabets of up to 256 symbols: the
+// sort (a rank count per symbol) and the canonical codes (ballots per code length) are lane-parallel; the two-queue merge
+// and the depths stay on lane 0 (255 steps).  Returns the longest code's bits, 0 if no valid tree.
+__device__ inline uint32_t ze_huf_build_wave(ZEncLds& Z, uint32_t max_sym, uint32_t max_bits = ZE_HUF_MAXBITS) {
+    const uint32_t lane = threadIdx.x & 63;
+    // rank of every present symbol by (count, symbol)
+    uint32_t mycnt[4], myrank[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t sy = lane + 64 * j;
+        mycnt[j] = sy <= max_sym ? Z.hist[sy] : 0u;
+        myrank[j] = 0;
+    }
+    uint32_t ns = 0;
+    for (uint32_t o = 0; o <= max_sym; o++) {
+        const uint32_t c = Z.hist[o];   // (uniform address: broadcast read)
+        if (!c) continue;
+        ns++;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t sy = lane + 64 * j;
+            if (mycnt[j] && (c < mycnt[j] || (c == mycnt[j] && o < sy))) myrank[j]++;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t sy = lane + 64 * j;
+        if (sy < 256) Z.hlen[sy] = 0;
+        if (mycnt[j]) Z.h_sorted[myrank[j]] = (uint16_t)sy;
+    }
+    wave_sync();
+    if (ns < 2) return 0;
+    if (lane == 0) {
+        for (uint32_t k = 0; k < ns; k++) Z.h_cnt[k] = Z.hist[Z.h_sorted[k]];
+        uint32_t leaf = 0, inode = ns, next_i = ns;
+        auto take = [&]() -> uint32_t {
+            if (leaf < ns && (inode >= next_i || Z.h_cnt[leaf] <= Z.h_cnt[inode])) return leaf++;
+            return inode++;
+        };
+        for (uint32_t k = 0; k + 1 < ns; k++) {
+            const uint32_t a = take(), b = take();
+            Z.h_cnt[next_i] = Z.h_cnt[a] + Z.h_cnt[b];
+            Z.h_parent[a] = (int16_t)next_i;
+            Z.h_parent[b] = (int16_t)next_i;
+            next_i++;
+        }
+        const uint32_t root = next_i - 1;
+        Z.h_parent[root] = -1;
+        for (uint32_t k = root; k-- > 0;) Z.h_cnt[k] = (Z.h_parent[k] == (int16_t)root ? 0u : Z.h_cnt[Z.h_parent[k]]) + 1;   // depth
+        uint32_t maxd = 0;
+        for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
+        bool ok = true;
+        if (maxd > max_bits) {   // clamp to 11 bits and repair the Kraft sum (as ze_huf_build)
+            uint32_t K = 0;
+            for (uint32_t k = 0; k < ns; k++) {
+                if (Z.h_cnt[k] > max_bits) Z.h_cnt[k] = max_bits;
+                K += 1u << (max_bits - Z.h_cnt[k]);
+            }
+            const uint32_t full = 1u << max_bits;
+            for (uint32_t L = max_bits - 1; K > full && L >= 1; L--)
+                for (uint32_t k = 0; k < ns && K > full; k++)
+                    if (Z.h_cnt[k] == L) {
+                        Z.h_cnt[k] = L + 1;
+                        K -= 1u << (max_bits - L - 1);
+                    }
+            if (K > full) ok = false;
+            uint32_t D = full - K;
+            for (uint32_t k = ns; ok && k-- > 0 && D;) {
+                while (Z.h_cnt[k] > 1 && (1u << (max_bits - Z.h_cnt[k])) <= D) {
+                    D -= 1u << (max_bits - Z.h_cnt[k]);
+                    Z.h_cnt[k]--;
+                }
+            }
+            if (D) ok = false;
+            maxd = 0;
+            for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
+        }
+        for (uint32_t k = 0; k < ns && ok; k++) Z.hlen[Z.h_sorted[k]] = (uint8_t)Z.h_cnt[k];
+        Z.misc[0] = ok ? maxd : 0u;
+    }
+    wave_sync();
+    const uint32_t maxd = Z.misc[0];
+    if (!maxd) return 0;
+    // canonical codes: longest codes first, symbols of one length in symbol order
+    uint32_t ml[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ml[j] = Z.hlen[(lane + 64 * j) & 255];
+    uint32_t code = 0;
+    for (uint32_t len = maxd; len >= 1; len--) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t m = __ballot(ml[j] == len && lane + 64 * j <= max_sym);
+            if (ml[j] == len && lane + 64 * j <= max_sym) Z.hcode[lane + 64 * j] = (uint16_t)(code + before + lane_rank(m));
+            before += (uint32_t)__popcll(m);
+        }
+        code = (code + before) >> 1;
+    }
+    wave_sync();
+    return maxd;
+}
+
+// The tree description for more than 128 symbols: the weights of symbols 0 .. max_sym - 1, FSE-coded with two interleaved
+// states (RFC 8878 4.2.1.2; HUF_compressWeights upstream).  Lane 0 only; returns the bytes written at dst (header byte =
+// compressed size < 128, table description, stream), 0 when the weights do not compress into that.
+__device__ inline uint32_t ze_huf_weights_fse(ZEncLds& Z, uint32_t max_sym, uint32_t hbits, uint8_t* dst) {
+    const uint32_t n = max_sym;   // weights written (the last symbol's weight is implied)
+    if (n < 2) return 0;
+    uint32_t cnt[13] = {0}, maxw = 0;
+    for (uint32_t sy = 0; sy < n; sy++) {
+        const uint32_t w = Z.hlen[sy] ? hbits + 1 - Z.hlen[sy] : 0;
+        Z.w_val[sy] = (uint8_t)w;
+        cnt[w]++;
+        maxw = max(maxw, w);
+    }
+    for (uint32_t w = 0; w <= maxw; w++)
+        if (cnt[w] == n) return 0;     // one weight only: not representable this way
+    // table log: at most 6, and small enough for the number of weights (FSE_optimalTableLog)
+    uint32_t log = 6;
+    while (log > 5 && (1u << log) > n) log--;
+    const uint32_t size = 1u << log;
+    // normalisation: proportional, every present weight at least 1, the largest takes the rounding
+    uint32_t tot = 0, big = 0;
+    for (uint32_t w = 0; w <= maxw; w++) {
+        uint32_t v = 0;
+        if (cnt[w]) v = max(1u, (uint32_t)(((uint64_t)cnt[w] * size + n / 2) / n));
+        Z.w_norm[w] = (int16_t)v;
+        tot += v;
+        if (cnt[w] > cnt[big]) big = w;
+    }
+    if (tot != size) {
+        const int32_t fix = (int32_t)size - (int32_t)tot;
+        if ((int32_t)Z.w_norm[big] + fix < 1) return 0;
+        Z.w_norm[big] = (int16_t)((int32_t)Z.w_norm[big] + fix);
+    }
+    // table description (FSE_writeNCount; the inverse of z_fse_header)
+    uint8_t* out = dst + 1;
+    {
+        uint64_t acc = 0;
+        uint32_t nb = 0;
+        uint8_t* q = out;
+        auto put = [&](uint32_t v, uint32_t bits) {
+            acc |= (uint64_t)v << nb;
+            nb += bits;
+            while (nb >= 8) {
+                *q++ = (uint8_t)acc;
+                acc >>= 8;
+                nb -= 8;
+            }
+        };
+        put(log - 5, 4);
+        int32_t remaining = (int32_t)size + 1, threshold = (int32_t)size, nbits = (int32_t)log + 1;
+        uint32_t sy = 0;
+        bool prev0 = false;
+        while (remaining > 1 && sy <= maxw) {
+            if (prev0) {   // run of zero probabilities: 2-bit repeat counts
+                uint32_t z = 0;
+                while (sy + z <= maxw && Z.w_norm[sy + z] == 0) z++;
+                uint32_t r = z;
+                while (r >= 3) {
+                    put(3, 2);
+                    r -= 3;
+                }
+                put(r, 2);
+                sy += z;
+                prev0 = false;
+                continue;
+            }
+            const int32_t count = Z.w_norm[sy];
+            const int32_t mx = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            int32_t c = count + 1;
+            if (c >= threshold) c += mx;
+            put((uint32_t)c, (uint32_t)(nbits - (c < mx ? 1 : 0)));
+            sy++;
+            prev0 = count == 0;
+            while (remaining < threshold) {
+                nbits--;
+                threshold >>= 1;
+            }
+        }
+        if (remaining != 1) return 0;
+        if (nb) *q++ = (uint8_t)acc;
+        out = q;
+    }
+    // encoding table, then the weights from the last to the first (FSE_compress_usingCTable)
+    ze_build_ctable(Z.w_norm, (int)maxw + 1, (int)log, Z.w_st, Z.w_tt, (uint8_t*)Z.sq_code);
+    auto init_state = [&](uint32_t sym) -> uint32_t {
+        const uint32_t nbo = (uint32_t)(Z.w_tt[sym].delta_nb_bits + (1 << 15)) >> 16;
+        const uint32_t value = (nbo << 16) - (uint32_t)Z.w_tt[sym].delta_nb_bits;
+        return Z.w_st[(value >> nbo) + Z.w_tt[sym].delta_find_state];
+    };
+    ZeBits bs{out, 0, 0};
+    auto enc = [&](uint32_t& st, uint32_t sym) {
+        const uint32_t nbo = (uint32_t)(st + Z.w_tt[sym].delta_nb_bits) >> 16;
+        bs.add(st, nbo);
+        bs.flush();
+        st = Z.w_st[(st >> nbo) + Z.w_tt[sym].delta_find_state];
+    };
+    uint32_t ip = n, s1, s2;
+    if (n & 1) {
+        s1 = init_state(Z.w_val[--ip]);
+        s2 = init_state(Z.w_val[--ip]);
+        enc(s1, Z.w_val[--ip]);
+    } else {
+        s2 = init_state(Z.w_val[--ip]);
+        s1 = init_state(Z.w_val[--ip]);
+    }
+    while (ip > 0) {
+        enc(s2, Z.w_val[--ip]);
+        if (ip == 0) break;   // (cannot happen: an even number is left)
+        enc(s1, Z.w_val[--ip]);
+    }
+    bs.add(s2, log);
+    bs.flush();
+    bs.add(s1, log);
+    bs.flush();
+    uint8_t* e = bs.close();
+    const uint32_t csize = (uint32_t)(e - (dst + 1));
+    if (csize >= 128 || csize < 2) return 0;
+    dst[0] = (uint8_t)csize;
+    return 1 + csize;
+}
+
 // One Huffman stream: symbols lits[0, m) in REVERSE order into a forward bit stream + end mark.  16 symbols per lane,
 // positions from prefix sums of the code lengths, bits OR-ed into an LDS window (Z.lz.out) tile by tile.
 // Returns the stream's size in bytes.
@@ -277,6 +507,32 @@ __host__ __device__ __forceinline__ uint64_t zstd_scratch_bytes(uint64_t n) {
     const uint64_t b = n < ZE_BLOCK ? n : ZE_BLOCK;
     return 6 * ((b + 15) & ~15ull) + 256;
 }
+// byte histogram of p[0, n) into Z.hist (all lanes; 16 bytes per lane and load) and the largest byte value present
+__device__ inline uint32_t ze_histogram(ZEncLds& Z, const uint8_t* p, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t k = lane; k < 256; k += 64) Z.hist[k] = 0;
+    wave_sync();
+    const uint32_t nvec = n >> 4;
+    for (uint32_t i = lane; i < nvec; i += 64) {
+        const u32x4 v = ldu128(p + 16 * (size_t)i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&Z.hist[w[k] & 255], 1u);
+            atomicAdd(&Z.hist[(w[k] >> 8) & 255], 1u);
+            atomicAdd(&Z.hist[(w[k] >> 16) & 255], 1u);
+            atomicAdd(&Z.hist[w[k] >> 24], 1u);
+        }
+    }
+    for (uint32_t i = (nvec << 4) + lane; i < n; i += 64) atomicAdd(&Z.hist[ldu8(p + i)], 1u);
+    wave_sync();
+    uint32_t maxs = 0;
+    for (uint32_t k = lane; k < 256; k += 64)
+        if (Z.hist[k]) maxs = max(maxs, k);
+    for (int d = 32; d > 0; d >>= 1) maxs = max(maxs, (uint32_t)__shfl_xor((int)maxs, d, 64));
+    return maxs;
+}
+
 // One block of a frame: src[c0, c1) of the input src[0, n) -> 3-byte header + content at bh; returns its size.  The matcher
 // carries its history from the blocks before (ALONE = false, one wave walks the frame) or starts without any (ALONE =
 // true: the block is the only one of a frame of its own, see zstd_compress_block_alone).  `scratch`: zstd_scratch_bytes(cap).
@@ -293,6 +549,8 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
     LZP_BEGIN
     uint32_t nseq = 0, nlit = 0;
     uint32_t tail_from = c0;
+    bool probed = false, lit_only = false;
+    uint32_t lit_maxs = 0, lit_hbits = 0;
     if (blk >= 32) {
         if (ALONE)
             mt.begin_alone(c0, c1 - 12, c1 - 5, false);
@@ -352,12 +610,53 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
             nseq += (uint32_t)__popcll(mt.C);
             mt.advance();
             LZP(10);
+            if (ALONE && !probed && blk >= 4096 && mt.anchor - c0 >= 2048) {
+                // After the first 2 KiB of a piece that is a frame of its own: are sequences worth their bits here?  A sequence
+                // costs ~20 bits of FSE codes and offset; entropy-coded as a literal, a byte costs h = (Huffman bits of the
+                // piece's byte histogram) / 8 bytes.  Matches of avg_ml bytes pay off only if avg_ml * h > 2.5 bytes — they do
+                // not for columns of small records (64-bit values whose upper bytes repeat: 3-byte matches; short codes
+                // like "s123"): those pieces become ONE Huffman-coded literals section with no sequences, which is smaller
+                // (C5: 13.6 -> 8.x MB per array; libzstd level 3 writes 9.7) and skips the matcher, the sequence coding and,
+                // on the read side, the sequence execution.
+                probed = true;
+                const uint32_t seen = mt.anchor - c0, matched = seen - min(seen, nlit);
+                const uint32_t maxs0 = ze_histogram(Z, src + c0, blk);
+                const uint32_t hb0 = maxs0 >= 1 ? ze_huf_build_wave(Z, maxs0, ZE_LITONLY_MAXBITS) : 0u;   // (codes the lane-per-stream decoder takes)
+                if (hb0) {
+                    uint32_t est = 0;
+                    for (uint32_t k2 = lane; k2 <= maxs0; k2 += 64) est += Z.hist[k2] * Z.hlen[k2];
+                    for (int d = 32; d > 0; d >>= 1) est += (uint32_t)__shfl_xor((int)est, d, 64);
+                    const bool helps = est / 8 + 160 < blk - blk / 32;
+                    // what the LZ parse would cost, extrapolated from the part seen: its literals at the piece's code lengths
+                    // (the bytes matches take away are often the cheap ones: the literals left over cost MORE per byte than
+                    // the average) + ~20 bits per sequence
+                    wave_stores_visible();
+                    uint32_t lbits = 0;
+                    for (uint32_t i2 = lane; i2 < nlit; i2 += 64) lbits += Z.hlen[ldu8(lits + i2)];
+                    for (int d = 32; d > 0; d >>= 1) lbits += (uint32_t)__shfl_xor((int)lbits, d, 64);
+                    const uint64_t lz_bits = ((uint64_t)lbits + 20ull * nseq) * blk / max(seen, 1u);
+                    (void)matched;
+                    const bool seq_poor = nseq == 0 || (uint64_t)est <= lz_bits;
+                    if (helps && seq_poor) {
+                        lit_only = true;
+                        lit_maxs = maxs0;
+                        lit_hbits = hb0;
+                        break;
+                    }
+                }
+            }
         }
         tail_from = mt.anchor;
     }
-    // trailing literals of the block
-    wave_copy_g2g(lits + nlit, src + tail_from, c1 - tail_from);
-    nlit += c1 - tail_from;
+    if (lit_only) {   // the piece's own bytes are the literals
+        lits = (uint8_t*)(src + c0);
+        nlit = blk;
+        nseq = 0;
+    } else {
+        // trailing literals of the block
+        wave_copy_g2g(lits + nlit, src + tail_from, c1 - tail_from);
+        nlit += c1 - tail_from;
+    }
     wave_stores_visible();   // lits / seqs are read back below
     LZP(11);
     LZP_CNT(16, nseq);
@@ -369,33 +668,14 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
     if (ok) {
         uint32_t q = 0;
         // ---- literals section
-        for (uint32_t k = lane; k < 256; k += 64) Z.hist[k] = 0;
-        wave_sync();
-        {   // 16 bytes per lane and load (lits is 16-byte aligned scratch)
-            const uint32_t nvec = nlit >> 4;
-            for (uint32_t i = lane; i < nvec; i += 64) {
-                const u32x4 v = ldu128(lits + 16 * (size_t)i);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    atomicAdd(&Z.hist[w[k] & 255], 1u);
-                    atomicAdd(&Z.hist[(w[k] >> 8) & 255], 1u);
-                    atomicAdd(&Z.hist[(w[k] >> 16) & 255], 1u);
-                    atomicAdd(&Z.hist[w[k] >> 24], 1u);
-                }
-            }
-            for (uint32_t i = (nvec << 4) + lane; i < nlit; i += 64) atomicAdd(&Z.hist[ldu8(lits + i)], 1u);
-        }
-        wave_sync();
-        uint32_t maxs = 0;
-        for (uint32_t k = lane; k < 256; k += 64)
-            if (Z.hist[k]) maxs = max(maxs, k);
-        for (int d = 32; d > 0; d >>= 1) maxs = max(maxs, (uint32_t)__shfl_xor((int)maxs, d, 64));
-        uint32_t hbits = 0;
-        if (nlit >= 64 && maxs <= 128 && maxs >= 1) {
-            if (lane == 0) Z.misc[0] = ze_huf_build(Z, maxs);
-            wave_sync();
-            hbits = Z.misc[0];
+        uint32_t maxs, hbits = 0;
+        if (lit_only) {   // (histogram and tree of exactly these bytes: the probe's)
+            maxs = lit_maxs;
+            hbits = lit_hbits;
+        } else {
+            maxs = ze_histogram(Z, lits, nlit);
+            // (a block without sequences is read lane per stream when its codes have at most ZE_LITONLY_MAXBITS bits)
+            if (nlit >= 64 && maxs >= 1) hbits = ze_huf_build_wave(Z, maxs, nseq == 0 ? ZE_LITONLY_MAXBITS : ZE_HUF_MAXBITS);
         }
         bool huf = hbits != 0;
         if (huf) {
@@ -403,7 +683,7 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
             uint32_t est = 0;
             for (uint32_t k = lane; k <= maxs; k += 64) est += Z.hist[k] * Z.hlen[k];
             for (int d = 32; d > 0; d >>= 1) est += (uint32_t)__shfl_xor((int)est, d, 64);
-            const uint32_t coded = (est + 7) / 8 + 1 + (maxs + 1) / 2 + 16;
+            const uint32_t coded = (est + 7) / 8 + 1 + (maxs <= 128 ? (maxs + 1) / 2 : 100u) + 16;
             if (coded >= nlit || nlit > 262143u) huf = false;
         }
         if (huf) {
@@ -412,18 +692,27 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
             const uint32_t hsz = !four ? 3u : 5u;   // (the compressed size is not known yet: the widest form always fits)
             uint8_t* lh = body + q;
             uint32_t w = hsz;
-            // tree description: direct 4-bit weights of symbols 0 .. maxs - 1
-            if (lane == 0) {
-                lh[w] = (uint8_t)(127 + maxs);
-                for (uint32_t s = 0; s < maxs; s += 2) {
-                    const uint32_t w0 = Z.hlen[s] ? hbits + 1 - Z.hlen[s] : 0;
-                    const uint32_t w1 = (s + 1 < maxs && Z.hlen[s + 1]) ? hbits + 1 - Z.hlen[s + 1] : 0;
-                    lh[w + 1 + s / 2] = (uint8_t)((w0 << 4) | w1);
+            // tree description: direct 4-bit weights of symbols 0 .. maxs - 1 (up to 128 of them), else FSE-coded weights
+            if (maxs <= 128) {
+                if (lane == 0) {
+                    lh[w] = (uint8_t)(127 + maxs);
+                    for (uint32_t s = 0; s < maxs; s += 2) {
+                        const uint32_t w0 = Z.hlen[s] ? hbits + 1 - Z.hlen[s] : 0;
+                        const uint32_t w1 = (s + 1 < maxs && Z.hlen[s + 1]) ? hbits + 1 - Z.hlen[s + 1] : 0;
+                        lh[w + 1 + s / 2] = (uint8_t)((w0 << 4) | w1);
+                    }
                 }
+                w += 1 + (maxs + 1) / 2;
+            } else {
+                if (lane == 0) Z.misc[2] = ze_huf_weights_fse(Z, maxs, hbits, lh + w);
+                wave_sync();
+                __builtin_amdgcn_s_waitcnt(0);
+                if (Z.misc[2] == 0) huf = false;
+                w += Z.misc[2];
             }
-            w += 1 + (maxs + 1) / 2;
             const uint32_t tree_end = w;
-            if (four) {
+            if (!huf) {
+            } else if (four) {
                 const uint32_t seg = (nlit + 3) / 4;
                 uint32_t ssz[4];
                 w += 6;   // jump table

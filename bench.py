@@ -260,7 +260,8 @@ def direction_summary(U, pb, ms, kernels, encode):
     top = max(ks.items(), key=lambda kv: kv[1][1]) if ks else (None, (0, 0.0))
     A = U + pb
     return {"GBps": round(U / ms / 1e6, 1), "ms": round(ms, 3), "frac_hbm": round(A / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "top_kernel": top[0], "top_kernel_ms": round(top[1][1], 3), "top_kernel_share": round(top[1][1] / tot, 3)}
+            "top_kernel": top[0], "top_kernel_ms": round(top[1][1], 3), "top_kernel_share": round(top[1][1] / tot, 3),
+            "kernels_ms": {k: round(v[1], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1])[:5]}}
 
 
 def config_entry(name, res, cpu, extra=None):
@@ -450,7 +451,9 @@ def run_c5(h, cpu_on, arrays=64):
     nested.write_nested_leaves(ctx, pairs, opts)
     st_e = ctx.profile_read()
     nested.read_nested_leaves(ctx, cps, kinds, opt)
-    st_d = ctx.profile_read()
+    st_d = ctx.profile_read()       # accumulated since profile(True): take the write's share out
+    st_d = {k: (v[0] - st_e.get(k, (0, 0.0))[0], v[1] - st_e.get(k, (0, 0.0))[1]) for k, v in st_d.items()}
+    st_d = {k: v for k, v in st_d.items() if v[0] > 0}
     ctx.profile(False)
     pb = sum(e.length for e in encs)
     res = dict(U=U, page_bytes=pb, n_pages=sum(e.n_pages for e in encs), enc_ms=te, dec_ms=td, kernels={})

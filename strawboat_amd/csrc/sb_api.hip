@@ -391,7 +391,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     if (n == 0) return SB_OK;
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    uint64_t P = 0, T = 0;
+    uint64_t P = 0, T = 0, max_page_len = 0;
     bool any_binary = false, any_prim = false;
     for (uint64_t i = 0; i < n; i++) {
         sb_column_read& c = cols[i];
@@ -402,6 +402,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         for (uint64_t p = 0; p < c.n_pages; p++) {
             rows += c.metas[p].num_values;
             T += (c.metas[p].num_values + TILE_ROWS - 1) / TILE_ROWS;
+            max_page_len = std::max<uint64_t>(max_page_len, c.metas[p].length);
         }
         c.rows = rows;
         c.values_len = 0;
@@ -552,6 +553,10 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     a.n_pages = (uint32_t)P;
     a.n_cols = (uint32_t)n;
     a.n_tiles = (uint32_t)T;
+    // LZ4 blocks for the workgroup decoder: in a call with few blocks every block of 16 KiB and more (a lone wave's latency
+    // is what the call waits for); in a call that fills the one-wave pool several times over only the blocks of 64 KiB and more
+    const uint32_t big_min = 2 * P >= 4096 ? LZ4_BIG_MIN : LZ4_BIG_MIN / 4;
+    a.lz4_big_min = max_page_len >= big_min ? big_min : 0xFFFFFFFFu;
     a.freq_log = nullptr;
     a.freq_count = nullptr;
     a.freq_cap = 0;

@@ -138,7 +138,9 @@ struct DecodeArgs {
     uint32_t sizes_only;   // sb_read_columns_sizes: only what values_len depends on is inflated (nested index blocks)
     uint32_t defer_payloads;  // the call has binary columns (queue B runs): Basic payloads nothing waits for go there too
     uint32_t job_cap_a, job_cap_b;  // entries of the two job queues (2 * n_pages + room for the frames of split Zstd buffers)
+    uint32_t lz4_big_min;  // LZ4 blocks of at least this many compressed bytes go to k_inflate_lz4_big (0xFFFFFFFF: the call has no page that long)
 };
+constexpr uint32_t LZ4_BIG_MIN = 64u << 10;
 
 }  // namespace sb
 

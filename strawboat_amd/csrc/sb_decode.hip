@@ -21,6 +21,7 @@
 #include "sb_host.h"
 #include "sb_zstd.h"
 #include "sb_lz4.h"
+#include "sb_lz4_big.h"
 
 namespace sb {
 
@@ -877,14 +878,28 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
 // LZ4 blocks: one wave per block from a pool of waves that loops over the job queue (sb_lz4.h: compressed
 // bytes and an 8 KiB output window in LDS, speculative 64-position token parse, matches batched)
 constexpr uint32_t LZ4_POOL = 4096;
-__global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, const uint32_t* count, Status* st) {
+__global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min) {
     __shared__ Lz4DecLds lds;
     const uint32_t njobs = *count;
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
-        if (j.codec != SB_CODEC_LZ4) continue;
+        if (j.codec != SB_CODEC_LZ4 || j.csize >= big_min) continue;
         const uint32_t e = lz4_inflate_block(j.src, j.csize, j.dst, j.out_len, lds);
         if (e && threadIdx.x == 0) raise(st, SB_ERR_EXTERNAL, j.page, e);
+    }
+}
+// LZ4 blocks of LZ4_BIG_MIN compressed bytes and more: one workgroup per block (sb_lz4_big.h: sequence starts and match
+// chains by pointer doubling).  Launched only when a page of the call is that long (DecodeArgs.lz4_big_min).
+constexpr uint32_t LZ4_BIG_POOL = 1024;
+__global__ void __launch_bounds__(LB_T, 4) k_inflate_lz4_big(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min) {
+    __shared__ Lz4BigLds lds;
+    const uint32_t njobs = *count;
+    for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+        const InflateJob j = jobs[job];
+        if (j.codec != SB_CODEC_LZ4 || j.csize < big_min) continue;
+        const uint32_t e = lz4_inflate_block_wg(j.src, j.csize, j.dst, j.out_len, lds);
+        if (e && threadIdx.x == 0) raise(st, SB_ERR_EXTERNAL, j.page, e);
+        __syncthreads();
     }
 }
 
@@ -2244,7 +2259,11 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     {
         KScope k(ctx, "k_inflate_lz4");
-        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min);
+    }
+    if (a.lz4_big_min != 0xFFFFFFFFu) {
+        KScope k(ctx, "k_inflate_lz4_big");
+        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min);
     }
     {
         KScope k(ctx, K_PLAN);
@@ -2259,7 +2278,11 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k(ctx, K_INFLATE_B);
         k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec);
         KScope k2(ctx, "k_inflate_lz4(values)");
-        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status);
+        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min);
+    }
+    if (any_binary && a.lz4_big_min != 0xFFFFFFFFu) {
+        KScope k(ctx, "k_inflate_lz4_big(values)");
+        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min);
     }
     // the three expand kernels work on disjoint pages (page-level RLE, tiles of primitives, tiles of binary columns): side
     // by side on streams of their own when the call has both kinds of columns (a mixed schema), joined before the call ends
@@ -2287,7 +2310,7 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a);
     k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
-    k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status);
+    k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
 }

@@ -339,3 +339,155 @@ def test_chunked_binary_boolean_nullable_pages(gpu_ctx):
         assert np.array_equal(back.values_numpy(), want["values"])
         # (the matcher's history is its 8 KiB LDS ring, liblz4's is 64 KiB: a vocabulary of 5000 strings costs ~45 %)
         assert pages.size <= 1.6 * wp.size + 4096
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# blocks of 64 KiB of compressed bytes and more: the workgroup decoder (strawboat_amd/csrc/sb_lz4_big.h)
+def _py_lz4(blk):
+    out = bytearray()
+    ip = 0
+    while ip < len(blk):
+        tok = blk[ip]; ip += 1
+        ll = tok >> 4
+        if ll == 15:
+            while True:
+                b = blk[ip]; ip += 1; ll += b
+                if b != 255:
+                    break
+        out += blk[ip:ip + ll]; ip += ll
+        if ip >= len(blk):
+            break
+        off = blk[ip] | (blk[ip + 1] << 8); ip += 2
+        ml = tok & 15
+        if ml == 15:
+            while True:
+                b = blk[ip]; ip += 1; ml += b
+                if b != 255:
+                    break
+        ml += 4
+        assert 0 < off <= len(out)
+        if off >= ml:
+            out += out[len(out) - off:len(out) - off + ml]
+        else:
+            seg = bytes(out[len(out) - off:])
+            out += (seg * (ml // off + 1))[:ml]
+    return np.frombuffer(bytes(out), np.uint8)
+
+
+def _big_blocks():
+    rng = np.random.default_rng(23)
+    words = [b"w%d" % i + b"x" * (i % 9) for i in range(3000)]
+    text = np.frombuffer(b" ".join(words[i] for i in rng.zipf(1.1, 260_000) % 3000), np.uint8)
+    yield "text", bytes(S.block_compress(S.LZ4, text))
+    yield "random", bytes(S.block_compress(S.LZ4, rng.integers(0, 256, 300_000, dtype=np.uint8)))
+    yield "small_ints", bytes(S.block_compress(S.LZ4, rng.integers(0, 1000, 200_000).astype(np.uint32).view(np.uint8)))
+    yield "low_entropy", bytes(S.block_compress(S.LZ4, rng.integers(0, 4, 1_200_000, dtype=np.uint8)))
+    yield "sorted_i64", bytes(S.block_compress(S.LZ4, np.cumsum(rng.integers(0, 9, 150_000)).astype(np.int64).view(np.uint8)))
+    # more than 1024 sequences in 4 KiB of input: 3-byte sequences (no literals, 4..18-byte matches)
+    dense = b"".join(_seq(b"", 4 + (i % 15), 1 + (i * 13) % 64) for i in range(40_000))
+    yield "dense", _seq(bytes(range(64)), 4, 64) + dense + _seq(b"final")
+    # literal runs that do not fit the staged input, between dense stretches; matches longer than a window; far offsets
+    lit = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    parts = [_seq(lit(70_000), 300_000, 1), _seq(lit(281), 4, 65_000), _seq(lit(5000), 40_000, 65_535)]
+    for i in range(6000):
+        parts.append(_seq(lit(i % 5), 4 + (i % 40), 1 + (i * 31) % 60_000))
+        if i % 500 == 0:
+            parts.append(_seq(lit(300 + i), 20_000 + i, 3 + i % 7))
+    parts.append(_seq(lit(66_000), 5, 2))
+    parts.append(_seq(b"", 100_000, 65_535))
+    parts.append(_seq(b"abcde"))
+    yield "long_and_far", b"".join(parts)
+    # literal length extensions that end exactly at the staged border, sequences straddling chunk borders
+    parts = [_seq(lit(20), 8, 3)]
+    for i in range(2000):
+        parts.append(_seq(lit(255 + 15 + (i % 40)), 4 + 15 + (255 if i % 3 == 0 else i % 7), 1 + (i * 17) % 20))
+    parts.append(_seq(b"tail!"))
+    yield "ext_borders", b"".join(parts)
+
+
+BIG = None
+
+
+def _big():
+    global BIG
+    if BIG is None:
+        BIG = dict(_big_blocks())
+    return BIG
+
+
+@pytest.mark.parametrize("name", ["text", "random", "small_ints", "low_entropy", "sorted_i64", "dense", "long_and_far", "ext_borders"])
+def test_big_block_decoder(gpu_ctx, name):
+    blk = _big()[name]
+    assert len(blk) >= 65536, len(blk)
+    want = _py_lz4(blk)
+    assert np.array_equal(S.block_decompress(S.LZ4, np.frombuffer(blk, np.uint8), want.size), want)
+    pages, metas = lz4_page(blk, want.size)
+    for shift in (0, 3):
+        pre = np.arange(shift, dtype=np.uint8)
+        if shift:
+            p0 = np.frombuffer(bytes([S.NONE]) + shift.to_bytes(4, "little") * 2 + bytes(pre), np.uint8)
+            pg = np.concatenate([p0, pages])
+            mt = np.concatenate([np.array([[9 + shift, shift]], np.uint64), metas])
+        else:
+            pg, mt = pages, metas
+        got = device_read(gpu_ctx, bytes_column(np.concatenate([pre, want])), pg, mt).values_numpy()
+        exp = np.concatenate([pre, want])
+        bad = np.flatnonzero(got != exp)
+        assert bad.size == 0, (name, shift, int(bad[0]), int(bad.size))
+
+
+def test_big_blocks_many_per_call(gpu_ctx):
+    """several big blocks and small ones in one call (both LZ4 kernels walk the same queue)"""
+    from strawboat_amd import read
+    B = _big()
+    names = ["text", "dense", "small_ints", "ext_borders"]
+    cols, want = [], []
+    for k in range(10):
+        blk = B[names[k % 4]] if k % 3 else _seq(b"abcd", 8, 2) + _seq(b"12345")
+        w = _py_lz4(blk)
+        pages, metas = lz4_page(blk, w.size)
+        cols.append(read.ColumnPages(S.T_U8, False, up(gpu_ctx, pages), metas))
+        want.append(w)
+    got = read.batch_read_columns(gpu_ctx, cols)
+    gpu_ctx.synchronize()
+    for g, w in zip(got, want):
+        assert np.array_equal(g.values_numpy(), w)
+
+
+@pytest.mark.parametrize("bad", ["offset0", "offset_too_far", "truncated", "short_output", "long_output", "no_last_literals",
+                                 "garbage_tail", "literal_overrun"])
+def test_big_block_decoder_rejects_malformed(gpu_ctx, bad):
+    from strawboat_amd._native import NativeError
+    rng = np.random.default_rng(5)
+    lit = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    body = [_seq(lit(1 + i % 9), 4 + i % 30, 1 + (i * 7) % (1 + i)) for i in range(20_000)]
+    good = b"".join(body) + _seq(b"final")
+    n = _py_lz4(good).size
+    if bad == "offset0":
+        blk = b"".join(body[:9000]) + _seq(b"ab", 9, 0) + b"".join(body[9000:]) + _seq(b"final")
+        n += 11
+    elif bad == "offset_too_far":
+        blk = _seq(b"abcd", 8, 5) + good
+        n += 12
+    elif bad == "truncated":
+        blk = good[:-3]
+    elif bad == "short_output":
+        blk, n = good, n - 1
+    elif bad == "long_output":
+        blk, n = good, n + 1
+    elif bad == "no_last_literals":
+        blk = b"".join(body)
+        n -= 5
+    elif bad == "garbage_tail":
+        blk = good + b"\x00"
+    else:
+        blk = b"".join(body) + bytes([0xF0, 255, 255, 255, 10]) + b"xy"
+        n = n - 5 + 2
+    assert len(blk) >= 65536
+    pages, metas = lz4_page(blk, n)
+    with pytest.raises(NativeError) as e:
+        device_read(gpu_ctx, bytes_column(np.zeros(n, np.uint8)), pages, metas)
+    assert e.value.code == -2
+    pages, metas = lz4_page(good, _py_lz4(good).size)
+    got = device_read(gpu_ctx, bytes_column(np.zeros(1, np.uint8)), pages, metas)
+    assert np.array_equal(got.values_numpy(), _py_lz4(good))

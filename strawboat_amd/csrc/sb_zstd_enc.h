@@ -320,6 +320,148 @@ __device__ inline uint32_t ze_huf_build_wave(ZEncLds& Z, uint32_t max_sym, uint3
     return maxd;
 }
 
+// The same result class — a complete prefix code of at most max_bits bits for the present symbols, canonical codes in
+// Z.hcode — with the lengths from PACKAGE-MERGE run by the whole wave (optimal for the length limit; no serial two-queue
+// merge, depth walk and Kraft repair on one lane: a 256-symbol alphabet cost ~1 M cycles there, ~40 k here).
+//   lists   level max_bits holds the leaves (weights ascending); level l = merge(leaves, packages of level l + 1), a package
+//           being the sum of two neighbours.  Every leaf / package finds its place by a binary search in the other list
+//           (9 steps, the four leaves and four packages of a lane side by side); PK[l][i] keeps the packages in front of leaf i.
+//   lengths top-down: the first 2n - 2 items of level 1 are taken; the packages among them open twice as many items of the
+//           level below; a leaf's code length is the number of levels in which it is among the items taken.
+// `sc`: 1536 + 64 * (max_bits + 1) words of LDS scratch (the matcher's table and ring once the block's parse is over).
+__device__ inline uint32_t ze_huf_build_pm(ZEncLds& Z, uint32_t max_sym, uint32_t max_bits, uint32_t* sc) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t* W = sc;            // [256] leaf weights, ascending
+    uint32_t* P = sc + 256;      // [256] packages of the current level
+    uint32_t* LA = sc + 512;     // [512] lists (ping-pong)
+    uint32_t* LB = sc + 1024;
+    uint8_t* PK = (uint8_t*)(sc + 1536);   // [max_bits + 1][256]
+    // order of the present symbols by (count, symbol): rank = keys below mine
+    uint32_t mykey[4], myrank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t sy = lane + 64 * j;
+        const uint32_t c = sy <= max_sym ? Z.hist[sy] : 0u;
+        mykey[j] = c ? (c << 8) | sy : 0xFFFFFFFFu;
+        LA[sy] = mykey[j];
+        Z.hlen[sy] = 0;
+    }
+    uint32_t ns = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) ns += (uint32_t)__popcll(__ballot(mykey[j] != 0xFFFFFFFFu));
+    wave_sync();
+    if (ns < 2) return 0;
+    for (uint32_t o = 0; o <= max_sym; o += 4) {   // (uniform addresses: broadcast reads)
+        const uint32_t k0 = LA[o], k1 = LA[o + 1], k2 = LA[o + 2], k3 = LA[o + 3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) myrank[j] += (k0 < mykey[j]) + (k1 < mykey[j]) + (k2 < mykey[j]) + (k3 < mykey[j]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (mykey[j] != 0xFFFFFFFFu) {
+            Z.h_sorted[myrank[j]] = (uint16_t)(lane + 64 * j);
+            W[myrank[j]] = mykey[j] >> 8;
+        }
+    }
+    wave_sync();
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = lane + 64 * j;
+        w[j] = i < ns ? W[i] : 0xFFFFFFFFu;
+        if (i < ns) {
+            LA[i] = w[j];
+            PK[max_bits * 256 + i] = 0;
+        }
+    }
+    wave_sync();
+    uint32_t* cur = LA;
+    uint32_t* nxt = LB;
+    uint32_t len = ns;
+    const uint32_t keep = 2 * ns - 2;
+    for (uint32_t l = max_bits - 1; l >= 1; l--) {
+        const uint32_t np = min(len / 2, ns - 1);
+        uint32_t pj[4], bl[4] = {0, 0, 0, 0}, bp[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t jj = lane + 64 * j;
+            pj[j] = jj < np ? cur[2 * jj] + cur[2 * jj + 1] : 0xFFFFFFFFu;
+            if (jj < np) P[jj] = pj[j];
+        }
+        wave_sync();
+        // bl = packages below my leaf (ties: the leaf first), bp = leaves at or below my package
+        for (uint32_t step = 256; step; step >>= 1) {
+            uint32_t vl[4], vp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                vl[j] = bl[j] + step <= np ? P[bl[j] + step - 1] : 0xFFFFFFFFu;
+                vp[j] = bp[j] + step <= ns ? W[bp[j] + step - 1] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (bl[j] + step <= np && vl[j] < w[j]) bl[j] += step;
+                if (bp[j] + step <= ns && vp[j] <= pj[j]) bp[j] += step;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i = lane + 64 * j;
+            if (i < ns) {
+                PK[l * 256 + i] = (uint8_t)bl[j];
+                if (i + bl[j] < keep) nxt[i + bl[j]] = w[j];
+            }
+            if (i < np && i + bp[j] < keep) nxt[i + bp[j]] = pj[j];
+        }
+        wave_sync();
+        len = min(ns + np, keep);
+        uint32_t* tsw = cur;
+        cur = nxt;
+        nxt = tsw;
+    }
+    uint32_t k = keep, mylen[4] = {0, 0, 0, 0};
+    for (uint32_t l = 1; l <= max_bits && k; l++) {
+        uint32_t a = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i = lane + 64 * j;
+            const bool in = i < ns && i + PK[l * 256 + i] < k;
+            a += (uint32_t)__popcll(__ballot(in));
+            if (in) mylen[j]++;
+        }
+        k = 2 * (k - a);
+    }
+    uint32_t maxd = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = lane + 64 * j;
+        if (i < ns) {
+            Z.hlen[Z.h_sorted[i]] = (uint8_t)mylen[j];
+            maxd = max(maxd, mylen[j]);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) maxd = max(maxd, (uint32_t)__shfl_xor((int)maxd, d, 64));
+    wave_sync();
+    if (!maxd || maxd > max_bits) return 0;
+    // canonical codes: longest codes first, symbols of one length in symbol order
+    uint32_t ml[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ml[j] = Z.hlen[(lane + 64 * j) & 255];
+    uint32_t code = 0;
+    for (uint32_t ln = maxd; ln >= 1; ln--) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t m = __ballot(ml[j] == ln && lane + 64 * j <= max_sym);
+            if (ml[j] == ln && lane + 64 * j <= max_sym) Z.hcode[lane + 64 * j] = (uint16_t)(code + before + lane_rank(m));
+            before += (uint32_t)__popcll(m);
+        }
+        code = (code + before) >> 1;
+    }
+    wave_sync();
+    return maxd;
+}
+
 // The tree description for more than 128 symbols: the weights of symbols 0 .. max_sym - 1, FSE-coded with two interleaved
 // states (RFC 8878 4.2.1.2; HUF_compressWeights upstream).  Lane 0 only; returns the bytes written at dst (header byte =
 // compressed size < 128, table description, stream), 0 when the weights do not compress into that.
@@ -550,7 +692,7 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
     uint32_t nseq = 0, nlit = 0;
     uint32_t tail_from = c0;
     bool probed = false, lit_only = false;
-    uint32_t lit_maxs = 0, lit_hbits = 0;
+    uint32_t lit_maxs = 0;
     if (blk >= 32) {
         if (ALONE)
             mt.begin_alone(c0, c1 - 12, c1 - 5, false);
@@ -621,26 +763,33 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
                 probed = true;
                 const uint32_t seen = mt.anchor - c0, matched = seen - min(seen, nlit);
                 const uint32_t maxs0 = ze_histogram(Z, src + c0, blk);
-                const uint32_t hb0 = maxs0 >= 1 ? ze_huf_build_wave(Z, maxs0, ZE_LITONLY_MAXBITS) : 0u;   // (codes the lane-per-stream decoder takes)
-                if (hb0) {
-                    uint32_t est = 0;
-                    for (uint32_t k2 = lane; k2 <= maxs0; k2 += 64) est += Z.hist[k2] * Z.hlen[k2];
-                    for (int d = 32; d > 0; d >>= 1) est += (uint32_t)__shfl_xor((int)est, d, 64);
+                if (maxs0 >= 1) {
+                    // order-0 cost of the piece: entropy + 2 % (what a Huffman code of these counts comes to), per symbol
+                    // in 1/64 bits in Z.hcode (free until the tree is built)
+                    uint32_t est64 = 0;
+                    for (uint32_t k2 = lane; k2 < 256; k2 += 64) {
+                        const uint32_t c = k2 <= maxs0 ? Z.hist[k2] : 0u;
+                        const uint32_t b64 = c ? min(65535u, (uint32_t)(__log2f((float)blk / (float)c) * 65.28f + 0.5f)) : 0u;
+                        Z.hcode[k2] = (uint16_t)max(b64, 64u);   // (no code of a tree is shorter than one bit)
+                        est64 += c * max(b64, 64u);
+                    }
+                    for (int d = 32; d > 0; d >>= 1) est64 += (uint32_t)__shfl_xor((int)est64, d, 64);
+                    const uint32_t est = est64 / 64;
                     const bool helps = est / 8 + 160 < blk - blk / 32;
                     // what the LZ parse would cost, extrapolated from the part seen: its literals at the piece's code lengths
                     // (the bytes matches take away are often the cheap ones: the literals left over cost MORE per byte than
                     // the average) + ~20 bits per sequence
                     wave_stores_visible();
                     uint32_t lbits = 0;
-                    for (uint32_t i2 = lane; i2 < nlit; i2 += 64) lbits += Z.hlen[ldu8(lits + i2)];
+                    for (uint32_t i2 = lane; i2 < nlit; i2 += 64) lbits += Z.hcode[ldu8(lits + i2)];
                     for (int d = 32; d > 0; d >>= 1) lbits += (uint32_t)__shfl_xor((int)lbits, d, 64);
+                    lbits /= 64;
                     const uint64_t lz_bits = ((uint64_t)lbits + 20ull * nseq) * blk / max(seen, 1u);
                     (void)matched;
                     const bool seq_poor = nseq == 0 || (uint64_t)est <= lz_bits;
                     if (helps && seq_poor) {
                         lit_only = true;
                         lit_maxs = maxs0;
-                        lit_hbits = hb0;
                         break;
                     }
                 }
@@ -669,13 +818,12 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
         uint32_t q = 0;
         // ---- literals section
         uint32_t maxs, hbits = 0;
-        if (lit_only) {   // (histogram and tree of exactly these bytes: the probe's)
-            maxs = lit_maxs;
-            hbits = lit_hbits;
-        } else {
-            maxs = ze_histogram(Z, lits, nlit);
+        maxs = lit_only ? lit_maxs : ze_histogram(Z, lits, nlit);   // (lit_only: the probe's histogram is of exactly these bytes)
+        if (nlit >= 64 && maxs >= 1) {
             // (a block without sequences is read lane per stream when its codes have at most ZE_LITONLY_MAXBITS bits)
-            if (nlit >= 64 && maxs >= 1) hbits = ze_huf_build_wave(Z, maxs, nseq == 0 ? ZE_LITONLY_MAXBITS : ZE_HUF_MAXBITS);
+            const uint32_t bits = nseq == 0 ? ZE_LITONLY_MAXBITS : ZE_HUF_MAXBITS;
+            // the parse of the frame's last block is over: the matcher's table and ring are the tree builder's scratch
+            hbits = (ALONE || last_block) ? ze_huf_build_pm(Z, maxs, bits, (uint32_t*)Z.lz.tab) : ze_huf_build_wave(Z, maxs, bits);
         }
         bool huf = hbits != 0;
         if (huf) {

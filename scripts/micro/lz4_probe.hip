@@ -110,6 +110,7 @@ int main(int argc, char** argv) {
                 unsigned long long tot = 0;
                 for (int i = 8; i < 15; i++) tot += prof[i];
                 for (int i = 8; i < 15; i++) printf("   %-16s %12llu ticks %5.1f %%\n", ZN[i], prof[i], 100.0 * prof[i] / (tot ? tot : 1));
+                printf("   (literals = streams; before them: histogram + tree %llu, tree description %llu ticks)\n", prof[15], prof[7]);
                 printf("   sequences %llu, literals %llu\n", prof[16], prof[17]);
             }
         }

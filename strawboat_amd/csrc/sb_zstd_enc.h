@@ -51,12 +51,6 @@ struct ZEncLds {
     ZeSymTT sq_tt[64][3];
 };
 
-__device__ const int16_t ZE_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
-                                              2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
-__device__ const int16_t ZE_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                              1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
-__device__ const int16_t ZE_OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
-                                              1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
 __device__ const uint8_t ZE_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
                                            1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 __device__ const uint8_t ZE_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
@@ -75,10 +69,10 @@ __device__ __forceinline__ uint32_t ze_ll_code(uint32_t ll) { return ll > 63 ? z
 __device__ __forceinline__ uint32_t ze_ml_code(uint32_t mlbase) { return mlbase > 127 ? ze_highbit(mlbase) + 36 : ZE_ML_CODE[mlbase]; }
 
 // FSE_buildCTable for a normalized distribution (executed by one lane)
-__device__ inline void ze_build_ctable(const int16_t* norm, int nsym, int log, uint16_t* state_table, ZeSymTT* tt, uint8_t* spread /* 1 << log */) {
+__device__ inline void ze_build_ctable(const int16_t* norm, int nsym, int log, uint16_t* state_table, ZeSymTT* tt, uint8_t* spread /* 1 << log */,
+                                       int* cumul /* nsym + 1 words of LDS: a private array indexed at run time would live in scratch */) {
     const int size = 1 << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
     int high = size - 1;
-    int cumul[54];
     cumul[0] = 0;
     for (int s = 0; s < nsym; s++) {
         if (norm[s] == -1) {
@@ -462,19 +456,38 @@ __device__ inline uint32_t ze_huf_build_pm(ZEncLds& Z, uint32_t max_sym, uint32_
     return maxd;
 }
 
+// weights of the symbols 0 .. max_sym - 1 into Z.w_val and their histogram into Z.sq_ml[0 .. 12] (the whole wave)
+__device__ inline void ze_huf_weights_prep(ZEncLds& Z, uint32_t max_sym, uint32_t hbits) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t sy = lane + 64 * j;
+        wv[j] = 0xFFu;
+        if (sy < max_sym) {
+            wv[j] = Z.hlen[sy] ? hbits + 1 - Z.hlen[sy] : 0u;
+            Z.w_val[sy] = (uint8_t)wv[j];
+        }
+    }
+    for (uint32_t w = 0; w < 13; w++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) c += (uint32_t)__popcll(__ballot(wv[j] == w));
+        if (lane == 0) Z.sq_ml[w] = c;
+    }
+    wave_sync();
+}
 // The tree description for more than 128 symbols: the weights of symbols 0 .. max_sym - 1, FSE-coded with two interleaved
 // states (RFC 8878 4.2.1.2; HUF_compressWeights upstream).  Lane 0 only; returns the bytes written at dst (header byte =
 // compressed size < 128, table description, stream), 0 when the weights do not compress into that.
 __device__ inline uint32_t ze_huf_weights_fse(ZEncLds& Z, uint32_t max_sym, uint32_t hbits, uint8_t* dst) {
     const uint32_t n = max_sym;   // weights written (the last symbol's weight is implied)
     if (n < 2) return 0;
-    uint32_t cnt[13] = {0}, maxw = 0;
-    for (uint32_t sy = 0; sy < n; sy++) {
-        const uint32_t w = Z.hlen[sy] ? hbits + 1 - Z.hlen[sy] : 0;
-        Z.w_val[sy] = (uint8_t)w;
-        cnt[w]++;
-        maxw = max(maxw, w);
-    }
+    // (Z.w_val and the counts of the 13 possible weights, Z.sq_ml[0 .. 12], come from ze_huf_weights_prep, run by the wave)
+    const uint32_t* cnt = Z.sq_ml;
+    uint32_t maxw = 0;
+    for (uint32_t w = 0; w < 13; w++)
+        if (cnt[w]) maxw = w;
     for (uint32_t w = 0; w <= maxw; w++)
         if (cnt[w] == n) return 0;     // one weight only: not representable this way
     // table log: at most 6, and small enough for the number of weights (FSE_optimalTableLog)
@@ -546,7 +559,7 @@ __device__ inline uint32_t ze_huf_weights_fse(ZEncLds& Z, uint32_t max_sym, uint
         out = q;
     }
     // encoding table, then the weights from the last to the first (FSE_compress_usingCTable)
-    ze_build_ctable(Z.w_norm, (int)maxw + 1, (int)log, Z.w_st, Z.w_tt, (uint8_t*)Z.sq_code);
+    ze_build_ctable(Z.w_norm, (int)maxw + 1, (int)log, Z.w_st, Z.w_tt, (uint8_t*)Z.sq_code, (int*)Z.sq_ll);
     auto init_state = [&](uint32_t sym) -> uint32_t {
         const uint32_t nbo = (uint32_t)(Z.w_tt[sym].delta_nb_bits + (1 << 15)) >> 16;
         const uint32_t value = (nbo << 16) - (uint32_t)Z.w_tt[sym].delta_nb_bits;
@@ -590,38 +603,60 @@ __device__ inline uint32_t ze_huf_weights_fse(ZEncLds& Z, uint32_t max_sym, uint
 __device__ inline uint32_t ze_huf_stream(ZEncLds& Z, const uint8_t* lits, uint32_t m, uint8_t* dst) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t* win = (uint32_t*)Z.lz.out;        // 2048 bytes = 512 words; a tile of 1024 symbols needs <= 11264 bits = 352 words
+    const uint32_t* hct = Z.h_cnt;               // code | length << 16 per symbol (ze_huf_pack_table)
     uint32_t out = 0;                            // whole bytes already written to dst
     uint32_t carry_bits = 0, carry = 0;          // bits of the unfinished byte (< 8), kept in `carry`
     for (uint32_t done = 0; done <= m; done += 1024) {   // (one extra round when m % 1024 == 0 writes the end mark)
         const uint32_t tile = min(1024u, m - done);
         for (uint32_t k = lane; k < 384; k += 64) win[k] = 0;
         wave_sync();
-        // my symbols: reverse positions [done + 16 lane, done + 16 lane + 16) -> lits[m - 1 - r]
+        // my symbols: reverse positions [done + 16 lane, done + 16 lane + 16) -> lits[m - 1 - r]: the 16 bytes in front of
+        // lits + m - done - 16 lane, last byte first
+        uint32_t sym[16];
+        const uint32_t mine = 16 * lane < tile ? min(16u, tile - 16 * lane) : 0u;
+        if (mine == 16) {
+            const u32x4 v = ldu128(lits + (m - done - 16 * lane - 16));
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) sym[j] = (wd[3 - (j >> 2)] >> (8 * (3 - (j & 3)))) & 0xFF;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) sym[j] = (uint32_t)j < mine ? (uint32_t)ldu8(lits + (m - 1 - (done + 16 * lane + j))) : 0u;
+        }
+        // the lane's codes back to back in a 192-bit register buffer (16 codes of <= 11 bits)
+        uint64_t a0 = 0, a1 = 0, a2 = 0;
         uint32_t bits = 0;
-        uint32_t lens[16], codes[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const uint32_t r = done + 16 * lane + j;
-            uint32_t l = 0, c = 0;
-            if (16 * lane + j < tile) {
-                const uint32_t s = ldu8(lits + (m - 1 - r));
-                l = Z.hlen[s];
-                c = Z.hcode[s];
+            const uint32_t e = (uint32_t)j < mine ? hct[sym[j]] : 0u;
+            const uint64_t c = e & 0xFFFFu;
+            const uint32_t l = e >> 16, sh = bits & 63, wd = bits >> 6;
+            const uint64_t lo = c << sh, hi = sh ? c >> (64 - sh) : 0ull;   // (hi != 0 only when the code crosses a 64-bit border)
+            if (wd == 0) {
+                a0 |= lo;
+                a1 |= hi;
+            } else if (wd == 1) {
+                a1 |= lo;
+                a2 |= hi;
+            } else {
+                a2 |= lo;
             }
-            lens[j] = l;
-            codes[j] = c;
             bits += l;
         }
         const uint32_t incl = wave_scan_dpp(bits);
-        uint32_t pos = carry_bits + incl - bits;
+        const uint32_t pos = carry_bits + incl - bits;
         if (lane == 0 && carry_bits) atomicOr(&win[0], carry);
+        if (bits) {   // the buffer, shifted to its bit position, word by word (<= 7 words)
+            const uint32_t w0 = pos >> 5, sh = pos & 31;
+            const uint32_t b32[6] = {(uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32), (uint32_t)a2, (uint32_t)(a2 >> 32)};
+            const uint32_t nw = (sh + bits + 31) >> 5;
+            uint32_t prev = 0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (lens[j]) {
-                const uint32_t w = pos >> 5, sh = pos & 31;
-                atomicOr(&win[w], codes[j] << sh);
-                if (sh + lens[j] > 32) atomicOr(&win[w + 1], codes[j] >> (32 - sh));
-                pos += lens[j];
+            for (int k = 0; k < 7; k++) {
+                const uint32_t cur = k < 6 ? b32[k] : 0u;
+                const uint32_t v = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
+                if ((uint32_t)k < nw && v) atomicOr(&win[w0 + k], v);
+                prev = cur;
             }
         }
         uint32_t total = carry_bits + rdlane(incl, 63);
@@ -633,7 +668,8 @@ __device__ inline uint32_t ze_huf_stream(ZEncLds& Z, const uint8_t* lits, uint32
         wave_sync();
         const uint32_t nbytes = last ? (total + 7) >> 3 : total >> 3;
         const uint8_t* wb = (const uint8_t*)win;
-        for (uint32_t k = lane; k < nbytes; k += 64) dst[out + k] = wb[k];
+        for (uint32_t k = lane; 4 * k + 4 <= nbytes; k += 64) stu32(dst + out + 4 * k, win[k]);
+        if (lane < (nbytes & 3)) dst[out + (nbytes & ~3u) + lane] = wb[(nbytes & ~3u) + lane];
         out += nbytes;
         carry_bits = last ? 0 : total & 7;
         carry = carry_bits ? (uint32_t)wb[nbytes] & ((1u << carry_bits) - 1) : 0;
@@ -641,6 +677,12 @@ __device__ inline uint32_t ze_huf_stream(ZEncLds& Z, const uint8_t* lits, uint32
         if (last) break;
     }
     return out;
+}
+// code | length << 16 of every symbol in Z.h_cnt (free once the tree is built): one lookup per literal in ze_huf_stream
+__device__ inline void ze_huf_pack_table(ZEncLds& Z) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t k = lane; k < 256; k += 64) Z.h_cnt[k] = (uint32_t)Z.hcode[k] | ((uint32_t)Z.hlen[k] << 16);
+    wave_sync();
 }
 
 // HBM scratch of one wave: literal buffer (1x), sequence records (2x) and the compressed block under construction (3x: a
@@ -825,6 +867,7 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
             // the parse of the frame's last block is over: the matcher's table and ring are the tree builder's scratch
             hbits = (ALONE || last_block) ? ze_huf_build_pm(Z, maxs, bits, (uint32_t*)Z.lz.tab) : ze_huf_build_wave(Z, maxs, bits);
         }
+        LZP(15);
         bool huf = hbits != 0;
         if (huf) {
             // size estimate: the tree + the coded bits must beat raw
@@ -852,6 +895,7 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
                 }
                 w += 1 + (maxs + 1) / 2;
             } else {
+                ze_huf_weights_prep(Z, maxs, hbits);
                 if (lane == 0) Z.misc[2] = ze_huf_weights_fse(Z, maxs, hbits, lh + w);
                 wave_sync();
                 __builtin_amdgcn_s_waitcnt(0);
@@ -859,6 +903,8 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
                 w += Z.misc[2];
             }
             const uint32_t tree_end = w;
+            LZP(7);
+            if (huf) ze_huf_pack_table(Z);   // (after the tree description: ze_huf_weights_fse is done with its scratch)
             if (!huf) {
             } else if (four) {
                 const uint32_t seg = (nlit + 3) / 4;
@@ -1045,13 +1091,83 @@ __device__ __forceinline__ uint32_t ze_frame_header(uint8_t* dst, uint32_t n) { 
     return n < 256 ? 6u : n < 65536 + 256 ? 7u : 9u;
 }
 __device__ __forceinline__ uint32_t ze_frame_header_bytes(uint32_t n) { return n < 256 ? 6u : n < 65536 + 256 ? 7u : 9u; }
-__device__ __forceinline__ void ze_tables(ZEncLds& Z) {   // FSE encoding tables of the predefined distributions (once per wave)
-    if ((threadIdx.x & 63) == 0) {
-        uint8_t* spread = Z.lz.out;
-        ze_build_ctable(ZE_LL_DEFAULT, 36, 6, Z.ll_st, Z.ll_tt, spread);
-        ze_build_ctable(ZE_ML_DEFAULT, 53, 6, Z.ml_st, Z.ml_tt, spread);
-        ze_build_ctable(ZE_OF_DEFAULT, 29, 5, Z.of_st, Z.of_tt, spread);
+// FSE encoding tables of the predefined distributions, built by the COMPILER (constexpr restatement of ze_build_ctable)
+// and copied into LDS by the wave: every piece is a frame of its own, and three table builds by one lane were a fixed
+// cost per 16 KiB piece.
+struct ZePreTables {
+    uint16_t ll_st[64], ml_st[64], of_st[32];
+    ZeSymTT ll_tt[36], ml_tt[53], of_tt[29];
+};
+constexpr int zec_highbit(uint32_t v) {
+    int r = 0;
+    while (v >>= 1) r++;
+    return r;
+}
+template <int NSYM, int LOG>
+constexpr void zec_ctable(const int16_t (&norm)[NSYM], uint16_t* state_table, ZeSymTT* tt) {
+    constexpr int size = 1 << LOG, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    int high = size - 1;
+    int cumul[NSYM + 1] = {};
+    uint8_t spread[size] = {};
+    for (int s = 0; s < NSYM; s++) {
+        if (norm[s] == -1) {
+            cumul[s + 1] = cumul[s] + 1;
+            spread[high--] = (uint8_t)s;
+        } else {
+            cumul[s + 1] = cumul[s] + norm[s];
+        }
     }
+    int pos = 0;
+    for (int s = 0; s < NSYM; s++) {
+        for (int k = 0; k < norm[s]; k++) {
+            spread[pos] = (uint8_t)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    for (int u = 0; u < size; u++) {
+        const int s = spread[u];
+        state_table[cumul[s]++] = (uint16_t)(size + u);
+    }
+    int total = 0;
+    for (int s = 0; s < NSYM; s++) {
+        const int c = norm[s];
+        if (c == 0) {
+            tt[s].delta_nb_bits = ((LOG + 1) << 16) - (1 << LOG);
+            tt[s].delta_find_state = 0;
+        } else if (c == -1 || c == 1) {
+            tt[s].delta_nb_bits = (LOG << 16) - (1 << LOG);
+            tt[s].delta_find_state = total - 1;
+            total++;
+        } else {
+            const int max_bits_out = LOG - zec_highbit((uint32_t)(c - 1));
+            const int min_state_plus = c << max_bits_out;
+            tt[s].delta_nb_bits = (max_bits_out << 16) - min_state_plus;
+            tt[s].delta_find_state = total - c;
+            total += c;
+        }
+    }
+}
+constexpr int16_t ZEC_LL[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+constexpr int16_t ZEC_ML[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+constexpr int16_t ZEC_OF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+constexpr ZePreTables zec_make_pre() {
+    ZePreTables t = {};
+    zec_ctable<36, 6>(ZEC_LL, t.ll_st, t.ll_tt);
+    zec_ctable<53, 6>(ZEC_ML, t.ml_st, t.ml_tt);
+    zec_ctable<29, 5>(ZEC_OF, t.of_st, t.of_tt);
+    return t;
+}
+__device__ const ZePreTables g_zepre = zec_make_pre();
+__device__ __forceinline__ void ze_tables(ZEncLds& Z) {   // (once per wave)
+    const uint32_t lane = threadIdx.x & 63;
+    Z.ll_st[lane] = g_zepre.ll_st[lane];
+    Z.ml_st[lane] = g_zepre.ml_st[lane];
+    if (lane < 32) Z.of_st[lane] = g_zepre.of_st[lane];
+    if (lane < 36) Z.ll_tt[lane] = g_zepre.ll_tt[lane];
+    if (lane < 53) Z.ml_tt[lane] = g_zepre.ml_tt[lane];
+    if (lane < 29) Z.of_tt[lane] = g_zepre.of_tt[lane];
     wave_sync();
 }
 

@@ -147,9 +147,19 @@ __device__ unsigned long long* g_dtl;
     do {                                                                                                      \
         if (g_dtl && blockIdx.x == 100 && threadIdx.x == 0) g_dtl[16 + (p)] = __builtin_readcyclecounter(); \
     } while (0)
+// k_inflate: wave 0, lane 0: g_dtl[32 + p] += cycles since the last stamp (scripts/micro/inflate_timeline.hip)
+#define ITL_BEGIN unsigned long long itl_t = __builtin_readcyclecounter();
+#define ITL(p)                                                                          \
+    do {                                                                                \
+        const unsigned long long n_ = __builtin_readcyclecounter();                     \
+        if (g_dtl && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_dtl[32 + (p)] += n_ - itl_t; \
+        itl_t = n_;                                                                     \
+    } while (0)
 #else
 #define DTL(p)
 #define PTL(p)
+#define ITL_BEGIN
+#define ITL(p)
 #endif
 
 // primitive RLE pages of <= 8-byte values are expanded by one workgroup per page (k_expand_rle)
@@ -780,6 +790,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
         return;
     }
     uint64_t* arena = zrec + (uint64_t)blockIdx.x * ZREC_PER_WAVE;
+    ITL_BEGIN
     for (uint32_t base = blockIdx.x * B; base < njobs; base += gridDim.x * B) {
         const uint32_t nb = min(B, njobs - base);
         InflateJob mine;
@@ -795,6 +806,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
         hf.dst = mine.dst;
         hf.lleft = hf.regen = 0;
         const bool lit_only = zs && z_lane_litonly(mine.src, mine.csize, mine.out_len, &hf.ls, &hf.lleft, &hf.regen);
+        ITL(0);
         uint64_t todo = __ballot(lit_only);
         uint64_t done_m = 0;
         if (todo) {
@@ -807,8 +819,10 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
                 if (in_group) H.fr[my_g] = hf;
                 const uint32_t ng = (uint32_t)__popcll(gm);
                 __syncthreads();
+                ITL(1);
                 if (lane < ng) z_lane_huf_table(H, lane);
                 __syncthreads();
+                ITL(2);
                 bool ok = true, act = false;
                 const uint32_t g = lane >> 2, j = lane & 3;
                 if (g < ng && H.bits[g]) {
@@ -827,6 +841,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
                         ok = z_lane_huf_stream(H.tab[g], H.bits[g], q + 6 + so, sn, f.dst + j * per, outn);
                     }
                 }
+                ITL(3);
                 // a frame is done when its four streams decoded; anything else is left to the one-wave decoder (and its errors)
                 const uint64_t okm = __ballot(act && ok);
                 uint64_t grp_done = 0;
@@ -843,6 +858,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             __syncthreads();
         }
+        ITL(4);
         // phase 0 (lane per frame): how many sequences, and does the frame qualify
         uint32_t cnt = (zs && !((done_m >> lane) & 1)) ? z_lane_frame(mine.src, mine.csize, mine.out_len, zt, nullptr, 0) : ZPRE_NONE;
         uint32_t start = 0;
@@ -863,6 +879,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            ITL(5);
             // phase 2 (the wave per job, in queue order)
             for (uint32_t k = start; k < end; k++) {
                 if ((done_m >> k) & 1) continue;   // decoded in phase H
@@ -870,6 +887,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
                 const uint32_t k_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)k);
                 inflate_one(jobs[base + k], st, wk, my_lit, s_win, s_pos, k_ok ? arena + k_off : nullptr);
             }
+            ITL(6);
             start = end;
         }
     }

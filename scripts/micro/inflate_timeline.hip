@@ -5,6 +5,15 @@
 //         -o scripts/micro/inflate_timeline.bin
 //   scripts/micro/inflate_timeline.bin [columns = 128] [kind: 0 = offsets-like Int32, 1 = random-walk Int64]
 #define SB_TIMELINE 1
+#include <hip/hip_runtime.h>
+__device__ unsigned long long* g_ztl;
+#define ZTL_BEGIN unsigned long long ztl_t = __builtin_readcyclecounter();
+#define ZTL(p)                                                                                             \
+    do {                                                                                                   \
+        const unsigned long long n_ = __builtin_readcyclecounter();                                        \
+        if (g_ztl && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_ztl[48 + (p)] += n_ - ztl_t;       \
+        ztl_t = n_;                                                                                        \
+    } while (0)
 #include "../../strawboat_amd/csrc/sb_decode.hip"
 #include <cstdio>
 #include <cstring>
@@ -57,6 +66,7 @@ int main(int argc, char** argv) {
     unsigned long long* tl;
     hipMalloc(&tl, 8 * 64); hipMemset(tl, 0, 8 * 64);
     hipMemcpyToSymbol(HIP_SYMBOL(sb::g_dtl), &tl, sizeof(tl));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ztl), &tl, sizeof(tl));
     for (int i = 0; i < 2; i++) CK(sb_read_columns(ctx, rc.data(), B, SB_MEM_DEVICE));
     CK(sb_ctx_synchronize(ctx));
     hipMemset(tl, 0, 8 * 64);
@@ -73,5 +83,7 @@ int main(int argc, char** argv) {
     const char* names[7] = {"headers (lane per frame)", "group setup", "Huffman tables (lane per frame)", "streams (lane per stream)", "end of phase H",
                             "sequence pre-decode (lane per frame)", "one-wave path"};
     for (int p = 0; p < 7; p++) printf("  %-40s %10.1f us\n", names[p], (double)t[32 + p] / 2400.0);
+    const char* zn[4] = {"streams: round setup", "streams: stage in", "streams: decode 64 symbols", "streams: store"};
+    for (int p = 0; p < 4; p++) printf("  %-40s %10.1f us\n", zn[p], (double)t[48 + p] / 2400.0);
     return 0;
 }

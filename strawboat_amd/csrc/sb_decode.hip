@@ -820,11 +820,16 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
                 const uint32_t ng = (uint32_t)__popcll(gm);
                 __syncthreads();
                 ITL(1);
-                if (lane < ng) z_lane_huf_table(H, lane);
+                if (lane < ng) z_lane_huf_table(H, lane);   // (the weights, lane per frame)
+                __syncthreads();
+                z_wave_huf_fill(H, ng);
                 __syncthreads();
                 ITL(2);
                 bool ok = true, act = false;
                 const uint32_t g = lane >> 2, j = lane & 3;
+                const uint8_t* sp = nullptr;
+                uint8_t* sd = nullptr;
+                uint32_t sn = 0, outn = 0, mbits = 0;
                 if (g < ng && H.bits[g]) {
                     act = true;
                     const ZHufFrame f = H.fr[g];
@@ -836,10 +841,17 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
                         ok = false;
                     } else {
                         const uint32_t so = j == 0 ? 0u : j == 1 ? s1 : j == 2 ? s1 + s2 : s1 + s2 + s3;
-                        const uint32_t sn = j == 0 ? s1 : j == 1 ? s2 : j == 2 ? s3 : left - 6 - s1 - s2 - s3;
-                        const uint32_t outn = j < 3 ? per : f.regen - 3 * per;
-                        ok = z_lane_huf_stream(H.tab[g], H.bits[g], q + 6 + so, sn, f.dst + j * per, outn);
+                        sn = j == 0 ? s1 : j == 1 ? s2 : j == 2 ? s3 : left - 6 - s1 - s2 - s3;
+                        outn = j < 3 ? per : f.regen - 3 * per;
+                        sp = q + 6 + so;
+                        sd = f.dst + j * per;
+                        mbits = H.bits[g];
                     }
+                }
+                __syncthreads();   // (the tables' scratch becomes the staging area)
+                {
+                    const bool sok = z_wave_huf_streams(H, g, mbits, sp, sn, sd, outn, act && ok);
+                    ok = ok && sok;
                 }
                 ITL(3);
                 // a frame is done when its four streams decoded; anything else is left to the one-wave decoder (and its errors)

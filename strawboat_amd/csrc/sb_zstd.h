@@ -604,16 +604,30 @@ struct ZHufFrame {   // a literals-only frame (filled by the lane that owns the 
     uint32_t lleft;      // bytes of that payload
     uint32_t regen;      // bytes it regenerates (= the frame's content)
 };
-struct ZHufLanes {   // phase workspace (shares its LDS with ZWork)
-    uint16_t tab[ZH_GROUP][1 << ZH_MAXBITS];
+struct ZHufBuild {   // table construction, lane per frame
     uint8_t wts[ZH_GROUP][256];
     ZFse fse[ZH_GROUP][64];
     int16_t norm[ZH_GROUP][16];
     uint16_t next[ZH_GROUP][16];
+};
+struct ZHufStage {   // stream decoding, lane per stream: the next 128 bytes of every stream, staged by the wave together
+    uint64_t in[64][16];   // row = stream; word k of stream s sits in slot (k + s) & 15 (all lanes read "their word k" at once)
+    uint64_t ptr[64];      // stream base, then (after the decode step) where the round's bytes go
+    int32_t lo[64];        // first staged byte of the stream (may lie in front of it: zeros), INT_MIN: stream idle
+    uint32_t cnt[64];      // bytes decoded in the round
+};
+struct ZHufLanes {   // phase workspace (shares its LDS with ZWork)
+    uint16_t tab[ZH_GROUP][1 << ZH_MAXBITS];
+    union {
+        ZHufBuild b;
+        ZHufStage s;
+    };
+    uint64_t ob[64][8];          // the round's output, 64 bytes per stream (u64 m of stream s in slot (m + s) & 7)
     ZHufFrame fr[ZH_GROUP];
     uint32_t bits[ZH_GROUP];     // code bits of frame g's table (0: not decodable here)
     uint32_t str0[ZH_GROUP];     // offset of the jump table inside ls
 };
+static_assert(sizeof(ZHufStage) <= sizeof(ZHufBuild), "sb_zstd.h: the staging area lives in the table builder's scratch");
 // One frame src[0, n) with content out_len: is it a literals-only frame of the shape above?  (lane per frame)
 __device__ inline bool z_lane_litonly(const uint8_t* src, uint32_t n, uint32_t out_len, const uint8_t** ls, uint32_t* lleft, uint32_t* regen_out) {
     if (n < 12 || ldu32(src) != 0xFD2FB528u) return false;
@@ -670,7 +684,7 @@ __device__ inline void z_lane_huf_table(ZHufLanes& H, uint32_t g) {
     const uint8_t* src = H.fr[g].ls;
     const uint32_t n = H.fr[g].lleft;
     H.bits[g] = 0;
-    uint8_t* wts = H.wts[g];
+    uint8_t* wts = H.b.wts[g];
     const uint8_t hb = ldu8(src);
     int nw;
     uint32_t used;
@@ -687,10 +701,10 @@ __device__ inline void z_lane_huf_table(ZHufLanes& H, uint32_t g) {
         const uint32_t clen = hb;
         if (n < 1 + clen || clen < 2) return;
         int nsym, log;
-        const uint32_t hsz = z_fse_header(src + 1, clen, 12, 6, H.norm[g], &nsym, &log);
+        const uint32_t hsz = z_fse_header(src + 1, clen, 12, 6, H.b.norm[g], &nsym, &log);
         if (!hsz || hsz >= clen) return;
-        ZFse* t = H.fse[g];
-        if (!z_fse_build2(t, H.next[g], H.norm[g], nsym, log)) return;
+        ZFse* t = H.b.fse[g];
+        if (!z_fse_build2(t, H.b.next[g], H.b.norm[g], nsym, log)) return;
         const uint8_t* bs = src + 1 + hsz;
         const uint32_t bn = clen - hsz;
         if (ldu8(bs + bn - 1) == 0) return;
@@ -725,41 +739,215 @@ __device__ inline void z_lane_huf_table(ZHufLanes& H, uint32_t g) {
         }
         used = 1 + clen;
     }
-    uint32_t total = 0;
-    for (int i = 0; i < nw; i++) {
-        if (wts[i] > 11) return;
-        total += wts[i] ? (1u << (wts[i] - 1)) : 0;
+    if (n < used + 6 || nw < 1) return;
+    H.str0[g] = used;
+    H.bits[g] = (uint32_t)nw;   // (weights decoded: z_wave_huf_fill turns this into the table's code bits)
+}
+// The tables of the group's frames from their weights, by the whole wave, frame after frame: class sizes by ballots, the
+// symbols in (weight, symbol) order into a 256-byte list, then every lane fills 8 of the table's entries (class of the
+// code by a compare chain over <= 11 class starts, symbol from the list).  One lane filling its frame's table weight by
+// weight (11 passes over 256 symbols + 512 stores) took 0.9 ms per group.
+__device__ inline void z_wave_huf_fill(ZHufLanes& H, uint32_t ng) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t nw = H.bits[g];   // (uniform)
+        if (!nw) continue;
+        wave_sync();
+        uint32_t w[4];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t sy = lane + 64 * j;
+            w[j] = sy < nw ? (uint32_t)H.b.wts[g][sy] : 0u;
+            bad = bad || w[j] > 11;
+        }
+        uint32_t cw[12], total = 0;
+#pragma unroll
+        for (uint32_t wv = 1; wv < 12; wv++) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) c += (uint32_t)__popcll(__ballot(w[j] == wv));
+            cw[wv] = c;
+            total += c << (wv - 1);
+        }
+        uint32_t max_bits = 0, lw = 0;
+        bool okf = !__ballot(bad) && total != 0;
+        if (okf) {
+            max_bits = 32u - (uint32_t)__clz((int)total);
+            const uint32_t left = (1u << max_bits) - total;
+            okf = left != 0 && !(left & (left - 1)) && max_bits <= ZH_MAXBITS;
+            lw = okf ? 32u - (uint32_t)__clz((int)left) : 0u;   // weight of the last symbol (implied)
+        }
+        if (!okf) {
+            if (lane == 0) H.bits[g] = 0;
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (lane + 64 * j == nw) w[j] = lw;
+        uint32_t start[12], before[12];
+        {
+            uint32_t code = 0, nb = 0;
+#pragma unroll
+            for (uint32_t wv = 1; wv < 12; wv++) {
+                const uint32_t c = cw[wv] + (wv == lw ? 1u : 0u);
+                cw[wv] = c;
+                start[wv] = code;
+                before[wv] = nb;
+                code += c << (wv - 1);
+                nb += c;
+            }
+        }
+        uint8_t* sl = (uint8_t*)H.b.fse[g];   // (the frame's FSE table is done with)
+#pragma unroll
+        for (uint32_t wv = 1; wv < 12; wv++) {
+            if (!cw[wv]) continue;   // (uniform)
+            uint32_t base = before[wv];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t m = __ballot(w[j] == wv);
+                if (w[j] == wv) sl[base + lane_rank(m)] = (uint8_t)(lane + 64 * j);
+                base += (uint32_t)__popcll(m);
+            }
+        }
+        wave_sync();
+        uint16_t* tab = H.tab[g];
+#pragma unroll
+        for (uint32_t k = 0; k < (1u << ZH_MAXBITS) / 64; k++) {
+            const uint32_t c = lane + 64 * k;
+            if (c >= (1u << max_bits)) break;
+            uint32_t cls = 1, st = 0, bf = 0;
+#pragma unroll
+            for (uint32_t wv = 1; wv < 12; wv++) {
+                if (cw[wv] && c >= start[wv]) {
+                    cls = wv;
+                    st = start[wv];
+                    bf = before[wv];
+                }
+            }
+            tab[c] = (uint16_t)((uint32_t)sl[bf + ((c - st) >> (cls - 1))] | ((max_bits + 1 - cls) << 8));
+        }
+        if (lane == 0) H.bits[g] = max_bits;
     }
-    if (total == 0) return;
-    const int max_bits = 32 - __clz((int)total);
-    const uint32_t left = (1u << max_bits) - total;
-    if (left == 0 || (left & (left - 1)) || max_bits > (int)ZH_MAXBITS) return;
-    wts[nw] = (uint8_t)(32 - __clz((int)left));
-    const int nn = nw + 1;
-    // start of every weight class (codes in increasing weight, symbols of one weight in symbol order), then one pass
-    uint32_t start[12], cnt[12];
-    for (int w = 0; w < 12; w++) cnt[w] = 0;
-    for (int sy = 0; sy < nn; sy++) cnt[wts[sy]]++;
-    uint32_t code = 0;
-    for (int w = 1; w <= max_bits; w++) {
-        start[w] = code;
-        code += cnt[w] << (w - 1);
-    }
-    uint16_t* tab = H.tab[g];
-    for (int w = 1; w <= max_bits; w++) {   // (per weight: no register array indexed by a loaded value)
-        uint32_t c = start[w];
-        const uint32_t span = 1u << (w - 1);
-        const uint16_t lenbits = (uint16_t)((max_bits + 1 - w) << 8);
-        if (!cnt[w]) continue;
-        for (int sy = 0; sy < nn; sy++) {
-            if (wts[sy] != w) continue;
-            for (uint32_t k = 0; k < span; k++) tab[c + k] = (uint16_t)sy | lenbits;
-            c += span;
+    wave_sync();
+}
+
+#ifndef ZTL   // phase stamps of z_wave_huf_streams (scripts/micro/inflate_timeline.hip defines them)
+#define ZTL_BEGIN
+#define ZTL(p)
+#endif
+// The streams of up to 16 staged frames, LANE PER STREAM (lane 4 g + j = stream j of frame g), in rounds of 64 symbols.
+// A lane reading its own stream from HBM is one cache line per lane and load, and the same again for its 8-byte stores:
+// 2600 cycles per symbol on C5's leaves.  Here the wave moves the data: per round it stages the next 128 bytes of every
+// stream in LDS (8 loads of 16 bytes per lane, eight lanes on one stream: 8-16 lines per load), every lane decodes 64
+// symbols from its row (<= 9 bits each: 72 bytes) into its row of `ob`, and the wave stores the 64 rows (four lanes per
+// stream, 16 bytes each).  `act`: the lane has a stream; returns its verdict (all bits consumed, nothing beyond).
+__device__ inline bool z_wave_huf_streams(ZHufLanes& H, uint32_t g, uint32_t mb, const uint8_t* sb_, uint32_t sn, uint8_t* dst, uint32_t outn, bool act) {
+    const uint32_t lane = threadIdx.x & 63;
+    ZHufStage& S = H.s;
+    int32_t left = 0;
+    if (act) {
+        const uint8_t lastb = sn ? ldu8(sb_ + sn - 1) : (uint8_t)0;
+        if (lastb == 0) {
+            act = false;
+        } else {
+            left = (int32_t)sn * 8 - (int32_t)(8 - (31 - (uint32_t)__clz((int)lastb)));   // bits above the end mark, and the mark, are gone
         }
     }
-    if (n < used + 6) return;
-    H.str0[g] = used;
-    H.bits[g] = (uint32_t)max_bits;
+    const bool had = act;
+    bool ok = true;
+    uint32_t done = 0;
+    ZTL_BEGIN
+    while (__ballot(act && ok && done < outn)) {
+        ZTL(0);
+        const bool run = act && ok && done < outn;
+        const int32_t hi = (left + 7) >> 3;   // byte just above the top bit
+        S.ptr[lane] = (uint64_t)(uintptr_t)sb_;
+        S.lo[lane] = run ? hi - 128 : (int32_t)0x80000000;
+        wave_sync();
+#pragma unroll
+        for (uint32_t p = 0; p < 8; p++) {
+            const uint32_t s = 8 * p + (lane >> 3), c = lane & 7;
+            const int32_t lo = S.lo[s];
+            if (lo == (int32_t)0x80000000) continue;
+            const uint8_t* src = (const uint8_t*)(uintptr_t)S.ptr[s];
+            const int32_t b = lo + 16 * (int32_t)c;   // (b + 16 <= hi <= the stream's size)
+            uint64_t v0 = 0, v1 = 0;
+            if (b >= 0) {
+                const u32x4 v = ldu128(src + b);
+                v0 = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                v1 = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            } else if (b > -16) {   // the stream starts inside this chunk: the bytes in front of it read as zeros
+                for (int32_t k = -b; k < 16; k++) {
+                    const uint64_t by = ldu8(src + b + k);
+                    if (k < 8)
+                        v0 |= by << (8 * k);
+                    else
+                        v1 |= by << (8 * (k - 8));
+                }
+            }
+            S.in[s][(2 * c + s) & 15] = v0;
+            S.in[s][(2 * c + 1 + s) & 15] = v1;
+        }
+        wave_sync();
+        ZTL(1);
+        uint32_t n_this = 0;
+        if (run) {
+            n_this = min(64u, outn - done);
+            // 32-bit words of my row, from the top (word w of stream s: half w & 1 of slot ((w >> 1) + s) & 15); bb holds
+            // the next bits top-aligned (cnt of them valid, > 32 after every refill): one 64-bit shift per symbol
+            const uint32_t* row32 = (const uint32_t*)S.in[lane];
+            auto word = [&](int32_t w) -> uint32_t { return w >= 0 ? row32[2 * (((uint32_t)(w >> 1) + lane) & 15) + (w & 1)] : 0u; };
+            const uint32_t u0 = (uint32_t)(8 * hi - left);   // unused bits of the top byte (0 .. 7)
+            uint64_t bb = (((uint64_t)word(31) << 32) | word(30)) << u0;
+            uint32_t cnt = 64 - u0;
+            int32_t wi = 29;
+            const uint16_t* tab = H.tab[g];
+            const uint32_t sh = 32 - mb;
+            uint32_t out32 = 0;
+            uint32_t* orow = (uint32_t*)H.ob[lane];
+            for (uint32_t i = 0; i < n_this; i++) {
+                if (cnt <= 32) {
+                    bb |= (uint64_t)word(wi--) << (32 - cnt);
+                    cnt += 32;
+                }
+#if defined(ZH_EXPERIMENT) && ZH_EXPERIMENT == 1
+                const uint32_t e = 0x0600u | (((uint32_t)(bb >> 32) >> sh) & 255u);
+#else
+                const uint32_t e = tab[(uint32_t)(bb >> 32) >> sh];
+#endif
+                const uint32_t len = e >> 8;
+                bb <<= len;
+                cnt -= len;
+                left -= (int32_t)len;
+                out32 = (out32 >> 8) | ((e & 255u) << 24);
+                if ((i & 3) == 3) orow[2 * ((((i >> 3)) + lane) & 7) + ((i >> 2) & 1)] = out32;
+            }
+            if (n_this & 3) orow[2 * ((((n_this >> 3)) + lane) & 7) + ((n_this >> 2) & 1)] = out32 >> (8 * (4 - (n_this & 3)));
+            if (left < 0) ok = false;
+        }
+        S.cnt[lane] = ok ? n_this : 0u;
+        S.ptr[lane] = (uint64_t)(uintptr_t)(dst + done);
+        wave_sync();
+        ZTL(2);
+#pragma unroll
+        for (uint32_t p = 0; p < 4; p++) {
+            const uint32_t s = 16 * p + (lane >> 2), c = lane & 3;
+            const uint32_t cs = S.cnt[s];
+            if (16 * c >= cs) continue;
+            uint8_t* d = (uint8_t*)(uintptr_t)S.ptr[s] + 16 * c;
+            const uint64_t v0 = H.ob[s][(2 * c + s) & 7], v1 = H.ob[s][(2 * c + 1 + s) & 7];
+            if (16 * c + 16 <= cs) {
+                stu128(d, u32x4{(uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)});
+            } else {
+                for (uint32_t k = 0; k < cs - 16 * c; k++) *(gptr)(d + k) = (uint8_t)((k < 8 ? v0 >> (8 * k) : v1 >> (8 * (k - 8))));
+            }
+        }
+        done += n_this;
+        wave_sync();
+        ZTL(3);
+    }
+    return had && ok && done == outn && left == 0;
 }
 // One stream sb_[0, sn) -> outn bytes at dst, by one lane; table: 2^mb entries.  Returns false on a malformed stream.
 __device__ inline bool z_lane_huf_stream(const uint16_t* tab, uint32_t mb, const uint8_t* sb_, uint32_t sn, uint8_t* dst, uint32_t outn) {

@@ -554,8 +554,9 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     a.n_cols = (uint32_t)n;
     a.n_tiles = (uint32_t)T;
     // LZ4 blocks for the workgroup decoder: in a call with few blocks every block of 16 KiB and more (a lone wave's latency
-    // is what the call waits for); in a call that fills the one-wave pool several times over only the blocks of 64 KiB and more
-    const uint32_t big_min = 2 * P >= 4096 ? LZ4_BIG_MIN : LZ4_BIG_MIN / 4;
+    // is what the call waits for); in a call that fills the one-wave pool several times over only the blocks of 128 KiB and
+    // more (64 KiB pages of incompressible values — the reference's bench shape — stay with the one-wave copy path)
+    const uint32_t big_min = 2 * P >= 4096 ? 2 * LZ4_BIG_MIN : LZ4_BIG_MIN / 4;
     a.lz4_big_min = max_page_len >= big_min ? big_min : 0xFFFFFFFFu;
     a.freq_log = nullptr;
     a.freq_count = nullptr;

@@ -18,6 +18,10 @@ forbidden_compressions: every codec of the reference is a candidate, as with its
 own bench shapes (benches/write_strawboat.rs:30-67), each with encode / decode GB/s of Arrow bytes,
 the fraction of the HBM roofline its algorithmic bytes reach per direction, the kernel that
 dominates each direction, and the CPU restatement timed on this box (1 thread and all cores).
+Every entry lists the five largest kernels of each direction, `page_bytes_vs_reference` (this library's page bytes
+over the bytes of the same pages written with the box's liblz4 / libzstd), and — `c3_lz4_reference_written`,
+`c5.leaf_pages_reference_written` — the decode of pages the reference's codecs wrote (one LZ4 block / one libzstd
+frame per buffer).  `config.summary` repeats one line per configuration inside the keys the driver keeps.
 C2 is the FRIENDLIEST configuration (16x compressible runs); the LZ4 / Dict / nested ones are
 one to two orders of magnitude slower per Arrow byte — read `configs`, not only `value`.
 

@@ -431,30 +431,32 @@ def run_c5(h, cpu_on, arrays=64):
 
     def measure(its, reps):
         pairs = [(dl, dc) for dl, dc, _, _ in its]
-        encs = nested.write_nested_leaves(ctx, pairs, opts)      # warm-up + outputs
+        wb = nested.NestedWriteBatch(ctx, pairs, opts)      # descriptors and buffers once, like WriteBatch for flat columns
+        encs = wb.run()                                     # warm-up + outputs
         t0 = time.perf_counter()
         for _ in range(reps):
-            encs = nested.write_nested_leaves(ctx, pairs, opts)
+            encs = wb.run()
         te = (time.perf_counter() - t0) / reps * 1e3
         cps = [ColumnPages(c["ptype"], False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (_, _, c, _) in zip(encs, its)]
         kinds = [[lv["kind"] for lv in lv_] for _, _, _, lv_ in its]
         opt = [[bool(lv["is_optional"]) for lv in lv_] for _, _, _, lv_ in its]
-        arrs = nested.read_nested_leaves(ctx, cps, kinds, opt)
+        rb = nested.NestedReadBatch(ctx, cps, kinds, opt)
+        arrs = rb.run()
         t0 = time.perf_counter()
         for _ in range(reps):
-            arrs = nested.read_nested_leaves(ctx, cps, kinds, opt)
+            arrs = rb.run()
         td = (time.perf_counter() - t0) / reps * 1e3
-        return pairs, encs, cps, kinds, opt, arrs, te, td
-    pairs, encs, cps, kinds, opt, arrs, te, td = measure(items, 3)
+        return pairs, encs, cps, kinds, opt, arrs, te, td, wb, rb
+    pairs, encs, cps, kinds, opt, arrs, te, td, wb, rb = measure(items, 3)
     # round trip: list offsets and leaf buffers of the first array
     assert np.array_equal(arrs[0].offsets_numpy(0), la[0]["offsets"].astype(np.int64)), "C5 list offsets round trip failed"
     assert np.array_equal(arrs[1].leaf.values_numpy(), b["values"]), "C5 Utf8 leaf round trip failed"
     m = np.unpackbits(a["validity"], bitorder="little")[:a["rows"]].astype(bool)
     assert np.array_equal(arrs[0].leaf.values_numpy().view(np.int64)[m], a["values"][m]), "C5 Int64 leaf round trip failed"
     ctx.profile(True)
-    nested.write_nested_leaves(ctx, pairs, opts)
+    wb.run()
     st_e = ctx.profile_read()
-    nested.read_nested_leaves(ctx, cps, kinds, opt)
+    rb.run()
     st_d = ctx.profile_read()       # accumulated since profile(True): take the write's share out
     st_d = {k: (v[0] - st_e.get(k, (0, 0.0))[0], v[1] - st_e.get(k, (0, 0.0))[1]) for k, v in st_d.items()}
     st_d = {k: v for k, v in st_d.items() if v[0] > 0}
@@ -469,8 +471,9 @@ def run_c5(h, cpu_on, arrays=64):
                            "the two leaf columns of one array as flat non-nullable columns (leaf blocks only, no level sections)")
     e = config_entry("c5", res, cpu, {"workload": "C5: %d x 1 M-row List<Struct<Int64,Utf8>> (list length U{0,1,2}, 10 %% null lists, leaves 20 %% "
                                                   "null), 64Ki-row pages, Zstd default, ratio None; %d leaf columns x 16 pages through the nested API "
-                                                  "(level sections of all leaves in one batch, then the BLOCKs of all leaves in one call); wall "
-                                                  "time of the calls incl. their host round trips" % (arrays, 2 * arrays)})
+                                                  "(NestedWriteBatch / NestedReadBatch: descriptors and buffers built once; a run = level sections of all "
+                                                  "leaves in one batch, then the BLOCKs of all leaves in one call); wall time of the runs incl. their "
+                                                  "host round trips" % (arrays, 2 * arrays)})
 
     def top(st, direction):
         if st:
@@ -496,7 +499,7 @@ def run_c5(h, cpu_on, arrays=64):
                             "decodes such a frame on one wave), decoded on the device" % arrays
             e["leaf_pages_reference_written"] = r
     if arrays > 1:   # the round-2 shape: one array per call
-        _, _, _, _, _, _, te1, td1 = measure(items[:2], 3)
+        _, _, _, _, _, _, te1, td1, _, _ = measure(items[:2], 3)
         U1 = W.arrow_bytes(a) + W.arrow_bytes(b) + 2 * ((la[0]["length"] + 1) * 4 + (la[0]["length"] + 7) // 8)
         e["single_array"] = {"arrow_MB": round(U1 / 1e6, 1), "write_ms": round(te1, 3), "read_ms": round(td1, 3),
                              "encode_GBps": round(U1 / te1 / 1e6, 2), "decode_GBps": round(U1 / td1 / 1e6, 2)}

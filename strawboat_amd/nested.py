@@ -68,35 +68,49 @@ class NestedLevels:
         return int(self.level_bytes.size)
 
 
+class _LevelsWrite:
+    """descriptors + outputs of one sb_nested_write_levels_batch call, built once; call() runs it (again)"""
+
+    def __init__(self, ctx, levels_list, max_page_size: Optional[int]):
+        import torch
+        self.ctx = ctx
+        self.n = n = len(levels_list)
+        self.mps = mps = 0 if max_page_size is None else int(max_page_size)
+        self.items = (N.NestedLevelsWriteC * max(n, 1))()
+        self.keep = []
+        with torch.cuda.stream(ctx.torch_stream):
+            for k, levels in enumerate(levels_list):
+                arr = _levels_c(levels)
+                rows = levels[0].length
+                bound = int(ctx._lib.sb_nested_levels_bound(arr, len(levels), rows, mps))
+                ps = min(mps, rows) if mps else rows
+                npages = (rows + ps - 1) // ps if rows else 0
+                out = torch.empty(max(bound, 1), dtype=torch.uint8, device=ctx.torch_device)
+                pages = (N.NestedPageC * max(npages, 1))()
+                it = self.items[k]
+                it.levels, it.n_levels, it.rows = arr, len(levels), rows
+                it.out_levels, it.out_capacity = _ptr(out), out.numel()
+                it.pages, it.n_pages_capacity = pages, len(pages)
+                self.keep.append((arr, out, pages))
+
+    def call(self):
+        if self.n:
+            self.ctx._check(self.ctx._lib.sb_nested_write_levels_batch(self.ctx._h, self.items, self.n, self.mps))
+
+    def info(self, k):
+        """(level_bytes, num_values, leaf_start, leaf_count) per page of leaf column k, as the last call() left them"""
+        return np.frombuffer(self.keep[k][2], dtype=np.uint64).reshape(-1, 4)[:int(self.items[k].n_pages)]
+
+    def results(self) -> List[NestedLevels]:
+        return [NestedLevels(out, self.info(k).copy()) for k, (_, out, _) in enumerate(self.keep)]
+
+
 def write_levels_batch(ctx, levels_list, max_page_size: Optional[int]) -> List[NestedLevels]:
     """write_nested_validity for every page of every leaf column of a call: ONE set of launches over all pages of all
     leaves and ONE host round trip for the page cut (sb_nested_write_levels_batch)."""
-    import torch
-    n = len(levels_list)
-    mps = 0 if max_page_size is None else int(max_page_size)
-    items = (N.NestedLevelsWriteC * max(n, 1))()
-    keep = []
-    with torch.cuda.stream(ctx.torch_stream):
-        for k, levels in enumerate(levels_list):
-            arr = _levels_c(levels)
-            rows = levels[0].length
-            bound = int(ctx._lib.sb_nested_levels_bound(arr, len(levels), rows, mps))
-            ps = min(mps, rows) if mps else rows
-            npages = (rows + ps - 1) // ps if rows else 0
-            out = torch.empty(max(bound, 1), dtype=torch.uint8, device=ctx.torch_device)
-            pages = (N.NestedPageC * max(npages, 1))()
-            it = items[k]
-            it.levels, it.n_levels, it.rows = arr, len(levels), rows
-            it.out_levels, it.out_capacity = _ptr(out), out.numel()
-            it.pages, it.n_pages_capacity = pages, len(pages)
-            keep.append((arr, out, pages))
-    if n:
-        ctx._check(ctx._lib.sb_nested_write_levels_batch(ctx._h, items, n, mps))
-    res = []
-    for k, (arr, out, pages) in enumerate(keep):
-        info = np.frombuffer(pages, dtype=np.uint64).reshape(-1, 4)[:int(items[k].n_pages)].copy()
-        res.append(NestedLevels(out, info))
-    return res
+    lw = _LevelsWrite(ctx, levels_list, max_page_size)
+    lw.call()
+    return lw.results()
 
 
 def write_levels(ctx, levels: Sequence[NestedLevel], rows: int, max_page_size: Optional[int]) -> NestedLevels:
@@ -121,63 +135,89 @@ class NestedEncodedColumn(EncodedColumn):
                         dtype=np.uint64).reshape(-1, 2)
 
 
+class NestedWriteBatch:
+    """The two calls behind write_nested_leaves with their descriptors and output buffers built ONCE (what WriteBatch is
+    for flat columns): run() = sb_nested_write_levels_batch (level sections of every leaf, one host round trip for the
+    page cut) + sb_write_columns (the BLOCKs of all leaves) + synchronize.  A host that writes chunk after chunk of one
+    schema keeps such an object per chunk shape instead of allocating per call."""
+
+    def __init__(self, ctx, items, options: WriteOptions):
+        import torch
+        self.ctx = ctx
+        self.n = n = len(items)
+        self.oc = oc = options_c(options)
+        oc.max_page_size = 0
+        self.arr = arr = (N.ColumnWriteC * max(n, 1))()
+        self.lw = _LevelsWrite(ctx, [levels for levels, _ in items], options.max_page_size)
+        self.lw.call()
+        self._fresh = True   # (the level sections of the first run() are already there)
+        self.keep, self.outs, self.page_rows, self.heads = [], [], [], []
+        for k, (levels, leaf) in enumerate(items):
+            info = self.lw.info(k)
+            n_pages = info.shape[0]
+            if n_pages and int(info[0, 2]) != 0:
+                raise ValueError("leaf slice must start at 0")
+            c = arr[k]
+            c.physical_type = leaf.physical_type
+            c.is_nullable = 0  # the def levels carry the validity; the BLOCK has no def section
+            total_leaf = int(info[:, 3].sum())
+            c.rows = total_leaf
+            c.values = _ptr(leaf.values)
+            c.values_bit_offset = leaf.values_bit_offset
+            c.values_len = leaf.values.numel() if leaf.values is not None else 0
+            c.validity = _ptr(leaf.validity)
+            c.validity_bit_offset = leaf.validity_bit_offset
+            c.offsets = _ptr(leaf.offsets)
+            # a (leaf, page range) work item (shard.WorkItem): the sampling seed and the hdr9 / total_bytes of its pages are
+            # the single writer's (first page of the range, array.values().len() of the whole leaf column)
+            c.first_page_index = leaf.first_page_index
+            c.column_values_len = leaf.column_values_len
+            vlen = c.values_len if PhysicalType.is_binary(leaf.physical_type) else 0
+            npg = C.c_uint64(0)
+            bound = int(ctx._lib.sb_write_bound(leaf.physical_type, 0, max(total_leaf, 1), vlen, C.byref(oc), C.byref(npg)))
+            bound += n_pages * 512 + int(info[:, 0].sum())
+            with torch.cuda.stream(ctx.torch_stream):
+                pages = torch.empty(bound, dtype=torch.uint8, device=ctx.torch_device)
+            metas = (N.PageMetaC * n_pages)()
+            c.out_pages = _ptr(pages)
+            c.out_capacity = pages.numel()
+            c.out_metas = metas
+            c.n_pages_capacity = n_pages
+            page_rows = np.ascontiguousarray(info[:, 3], dtype=np.uint64)
+            heads = np.ascontiguousarray(info[:, 0], dtype=np.uint64)
+            c.page_rows = page_rows.ctypes.data_as(C.c_void_p)
+            c.page_head_bytes = heads.ctypes.data_as(C.c_void_p)
+            c.page_heads = _ptr(self.lw.keep[k][1])
+            c.n_pages_in = n_pages
+            self.keep.append((leaf, pages, metas))
+            self.page_rows.append(page_rows)
+            self.heads.append(heads)
+            self.outs.append((pages, metas))
+
+    def run(self) -> List[NestedEncodedColumn]:
+        ctx = self.ctx
+        if not self._fresh:
+            self.lw.call()
+            for k in range(self.n):   # the page cut of THIS call (same shapes: the arrays were sized by the first one)
+                info = self.lw.info(k)
+                self.page_rows[k][:] = info[:, 3]
+                self.heads[k][:] = info[:, 0]
+        self._fresh = False
+        if self.n:
+            ctx._check(ctx._lib.sb_write_columns(ctx._h, self.arr, self.n, C.byref(self.oc), N.SB_MEM_DEVICE))
+        ctx.synchronize()
+        return [NestedEncodedColumn(pages, metas, self.arr[k], self.lw.info(k)[:, 1].copy()) for k, (pages, metas) in enumerate(self.outs)]
+
+
 def write_nested_leaves(ctx, items, options: WriteOptions) -> List[NestedEncodedColumn]:
     """Encode the leaf columns of one nested array together (synchronous): `items` = [(levels, leaf), ...] — what
     NativeWriter::encode_chunk's loop over the leaves of an array does (src/write/common.rs:60-116), with the level
     sections of every leaf written first and the leaf BLOCKs of all leaves in ONE sb_write_columns call, so that the
     pages of all leaves are in flight together.  For each item leaf.rows = levels[-1].length; its validity is the leaf
     validity, also referenced by levels[-1].validity; options.max_page_size counts TOP-LEVEL rows like upstream."""
-    import torch
-    n = len(items)
-    oc = options_c(options)
-    oc.max_page_size = 0
-    arr = (N.ColumnWriteC * max(n, 1))()
-    keep, lvs, outs = [], [], []
-    all_lv = write_levels_batch(ctx, [levels for levels, _ in items], options.max_page_size)
-    for k, (levels, leaf) in enumerate(items):
-        lv = all_lv[k]
-        if int(lv.leaf_start[0]) != 0:
-            raise ValueError("leaf slice must start at 0")
-        c = arr[k]
-        c.physical_type = leaf.physical_type
-        c.is_nullable = 0  # the def levels carry the validity; the BLOCK has no def section
-        total_leaf = int(lv.leaf_count.sum())
-        c.rows = total_leaf
-        c.values = _ptr(leaf.values)
-        c.values_bit_offset = leaf.values_bit_offset
-        c.values_len = leaf.values.numel() if leaf.values is not None else 0
-        c.validity = _ptr(leaf.validity)
-        c.validity_bit_offset = leaf.validity_bit_offset
-        c.offsets = _ptr(leaf.offsets)
-        # a (leaf, page range) work item (shard.WorkItem): the sampling seed and the hdr9 / total_bytes of its pages are
-        # the single writer's (first page of the range, array.values().len() of the whole leaf column)
-        c.first_page_index = leaf.first_page_index
-        c.column_values_len = leaf.column_values_len
-        vlen = c.values_len if PhysicalType.is_binary(leaf.physical_type) else 0
-        npg = C.c_uint64(0)
-        bound = int(ctx._lib.sb_write_bound(leaf.physical_type, 0, max(total_leaf, 1), vlen, C.byref(oc), C.byref(npg)))
-        bound += lv.n_pages * 512 + int(lv.level_bytes.sum())
-        with torch.cuda.stream(ctx.torch_stream):
-            pages = torch.empty(bound, dtype=torch.uint8, device=ctx.torch_device)
-        metas = (N.PageMetaC * lv.n_pages)()
-        c.out_pages = _ptr(pages)
-        c.out_capacity = pages.numel()
-        c.out_metas = metas
-        c.n_pages_capacity = lv.n_pages
-        page_rows = np.ascontiguousarray(lv.leaf_count, dtype=np.uint64)
-        heads = np.ascontiguousarray(lv.level_bytes, dtype=np.uint64)
-        c.page_rows = page_rows.ctypes.data_as(C.c_void_p)
-        c.page_head_bytes = heads.ctypes.data_as(C.c_void_p)
-        c.page_heads = _ptr(lv.sections)
-        c.n_pages_in = lv.n_pages
-        keep.append((page_rows, heads, lv, leaf, pages, metas))
-        lvs.append(lv)
-        outs.append((pages, metas))
-    ctx._keep.append((arr, oc, keep))
-    if n:
-        ctx._check(ctx._lib.sb_write_columns(ctx._h, arr, n, C.byref(oc), N.SB_MEM_DEVICE))
-    ctx.synchronize()
-    return [NestedEncodedColumn(pages, metas, arr[k], lvs[k].num_values) for k, (pages, metas) in enumerate(outs)]
+    wb = NestedWriteBatch(ctx, items, options)
+    ctx._keep.append(wb)
+    return wb.run()
 
 
 def write_nested(ctx, levels: Sequence[NestedLevel], leaf: DeviceColumn, options: WriteOptions) -> NestedEncodedColumn:
@@ -199,113 +239,134 @@ class NestedArray:
         return self.validity[k][:(self.lengths[k] + 7) // 8].cpu().numpy()
 
 
+class NestedReadBatch:
+    """The calls behind read_nested_leaves with their descriptors and output buffers built ONCE (what ReadBatch is for
+    flat columns): run() = sb_nested_read_levels_batch (offsets / validity per level, leaf validity, per page the leaf
+    count and where its BLOCK starts: one host round trip) + sb_read_columns over the BLOCKs of all leaves + synchronize.
+    The buffers are sized by the first pass (which includes the sizing call for binary leaves)."""
+
+    def __init__(self, ctx, columns, kinds_list, nullable_list):
+        import torch
+        self.ctx = ctx
+        dev = ctx.torch_device
+        self.n = n = len(columns)
+        self.arr = arr = (N.ColumnReadC * max(n, 1))()
+        self.items = items = (N.NestedLevelsReadC * max(n, 1))()
+        self.prep, self.per, self.keep, self.bufs = [], [], [], []
+        for j, (column, kinds, nullable) in enumerate(zip(columns, kinds_list, nullable_list)):
+            D = len(kinds)
+            metas = np.ascontiguousarray(column.metas_array(), dtype=np.uint64).reshape(-1, 2)
+            n_pages = metas.shape[0]
+            entries = int(metas[:, 1].sum()) if n_pages else 0
+            lv = (N.NestedLevelOutC * D)()
+            offs, vals = [None] * D, [None] * D
+            vbytes = ((entries + 31) // 32) * 4
+            with torch.cuda.stream(ctx.torch_stream):
+                for k in range(D):
+                    lv[k].kind = kinds[k]
+                    lv[k].is_nullable = 1 if nullable[k] else 0
+                    if kinds[k] in (LIST, LARGE_LIST):
+                        offs[k] = torch.empty((entries + 1) * 8, dtype=torch.uint8, device=dev)
+                        lv[k].offsets = _ptr(offs[k])
+                        lv[k].offsets_capacity = entries + 1
+                    if nullable[k] and kinds[k] != PRIMITIVE:
+                        vals[k] = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev)
+                        lv[k].validity = _ptr(vals[k])
+                        lv[k].validity_capacity = vals[k].numel()
+                leaf_validity = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev) if nullable[-1] else None
+            counts = np.zeros(max(n_pages, 1), np.uint64)
+            block_offs = np.zeros(max(n_pages, 1), np.uint64)
+            pages = column.pages
+            it = items[j]
+            it.pages, it.pages_len = _ptr(pages), pages.numel()
+            it.metas, it.n_pages = metas.ctypes.data_as(C.c_void_p), n_pages
+            it.levels, it.n_levels = lv, D
+            it.leaf_validity = _ptr(leaf_validity)
+            it.leaf_validity_capacity = leaf_validity.numel() if leaf_validity is not None else 0
+            it.page_leaf_counts = counts.ctypes.data_as(C.c_void_p)
+            it.page_block_offsets = block_offs.ctypes.data_as(C.c_void_p)
+            starts = np.concatenate([[0], np.cumsum(metas[:, 0])[:-1]]).astype(np.uint64) if n_pages else np.zeros(0, np.uint64)
+            leaf_metas = np.zeros((n_pages, 2), np.uint64)
+            po = np.zeros(n_pages, np.uint64)
+            self.prep.append((metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages, starts, leaf_metas, po))
+        self._levels()
+        for j, (column, kinds, nullable) in enumerate(zip(columns, kinds_list, nullable_list)):
+            metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages, starts, leaf_metas, po = self.prep[j]
+            t = column.physical_type
+            c = arr[j]
+            c.physical_type = t
+            c.is_nullable = 0
+            c.pages = _ptr(pages)
+            c.pages_len = pages.numel()
+            c.metas = leaf_metas.ctypes.data_as(C.POINTER(N.PageMetaC))
+            c.n_pages = n_pages
+            c.page_offsets = po.ctypes.data_as(C.c_void_p)
+            self.per.append(dict(kinds=list(kinds), nullable=list(nullable), offs=offs, vals=vals, leaf_validity=leaf_validity,
+                                 rows=int(counts[:n_pages].sum()), t=t))
+        binary = [j for j in range(n) if PhysicalType.is_binary(self.per[j]["t"])]
+        if binary:   # values_len of the binary leaves: one sizing call over all of them
+            sub = (N.ColumnReadC * len(binary))()
+            for q, j in enumerate(binary):
+                C.memmove(C.byref(sub[q]), C.byref(arr[j]), C.sizeof(N.ColumnReadC))
+            ctx._check(ctx._lib.sb_read_columns_sizes(ctx._h, sub, len(binary), N.SB_MEM_DEVICE))
+            for q, j in enumerate(binary):
+                self.per[j]["values_len"] = int(sub[q].values_len)
+        with torch.cuda.stream(ctx.torch_stream):
+            for j in range(n):
+                t, rows = self.per[j]["t"], self.per[j]["rows"]
+                values = offsets = None
+                if t == PhysicalType.BOOLEAN:
+                    values = torch.empty(((rows + 31) // 32) * 4 + 4, dtype=torch.uint8, device=dev)
+                elif PhysicalType.is_binary(t):
+                    values = torch.empty(max(self.per[j]["values_len"], 1), dtype=torch.uint8, device=dev)
+                    offsets = torch.empty((rows + 1) * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
+                elif t != PhysicalType.NULL:
+                    values = torch.empty(max(rows * PhysicalType.WIDTH[t], 1), dtype=torch.uint8, device=dev)
+                c = arr[j]
+                c.values = _ptr(values)
+                c.values_capacity = values.numel() if values is not None else 0
+                c.offsets = _ptr(offsets)
+                c.offsets_capacity = offsets.numel() if offsets is not None else 0
+                self.bufs.append((values, offsets))
+        self._fresh = True   # (the level outputs of the first run() are already there)
+
+    def _levels(self):
+        """the level sections of every leaf (one set of launches, one host round trip), then the page table of the BLOCKs"""
+        ctx = self.ctx
+        if self.n:
+            ctx._check(ctx._lib.sb_nested_read_levels_batch(ctx._h, self.items, self.n))
+        for metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages, starts, leaf_metas, po in self.prep:
+            leaf_metas[:, 0] = metas[:, 0] - (block_offs[:n_pages] - starts)
+            leaf_metas[:, 1] = counts[:n_pages]
+            po[:] = block_offs[:n_pages]
+
+    def run(self) -> List[NestedArray]:
+        ctx = self.ctx
+        if not self._fresh:
+            self._levels()
+        self._fresh = False
+        if self.n:
+            ctx._check(ctx._lib.sb_read_columns(ctx._h, self.arr, self.n, N.SB_MEM_DEVICE))
+        ctx.synchronize()
+        out = []
+        for j in range(self.n):
+            d = self.per[j]
+            lv = self.prep[j][2]
+            lengths = [int(lv[k].length) for k in range(len(d["kinds"]))]
+            leaf = DeviceArray(d["t"], bool(d["nullable"][-1]), d["rows"], self.bufs[j][0], d["leaf_validity"], self.bufs[j][1], self.arr[j])
+            out.append(NestedArray(d["kinds"], d["nullable"], lengths, d["offs"], d["vals"], leaf))
+        return out
+
+
 def read_nested_leaves(ctx, columns, kinds_list, nullable_list) -> List[NestedArray]:
     """read_nested_* for the leaf columns of one nested array together (synchronous): per leaf the level sections are
     decoded (offsets / validity per level, leaf validity, per page the leaf count and where its BLOCK starts), then the
     BLOCKs of ALL leaves go through the flat decoder in one sizing call (binary leaves) and one sb_read_columns call.
     `kinds` / `nullable` per leaf are the InitNested chain root -> leaf (src/read/batch_read.rs:66-230 builds it from
     the schema)."""
-    import torch
-    dev = ctx.torch_device
-    n = len(columns)
-    arr = (N.ColumnReadC * max(n, 1))()
-    per, keep = [], []
-    items = (N.NestedLevelsReadC * max(n, 1))()
-    prep = []
-    for j, (column, kinds, nullable) in enumerate(zip(columns, kinds_list, nullable_list)):
-        D = len(kinds)
-        metas = np.ascontiguousarray(column.metas_array(), dtype=np.uint64).reshape(-1, 2)
-        n_pages = metas.shape[0]
-        entries = int(metas[:, 1].sum()) if n_pages else 0
-        lv = (N.NestedLevelOutC * D)()
-        offs, vals = [None] * D, [None] * D
-        vbytes = ((entries + 31) // 32) * 4
-        with torch.cuda.stream(ctx.torch_stream):
-            for k in range(D):
-                lv[k].kind = kinds[k]
-                lv[k].is_nullable = 1 if nullable[k] else 0
-                if kinds[k] in (LIST, LARGE_LIST):
-                    offs[k] = torch.empty((entries + 1) * 8, dtype=torch.uint8, device=dev)
-                    lv[k].offsets = _ptr(offs[k])
-                    lv[k].offsets_capacity = entries + 1
-                if nullable[k] and kinds[k] != PRIMITIVE:
-                    vals[k] = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev)
-                    lv[k].validity = _ptr(vals[k])
-                    lv[k].validity_capacity = vals[k].numel()
-            leaf_validity = torch.empty(max(vbytes, 4), dtype=torch.uint8, device=dev) if nullable[-1] else None
-        counts = np.zeros(max(n_pages, 1), np.uint64)
-        block_offs = np.zeros(max(n_pages, 1), np.uint64)
-        pages = column.pages
-        it = items[j]
-        it.pages, it.pages_len = _ptr(pages), pages.numel()
-        it.metas, it.n_pages = metas.ctypes.data_as(C.c_void_p), n_pages
-        it.levels, it.n_levels = lv, D
-        it.leaf_validity = _ptr(leaf_validity)
-        it.leaf_validity_capacity = leaf_validity.numel() if leaf_validity is not None else 0
-        it.page_leaf_counts = counts.ctypes.data_as(C.c_void_p)
-        it.page_block_offsets = block_offs.ctypes.data_as(C.c_void_p)
-        prep.append((metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages))
-    if n:   # the level sections of every leaf: one set of launches, one host round trip
-        ctx._check(ctx._lib.sb_nested_read_levels_batch(ctx._h, items, n))
-    for j, (column, kinds, nullable) in enumerate(zip(columns, kinds_list, nullable_list)):
-        metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages = prep[j]
-        D = len(kinds)
-        lengths = [int(lv[k].length) for k in range(D)]
-        # the leaf BLOCKs through the flat decoder
-        starts = np.concatenate([[0], np.cumsum(metas[:, 0])[:-1]]).astype(np.uint64) if n_pages else np.zeros(0, np.uint64)
-        leaf_metas = np.zeros((n_pages, 2), np.uint64)
-        leaf_metas[:, 0] = metas[:, 0] - (block_offs[:n_pages] - starts)
-        leaf_metas[:, 1] = counts[:n_pages]
-        t = column.physical_type
-        rows = int(counts[:n_pages].sum())
-        c = arr[j]
-        c.physical_type = t
-        c.is_nullable = 0
-        c.pages = _ptr(pages)
-        c.pages_len = pages.numel()
-        c.metas = leaf_metas.ctypes.data_as(C.POINTER(N.PageMetaC))
-        c.n_pages = n_pages
-        po = np.ascontiguousarray(block_offs[:n_pages])
-        c.page_offsets = po.ctypes.data_as(C.c_void_p)
-        per.append(dict(kinds=list(kinds), nullable=list(nullable), lengths=lengths, offs=offs, vals=vals, leaf_validity=leaf_validity,
-                        rows=rows, t=t))
-        keep.append((leaf_metas, po, pages, lv))
-    binary = [j for j in range(n) if PhysicalType.is_binary(per[j]["t"])]
-    if binary:   # values_len of the binary leaves: one sizing call over all of them
-        sub = (N.ColumnReadC * len(binary))()
-        for q, j in enumerate(binary):
-            C.memmove(C.byref(sub[q]), C.byref(arr[j]), C.sizeof(N.ColumnReadC))
-        ctx._check(ctx._lib.sb_read_columns_sizes(ctx._h, sub, len(binary), N.SB_MEM_DEVICE))
-        for q, j in enumerate(binary):
-            per[j]["values_len"] = int(sub[q].values_len)
-    bufs = []
-    with torch.cuda.stream(ctx.torch_stream):
-        for j in range(n):
-            t, rows = per[j]["t"], per[j]["rows"]
-            values = offsets = None
-            if t == PhysicalType.BOOLEAN:
-                values = torch.empty(((rows + 31) // 32) * 4 + 4, dtype=torch.uint8, device=dev)
-            elif PhysicalType.is_binary(t):
-                values = torch.empty(max(per[j]["values_len"], 1), dtype=torch.uint8, device=dev)
-                offsets = torch.empty((rows + 1) * PhysicalType.WIDTH[t], dtype=torch.uint8, device=dev)
-            elif t != PhysicalType.NULL:
-                values = torch.empty(max(rows * PhysicalType.WIDTH[t], 1), dtype=torch.uint8, device=dev)
-            c = arr[j]
-            c.values = _ptr(values)
-            c.values_capacity = values.numel() if values is not None else 0
-            c.offsets = _ptr(offsets)
-            c.offsets_capacity = offsets.numel() if offsets is not None else 0
-            bufs.append((values, offsets))
-    ctx._keep.append((arr, keep, bufs))
-    if n:
-        ctx._check(ctx._lib.sb_read_columns(ctx._h, arr, n, N.SB_MEM_DEVICE))
-    ctx.synchronize()
-    out = []
-    for j in range(n):
-        d = per[j]
-        leaf = DeviceArray(d["t"], bool(d["nullable"][-1]), d["rows"], bufs[j][0], d["leaf_validity"], bufs[j][1], arr[j])
-        out.append(NestedArray(d["kinds"], d["nullable"], d["lengths"], d["offs"], d["vals"], leaf))
-    return out
+    rb = NestedReadBatch(ctx, columns, kinds_list, nullable_list)
+    ctx._keep.append(rb)
+    return rb.run()
 
 
 def read_nested(ctx, column: ColumnPages, kinds: Sequence[int], nullable: Sequence[bool]) -> NestedArray:

@@ -807,7 +807,18 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)  # nccl == RCCL on ROCm
+        # (the gloo backend reports its peer connections on stdout; stdout carries the ONE JSON line, so it is pointed at
+        # stderr while the group comes up)
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)  # nccl == RCCL on ROCm
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
 
     import strawboat_amd as sb
     from strawboat_amd import read, write

@@ -774,7 +774,10 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
     const uint32_t lane = threadIdx.x;
     if (threadIdx.x == 0) wk.pre_built = 0;
     uint8_t* my_lit = zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE;
-    const uint32_t B = (zrec && njobs >= 4 * gridDim.x) ? min(64u, njobs / gridDim.x) : 1u;
+    // batch size: a multiple of the 16 frames the literals-only phase decodes together (a group of 2 frames costs a wave as
+    // much time as a group of 16), at most the 64 lanes of the lane-per-frame phases
+    // (from 2 jobs per pool wave on; the lane-per-frame sequence phases also need the record arena)
+    const uint32_t B = njobs >= 2 * gridDim.x ? min(64u, max(16u, (njobs / gridDim.x) & ~15u)) : 1u;
     if (B > 1) {
         for (uint32_t i = lane; i < 64; i += 64) {
             zt.ll[i] = g_zpre.ll[i];
@@ -789,7 +792,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
         for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) inflate_one(jobs[job], st, wk, my_lit, s_win, s_pos, nullptr);
         return;
     }
-    uint64_t* arena = zrec + (uint64_t)blockIdx.x * ZREC_PER_WAVE;
+    uint64_t* arena = zrec ? zrec + (uint64_t)blockIdx.x * ZREC_PER_WAVE : nullptr;
     ITL_BEGIN
     for (uint32_t base = blockIdx.x * B; base < njobs; base += gridDim.x * B) {
         const uint32_t nb = min(B, njobs - base);
@@ -872,7 +875,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
         }
         ITL(4);
         // phase 0 (lane per frame): how many sequences, and does the frame qualify
-        uint32_t cnt = (zs && !((done_m >> lane) & 1)) ? z_lane_frame(mine.src, mine.csize, mine.out_len, zt, nullptr, 0) : ZPRE_NONE;
+        uint32_t cnt = (arena && zs && !((done_m >> lane) & 1)) ? z_lane_frame(mine.src, mine.csize, mine.out_len, zt, nullptr, 0) : ZPRE_NONE;
         uint32_t start = 0;
         while (start < nb) {
             const uint32_t need = (lane >= start && cnt != ZPRE_NONE) ? cnt : 0u;

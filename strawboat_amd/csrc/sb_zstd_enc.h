@@ -30,16 +30,18 @@ struct ZeSymTT {
     int32_t delta_nb_bits;
     int32_t delta_find_state;
 };
+// Matcher geometry: 2^11 table entries, 8 KiB ring.  LDS per wave is the encoder's occupancy (one wave per 16 KiB piece):
+// 28 KB allowed 5 waves per CU, 21 KB allow 7.
+constexpr int ZE_HB = 11, ZE_RB = 13;
 struct ZEncLds {
-    Lz4EncLds<12, 13> lz;            // matcher; lz.out doubles as the bit window of the Huffman streams
+    Lz4EncLds<ZE_HB, ZE_RB> lz;      // matcher; lz.out doubles as the bit window of the Huffman streams, tab + ring as the tree builder's scratch
     uint32_t hist[256];
     uint16_t hcode[256];
     uint8_t hlen[256];
     uint16_t ll_st[64], ml_st[64], of_st[32];   // FSE state tables (predefined distributions)
     ZeSymTT ll_tt[36], ml_tt[53], of_tt[29];
     uint16_t h_sorted[256];          // Huffman build scratch
-    uint32_t h_cnt[512];
-    int16_t h_parent[512];
+    uint32_t h_cnt[256];             // code | length << 16 per symbol for the stream packer
     // FSE coding of the Huffman weights (alphabets of more than 128 symbols: RFC 8878 4.2.1.2)
     uint16_t w_st[64];
     ZeSymTT w_tt[13];
@@ -137,192 +139,18 @@ struct ZeBits {
     }
 };
 
-// Huffman code lengths (<= 11 bits) and libzstd's canonical codes for the symbols with hist[s] > 0, s <= max_sym <= 128.
-// Executed by lane 0.  Returns the number of bits of the longest code, 0 if no valid tree (the caller stores raw literals).
-__device__ inline uint32_t ze_huf_build(ZEncLds& Z, uint32_t max_sym) {
-    // symbols sorted by count, ascending (insertion sort: <= 129 symbols)
-    uint32_t ns = 0;
-    for (uint32_t s = 0; s <= max_sym; s++) {
-        Z.hlen[s] = 0;
-        if (!Z.hist[s]) continue;
-        uint32_t k = ns++;
-        while (k > 0 && Z.hist[Z.h_sorted[k - 1]] > Z.hist[s]) {
-            Z.h_sorted[k] = Z.h_sorted[k - 1];
-            k--;
-        }
-        Z.h_sorted[k] = (uint16_t)s;
-    }
-    if (ns < 2) return 0;
-    // two-queue Huffman: leaves 0..ns-1 (sorted), internal nodes ns..2ns-2
-    for (uint32_t k = 0; k < ns; k++) Z.h_cnt[k] = Z.hist[Z.h_sorted[k]];
-    uint32_t leaf = 0, inode = ns, next_i = ns;
-    auto take = [&]() -> uint32_t {
-        if (leaf < ns && (inode >= next_i || Z.h_cnt[leaf] <= Z.h_cnt[inode])) return leaf++;
-        return inode++;
-    };
-    for (uint32_t k = 0; k + 1 < ns; k++) {
-        const uint32_t a = take(), b = take();
-        Z.h_cnt[next_i] = Z.h_cnt[a] + Z.h_cnt[b];
-        Z.h_parent[a] = (int16_t)next_i;
-        Z.h_parent[b] = (int16_t)next_i;
-        next_i++;
-    }
-    const uint32_t root = next_i - 1;
-    Z.h_parent[root] = -1;
-    // depths: parents have larger indices than their children
-    for (uint32_t k = root; k-- > 0;) Z.h_cnt[k] = (Z.h_parent[k] == (int16_t)root ? 0u : Z.h_cnt[Z.h_parent[k]]) + 1;   // h_cnt now = depth
-    uint32_t maxd = 0;
-    for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
-    if (maxd > ZE_HUF_MAXBITS) {
-        // clamp, then repair the Kraft sum: K = sum 2^(11 - len) must be exactly 2^11
-        uint32_t K = 0;
-        for (uint32_t k = 0; k < ns; k++) {
-            if (Z.h_cnt[k] > ZE_HUF_MAXBITS) Z.h_cnt[k] = ZE_HUF_MAXBITS;
-            K += 1u << (ZE_HUF_MAXBITS - Z.h_cnt[k]);
-        }
-        const uint32_t full = 1u << ZE_HUF_MAXBITS;
-        // over-subscribed: lengthen the rarest symbols that are still short of 11 bits (k ascending = rarest first)
-        for (uint32_t L = ZE_HUF_MAXBITS - 1; K > full && L >= 1; L--)
-            for (uint32_t k = 0; k < ns && K > full; k++)
-                if (Z.h_cnt[k] == L) {
-                    Z.h_cnt[k] = L + 1;
-                    K -= 1u << (ZE_HUF_MAXBITS - L - 1);
-                }
-        if (K > full) return 0;
-        // under-subscribed: shorten the most frequent symbols whose step fits the deficit (k descending = most frequent)
-        uint32_t D = full - K;
-        for (uint32_t k = ns; k-- > 0 && D;) {
-            while (Z.h_cnt[k] > 1 && (1u << (ZE_HUF_MAXBITS - Z.h_cnt[k])) <= D) {
-                D -= 1u << (ZE_HUF_MAXBITS - Z.h_cnt[k]);
-                Z.h_cnt[k]--;
-            }
-        }
-        if (D) return 0;
-        maxd = 0;
-        for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
-    }
-    for (uint32_t k = 0; k < ns; k++) Z.hlen[Z.h_sorted[k]] = (uint8_t)Z.h_cnt[k];
-    // canonical codes: longest codes first (rank = number of bits), symbols of one length in symbol order
-    uint32_t code = 0;
-    for (uint32_t len = maxd; len >= 1; len--) {
-        for (uint32_t s = 0; s <= max_sym; s++)
-            if (Z.hlen[s] == len) Z.hcode[s] = (uint16_t)code++;
-        code >>= 1;
-    }
-    return maxd;
-}
-
-// The same tree by the whole wave (all lanes call it, the result is uniform), for alphabets of up to 256 symbols: the
-// sort (a rank count per symbol) and the canonical codes (ballots per code length) are lane-parallel; the two-queue merge
-// and the depths stay on lane 0 (255 steps).  Returns the longest code's bits, 0 if no valid tree.
-__device__ inline uint32_t ze_huf_build_wave(ZEncLds& Z, uint32_t max_sym, uint32_t max_bits = ZE_HUF_MAXBITS) {
-    const uint32_t lane = threadIdx.x & 63;
-    // rank of every present symbol by (count, symbol)
-    uint32_t mycnt[4], myrank[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t sy = lane + 64 * j;
-        mycnt[j] = sy <= max_sym ? Z.hist[sy] : 0u;
-        myrank[j] = 0;
-    }
-    uint32_t ns = 0;
-    for (uint32_t o = 0; o <= max_sym; o++) {
-        const uint32_t c = Z.hist[o];   // (uniform address: broadcast read)
-        if (!c) continue;
-        ns++;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t sy = lane + 64 * j;
-            if (mycnt[j] && (c < mycnt[j] || (c == mycnt[j] && o < sy))) myrank[j]++;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t sy = lane + 64 * j;
-        if (sy < 256) Z.hlen[sy] = 0;
-        if (mycnt[j]) Z.h_sorted[myrank[j]] = (uint16_t)sy;
-    }
-    wave_sync();
-    if (ns < 2) return 0;
-    if (lane == 0) {
-        for (uint32_t k = 0; k < ns; k++) Z.h_cnt[k] = Z.hist[Z.h_sorted[k]];
-        uint32_t leaf = 0, inode = ns, next_i = ns;
-        auto take = [&]() -> uint32_t {
-            if (leaf < ns && (inode >= next_i || Z.h_cnt[leaf] <= Z.h_cnt[inode])) return leaf++;
-            return inode++;
-        };
-        for (uint32_t k = 0; k + 1 < ns; k++) {
-            const uint32_t a = take(), b = take();
-            Z.h_cnt[next_i] = Z.h_cnt[a] + Z.h_cnt[b];
-            Z.h_parent[a] = (int16_t)next_i;
-            Z.h_parent[b] = (int16_t)next_i;
-            next_i++;
-        }
-        const uint32_t root = next_i - 1;
-        Z.h_parent[root] = -1;
-        for (uint32_t k = root; k-- > 0;) Z.h_cnt[k] = (Z.h_parent[k] == (int16_t)root ? 0u : Z.h_cnt[Z.h_parent[k]]) + 1;   // depth
-        uint32_t maxd = 0;
-        for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
-        bool ok = true;
-        if (maxd > max_bits) {   // clamp to 11 bits and repair the Kraft sum (as ze_huf_build)
-            uint32_t K = 0;
-            for (uint32_t k = 0; k < ns; k++) {
-                if (Z.h_cnt[k] > max_bits) Z.h_cnt[k] = max_bits;
-                K += 1u << (max_bits - Z.h_cnt[k]);
-            }
-            const uint32_t full = 1u << max_bits;
-            for (uint32_t L = max_bits - 1; K > full && L >= 1; L--)
-                for (uint32_t k = 0; k < ns && K > full; k++)
-                    if (Z.h_cnt[k] == L) {
-                        Z.h_cnt[k] = L + 1;
-                        K -= 1u << (max_bits - L - 1);
-                    }
-            if (K > full) ok = false;
-            uint32_t D = full - K;
-            for (uint32_t k = ns; ok && k-- > 0 && D;) {
-                while (Z.h_cnt[k] > 1 && (1u << (max_bits - Z.h_cnt[k])) <= D) {
-                    D -= 1u << (max_bits - Z.h_cnt[k]);
-                    Z.h_cnt[k]--;
-                }
-            }
-            if (D) ok = false;
-            maxd = 0;
-            for (uint32_t k = 0; k < ns; k++) maxd = max(maxd, Z.h_cnt[k]);
-        }
-        for (uint32_t k = 0; k < ns && ok; k++) Z.hlen[Z.h_sorted[k]] = (uint8_t)Z.h_cnt[k];
-        Z.misc[0] = ok ? maxd : 0u;
-    }
-    wave_sync();
-    const uint32_t maxd = Z.misc[0];
-    if (!maxd) return 0;
-    // canonical codes: longest codes first, symbols of one length in symbol order
-    uint32_t ml[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) ml[j] = Z.hlen[(lane + 64 * j) & 255];
-    uint32_t code = 0;
-    for (uint32_t len = maxd; len >= 1; len--) {
-        uint32_t before = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint64_t m = __ballot(ml[j] == len && lane + 64 * j <= max_sym);
-            if (ml[j] == len && lane + 64 * j <= max_sym) Z.hcode[lane + 64 * j] = (uint16_t)(code + before + lane_rank(m));
-            before += (uint32_t)__popcll(m);
-        }
-        code = (code + before) >> 1;
-    }
-    wave_sync();
-    return maxd;
-}
-
-// The same result class — a complete prefix code of at most max_bits bits for the present symbols, canonical codes in
-// Z.hcode — with the lengths from PACKAGE-MERGE run by the whole wave (optimal for the length limit; no serial two-queue
-// merge, depth walk and Kraft repair on one lane: a 256-symbol alphabet cost ~1 M cycles there, ~40 k here).
+// Huffman codes of the literals: a complete prefix code of at most max_bits bits for the symbols with hist[s] > 0, canonical
+// codes (libzstd's order) in Z.hcode, lengths in Z.hlen; returns the longest length (0: no tree, the caller stores raw
+// literals).  The lengths come from PACKAGE-MERGE run by the whole wave (optimal for the length limit; the round-2 builder
+// — two-queue merge, depth walk and Kraft repair on one lane — cost ~1 M cycles for a 256-symbol alphabet, this ~40 k).
 //   lists   level max_bits holds the leaves (weights ascending); level l = merge(leaves, packages of level l + 1), a package
 //           being the sum of two neighbours.  Every leaf / package finds its place by a binary search in the other list
 //           (9 steps, the four leaves and four packages of a lane side by side); PK[l][i] keeps the packages in front of leaf i.
 //   lengths top-down: the first 2n - 2 items of level 1 are taken; the packages among them open twice as many items of the
 //           level below; a leaf's code length is the number of levels in which it is among the items taken.
 // `sc`: 1536 + 64 * (max_bits + 1) words of LDS scratch (the matcher's table and ring once the block's parse is over).
+static_assert(sizeof(((Lz4EncLds<ZE_HB, ZE_RB>*)nullptr)->tab) + sizeof(((Lz4EncLds<ZE_HB, ZE_RB>*)nullptr)->ring) >= 4 * (1536 + 64 * (ZE_HUF_MAXBITS + 1)),
+              "sb_zstd_enc.h: the tree builder's scratch must fit the matcher's table + ring");
 __device__ inline uint32_t ze_huf_build_pm(ZEncLds& Z, uint32_t max_sym, uint32_t max_bits, uint32_t* sc) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t* W = sc;            // [256] leaf weights, ascending
@@ -775,7 +603,7 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
                 uint8_t* w = lits + nlit + (incl - myll);
                 if (myll <= 64) {   // (at most 64 bytes back: in the matcher's ring, no HBM load)
                     for (uint32_t i = 0; i < myll; i += 8) {
-                        const uint64_t v = lds_rd8_ring(Z.lz.ring, (lit_start + i) & (LzMatcher<12, 13>::R - 1), LzMatcher<12, 13>::RWM);
+                        const uint64_t v = lds_rd8_ring(Z.lz.ring, (lit_start + i) & (LzMatcher<ZE_HB, ZE_RB>::R - 1), LzMatcher<ZE_HB, ZE_RB>::RWM);
                         if (myll - i >= 8) {
                             stu64(w + i, v);
                         } else {
@@ -865,7 +693,9 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
             // (a block without sequences is read lane per stream when its codes have at most ZE_LITONLY_MAXBITS bits)
             const uint32_t bits = nseq == 0 ? ZE_LITONLY_MAXBITS : ZE_HUF_MAXBITS;
             // the parse of the frame's last block is over: the matcher's table and ring are the tree builder's scratch
-            hbits = (ALONE || last_block) ? ze_huf_build_pm(Z, maxs, bits, (uint32_t*)Z.lz.tab) : ze_huf_build_wave(Z, maxs, bits);
+            // (a block that is not its frame's last keeps the matcher's history: its literals stay raw — one wave never
+            // walks a frame of several blocks in this library, buffers of more than one piece go through the chunk kernel)
+            hbits = (ALONE || last_block) ? ze_huf_build_pm(Z, maxs, bits, (uint32_t*)Z.lz.tab) : 0u;
         }
         LZP(15);
         bool huf = hbits != 0;
@@ -1184,7 +1014,7 @@ __device__ uint32_t zstd_compress_wave(const uint8_t* src, uint32_t n, uint8_t* 
     }
     ze_tables(Z);
     const uint32_t blk_cap = min(n, ZE_BLOCK);
-    LzMatcher<12, 13> mt(Z.lz, src, n);
+    LzMatcher<ZE_HB, ZE_RB> mt(Z.lz, src, n);
     mt.init();
     for (uint32_t c0 = 0; c0 < n; c0 += ZE_BLOCK) {
         const uint32_t c1 = min(n, c0 + ZE_BLOCK);
@@ -1202,7 +1032,7 @@ __device__ uint32_t zstd_compress_block_alone(const uint8_t* src, uint32_t n, ui
     if ((threadIdx.x & 63) == 0) ze_frame_header(out, c1 - c0);
     const uint32_t h = ze_frame_header_bytes(c1 - c0);
     ze_tables(Z);
-    LzMatcher<12, 13> mt(Z.lz, src, n);
+    LzMatcher<ZE_HB, ZE_RB> mt(Z.lz, src, n);
     mt.init();
     return h + ze_block<true>(src, n, c0, c1, true, out + h, Z, scratch, blk_cap, mt);
 }

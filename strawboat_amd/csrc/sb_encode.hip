@@ -125,7 +125,7 @@ struct EncodeArgs {
     uint32_t redo;                  // k_enc_select: second pass over the binary pages k_enc_bin_verify failed (no tags, exact count)
 };
 constexpr uint32_t ZPAR_CH = 16384;      // a Zstd frame's blocks when they are compressed by waves of their own
-constexpr uint32_t ZPAR_WAVES = 1792;     // 7 per CU: what 21 KB of LDS per wave keep resident (a pool larger than that runs a second, thin round)
+constexpr uint32_t ZPAR_WAVES = 2048;     // 8 per CU: what 20 KB of LDS per wave (and 221 VGPRs) keep resident; a larger pool runs a second, thin round
 constexpr uint32_t LZC_CH = 65536;                                         // chunk bytes (a multiple of 1024)
 constexpr uint32_t LZC_SLOT = (16 + LZC_CH + LZC_CH / 255 + 16 + 15) / 16 * 16;   // u32 size | u32 tail anchor | 8 pad | sequences
 struct LzChunkPlan { uint32_t base, n_a, n_b, pad; };   // chunks [base, base + n_a) = first block, then n_b of a binary page's values block

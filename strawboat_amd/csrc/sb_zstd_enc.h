@@ -31,26 +31,36 @@ struct ZeSymTT {
     int32_t delta_find_state;
 };
 // Matcher geometry: 2^11 table entries, 8 KiB ring.  LDS per wave is the encoder's occupancy (one wave per 16 KiB piece):
-// 28 KB allowed 5 waves per CU, 21 KB allow 7.
+// 28 KB allowed 5 waves per CU, 20 KB allow 8 (arrays that are never live together share their bytes).
 constexpr int ZE_HB = 11, ZE_RB = 13;
 struct ZEncLds {
     Lz4EncLds<ZE_HB, ZE_RB> lz;      // matcher; lz.out doubles as the bit window of the Huffman streams, tab + ring as the tree builder's scratch
-    uint32_t hist[256];
+    union {
+        uint32_t hist[256];          // byte histogram of the literals ...
+        uint32_t h_cnt[256];         // ... which is dead once the tree is described: code | length << 16 per symbol for the stream packer
+    };
     uint16_t hcode[256];
     uint8_t hlen[256];
     uint16_t ll_st[64], ml_st[64], of_st[32];   // FSE state tables (predefined distributions)
     ZeSymTT ll_tt[36], ml_tt[53], of_tt[29];
-    uint16_t h_sorted[256];          // Huffman build scratch
-    uint32_t h_cnt[256];             // code | length << 16 per symbol for the stream packer
-    // FSE coding of the Huffman weights (alphabets of more than 128 symbols: RFC 8878 4.2.1.2)
-    uint16_t w_st[64];
-    ZeSymTT w_tt[13];
-    int16_t w_norm[13];
-    uint8_t w_val[256];
     uint32_t misc[8];
-    // one batch of sequences, prepared by all lanes for lane 0: codes + extra-bit values + the FSE transforms of the codes
-    uint32_t sq_code[64], sq_ll[64], sq_ml[64], sq_of[64];
-    ZeSymTT sq_tt[64][3];
+    union {
+        // one batch of sequences, prepared by all lanes for lane 0: codes + extra-bit values + the FSE transforms of the codes
+        struct {
+            uint32_t sq_code[64], sq_ll[64], sq_ml[64], sq_of[64];
+            ZeSymTT sq_tt[64][3];
+        };
+        // the literals section comes before the sequences section: its scratch shares the batch area (behind sq_code / sq_ll /
+        // sq_ml, which the FSE coder of the weights borrows as spread table, cumulative counts and weight histogram)
+        struct {
+            uint32_t lit_pad_[192];
+            uint16_t h_sorted[256];          // symbols by (count, symbol)
+            uint16_t w_st[64];               // FSE coding of the Huffman weights (alphabets of more than 128 symbols: RFC 8878 4.2.1.2)
+            ZeSymTT w_tt[13];
+            int16_t w_norm[13];
+            uint8_t w_val[256];
+        };
+    };
 };
 
 __device__ const uint8_t ZE_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,

@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, cons
 }
 // LZ4 blocks of LZ4_BIG_MIN compressed bytes and more: one workgroup per block (sb_lz4_big.h: sequence starts and match
 // chains by pointer doubling).  Launched only when a page of the call is that long (DecodeArgs.lz4_big_min).
-constexpr uint32_t LZ4_BIG_POOL = 1024;
+constexpr uint32_t LZ4_BIG_POOL = 4096;   // (1024 are resident; blocks differ in size by 20 x, so a workgroup per block — handed out by the hardware as slots free — beats a strided pool)
 __global__ void __launch_bounds__(LB_T, 4) k_inflate_lz4_big(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min) {
     __shared__ Lz4BigLds lds;
     const uint32_t njobs = *count;

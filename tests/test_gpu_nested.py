@@ -286,3 +286,43 @@ def test_leaves_of_an_array_in_one_call(gpu_ctx, dc):
         assert np.array_equal(arr.leaf.validity_numpy(), one.leaf.validity_numpy())
         if ptype == S.T_BIN32:
             assert np.array_equal(arr.leaf.offsets_numpy(), one.leaf.offsets_numpy())
+
+
+def test_batch_objects_run_repeatedly(gpu_ctx):
+    """NestedWriteBatch / NestedReadBatch (descriptors and buffers built once): every run() gives the pages / buffers of the
+    one-shot calls, also after the output buffers were overwritten in between"""
+    from strawboat_amd import WriteOptions, nested
+    from strawboat_amd.read import ColumnPages
+    opts = WriteOptions(max_page_size=2048, default_compression=S.ZSTD)
+    items, shapes = [], []
+    for shape, ptype, seed in (("list_struct", S.T_I64, 7), ("list_struct", S.T_BIN32, 8)):
+        levels, rows = make_nested(shape, 30_000, seed)
+        dcol, vals, offs = _leaf_column(gpu_ctx, levels, ptype, seed + 10)
+        items.append((device_levels(gpu_ctx, levels), dcol))
+        shapes.append((levels, ptype))
+    want = [(e.pages_numpy().copy(), e.metas_array().copy()) for e in nested.write_nested_leaves(gpu_ctx, items, opts)]
+    wb = nested.NestedWriteBatch(gpu_ctx, items, opts)
+    for rep in range(3):
+        encs = wb.run()
+        for e, (p, m) in zip(encs, want):
+            assert np.array_equal(e.metas_array(), m), rep
+            assert np.array_equal(e.pages_numpy(), p), rep
+        for e in encs:
+            e.pages.zero_()   # the next run has to write everything again
+    encs = wb.run()
+    cps = [ColumnPages(pt, False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (_, pt) in zip(encs, shapes)]
+    kinds = [[lv["kind"] for lv in levels] for levels, _ in shapes]
+    nul = [[bool(lv["is_optional"]) for lv in levels] for levels, _ in shapes]
+    ref = nested.read_nested_leaves(gpu_ctx, cps, kinds, nul)
+    ref_vals = [(a.leaf.values_numpy().copy(), a.leaf.validity_numpy().copy(), a.offsets_numpy(0).copy(), list(a.lengths)) for a in ref]
+    rb = nested.NestedReadBatch(gpu_ctx, cps, kinds, nul)
+    for rep in range(3):
+        arrs = rb.run()
+        for a, (v, vd, o, ln) in zip(arrs, ref_vals):
+            assert a.lengths == ln
+            assert np.array_equal(a.leaf.values_numpy(), v), rep
+            assert np.array_equal(a.leaf.validity_numpy(), vd), rep
+            assert np.array_equal(a.offsets_numpy(0), o), rep
+        for a in arrs:
+            a.leaf.values.zero_()
+            a.offsets[0].zero_()

@@ -911,11 +911,7 @@ __device__ inline bool z_wave_huf_streams(ZHufLanes& H, uint32_t g, uint32_t mb,
                     bb |= (uint64_t)word(wi--) << (32 - cnt);
                     cnt += 32;
                 }
-#if defined(ZH_EXPERIMENT) && ZH_EXPERIMENT == 1
-                const uint32_t e = 0x0600u | (((uint32_t)(bb >> 32) >> sh) & 255u);
-#else
                 const uint32_t e = tab[(uint32_t)(bb >> 32) >> sh];
-#endif
                 const uint32_t len = e >> 8;
                 bb <<= len;
                 cnt -= len;

@@ -610,11 +610,12 @@ struct ZHufBuild {   // table construction, lane per frame
     int16_t norm[ZH_GROUP][16];
     uint16_t next[ZH_GROUP][16];
 };
-struct ZHufStage {   // stream decoding, lane per stream: the next 128 bytes of every stream, staged by the wave together
-    uint64_t in[64][16];   // row = stream; word k of stream s sits in slot (k + s) & 15 (all lanes read "their word k" at once)
-    uint64_t ptr[64];      // stream base, then (after the decode step) where the round's bytes go
-    int32_t lo[64];        // first staged byte of the stream (may lie in front of it: zeros), INT_MIN: stream idle
-    uint32_t cnt[64];      // bytes decoded in the round
+struct ZHufStage {   // stream decoding, lane per stream: a 128-byte ring per stream, filled by the wave together
+    uint32_t ring[64][32];   // row = stream; the stream's 32-bit word w (bytes [4 w, 4 w + 4) of it) sits in slot (w + stream) & 31
+    uint64_t ptr[64];        // stream base, then (after the loads of a round are issued) where the round's bytes go
+    int32_t lo[64];          // lowest byte offset of the stream that is in its ring (a multiple of 16)
+    uint8_t nch[64];         // 16-byte chunks below `lo` to bring in this round (0 .. 4)
+    uint8_t cnt[64];         // bytes decoded in the round
 };
 struct ZHufLanes {   // phase workspace (shares its LDS with ZWork)
     uint16_t tab[ZH_GROUP][1 << ZH_MAXBITS];
@@ -836,15 +837,21 @@ __device__ inline void z_wave_huf_fill(ZHufLanes& H, uint32_t ng) {
 #define ZTL_BEGIN
 #define ZTL(p)
 #endif
-// The streams of up to 16 staged frames, LANE PER STREAM (lane 4 g + j = stream j of frame g), in rounds of 64 symbols.
+// The streams of up to 16 staged frames, LANE PER STREAM (lane 4 g + j = stream j of frame g), in rounds of 32 symbols.
 // A lane reading its own stream from HBM is one cache line per lane and load, and the same again for its 8-byte stores:
-// 2600 cycles per symbol on C5's leaves.  Here the wave moves the data: per round it stages the next 128 bytes of every
-// stream in LDS (8 loads of 16 bytes per lane, eight lanes on one stream: 8-16 lines per load), every lane decodes 64
-// symbols from its row (<= 9 bits each: 72 bytes) into its row of `ob`, and the wave stores the 64 rows (four lanes per
-// stream, 16 bytes each).  `act`: the lane has a stream; returns its verdict (all bits consumed, nothing beyond).
+// 2600 cycles per symbol on C5's leaves.  Here the wave moves the data.  Every stream has a 128-byte RING in LDS, addressed
+// by the byte offset inside the stream (streams are read from their end downwards); a round reads at most 32 x 9 bits + the
+// 64 bits of look-ahead = 44 bytes of it.  At the START of a round the wave issues the loads of the 16-byte chunks the round
+// AFTER it may need (four lanes per stream, at most four chunks each), every lane decodes its 32 symbols into a 32-byte
+// row of `ob`, and only then the chunks are written into the rings and the rows stored (two lanes per stream): the HBM
+// latency of the input hides behind the symbol loop.  `act`: the lane has a stream; returns its verdict (all bits consumed,
+// nothing beyond).
+constexpr uint32_t ZH_ROUND = 32;
 __device__ inline bool z_wave_huf_streams(ZHufLanes& H, uint32_t g, uint32_t mb, const uint8_t* sb_, uint32_t sn, uint8_t* dst, uint32_t outn, bool act) {
     const uint32_t lane = threadIdx.x & 63;
     ZHufStage& S = H.s;
+    uint32_t* ob32 = (uint32_t*)H.ob;          // [64][8]: the round's output, u32 m of stream s in slot (m + s) & 7
+    uint32_t* sn_pub = ob32 + 64 * 8;          // (the second half of ob: the streams' sizes while the rings are primed)
     int32_t left = 0;
     if (act) {
         const uint8_t lastb = sn ? ldu8(sb_ + sn - 1) : (uint8_t)0;
@@ -857,55 +864,84 @@ __device__ inline bool z_wave_huf_streams(ZHufLanes& H, uint32_t g, uint32_t mb,
     const bool had = act;
     bool ok = true;
     uint32_t done = 0;
+    // ---- prime the rings: the 128 bytes below the 16-byte border at or above the stream's top
+    const int32_t hi0 = (left + 7) >> 3;                   // bytes that still hold unread bits
+    const int32_t top = (hi0 + 15) & ~15;
+    S.ptr[lane] = (uint64_t)(uintptr_t)sb_;
+    S.lo[lane] = act ? top - 128 : (int32_t)0x80000000;
+    sn_pub[lane] = sn;
+    wave_sync();
+#pragma unroll
+    for (uint32_t p = 0; p < 8; p++) {
+        const uint32_t s = 8 * p + (lane >> 3), c = lane & 7;
+        const int32_t lo = S.lo[s];
+        if (lo == (int32_t)0x80000000) continue;
+        const uint8_t* src = (const uint8_t*)(uintptr_t)S.ptr[s];
+        const int32_t b = lo + 16 * (int32_t)c, sns = (int32_t)sn_pub[s];
+        if (b + 16 <= 0 || b >= sns) continue;
+        uint32_t w4[4] = {0, 0, 0, 0};
+        if (b >= 0 && b + 16 <= sns) {
+            const u32x4 v = ldu128(src + b);
+            w4[0] = v.x; w4[1] = v.y; w4[2] = v.z; w4[3] = v.w;
+        } else {   // the stream starts or ends inside this chunk: the bytes outside read as zeros
+            for (int32_t k = 0; k < 16; k++)
+                if (b + k >= 0 && b + k < sns) w4[k >> 2] |= (uint32_t)ldu8(src + b + k) << (8 * (k & 3));
+        }
+        const uint32_t w0 = (uint32_t)(b >> 2);   // (b >= -15: a chunk that starts in front of the stream holds its words 0 ..)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (b + 4 * q >= 0) S.ring[s][(w0 + q + s) & 31] = w4[q];
+    }
+    wave_sync();
+    int32_t lo_loaded = top - 128 > 0 ? top - 128 : 0;
+    const uint32_t* ring = S.ring[lane];
+    auto word = [&](int32_t w) -> uint32_t { return w >= 0 ? ring[((uint32_t)w + lane) & 31] : 0u; };
+    // the bit buffer: the next bits of the stream top-aligned, cnt of them valid (> 32 after every refill); wi = next word
+    uint64_t bb = 0;
+    uint32_t cnt = 0;
+    int32_t wi = -1;
+    if (act) {
+        const uint32_t kb = (uint32_t)((hi0 - 1) & 3) + 1;   // bytes of the top word that belong to the stream
+        const int32_t wt = (hi0 - 1) >> 2;
+        const uint32_t u0 = (uint32_t)(8 * hi0 - left);      // unused bits of the top byte (0 .. 7)
+        bb = ((uint64_t)word(wt) << (32 + 8 * (4 - kb))) << u0;
+        cnt = 8 * kb - u0;
+        wi = wt - 1;
+    }
+    const uint16_t* tab = H.tab[g];
+    const uint32_t sh = 32 - mb;
     ZTL_BEGIN
     while (__ballot(act && ok && done < outn)) {
-        ZTL(0);
         const bool run = act && ok && done < outn;
-        const int32_t hi = (left + 7) >> 3;   // byte just above the top bit
-        S.ptr[lane] = (uint64_t)(uintptr_t)sb_;
-        S.lo[lane] = run ? hi - 128 : (int32_t)0x80000000;
-        wave_sync();
-#pragma unroll
-        for (uint32_t p = 0; p < 8; p++) {
-            const uint32_t s = 8 * p + (lane >> 3), c = lane & 7;
-            const int32_t lo = S.lo[s];
-            if (lo == (int32_t)0x80000000) continue;
-            const uint8_t* src = (const uint8_t*)(uintptr_t)S.ptr[s];
-            const int32_t b = lo + 16 * (int32_t)c;   // (b + 16 <= hi <= the stream's size)
-            uint64_t v0 = 0, v1 = 0;
-            if (b >= 0) {
-                const u32x4 v = ldu128(src + b);
-                v0 = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                v1 = (uint64_t)v.z | ((uint64_t)v.w << 32);
-            } else if (b > -16) {   // the stream starts inside this chunk: the bytes in front of it read as zeros
-                for (int32_t k = -b; k < 16; k++) {
-                    const uint64_t by = ldu8(src + b + k);
-                    if (k < 8)
-                        v0 |= by << (8 * k);
-                    else
-                        v1 |= by << (8 * (k - 8));
-                }
-            }
-            S.in[s][(2 * c + s) & 15] = v0;
-            S.in[s][(2 * c + 1 + s) & 15] = v1;
+        ZTL(0);
+        // ---- the chunks the NEXT round may read: down to word wi - 20 (this round reads down to wi - 10 at most)
+        int32_t lo_new = lo_loaded;
+        if (run) {
+            const int32_t need = (4 * (wi - 20)) & ~15;
+            lo_new = need < 0 ? 0 : need;
+            if (lo_new > lo_loaded) lo_new = lo_loaded;
         }
+        S.lo[lane] = lo_loaded;
+        S.nch[lane] = (uint8_t)((lo_loaded - lo_new) >> 4);
         wave_sync();
+        u32x4 pre[4];
+        uint32_t pre_m = 0;
+#pragma unroll
+        for (uint32_t p = 0; p < 4; p++) {
+            const uint32_t s = 16 * p + (lane >> 2), c = lane & 3;
+            pre[p] = u32x4{0, 0, 0, 0};
+            if (c < S.nch[s]) {   // (below what is loaded: inside the stream)
+                pre[p] = ldu128((const uint8_t*)(uintptr_t)S.ptr[s] + (S.lo[s] - 16 * (int32_t)(c + 1)));
+                pre_m |= 1u << p;
+            }
+        }
         ZTL(1);
+        // ---- 32 symbols
         uint32_t n_this = 0;
         if (run) {
-            n_this = min(64u, outn - done);
-            // 32-bit words of my row, from the top (word w of stream s: half w & 1 of slot ((w >> 1) + s) & 15); bb holds
-            // the next bits top-aligned (cnt of them valid, > 32 after every refill): one 64-bit shift per symbol
-            const uint32_t* row32 = (const uint32_t*)S.in[lane];
-            auto word = [&](int32_t w) -> uint32_t { return w >= 0 ? row32[2 * (((uint32_t)(w >> 1) + lane) & 15) + (w & 1)] : 0u; };
-            const uint32_t u0 = (uint32_t)(8 * hi - left);   // unused bits of the top byte (0 .. 7)
-            uint64_t bb = (((uint64_t)word(31) << 32) | word(30)) << u0;
-            uint32_t cnt = 64 - u0;
-            int32_t wi = 29;
-            const uint16_t* tab = H.tab[g];
-            const uint32_t sh = 32 - mb;
+            n_this = min(ZH_ROUND, outn - done);
             uint32_t out32 = 0;
-            uint32_t* orow = (uint32_t*)H.ob[lane];
+            uint32_t* orow = ob32 + 8 * lane;
             for (uint32_t i = 0; i < n_this; i++) {
                 if (cnt <= 32) {
                     bb |= (uint64_t)word(wi--) << (32 - cnt);
@@ -917,30 +953,47 @@ __device__ inline bool z_wave_huf_streams(ZHufLanes& H, uint32_t g, uint32_t mb,
                 cnt -= len;
                 left -= (int32_t)len;
                 out32 = (out32 >> 8) | ((e & 255u) << 24);
-                if ((i & 3) == 3) orow[2 * ((((i >> 3)) + lane) & 7) + ((i >> 2) & 1)] = out32;
+                if ((i & 3) == 3) orow[((i >> 2) + lane) & 7] = out32;
             }
-            if (n_this & 3) orow[2 * ((((n_this >> 3)) + lane) & 7) + ((n_this >> 2) & 1)] = out32 >> (8 * (4 - (n_this & 3)));
+            if (n_this & 3) orow[((n_this >> 2) + lane) & 7] = out32 >> (8 * (4 - (n_this & 3)));
             if (left < 0) ok = false;
         }
-        S.cnt[lane] = ok ? n_this : 0u;
-        S.ptr[lane] = (uint64_t)(uintptr_t)(dst + done);
-        wave_sync();
         ZTL(2);
+        wave_sync();   // (every lane is done with the ring words the new chunks replace: they lie 128 bytes higher)
+        // ---- the chunks into the rings, the rows to HBM
 #pragma unroll
         for (uint32_t p = 0; p < 4; p++) {
+            if (!((pre_m >> p) & 1)) continue;
             const uint32_t s = 16 * p + (lane >> 2), c = lane & 3;
+            const uint32_t w0 = (uint32_t)((S.lo[s] - 16 * (int32_t)(c + 1)) >> 2);
+            S.ring[s][(w0 + s) & 31] = pre[p].x;
+            S.ring[s][(w0 + 1 + s) & 31] = pre[p].y;
+            S.ring[s][(w0 + 2 + s) & 31] = pre[p].z;
+            S.ring[s][(w0 + 3 + s) & 31] = pre[p].w;
+        }
+        lo_loaded = lo_new;
+        S.cnt[lane] = (uint8_t)(ok ? n_this : 0u);
+        wave_sync();
+        S.ptr[lane] = (uint64_t)(uintptr_t)(dst + done);   // (the loads through ptr are done: it now says where the rows go)
+        wave_sync();
+#pragma unroll
+        for (uint32_t p = 0; p < 2; p++) {
+            const uint32_t s = 32 * p + (lane >> 1), c = lane & 1;
             const uint32_t cs = S.cnt[s];
             if (16 * c >= cs) continue;
             uint8_t* d = (uint8_t*)(uintptr_t)S.ptr[s] + 16 * c;
-            const uint64_t v0 = H.ob[s][(2 * c + s) & 7], v1 = H.ob[s][(2 * c + 1 + s) & 7];
+            const uint32_t* orow = ob32 + 8 * s;
+            const uint32_t v0 = orow[(4 * c + s) & 7], v1 = orow[(4 * c + 1 + s) & 7], v2 = orow[(4 * c + 2 + s) & 7], v3 = orow[(4 * c + 3 + s) & 7];
             if (16 * c + 16 <= cs) {
-                stu128(d, u32x4{(uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)});
+                stu128(d, u32x4{v0, v1, v2, v3});
             } else {
-                for (uint32_t k = 0; k < cs - 16 * c; k++) *(gptr)(d + k) = (uint8_t)((k < 8 ? v0 >> (8 * k) : v1 >> (8 * (k - 8))));
+                const uint32_t vv[4] = {v0, v1, v2, v3};
+                for (uint32_t k = 0; k < cs - 16 * c; k++) *(gptr)(d + k) = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
             }
         }
         done += n_this;
         wave_sync();
+        S.ptr[lane] = (uint64_t)(uintptr_t)sb_;
         ZTL(3);
     }
     return had && ok && done == outn && left == 0;

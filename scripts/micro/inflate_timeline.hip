@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
     const char* names[7] = {"headers (lane per frame)", "group setup", "Huffman tables (lane per frame)", "streams (lane per stream)", "end of phase H",
                             "sequence pre-decode (lane per frame)", "one-wave path"};
     for (int p = 0; p < 7; p++) printf("  %-40s %10.1f us\n", names[p], (double)t[32 + p] / 2400.0);
-    const char* zn[4] = {"streams: round setup", "streams: stage in", "streams: decode 64 symbols", "streams: store"};
+    const char* zn[4] = {"streams: round setup", "streams: issue the prefetch", "streams: decode 32 symbols", "streams: ring writes + store"};
     for (int p = 0; p < 4; p++) printf("  %-40s %10.1f us\n", zn[p], (double)t[48 + p] / 2400.0);
     return 0;
 }

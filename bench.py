@@ -210,7 +210,7 @@ class GpuHarness:
         return dict(U=U, page_bytes=pb, n_pages=npages, enc_ms=te, dec_ms=td, kernels=st, enc=enc)
 
 
-def measure_reference_pages(h, cols, sbo_opts, reps=3):
+def measure_reference_pages(h, cols, sbo_opts, reps=3, check_all=False):
     """decode of pages the REFERENCE's codecs wrote: the restatement with the box's liblz4 / libzstd writes the columns'
     pages in the untimed setup (one LZ4 block / one libzstd frame per buffer, src/compression/basic.rs:108-135), the device
     reads them back; returns None when the libraries do not load"""
@@ -231,7 +231,8 @@ def measure_reference_pages(h, cols, sbo_opts, reps=3):
     pages = [read.ColumnPages(c["ptype"], c["nullable"], torch.from_numpy(p).to(h.dev), m) for c, (p, m) in zip(cols, written)]
     dec = read.batch_read_columns(ctx, pages)
     ctx.synchronize()
-    h.check_round_trip(cols[0], dec[0])
+    for c, d in zip(cols if check_all else cols[:2], dec):
+        h.check_round_trip(c, d)
     rb = read.ReadBatch(ctx, pages, out=dec)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     rb.enqueue()
@@ -265,7 +266,7 @@ def direction_summary(U, pb, ms, kernels, encode):
     A = U + pb
     return {"GBps": round(U / ms / 1e6, 1), "ms": round(ms, 3), "frac_hbm": round(A / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "top_kernel": top[0], "top_kernel_ms": round(top[1][1], 3), "top_kernel_share": round(top[1][1] / tot, 3),
-            "kernels_ms": {k: round(v[1], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1])[:5]}}
+            "kernels_ms": {k: round(v[1], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1])[:8]}}
 
 
 def config_entry(name, res, cpu, extra=None):

@@ -412,6 +412,11 @@ typedef struct sb_kernel_stat {
 } sb_kernel_stat;
 int32_t sb_ctx_profile(sb_ctx* ctx, int32_t enable);  /* enable/disable; resets the totals */
 uint32_t sb_ctx_profile_read(sb_ctx* ctx, sb_kernel_stat* out, uint32_t cap);
+/* Totals of the block-parallel Zstd decoder (basic.rs:93-97: libzstd frames are decoded block by block, all blocks of a
+ * call at once) since the context was created: out[0] frames it decoded, out[1] frames handed back to the frame-serial
+ * decoder (pools exhausted, or a malformed stream whose error that decoder names), out[2] blocks, out[3] sequences.
+ * Synchronises the context. */
+int32_t sb_ctx_zstd_block_stats(sb_ctx* ctx, uint64_t out[4]);
 
 /* version / build info string ("strawboat-hip <ver> gfx950") */
 const char* sb_version(void);

@@ -68,8 +68,14 @@ class Context:
         """Per-kernel HIP-event timing on this context's stream (resets the totals)."""
         self._check(self._lib.sb_ctx_profile(self._h, 1 if enable else 0))
 
+    def zstd_block_stats(self):
+        """(frames decoded block-parallel, frames handed back to the frame-serial decoder, blocks, sequences) so far"""
+        out = (C.c_uint64 * 4)()
+        self._check(self._lib.sb_ctx_zstd_block_stats(self._h, out), drain=False)
+        return tuple(int(x) for x in out)
+
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated up to the last synchronize()."""
-        arr = (N.KernelStatC * 32)()
-        n = self._lib.sb_ctx_profile_read(self._h, arr, 32)
+        arr = (N.KernelStatC * 96)()
+        n = self._lib.sb_ctx_profile_read(self._h, arr, 96)
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n)}

@@ -171,6 +171,13 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
         return SB_ERR_EXTERNAL;
     }
     (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
+    if (hipMalloc((void**)&ctx->zb_stats, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        sb_ctx_destroy(ctx);
+        return SB_ERR_EXTERNAL;
+    }
+    (void)hipMemsetAsync(ctx->zb_stats, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    if (const char* e = getenv("SB_ZSTD_BLOCKS")) ctx->zb_mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
+    if (const char* e = getenv("SB_ZSTD_BLOCKS_MIN")) ctx->zb_min_csize = (uint32_t)strtoul(e, nullptr, 10);
     *out = ctx;
     return SB_OK;
 }
@@ -196,6 +203,10 @@ void sb_ctx_destroy(sb_ctx* ctx) {
     if (ctx->staging.p) (void)hipFree(ctx->staging.p);
     if (ctx->zlit.p) (void)hipFree(ctx->zlit.p);
     if (ctx->zrec.p) (void)hipFree(ctx->zrec.p);
+    if (ctx->zb_stats) (void)hipFree(ctx->zb_stats);
+    if (ctx->zb_blocks.p) (void)hipFree(ctx->zb_blocks.p);
+    if (ctx->zb_lit.p) (void)hipFree(ctx->zb_lit.p);
+    if (ctx->zb_rec.p) (void)hipFree(ctx->zb_rec.p);
     if (ctx->enc_plan.pages.p) (void)hipFree(ctx->enc_plan.pages.p);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -297,6 +308,7 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     // status word travels with the stream
     hipError_t e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(Status), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) ctx->kinds_seen |= ctx->h_status->kinds;
     if (e != hipSuccess) {
         rc = check_hip(ctx, e, "sb_ctx_synchronize");
     } else if (ctx->h_status->code != 0) {
@@ -358,6 +370,13 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     ctx->temp_dev.clear();
     ctx->stage_rewind();
     ctx->sticky = 0;
+    return rc;
+}
+
+int32_t sb_ctx_zstd_block_stats(sb_ctx* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return SB_ERR_INVALID;
+    const int32_t rc = sb_ctx_synchronize(ctx);
+    if (hipMemcpy(out, ctx->zb_stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return SB_ERR_EXTERNAL;
     return rc;
 }
 
@@ -453,6 +472,12 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     off = align_up(off + 64, 64);
     const size_t o_vlen = off;
     off = align_up(off + n * sizeof(uint64_t), 64);
+    // the block-parallel Zstd pipeline: frames + counters here, blocks / literals / records in pools of their own
+    const bool zb_on = ctx->zb_mode == 1 || (ctx->zb_mode == 2 && (ctx->kinds_seen & KIND_ZSTD));
+    const size_t o_zb_counts = off;
+    if (zb_on) off = align_up(off + 64, 64);
+    const size_t o_zb_frames = off;
+    if (zb_on) off = align_up(off + job_cap * sizeof(ZbFrame), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
     StageSlot* slot = acquire_slot(ctx, upload_bytes + n * sizeof(uint64_t));
@@ -530,7 +555,26 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     // the inflate pool's per-wave areas: a literal buffer of one block, and (calls with at least 4 queue entries per pool
     // wave: batches) the arena of pre-decoded Zstd sequences
     if (!ensure(ctx, ctx->zlit, (size_t)INFLATE_POOL * (128 * 1024 + 64))) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zlit) failed");
-    const bool zrec_wanted = pages_bytes >= (48ull << 20);   // (a call that can hold >= 4 x INFLATE_POOL frames of 16 KiB)
+    // (the lane-per-frame record arena only for calls that can hold >= 4 x INFLATE_POOL frames of 16 KiB, and only in a
+    // context that has met Zstd pages: LZ4 / plain / Dict-only readers never pay for it)
+    const bool zrec_wanted = pages_bytes >= (48ull << 20) && (ctx->zb_mode == 1 || (ctx->kinds_seen & KIND_ZSTD));
+    uint64_t zb_block_cap = 0, zb_lit_cap = 0, zb_rec_cap = 0;
+    if (zb_on) {
+        // blocks: libzstd's are 128 KiB of content (sub-blocks of a few KiB when it splits them); literals: at most the
+        // output (a Huffman stream expands <= 8 x); records: one per >= 3 output bytes, in practice one per >= 2 stream bytes.
+        // A frame that does not fit is decoded by the one-wave path.
+        uint64_t out_bytes = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t rows = cols[i].rows;
+            out_bytes += sizes_only ? rows * 8 + 64 : cols[i].values_capacity + (is_binary_t(cols[i].physical_type) ? cols[i].offsets_capacity : 0) + rows * 8 + 64;
+        }
+        zb_block_cap = std::min<uint64_t>(pages_bytes / 2048 + 2 * job_cap + 64, 1u << 23);
+        zb_lit_cap = std::min<uint64_t>(4 * pages_bytes, out_bytes) + 16 * zb_block_cap + (1u << 16);
+        zb_rec_cap = std::min<uint64_t>(pages_bytes / 2, out_bytes / 3) + (1u << 14);
+        if (!ensure(ctx, ctx->zb_blocks, zb_block_cap * sizeof(ZbBlock)) || !ensure(ctx, ctx->zb_lit, zb_lit_cap + 64) ||
+            !ensure(ctx, ctx->zb_rec, zb_rec_cap * 12 + 16))
+            return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zstd block pools) failed");
+    }
     if (zrec_wanted && !ensure(ctx, ctx->zrec, (size_t)INFLATE_POOL * ZREC_PER_WAVE * 8))
         return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zrec) failed");
 
@@ -558,6 +602,20 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     // more (64 KiB pages of incompressible values — the reference's bench shape — stay with the one-wave copy path)
     const uint32_t big_min = 2 * P >= 4096 ? 2 * LZ4_BIG_MIN : LZ4_BIG_MIN / 4;
     a.lz4_big_min = max_page_len >= big_min ? big_min : 0xFFFFFFFFu;
+    memset(&a.zb, 0, sizeof a.zb);
+    if (zb_on) {
+        a.zb.blocks = (ZbBlock*)ctx->zb_blocks.p;
+        a.zb.frames = (ZbFrame*)(tb + o_zb_frames);
+        a.zb.lit = ctx->zb_lit.p;
+        a.zb.rec = (uint64_t*)ctx->zb_rec.p;
+        a.zb.counters = (uint32_t*)(tb + o_zb_counts);
+        a.zb.block_cap = (uint32_t)zb_block_cap;
+        a.zb.frame_cap = (uint32_t)std::min<uint64_t>(job_cap, 0x7FFFFFFFu);
+        a.zb.lit_cap = zb_lit_cap;
+        a.zb.rec_cap = zb_rec_cap;
+        a.zb.min_csize = ctx->zb_min_csize;
+        a.zb.stats = ctx->zb_stats;
+    }
     a.freq_log = nullptr;
     a.freq_count = nullptr;
     a.freq_cap = 0;

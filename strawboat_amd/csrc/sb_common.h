@@ -85,8 +85,9 @@ struct Status {
     int32_t code;   // first error (SB_ERR_*), 0 = ok
     uint32_t page;  // page index within the call
     uint32_t where; // kernel-specific tag
-    uint32_t pad;
+    uint32_t kinds; // KIND_* bits of what the calls have met so far (never cleared: the host sizes later calls by it)
 };
+constexpr uint32_t KIND_ZSTD = 1u;   // a Zstd buffer was queued
 
 // one general-purpose block (LZ4 / Zstd / Snappy) to inflate: src -> dst
 struct InflateJob {
@@ -111,6 +112,45 @@ struct FreqEntry {
     uint32_t ptype, width;
     uint32_t page, pad;
 };
+
+// ---- the block-parallel Zstd pipeline (sb_zstd_blocks.h): descriptors and pools of one call
+struct ZbBlock {
+    const uint8_t* src;     // block content (after the 3-byte block header)
+    uint32_t bsize;         // content bytes in the stream (RLE block: 1)
+    uint32_t frame;
+    uint32_t btype;         // 0 raw, 1 RLE, 2 compressed
+    uint32_t out_size;      // raw / RLE: from the header; compressed: literals + match bytes (zb_seq; nseq == 0: regen)
+    uint32_t ltype, lstreams, regen, lcsize, lpay;   // literals section: type, streams, regenerated / compressed size, payload offset
+    uint32_t huf_def;       // block whose literal payload starts with the Huffman tree in use
+    uint32_t nseq, modes, seq_off;                   // sequences: count, modes byte, offset of the byte after it
+    uint32_t def[3];        // LL, OF, ML: block whose description defines the table in use; ZB_NONE: predefined
+    uint32_t desc[3];       // zb_hdr: offsets (in this block) of its own descriptions (modes 1 and 2)
+    uint32_t bits_off;      // zb_hdr: offset of the sequence bit stream
+    uint64_t lit_pos;       // the block's literals in the literal pool (types 1, 2, 3)
+    uint64_t rec_pos;       // the block's records in the record pool
+};
+struct ZbFrame {
+    uint8_t* dst;
+    uint32_t out_len;
+    uint32_t first, nblocks;
+    uint32_t job;           // queue entry
+    uint32_t page;
+    uint32_t punt;          // != 0: the one-wave decoder takes the frame
+    uint32_t avail;         // bytes of the queue entry's buffer (loads never reach beyond it)
+    const uint8_t* base;    // the queue entry's buffer
+};
+struct ZbPools {
+    ZbBlock* blocks;
+    ZbFrame* frames;
+    uint8_t* lit;
+    uint64_t* rec;          // 12 bytes per sequence: literal length, match length, offset value (rec_pos counts sequences)
+    uint32_t* counters;     // [0] blocks, [1] frames, [2] blocks with sequences (unused), [4..5] literal bytes, [6..7] records
+    uint32_t block_cap, frame_cap;
+    uint64_t lit_cap, rec_cap;
+    uint32_t min_csize;     // frames shorter than this stay with the one-wave / lane-per-frame paths
+    unsigned long long* stats;   // totals of the context: [0] frames decoded, [1] frames handed back, [2] blocks, [3] sequences
+};
+
 
 // the pool of inflate waves (k_inflate) and its per-wave areas
 constexpr uint32_t INFLATE_POOL = 2048;          // waves
@@ -139,6 +179,7 @@ struct DecodeArgs {
     uint32_t defer_payloads;  // the call has binary columns (queue B runs): Basic payloads nothing waits for go there too
     uint32_t job_cap_a, job_cap_b;  // entries of the two job queues (2 * n_pages + room for the frames of split Zstd buffers)
     uint32_t lz4_big_min;  // LZ4 blocks of at least this many compressed bytes go to k_inflate_lz4_big (0xFFFFFFFF: the call has no page that long)
+    ZbPools zb;            // block-parallel Zstd pipeline (zb.blocks == nullptr: not launched for this call)
 };
 constexpr uint32_t LZ4_BIG_MIN = 64u << 10;
 

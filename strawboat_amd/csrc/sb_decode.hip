@@ -20,6 +20,7 @@
 // LDS for the per-tile scans, wave64 shuffles for the scan carries.
 #include "sb_host.h"
 #include "sb_zstd.h"
+#include "sb_zstd_blocks.h"
 #include "sb_lz4.h"
 #include "sb_lz4_big.h"
 
@@ -82,13 +83,14 @@ __device__ inline bool zstd_frame_extent(const uint8_t* src, uint32_t n, uint32_
 // up to the entry's output is replaced by one entry per frame (the walk reads a few bytes per frame).  Anything else stays
 // as it is and is decoded by one wave, frame after frame.  Threads only look at entries below *n0_p, so the entries other
 // threads append meanwhile are never walked.
-__global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt, const uint32_t* n0_p, uint32_t cap) {
+__global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt, const uint32_t* n0_p, uint32_t cap, Status* st) {
     const uint32_t n0 = *n0_p;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n0 || j >= cap) return;
     {
         const InflateJob job = q[j];
         if (job.codec != SB_CODEC_ZSTD) return;
+        if (!(st->kinds & KIND_ZSTD)) atomicOr(&st->kinds, KIND_ZSTD);   // (the host sizes the block pipeline's pools for later calls)
         uint32_t nf = 0, pos = 0, total = 0;
         bool ok = true;
         while (pos < job.csize) {
@@ -740,8 +742,9 @@ __device__ void patas_inflate_wave(const InflateJob& j, Status* st, uint8_t* s_w
 // One job of queue entries that k_inflate owns (all lanes, uniform arguments).  recs: the frame's pre-decoded sequences or null.
 __device__ __forceinline__ void inflate_one(const InflateJob& j, Status* st, ZWork& wk, uint8_t* zlit, uint8_t* s_win, uint16_t* s_pos,
                                             const uint64_t* recs) {
-    if (j.codec == SB_CODEC_LZ4 || j.codec == CODEC_SPLIT) {
-        // k_inflate_lz4 owns the LZ4 blocks; a split Zstd buffer is decoded through its frames' entries
+    if (j.codec == SB_CODEC_LZ4 || j.codec == CODEC_SPLIT || j.codec == CODEC_ZB) {
+        // k_inflate_lz4 owns the LZ4 blocks; a split Zstd buffer is decoded through its frames' entries; the block pipeline
+        // (sb_zstd_blocks.h) has decoded the frames it took
     } else if (j.codec == SB_CODEC_ZSTD) {
         zstd_inflate_wave(j.src, j.csize, j.dst, j.out_len, &wk, zlit, recs);
         if (threadIdx.x == 0 && wk.err) raise(st, SB_ERR_EXTERNAL, j.page, 120 + (uint32_t)wk.err);
@@ -2278,14 +2281,44 @@ void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, cons
     if (n) k_freq_scatter<<<n, WG, 0, ctx->stream>>>(entries, ex_off, ex_base, ctx->d_status);
 }
 
+// The block-parallel Zstd pipeline over one job queue (launched when the context has met Zstd pages: a.zb.blocks != null).
+// Frames it takes are marked CODEC_ZB; k_inflate, launched after it, decodes the rest (and the frames handed back).
+static void launch_zb(sb_ctx* ctx, const DecodeArgs& a, InflateJob* jobs, const uint32_t* count, const char* tag) {
+    if (!a.zb.blocks) return;
+    hipStream_t s = ctx->stream;
+    (void)hipMemsetAsync(a.zb.counters, 0, 8 * sizeof(uint32_t), s);
+    {
+        KScope k(ctx, tag[0] == 'a' ? "zb_scan" : "zb_scan(values)");
+        zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(jobs, count, a.zb);
+        zb_hdr<<<std::min<uint32_t>((a.zb.block_cap + WG - 1) / WG, 1024u), WG, 0, s>>>(a.zb);
+    }
+    // literals and sequences of a block are independent of each other (different pools): side by side on two streams
+    const bool multi = !ctx->profile && side_streams(ctx);
+    if (multi) side_fork(ctx, 1u);
+    {
+        KScope k(ctx, tag[0] == 'a' ? "zb_lit" : "zb_lit(values)");
+        zb_lit<<<std::min<uint32_t>((a.zb.block_cap + ZL_BLOCKS - 1) / ZL_BLOCKS, 768u), 64, 0, s>>>(a.zb);
+    }
+    {
+        KScope k(ctx, tag[0] == 'a' ? "zb_seq" : "zb_seq(values)");
+        zb_seq<<<std::min<uint32_t>((a.zb.block_cap + ZS_BLOCKS - 1) / ZS_BLOCKS, 3072u), 64, 0, multi ? ctx->side[0] : s>>>(a.zb);
+    }
+    if (multi) side_join(ctx, 1u);
+    {
+        KScope k(ctx, tag[0] == 'a' ? "zb_exec" : "zb_exec(values)");
+        zb_exec<<<std::min<uint32_t>(a.zb.frame_cap, 4096u), 64, 0, s>>>(jobs, a.status, a.zb);
+    }
+}
+
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
     {
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a);
+        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, a.status);
     }
+    launch_zb(ctx, a, a.jobs_a, a.job_counts, "a");
     {
         KScope k(ctx, K_INFLATE_A);
         k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
@@ -2305,8 +2338,9 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     if (any_binary) {  // (without binary columns the host knows every values_len itself)
         KScope k(ctx, K_COLSCAN);
         k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
-        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.job_counts + 9, a.job_cap_b);
+        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.job_counts + 9, a.job_cap_b, a.status);
     }
+    if (any_binary) launch_zb(ctx, a, a.jobs_b, a.job_counts + 1, "b");
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
         k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec);
@@ -2341,7 +2375,8 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-    k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a);
+    k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, a.status);
+    launch_zb(ctx, a, a.jobs_a, a.job_counts, "a");
     k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
     k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);

@@ -55,6 +55,13 @@ struct sb_ctx {
     sb::DevBuf zrec;     // Zstd sequence records (one arena per inflate wave; allocated by the first batch-sized read)
     sb::Status* d_status = nullptr;
     sb::Status* h_status = nullptr;  // pinned
+    // the block-parallel Zstd pipeline (sb_zstd_blocks.h): pools sized per call once the context has met Zstd pages
+    // (Status.kinds, read back at every synchronize); SB_ZSTD_BLOCKS = 0 / 1 in the environment forces it off / on
+    sb::DevBuf zb_blocks, zb_lit, zb_rec;
+    unsigned long long* zb_stats = nullptr;   // device: sb_ctx_zstd_block_stats
+    uint32_t kinds_seen = 0;
+    int zb_mode = 2;             // 0 off, 1 always, 2 once Zstd has been seen
+    uint32_t zb_min_csize = 0;   // SB_ZSTD_BLOCKS_MIN: frames shorter than this keep the one-wave / lane-per-frame paths
 
     static constexpr int NSLOTS = 8;
     sb::StageSlot slots[NSLOTS];

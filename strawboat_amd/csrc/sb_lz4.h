@@ -546,7 +546,9 @@ struct LzSeqExec {
     }
     // One batch: lane k < nb holds sequence k (ll, ml, off; off validated by the caller: 0 < off <= its match position).
     // lit = the batch's literals, contiguous.  op = output position of the batch's first byte.  Returns the bytes produced.
-    __device__ uint32_t run(uint32_t nb, uint32_t ll, uint32_t ml, uint32_t off, const uint8_t* lit, uint32_t op) {
+    // has_pre: pre8 holds the first min(ll, 8) literal bytes of the lane's sequence (requested by the caller a batch ahead)
+    __device__ uint32_t run(uint32_t nb, uint32_t ll, uint32_t ml, uint32_t off, const uint8_t* lit, uint32_t op, bool has_pre = false,
+                            uint64_t pre8 = 0) {
         const uint32_t lane = threadIdx.x & 63;
         const bool have = lane < nb;
         const uint32_t tot = have ? ll + ml : 0u;
@@ -555,16 +557,89 @@ struct LzSeqExec {
         const uint32_t lincl = wave_scan_dpp(have ? ll : 0u);
         const uint32_t my_op = op + incl - tot;             // my literals start here, my match at my_op + ll
         const uint32_t my_lit = lincl - (have ? ll : 0u);  // offset of my literals in `lit`
-        const uint64_t bigm = __ballot(have && (ll > 512 || ml > 512));
+        const uint64_t bigm = __ballot(have && (ll > 128 || ml > 512));
         if (total > LZX_BATCH || bigm) {
-            // ---- oversized batch: sequence by sequence through HBM (long literal runs / long matches)
+            // ---- a batch with long literal runs / long matches goes through HBM, in two phases.  Literals depend on
+            // nothing: every run of the batch is copied to its place first, wave-wide, no waits in between.  Then the
+            // matches: short ones that do not overlap themselves lane per match, every one whose source ends at or in front
+            // of the first pending match's destination at once (the bytes there are final), one store -> load wait per
+            // round; a long or self-overlapping match wave-wide when it is the first pending one.
             flush(op + a0, true);
-            uint32_t o = op;
-            for (uint32_t k = 0; k < nb; k++) {
-                const uint32_t kl = rdlane(ll, k), km = rdlane(ml, k), ko = rdlane(off, k), kp = rdlane(my_lit, k);
-                wave_copy_g2g(dst + o, lit + kp, kl);
-                o += kl;
-                wave_stores_visible();
+            // (lane per run, four 16-byte moves in flight per lane: a wave-wide copy per run would wait for HBM once per run;
+            // runs of 2 KiB and more — few, and the lanes next to them would idle — are moved by the whole wave)
+            if (have && ll < 2048) {
+                uint8_t* ld = dst + my_op;
+                const uint8_t* ls = lit + my_lit;
+                for (uint32_t i0 = 0; i0 < ll; i0 += 64) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        const uint32_t i = i0 + 16 * j;
+                        if (i + 16 <= ll) {
+                            v[j] = ldu128(ls + i);
+                        } else if (i < ll) {
+                            uint32_t w4[4] = {0, 0, 0, 0};
+                            for (uint32_t q = 0; i + q < ll; q++) w4[q >> 2] |= (uint32_t)ldu8(ls + i + q) << (8 * (q & 3));
+                            v[j] = u32x4{w4[0], w4[1], w4[2], w4[3]};
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        const uint32_t i = i0 + 16 * j;
+                        if (i + 16 <= ll) {
+                            stu128(ld + i, v[j]);
+                        } else if (i < ll) {
+                            const uint32_t w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                            for (uint32_t q = 0; i + q < ll; q++) *(gptr)(ld + i + q) = (uint8_t)(w4[q >> 2] >> (8 * (q & 3)));
+                        }
+                    }
+                }
+            }
+            {
+                uint64_t lm = __ballot(have && ll >= 2048);
+                while (lm) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(lm);
+                    lm &= lm - 1;
+                    wave_copy_g2g(dst + rdlane(my_op, k), lit + rdlane(my_lit, k), rdlane(ll, k));
+                }
+            }
+            wave_stores_visible();
+            const uint32_t md = my_op + ll, ms = md - off;          // (off <= md: checked by the caller)
+            const bool ism_ = have && ml > 0;
+            const bool smp = ism_ && ml <= 32 && off >= ml;
+            const uint32_t msend = ms + min(ml, off);
+            uint64_t rem_ = __ballot(ism_);
+            const uint64_t smp_m = __ballot(smp);
+            while (rem_) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(rem_);
+                if ((smp_m >> first) & 1) {
+                    const uint32_t fdst = rdlane(md, first);
+                    const bool go = ((rem_ >> lane) & 1) && smp && msend <= fdst;
+                    if (go) {
+                        uint64_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            if (8 * j + 8 <= ml) {
+                                v[j] = ldu64(dst + ms + 8 * j);
+                            } else if (8 * j < ml) {
+                                for (uint32_t q = 0; 8 * j + q < ml; q++) v[j] |= (uint64_t)ldu8(dst + ms + 8 * j + q) << (8 * q);
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            if (8 * j + 8 <= ml) {
+                                stu64(dst + md + 8 * j, v[j]);
+                            } else if (8 * j < ml) {
+                                for (uint32_t q = 0; 8 * j + q < ml; q++) *(gptr)(dst + md + 8 * j + q) = (uint8_t)(v[j] >> (8 * q));
+                            }
+                        }
+                    }
+                    rem_ &= ~__ballot(go);
+                    wave_stores_visible();
+                    continue;
+                }
+                rem_ &= rem_ - 1;
+                const uint32_t km = rdlane(ml, first), ko = rdlane(off, first), o = rdlane(md, first);
                 if (ko >= km) {
                     wave_copy_g2g(dst + o, dst + o - ko, km);
                 } else if (ko >= 1024) {
@@ -576,23 +651,34 @@ struct LzSeqExec {
                     const uint8_t* hist = dst + o - ko;
                     for (uint32_t i = lane; i < km; i += 64) dst[o + i] = ldu8(hist + i % ko);
                 }
-                o += km;
+                wave_stores_visible();
             }
-            restart(o);
-            return o - op;
+            restart(op + total);
+            return total;
         }
         const uint32_t g_end = op + total + a0;
         // ---- literals: HBM -> ring, lane per sequence, 8 bytes per round trip
-        if (have) {
-            for (uint32_t i = 0; i < ll; i += 8) {
-                uint64_t v = 0;
-                const uint32_t nbytes = min(8u, ll - i);
-                if (nbytes == 8) {
-                    v = ldu64(lit + my_lit + i);
-                } else {
-                    for (uint32_t b = 0; b < nbytes; b++) v |= (uint64_t)ldu8(lit + my_lit + i + b) << (8 * b);
+        if (have) {   // (four loads in flight per wait)
+            for (uint32_t i0 = 0; i0 < ll; i0 += 32) {
+                uint64_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t i = i0 + 8 * j;
+                    if (i >= ll) continue;
+                    const uint32_t nbytes = min(8u, ll - i);
+                    if (i == 0 && has_pre) {
+                        v[j] = pre8;
+                    } else if (nbytes == 8) {
+                        v[j] = ldu64(lit + my_lit + i);
+                    } else {
+                        for (uint32_t b = 0; b < nbytes; b++) v[j] |= (uint64_t)ldu8(lit + my_lit + i + b) << (8 * b);
+                    }
                 }
-                lds_wr_bytes(L.ring, RM, my_op + a0 + i, v, nbytes);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t i = i0 + 8 * j;
+                    if (i < ll) lds_wr_bytes(L.ring, RM, my_op + a0 + i, v[j], min(8u, ll - i));
+                }
             }
         }
         wave_sync();
@@ -614,8 +700,28 @@ struct LzSeqExec {
         wave_sync();
         uint64_t rem = __ballot(in_ring || mixed);
         const uint64_t mixed_m = __ballot(mixed);
+        // short matches that do not overlap themselves are copied LANE PER MATCH, many at a time: everything in front of
+        // the first pending match's destination is final (literals and far matches are in place, earlier matches done),
+        // so every pending short match whose source ends there or earlier may go at once — 8 + 8 source bytes read, then
+        // written.  Text whose matches reach back further than a batch's ~300 bytes of output: one or two rounds per batch
+        // instead of one LDS round trip per match
+        const bool simple = in_ring && ml <= 16 && off >= ml;
+        const uint64_t simple_m = __ballot(simple);
         while (rem) {
             const uint32_t first = (uint32_t)__builtin_ctzll(rem);
+            if ((simple_m >> first) & 1) {
+                const uint32_t fdst = rdlane(d, first);
+                const bool go = ((rem >> lane) & 1) && simple && send <= fdst;
+                if (go) {
+                    const uint32_t* r32 = (const uint32_t*)L.ring;
+                    const uint64_t v0 = lds_rd8_ring(r32, s & RM, RM >> 2), v1 = lds_rd8_ring(r32, (s + 8) & RM, RM >> 2);
+                    lds_wr_bytes(L.ring, RM, d, v0, min(ml, 8u));
+                    lds_wr_bytes(L.ring, RM, d + 8, v1, ml > 8 ? ml - 8 : 0u);
+                }
+                rem &= ~__ballot(go);
+                wave_sync();
+                continue;
+            }
             rem &= rem - 1;
             const uint32_t fd = rdlane(d, first), fml = rdlane(ml, first), foff = rdlane(off, first);
             const uint32_t fs = fd - foff;

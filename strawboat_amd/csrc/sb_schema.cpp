@@ -291,6 +291,8 @@ uint64_t read_key_values(Reader& r, size_t t, uint16_t id, std::string* packed) 
         packed->push_back('\0');
         packed->append(val.c_str());
         packed->push_back('\0');
+        // slots may all point at one table with a long string: honest metadata is never larger than the buffer it came from
+        if (packed->size() > r.n + 2 * (size_t)n) r.ok = false;
     }
     return n;
 }

@@ -133,12 +133,19 @@ def schema_to_bytes(schema) -> bytes:
     for i, (k, v) in enumerate(md.items()):
         kv[2 * i], kv[2 * i + 1] = bytes(k), bytes(v)
     n = C.c_uint64(0)
-    cap = 256 + 128 * len(ents) + sum(len(x) for x in keep if x) + sum(len(k) + len(v) + 32 for k, v in md.items())
-    buf = C.create_string_buffer(cap)
-    rc = lib.sb_schema_to_bytes(arr, len(ents), len(schema), kv if md else None, len(md), buf, cap, C.byref(n))
-    if rc != N.SB_OK:
-        raise N.NativeError(rc, lib.sb_schema_last_error().decode())
-    return buf.raw[:n.value]
+    # a KeyValue costs ~48 bytes of flatbuffer structure (two padded, length-prefixed strings, a table, a vtable, a
+    # vector slot) on top of its characters; should the estimate still be short, the call reports the length it needs
+    n_pairs = len(md) + sum(len(e["metadata"]) for e in ents if e["metadata"])
+    cap = 256 + 128 * len(ents) + sum(len(x) for x in keep if x) + sum(len(k) + len(v) for k, v in md.items()) + 64 * n_pairs
+    for _ in range(2):
+        buf = C.create_string_buffer(cap)
+        rc = lib.sb_schema_to_bytes(arr, len(ents), len(schema), kv if md else None, len(md), buf, cap, C.byref(n))
+        if rc == N.SB_OK:
+            return buf.raw[:n.value]
+        if n.value <= cap:
+            break
+        cap = n.value
+    raise N.NativeError(rc, lib.sb_schema_last_error().decode())
 
 
 def _build(ents, pos):

@@ -187,3 +187,44 @@ def test_hostile_footers_are_refused_without_blowup():
                 SC.schema_from_bytes(bytes(b))
             except (NativeError, NotImplementedError, UnicodeDecodeError, ValueError, LookupError):
                 pass
+
+
+def test_many_small_metadata_pairs_round_trip():
+    """every KeyValue costs ~40 bytes of flatbuffer structure: the caller-side capacity estimate must count pairs, not
+    only characters (a field with ten 1-byte pairs used to fail with 'schema buffer too small')"""
+    for n in (5, 10, 40, 300):
+        fmd = {("k%d" % i).encode(): b"v" for i in range(n)}
+        smd = {("s%d" % i).encode(): b"" for i in range(n)}
+        sch = pa.schema([pa.field("a", pa.int32(), metadata=fmd), pa.field("b", pa.utf8(), metadata=fmd)], metadata=smd)
+        assert SC.schema_from_bytes(SC.schema_to_bytes(sch)).equals(sch, check_metadata=True)
+
+
+def test_hostile_metadata_vector_sharing_one_long_string_is_refused():
+    """custom_metadata with N slots that all point at ONE KeyValue holding a long string would expand to N x len bytes
+    (64 KiB of footer -> ~1 GiB): the accumulated metadata may not exceed the buffer it came from"""
+    import time
+    from strawboat_amd._native import NativeError
+    z = b"\0\0\0\0"
+    f = _Fwd()
+    msg, mp = f.table({0: struct.pack("<hxx", 4), 1: b"\x01\0\0\0", 2: z})
+    f.point(0, msg)
+    sch, sp = f.table({1: z, 2: z})
+    f.point(mp[2], sch)
+    vec = len(f.b)
+    f.b += struct.pack("<I", 0)                       # no fields
+    f.point(sp[1], vec)
+    n_slots = 8000
+    mvec = len(f.b)
+    f.b += struct.pack("<I", n_slots) + z * n_slots
+    f.point(sp[2], mvec)
+    kv, kp = f.table({0: z, 1: z})
+    for k in range(n_slots):
+        f.point(mvec + 4 + 4 * k, kv)
+    s = len(f.b)
+    f.b += struct.pack("<I", 30000) + b"x" * 30000 + b"\0"
+    f.point(kp[0], s)
+    f.point(kp[1], s)
+    t0 = time.time()
+    with pytest.raises(NativeError):
+        SC.schema_from_bytes(bytes(f.b))
+    assert time.time() - t0 < 2.0

@@ -38,7 +38,14 @@ def main():
         print("pass %d: arrow %.1f MB pages %.1f MB: decode %.3f ms = %.1f GB/s" % (rep, r["arrow_MB"], r["page_MB"], d["ms"], d["GBps"]))
         for k, v in d.get("kernels_ms", {}).items():
             print("    %-28s %8.3f ms" % (k, v))
-    # every column against the oracle's decode of the same pages
+    import ctypes as C
+    lib = ctx._lib
+    if hasattr(lib, "sb_debug_zb_timers"):   # a development build (-DZB_TL): phase clocks of zb_exec / LzSeqExec::run
+        out = (C.c_uint64 * 20)()
+        lib.sb_debug_zb_timers(ctx._h, out)
+        v = [int(x) for x in out]
+        print("zb_exec (2 frames): rec %d rep %d scans %d run %d rest %d batches %d" % (v[0], v[1], v[2], v[3], v[4], v[11]))
+        print("run: hbm-mode %d (n=%d) literals %d classify %d matches %d flush %d | rounds %d serial matches %d" % (v[12], v[18], v[13], v[14], v[15], v[16], v[19], v[17]))
     print("ok")
 
 

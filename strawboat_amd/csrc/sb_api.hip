@@ -171,11 +171,11 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
         return SB_ERR_EXTERNAL;
     }
     (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
-    if (hipMalloc((void**)&ctx->zb_stats, 4 * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->zb_stats, 16 * sizeof(unsigned long long)) != hipSuccess) {
         sb_ctx_destroy(ctx);
         return SB_ERR_EXTERNAL;
     }
-    (void)hipMemsetAsync(ctx->zb_stats, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    (void)hipMemsetAsync(ctx->zb_stats, 0, 16 * sizeof(unsigned long long), ctx->stream);
     if (const char* e = getenv("SB_ZSTD_BLOCKS")) ctx->zb_mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
     if (const char* e = getenv("SB_ZSTD_BLOCKS_MIN")) ctx->zb_min_csize = (uint32_t)strtoul(e, nullptr, 10);
     *out = ctx;
@@ -380,6 +380,16 @@ int32_t sb_ctx_zstd_block_stats(sb_ctx* ctx, uint64_t out[4]) {
     return rc;
 }
 
+#ifdef ZB_TL
+extern "C++" { namespace sb { void debug_lzx_timers(uint64_t* out8); } }
+extern "C" int32_t sb_debug_zb_timers(sb_ctx* ctx, uint64_t out[20]) {   // development only (not in the header)
+    (void)sb_ctx_synchronize(ctx);
+    if (hipMemcpy(out, ctx->zb_stats + 4, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return SB_ERR_EXTERNAL;
+    sb::debug_lzx_timers(out + 12);
+    return SB_OK;
+}
+#endif
+
 int32_t sb_ctx_profile(sb_ctx* ctx, int32_t enable) {
     if (!ctx) return SB_ERR_INVALID;
     int32_t rc = sb_ctx_synchronize(ctx);
@@ -571,7 +581,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         zb_block_cap = std::min<uint64_t>(pages_bytes / 2048 + 2 * job_cap + 64, 1u << 23);
         zb_lit_cap = std::min<uint64_t>(4 * pages_bytes, out_bytes) + 16 * zb_block_cap + (1u << 16);
         zb_rec_cap = std::min<uint64_t>(pages_bytes / 2, out_bytes / 3) + (1u << 14);
-        if (!ensure(ctx, ctx->zb_blocks, zb_block_cap * sizeof(ZbBlock)) || !ensure(ctx, ctx->zb_lit, zb_lit_cap + 64) ||
+        if (!ensure(ctx, ctx->zb_blocks, zb_block_cap * (sizeof(ZbBlock) + 16)) || !ensure(ctx, ctx->zb_lit, zb_lit_cap + 64) ||
             !ensure(ctx, ctx->zb_rec, zb_rec_cap * 12 + 16))
             return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zstd block pools) failed");
     }
@@ -605,6 +615,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     memset(&a.zb, 0, sizeof a.zb);
     if (zb_on) {
         a.zb.blocks = (ZbBlock*)ctx->zb_blocks.p;
+        a.zb.lists = (uint32_t*)(ctx->zb_blocks.p + zb_block_cap * sizeof(ZbBlock));
         a.zb.frames = (ZbFrame*)(tb + o_zb_frames);
         a.zb.lit = ctx->zb_lit.p;
         a.zb.rec = (uint64_t*)ctx->zb_rec.p;

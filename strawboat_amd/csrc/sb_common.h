@@ -144,7 +144,8 @@ struct ZbPools {
     ZbFrame* frames;
     uint8_t* lit;
     uint64_t* rec;          // 12 bytes per sequence: literal length, match length, offset value (rec_pos counts sequences)
-    uint32_t* counters;     // [0] blocks, [1] frames, [2] blocks with sequences (unused), [4..5] literal bytes, [6..7] records
+    uint32_t* counters;     // [0] blocks, [1] frames, [4..5] literal bytes, [6..7] records, [8..11] blocks with sequences per size class
+    uint32_t* lists;        // zb_hdr: the blocks with sequences, by size class (4 x block_cap indices)
     uint32_t block_cap, frame_cap;
     uint64_t lit_cap, rec_cap;
     uint32_t min_csize;     // frames shorter than this stay with the one-wave / lane-per-frame paths

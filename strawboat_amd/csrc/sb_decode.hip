@@ -2286,7 +2286,7 @@ void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, cons
 static void launch_zb(sb_ctx* ctx, const DecodeArgs& a, InflateJob* jobs, const uint32_t* count, const char* tag) {
     if (!a.zb.blocks) return;
     hipStream_t s = ctx->stream;
-    (void)hipMemsetAsync(a.zb.counters, 0, 8 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.zb.counters, 0, 16 * sizeof(uint32_t), s);
     {
         KScope k(ctx, tag[0] == 'a' ? "zb_scan" : "zb_scan(values)");
         zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(jobs, count, a.zb);
@@ -2301,7 +2301,7 @@ static void launch_zb(sb_ctx* ctx, const DecodeArgs& a, InflateJob* jobs, const 
     }
     {
         KScope k(ctx, tag[0] == 'a' ? "zb_seq" : "zb_seq(values)");
-        zb_seq<<<std::min<uint32_t>((a.zb.block_cap + ZS_BLOCKS - 1) / ZS_BLOCKS, 3072u), 64, 0, multi ? ctx->side[0] : s>>>(a.zb);
+        zb_seq<<<std::min<uint32_t>((a.zb.block_cap + ZS_BLOCKS - 1) / ZS_BLOCKS + 4, 768u), 64, 0, multi ? ctx->side[0] : s>>>(a.zb);
     }
     if (multi) side_join(ctx, 1u);
     {
@@ -2309,6 +2309,10 @@ static void launch_zb(sb_ctx* ctx, const DecodeArgs& a, InflateJob* jobs, const 
         zb_exec<<<std::min<uint32_t>(a.zb.frame_cap, 4096u), 64, 0, s>>>(jobs, a.status, a.zb);
     }
 }
+
+#ifdef ZB_TL
+void debug_lzx_timers(uint64_t* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lzx_t), 8 * sizeof(uint64_t)); }
+#endif
 
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;

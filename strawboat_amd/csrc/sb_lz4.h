@@ -502,8 +502,19 @@ __device__ uint32_t lz4_inflate_block(const uint8_t* src, uint32_t n, uint8_t* d
 // to 64 sequences costs one HBM round trip for its literals and at most one store->load wait for matches that reach
 // behind the ring, instead of two waits per sequence.
 constexpr uint32_t LZX_RING = 8192, LZX_BATCH = 4096;
+#ifdef ZB_TL
+__device__ unsigned long long g_lzx_t[8];
+#define LZXT_BEGIN unsigned long long lzxt = __builtin_readcyclecounter();
+#define LZXT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x < 2 && (threadIdx.x & 63) == 0) atomicAdd(&g_lzx_t[i], n_ - lzxt); lzxt = n_; } while (0)
+#define LZXT_CNT(i, v) do { if (blockIdx.x < 2 && (threadIdx.x & 63) == 0) atomicAdd(&g_lzx_t[i], (unsigned long long)(v)); } while (0)
+#else
+#define LZXT_BEGIN
+#define LZXT(i)
+#define LZXT_CNT(i, v)
+#endif
 struct LzSeqLds {
     __attribute__((aligned(16))) uint8_t ring[LZX_RING];
+    uint32_t ls[65], lo[64];   // HBM-mode batches: where a sequence's literal run starts in the batch's literal stream / in the output
 };
 struct LzSeqExec {
     LzSeqLds& L;
@@ -544,6 +555,36 @@ struct LzSeqExec {
         if (lane < keep && fl + lane >= a0) L.ring[(fl + lane) & RM] = ldu8(gbase + fl + lane);
         wave_sync();
     }
+    // Which matches of the batch (bit j = sequence j) write bytes that lane's match reads: the destinations [mdst, mdst + ml)
+    // are sorted and disjoint, so they are the sequences from the first one that ends behind my source's start to the last
+    // one that starts in front of my source's end — two binary searches over the published starts / ends, once per batch.
+    // A match may go as soon as none of these is pending; everything else it reads (literals, earlier batches) is final.
+    __device__ uint64_t dep_mask(uint32_t mdst, uint32_t ml, uint32_t msrc, uint32_t msend) {
+        const uint32_t lane = threadIdx.x & 63;
+        wave_sync();
+        L.lo[lane] = mdst;
+        L.ls[lane] = mdst + ml;
+        wave_sync();
+        uint32_t lo_ = 0, hi_ = 64;     // ja = the first j whose end is > msrc: count of j with end <= msrc
+        uint32_t lo2 = 0, hi2 = 64;     // jb + 1 = count of j whose start is < msend
+#pragma unroll
+        for (int st = 0; st < 7; st++) {
+            if (lo_ < hi_) {
+                const uint32_t mid = (lo_ + hi_) >> 1;
+                if (L.ls[mid] <= msrc) lo_ = mid + 1;
+                else hi_ = mid;
+            }
+            if (lo2 < hi2) {
+                const uint32_t mid = (lo2 + hi2) >> 1;
+                if (L.lo[mid] < msend) lo2 = mid + 1;
+                else hi2 = mid;
+            }
+        }
+        const uint32_t ja = lo_, je = lo2;   // sequences [ja, je)
+        if (je <= ja) return 0ull;
+        const uint64_t upto = je >= 64 ? ~0ull : ((1ull << je) - 1);
+        return upto & ~((1ull << ja) - 1);
+    }
     // One batch: lane k < nb holds sequence k (ll, ml, off; off validated by the caller: 0 < off <= its match position).
     // lit = the batch's literals, contiguous.  op = output position of the batch's first byte.  Returns the bytes produced.
     // has_pre: pre8 holds the first min(ll, 8) literal bytes of the lane's sequence (requested by the caller a batch ahead)
@@ -558,6 +599,7 @@ struct LzSeqExec {
         const uint32_t my_op = op + incl - tot;             // my literals start here, my match at my_op + ll
         const uint32_t my_lit = lincl - (have ? ll : 0u);  // offset of my literals in `lit`
         const uint64_t bigm = __ballot(have && (ll > 128 || ml > 512));
+        LZXT_BEGIN
         if (total > LZX_BATCH || bigm) {
             // ---- a batch with long literal runs / long matches goes through HBM, in two phases.  Literals depend on
             // nothing: every run of the batch is copied to its place first, wave-wide, no waits in between.  Then the
@@ -565,56 +607,83 @@ struct LzSeqExec {
             // of the first pending match's destination at once (the bytes there are final), one store -> load wait per
             // round; a long or self-overlapping match wave-wide when it is the first pending one.
             flush(op + a0, true);
-            // (lane per run, four 16-byte moves in flight per lane: a wave-wide copy per run would wait for HBM once per run;
-            // runs of 2 KiB and more — few, and the lanes next to them would idle — are moved by the whole wave)
-            if (have && ll < 2048) {
-                uint8_t* ld = dst + my_op;
-                const uint8_t* ls = lit + my_lit;
-                for (uint32_t i0 = 0; i0 < ll; i0 += 64) {
-                    u32x4 v[4];
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        const uint32_t i = i0 + 16 * j;
-                        if (i + 16 <= ll) {
-                            v[j] = ldu128(ls + i);
-                        } else if (i < ll) {
-                            uint32_t w4[4] = {0, 0, 0, 0};
-                            for (uint32_t q = 0; i + q < ll; q++) w4[q >> 2] |= (uint32_t)ldu8(ls + i + q) << (8 * (q & 3));
-                            v[j] = u32x4{w4[0], w4[1], w4[2], w4[3]};
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        const uint32_t i = i0 + 16 * j;
-                        if (i + 16 <= ll) {
-                            stu128(ld + i, v[j]);
-                        } else if (i < ll) {
-                            const uint32_t w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-                            for (uint32_t q = 0; i + q < ll; q++) *(gptr)(ld + i + q) = (uint8_t)(w4[q >> 2] >> (8 * (q & 3)));
-                        }
-                    }
-                }
-            }
+            LZXT(1);
+            // The batch's literal runs are ONE contiguous stretch of `lit`.  Lane per run: its first and its last 16 bytes (runs
+            // of less than 16 bytes: 8 + 4 + 2 + 1).  Then the 16-byte chunks of the stretch that lie INSIDE one run: chunk c
+            // goes to lane c % 64, eight chunks per lane in flight (1 KiB per wave and load, coalesced); a chunk finds its run
+            // by a binary search over the runs' start offsets (LDS).  (Lane per run alone waited for HBM once per 64 bytes of
+            // the LONGEST run of the batch: 40 us per batch on C5's Int64 leaves.)
             {
-                uint64_t lm = __ballot(have && ll >= 2048);
-                while (lm) {
-                    const uint32_t k = (uint32_t)__builtin_ctzll(lm);
-                    lm &= lm - 1;
-                    wave_copy_g2g(dst + rdlane(my_op, k), lit + rdlane(my_lit, k), rdlane(ll, k));
+                const uint32_t T = rdlane(lincl, 63);
+                L.ls[lane] = have ? my_lit : T;
+                L.lo[lane] = my_op;
+                if (lane == 0) L.ls[64] = T;
+                wave_sync();
+                if (have && ll) {
+                    const uint8_t* sp = lit + my_lit;
+                    uint8_t* dp = dst + my_op;
+                    if (ll >= 16) {
+                        const u32x4 h = ldu128(sp), t = ldu128(sp + ll - 16);
+                        stu128(dp, h);
+                        stu128(dp + ll - 16, t);
+                    } else {
+                        uint32_t o = 0;
+                        uint64_t v8 = 0;
+                        uint32_t v4 = 0, v2 = 0, v1 = 0;
+                        if (ll & 8) v8 = ldu64(sp);
+                        if (ll & 4) v4 = ldu32(sp + (ll & 8));
+                        if (ll & 2) v2 = ldu16(sp + (ll & 12));
+                        if (ll & 1) v1 = ldu8(sp + (ll & 14));
+                        if (ll & 8) { stu64(dp, v8); o = 8; }
+                        if (ll & 4) { stu32(dp + o, v4); o += 4; }
+                        if (ll & 2) { const uint16_t w = (uint16_t)v2; __builtin_memcpy((gptr)(dp + o), &w, 2); o += 2; }
+                        if (ll & 1) *(gptr)(dp + o) = (uint8_t)v1;
+                    }
+                }
+                const uint32_t nchunks = T >> 4;   // (full chunks only: the last bytes of the stretch are some run's last bytes)
+                for (uint32_t c0 = 0; c0 < nchunks; c0 += 64 * 8) {
+                    uint32_t kk[8];
+                    u32x4 v[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const uint32_t x = 16 * (c0 + 64 * j + lane);
+                        uint32_t lo_ = 0, hi_ = 64;   // the last run that starts at or in front of x (runs of length 0 never win)
+#pragma unroll
+                        for (int st = 0; st < 6; st++) {
+                            const uint32_t mid = (lo_ + hi_) >> 1;
+                            if (L.ls[mid] <= x) lo_ = mid;
+                            else hi_ = mid;
+                        }
+                        kk[j] = lo_;
+                    }
+                    bool in_[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const uint32_t x = 16 * (c0 + 64 * j + lane);
+                        in_[j] = c0 + 64 * j + lane < nchunks && x + 16 <= L.ls[kk[j] + 1];   // (chunks over a run border: the runs' own moves)
+                        if (in_[j]) v[j] = ldu128(lit + x);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const uint32_t x = 16 * (c0 + 64 * j + lane);
+                        if (in_[j]) stu128(dst + L.lo[kk[j]] + (x - L.ls[kk[j]]), v[j]);
+                    }
                 }
             }
+            LZXT(2);
             wave_stores_visible();
+            LZXT(3);
             const uint32_t md = my_op + ll, ms = md - off;          // (off <= md: checked by the caller)
             const bool ism_ = have && ml > 0;
             const bool smp = ism_ && ml <= 32 && off >= ml;
             const uint32_t msend = ms + min(ml, off);
             uint64_t rem_ = __ballot(ism_);
             const uint64_t smp_m = __ballot(smp);
+            const uint64_t deps_ = dep_mask(have ? md : 0xFFFFFFFFu, have ? ml : 0u, ms, msend);
             while (rem_) {
                 const uint32_t first = (uint32_t)__builtin_ctzll(rem_);
                 if ((smp_m >> first) & 1) {
-                    const uint32_t fdst = rdlane(md, first);
-                    const bool go = ((rem_ >> lane) & 1) && smp && msend <= fdst;
+                    const bool go = ((rem_ >> lane) & 1) && smp && !(deps_ & rem_);
                     if (go) {
                         uint64_t v[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -636,6 +705,7 @@ struct LzSeqExec {
                     }
                     rem_ &= ~__ballot(go);
                     wave_stores_visible();
+                    LZXT_CNT(5, 1);
                     continue;
                 }
                 rem_ &= rem_ - 1;
@@ -653,7 +723,10 @@ struct LzSeqExec {
                 }
                 wave_stores_visible();
             }
+            LZXT(4);
             restart(op + total);
+            LZXT(0);
+            LZXT_CNT(6, 1);
             return total;
         }
         const uint32_t g_end = op + total + a0;
@@ -682,6 +755,7 @@ struct LzSeqExec {
             }
         }
         wave_sync();
+        LZXT(1);
         // ---- matches
         const uint32_t ring_min = max(ring_lo, g_end > LZX_RING ? g_end - LZX_RING : 0u);
         const uint32_t d = my_op + ll + a0, s = d - off;
@@ -692,14 +766,33 @@ struct LzSeqExec {
         const bool mixed = ism && !in_ring && !far;
         if (__ballot(far || mixed)) wave_stores_visible();
         if (far) {
-            for (uint32_t i = 0, j = 0; i < ml; i++) {
-                L.ring[(d + i) & RM] = ldu8(gbase + s + j);
-                if (++j == off) j = 0;
+            if (ml <= 16 && off >= ml) {   // (8 bytes per load where that stays inside what has been flushed)
+                uint64_t v0 = 0, v1 = 0;
+                if (s + 8 <= fl) {
+                    v0 = ldu64(gbase + s);
+                } else {
+                    for (uint32_t q = 0; q < ml && q < 8; q++) v0 |= (uint64_t)ldu8(gbase + s + q) << (8 * q);
+                }
+                if (ml > 8) {
+                    if (s + 16 <= fl) {
+                        v1 = ldu64(gbase + s + 8);
+                    } else {
+                        for (uint32_t q = 8; q < ml; q++) v1 |= (uint64_t)ldu8(gbase + s + q) << (8 * (q - 8));
+                    }
+                }
+                lds_wr_bytes(L.ring, RM, d, v0, min(ml, 8u));
+                if (ml > 8) lds_wr_bytes(L.ring, RM, d + 8, v1, ml - 8);
+            } else {
+                for (uint32_t i = 0, j = 0; i < ml; i++) {
+                    L.ring[(d + i) & RM] = ldu8(gbase + s + j);
+                    if (++j == off) j = 0;
+                }
             }
         }
         wave_sync();
         uint64_t rem = __ballot(in_ring || mixed);
         const uint64_t mixed_m = __ballot(mixed);
+        LZXT(2);
         // short matches that do not overlap themselves are copied LANE PER MATCH, many at a time: everything in front of
         // the first pending match's destination is final (literals and far matches are in place, earlier matches done),
         // so every pending short match whose source ends there or earlier may go at once — 8 + 8 source bytes read, then
@@ -707,22 +800,27 @@ struct LzSeqExec {
         // instead of one LDS round trip per match
         const bool simple = in_ring && ml <= 16 && off >= ml;
         const uint64_t simple_m = __ballot(simple);
+        const uint64_t deps = simple_m ? dep_mask(have ? d : 0xFFFFFFFFu, have ? ml : 0u, s, send) : 0ull;
         while (rem) {
             const uint32_t first = (uint32_t)__builtin_ctzll(rem);
             if ((simple_m >> first) & 1) {
-                const uint32_t fdst = rdlane(d, first);
-                const bool go = ((rem >> lane) & 1) && simple && send <= fdst;
+                const bool go = ((rem >> lane) & 1) && simple && !(deps & rem);
+                const bool long_ = __ballot(go && ml > 8) != 0;   // (uniform: most rounds move matches of <= 8 bytes only)
                 if (go) {
                     const uint32_t* r32 = (const uint32_t*)L.ring;
-                    const uint64_t v0 = lds_rd8_ring(r32, s & RM, RM >> 2), v1 = lds_rd8_ring(r32, (s + 8) & RM, RM >> 2);
+                    const uint64_t v0 = lds_rd8_ring(r32, s & RM, RM >> 2);
+                    uint64_t v1 = 0;
+                    if (long_) v1 = lds_rd8_ring(r32, (s + 8) & RM, RM >> 2);
                     lds_wr_bytes(L.ring, RM, d, v0, min(ml, 8u));
-                    lds_wr_bytes(L.ring, RM, d + 8, v1, ml > 8 ? ml - 8 : 0u);
+                    if (long_) lds_wr_bytes(L.ring, RM, d + 8, v1, ml > 8 ? ml - 8 : 0u);
                 }
                 rem &= ~__ballot(go);
                 wave_sync();
+                LZXT_CNT(7, 1);
                 continue;
             }
             rem &= rem - 1;
+            LZXT_CNT(5, 1);
             const uint32_t fd = rdlane(d, first), fml = rdlane(ml, first), foff = rdlane(off, first);
             const uint32_t fs = fd - foff;
             if (__builtin_expect(fml <= 64 && foff >= fml && !((mixed_m >> first) & 1), 1)) {
@@ -741,7 +839,9 @@ struct LzSeqExec {
                 wave_sync();
             }
         }
+        LZXT(3);
         flush(g_end, false);
+        LZXT(4);
         return total;
     }
     __device__ void finish(uint32_t op) { flush(op + a0, true); }

@@ -355,7 +355,13 @@ __global__ void __launch_bounds__(WG) zb_hdr(ZbPools zp) {
         }
         if (ok && pos >= b.bsize) ok = false;
         b.bits_off = pos;
-        if (!ok) zp.frames[b.frame].punt = 1;
+        if (!ok) {
+            zp.frames[b.frame].punt = 1;
+        } else {   // size classes: zb_seq runs four blocks per wave in lockstep, so they should be about as long as each other
+            const uint32_t cls = b.nseq >= 8192 ? 0u : b.nseq >= 2048 ? 1u : b.nseq >= 512 ? 2u : 3u;
+            const uint32_t at = atomicAdd(&zp.counters[8 + cls], 1u);
+            if (at < zp.block_cap) zp.lists[(size_t)cls * zp.block_cap + at] = i;
+        }
     }
 }
 
@@ -828,11 +834,11 @@ __global__ void __launch_bounds__(64) zb_lit(ZbPools zp) {
 }
 
 // ---------------------------------------------------------------------------------------------------- zb_seq
-// ONE block per wave (all lanes run the same chain; they share the work of the window moves and the table builds): what a
-// call waits for is its longest chain, so every chain should be resident from the start — 13 KB of LDS and <= 168 VGPRs
-// put 12 waves on a CU, 3072 on the chip (four blocks per wave, 50 KB: 768 waves, and the 2048 heavy blocks of the C5
-// batch ran in three rounds)
-constexpr uint32_t ZS_BLOCKS = 1;
+// Four blocks per wave, 16 lanes each (they run the same chain; lane 0 of the 16 stores), taken from zb_hdr's size classes,
+// largest first: a wave's instructions serve four chains of about the same length.  (Four CONSECUTIVE blocks put every
+// heavy block of the C5 batch — 2048 of 12 000 — into a wave of its own: three rounds of 768 resident waves; one block
+// per wave, 3072 resident, made every chain slower: three waves per SIMD share its issue slots.)
+constexpr uint32_t ZS_BLOCKS = 4;
 constexpr uint32_t ZS_WIN = 1024;       // bytes of the bit stream staged per block
 constexpr uint32_t ZS_DESC = 96;        // bytes of a table description staged in LDS
 // A wave issues one instruction every ~4 cycles whatever it is, so the chain is written for INSTRUCTION COUNT: one 8-byte
@@ -851,7 +857,7 @@ struct ZsLds {
     uint16_t next[ZS_BLOCKS][3][64];
     uint32_t log[ZS_BLOCKS][3];      // table log per block and table; 0xFF: could not be built
 };
-static_assert(sizeof(ZsLds) <= 13 * 1024, "zb_seq: twelve waves per CU");
+static_assert(sizeof(ZsLds) <= 53 * 1024, "zb_seq: three waves per CU");
 
 // table t (0 LL, 1 OF, 2 ML) of one block from its description d[0, n) (LDS; mode 1: one symbol, mode 2: FSE) or the
 // predefined distribution (mode 0) -> packed entries; returns the table log or 0xFF
@@ -908,13 +914,24 @@ __device__ inline uint32_t zs_build(uint64_t* tab, int t, uint32_t mode, const u
     return (uint32_t)log;
 }
 
-__global__ void __launch_bounds__(64, 3) zb_seq(ZbPools zp) {
+__global__ void __launch_bounds__(64) zb_seq(ZbPools zp) {
     __shared__ ZsLds L;
-    const uint32_t lane = threadIdx.x, gi = 0, li = lane;
+    const uint32_t lane = threadIdx.x, gi = lane >> 4, li = lane & 15;
     const uint32_t nblocks = min(zp.counters[0], zp.block_cap);
-    const uint32_t ngroups = (nblocks + ZS_BLOCKS - 1) / ZS_BLOCKS;
+    uint32_t ccount[4], gbase[5];
+    gbase[0] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        ccount[c] = min(zp.counters[8 + c], zp.block_cap);
+        gbase[c + 1] = gbase[c] + (ccount[c] + ZS_BLOCKS - 1) / ZS_BLOCKS;
+    }
+    const uint32_t ngroups = gbase[4];
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const uint32_t bi = grp * ZS_BLOCKS + gi;
+        const uint32_t cls = grp >= gbase[3] ? 3u : grp >= gbase[2] ? 2u : grp >= gbase[1] ? 1u : 0u;
+        const uint32_t cb = cls == 3 ? gbase[3] : cls == 2 ? gbase[2] : cls == 1 ? gbase[1] : 0u;
+        const uint32_t cn = cls == 3 ? ccount[3] : cls == 2 ? ccount[2] : cls == 1 ? ccount[1] : ccount[0];
+        const uint32_t at = (grp - cb) * ZS_BLOCKS + gi;
+        const uint32_t bi = at < cn ? zp.lists[(size_t)cls * zp.block_cap + at] : ZB_NONE;
         ZbBlock b;
         b.nseq = 0;
         bool act = false;
@@ -980,7 +997,7 @@ __global__ void __launch_bounds__(64, 3) zb_seq(ZbPools zp) {
                 const int32_t bitpos = bp + 8 * wlo;
                 const int32_t hi_byte = min(sn_, (bitpos >> 3) + 9);
                 const int32_t lo_byte = hi_byte > (int32_t)ZS_WIN ? (hi_byte - (int32_t)ZS_WIN) & ~15 : 0;
-                for (uint32_t k = li * 16; k < ZS_WIN + 48; k += 64 * 16) {
+                for (uint32_t k = li * 16; k < ZS_WIN + 48; k += 16 * 16) {
                     const int32_t o = lo_byte - 8 + (int32_t)k;
                     u32x4 v = u32x4{0, 0, 0, 0};
                     if (o >= 0 && o + 16 <= sn_) {
@@ -1092,6 +1109,18 @@ __global__ void __launch_bounds__(64, 3) zb_seq(ZbPools zp) {
     }
 }
 
+// phase clocks of lane 0 of one wave (development: -DZB_TL; read back by sb_debug_zb_timers)
+#ifdef ZB_TL
+#define ZBT_BEGIN unsigned long long zbt_acc[12] = {0}; unsigned long long zbt_t = __builtin_readcyclecounter();
+#define ZBT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); zbt_acc[i] += n_ - zbt_t; zbt_t = n_; } while (0)
+#define ZBT_CNT(i, v) do { zbt_acc[i] += (v); } while (0)
+#define ZBT_END(cond) do { if ((cond) && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&zp.stats[4 + i_], zbt_acc[i_]); } while (0)
+#else
+#define ZBT_BEGIN
+#define ZBT(i)
+#define ZBT_CNT(i, v)
+#define ZBT_END(cond)
+#endif
 // ---------------------------------------------------------------------------------------------------- zb_exec
 // A pool of waves over the frames: blocks in order.
 __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools zp) {
@@ -1116,6 +1145,7 @@ __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools
         }
         uint8_t* dst = f.dst;
         const uint32_t out_len = f.out_len;
+        ZBT_BEGIN
         uint32_t op = 0, err = 0;
         uint32_t e0 = 1, e1 = 4, e2 = 8;
         LzSeqExec ex(ring, dst);
@@ -1178,6 +1208,7 @@ __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools
                 const Rec r_n2 = load_rec(done + 128);
                 const uint32_t llen = r_cur.ll, mlen = r_cur.ml;
                 if (__ballot(have && (llen >= (1u << 18) || mlen >= (1u << 18)))) { err = 29; break; }
+                ZBT(0);
                 // ---- repeat offsets (RFC 8878 3.1.1.5): what a sequence does to the three of them is a small map — push a new
                 // offset, keep, swap, rotate, push "first minus one" — whose outputs are constants or "entry value i minus d";
                 // an inclusive scan of the batch's maps under composition gives every lane the state after its sequence in
@@ -1203,6 +1234,7 @@ __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools
                         }
                     }
                 }
+                ZBT(1);
                 const uint32_t off = have ? zb_resolve(t0, e0, e1, e2) : 1u;
                 {   // the state after the batch's last sequence
                     const uint32_t l0 = rdlane(t0, nb - 1), l1 = rdlane(t1, nb - 1), l2 = rdlane(t2, nb - 1);
@@ -1216,7 +1248,10 @@ __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools
                 if (__ballot(bad)) { err = 30; break; }
                 const uint32_t lit_total = rdlane(lsum, 63);
                 const uint64_t l8_nxt = load_lit8(lit_pos + lit_total + wave_scan_dpp(r_nxt.ll) - r_nxt.ll, r_nxt.ll);
+                ZBT(2);
+                ZBT_CNT(11, 1);
                 op += ex.run(nb, llen, mlen, off, litp + lit_pos, op, true, l8_cur);
+                ZBT(3);
                 lit_pos += lit_total;
                 r_cur = r_nxt;
                 r_nxt = r_n2;
@@ -1236,6 +1271,8 @@ __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools
             ex.restart(op);
         }
         if (!err && op != out_len) err = 34;
+        ZBT(4);
+        ZBT_END(fi == 1 || fi == 0);
         if (err && lane == 0) raise(st, SB_ERR_EXTERNAL, f.page, 120 + err);
         wave_stores_visible();
     }

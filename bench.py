@@ -256,6 +256,86 @@ def measure_reference_pages(h, cols, sbo_opts, reps=3, check_all=False):
             "written_by": "the restatement with liblz4 %s / libzstd %s (untimed setup)" % (sysc["lz4"], sysc["zstd"])}
 
 
+def run_host_boundary(h, which, ncols=64, reps=3):
+    """The drop-in boundary as the reference's callers see it: HOST Arrow buffers in, host page bytes out (write::write,
+    src/write/serialize.rs:36-49) and host pages in, host Arrow buffers out (read_simple, src/read/batch_read.rs:27-64), through
+    sb_write_columns / sb_read_columns with SB_MEM_HOST.  PCIe-inclusive: never `value`.  which = "c2" (nullable f64, adaptive
+    -> RLE pages) or "c1" (Int64, one page per column, no compression)."""
+    import ctypes as C
+    import torch
+    from strawboat_amd import _native as N
+    from strawboat_amd.types import WriteOptions
+    from strawboat_amd.write import options_c
+    ctx = h.ctx
+    lib, hh = ctx._lib, ctx._h
+    if which == "c2":
+        oc = options_c(WriteOptions(max_page_size=PAGE, default_compress_ratio=2.0))
+        ptype, nullable = W.T_F64, 1
+        gen = gen_parallel(gen_c2_column, [7000 + b for b in range(ncols)])
+    else:
+        from strawboat_amd.types import Compression
+        oc = options_c(WriteOptions(max_page_size=None, force_codec=Compression.NONE))
+        ptype, nullable = W.T_I64, 0
+        rng = np.random.default_rng(7)
+        gen = [(rng.integers(-2**62, 2**62, ROWS), None) for _ in range(ncols)]
+    npg = C.c_uint64()
+    bound = lib.sb_write_bound(ptype, nullable, ROWS, 0, C.byref(oc), C.byref(npg))
+
+    def pinned(n):
+        return torch.zeros(n, dtype=torch.uint8).pin_memory()
+    vals, valids, outs, metas, vouts, bouts = [], [], [], [], [], []
+    for v, m in gen:
+        tv = pinned(ROWS * 8)
+        tv.numpy()[:] = np.ascontiguousarray(v).view(np.uint8)
+        vals.append(tv)
+        if nullable:
+            tb = pinned(m.size)
+            tb.numpy()[:] = m
+            valids.append(tb)
+            bouts.append(pinned((ROWS + 31) // 32 * 4))
+        outs.append(pinned(bound))
+        metas.append((N.PageMetaC * npg.value)())
+        vouts.append(pinned(ROWS * 8))
+    cw = (N.ColumnWriteC * ncols)()
+    for c in range(ncols):
+        cw[c].physical_type, cw[c].is_nullable, cw[c].rows = ptype, nullable, ROWS
+        cw[c].values = vals[c].data_ptr()
+        if nullable:
+            cw[c].validity = valids[c].data_ptr()
+        cw[c].out_pages, cw[c].out_capacity = outs[c].data_ptr(), bound
+        cw[c].out_metas, cw[c].n_pages_capacity = metas[c], npg.value
+    te = td = 1e9
+    for _ in range(reps + 1):
+        t = time.perf_counter()
+        ctx._check(lib.sb_write_columns(hh, cw, ncols, C.byref(oc), N.SB_MEM_HOST))
+        ctx.synchronize()
+        te = min(te, time.perf_counter() - t)
+        cr = (N.ColumnReadC * ncols)()
+        for c in range(ncols):
+            cr[c].physical_type, cr[c].is_nullable = ptype, nullable
+            cr[c].pages, cr[c].pages_len = outs[c].data_ptr(), int(cw[c].out_len)
+            cr[c].metas, cr[c].n_pages = metas[c], int(cw[c].n_pages)
+            cr[c].values, cr[c].values_capacity = vouts[c].data_ptr(), ROWS * 8
+            if nullable:
+                cr[c].validity, cr[c].validity_capacity = bouts[c].data_ptr(), bouts[c].numel()
+        t = time.perf_counter()
+        ctx._check(lib.sb_read_columns(hh, cr, ncols, N.SB_MEM_HOST))
+        ctx.synchronize()
+        td = min(td, time.perf_counter() - t)
+    if nullable:
+        m = np.unpackbits(valids[0].numpy(), bitorder="little")[:ROWS].astype(bool)
+        assert np.array_equal(vouts[0].numpy().view(np.float64)[m], vals[0].numpy().view(np.float64)[m]), "host-boundary round trip failed"
+    else:
+        assert np.array_equal(vouts[0].numpy(), vals[0].numpy()), "host-boundary round trip failed"
+    arrow = ncols * (ROWS * 8 + ((ROWS + 7) // 8 if nullable else 0))
+    pages = sum(int(cw[c].out_len) for c in range(ncols))
+    return {"columns": ncols, "arrow_MB": round(arrow / 1e6, 1), "page_MB": round(pages / 1e6, 1),
+            "encode_GBps": round(arrow / te / 1e9, 1), "decode_GBps": round(arrow / td / 1e9, 1),
+            "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
+            # what crosses the link per direction: Arrow bytes one way, page bytes the other
+            "pcie_GBps_encode": round((arrow + pages) / te / 1e9, 1), "pcie_GBps_decode": round((arrow + pages) / td / 1e9, 1)}
+
+
 def direction_summary(U, pb, ms, kernels, encode):
     """GB/s of Arrow bytes, fraction of the HBM roofline reached by the direction's algorithmic bytes
     (A_enc = Arrow bytes read + page bytes written, A_dec = page bytes read + Arrow bytes written),
@@ -377,6 +457,16 @@ def run_configs(h, only, cpu_on, log):
                                      "codecs": page_codecs(c, r["enc"][0])}
         out["c4"]["per_column_type"] = per
         del named, cols
+    if want("host_boundary"):
+        try:
+            out["host_boundary"] = {"c2": run_host_boundary(h, "c2"), "c1": run_host_boundary(h, "c1"),
+                                    "note": "SB_MEM_HOST: pinned host Arrow buffers <-> pinned host page bytes, wall time of the calls incl. "
+                                            "both PCIe directions; the link is PCIe Gen5 x16, 63 GB/s per direction by spec (never `value`)",
+                                    "pcie_peak_GBps": 63.0}
+            log("host_boundary: c2 %.1f / %.1f GB/s, c1 %.1f / %.1f GB/s" % (out["host_boundary"]["c2"]["encode_GBps"], out["host_boundary"]["c2"]["decode_GBps"],
+                                                                               out["host_boundary"]["c1"]["encode_GBps"], out["host_boundary"]["c1"]["decode_GBps"]))
+        except Exception as e:   # (a bench leg must not take the headline line down)
+            out["host_boundary"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if want("c5"):
         out["c5"] = run_c5(h, cpu_on)
         log("c5: encode %.2f GB/s, decode %.2f GB/s" % (out["c5"]["encode"]["GBps"], out["c5"]["decode"]["GBps"]))
@@ -465,11 +555,50 @@ def run_c5(h, cpu_on, arrays=64):
     pb = sum(e.length for e in encs)
     res = dict(U=U, page_bytes=pb, n_pages=sum(e.n_pages for e in encs), enc_ms=te, dec_ms=td, kernels={})
     cpu = None
-    if cpu_on:   # leaf blocks only (the level arithmetic has no page-parallel CPU leg in the oracle)
+    if cpu_on:   # one array: its two leaf columns' blocks + the level sections of their 2 x 16 pages (write_nested_validity / read_validity_nested)
         from oracle import sbo
         o = sbo.make_options(default_compression=sbo.ZSTD, max_page_size=PAGE)
-        cpu = cpu_baseline([dict(a, nullable=False), dict(b, nullable=False)], o, W.arrow_bytes(a) + W.arrow_bytes(b),
-                           "the two leaf columns of one array as flat non-nullable columns (leaf blocks only, no level sections)")
+        U1c = W.arrow_bytes(a) + W.arrow_bytes(b) + 2 * ((la[0]["length"] + 1) * 4 + (la[0]["length"] + 7) // 8)
+        cpu = cpu_baseline([dict(a, nullable=False), dict(b, nullable=False)], o, U1c,
+                           "one array (1 M rows): the blocks of its two leaf columns + the rep / def level sections of their 2 x 16 pages")
+        rows1 = la[0]["length"]
+        items_l = [(lv_, r0, min(PAGE, rows1 - r0)) for lv_ in (la, lb) for r0 in range(0, rows1, PAGE)]
+        kinds_l = [[lv["kind"] for lv in lv_] for lv_ in (la, lb)]
+        opt_l = [[int(bool(lv["is_optional"])) for lv in lv_] for lv_ in (la, lb)]
+
+        def lv_write(it):
+            return sbo.nested_write_levels(it[0], it[1], it[2])
+
+        def lv_time(threads, rep):
+            work = items_l * rep
+            t0 = time.perf_counter()
+            if threads == 1:
+                written = [lv_write(it) for it in work]
+            else:
+                with ThreadPoolExecutor(max_workers=threads) as ex:
+                    written = list(ex.map(lv_write, work, chunksize=4))
+            tw_ = time.perf_counter() - t0
+            rd = [(w[0], w[1], kinds_l[0 if it[0] is la else 1], opt_l[0 if it[0] is la else 1]) for w, it in zip(written, work)]
+            t0 = time.perf_counter()
+            if threads == 1:
+                for r in rd:
+                    sbo.nested_read_levels(*r)
+            else:
+                with ThreadPoolExecutor(max_workers=threads) as ex:
+                    list(ex.map(lambda r: sbo.nested_read_levels(*r), rd, chunksize=4))
+            return tw_, time.perf_counter() - t0
+        lw1, lr1 = lv_time(1, 1)
+        repl = cpu["all_cores"]["sample_replicas"]
+        lwm, lrm = lv_time(host_cores(), repl)
+        # fold the level times into the leaf times (GB/s of the array's Arrow bytes incl. list offsets / validity)
+        def fold(leg, tw_, tr_, n):
+            te_ = U1c * n / (leg["encode"] * 1e9) + tw_
+            td_ = U1c * n / (leg["decode"] * 1e9) + tr_
+            leg.update(encode=round(U1c * n / te_ / 1e9, 3), decode=round(U1c * n / td_ / 1e9, 3), value=round(2.0 * U1c * n / (te_ + td_) / 1e9, 3),
+                       level_sections_s={"write": round(tw_, 4), "read": round(tr_, 4)})
+        fold(cpu["one_thread"], lw1, lr1, 1)
+        fold(cpu["all_cores"], lwm, lrm, repl)
+        cpu["value"] = cpu["one_thread"]["value"]
     e = config_entry("c5", res, cpu, {"workload": "C5: %d x 1 M-row List<Struct<Int64,Utf8>> (list length U{0,1,2}, 10 %% null lists, leaves 20 %% "
                                                   "null), 64Ki-row pages, Zstd default, ratio None; %d leaf columns x 16 pages through the nested API "
                                                   "(NestedWriteBatch / NestedReadBatch: descriptors and buffers built once; a run = level sections of all "
@@ -748,6 +877,17 @@ def self_launch(n, backend):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def kernel_source_sha():
+    """first 16 hex digits of the sha256 over the encode kernels' sources: a PMC profile is this run's traffic only if it was
+    collected for the same sources (scripts/pmc_traffic.py stamps it)"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("sb_encode.hip", "sb_select_runs.h", "sb_select_rle.h", "sb_select.h", "sb_common.h"):
+        with open(os.path.join(ROOT, "strawboat_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
 def config_summary(configs):
     """one line per configuration (the driver's record keeps `config`, not `configs`): Arrow GB/s and HBM fraction per direction"""
     out = {}
@@ -757,8 +897,19 @@ def config_summary(configs):
         if "encode" in e and "decode" in e:
             out[k] = "enc %.1f GB/s (%.3f of HBM peak), dec %.1f GB/s (%.3f)" % (
                 e["encode"]["GBps"], e["encode"]["frac_hbm"], e["decode"]["GBps"], e["decode"]["frac_hbm"])
+            for rk in ("leaf_pages_reference_written",):
+                if isinstance(e.get(rk), dict) and "decode" in e[rk]:
+                    out[k] += "; pages written by the reference's codec: dec %.1f GB/s" % e[rk]["decode"]["GBps"]
+            if isinstance(e.get("cpu_baseline"), dict):
+                c = e["cpu_baseline"]
+                out[k] += "; CPU 1 thread %.2f, %d threads %.1f GB/s (enc+dec)" % (c["one_thread"]["value"], c["all_cores"]["cores"], c["all_cores"]["value"])
+        elif "decode" in e and "written_by" in e:
+            out[k] = "dec %.1f GB/s (%.3f of HBM peak)" % (e["decode"]["GBps"], e["decode"]["frac_hbm"])
         elif "encdec_GBps" in e:
             out[k] = "enc+dec %.1f GB/s over %d GPU(s), %.3f ms per step" % (e["encdec_GBps"], e.get("n_gpus", 1), e.get("ms_per_step", 0.0))
+        elif k == "host_boundary" and "c2" in e:
+            out[k] = "PCIe-inclusive (SB_MEM_HOST, pinned): C2 enc %.1f / dec %.1f GB/s, C1 enc %.1f / dec %.1f GB/s of Arrow bytes; link peak 63 GB/s" % (
+                e["c2"]["encode_GBps"], e["c2"]["decode_GBps"], e["c1"]["encode_GBps"], e["c1"]["decode_GBps"])
         elif "error" in e:
             out[k] = "error: %s" % e["error"]
         else:
@@ -946,10 +1097,15 @@ def main():
         kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / v[0], 4)} for k, v in stats.items()}
         # HBM traffic of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate passes of this same command; summary committed under profiles/)
-        for pf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        src_sha = kernel_source_sha()
+        for pf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 pc = pmc["config"]
+                if pmc.get("kernel_source_sha16") != src_sha:   # the counters belong to another version of the kernel: not this run's traffic
+                    if roof:
+                        roof["traffic_stale"] = "profiles/%s was collected for kernel sources %s, this build is %s" % (pf, pmc.get("kernel_source_sha16"), src_sha)
+                    continue
                 if roof and str(pc.get("workload", "")).lower().startswith("c2") and pc.get("columns_per_gpu", B) == B \
                         and pc.get("codec", args.codec) == args.codec:
                     cand = [rec["hbm_bytes_per_launch"] for name, rec in pmc["kernels"].items() if name.split("<")[0].startswith(dom.split("<")[0])]
@@ -977,21 +1133,36 @@ def main():
             del wbatch, rbatch, enc, dec, pages, cols
             torch.cuda.empty_cache()
             configs = run_configs(harness, None, not args.no_cpu_baseline, log)
+        summ = config_summary(configs)
+        north = None
+        c1e = (configs or {}).get("c1")
+        if isinstance(c1e, dict) and "decode" in c1e:   # BASELINE.json north_star: >= 40 % of HBM peak on 1 M-row primitive-page decode
+            dk = c1e["decode"]
+            A1 = (c1e["arrow_MB"] + c1e["page_MB"]) * 1e6
+            kms = dk["kernels_ms"].get("k_expand")
+            north = {"config": "C1 (128 x 1 M-row Int64 pages, one page per column, no compression)", "target_frac": 0.40,
+                     "frac_end_to_end": dk["frac_hbm"], "decode_ms": dk["ms"],
+                     "frac_kernel": round(A1 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms else None, "kernel": "k_expand", "kernel_ms": kms}
+        cfg = {"workload": "C2: %d x 1M-row nullable Float64 columns per GPU, 64Ki-row pages, codec %s, "
+                           "inputs resident in HBM" % (B, args.codec),
+               "columns_per_gpu": B, "rows_per_column": ROWS, "page_rows": PAGE,
+               "arrow_bytes_per_step": U, "page_bytes_per_step": page_bytes,
+               "parallelism": "pages of independent columns sharded across %d GPU(s)" % world,
+               "note": "C2 is the most compressible configuration (RLE, 16x); the keys below are one line per other configuration "
+                       "(GB/s of Arrow bytes, fraction of the 8 TB/s HBM peak reached by the direction's algorithmic bytes)"}
+        for k, v in summ.items():   # flat, string-valued: the driver's record keeps `config`
+            cfg[k.replace(".", "_")] = v
         out = {
             "metric": METRIC,
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 bit patterns (integer/bit work, no arithmetic)",
             "data": "synthetic",
-            "config": {"workload": "C2: %d x 1M-row nullable Float64 columns per GPU, 64Ki-row pages, codec %s, "
-                                   "inputs resident in HBM" % (B, args.codec),
-                       "columns_per_gpu": B, "rows_per_column": ROWS, "page_rows": PAGE,
-                       "arrow_bytes_per_step": U, "page_bytes_per_step": page_bytes,
-                       "parallelism": "pages of independent columns sharded across %d GPU(s)" % world,
-                       "note": "C2 is the most compressible configuration (RLE, 16x): see `configs` / `summary` for the others",
-                       "summary": config_summary(configs)},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "configs": configs,
+            "config": cfg,
+            "roofline": roof, "north_star_decode": north, "cpu_baseline": cpu, "kernels": kernels, "configs": configs,
         }
+        # the line is long (every configuration with its kernels): the short keys go LAST so that a tail of the output holds them
+        out["summary"] = summ
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -4,7 +4,7 @@
 # Usage (on the GPU box, from the repo root): scripts/profile_round.sh r03 ; then, per configuration,
 #   python scripts/summarize_rocpd.py gpurun_out/prof_r03 r03 <cfg> '<config json>'
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -29,5 +29,16 @@ for cfg in c2 c1 c3 c4 c5; do
     python $R/scripts/summarize_rocpd.py $OUT $TAG $cfg "{\"workload\": \"$cfg (bench.py, see profiles/${TAG}_${cfg}_stdout.txt)\"}" > $OUT/${cfg}_summary.txt 2>&1
     cp $OUT/${cfg}_stdout.txt $R/profiles/${TAG}_${cfg}_stdout.txt 2>/dev/null
 done
+cp $R/profiles/${TAG}_c2_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json 2>/dev/null   # (bench.py's roofline.traffic: the headline's counters)
+python - <<PYEOF
+import json
+p = "$R/profiles/${TAG}_pmc_traffic.json"
+try:
+    d = json.load(open(p))
+    d["config"].update(workload="c2 (bench.py default run)", columns_per_gpu=512, codec="adaptive")
+    json.dump(d, open(p, "w"), indent=1)
+except OSError:
+    pass
+PYEOF
 mkdir -p $R/gpurun_out/profiles_$TAG && cp $R/profiles/${TAG}_* $R/gpurun_out/profiles_$TAG/ 2>/dev/null
 ls -la $R/gpurun_out/profiles_$TAG

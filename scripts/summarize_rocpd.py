@@ -50,7 +50,10 @@ kern = {}
 for k, v in sorted(res.items()):
     fsz, wsz = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
     kern[k] = {"fetch_size_kb_raw": round(fsz, 1), "write_size_kb_raw": round(wsz, 1), "hbm_bytes_per_launch": int((2 * fsz + wsz) * 1024)}
-json.dump({"config": cfg_desc, "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3 --pmc, separate passes)",
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench  # noqa: E402  (kernel_source_sha: bench.py reports this file's traffic only for the sources it was collected for)
+json.dump({"config": cfg_desc, "kernel_source_sha16": _bench.kernel_source_sha(),
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3 --pmc, separate passes)",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half for wide coalesced streams)",
            "kernels": kern}, open(os.path.join(out_dir, "%s_%s_pmc_traffic.json" % (tag, cfg)), "w"), indent=1)
 top = sorted(kern.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:6]

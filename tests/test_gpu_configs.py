@@ -122,7 +122,7 @@ def test_c3_default_encoder(gpu_ctx):
     default_encoder_parity(gpu_ctx, col, 1.35, max_page_size=65536, default_compression=S.LZ4)
 
 
-@pytest.mark.parametrize("name", ["int32_0", "float64_0", "utf8_0", "boolean_0"])
+@pytest.mark.parametrize("name", ["int32_0", "int32_1", "float64_0", "float64_1", "utf8_0", "utf8_1", "boolean_0", "boolean_1"])
 def test_c4_default_encoder_at_the_size_baseline_states(gpu_ctx, name):
     """every C4 column type at 10 M rows with the default encoder (Boolean pages are LZ4 blocks of incompressible bitmaps)"""
     col = dict(workloads.c4_columns(10_000_000))[name]
@@ -158,7 +158,7 @@ def test_c4_mixed_schema_shard(gpu_ctx, kind):
                                           forbidden=NOT_ON_DEVICE)
 
 
-@pytest.mark.parametrize("name", ["int32_0", "float64_0", "utf8_0", "boolean_0"])
+@pytest.mark.parametrize("name", ["int32_0", "int32_1", "float64_0", "float64_1", "utf8_0", "utf8_1", "boolean_0", "boolean_1"])
 def test_c4_at_the_size_baseline_states(gpu_ctx, name):
     """C4 as BASELINE.json states it: 10 M rows per column = 153 pages, the last one of 38 528 rows (= 301 x 128: its
     Dict indices bit-pack, unlike the 16 960-row tail of a 1 M-row column) — the columns bench.py's `c4` entry times,
@@ -192,3 +192,29 @@ def test_c5_nested_list_struct_zstd_file(gpu_ctx, tmp_path):
         assert [len(m.pages) for m in w.metas] == [16, 16]          # 2 leaf columns x 16 pages
     got = F.read_table(gpu_ctx, path)
     assert got.column("ls").combine_chunks().equals(t.column("ls").combine_chunks())
+
+
+def test_c5_level_sections_match_oracle_full_size(gpu_ctx):
+    """C5 at the size BASELINE.json states (1 M top-level rows, 64 Ki-row pages, ~1.1 M level entries per leaf): the rep / def
+    level section of every page of both leaf columns, byte for byte against the oracle's write_nested_validity
+    (src/write/serialize.rs:217-232) — a round trip alone would accept a section that is self-consistently wrong"""
+    import torch
+    from strawboat_amd import nested
+    la, a, lb, b = workloads.c5_nested()
+    rows = la[0]["length"]
+
+    def up(x):
+        return None if x is None else torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).to(gpu_ctx.torch_device)
+    for levels in (la, lb):
+        dl = [nested.NestedLevel(lv["kind"], bool(lv["is_optional"]), lv["length"], up(lv.get("validity")), up(lv.get("offsets"))) for lv in levels]
+        got = nested.write_levels(gpu_ctx, dl, rows, 65536)
+        sec = got.sections.cpu().numpy()
+        assert got.n_pages == 16
+        off = 0
+        for p, r0 in enumerate(range(0, rows, 65536)):
+            ln = min(65536, rows - r0)
+            want, nv, ls, lc = S.nested_write_levels(levels, r0, ln)
+            assert (int(got.num_values[p]), int(got.leaf_start[p]), int(got.leaf_count[p])) == (nv, ls, lc), p
+            assert int(got.level_bytes[p]) == len(want), p
+            assert bytes(sec[off:off + len(want)]) == bytes(want), "level section of page %d differs" % p
+            off += len(want)

@@ -478,6 +478,10 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     off = align_up(off + job_cap * sizeof(InflateJob), 64);
     const size_t o_jobs_b = off;
     off = align_up(off + job_cap * sizeof(InflateJob), 64);
+    // queue Z (calls with binary columns that produce values): Zstd payloads known to k_parse, entropy stages with queue A's
+    const bool want_z = any_binary && !sizes_only;
+    const size_t o_jobs_z = off;
+    if (want_z) off = align_up(off + job_cap * sizeof(InflateJob), 64);
     const size_t o_counts = off;
     off = align_up(off + 64, 64);
     const size_t o_vlen = off;
@@ -603,6 +607,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     a.status = ctx->d_status;
     a.jobs_a = (InflateJob*)(tb + o_jobs_a);
     a.jobs_b = (InflateJob*)(tb + o_jobs_b);
+    a.jobs_z = want_z ? (InflateJob*)(tb + o_jobs_z) : nullptr;
     a.job_counts = (uint32_t*)(tb + o_counts);
     a.n_pages = (uint32_t)P;
     a.n_cols = (uint32_t)n;

@@ -95,9 +95,10 @@ struct InflateJob {
     uint8_t* dst;
     uint32_t csize;
     uint32_t out_len;
-    uint32_t codec;
+    uint32_t codec;     // codec id | JOB_REL
     uint32_t page;
 };
+constexpr uint32_t JOB_REL = 0x100;   // dst is a byte offset from the page's value base (cols[col].values + descs[page].val_base)
 
 // one Freq page (integer/freq.rs:90-127), logged by k_parse: its exceptions block is an ordinary
 // BLOCK<T> that a second decode pass expands, then k_freq_scatter puts the values in place
@@ -137,6 +138,8 @@ struct ZbFrame {
     uint32_t page;
     uint32_t punt;          // != 0: the one-wave decoder takes the frame
     uint32_t avail;         // bytes of the queue entry's buffer (loads never reach beyond it)
+    uint32_t queue;         // 0: queue A, 1: queue Z (executed after k_colscan)
+    uint32_t rel;           // dst is relative to the page's value base (JOB_REL)
     const uint8_t* base;    // the queue entry's buffer
 };
 struct ZbPools {
@@ -166,7 +169,13 @@ struct DecodeArgs {
     Status* status;
     InflateJob* jobs_a;  // capacity job_cap_a
     InflateJob* jobs_b;  // capacity job_cap_b
-    uint32_t* job_counts;  // [0] = queue A, [1] = queue B, [2] tiles, [3] planned pages, [4] page-level RLE, [5] / [6] workgroups of k_parse / k_colscan that are done
+    // queue Z (calls with binary columns): the Zstd payloads nothing in the planning steps waits for — Basic pages of
+    // primitives (absolute dst) and the VALUE blocks of Basic binary pages, whose place in the column's values buffer is only
+    // known after k_colscan (JOB_REL: dst is an offset from the page's value base).  k_parse fills it, so the block-parallel
+    // Zstd pipeline runs its entropy stages for queue A and queue Z in ONE pass, before k_plan; the frames of queue Z are
+    // executed after k_colscan.  null: no such queue in this call.
+    InflateJob* jobs_z;
+    uint32_t* job_counts;  // [0] = queue A, [1] = queue B, [2] tiles, [3] planned pages, [4] page-level RLE, [5] / [6] workgroups of k_parse / k_colscan that are done, [8] / [9] / [11] lengths of A / B / Z when complete, [10] = queue Z
     uint8_t* zlit;         // Zstd literal buffers, one per inflate wave
     uint64_t* zrec;        // Zstd sequence records, one arena per inflate wave (k_inflate's lane-per-frame pre-decode)
     uint32_t n_pages;

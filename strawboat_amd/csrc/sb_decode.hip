@@ -30,6 +30,16 @@ __device__ __forceinline__ bool is_basic(uint32_t c) { return c <= 3; }
 __device__ __forceinline__ bool is_binary(int32_t t) { return t == SB_TYPE_BINARY || t == SB_TYPE_LARGE_BINARY; }
 
 __device__ __forceinline__ void push_job(InflateJob* q, uint32_t* cnt, const uint8_t* src, uint32_t csize,
+                                         uint8_t* dst, uint32_t out_len, uint32_t codec, uint32_t page);
+// a Basic payload that no planning step reads: queue A when the call has no binary column (there is no later phase), else
+// queue Z (Zstd: its entropy stages run with queue A's) or queue B (the other codecs, inflated next to the binary value blocks)
+__device__ __forceinline__ void push_payload(const DecodeArgs& a, const uint8_t* src, uint32_t csize, uint8_t* dst, uint32_t out_len,
+                                             uint32_t codec, uint32_t page) {
+    if (!a.defer_payloads) push_job(a.jobs_a, a.job_counts, src, csize, dst, out_len, codec, page);
+    else if (codec == SB_CODEC_ZSTD && a.jobs_z) push_job(a.jobs_z, a.job_counts + 10, src, csize, dst, out_len, codec, page);
+    else push_job(a.jobs_b, a.job_counts + 1, src, csize, dst, out_len, codec, page);
+}
+__device__ __forceinline__ void push_job(InflateJob* q, uint32_t* cnt, const uint8_t* src, uint32_t csize,
                                          uint8_t* dst, uint32_t out_len, uint32_t codec, uint32_t page) {
     uint32_t i = atomicAdd(cnt, 1u);
     InflateJob j;
@@ -89,7 +99,7 @@ __global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt,
     if (j >= n0 || j >= cap) return;
     {
         const InflateJob job = q[j];
-        if (job.codec != SB_CODEC_ZSTD) return;
+        if ((job.codec & ~JOB_REL) != SB_CODEC_ZSTD) return;
         if (!(st->kinds & KIND_ZSTD)) atomicOr(&st->kinds, KIND_ZSTD);   // (the host sizes the block pipeline's pools for later calls)
         uint32_t nf = 0, pos = 0, total = 0;
         bool ok = true;
@@ -237,8 +247,7 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
         } else if (is_basic(codec)) {
             // (payloads that no planning step reads are inflated in queue B when it runs, next to the value blocks of the
             // binary columns, instead of in front of them: the phases of a call are serial, their jobs are not)
-            if (!a.sizes_only)
-                push_job(a.defer_payloads ? a.jobs_b : a.jobs_a, a.job_counts + (a.defer_payloads ? 1 : 0), d.body, d.csize, infl, (uint32_t)nbytes, codec, p);
+            if (!a.sizes_only) push_payload(a, d.body, d.csize, infl, (uint32_t)nbytes, codec, p);
             d.src = infl;
         } else if (codec == SB_CODEC_ONEVALUE) {
             if (d.csize < 1) FAIL(SB_ERR_OUT_OF_SPEC, 12);
@@ -264,6 +273,9 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
             if ((uint64_t)(end - d.vbody) < d.vcsize) FAIL(SB_ERR_IO, 16);
             if (codec == SB_CODEC_NONE && d.vcsize != d.vusize) FAIL(SB_ERR_OUT_OF_SPEC, 17);
             d.val_bytes = d.vusize;
+            // a Zstd value block is queued HERE (queue Z, dst relative to the page's value base: k_colscan places the page)
+            if (codec == SB_CODEC_ZSTD && a.jobs_z && !a.sizes_only)
+                push_job(a.jobs_z, a.job_counts + 10, d.vbody, d.vcsize, nullptr, d.vusize, SB_CODEC_ZSTD | JOB_REL, p);
         } else if (codec == SB_CODEC_ONEVALUE) {  // u32 len | bytes  (binary/one_value.rs:70-97)
             if (d.csize < 4) FAIL(SB_ERR_IO, 18);
             d.dict_n = ldu32(d.body);
@@ -299,9 +311,7 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
             if (d.csize != N * w) FAIL(SB_ERR_OUT_OF_SPEC, 21);
         } else if (is_basic(codec)) {
             // inflate straight into the column's values buffer (integer/mod.rs:97-107)
-            if (!a.sizes_only)
-                push_job(a.defer_payloads ? a.jobs_b : a.jobs_a, a.job_counts + (a.defer_payloads ? 1 : 0), d.body, d.csize,
-                         c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
+            if (!a.sizes_only) push_payload(a, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
             d.src = nullptr;  // nothing left for expand
         } else if (codec == SB_CODEC_ONEVALUE) {
             if (d.csize < w) FAIL(SB_ERR_IO, 22);
@@ -312,9 +322,7 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
         } else if (codec == SB_CODEC_PATAS) {
             if (c.ptype == SB_TYPE_FLOAT32) FAIL(SB_ERR_NYI, 26);   // f32 Patas decode is broken upstream
             if (c.ptype != SB_TYPE_FLOAT64) FAIL(SB_ERR_OUT_OF_SPEC, 27);  // "Unknown compression codec Patas for integer"
-            if (!a.sizes_only)
-                push_job(a.defer_payloads ? a.jobs_b : a.jobs_a, a.job_counts + (a.defer_payloads ? 1 : 0), d.body, d.csize,
-                         c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
+            if (!a.sizes_only) push_payload(a, d.body, d.csize, c.values + t.out_row * w, (uint32_t)(N * w), codec, p);
             d.src = nullptr;
         } else if (codec == SB_CODEC_FREQ) {  // top[w] | u32 rb_size | roaring | BLOCK<T exceptions>  (freq.rs:71-83)
             if (a.no_freq) FAIL(SB_ERR_OUT_OF_SPEC, 28);
@@ -494,8 +502,10 @@ __global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < a.n_pages) parse_page(a, p);
     // queue A is complete when the last workgroup is done: its length goes to job_counts[8] for k_zstd_split
-    if (last_workgroup_done(&a.job_counts[5]) && threadIdx.x == 0)
+    if (last_workgroup_done(&a.job_counts[5]) && threadIdx.x == 0) {
         a.job_counts[8] = __hip_atomic_load(&a.job_counts[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.job_counts[11] = __hip_atomic_load(&a.job_counts[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (queue Z is complete too)
+    }
 }
 
 // -------------------------------------------------------------------------------- inflate (LZ4)
@@ -740,8 +750,14 @@ __device__ void patas_inflate_wave(const InflateJob& j, Status* st, uint8_t* s_w
 }
 
 // One job of queue entries that k_inflate owns (all lanes, uniform arguments).  recs: the frame's pre-decoded sequences or null.
-__device__ __forceinline__ void inflate_one(const InflateJob& j, Status* st, ZWork& wk, uint8_t* zlit, uint8_t* s_win, uint16_t* s_pos,
-                                            const uint64_t* recs) {
+__device__ __forceinline__ void inflate_one(const InflateJob& j0, Status* st, ZWork& wk, uint8_t* zlit, uint8_t* s_win, uint16_t* s_pos,
+                                            const uint64_t* recs, const RelCtx& rc) {
+    InflateJob j = j0;
+    if (j.codec & JOB_REL) {   // (queue Z: the page's place in the values buffer is known since k_colscan)
+        j.dst = job_dst(rc, j.dst, j.page, true);
+        j.codec &= ~JOB_REL;
+        if (!j.dst) return;    // the page's values do not fit the caller's buffer: not expanded
+    }
     if (j.codec == SB_CODEC_LZ4 || j.codec == CODEC_SPLIT || j.codec == CODEC_ZB) {
         // k_inflate_lz4 owns the LZ4 blocks; a split Zstd buffer is decoded through its frames' entries; the block pipeline
         // (sb_zstd_blocks.h) has decoded the frames it took
@@ -767,7 +783,7 @@ union InflateLds {   // the one-wave decoder's workspace and the lane-per-stream
     ZHufLanes hl;
 };
 __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st,
-                                                uint8_t* zlit, uint64_t* zrec) {
+                                                uint8_t* zlit, uint64_t* zrec, RelCtx rc) {
     __shared__ InflateLds u;
     ZWork& wk = u.wk;
     __shared__ ZLaneTabs zt;
@@ -792,7 +808,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
     }
     __syncthreads();
     if (B == 1) {
-        for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) inflate_one(jobs[job], st, wk, my_lit, s_win, s_pos, nullptr);
+        for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) inflate_one(jobs[job], st, wk, my_lit, s_win, s_pos, nullptr, rc);
         return;
     }
     uint64_t* arena = zrec ? zrec + (uint64_t)blockIdx.x * ZREC_PER_WAVE : nullptr;
@@ -804,7 +820,13 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
         mine.src = nullptr;
         mine.dst = nullptr;
         mine.csize = mine.out_len = 0;
-        if (lane < nb) mine = jobs[base + lane];
+        if (lane < nb) {
+            mine = jobs[base + lane];
+            if (mine.codec & JOB_REL) {
+                mine.dst = job_dst(rc, mine.dst, mine.page, true);
+                mine.codec = mine.dst ? (mine.codec & ~JOB_REL) : CODEC_SPLIT;
+            }
+        }
         const bool zs = lane < nb && mine.codec == SB_CODEC_ZSTD;
         // ---- phase H: literals-only frames, 16 at a time, lane per stream (sb_zstd.h)
         ZHufFrame hf;
@@ -903,7 +925,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
                 if ((done_m >> k) & 1) continue;   // decoded in phase H
                 const uint32_t k_ok = (uint32_t)__builtin_amdgcn_readlane((int)(ok ? 1u : 0u), (int)k);
                 const uint32_t k_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)k);
-                inflate_one(jobs[base + k], st, wk, my_lit, s_win, s_pos, k_ok ? arena + k_off : nullptr);
+                inflate_one(jobs[base + k], st, wk, my_lit, s_win, s_pos, k_ok ? arena + k_off : nullptr, rc);
             }
             ITL(6);
             start = end;
@@ -1661,7 +1683,7 @@ __device__ __forceinline__ void colscan_column(const DecodeArgs& a, uint64_t* co
         if (!fits) d.ok = 0;
         a.descs[p] = d;
         if (!was_ok) continue;
-        if (fits && is_basic(d.codec) && d.codec != SB_CODEC_NONE)
+        if (fits && is_basic(d.codec) && d.codec != SB_CODEC_NONE && !(d.codec == SB_CODEC_ZSTD && a.jobs_z))
             push_job(a.jobs_b, a.job_counts + 1, d.vbody, d.vcsize, c.values + vbase, d.vusize, d.codec, p);
         vbase += d.val_bytes;
         obase += d.off_last;
@@ -2281,33 +2303,45 @@ void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, cons
     if (n) k_freq_scatter<<<n, WG, 0, ctx->stream>>>(entries, ex_off, ex_base, ctx->d_status);
 }
 
-// The block-parallel Zstd pipeline over one job queue (launched when the context has met Zstd pages: a.zb.blocks != null).
-// Frames it takes are marked CODEC_ZB; k_inflate, launched after it, decodes the rest (and the frames handed back).
-static void launch_zb(sb_ctx* ctx, const DecodeArgs& a, InflateJob* jobs, const uint32_t* count, const char* tag) {
+// The block-parallel Zstd pipeline (launched when the context has met Zstd pages: a.zb.blocks != null).  Entropy stages
+// for the frames of queue A and — calls with binary columns — of queue Z in one pass; the frames of queue A are executed
+// right away, those of queue Z after k_colscan (launch_zb_exec).  Frames the pipeline takes are marked CODEC_ZB; k_inflate,
+// launched after it, decodes the rest (and the frames handed back).
+static RelCtx rel_ctx(const DecodeArgs& a) {
+    RelCtx rc;
+    rc.cols = a.cols;
+    rc.tasks = a.tasks;
+    rc.descs = a.descs;
+    return rc;
+}
+static void launch_zb_exec(sb_ctx* ctx, const DecodeArgs& a, uint32_t queue) {
+    if (!a.zb.blocks) return;
+    KScope k(ctx, queue == 0 ? "zb_exec" : "zb_exec(values)");
+    zb_exec<<<std::min<uint32_t>(a.zb.frame_cap, 4096u), 64, 0, ctx->stream>>>(queue == 0 ? a.jobs_a : a.jobs_z, a.status, a.zb, queue, rel_ctx(a));
+}
+static void launch_zb(sb_ctx* ctx, const DecodeArgs& a) {
     if (!a.zb.blocks) return;
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.zb.counters, 0, 16 * sizeof(uint32_t), s);
     {
-        KScope k(ctx, tag[0] == 'a' ? "zb_scan" : "zb_scan(values)");
-        zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(jobs, count, a.zb);
+        KScope k(ctx, "zb_scan");
+        zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(a.jobs_a, a.job_counts, a.zb, 0u);
+        if (a.jobs_z) zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(a.jobs_z, a.job_counts + 10, a.zb, 1u);
         zb_hdr<<<std::min<uint32_t>((a.zb.block_cap + WG - 1) / WG, 1024u), WG, 0, s>>>(a.zb);
     }
     // literals and sequences of a block are independent of each other (different pools): side by side on two streams
     const bool multi = !ctx->profile && side_streams(ctx);
     if (multi) side_fork(ctx, 1u);
     {
-        KScope k(ctx, tag[0] == 'a' ? "zb_lit" : "zb_lit(values)");
+        KScope k(ctx, "zb_lit");
         zb_lit<<<std::min<uint32_t>((a.zb.block_cap + ZL_BLOCKS - 1) / ZL_BLOCKS, 768u), 64, 0, s>>>(a.zb);
     }
     {
-        KScope k(ctx, tag[0] == 'a' ? "zb_seq" : "zb_seq(values)");
+        KScope k(ctx, "zb_seq");
         zb_seq<<<std::min<uint32_t>((a.zb.block_cap + ZS_BLOCKS - 1) / ZS_BLOCKS + 4, 768u), 64, 0, multi ? ctx->side[0] : s>>>(a.zb);
     }
     if (multi) side_join(ctx, 1u);
-    {
-        KScope k(ctx, tag[0] == 'a' ? "zb_exec" : "zb_exec(values)");
-        zb_exec<<<std::min<uint32_t>(a.zb.frame_cap, 4096u), 64, 0, s>>>(jobs, a.status, a.zb);
-    }
+    launch_zb_exec(ctx, a, 0u);
 }
 
 #ifdef ZB_TL
@@ -2321,11 +2355,12 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
         k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, a.status);
+        if (a.jobs_z) k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_z, a.job_counts + 10, a.job_counts + 11, a.job_cap_a, a.status);
     }
-    launch_zb(ctx, a, a.jobs_a, a.job_counts, "a");
+    launch_zb(ctx, a);
     {
         KScope k(ctx, K_INFLATE_A);
-        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
+        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a));
     }
     {
         KScope k(ctx, "k_inflate_lz4");
@@ -2344,10 +2379,14 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
         k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.job_counts + 9, a.job_cap_b, a.status);
     }
-    if (any_binary) launch_zb(ctx, a, a.jobs_b, a.job_counts + 1, "b");
+    if (a.jobs_z) {   // queue Z: the frames the pipeline took are executed now that every page has its place; the rest by k_inflate
+        launch_zb_exec(ctx, a, 1u);
+        KScope k(ctx, "k_inflate(zstd values)");
+        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_z, a.job_counts + 10, a.status, a.zlit, a.zrec, rel_ctx(a));
+    }
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
-        k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec);
+        k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec, rel_ctx(a));
         KScope k2(ctx, "k_inflate_lz4(values)");
         k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min);
     }
@@ -2380,8 +2419,8 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, a.status);
-    launch_zb(ctx, a, a.jobs_a, a.job_counts, "a");
-    k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec);
+    launch_zb(ctx, a);
+    k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a));
     k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);

@@ -106,11 +106,11 @@ __device__ inline bool zb_lit_header(const uint8_t* bs, uint32_t n, uint32_t* lt
 // ---------------------------------------------------------------------------------------------------- zb_scan
 // One thread per queue entry.  An entry is taken when it is exactly one frame (no dictionary, content size — if the header
 // has one — equal to the entry's output) whose blocks are well-formed as far as their headers go, and the pools have room.
-__global__ void __launch_bounds__(WG) zb_scan(InflateJob* q, const uint32_t* count, ZbPools zp) {
+__global__ void __launch_bounds__(WG) zb_scan(InflateJob* q, const uint32_t* count, ZbPools zp, uint32_t queue) {
     const uint32_t njobs = *count;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < njobs; j += gridDim.x * blockDim.x) {
         const InflateJob job = q[j];
-        if (job.codec != SB_CODEC_ZSTD || job.csize < zp.min_csize) continue;
+        if ((job.codec & ~JOB_REL) != SB_CODEC_ZSTD || job.csize < zp.min_csize) continue;
         const uint8_t* src = job.src;
         const uint32_t n = job.csize;
         if (n < 9 || ldu32(src) != 0xFD2FB528u) continue;
@@ -269,8 +269,10 @@ __global__ void __launch_bounds__(WG) zb_scan(InflateJob* q, const uint32_t* cou
         fr.punt = bad ? 1u : 0u;
         fr.avail = n;
         fr.base = src;
+        fr.queue = queue;
+        fr.rel = (job.codec & JOB_REL) ? 1u : 0u;
         zp.frames[f] = fr;
-        q[j].codec = CODEC_ZB;   // (zb_exec restores it for a punted frame)
+        q[j].codec = CODEC_ZB | (job.codec & JOB_REL);   // (zb_exec restores it for a punted frame)
     }
 }
 
@@ -1123,19 +1125,35 @@ __global__ void __launch_bounds__(64) zb_seq(ZbPools zp) {
 #endif
 // ---------------------------------------------------------------------------------------------------- zb_exec
 // A pool of waves over the frames: blocks in order.
-__global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools zp) {
+// where a queue entry's output goes: absolute, or (JOB_REL) relative to the page's value base, known after k_colscan;
+// null: the page does not take part (its values do not fit the caller's buffer)
+struct RelCtx {
+    const ColDesc* cols;
+    const PageTask* tasks;
+    const PageDesc* descs;
+};
+__device__ __forceinline__ uint8_t* job_dst(const RelCtx& rc, uint8_t* dst, uint32_t page, bool rel) {
+    if (!rel) return dst;
+    const PageDesc& d = rc.descs[page];
+    if (!d.ok) return nullptr;
+    return rc.cols[rc.tasks[page].col].values + d.val_base + (uintptr_t)dst;
+}
+__global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools zp, uint32_t queue, RelCtx rc) {
     __shared__ LzSeqLds ring;
     const uint32_t lane = threadIdx.x;
     const uint32_t nframes = min(zp.counters[1], zp.frame_cap);
     for (uint32_t fi = blockIdx.x; fi < nframes; fi += gridDim.x) {
         const ZbFrame f = zp.frames[fi];
+        if (f.queue != queue) continue;
         if (f.punt) {
             if (lane == 0) {
-                q[f.job].codec = SB_CODEC_ZSTD;
+                q[f.job].codec = SB_CODEC_ZSTD | (f.rel ? JOB_REL : 0u);
                 atomicAdd(&zp.stats[1], 1ull);
             }
             continue;
         }
+        uint8_t* const fdst = job_dst(rc, f.dst, f.page, f.rel != 0);
+        if (!fdst) continue;
         if (lane == 0) {
             unsigned long long ns = 0;
             for (uint32_t k = 0; k < f.nblocks; k++) ns += zp.blocks[f.first + k].nseq;
@@ -1143,7 +1161,7 @@ __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools
             atomicAdd(&zp.stats[2], (unsigned long long)f.nblocks);
             atomicAdd(&zp.stats[3], ns);
         }
-        uint8_t* dst = f.dst;
+        uint8_t* dst = fdst;
         const uint32_t out_len = f.out_len;
         ZBT_BEGIN
         uint32_t op = 0, err = 0;

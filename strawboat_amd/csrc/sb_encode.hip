@@ -5203,8 +5203,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
 
     // ---- plan cache: everything below that depends only on the shape of the call (sb_ctx::EncPlan)
     uint64_t plan_key = 0xcbf29ce484222325ull;
+    std::vector<uint64_t>& key_words = ctx->enc_plan_probe;   // every word that goes into the hash: a hit compares them all
+    key_words.clear();
     {
-        auto mixk = [&](uint64_t v) { plan_key = (plan_key ^ v) * 0x100000001b3ull; plan_key ^= plan_key >> 29; };
+        auto mixk = [&](uint64_t v) {
+            plan_key = (plan_key ^ v) * 0x100000001b3ull;
+            plan_key ^= plan_key >> 29;
+            key_words.push_back(v);
+        };
         mixk(n); mixk((uint64_t)mem);
         mixk((uint64_t)opts->default_compression); mixk((uint64_t)opts->has_default_compress_ratio); mixk(opts->max_page_size);
         mixk(opts->forbidden_compressions); mixk((uint64_t)(int64_t)opts->force_codec); mixk((uint64_t)(int64_t)opts->force_index_codec);
@@ -5221,7 +5227,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
     }
     sb_ctx::EncPlan& plan = ctx->enc_plan;
-    bool hit = plan.valid && plan.key == plan_key && plan.n == n;
+    // (a 64-bit hash is not proof of an identical shape: a collision would reuse page offsets and row counts of another
+    // call and write outside the scratch and output areas)
+    bool hit = plan.valid && plan.key == plan_key && plan.n == n && plan.key_words == key_words;
     if (hit) {   // (a second, independent look at the shape: the page count per column)
         for (uint64_t i = 0; i < n && hit; i++) {
             const uint64_t ps = page_size_of(cols[i].rows, opts);
@@ -5553,6 +5561,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         e = hipMemcpyAsync(plan.pages.p, hp, P * sizeof(EncPage), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return check_hip(ctx, e, "page table upload");
         plan.key = plan_key;
+        plan.key_words = key_words;
         plan.n = n;
         plan.P = P;
         plan.max_tiles = max_tiles;

@@ -141,10 +141,12 @@ struct sb_ctx {
         uint64_t P = 0, max_tiles = 1, max_chunks = 1, lz_cap = 0;
         bool any_tiles = false, any_pages = false, any_compact = false, any_lz4 = false;
         size_t scratch_total = 0, lz_pool_off = 0, zpar_off = 0;
+        std::vector<uint64_t> key_words;   // the words the key was hashed from (compared on a hit)
         std::vector<uint32_t> col_first, col_pages;
         std::vector<uint64_t> hro;
         sb::DevBuf pages;   // EncPage[P] on the device
     } enc_plan;
+    std::vector<uint64_t> enc_plan_probe;   // the key words of the call at hand
     // side streams: kernels of a call that work on disjoint pages (the selector / emit chains of different column kinds, the
     // three expand kernels of a read) run side by side between a fork and a join on `stream`; seen from outside the call is
     // still one span of work on `stream`.  Not used while profiling (the per-kernel events bracket launches on `stream`).

@@ -195,11 +195,23 @@ class NestedWriteBatch:
             self.outs.append((pages, metas))
 
     def run(self) -> List[NestedEncodedColumn]:
+        """Encodes what the buffers hold NOW.  The batch was sized by the buffers' first contents: rows per level, page
+        count and output capacity are fixed, so the data may change but its level STRUCTURE (list lengths, hence leaf slots
+        per page) must still fit — a page cut that does not is refused here, before anything is enqueued.  The returned
+        columns alias the batch's output buffers: the next run() overwrites them."""
         ctx = self.ctx
         if not self._fresh:
             self.lw.call()
-            for k in range(self.n):   # the page cut of THIS call (same shapes: the arrays were sized by the first one)
+            for k in range(self.n):   # the page cut of THIS call
                 info = self.lw.info(k)
+                if info.shape[0] != self.page_rows[k].shape[0]:
+                    raise ValueError("NestedWriteBatch.run(): leaf column %d now has %d pages, the batch was built for %d" % (k, info.shape[0], self.page_rows[k].shape[0]))
+                leaf_slots, heads = int(info[:, 3].sum()), int(info[:, 0].sum())
+                if leaf_slots != int(self.arr[k].rows):
+                    raise ValueError("NestedWriteBatch.run(): leaf column %d now has %d leaf slots, the batch was built for %d (build a new "
+                                     "batch for a chunk with other list lengths)" % (k, leaf_slots, int(self.arr[k].rows)))
+                if heads > int(self.heads[k].sum()) + self.page_rows[k].shape[0] * 512:
+                    raise ValueError("NestedWriteBatch.run(): the level sections of leaf column %d outgrew the output capacity" % k)
                 self.page_rows[k][:] = info[:, 3]
                 self.heads[k][:] = info[:, 0]
         self._fresh = False

@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/test_gpu_nested.py tests/test_gpu_configs.py tests/test_gpu_io.py tests/test_gpu_file.py tests/test_gpu_dist.py -x -q 2>&1 | tail -8
-timeout 900 python bench.py --only c5 --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())['configs']['c5']
-print('c5 enc', d['encode']['GBps'], d['encode']['ms'], d['encode']['kernels_ms'])
-print('c5 dec', d['decode']['GBps'], d['decode']['ms'], d['decode']['kernels_ms'], d.get('single_array'))"
+timeout 1200 python -m pytest tests/test_gpu_zstd_blocks.py tests/test_gpu_zstd.py -x -q 2>&1 | tail -5
+timeout 900 python tests/probes/fuzz_zb.py 60 2>&1 | tail -2
+export SB_ZSTD_BLOCKS=1
+timeout 600 python scripts/prof_zstd_ref.py 8 b 2>&1 | grep -v amdgpu | head -8
+timeout 600 python scripts/prof_zstd_ref.py 64 ab 2>&1 | grep -v amdgpu | head -10

@@ -177,6 +177,7 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
     }
     (void)hipMemsetAsync(ctx->zb_stats, 0, 16 * sizeof(unsigned long long), ctx->stream);
     if (const char* e = getenv("SB_ZSTD_BLOCKS")) ctx->zb_mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
+    if (const char* e = getenv("SB_ZSTD_BLOCKS_WG")) ctx->zb_wg_exec = e[0] != '0';
     if (const char* e = getenv("SB_ZSTD_BLOCKS_MIN")) ctx->zb_min_csize = (uint32_t)strtoul(e, nullptr, 10);
     *out = ctx;
     return SB_OK;
@@ -630,6 +631,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         a.zb.lit_cap = zb_lit_cap;
         a.zb.rec_cap = zb_rec_cap;
         a.zb.min_csize = ctx->zb_min_csize;
+        a.zb.wg_exec = ctx->zb_wg_exec;
         a.zb.stats = ctx->zb_stats;
     }
     a.freq_log = nullptr;

@@ -140,6 +140,7 @@ struct ZbFrame {
     uint32_t avail;         // bytes of the queue entry's buffer (loads never reach beyond it)
     uint32_t queue;         // 0: queue A, 1: queue Z (executed after k_colscan)
     uint32_t rel;           // dst is relative to the page's value base (JOB_REL)
+    uint32_t wg;            // executed by zb_exec_wg (many short sequences) instead of zb_exec
     const uint8_t* base;    // the queue entry's buffer
 };
 struct ZbPools {
@@ -152,6 +153,7 @@ struct ZbPools {
     uint32_t block_cap, frame_cap;
     uint64_t lit_cap, rec_cap;
     uint32_t min_csize;     // frames shorter than this stay with the one-wave / lane-per-frame paths
+    uint32_t wg_exec;       // 0: every frame through the wave executor (SB_ZSTD_BLOCKS_WG=0)
     unsigned long long* stats;   // totals of the context: [0] frames decoded, [1] frames handed back, [2] blocks, [3] sequences
 };
 

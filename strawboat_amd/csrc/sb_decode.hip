@@ -2316,8 +2316,18 @@ static RelCtx rel_ctx(const DecodeArgs& a) {
 }
 static void launch_zb_exec(sb_ctx* ctx, const DecodeArgs& a, uint32_t queue) {
     if (!a.zb.blocks) return;
-    KScope k(ctx, queue == 0 ? "zb_exec" : "zb_exec(values)");
-    zb_exec<<<std::min<uint32_t>(a.zb.frame_cap, 4096u), 64, 0, ctx->stream>>>(queue == 0 ? a.jobs_a : a.jobs_z, a.status, a.zb, queue, rel_ctx(a));
+    // the two executors work on disjoint frames: side by side
+    const bool multi = a.zb.wg_exec && !ctx->profile && side_streams(ctx);
+    if (multi) side_fork(ctx, 1u);
+    {
+        KScope k(ctx, queue == 0 ? "zb_exec" : "zb_exec(values)");
+        zb_exec<<<std::min<uint32_t>(a.zb.frame_cap, 4096u), 64, 0, ctx->stream>>>(queue == 0 ? a.jobs_a : a.jobs_z, a.status, a.zb, queue, rel_ctx(a));
+    }
+    if (a.zb.wg_exec) {
+        KScope k(ctx, queue == 0 ? "zb_exec_wg" : "zb_exec_wg(values)");
+        zb_exec_wg<<<std::min<uint32_t>(a.zb.frame_cap, 1024u), ZX_T, 0, multi ? ctx->side[0] : ctx->stream>>>(queue == 0 ? a.jobs_a : a.jobs_z, a.status, a.zb, queue, rel_ctx(a));
+    }
+    if (multi) side_join(ctx, 1u);
 }
 static void launch_zb(sb_ctx* ctx, const DecodeArgs& a) {
     if (!a.zb.blocks) return;

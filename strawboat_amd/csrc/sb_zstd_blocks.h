@@ -26,6 +26,7 @@
 // entry before k_inflate runs.
 #pragma once
 #include "sb_zstd.h"
+#include "sb_lz4_big.h"   // wave_scan_max_dpp; zb_exec_wg copies windows the way lz4_inflate_block_wg does
 
 namespace sb {
 
@@ -50,6 +51,19 @@ __device__ __forceinline__ uint32_t zb_subst(uint32_t v, uint32_t a0, uint32_t a
     return a > dl ? a - dl : 0u;            // 0: invalid, and stays so (0 minus anything is 0 here)
 }
 
+// where a queue entry's output goes: absolute, or (JOB_REL) relative to the page's value base, known after k_colscan;
+// null: the page does not take part (its values do not fit the caller's buffer)
+struct RelCtx {
+    const ColDesc* cols;
+    const PageTask* tasks;
+    const PageDesc* descs;
+};
+__device__ __forceinline__ uint8_t* job_dst(const RelCtx& rc, uint8_t* dst, uint32_t page, bool rel) {
+    if (!rel) return dst;
+    const PageDesc& d = rc.descs[page];
+    if (!d.ok) return nullptr;
+    return rc.cols[rc.tasks[page].col].values + d.val_base + (uintptr_t)dst;
+}
 // literals section header at bs[0, n): false when it does not fit
 __device__ inline bool zb_lit_header(const uint8_t* bs, uint32_t n, uint32_t* ltype, uint32_t* streams, uint32_t* regen, uint32_t* csize,
                                      uint32_t* hdr) {
@@ -271,6 +285,8 @@ __global__ void __launch_bounds__(WG) zb_scan(InflateJob* q, const uint32_t* cou
         fr.base = src;
         fr.queue = queue;
         fr.rel = (job.codec & JOB_REL) ? 1u : 0u;
+        // many short sequences (less than 24 output bytes each): the workgroup executor, which pays per byte, not per sequence
+        fr.wg = (zp.wg_exec && rec_need >= 2048 && (uint64_t)job.out_len < 24 * rec_need) ? 1u : 0u;
         zp.frames[f] = fr;
         q[j].codec = CODEC_ZB | (job.codec & JOB_REL);   // (zb_exec restores it for a punted frame)
     }
@@ -1111,6 +1127,380 @@ __global__ void __launch_bounds__(64) zb_seq(ZbPools zp) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- zb_exec_wg
+// Frames of many short sequences (text: a few output bytes per sequence) by a WORKGROUP per frame, the way sb_lz4_big.h
+// copies an LZ4 block: 512 records per round — repeat offsets by the composition scan over the workgroup, output and
+// literal positions by prefix sums — then the round's output in windows of 8 KiB: one u16 entry per output byte, either
+// FINAL (0x8000 | byte: a literal, or a match byte whose source lies in front of the window, read back from HBM) or a
+// POINTER to the window byte it copies; a round of `ent[p] = ent[ent[p]]` per pointer entry resolves chains of matches
+// in log2(depth) rounds.  The wave executor (zb_exec) pays ~70 cycles per sequence in batch bookkeeping and dependency
+// rounds; this one ~9 cycles per output BYTE whatever the sequences look like: zb_scan picks per frame.
+constexpr uint32_t ZX_T = 256, ZX_REC = 512, ZX_WIN = 8192;
+struct ZxLds {
+    __attribute__((aligned(16))) uint16_t ent[ZX_WIN + 16];
+    uint32_t r_out[ZX_REC + 4];   // output position of the record's first byte; [nrec] = end of the round's output
+    uint32_t r_lit[ZX_REC];       // position of its literals in the block's literal buffer
+    uint32_t r_off[ZX_REC];       // match distance (directly behind r_lit: the entries phase picks one of the two with one load)
+    uint32_t r_ll[ZX_REC];        // literal length (the rest of the record's bytes are the match)
+    uint32_t wt[4][3];            // repeat-offset maps of the waves
+    uint32_t wsum[8];
+    uint32_t err;
+};
+__device__ __forceinline__ void zx_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {   // by the workgroup, no overlap
+    const uint32_t t = threadIdx.x;
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (head > n) head = n;
+    if (t < head) dst[t] = ldu8(src + t);
+    const uint32_t nvec = (n - head) >> 4;
+    for (uint32_t i = t; i < nvec; i += ZX_T) stu128(dst + head + 16 * (uint64_t)i, ldu128(src + head + 16 * (uint64_t)i));
+    const uint32_t done = head + (nvec << 4);
+    if (t < n - done) dst[done + t] = ldu8(src + done + t);
+}
+__global__ void __launch_bounds__(ZX_T, 4) zb_exec_wg(InflateJob* q, Status* st, ZbPools zp, uint32_t queue, RelCtx rc) {
+    __shared__ ZxLds L;
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t nframes = min(zp.counters[1], zp.frame_cap);
+    for (uint32_t fi = blockIdx.x; fi < nframes; fi += gridDim.x) {
+        const ZbFrame f = zp.frames[fi];
+        if (f.queue != queue || !f.wg || f.punt) continue;   // (punted frames are handed back by zb_exec)
+        uint8_t* const dst = job_dst(rc, f.dst, f.page, f.rel != 0);
+        if (!dst) continue;
+        const uint32_t out_len = f.out_len;
+        uint32_t op = 0, err = 0;
+        uint32_t e0 = 1, e1 = 4, e2 = 8;
+        __syncthreads();
+        if (t == 0) L.err = 0;
+        __syncthreads();
+        for (uint32_t k = 0; k < f.nblocks && !err; k++) {
+            const ZbBlock b = zp.blocks[f.first + k];
+            if (b.btype == 0 || b.btype == 1) {
+                if (out_len - op < b.out_size) { err = 10; break; }
+                if (b.btype == 0) {
+                    zx_copy(dst + op, b.src, b.out_size);
+                } else {
+                    const uint8_t v = ldu8(b.src);
+                    for (uint32_t i = t; i < b.out_size; i += ZX_T) dst[op + i] = v;
+                }
+                op += b.out_size;
+                wave_stores_visible();
+                __syncthreads();
+                continue;
+            }
+            const uint8_t* litp;
+            if (b.ltype == 0) {
+                litp = b.src + b.lpay;
+            } else {
+                uint8_t* lp = zp.lit + b.lit_pos;
+                if (b.ltype == 1) {
+                    const uint8_t v = ldu8(b.src + b.lpay);
+                    for (uint32_t i = t; i < b.regen; i += ZX_T) lp[i] = v;
+                    wave_stores_visible();
+                    __syncthreads();
+                }
+                litp = lp;
+            }
+            uint32_t lit_pos = 0;
+            const uint32_t* recs = (const uint32_t*)zp.rec + 3 * b.rec_pos;
+            for (uint32_t done = 0; done < b.nseq && !err; done += ZX_REC) {
+                const uint32_t nrec = min(ZX_REC, b.nseq - done);
+                // ---- thread t: records 2 t and 2 t + 1 of the round
+                uint32_t ll[2], ml[2], ofv[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t r = 2 * t + u;
+                    ll[u] = ml[u] = 0;
+                    ofv[u] = 1;
+                    if (r < nrec) {
+                        uint32_t v3[3];
+                        __builtin_memcpy(v3, (gcptr)(const uint8_t*)(recs + 3 * (done + r)), 12);
+                        ll[u] = v3[0];
+                        ml[u] = v3[1];
+                        ofv[u] = v3[2];
+                    }
+                }
+                bool bad = ll[0] >= (1u << 18) || ml[0] >= (1u << 18) || ll[1] >= (1u << 18) || ml[1] >= (1u << 18);
+                // ---- repeat offsets: the records' maps, composed over the thread, the wave, the workgroup (cf. zb_exec)
+                uint32_t m0[2], m1[2], m2[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const bool valid = 2 * t + u < nrec;
+                    const uint32_t idx = ofv[u] - 1 + (ll[u] == 0 ? 1u : 0u);
+                    const bool real = ofv[u] > 3;
+                    if (valid && real && ofv[u] - 3 >= ZB_SYM) bad = true;
+                    m0[u] = !valid ? zb_sym(0) : real ? ofv[u] - 3 : idx == 0 ? zb_sym(0) : idx == 1 ? zb_sym(1) : idx == 2 ? zb_sym(2) : (zb_sym(0) | 1u);
+                    m1[u] = (valid && (real || idx >= 1)) ? zb_sym(0) : zb_sym(1);
+                    m2[u] = (valid && (real || idx >= 2)) ? zb_sym(1) : zb_sym(2);
+                }
+                // the thread's two records together, then an inclusive scan over the wave
+                uint32_t c0 = zb_subst(m0[1], m0[0], m1[0], m2[0]), c1 = zb_subst(m1[1], m0[0], m1[0], m2[0]), c2 = zb_subst(m2[1], m0[0], m1[0], m2[0]);
+#pragma unroll
+                for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+                    const uint32_t a0_ = (uint32_t)__shfl_up((int)c0, dlt, 64), a1_ = (uint32_t)__shfl_up((int)c1, dlt, 64), a2_ = (uint32_t)__shfl_up((int)c2, dlt, 64);
+                    if (lane >= dlt) {
+                        const uint32_t n0 = zb_subst(c0, a0_, a1_, a2_), n1 = zb_subst(c1, a0_, a1_, a2_), n2 = zb_subst(c2, a0_, a1_, a2_);
+                        c0 = n0;
+                        c1 = n1;
+                        c2 = n2;
+                    }
+                }
+                __syncthreads();
+                if (lane == 63) {
+                    L.wt[wv][0] = c0;
+                    L.wt[wv][1] = c1;
+                    L.wt[wv][2] = c2;
+                }
+                __syncthreads();
+                // the state in front of the thread's first record: the lanes before it in the wave, after the waves before it
+                uint32_t p0 = (uint32_t)__shfl_up((int)c0, 1, 64), p1 = (uint32_t)__shfl_up((int)c1, 1, 64), p2 = (uint32_t)__shfl_up((int)c2, 1, 64);
+                if (lane == 0) {
+                    p0 = zb_sym(0);
+                    p1 = zb_sym(1);
+                    p2 = zb_sym(2);
+                }
+                uint32_t w0_ = zb_sym(0), w1_ = zb_sym(1), w2_ = zb_sym(2);   // the waves before mine, composed
+                uint32_t tot0 = zb_sym(0), tot1 = zb_sym(1), tot2 = zb_sym(2);
+                for (uint32_t w = 0; w < 4; w++) {
+                    const uint32_t x0 = L.wt[w][0], x1 = L.wt[w][1], x2 = L.wt[w][2];
+                    const uint32_t n0 = zb_subst(x0, tot0, tot1, tot2), n1 = zb_subst(x1, tot0, tot1, tot2), n2 = zb_subst(x2, tot0, tot1, tot2);
+                    tot0 = n0;
+                    tot1 = n1;
+                    tot2 = n2;
+                    if (w + 1 == wv) {
+                        w0_ = tot0;
+                        w1_ = tot1;
+                        w2_ = tot2;
+                    }
+                }
+                {
+                    const uint32_t n0 = zb_subst(p0, w0_, w1_, w2_), n1 = zb_subst(p1, w0_, w1_, w2_), n2 = zb_subst(p2, w0_, w1_, w2_);
+                    p0 = n0;
+                    p1 = n1;
+                    p2 = n2;
+                }
+                uint32_t off[2];
+                {
+                    const uint32_t s0 = zb_subst(m0[0], p0, p1, p2), s1 = zb_subst(m1[0], p0, p1, p2), s2 = zb_subst(m2[0], p0, p1, p2);
+                    off[0] = zb_resolve(s0, e0, e1, e2);
+                    off[1] = zb_resolve(zb_subst(m0[1], s0, s1, s2), e0, e1, e2);
+                }
+                {   // the state after the round
+                    const uint32_t n0 = zb_resolve(tot0, e0, e1, e2), n1 = zb_resolve(tot1, e0, e1, e2), n2 = zb_resolve(tot2, e0, e1, e2);
+                    e0 = n0;
+                    e1 = n1;
+                    e2 = n2;
+                }
+                // ---- positions: output (ll + ml) and literal (ll) prefix sums over the round
+                const uint32_t len2 = ll[0] + ml[0] + ll[1] + ml[1], lit2 = ll[0] + ll[1];
+                const uint32_t li = wave_scan_dpp(len2), lli = wave_scan_dpp(lit2);
+                if (lane == 63) {
+                    L.wsum[wv] = li;
+                    L.wsum[4 + wv] = lli;
+                }
+                __syncthreads();
+                uint32_t obase = li - len2, lbase = lli - lit2;
+                for (uint32_t w = 0; w < wv; w++) {
+                    obase += L.wsum[w];
+                    lbase += L.wsum[4 + w];
+                }
+                const uint64_t round_out = (uint64_t)L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+                const uint64_t round_lit = (uint64_t)L.wsum[4] + L.wsum[5] + L.wsum[6] + L.wsum[7];
+                if (round_out > (uint64_t)(out_len - op) || (uint64_t)lit_pos + round_lit > b.regen) bad = true;
+                {
+                    uint32_t o = op + obase, lp_ = lit_pos + lbase;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t r = 2 * t + u;
+                        if (r < nrec) {
+                            L.r_out[r] = o;
+                            L.r_lit[r] = lp_;
+                            L.r_off[r] = off[u];
+                            L.r_ll[r] = ll[u];
+                            if (ml[u] && (off[u] == 0 || off[u] > o + ll[u])) bad = true;   // a match may not reach in front of the frame
+                        }
+                        o += ll[u] + ml[u];
+                        lp_ += ll[u];
+                    }
+                }
+                if (bad) L.err = 30;
+                const uint32_t o_end = op + (uint32_t)round_out;
+                if (t == 0) L.r_out[nrec] = o_end;
+                __syncthreads();
+                if (L.err) { err = L.err; break; }
+                // ---- windows of the round's output (sb_lz4_big.h's copy stage; literals come from the block's literal buffer)
+                const uint32_t nwin = (o_end - op + ZX_WIN - 1) / ZX_WIN;
+                const uint32_t wstep = nwin ? min(ZX_WIN, ((o_end - op + nwin - 1) / nwin + 255) & ~255u) : ZX_WIN;
+                for (uint32_t w0 = op; w0 < o_end; w0 += wstep) {
+                    const uint32_t wl = min(wstep, o_end - w0);
+                    __syncthreads();
+                    for (uint32_t i = t * 8; i < wl; i += ZX_T * 8) *(u32x4*)(L.ent + i) = u32x4{0, 0, 0, 0};
+                    __syncthreads();
+                    for (uint32_t r = t; r < nrec; r += ZX_T) {
+                        const uint32_t o = L.r_out[r];
+                        if (o >= w0 && o - w0 < wl && L.r_out[r + 1] > o) L.ent[o - w0] = (uint16_t)(r + 1);
+                    }
+                    __syncthreads();
+                    {   // every byte finds its record: max-scan of the markers (wave = a quarter of the window)
+                        const uint32_t wq = ((wl + 255) / 256) * 64;
+                        const uint32_t b0 = wv * wq;
+                        uint32_t carry = 0;
+                        if (b0 < wl) {
+                            uint32_t lo = 0, hi = nrec;   // largest r with r_out[r] <= w0 + b0 (r_out[0] <= w0)
+                            const uint32_t x = w0 + b0;
+                            while (hi - lo > 1) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (L.r_out[mid] <= x) lo = mid;
+                                else hi = mid;
+                            }
+                            carry = lo + 1;
+                        }
+                        const uint32_t b1 = min(b0 + wq, wl);
+                        for (uint32_t rb = b0; rb < b1; rb += 512) {
+                            uint32_t m[8];
+#pragma unroll
+                            for (uint32_t u = 0; u < 8; u++) {
+                                const uint32_t p_ = rb + 64 * u + lane;
+                                m[u] = p_ < b1 ? (uint32_t)L.ent[p_] : 0u;
+                            }
+#pragma unroll
+                            for (uint32_t u = 0; u < 8; u++) {
+                                const uint32_t p_ = rb + 64 * u + lane;
+                                const uint32_t sc = max(wave_scan_max_dpp(m[u]), carry);
+                                carry = rdlane(sc, 63);
+                                if (p_ < b1) L.ent[p_] = (uint16_t)sc;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    // first entries (thread owns the bytes t + 256 k): a literal or a byte from in front of the window (both from
+                    // HBM, second pass), or a pointer
+                    uint32_t pend = 0, gmask = 0;
+#pragma unroll 1
+                    for (uint32_t k0 = 0; k0 * ZX_T < wl; k0 += 8) {
+                        uint32_t id[8], kk[8], x[8];
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; u++) {
+                            const uint32_t p_ = t + ZX_T * (k0 + u);
+                            id[u] = p_ < wl ? (uint32_t)L.ent[p_] - 1 : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; u++) {
+                            const uint32_t p_ = t + ZX_T * (k0 + u);
+                            kk[u] = w0 + p_ - L.r_out[id[u]];   // byte of the record
+                            x[u] = L.r_ll[id[u]];
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; u++) {
+                            const uint32_t p_ = t + ZX_T * (k0 + u);
+                            if (p_ < wl) {
+                                if (kk[u] < x[u]) {
+                                    gmask |= 1u << (k0 + u);   // a literal (ent[p] keeps the record until the second pass)
+                                } else {
+                                    const uint32_t dist = L.r_off[id[u]];
+                                    if (dist <= p_) {
+                                        L.ent[p_] = (uint16_t)(p_ - dist);
+                                        pend |= 1u << (k0 + u);
+                                    } else {
+                                        gmask |= 1u << (k0 + u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    while (gmask) {   // sixteen loads in flight
+                        uint32_t kq[16], gv[16];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) {
+                            kq[u] = gmask ? (uint32_t)__builtin_ctz(gmask) : 32u;
+                            gmask &= gmask - 1;   // (0 stays 0)
+                            gv[u] = kq[u] < 32 ? (uint32_t)L.ent[t + ZX_T * kq[u]] - 1 : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; u++) {
+                            if (kq[u] < 32) {
+                                const uint32_t r = gv[u], p_ = t + ZX_T * kq[u];
+                                const uint32_t kb = w0 + p_ - L.r_out[r];
+                                gv[u] = kb < L.r_ll[r] ? (uint32_t)ldu8(litp + L.r_lit[r] + kb) : (uint32_t)ldu8(dst + (w0 + p_ - L.r_off[r]));
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; u++)
+                            if (kq[u] < 32) L.ent[t + ZX_T * kq[u]] = (uint16_t)(0x8000u | gv[u]);
+                    }
+                    __syncthreads();
+                    for (;;) {   // pointer jumping: every pointer entry takes over the entry it points to
+                        int any = 0;
+                        uint32_t m = pend;
+                        while (m) {
+                            uint32_t kq[4], pp[4], ss[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                kq[u] = m ? (uint32_t)__builtin_ctz(m) : 32u;
+                                m &= m - 1;
+                                pp[u] = kq[u] < 32 ? (uint32_t)L.ent[t + ZX_T * kq[u]] : 0u;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) ss[u] = L.ent[pp[u]];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                if (kq[u] < 32) {
+                                    L.ent[t + ZX_T * kq[u]] = (uint16_t)ss[u];
+                                    if (ss[u] & 0x8000u) pend &= ~(1u << kq[u]);
+                                    else any = 1;
+                                }
+                            }
+                        }
+                        if (!__syncthreads_or(any)) break;
+                    }
+                    {   // window -> HBM: 16-byte groups of the line frame of dst + w0
+                        const uint32_t a0 = (uint32_t)((uintptr_t)(dst + w0) & 15);
+                        uint8_t* gb = dst + w0 - a0;
+                        const uint32_t ng = (a0 + wl + 15) >> 4;
+                        for (uint32_t g = t; g < ng; g += ZX_T) {
+                            const int32_t f0 = (int32_t)(16 * g) - (int32_t)a0;
+                            if (f0 >= 0 && (uint32_t)f0 + 16 <= wl) {
+                                uint32_t w4[4];
+#pragma unroll
+                                for (int qq = 0; qq < 4; qq++) {
+                                    w4[qq] = (uint32_t)(L.ent[f0 + 4 * qq] & 0xFF) | ((uint32_t)(L.ent[f0 + 4 * qq + 1] & 0xFF) << 8) |
+                                             ((uint32_t)(L.ent[f0 + 4 * qq + 2] & 0xFF) << 16) | ((uint32_t)(L.ent[f0 + 4 * qq + 3] & 0xFF) << 24);
+                                }
+                                stu128(gb + 16 * g, u32x4{w4[0], w4[1], w4[2], w4[3]});
+                            } else {
+                                for (int bq = 0; bq < 16; bq++) {
+                                    const int32_t fq = f0 + bq;
+                                    if (fq >= 0 && (uint32_t)fq < wl) gb[16 * g + bq] = (uint8_t)L.ent[fq];
+                                }
+                            }
+                        }
+                    }
+                    wave_stores_visible();   // later windows read these bytes back
+                }
+                op = o_end;
+                lit_pos += (uint32_t)round_lit;
+                __syncthreads();
+            }
+            if (err) break;
+            const uint32_t rest = b.regen - lit_pos;
+            if (out_len - op < rest) { err = 31; break; }
+            zx_copy(dst + op, litp + lit_pos, rest);
+            op += rest;
+            wave_stores_visible();
+            __syncthreads();
+        }
+        if (!err && op != out_len) err = 34;
+        if (err && t == 0) raise(st, SB_ERR_EXTERNAL, f.page, 120 + err);
+        if (t == 0) {
+            unsigned long long ns = 0;
+            for (uint32_t k = 0; k < f.nblocks; k++) ns += zp.blocks[f.first + k].nseq;
+            atomicAdd(&zp.stats[0], 1ull);
+            atomicAdd(&zp.stats[2], (unsigned long long)f.nblocks);
+            atomicAdd(&zp.stats[3], ns);
+        }
+        wave_stores_visible();
+        __syncthreads();
+    }
+}
+
 // phase clocks of lane 0 of one wave (development: -DZB_TL; read back by sb_debug_zb_timers)
 #ifdef ZB_TL
 #define ZBT_BEGIN unsigned long long zbt_acc[12] = {0}; unsigned long long zbt_t = __builtin_readcyclecounter();
@@ -1125,19 +1515,6 @@ __global__ void __launch_bounds__(64) zb_seq(ZbPools zp) {
 #endif
 // ---------------------------------------------------------------------------------------------------- zb_exec
 // A pool of waves over the frames: blocks in order.
-// where a queue entry's output goes: absolute, or (JOB_REL) relative to the page's value base, known after k_colscan;
-// null: the page does not take part (its values do not fit the caller's buffer)
-struct RelCtx {
-    const ColDesc* cols;
-    const PageTask* tasks;
-    const PageDesc* descs;
-};
-__device__ __forceinline__ uint8_t* job_dst(const RelCtx& rc, uint8_t* dst, uint32_t page, bool rel) {
-    if (!rel) return dst;
-    const PageDesc& d = rc.descs[page];
-    if (!d.ok) return nullptr;
-    return rc.cols[rc.tasks[page].col].values + d.val_base + (uintptr_t)dst;
-}
 __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools zp, uint32_t queue, RelCtx rc) {
     __shared__ LzSeqLds ring;
     const uint32_t lane = threadIdx.x;
@@ -1152,6 +1529,7 @@ __global__ void __launch_bounds__(64) zb_exec(InflateJob* q, Status* st, ZbPools
             }
             continue;
         }
+        if (f.wg) continue;   // zb_exec_wg's
         uint8_t* const fdst = job_dst(rc, f.dst, f.page, f.rel != 0);
         if (!fdst) continue;
         if (lane == 0) {

@@ -33,11 +33,37 @@ __device__ __forceinline__ void push_job(InflateJob* q, uint32_t* cnt, const uin
                                          uint8_t* dst, uint32_t out_len, uint32_t codec, uint32_t page);
 // a Basic payload that no planning step reads: queue A when the call has no binary column (there is no later phase), else
 // queue Z (Zstd: its entropy stages run with queue A's) or queue B (the other codecs, inflated next to the binary value blocks)
+// push_job for the lanes with `pred`, called by ALL lanes of a branch with the SAME queue: one atomic per wave — the lane that
+// leads takes popcount slots, every lane its rank among them.  (The compiler aggregates a plain atomicAdd by itself only
+// while the counter's address is provably wave-uniform; a queue chosen per page is not, and 65 536 one-thread atomics on one
+// word made k_parse ten times slower.)
+__device__ __forceinline__ void push_job_if(bool pred, InflateJob* q, uint32_t* cnt, const uint8_t* src, uint32_t csize, uint8_t* dst,
+                                            uint32_t out_len, uint32_t codec, uint32_t page) {
+    const uint64_t m = __ballot(pred);
+    if (!m) return;   // (uniform)
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    uint32_t base = 0;
+    if (pred && rank == 0) base = __hip_atomic_fetch_add(cnt, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    if (pred) {
+        InflateJob j;
+        j.src = src;
+        j.dst = dst;
+        j.csize = csize;
+        j.out_len = out_len;
+        j.codec = codec;
+        j.page = page;
+        q[base + rank] = j;
+    }
+}
 __device__ __forceinline__ void push_payload(const DecodeArgs& a, const uint8_t* src, uint32_t csize, uint8_t* dst, uint32_t out_len,
                                              uint32_t codec, uint32_t page) {
-    if (!a.defer_payloads) push_job(a.jobs_a, a.job_counts, src, csize, dst, out_len, codec, page);
-    else if (codec == SB_CODEC_ZSTD && a.jobs_z) push_job(a.jobs_z, a.job_counts + 10, src, csize, dst, out_len, codec, page);
-    else push_job(a.jobs_b, a.job_counts + 1, src, csize, dst, out_len, codec, page);
+    // every lane that gets here offers its payload to each queue in turn: the queues are the call's (wave-uniform)
+    const bool z = a.defer_payloads && a.jobs_z && codec == SB_CODEC_ZSTD;
+    const bool b = a.defer_payloads && !z;
+    push_job_if(!a.defer_payloads, a.jobs_a, a.job_counts, src, csize, dst, out_len, codec, page);
+    push_job_if(b, a.jobs_b, a.job_counts + 1, src, csize, dst, out_len, codec, page);
+    if (a.jobs_z) push_job_if(z, a.jobs_z, a.job_counts + 10, src, csize, dst, out_len, codec, page);
 }
 __device__ __forceinline__ void push_job(InflateJob* q, uint32_t* cnt, const uint8_t* src, uint32_t csize,
                                          uint8_t* dst, uint32_t out_len, uint32_t codec, uint32_t page) {

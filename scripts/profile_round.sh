@@ -12,21 +12,21 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, pmc (0/1), bench args...
     local name=$1; shift
     local pmc=$1; shift
-    rocprofv3 --kernel-trace --stats -d $OUT/${name}_kt -o b -- python $R/bench.py "$@" > $OUT/${name}_stdout.txt 2> $OUT/${name}_kt.err
+    timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${name}_kt -o b -- python $R/bench.py "$@" > $OUT/${name}_stdout.txt 2> $OUT/${name}_kt.err < /dev/null
     if [ "$pmc" = "1" ]; then
         for c in FETCH_SIZE WRITE_SIZE; do
-            rocprofv3 --pmc $c -d $OUT/${name}_pmc/$c -o b -- python $R/bench.py "$@" > /dev/null 2> $OUT/${name}_pmc_$c.err
+            timeout 400 rocprofv3 --pmc $c -d $OUT/${name}_pmc/$c -o b -- python $R/bench.py "$@" > /dev/null 2> $OUT/${name}_pmc_$c.err < /dev/null
         done
     fi
 }
 run c2 1 --no-configs --no-cpu-baseline --steps 10
 run c1 1 --only c1 --no-cpu-baseline
-run c3 1 --only c3,c3_lz4 --no-cpu-baseline
-run c4 1 --only c4 --no-cpu-baseline
+run c3 0 --only c3,c3_lz4 --no-cpu-baseline
+run c4 0 --only c4 --no-cpu-baseline
 run c5 1 --only c5 --no-cpu-baseline
 find $OUT -name "*.db" -o -name "*.csv" | head -80 > $OUT/files.txt
 for cfg in c2 c1 c3 c4 c5; do
-    python $R/scripts/summarize_rocpd.py $OUT $TAG $cfg "{\"workload\": \"$cfg (bench.py, see profiles/${TAG}_${cfg}_stdout.txt)\"}" > $OUT/${cfg}_summary.txt 2>&1
+    timeout 120 python $R/scripts/summarize_rocpd.py $OUT $TAG $cfg "{\"workload\": \"$cfg (bench.py, see profiles/${TAG}_${cfg}_stdout.txt)\"}" > $OUT/${cfg}_summary.txt 2>&1
     cp $OUT/${cfg}_stdout.txt $R/profiles/${TAG}_${cfg}_stdout.txt 2>/dev/null
 done
 cp $R/profiles/${TAG}_c2_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json 2>/dev/null   # (bench.py's roofline.traffic: the headline's counters)

@@ -1,7 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_gpu_decode.py tests/test_gpu_zstd.py -x -q 2>&1 | tail -2
-timeout 200 python bench.py --only continuity --no-cpu-baseline 2>&1 | tail -1 | timeout 20 python -c "
-import json,sys
-d=json.loads(sys.stdin.read())['configs']['continuity']
-for k in ('bool','i64','utf8'):
-    print(k, 'dec', d[k]['decode']['GBps'], d[k]['decode']['ms'], d[k]['decode']['kernels_ms'])"
+timeout 400 python -m pytest tests/test_gpu_nested.py tests/test_gpu_io.py -x -q 2>&1 | tail -2
+timeout 300 python scripts/prof_c5_host.py 64 2>&1 | grep -E "per run|_levels|synchronize|nested.py:96"

@@ -1,50 +1,48 @@
-"""Where the host time of the C5 nested calls goes (cProfile over one batched write and one batched read of 64 arrays):
-python scripts/prof_c5_host.py [arrays]"""
-import cProfile
-import os
-import pstats
-import sys
-import time
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Development probe: where the wall time of NestedWriteBatch.run() / NestedReadBatch.run() goes on the host (C5 x 64)."""
+import cProfile, os, pstats, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
 import bench as B
-from strawboat_amd import nested
 import workloads as W
-from strawboat_amd.read import ColumnPages
-from strawboat_amd.types import Compression as C, WriteOptions
 
 
 def main():
-    arrays = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    import torch
     import strawboat_amd as sb
+    from strawboat_amd import nested
+    from strawboat_amd.read import ColumnPages
+    from strawboat_amd.types import Compression as C, WriteOptions
+    arrays = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     ctx = sb.Context(0)
     h = B.GpuHarness(ctx)
     opts = WriteOptions(max_page_size=B.PAGE, default_compression=C.ZSTD)
-
-    def dlevels(levels):
-        return [nested.NestedLevel(lv["kind"], bool(lv["is_optional"]), lv["length"], h.up(lv.get("validity")), h.up(lv.get("offsets")))
-                for lv in levels]
+    gen = B.gen_parallel(lambda s: W.c5_nested(seed=s), range(42, 42 + arrays))
     items = []
-    for la, a, lb, b in B.gen_parallel(lambda s: W.c5_nested(seed=s), range(42, 42 + arrays)):
+    for la, a, lb, b in gen:
         for lv_, leaf in ((la, a), (lb, b)):
             dc = h.dcol(leaf)
             dc.is_nullable = False
-            items.append((dlevels(lv_), dc, leaf, lv_))
-    pairs = [(dl, dc) for dl, dc, _, _ in items]
-    encs = nested.write_nested_leaves(ctx, pairs, opts)
+            items.append(([nested.NestedLevel(lv["kind"], bool(lv["is_optional"]), lv["length"], h.up(lv.get("validity")), h.up(lv.get("offsets"))) for lv in lv_], dc, leaf, lv_))
+    wb = nested.NestedWriteBatch(ctx, [(dl, dc) for dl, dc, _, _ in items], opts)
+    encs = wb.run()
     cps = [ColumnPages(c["ptype"], False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (_, _, c, _) in zip(encs, items)]
-    kinds = [[lv["kind"] for lv in lv_] for _, _, _, lv_ in items]
-    opt = [[bool(lv["is_optional"]) for lv in lv_] for _, _, _, lv_ in items]
-    nested.read_nested_leaves(ctx, cps, kinds, opt)
-    for name, fn in (("write", lambda: nested.write_nested_leaves(ctx, pairs, opts)), ("read", lambda: nested.read_nested_leaves(ctx, cps, kinds, opt))):
+    rb = nested.NestedReadBatch(ctx, cps, [[lv["kind"] for lv in lv_] for _, _, _, lv_ in items], [[bool(lv["is_optional"]) for lv in lv_] for _, _, _, lv_ in items])
+    rb.run()
+    for name, fn in (("write", wb.run), ("read", rb.run)):
+        for _ in range(2):
+            fn()
         t0 = time.perf_counter()
-        fn()
-        print("%s: %.2f ms wall" % (name, (time.perf_counter() - t0) * 1e3))
+        for _ in range(5):
+            fn()
+        print("%s: %.3f ms per run" % (name, (time.perf_counter() - t0) / 5 * 1e3))
         pr = cProfile.Profile()
         pr.enable()
-        fn()
+        for _ in range(5):
+            fn()
         pr.disable()
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+        st = pstats.Stats(pr)
+        st.sort_stats("tottime").print_stats(8)
 
 
 if __name__ == "__main__":

@@ -114,6 +114,35 @@ __device__ inline bool zstd_frame_extent(const uint8_t* src, uint32_t n, uint32_
     *fcs_out = fcs;
     return true;
 }
+// The same for the common shape — a frame of ONE block whose header sits in the first 16 bytes — from a single 16-byte
+// load: the walk over a buffer of many frames is a chain of dependent HBM reads, one per frame this way instead of ~8
+__device__ inline bool zstd_frame_extent_fast(const uint8_t* src, uint32_t n, uint32_t pos, uint32_t* fsize, uint32_t* fcs_out) {
+    if (n - pos >= 16) {
+        const u32x4 q = ldu128(src + pos);
+        const uint64_t lo = (uint64_t)q.x | ((uint64_t)q.y << 32), hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+        auto byte = [&](uint32_t i) { return (uint32_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xFF); };
+        const uint32_t fhd = byte(4);
+        const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+        const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
+        if (q.x == 0xFD2FB528u && !(fhd & 0x08) && !did && !checksum && fcs_bytes != 0 && fcs_bytes != 8) {
+            uint32_t ip = 5 + (single ? 0 : 1);
+            uint32_t fcs = 0;
+            for (int i = 0; i < fcs_bytes; i++) fcs |= byte(ip + i) << (8 * i);
+            if (fcs_bytes == 2) fcs += 256;
+            ip += fcs_bytes;   // <= 10
+            const uint32_t bh = byte(ip) | (byte(ip + 1) << 8) | (byte(ip + 2) << 16);
+            const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+            if ((bh & 1) && btype != 3) {
+                const uint32_t body = btype == 1 ? 1u : bsize;
+                if (n - pos - (ip + 3) < body) return false;
+                *fsize = ip + 3 + body;
+                *fcs_out = fcs;
+                return true;
+            }
+        }
+    }
+    return zstd_frame_extent(src, n, pos, fsize, fcs_out);
+}
 // k_zstd_split, one thread per queue entry, launched when the queue is complete (*n0_p = its length then, recorded by the
 // last workgroup of the kernel that filled it): every Zstd entry that is >= 2 well-formed frames whose content sizes add
 // up to the entry's output is replaced by one entry per frame (the walk reads a few bytes per frame).  Anything else stays
@@ -127,39 +156,62 @@ __global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt,
         const InflateJob job = q[j];
         if ((job.codec & ~JOB_REL) != SB_CODEC_ZSTD) return;
         if (!(st->kinds & KIND_ZSTD)) atomicOr(&st->kinds, KIND_ZSTD);   // (the host sizes the block pipeline's pools for later calls)
-        uint32_t nf = 0, pos = 0, total = 0;
+        // ONE walk: the frames go to queue slots reserved SPLIT_BATCH at a time as they are found; when the buffer turns
+        // out not to be a plain chain of frames the slots written so far are marked "skip" and the entry keeps its frames
+        // (the queue's consumers are launched after this kernel)
+        constexpr uint32_t SPLIT_BATCH = 64, MAX_BATCHES = 16;   // batch k holds 64 (k + 1) slots: 16 reservations reach 8 704 frames
+        uint32_t first_pos, first_fs = 0, first_fc = 0;
+        if (!zstd_frame_extent_fast(job.src, job.csize, 0, &first_fs, &first_fc) || first_fs >= job.csize || first_fc > job.out_len) return;
+        first_pos = first_fs;   // (a single frame: nothing to split)
+        uint32_t bases[MAX_BATCHES], nb = 0, room = 0, at = 0, nf = 0, pos = 0, total = 0;
         bool ok = true;
-        while (pos < job.csize) {
-            uint32_t fs, fc;
-            if (!zstd_frame_extent(job.src, job.csize, pos, &fs, &fc) || fc > job.out_len - total) {
-                ok = false;
-                break;
+        uint32_t fs = first_fs, fc = first_fc;
+        (void)first_pos;
+        for (;;) {
+            if (room == 0) {
+                if (nb == MAX_BATCHES) {
+                    ok = false;
+                    break;
+                }
+                const uint32_t want = SPLIT_BATCH * (nb + 1);
+                const uint32_t b = atomicAdd(cnt, want);
+                if (b + want > cap) {   // no room: the part of the reservation inside the queue is marked "skip" (slots at
+                    ok = false;         // or beyond cap are never read: the consumers clamp the count to cap)
+                    for (uint32_t k = b; k < cap && k < b + want; k++) q[k].codec = CODEC_SPLIT;
+                    break;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < MAX_BATCHES; k++)
+                    if (k == nb) bases[k] = b;
+                at = b;
+                room = want;
+                nb++;
             }
-            pos += fs;
-            total += fc;
-            nf++;
-        }
-        if (!ok || nf < 2 || total != job.out_len) return;
-        const uint32_t base = atomicAdd(cnt, nf);
-        if (base + nf > cap) {   // no room: the entry keeps its frames
-            atomicSub(cnt, nf);
-            return;
-        }
-        pos = 0;
-        total = 0;
-        for (uint32_t k = 0; k < nf; k++) {
-            uint32_t fs = 0, fc = 0;
-            zstd_frame_extent(job.src, job.csize, pos, &fs, &fc);
             InflateJob f = job;
             f.src = job.src + pos;
             f.dst = job.dst + total;
             f.csize = fs;
             f.out_len = fc;
-            q[base + k] = f;
+            q[at++] = f;
+            room--;
+            nf++;
             pos += fs;
             total += fc;
+            if (pos >= job.csize) break;
+            if (!zstd_frame_extent_fast(job.src, job.csize, pos, &fs, &fc) || fc > job.out_len - total) {
+                ok = false;
+                break;
+            }
         }
-        q[j].codec = CODEC_SPLIT;
+        ok = ok && nf >= 2 && total == job.out_len && pos == job.csize;
+#pragma unroll
+        for (uint32_t k = 0; k < MAX_BATCHES; k++) {   // the unused tail of the last batch — or, on failure, every slot of mine
+            if (k >= nb) break;
+            const uint32_t want = SPLIT_BATCH * (k + 1);
+            const uint32_t lo = ok ? (k + 1 == nb ? at : bases[k] + want) : bases[k];
+            for (uint32_t i = lo; i < bases[k] + want; i++) q[i].codec = CODEC_SPLIT;
+        }
+        if (ok) q[j].codec = CODEC_SPLIT;
     }
 }
 // true in every thread of the LAST workgroup of the grid to get here (all threads of every workgroup must call it)
@@ -809,13 +861,13 @@ union InflateLds {   // the one-wave decoder's workspace and the lane-per-stream
     ZHufLanes hl;
 };
 __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const uint32_t* count, Status* st,
-                                                uint8_t* zlit, uint64_t* zrec, RelCtx rc) {
+                                                uint8_t* zlit, uint64_t* zrec, RelCtx rc, uint32_t cap) {
     __shared__ InflateLds u;
     ZWork& wk = u.wk;
     __shared__ ZLaneTabs zt;
     __shared__ uint8_t s_win[64 * 10 + 8];
     __shared__ uint16_t s_pos[65];
-    const uint32_t njobs = *count;
+    const uint32_t njobs = min(*count, cap);   // (k_zstd_split may have asked for slots beyond the queue's end)
     const uint32_t lane = threadIdx.x;
     if (threadIdx.x == 0) wk.pre_built = 0;
     uint8_t* my_lit = zlit + (uint64_t)blockIdx.x * ZLIT_STRIDE;
@@ -962,9 +1014,9 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
 // LZ4 blocks: one wave per block from a pool of waves that loops over the job queue (sb_lz4.h: compressed
 // bytes and an 8 KiB output window in LDS, speculative 64-position token parse, matches batched)
 constexpr uint32_t LZ4_POOL = 4096;
-__global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min) {
+__global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min, uint32_t cap) {
     __shared__ Lz4DecLds lds;
-    const uint32_t njobs = *count;
+    const uint32_t njobs = min(*count, cap);
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
         if (j.codec != SB_CODEC_LZ4 || j.csize >= big_min) continue;
@@ -975,9 +1027,9 @@ __global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, cons
 // LZ4 blocks of LZ4_BIG_MIN compressed bytes and more: one workgroup per block (sb_lz4_big.h: sequence starts and match
 // chains by pointer doubling).  Launched only when a page of the call is that long (DecodeArgs.lz4_big_min).
 constexpr uint32_t LZ4_BIG_POOL = 4096;   // (1024 are resident; blocks differ in size by 20 x, so a workgroup per block — handed out by the hardware as slots free — beats a strided pool)
-__global__ void __launch_bounds__(LB_T, 4) k_inflate_lz4_big(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min) {
+__global__ void __launch_bounds__(LB_T, 4) k_inflate_lz4_big(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min, uint32_t cap) {
     __shared__ Lz4BigLds lds;
-    const uint32_t njobs = *count;
+    const uint32_t njobs = min(*count, cap);
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
         if (j.codec != SB_CODEC_LZ4 || j.csize < big_min) continue;
@@ -2361,8 +2413,8 @@ static void launch_zb(sb_ctx* ctx, const DecodeArgs& a) {
     (void)hipMemsetAsync(a.zb.counters, 0, 16 * sizeof(uint32_t), s);
     {
         KScope k(ctx, "zb_scan");
-        zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(a.jobs_a, a.job_counts, a.zb, 0u);
-        if (a.jobs_z) zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(a.jobs_z, a.job_counts + 10, a.zb, 1u);
+        zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(a.jobs_a, a.job_counts, a.zb, 0u, a.job_cap_a);
+        if (a.jobs_z) zb_scan<<<std::min<uint32_t>((a.job_cap_a + WG - 1) / WG, 1024u), WG, 0, s>>>(a.jobs_z, a.job_counts + 10, a.zb, 1u, a.job_cap_a);
         zb_hdr<<<std::min<uint32_t>((a.zb.block_cap + WG - 1) / WG, 1024u), WG, 0, s>>>(a.zb);
     }
     // literals and sequences of a block are independent of each other (different pools): side by side on two streams
@@ -2396,15 +2448,15 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     launch_zb(ctx, a);
     {
         KScope k(ctx, K_INFLATE_A);
-        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a));
+        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
     }
     {
         KScope k(ctx, "k_inflate_lz4");
-        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min);
+        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
     }
     if (a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big");
-        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min);
+        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
     }
     {
         KScope k(ctx, K_PLAN);
@@ -2418,17 +2470,17 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     if (a.jobs_z) {   // queue Z: the frames the pipeline took are executed now that every page has its place; the rest by k_inflate
         launch_zb_exec(ctx, a, 1u);
         KScope k(ctx, "k_inflate(zstd values)");
-        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_z, a.job_counts + 10, a.status, a.zlit, a.zrec, rel_ctx(a));
+        k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_z, a.job_counts + 10, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
     }
     if (any_binary) {
         KScope k(ctx, K_INFLATE_B);
-        k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec, rel_ctx(a));
+        k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
         KScope k2(ctx, "k_inflate_lz4(values)");
-        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min);
+        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
     }
     if (any_binary && a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big(values)");
-        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min);
+        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
     }
     // the three expand kernels work on disjoint pages (page-level RLE, tiles of primitives, tiles of binary columns): side
     // by side on streams of their own when the call has both kinds of columns (a mixed schema), joined before the call ends
@@ -2456,8 +2508,8 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
     k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, a.status);
     launch_zb(ctx, a);
-    k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a));
-    k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu);
+    k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
+    k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu, a.job_cap_a);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
 }

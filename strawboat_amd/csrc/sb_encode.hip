@@ -1231,7 +1231,7 @@ __device__ __forceinline__ uint32_t snappy_compress_block_wg(const uint8_t* src,
 __device__ uint32_t zstd_store_frame_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t* s4);
 
 __device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, uint32_t chunk_bytes, const uint8_t* src, uint32_t n,
-                                     uint32_t nch, uint8_t* dst, uint32_t* sh);
+                                     uint32_t nch, uint8_t* dst, uint32_t* sh, uint32_t part = 0, uint32_t parts = 1);
 // An LZ4 block inside a page kernel (the u32 indices of a Dict page whose row count is not a multiple of 128: 68 KB on the
 // 16 960-row last page of a 1 M-row column, 2 ms through one wave while the other three wait): three waves compress a
 // third of the block each into slots of `tmp` (HBM), then the workgroup joins them like k_enc_lz4_stitch does.
@@ -2261,13 +2261,20 @@ struct PrimPartials {
     uint32_t vote_n;
 };
 
+// numbers decide_prim would otherwise obtain by walking the page with one workgroup (long pages: sb_select_big.h)
+struct PrimCounts {
+    bool have_uq, have_mc;
+    uint32_t uq, mc;   // distinct keys (or any value above Dict's limit), rows equal to the vote's candidate
+};
+
 // gen_stats' reductions + choose_compressor (integer/mod.rs:231-308, double/mod.rs:231-307): the part of
 // the selector that does not depend on how the page was streamed
 template <int W, class GetVal>
 __device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, uint32_t nk, const SelectOpts& o,
                                 const SelScratch& sc, const PrimPartials<W>& pp, bool want_set, bool want_vote, uint32_t s_kcnt,
                                 uint32_t s_ksent, const SamplePre<W>& pre_rle, const SamplePre<W>& pre_bp,
-                                const SamplePre<W>& pre_dbp, const SamplePre<W>& pre_patas, bool prefetched = true) {
+                                const SamplePre<W>& pre_dbp, const SamplePre<W>& pre_patas, bool prefetched = true,
+                                const PrimCounts* pc = nullptr) {
     auto valid = [&](uint64_t i) { return vv.get(i); };
     (void)valid;
     const int t = threadIdx.x;
@@ -2377,9 +2384,13 @@ __device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
                 if constexpr (SMALL) {
                     mc = 0;
                     if ((double)maj_n + 1.0 >= 0.8 * tuple_count) {  // only then can a key hold >= 90 % of the rows
-                        uint32_t mine = 0;
-                        for (uint64_t i = t; i < N; i += WG) mine += k64(key(i)) == maj_k ? 1 : 0;
-                        mc = wg_sum32(mine, s4);
+                        if (pc && pc->have_mc) {
+                            mc = pc->mc;
+                        } else {
+                            uint32_t mine = 0;
+                            for (uint64_t i = t; i < N; i += WG) mine += k64(key(i)) == maj_k ? 1 : 0;
+                            mc = wg_sum32(mine, s4);
+                        }
                     }
                 } else {
                     mc = majority_count(kops, N, sc.s_misc);
@@ -2391,7 +2402,7 @@ __device__ uint32_t decide_prim(GetVal getv, const ValidView& vv, uint64_t N, ui
             case SB_CODEC_DICT: {  // dict.rs:109-120
                 if (N < 3) break;
                 const uint32_t limit = (uint32_t)((N - 1) / 3);  // largest unique with unique*3 < N
-                const uint32_t uq = all_equal ? 1u : (set_ok ? set_unique : distinct_count(kops, N, limit, sc, nullptr));
+                const uint32_t uq = all_equal ? 1u : set_ok ? set_unique : (pc && pc->have_uq) ? pc->uq : distinct_count(kops, N, limit, sc, nullptr);
                 if ((uint64_t)uq * 3 >= N) break;
                 uint64_t after = (uint64_t)uq * W + N * (uint64_t)(bits_needed(uq) / 8);
                 after += N * 2 / 128;
@@ -3240,6 +3251,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
 // codec choice per page (adaptive mode): one workgroup per page, one instance per KIND
 #include "sb_select_rle.h"
 #include "sb_select_runs.h"
+#include "sb_select_big.h"
 
 // Binary pages hash strings: a probe that misses the LDS tier costs a random HBM access per row (13 GB of traffic for
 // 1.15 GB of C3 input when the table sat in HBM), so their LDS table is 16 Ki slots (~10 000 distinct strings per page).
@@ -3500,6 +3512,7 @@ __global__ void __launch_bounds__(WG, 4) k_enc_select_rle(EncodeArgs a) {
     if (c.width != (uint32_t)KIND || (c.fkind != 0) != (FK != 0)) return;
     if (a.codecs[page] != CODEC_PENDING) return;  // k_enc_select_runs (launched before) took the page
     const uint64_t N = p.rows;
+    if (N >= SEL_BIG_ROWS) return;   // long pages: section-parallel (sb_select_big.h, launched after this kernel)
     SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
     SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
     if (sc.gtab) {  // the Dict aux area starts with a table of pow2 >= 2N slots
@@ -4690,7 +4703,9 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
     const LzBlocks b = lz4_page_blocks(a, c, p);
     if (!lz4_page_chunked(a, bc, page, b, p.zst_off)) return;
     const uint64_t N = p.rows;
-    if (c.nullable) {
+    // gridDim.y workgroups share the staging loops of a long page; the def levels and the chunk list are part 0's
+    const uint64_t t0 = (uint64_t)blockIdx.y * WG + threadIdx.x, tstep = (uint64_t)gridDim.y * WG;
+    if (c.nullable && blockIdx.y == 0) {
         uint8_t* bits = def_header(page_slot(a, c, p), N);
         def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
     }
@@ -4698,7 +4713,7 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
     if (c.ptype == SB_TYPE_BOOLEAN) {
         if (b.stage_a) {   // bitmap re-packed from bit 0 (boolean/mod.rs:44-54)
             const uint64_t boff = c.values_bit_offset + p.row0, total_bits = c.values_bit_offset + c.rows;
-            for (uint64_t i = threadIdx.x; i < b.n_a; i += WG) {
+            for (uint64_t i = t0; i < b.n_a; i += tstep) {
                 uint32_t w = bits32(c.values, boff + i * 8, total_bits);
                 const uint64_t nb = min((uint64_t)8, N - i * 8);
                 if (nb < 8) w &= (1u << nb) - 1;
@@ -4708,13 +4723,14 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
     } else if (b.src_b) {  // offsets re-based to 0 (binary/mod.rs:45-55)
         const uint32_t ow = c.width;
         const uint8_t* offs = c.offsets + p.row0 * ow;
-        for (uint64_t i = threadIdx.x; i <= N; i += WG) {
+        for (uint64_t i = t0; i <= N; i += tstep) {
             if (ow == 4)
                 stu32(stage + i * 4, (uint32_t)(ldu32(offs + i * 4) - b.first));
             else
                 stu64(stage + i * 8, ldu64(offs + i * 8) - b.first);
         }
     }
+    if (blockIdx.y) return;
     const uint32_t na = (b.n_a + a.lzc_chunk - 1) / a.lzc_chunk, nb = (b.n_b + a.lzc_chunk - 1) / a.lzc_chunk;
     if (threadIdx.x == 0) {
         uint32_t base = atomicAdd(a.lzc_count, na + nb);
@@ -4790,17 +4806,20 @@ __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
 
 // the frames [chunk0, chunk0 + nch) of the pieces of src[0, n) back to back; returns their size.  sh: 2 * WG + 8 words.
 // (SNAPPY: the stream's uvarint length followed by the chunks' elements — the same concatenation)
+// part / parts: the workgroups (blockIdx.y) that share one block — every one of them computes all offsets, each copies the
+// chunks k with k % parts == part; the fixed bytes are written by part 0
 template <bool SNAPPY>
-__device__ uint32_t zstd_stitch_frame(const EncodeArgs& a, uint32_t n, uint32_t chunk0, uint32_t nch, uint8_t* dst, uint32_t* sh) {
+__device__ uint32_t zstd_stitch_frame(const EncodeArgs& a, uint32_t n, uint32_t chunk0, uint32_t nch, uint8_t* dst, uint32_t* sh,
+                                      uint32_t part = 0, uint32_t parts = 1) {
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t *s_off = sh, *s_len = sh + WG, *s_w = sh + 2 * WG;
     uint32_t run = 0;
     if (SNAPPY) {
-        if (t == 0) snappy_put_preamble(dst, n);
+        if (t == 0 && part == 0) snappy_put_preamble(dst, n);
         run = snappy_preamble_bytes(n);
         if (nch == 0) return run;
     } else if (nch == 0) {   // an empty buffer: one frame with one empty raw block
-        if (t == 0) {
+        if (t == 0 && part == 0) {
             const uint32_t h = ze_frame_header(dst, 0);
             dst[h] = 1; dst[h + 1] = 0; dst[h + 2] = 0;
         }
@@ -4822,16 +4841,37 @@ __device__ uint32_t zstd_stitch_frame(const EncodeArgs& a, uint32_t n, uint32_t 
         __syncthreads();
         run += tot;
         const uint32_t cnt = min((uint32_t)WG, nch - b0);
-        for (uint32_t j = 0; j < cnt; j++) wg_copy(dst + s_off[j], a.lzc_pool + (uint64_t)(chunk0 + b0 + j) * LZC_SLOT + 16, s_len[j]);
+        for (uint32_t j = (part + parts - b0 % parts) % parts; j < cnt; j += parts)
+            wg_copy(dst + s_off[j], a.lzc_pool + (uint64_t)(chunk0 + b0 + j) * LZC_SLOT + 16, s_len[j]);
         __syncthreads();
     }
     return run;
 }
 
+// lz4_put_head by a whole workgroup (every thread calls it): a literal run of 48 MB has a 188 KB length extension
+// (part / parts: the workgroups that share it)
+__device__ __forceinline__ void lz4_put_head_wg(uint8_t* o, uint32_t lit, uint32_t mcode, uint32_t part = 0, uint32_t parts = 1) {
+    if (lit < 15 + 255 * 64) {   // short: one lane
+        if (threadIdx.x == 0 && part == 0) lz4_put_head(o, lit, mcode);
+        return;
+    }
+    const uint32_t r = lit - 15, n255 = r / 255;
+    if (threadIdx.x == 0 && part == 0) {
+        o[0] = (uint8_t)(0xF0u | min(mcode, 15u));
+        o[1 + n255] = (uint8_t)(r - n255 * 255);
+    }
+    const uint32_t per = ((n255 + parts - 1) / parts + 15) & ~15u;
+    const uint32_t b0 = min(n255, per * part), b1 = min(n255, b0 + per);
+    const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const uint32_t n16 = (b1 - b0) / 16;
+    for (uint32_t i = threadIdx.x; i < n16; i += WG) stu128(o + 1 + b0 + 16 * i, ff);
+    for (uint32_t i = b0 + 16 * n16 + threadIdx.x; i < b1; i += WG) o[1 + i] = 255;
+}
+
 // joins the nch chunks (slots of slot_stride bytes at pool: u32 size | u32 tail anchor | 8 pad | sequences) of the block
 // src[0, n) at dst; returns the block size.  sh: 5 * WG + 8 words.
 __device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, uint32_t chunk_bytes, const uint8_t* src, uint32_t n,
-                                     uint32_t nch, uint8_t* dst, uint32_t* sh) {
+                                     uint32_t nch, uint8_t* dst, uint32_t* sh, uint32_t part, uint32_t parts) {
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t *s_off = sh, *s_cs = sh + WG, *s_ll = sh + 2 * WG, *s_e1 = sh + 3 * WG, *s_len = sh + 4 * WG, *s_w = sh + 5 * WG;
     uint32_t run_base = 0;    // bytes of the block written by the chunks before this batch
@@ -4889,7 +4929,7 @@ __device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, 
         run_base += tot;
         run_carry = max(run_carry, bmax);
         const uint32_t cnt = min((uint32_t)WG, nch - b0);
-        for (uint32_t j = 0; j < cnt; j++) {
+        for (uint32_t j = (part + parts - b0 % parts) % parts; j < cnt; j += parts) {
             const uint32_t len_j = s_len[j];
             if (!len_j) continue;
             const uint8_t* sl = pool + (uint64_t)(b0 + j) * slot_stride + 16;
@@ -4900,15 +4940,17 @@ __device__ uint32_t lz4_stitch_block(const uint8_t* pool, uint32_t slot_stride, 
                 continue;
             }
             const uint32_t ll_j = s_ll[j], e1_j = s_e1[j], nl = carry_j + ll_j, hb = lz4_head_bytes(nl);
-            if (t == 0) lz4_put_head(d, nl, sl[0] & 15u);
+            lz4_put_head_wg(d, nl, sl[0] & 15u);
             wg_copy(d + hb, src + s_cs[j], nl);
             wg_copy(d + hb + nl, sl + 1 + e1_j + ll_j, len_j - 1 - e1_j - ll_j);
         }
         __syncthreads();
     }
-    const uint32_t lit = n - run_carry, hb = lz4_head_bytes(lit);   // the literals-only last sequence
-    if (t == 0) lz4_put_head(dst + run_base, lit, 0);
-    wg_copy(dst + run_base + hb, src + run_carry, lit);
+    const uint32_t lit = n - run_carry, hb = lz4_head_bytes(lit);   // the literals-only last sequence (the whole block when
+    lz4_put_head_wg(dst + run_base, lit, 0, part, parts);            // nothing matched): shared like the chunks
+    const uint32_t per = ((lit + parts - 1) / parts + 63) & ~63u;
+    const uint32_t l0 = min(lit, per * part), l1 = min(lit, l0 + per);
+    if (l1 > l0) wg_copy(dst + run_base + hb + l0, src + run_carry + l0, l1 - l0);
     return run_base + hb + lit;
 }
 
@@ -4927,20 +4969,22 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_stitch(EncodeArgs a) {
     const uint64_t N = p.rows;
     const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
     uint8_t* blk = slot + pos;
-    const uint32_t s1 = zstd ? zstd_stitch_frame<false>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh)
-                        : snap ? zstd_stitch_frame<true>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh)
-                             : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_a, b.n_a, pl.n_a, blk + 9, sh);
-    if (threadIdx.x == 0) put_hdr9(blk, codec, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
+    // gridDim.y workgroups share the page's chunks (few pages of many chunks: a one-page column)
+    const uint32_t part = blockIdx.y, parts = gridDim.y;
+    const uint32_t s1 = zstd ? zstd_stitch_frame<false>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh, part, parts)
+                        : snap ? zstd_stitch_frame<true>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh, part, parts)
+                             : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_a, b.n_a, pl.n_a, blk + 9, sh, part, parts);
+    if (threadIdx.x == 0 && part == 0) put_hdr9(blk, codec, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
     uint64_t length = pos + 9 + s1;
     if (b.src_b) {
         uint8_t* b2 = blk + 9 + s1;
-        const uint32_t s2 = zstd ? zstd_stitch_frame<false>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh)
-                            : snap ? zstd_stitch_frame<true>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh)
-                                 : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_b, b.n_b, pl.n_b, b2 + 9, sh);
-        if (threadIdx.x == 0) put_hdr9(b2, codec, s2, b.n_b);
+        const uint32_t s2 = zstd ? zstd_stitch_frame<false>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh, part, parts)
+                            : snap ? zstd_stitch_frame<true>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh, part, parts)
+                                 : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_b, b.n_b, pl.n_b, b2 + 9, sh, part, parts);
+        if (threadIdx.x == 0 && part == 0) put_hdr9(b2, codec, s2, b.n_b);
         length += 9 + s2;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && part == 0) {
         EncOut o{length, 0, slot, codec, 0};
         a.outs[page] = o;
     }
@@ -5375,6 +5419,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         plan.col_first.assign(n, 0);
         plan.col_pages.assign(n, 0);
         plan.hro.assign(n, 0);
+        plan.big4.clear();
+        plan.big8.clear();
+        plan.big_secs4 = plan.big_secs8 = 0;
     }
 
     size_t scratch_off = 0;
@@ -5432,6 +5479,13 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             p.icodec = opts->force_index_codec;
             p.seed = page_seed_of(opts->rng_seed, c.first_page_index + k);
             p.direct = direct ? 1 : 0;
+            if (adaptive && !bin && N >= SEL_BIG_ROWS && (d.width == 4 || d.width == 8) && c.physical_type != SB_TYPE_BOOLEAN &&
+                c.physical_type != SB_TYPE_NULL) {
+                const uint32_t secs = (uint32_t)((N + big_sec_rows(N) - 1) / big_sec_rows(N));
+                (d.width == 4 ? plan.big4 : plan.big8).push_back((uint32_t)pi);
+                uint32_t& mx = d.width == 4 ? plan.big_secs4 : plan.big_secs8;
+                mx = std::max(mx, secs);
+            }
             if (direct) {
                 p.direct_off = direct_off;
                 const uint64_t body = c.physical_type == SB_TYPE_BOOLEAN
@@ -5560,6 +5614,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (!hit) {   // the page table goes to the plan's own device buffer and stays there
         e = hipMemcpyAsync(plan.pages.p, hp, P * sizeof(EncPage), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return check_hip(ctx, e, "page table upload");
+        if (const size_t nb = plan.big4.size() + plan.big8.size()) {   // (pageable source: the copy is staged before the call returns)
+            if (!ensure(ctx, plan.big, nb * sizeof(uint32_t) + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(long-page list) failed");
+            std::vector<uint32_t> both(plan.big4);
+            both.insert(both.end(), plan.big8.begin(), plan.big8.end());
+            e = hipMemcpyAsync(plan.big.p, both.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);   // (`both` goes out of scope; plan misses are rare)
+            if (e != hipSuccess) return check_hip(ctx, e, "long-page list upload");
+        }
         plan.key = plan_key;
         plan.key_words = key_words;
         plan.n = n;
@@ -5695,6 +5757,31 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     else
                         k_enc_select_rle<8, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
                 }
+                // long pages the run-level selector left: section-parallel statistics, then the same decision
+                const uint32_t nbig = (uint32_t)(kd == 4 ? plan.big4.size() : plan.big8.size());
+                if (nbig && aa.page_base == 0) {
+                    const uint32_t* list = (const uint32_t*)plan.big.p + (kd == 4 ? 0 : plan.big4.size());
+                    const dim3 sg(kd == 4 ? plan.big_secs4 : plan.big_secs8, nbig);
+                    {
+                        KScope k(ctx, "k_sel_big_sec");
+                        if (kd == 4) k_sel_big_sec<4><<<sg, WG, 0, st>>>(aa, list);
+                        else k_sel_big_sec<8><<<sg, WG, 0, st>>>(aa, list);
+                    }
+                    {
+                        KScope k(ctx, "k_sel_big_merge");
+                        if (kd == 4) k_sel_big_merge<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                        else k_sel_big_merge<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                    }
+                    {
+                        KScope k(ctx, "k_sel_big_count");
+                        k_sel_big_clear<<<sg, WG, 0, st>>>(aa, list);
+                        if (kd == 4) k_sel_big_count<4><<<sg, WG, 0, st>>>(aa, list);
+                        else k_sel_big_count<8><<<sg, WG, 0, st>>>(aa, list);
+                    }
+                    KScope k(ctx, "k_sel_big_decide");
+                    if (kd == 4) k_sel_big_decide<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                    else k_sel_big_decide<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                }
                 return;
             }
             char nm[48];
@@ -5781,13 +5868,15 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const bool basic_comp = dc == SB_CODEC_LZ4 || dc == SB_CODEC_ZSTD || dc == SB_CODEC_SNAPPY;
         if (nested ? (wave_adaptive ? dc == SB_CODEC_NONE : wave_codec == SB_CODEC_NONE) : any_tiles) {
             KScope k(ctx, K_ENC_TILES);
-            k_enc_emit_tiles<<<dim3((uint32_t)P, wave_adaptive ? 1u : (uint32_t)max_tiles), WG, 0, s>>>(aa, (uint32_t)max_tiles);
+            // (adaptive: few pages stay plain, so one workgroup per page looks — unless the pages are few and long)
+            const uint32_t ty = wave_adaptive ? (uint32_t)std::min<uint64_t>(max_tiles, std::max<uint64_t>(1, 2048 / P)) : (uint32_t)max_tiles;
+            k_enc_emit_tiles<<<dim3((uint32_t)P, ty), WG, 0, s>>>(aa, (uint32_t)max_tiles);
         }
         if (nested ? (wave_adaptive ? basic_comp : (wave_codec >= 1 && wave_codec <= 3)) : any_lz4) {
             if (!nested && aa.lzc_plan) {   // blocks of more than one chunk: one wave per chunk, then joined
                 {
                     KScope k(ctx, "k_enc_lz4_plan");
-                    k_enc_lz4_plan<<<(uint32_t)P, WG, 0, s>>>(aa);
+                    k_enc_lz4_plan<<<dim3((uint32_t)P, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, max_tiles / 8), std::max<uint64_t>(1, 1024 / P))), WG, 0, s>>>(aa);
                 }
                 if (aa.zpar_scratch) {
                     KScope k(ctx, "k_enc_zstd_chunks");
@@ -5797,7 +5886,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     k_enc_lz4_chunks<<<(uint32_t)std::min<uint64_t>(aa.lzc_cap, 1u << 20), 64, 0, s>>>(aa);
                 }
                 KScope k(ctx, "k_enc_lz4_stitch");
-                k_enc_lz4_stitch<<<(uint32_t)P, WG, 0, s>>>(aa);
+                k_enc_lz4_stitch<<<dim3((uint32_t)P, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, max_chunks / 4), std::max<uint64_t>(1, 2048 / P))), WG, 0, s>>>(aa);
             }
             KScope k(ctx, K_ENC_LZ4);
             k_enc_emit_lz4<false><<<(uint32_t)P, WG, 0, s>>>(aa);

@@ -146,6 +146,11 @@ struct sb_ctx {
         std::vector<uint32_t> col_first, col_pages;
         std::vector<uint64_t> hro;
         sb::DevBuf pages;   // EncPage[P] on the device
+        // long pages of 4- / 8-byte values (adaptive calls): selected section-parallel (sb_select_big.h); page indices on
+        // the device as [big4 | big8], grid.x = the most sections any of them has
+        std::vector<uint32_t> big4, big8;
+        uint32_t big_secs4 = 0, big_secs8 = 0;
+        sb::DevBuf big;
     } enc_plan;
     std::vector<uint64_t> enc_plan_probe;   // the key words of the call at hand
     // side streams: kernels of a call that work on disjoint pages (the selector / emit chains of different column kinds, the

@@ -1,0 +1,620 @@
+// strawboat-hip: adaptive selection of LONG pages, section-parallel (included by sb_encode.hip inside namespace sb, after
+// sb_select_runs.h).
+//
+// The reference's default paging is one page per column and chunk (src/write/common.rs:54-58: max_page_size = None), so a
+// page can hold millions of rows.  The page selectors above stream a page through ONE workgroup (3 000 latency-bound
+// chunk iterations for 12 M rows: 60-85 ms), and when the page holds more distinct values than the LDS set takes they
+// count them exactly on an HBM table — still one workgroup, one probe chain at a time.  Pages of SEL_BIG_ROWS rows or more
+// (4- and 8-byte values) go through these kernels instead; the choice is decide_prim's, fed with the same statistics:
+//
+//   k_sel_big_sec    (sections x pages)   gen_stats of one section of <= 256 per page: flags, null count, typed maximum,
+//                                         Boyer-Moore vote, the section's distinct keys (LDS set, <= 2048, dumped to HBM)
+//   k_sel_big_merge  (1 workgroup / page) the sections' partials merged, the key sets united in LDS; when neither an exact
+//                                         distinct count nor a majority count is missing the codec is chosen here
+//   k_sel_big_clear  (sections x pages)   pages that need the HBM table: cleared
+//   k_sel_big_count  (sections x pages)   every section inserts its rows into the page's table (agent-scope CAS, the count
+//                                         in the page record; all sections stop once it passes Dict's limit) and counts
+//                                         the rows equal to the vote's candidate
+//   k_sel_big_decide (1 workgroup / page) decide_prim with those two numbers
+//
+// The sections' records live in the page's own output slot (nothing has been written there yet: speculative RLE is off
+// for these pages; >= 12 bytes of slot per row against 16.5 KB per section of >= 16 384 rows).  integer/mod.rs:179-308,
+// double/mod.rs:178-307.
+constexpr uint64_t SEL_BIG_ROWS = 1ull << 18;
+constexpr uint32_t SEL_BIG_SECTIONS = 256;    // at most, per page
+constexpr uint32_t SEL_BIG_MIN_SEC = 16384;   // rows of a section: a power of two, at least this
+constexpr uint32_t BIG_KCAP = SEL_LDS_SLOTS / 4;   // keys of an LDS set (KSLOTS / 2 of the page selectors)
+
+__host__ __device__ __forceinline__ uint64_t big_sec_rows(uint64_t N) {
+    uint64_t r = SEL_BIG_MIN_SEC;
+    while (r * SEL_BIG_SECTIONS < N) r <<= 1;
+    return r;
+}
+struct BigSec {   // 64 bytes, followed by the section's keys (BIG_KCAP x u64)
+    uint32_t flags, nulls, vote_n, kcnt;   // flags: neq0 | unsorted << 1 | neg << 2; kcnt > BIG_KCAP: the set overflowed
+    uint64_t tmax, vote_k;
+    uint32_t ksent, pad[7];
+};
+struct BigPage {   // 256 bytes at the start of the slot
+    uint32_t flags, nulls, maj_n, set_ok;
+    uint64_t tmax, maj_k;
+    uint32_t set_unique, ksent, need_uq, need_mc;
+    uint32_t uq, mc;   // k_sel_big_count's results (atomics)
+    uint32_t pad[50];
+};
+constexpr uint32_t BIG_SEC_STRIDE = 64 + BIG_KCAP * 8;
+static_assert(sizeof(BigSec) == 64 && sizeof(BigPage) == 256, "records of the long-page selector");
+__device__ __forceinline__ BigPage* big_page_rec(uint8_t* slot) { return (BigPage*)slot; }
+__device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { return (BigSec*)(slot + 256 + (uint64_t)s * BIG_SEC_STRIDE); }
+
+__device__ __forceinline__ bool big_page_of(const EncodeArgs& a, const uint32_t* big, int W, uint32_t* page, EncPage* p, EncCol* c) {
+    *page = big[blockIdx.y];
+    *p = a.pages[*page];
+    *c = a.cols[p->col];
+    return (int)c->width == W && a.codecs[*page] == CODEC_PENDING;   // (k_enc_select_runs may have taken the page)
+}
+
+// one step of the merge of two Boyer-Moore states
+__device__ __forceinline__ void vote_merge(unsigned long long& k0, uint32_t& n0, unsigned long long k1, uint32_t n1) {
+    if (!n1) return;
+    if (n0 == 0) {
+        k0 = k1;
+        n0 = n1;
+    } else if (k0 == k1) {
+        n0 += n1;
+    } else if (n1 > n0) {
+        k0 = k1;
+        n0 = n1 - n0;
+    } else {
+        n0 -= n1;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint32_t* big) {
+    constexpr int K = 16;
+    constexpr uint32_t CHUNK = WG * K;
+    constexpr uint64_t SENT = ~0ull;
+    constexpr uint32_t KSLOTS = SEL_LDS_SLOTS / 2;
+    constexpr uint32_t CBUF = 96;
+    using KE = typename std::conditional<(W == 8), unsigned long long, uint32_t>::type;
+    __shared__ unsigned long long kset[KSLOTS];
+    __shared__ KE cbufs[4 * CBUF];
+    __shared__ unsigned long long s_vk[WG];
+    __shared__ uint32_t s_vn[WG];
+    __shared__ uint32_t s4[4];
+    __shared__ uint32_t s_kcnt, s_ksent, s_dump;
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (!big_page_of(a, big, W, &page, &p, &c)) return;
+    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    const uint64_t s0 = (uint64_t)blockIdx.x * SR;
+    if (s0 >= N) return;
+    const uint64_t s1 = min(N, s0 + SR);
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint8_t* vals = c.values + p.row0 * W;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    const uint32_t nk = c.nk;
+    const bool is_float = nk >= NK_F32;
+    const uint32_t forb = a.forbidden | p.forb_extra;
+    auto getv = [=](uint64_t i) { return ld_val<W>(vals + i * W); };
+    auto k64 = [&](const Val<W>& k) {
+        uint64_t x = 0;
+        __builtin_memcpy(&x, &k, W);
+        return x;
+    };
+    const Val<W> k0 = stat_key<W>(getv(0), nk);
+    uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, nulls = 0;
+    Val<W> tmax = getv(0);
+    uint64_t vote_k = 0;
+    uint32_t vote_n = 0;
+    const bool want_set = !((forb >> SB_CODEC_DICT) & 1) && N >= 3;
+    const bool want_vote = !((forb >> SB_CODEC_FREQ) & 1);
+    for (uint32_t i = t; i < KSLOTS; i += WG) kset[i] = SENT;
+    if (t == 0) {
+        s_kcnt = 0;
+        s_ksent = 0;
+        s_dump = 0;
+    }
+    KE* cbuf = cbufs + w * CBUF;
+    __syncthreads();
+    uint32_t ccount = 0;
+    auto flush = [&]() {
+        for (uint32_t base = 0; base < ccount; base += 64) {
+            const bool act = base + lane < ccount;
+            const uint64_t rawx = act ? (uint64_t)cbuf[base + lane] : 0;
+            Val<W> rv;
+            __builtin_memcpy(&rv, &rawx, W);
+            const Val<W> kk = stat_key<W>(rv, nk);
+            const uint64_t x = k64(kk);
+            if (act && !bits_eq<W>(kk, k0)) f_neq0 = 1;
+            if (want_set && act && s_kcnt <= BIG_KCAP) {
+                if (x == SENT) {
+                    s_ksent = 1;
+                } else {
+                    uint32_t h = (((uint32_t)x ^ (uint32_t)(x >> 32) * 0x85EBCA6Bu) * 0x9E3779B1u >> 15) & (KSLOTS - 1);
+                    for (;;) {
+                        unsigned long long cur = kset[h];
+                        if (cur == x) break;
+                        if (cur == SENT) {
+                            const unsigned long long old = atomicCAS(&kset[h], (unsigned long long)SENT, (unsigned long long)x);
+                            if (old == SENT) {
+                                atomicAdd(&s_kcnt, 1u);
+                                break;
+                            }
+                            if (old == x) break;
+                        }
+                        h = (h + 1) & (KSLOTS - 1);
+                    }
+                }
+            }
+        }
+        ccount = 0;
+    };
+    const uint64_t vtotal = vv.off + N;
+    for (uint64_t cb = s0; cb < s1; cb += CHUNK) {
+        const uint32_t n = (uint32_t)min((uint64_t)CHUNK, s1 - cb);
+        const uint32_t r0 = (uint32_t)t * K;
+        const uint32_t mine = r0 < n ? min((uint32_t)K, n - r0) : 0u;
+        Val<W> v[K];
+        if (r0 + K <= n) {
+            constexpr int NV = K * W / 16;
+            u32x4 q[NV];
+#pragma unroll
+            for (int u = 0; u < NV; u++) q[u] = ldu128(vals + (cb + r0) * W + 16 * u);
+            __builtin_memcpy(v, q, K * W);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; j++) v[j] = getv(cb + (r0 + j < n ? r0 + j : n - 1));
+        }
+        VWord vw = vword_issue(vv.bits, vv.off + cb + r0, vtotal, mine);
+        if (!mine) vw.mask = 0;
+        // the row before my first one (lane 0 of a wave: fetched — it belongs to another wave, chunk or section)
+        Val<W> pvrow = shfl_val<W>(v[K - 1], (lane + 63) & 63);
+        if (lane == 0) pvrow = getv(cb + r0 > 0 ? min(cb + r0 - 1, N - 1) : 0);
+        const bool has_prev_row = cb + r0 > 0;
+        const uint32_t m = vw.word();
+        nulls += mine - (uint32_t)__popc(m);
+        uint32_t sbm = 0;   // rows whose key differs from the row before (null slots included)
+        {
+            Val<W> pk = stat_key<W>(pvrow, nk);
+            Val<W> pv_int = pvrow;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const bool in = (uint32_t)j < mine;
+                const Val<W> kj = stat_key<W>(v[j], nk);
+                if (in && ((j == 0 && !has_prev_row) || !bits_eq<W>(kj, pk))) sbm |= 1u << j;
+                if (!is_float && in) {
+                    if (int_lt<W>(tmax, v[j], nk)) tmax = v[j];
+                    if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(v[j], nk) < 0) f_neg = 1;
+                    if (W == 4 && (j > 0 || has_prev_row) && int_lt<W>(v[j], pv_int, nk)) f_unsorted = 1;
+                }
+                if (want_vote && in) {
+                    const uint64_t x = k64(kj);
+                    if (vote_n == 0) {
+                        vote_k = x;
+                        vote_n = 1;
+                    } else if (vote_k == x) {
+                        vote_n++;
+                    } else {
+                        vote_n--;
+                    }
+                }
+                pk = kj;
+                pv_int = v[j];
+            }
+        }
+        // a section's first row always goes to the section's set (the key may be new to THIS section)
+        if (cb == s0 && t == 0 && mine) sbm |= 1u;
+        {
+            const uint32_t mycnt = (uint32_t)__popc(sbm);
+            const uint32_t incl = wave_incl_scan(mycnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total) {
+                if (ccount + total > CBUF) flush();
+                if (total <= CBUF) {
+                    uint32_t at = ccount + incl - mycnt;
+#pragma unroll
+                    for (int j = 0; j < K; j++)
+                        if ((sbm >> j) & 1) cbuf[at++] = (KE)k64(v[j]);
+                    ccount += total;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < K; j++) {
+                        const bool b = (sbm >> j) & 1;
+                        const uint64_t bm = __ballot(b);
+                        const uint32_t nb = (uint32_t)__popcll(bm);
+                        if (ccount + nb > CBUF) flush();
+                        if (b) cbuf[ccount + mbcnt64(bm)] = (KE)k64(v[j]);
+                        ccount += nb;
+                    }
+                }
+            }
+        }
+    }
+    flush();
+    __syncthreads();
+    // ---- the section's record
+    const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
+    const uint32_t null_count = wg_sum32(nulls, s4);
+    s_vk[t] = vote_k;
+    s_vn[t] = vote_n;
+    __syncthreads();
+    for (int stride = WG / 2; stride > 0; stride >>= 1) {
+        if (t < stride) {
+            unsigned long long kk = s_vk[t];
+            uint32_t nn = s_vn[t];
+            vote_merge(kk, nn, s_vk[t + stride], s_vn[t + stride]);
+            s_vk[t] = kk;
+            s_vn[t] = nn;
+        }
+        __syncthreads();
+    }
+    const uint64_t mk = s_vk[0];
+    const uint32_t mn = s_vn[0];
+    __syncthreads();
+    uint64_t mx = 0;
+    if (!is_float) {   // typed maximum
+        s_vk[t] = k64(tmax);
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                Val<W> x, y;
+                const unsigned long long xa = s_vk[t], ya = s_vk[t + stride];
+                __builtin_memcpy(&x, &xa, W);
+                __builtin_memcpy(&y, &ya, W);
+                if (int_lt<W>(x, y, nk)) s_vk[t] = ya;
+            }
+            __syncthreads();
+        }
+        mx = s_vk[0];
+    }
+    uint8_t* slot = page_slot(a, c, p);
+    BigSec* rec = big_sec_rec(slot, blockIdx.x);
+    const uint32_t kc = want_set ? s_kcnt : 0u;
+    if (t == 0) {
+        BigSec r;
+        __builtin_memset(&r, 0, sizeof r);
+        r.flags = flags;
+        r.nulls = null_count;
+        r.vote_n = want_vote ? mn : 0u;
+        r.vote_k = mk;
+        r.kcnt = kc;
+        r.tmax = mx;
+        r.ksent = want_set ? s_ksent : 0u;
+        *rec = r;
+    }
+    if (want_set && kc <= BIG_KCAP) {   // the keys, in any order
+        unsigned long long* keys = (unsigned long long*)((uint8_t*)rec + 64);
+        for (uint32_t i = t; i < KSLOTS; i += WG) {
+            const unsigned long long x = kset[i];
+            if (x != SENT) keys[atomicAdd(&s_dump, 1u)] = x;
+        }
+    }
+}
+
+// the sections of a page merged: flags, nulls, maximum, vote -> thread 0's PrimPartials (the other threads: neutral)
+template <int W>
+__device__ PrimPartials<W> big_merged_partials(const BigPage& bp, const Val<W>& first) {
+    PrimPartials<W> pp;
+    const bool lead = threadIdx.x == 0;
+    pp.f_neq0 = lead ? (bp.flags & 1u) : 0u;
+    pp.f_unsorted = lead ? ((bp.flags >> 1) & 1u) : 0u;
+    pp.f_neg = lead ? ((bp.flags >> 2) & 1u) : 0u;
+    pp.nulls = lead ? bp.nulls : 0u;
+    pp.tmax = first;
+    if (lead) __builtin_memcpy(&pp.tmax, &bp.tmax, W);
+    pp.vote_k = bp.maj_k;
+    pp.vote_n = lead ? bp.maj_n : 0u;
+    return pp;
+}
+
+template <int W>
+__device__ void big_decide(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, const BigPage& bp, const PrimCounts& pc,
+                           uint32_t* lds_tab, uint32_t* s_misc, uint8_t* sample_mem) {
+    const uint64_t N = p.rows;
+    const uint8_t* vals = c.values + p.row0 * W;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    auto getv = [=](uint64_t i) { return ld_val<W>(vals + i * W); };
+    SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
+    SelScratch sc{lds_tab, s_misc, sample_mem, nullptr, 0};
+    const uint32_t forb = so.forbidden;
+    const bool want_set = !((forb >> SB_CODEC_DICT) & 1) && N >= 3;
+    const bool want_vote = !((forb >> SB_CODEC_FREQ) & 1);
+    const PrimPartials<W> pp = big_merged_partials<W>(bp, getv(0));
+    SamplePre<W> none;
+    __builtin_memset(&none, 0, sizeof none);
+    // (s_kcnt as decide_prim reads it: <= KCAP means "the set holds every key")
+    const uint32_t s_k = bp.set_ok ? bp.set_unique - bp.ksent : BIG_KCAP + 1, s_s = bp.ksent;
+    const uint32_t codec = decide_prim<W>(getv, vv, N, c.nk, so, sc, pp, want_set, want_vote, want_set ? s_k : 0u, want_set ? s_s : 0u, none, none,
+                                          none, none, false, &pc);
+    if (threadIdx.x == 0) {
+        a.codecs[page] = (int32_t)codec;
+        atomicAdd(&a.codec_counts[codec & 31], 1u);
+        if (!has_device_encoder(codec))
+            raise(a.status, SB_ERR_NYI, page, 700 + codec);
+        else if (codec == SB_CODEC_FREQ)
+            atomicAdd(a.freq_count, 1u);
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uint32_t* big) {
+    constexpr uint64_t SENT = ~0ull;
+    constexpr uint32_t KSLOTS = SEL_LDS_SLOTS / 2;
+    __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
+    __shared__ uint32_t s_misc[2 * WG + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * (W + 1) + 16];
+    __shared__ uint32_t s_pref[SEL_BIG_SECTIONS + 1];
+    __shared__ uint32_t s_kcnt;
+    __shared__ BigPage s_bp;
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (!big_page_of(a, big, W, &page, &p, &c)) return;
+    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
+    const int t = threadIdx.x;
+    const uint32_t nk = c.nk;
+    const bool is_float = nk >= NK_F32;
+    const uint32_t forb = a.forbidden | p.forb_extra;
+    const bool want_set = !((forb >> SB_CODEC_DICT) & 1) && N >= 3;
+    const bool want_vote = !((forb >> SB_CODEC_FREQ) & 1);
+    uint8_t* slot = page_slot(a, c, p);
+    uint32_t* s4 = s_misc + 2 * WG;
+    // ---- thread = section
+    BigSec r;
+    __builtin_memset(&r, 0, sizeof r);
+    const bool has = (uint32_t)t < nsec;
+    if (has) r = *big_sec_rec(slot, (uint32_t)t);
+    const uint32_t flags = wg_or32(r.flags, s4);
+    const uint32_t null_count = wg_sum32(r.nulls, s4);
+    const uint32_t ksent = wg_or32(r.ksent, s4);
+    const uint32_t over = wg_or32(has && r.kcnt > BIG_KCAP ? 1u : 0u, s4);
+    unsigned long long* vk = (unsigned long long*)sample_mem;
+    uint32_t* vn = s_misc;
+    vk[t] = r.vote_k;
+    vn[t] = has ? r.vote_n : 0u;
+    __syncthreads();
+    for (int stride = WG / 2; stride > 0; stride >>= 1) {
+        if (t < stride) {
+            unsigned long long kk = vk[t];
+            uint32_t nn = vn[t];
+            vote_merge(kk, nn, vk[t + stride], vn[t + stride]);
+            vk[t] = kk;
+            vn[t] = nn;
+        }
+        __syncthreads();
+    }
+    const uint64_t maj_k = vk[0];
+    const uint32_t maj_n = vn[0];
+    __syncthreads();
+    uint64_t mx = 0;
+    if (!is_float) {
+        vk[t] = has ? r.tmax : big_sec_rec(slot, 0)->tmax;
+        __syncthreads();
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                Val<W> x, y;
+                const unsigned long long xa = vk[t], ya = vk[t + stride];
+                __builtin_memcpy(&x, &xa, W);
+                __builtin_memcpy(&y, &ya, W);
+                if (int_lt<W>(x, y, nk)) vk[t] = ya;
+            }
+            __syncthreads();
+        }
+        mx = vk[0];
+        __syncthreads();
+    }
+    // ---- the union of the sections' key sets
+    bool set_ok = false;
+    uint32_t set_unique = 0;
+    if (want_set && !over) {
+        unsigned long long* kset = (unsigned long long*)lds_tab;
+        for (uint32_t i = t; i < KSLOTS; i += WG) kset[i] = SENT;
+        // exclusive prefix of the sections' key counts
+        {
+            const uint32_t mine = has ? r.kcnt : 0u;
+            const uint32_t incl = wave_incl_scan(mine);
+            if ((t & 63) == 63) s4[t >> 6] = incl;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int q = 0; q < (t >> 6); q++) base += s4[q];
+            s_pref[t + 1] = base + incl;
+            if (t == 0) {
+                s_pref[0] = 0;
+                s_kcnt = 0;
+            }
+            __syncthreads();
+        }
+        const uint32_t total = s_pref[WG];
+        for (uint32_t i0 = 0; i0 < total; i0 += WG * 8) {
+            if (s_kcnt > BIG_KCAP) break;   // (monotonic: a stale value only delays the exit)
+            unsigned long long x[8];
+            bool act[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = i0 + (uint32_t)u * WG + t;
+                act[u] = i < total;
+                x[u] = SENT;
+                if (act[u]) {
+                    uint32_t lo = 0, hi = nsec;   // the section s with pref[s] <= i < pref[s + 1]
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= i) lo = mid;
+                        else hi = mid;
+                    }
+                    const unsigned long long* keys = (const unsigned long long*)((const uint8_t*)big_sec_rec(slot, lo) + 64);
+                    x[u] = keys[i - s_pref[lo]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (!act[u]) continue;
+                const unsigned long long xx = x[u];
+                uint32_t h = (((uint32_t)xx ^ (uint32_t)(xx >> 32) * 0x85EBCA6Bu) * 0x9E3779B1u >> 15) & (KSLOTS - 1);
+                for (;;) {
+                    if (s_kcnt > BIG_KCAP) break;
+                    unsigned long long cur = kset[h];
+                    if (cur == xx) break;
+                    if (cur == SENT) {
+                        const unsigned long long old = atomicCAS(&kset[h], (unsigned long long)SENT, xx);
+                        if (old == SENT) {
+                            atomicAdd(&s_kcnt, 1u);
+                            break;
+                        }
+                        if (old == xx) break;
+                    }
+                    h = (h + 1) & (KSLOTS - 1);
+                }
+            }
+        }
+        __syncthreads();
+        set_ok = s_kcnt <= BIG_KCAP;
+        set_unique = s_kcnt + (ksent ? 1u : 0u);
+        __syncthreads();
+    }
+    // ---- what is missing for the decision?
+    const bool all_equal = !(flags & 1u);
+    const double tuple_count = (double)N;
+    const bool need_uq = want_set && !all_equal && !set_ok;
+    const bool need_mc = want_vote && !all_equal && !((double)null_count / tuple_count >= 0.9) && ((double)maj_n + 1.0 >= 0.8 * tuple_count);
+    if (t == 0) {
+        BigPage b;
+        __builtin_memset(&b, 0, sizeof b);
+        b.flags = flags;
+        b.nulls = null_count;
+        b.maj_n = maj_n;
+        b.maj_k = maj_k;
+        b.tmax = mx;
+        b.set_ok = set_ok ? 1u : 0u;
+        b.set_unique = set_unique;
+        b.ksent = ksent ? 1u : 0u;
+        b.need_uq = need_uq ? 1u : 0u;
+        b.need_mc = need_mc ? 1u : 0u;
+        s_bp = b;
+        *big_page_rec(slot) = b;
+    }
+    __syncthreads();
+    if (need_uq || need_mc) return;   // k_sel_big_count, then k_sel_big_decide
+    const BigPage bp = s_bp;
+    const PrimCounts pc{false, false, 0, 0};
+    __syncthreads();
+    big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
+}
+
+__global__ void __launch_bounds__(WG) k_sel_big_clear(EncodeArgs a, const uint32_t* big) {
+    const uint32_t page = big[blockIdx.y];
+    if (a.codecs[page] != CODEC_PENDING) return;
+    const EncPage p = a.pages[page];
+    const EncCol c = a.cols[p.col];
+    if (c.width != 4 && c.width != 8) return;
+    const BigPage* bp = big_page_rec(page_slot(a, c, p));
+    if (!bp->need_uq || !p.aux_bytes) return;
+    uint64_t M = 64;
+    while (M < 2 * p.rows) M <<= 1;
+    u32x4* tab = (u32x4*)(a.scratch + p.aux_off);   // (aux areas are 16-byte aligned)
+    const u32x4 e = {SEL_EMPTY, SEL_EMPTY, SEL_EMPTY, SEL_EMPTY};
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < M / 4; i += (uint64_t)gridDim.x * WG) tab[i] = e;
+}
+
+template <int W>
+__global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uint32_t* big) {
+    __shared__ uint32_t s4[4];
+    __shared__ uint32_t s_stop;
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (!big_page_of(a, big, W, &page, &p, &c)) return;
+    uint8_t* slot = page_slot(a, c, p);
+    BigPage* bp = big_page_rec(slot);
+    const bool need_uq = bp->need_uq && p.aux_bytes, need_mc = bp->need_mc;
+    if (!need_uq && !need_mc) return;
+    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    const uint64_t s0 = (uint64_t)blockIdx.x * SR;
+    if (s0 >= N) return;
+    const uint64_t s1 = min(N, s0 + SR);
+    const int t = threadIdx.x;
+    const uint8_t* vals = c.values + p.row0 * W;
+    const uint32_t nk = c.nk;
+    auto key = [=](uint64_t i) { return stat_key<W>(ld_val<W>(vals + i * W), nk); };
+    auto k64 = [&](const Val<W>& k) {
+        uint64_t x = 0;
+        __builtin_memcpy(&x, &k, W);
+        return x;
+    };
+    if (need_mc) {   // rows whose key is the vote's candidate (freq.rs:129-151 counts them exactly)
+        const uint64_t mk = bp->maj_k;
+        uint32_t mine = 0;
+        for (uint64_t i = s0 + t; i < s1; i += WG) mine += k64(key(i)) == mk ? 1u : 0u;
+        const uint32_t tot = wg_sum32(mine, s4);
+        if (t == 0 && tot) atomicAdd(&bp->mc, tot);
+    }
+    if (!need_uq) return;
+    // distinct keys of the page: row indices in the page's HBM table (dict.rs:109-120 wants unique * 3 < N exactly)
+    uint64_t M = 64;
+    while (M < 2 * N) M <<= 1;
+    const SlotTable tab{(uint32_t*)(a.scratch + p.aux_off), false};
+    const uint32_t mask = (uint32_t)(M - 1);
+    const uint32_t limit = (uint32_t)((N - 1) / 3);
+    for (uint64_t base = s0; base < s1; base += WG * 8) {
+        __syncthreads();
+        if (t == 0) s_stop = __hip_atomic_load(&bp->uq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit ? 1u : 0u;
+        __syncthreads();
+        if (s_stop) break;
+        uint64_t iu[8];
+        uint32_t hu[8], cu[8];
+        uint32_t pend = 0, newc = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            iu[u] = base + (uint64_t)u * WG + t;
+            if (iu[u] < s1) pend |= 1u << u;
+            else iu[u] = s0;
+            hu[u] = stat_hash<W>(key(iu[u])) & mask;
+        }
+        while (pend) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if ((pend >> u) & 1) cu[u] = tab.ld(hu[u]);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (!((pend >> u) & 1) || cu[u] != SEL_EMPTY) continue;
+                const uint32_t old = tab.cas(hu[u], SEL_EMPTY, (uint32_t)iu[u]);
+                if (old == SEL_EMPTY) {
+                    newc++;
+                    pend &= ~(1u << u);
+                } else {
+                    cu[u] = old;
+                }
+            }
+            bool same[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) same[u] = bits_eq<W>(key(((pend >> u) & 1) ? (uint64_t)cu[u] : iu[u]), key(iu[u]));
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (!((pend >> u) & 1)) continue;
+                if (same[u]) pend &= ~(1u << u);
+                else hu[u] = (hu[u] + 1) & mask;
+            }
+        }
+        const uint32_t tot = wg_sum32(newc, s4);
+        if (t == 0 && tot) atomicAdd(&bp->uq, tot);
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const uint32_t* big) {
+    __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
+    __shared__ uint32_t s_misc[2 * WG + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * (W + 1) + 16];
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (!big_page_of(a, big, W, &page, &p, &c)) return;   // (chosen by k_sel_big_merge already)
+    const BigPage bp = *big_page_rec(page_slot(a, c, p));
+    // without an aux area (cannot happen while Dict is a candidate) the count stays unknown: "more than the limit"
+    const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes ? bp.uq : 0xFFFFFFFEu, bp.mc};
+    big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
+}

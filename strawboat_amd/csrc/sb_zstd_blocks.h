@@ -120,8 +120,8 @@ __device__ inline bool zb_lit_header(const uint8_t* bs, uint32_t n, uint32_t* lt
 // ---------------------------------------------------------------------------------------------------- zb_scan
 // One thread per queue entry.  An entry is taken when it is exactly one frame (no dictionary, content size — if the header
 // has one — equal to the entry's output) whose blocks are well-formed as far as their headers go, and the pools have room.
-__global__ void __launch_bounds__(WG) zb_scan(InflateJob* q, const uint32_t* count, ZbPools zp, uint32_t queue) {
-    const uint32_t njobs = *count;
+__global__ void __launch_bounds__(WG) zb_scan(InflateJob* q, const uint32_t* count, ZbPools zp, uint32_t queue, uint32_t cap) {
+    const uint32_t njobs = min(*count, cap);
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < njobs; j += gridDim.x * blockDim.x) {
         const InflateJob job = q[j];
         if ((job.codec & ~JOB_REL) != SB_CODEC_ZSTD || job.csize < zp.min_csize) continue;

@@ -1,0 +1,114 @@
+"""GPU parity for LONG pages: a column written without max_page_size is ONE page (src/write/common.rs:54-58), so a page can
+hold millions of rows.  Pages of 2^18 rows or more are selected section-parallel (strawboat_amd/csrc/sb_select_big.h) and
+their plain / LZ4 / Zstd blocks are written by many workgroups; whatever the path, the bytes must be the oracle's and the
+pages must decode to the input.  (The shapes of tests/probes/big_pages.py at a size the oracle writes in seconds.)"""
+import numpy as np
+import pytest
+
+from oracle import sbo as S
+from tests import gen
+from tests.test_gpu_decode import check as dec_check
+from tests.test_gpu_freq import sparse
+from tests.test_gpu_select import check as sel_check
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 128 * 4800          # 614 400 rows = 38 sections of 16 384
+ROWS_ODD = 700_001         # not a multiple of 128 (no bit-packing), a short last section
+
+
+def cases():
+    rng = np.random.default_rng(77)
+    out = {
+        "runs_i64": gen.prim(S.T_I64, ROWS, uniq=200, runs=50, seed=1),
+        "short_runs_i32": gen.prim(S.T_I32, ROWS, uniq=40, runs=3, seed=11),
+        "lowcard_i32": gen.prim(S.T_I32, ROWS, uniq=500, seed=2),
+        "lowcard_nullable_f64": gen.prim(S.T_F64, ROWS_ODD, uniq=300, null_density=0.1, seed=3),
+        "midcard_i64": gen.prim(S.T_I64, ROWS, uniq=150_000, seed=12),      # more keys than the LDS sets take, fewer than N / 3
+        "highcard_i64": gen.prim(S.T_I64, ROWS, uniq=230_000, seed=13),     # just above / below Dict's limit of N / 3 distinct
+        "sparse_i64": sparse(S.T_I64, ROWS, 0.02, 4),
+        "sparse_f32": sparse(S.T_F32, ROWS_ODD, 0.05, 5),
+        "mostly_null_i32": gen.prim(S.T_I32, ROWS, uniq=1000, null_density=0.93, seed=14),
+        "random_u32": gen.prim(S.T_U32, ROWS, uniq=1 << 30, seed=5),
+        "small_u32": gen.prim(S.T_U32, ROWS, uniq=1 << 9, seed=15),         # bit-packing territory
+        "sorted_u32": gen.prim(S.T_U32, ROWS, uniq=1 << 28, sorted_=True, seed=16),
+        "sorted_i64": gen.prim(S.T_I64, ROWS_ODD, uniq=1 << 40, sorted_=True, seed=6),
+        "negative_i32": gen.prim(S.T_I32, ROWS, uniq=1 << 20, seed=17),
+        "one_value_i64": gen.prim(S.T_I64, ROWS, uniq=1, seed=18),
+        "one_value_then_other": None,
+        "f64_random": gen.prim(S.T_F64, ROWS, uniq=1 << 30, seed=19),
+    }
+    v = np.full(ROWS, 7, np.int64)
+    v[-3] = 9                                                            # all-equal fails in the LAST section only
+    out["one_value_then_other"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    k = rng.integers(0, 1 << 40, 3000)
+    v = k[rng.integers(0, 3000, ROWS)].astype(np.int64)                 # > 2048 keys in the page, fewer in a section?  no: all
+    out["union_overflows_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    v = (np.arange(ROWS) // 16384 * 50 + rng.integers(0, 50, ROWS)).astype(np.int32)   # 50 keys per section, 1 900 in the page
+    out["sets_unite_i32"] = dict(ptype=S.T_I32, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    v = (np.arange(ROWS) // 16384 * 60 + rng.integers(0, 60, ROWS)).astype(np.int32)   # 60 per section: 2 280 > 2 048 in the page
+    out["sets_unite_overflow_i32"] = dict(ptype=S.T_I32, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    return out
+
+
+CASES = cases()
+OPTS = [dict(ratio=2.0, forbidden=()), dict(ratio=1.2, default_compression=S.LZ4, forbidden=()),
+        dict(ratio=3.0, default_compression=S.LZ4, forbidden=(S.DICT,))]
+# the default encoder (parallel LZ4 matcher / Zstd frames per piece: chunk, plan and stitch kernels shared by many
+# workgroups on a long page): format-valid streams of another parse, checked by structure and round trips
+DEFAULT_ENC = {"random_u32": [dict(default_compression=S.LZ4), dict(ratio=3.0, default_compression=S.ZSTD, forbidden=(S.DICT,))],
+               "sorted_i64": [dict(ratio=2.0, default_compression=S.LZ4), dict(default_compression=S.ZSTD)],
+               "lowcard_nullable_f64": [dict(default_compression=S.LZ4), dict(default_compression=S.SNAPPY)],
+               "runs_i64": [dict(default_compression=S.ZSTD), dict(default_compression=S.LZ4)]}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_one_page_columns_match_the_oracle(gpu_ctx, name):
+    col = CASES[name]
+    assert col["rows"] >= 1 << 18
+    for opt in OPTS:
+        sel_check(gpu_ctx, col, **opt)      # codecs, metas and bytes == the oracle's
+    dec_check(gpu_ctx, col, **OPTS[0])
+
+
+@pytest.mark.parametrize("name", sorted(DEFAULT_ENC))
+def test_one_page_columns_default_encoder(gpu_ctx, name):
+    from tests.test_gpu_configs import default_encoder_parity
+    col = CASES[name]
+    for opt in DEFAULT_ENC[name]:   # (bound: the chunked LZ4 matcher's small table against liblz4 on 8-byte floats: 1.96 x)
+        default_encoder_parity(gpu_ctx, col, 2.2, **opt)
+
+
+def test_one_page_binary_and_boolean_default_encoder(gpu_ctx):
+    """the staging loops of the chunk planner (re-based offsets, re-packed bitmaps) are shared by many workgroups too"""
+    from tests.test_gpu_configs import default_encoder_parity
+    for col, opts in ((gen.binary(400_000, uniq=5000, zipf=1.2, maxlen=24, seed=8), (dict(default_compression=S.LZ4),)),
+                      (gen.binary(300_000, uniq=250_000, maxlen=16, null_density=0.1, seed=9), (dict(default_compression=S.ZSTD),)),
+                      (gen.boolean(3_000_001, null_density=0.05, runs=30, seed=7), (dict(default_compression=S.LZ4), dict(default_compression=S.ZSTD)))):
+        for opt in opts:
+            default_encoder_parity(gpu_ctx, col, 2.2, **opt)
+
+
+def test_long_and_short_pages_in_one_call(gpu_ctx):
+    """explicit paging that leaves long and short pages side by side, several columns of both widths in one call"""
+    import torch
+    from strawboat_amd import write, WriteOptions
+    from tests.test_gpu_encode import to_device_column
+    names = ["lowcard_i32", "midcard_i64", "random_u32", "sparse_i64", "small_u32"]
+    cols = [CASES[n] for n in names]
+    for mps in (None, 300_000, 262_144):
+        wo = WriteOptions(default_compress_ratio=2.0, max_page_size=mps, lz4_exact=True)
+        encs = write.encode_columns(gpu_ctx, [to_device_column(gpu_ctx, c) for c in cols], wo)
+        gpu_ctx.synchronize()
+        for c, e in zip(cols, encs):
+            want_pages, want_metas = gen.oracle_write(c, ratio=2.0, max_page_size=mps, forbidden=())
+            assert np.array_equal(e.metas_array(), want_metas)
+            assert np.array_equal(e.pages_numpy(), want_pages)
+
+
+def test_five_million_rows_one_page(gpu_ctx):
+    """sections longer than 16 384 rows (256 sections at most per page)"""
+    col = gen.prim(S.T_I32, 5_000_064, uniq=70_000, seed=21)
+    sel_check(gpu_ctx, col, ratio=2.0, forbidden=())
+    col = gen.prim(S.T_I64, 4_500_001, uniq=1 << 40, sorted_=True, seed=22)
+    sel_check(gpu_ctx, col, ratio=2.0, default_compression=S.LZ4, forbidden=())

@@ -457,6 +457,26 @@ def run_configs(h, only, cpu_on, log):
                                      "codecs": page_codecs(c, r["enc"][0])}
         out["c4"]["per_column_type"] = per
         del named, cols
+    if want("one_page"):
+        # the reference's default paging (WriteOptions.max_page_size = None, src/write/common.rs:54-58): a column is ONE page.
+        # Pages this long run the section-parallel selector (sb_select_big.h) and many-workgroup plain / LZ4 / Zstd writers;
+        # Dict / RLE / Freq pages and a one-block LZ4 buffer are still one workgroup's work.
+        rng = np.random.default_rng(7)
+        n64 = 12_000_000
+        i64 = dict(ptype=W.T_I64, nullable=False, rows=n64, values=np.sort(rng.integers(0, 1 << 40, n64)).astype(np.int64), validity=None, offsets=None)
+        utf8 = W.zipf_utf8(3_000_000, 42)
+        one = {}
+        for nm, col, o, desc in (
+                ("int64_adaptive", i64, WriteOptions(default_compress_ratio=2.0), "sorted Int64 (40-bit), adaptive (ratio 2.0), no default compression -> a plain page"),
+                ("int64_zstd", i64, WriteOptions(default_compression=C.ZSTD), "the same column, Basic(Zstd)"),
+                ("int64_lz4", i64, WriteOptions(default_compression=C.LZ4), "the same column, Basic(LZ4): one LZ4 block of 68 MB, decoded by one workgroup"),
+                ("utf8_zstd", utf8, WriteOptions(default_compression=C.ZSTD), "Utf8 (zipf over 10 000 words), Basic(Zstd)"),
+                ("utf8_adaptive", utf8, WriteOptions(default_compress_ratio=2.0), "the same column, adaptive -> one Dict page (one workgroup builds it)")):
+            res = h.measure_flat([col], o, reps=3, check=1)
+            one[nm] = config_entry(nm, res, None, {"workload": "ONE page of %d rows: %s" % (col["rows"], desc)})
+            log("one_page %s: encode %.1f GB/s, decode %.1f GB/s" % (nm, one[nm]["encode"]["GBps"], one[nm]["decode"]["GBps"]))
+        out["one_page"] = one
+        del i64, utf8
     if want("host_boundary"):
         try:
             out["host_boundary"] = {"c2": run_host_boundary(h, "c2"), "c1": run_host_boundary(h, "c1"),
@@ -882,7 +902,7 @@ def kernel_source_sha():
     collected for the same sources (scripts/pmc_traffic.py stamps it)"""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("sb_encode.hip", "sb_select_runs.h", "sb_select_rle.h", "sb_select.h", "sb_common.h"):
+    for f in ("sb_encode.hip", "sb_select_runs.h", "sb_select_rle.h", "sb_select_big.h", "sb_select.h", "sb_common.h"):
         with open(os.path.join(ROOT, "strawboat_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]
@@ -932,7 +952,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; nccl = RCCL over xGMI (the measured configuration).  gloo lets the N > 1 path be "
                          "exercised on a box with fewer GPUs than ranks (ranks then share devices): a functional check, not a number")
-    ap.add_argument("--only", default=None, help="comma list of configs (c1,c3,c3_lz4,c4,c5,continuity): run ONLY these, "
+    ap.add_argument("--only", default=None, help="comma list of configs (c1,c3,c3_lz4,c4,c5,one_page,host_boundary,continuity): run ONLY these, "
                                                  "without the headline (profiling runs)")
     args = ap.parse_args()
 

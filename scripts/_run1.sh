@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python tests/probes/fuzz_zstd_frames.py 2>&1 | grep -v amdgpu.ids | tail -4
-timeout 600 python bench.py --only one_page --no-cpu-baseline > gpurun_out/b_one_page.json 2> gpurun_out/b_one_page.err
-tail -12 gpurun_out/b_one_page.err
+timeout 2400 bash scripts/profile_round.sh r04 > gpurun_out/profile_round_r04.log 2>&1 < /dev/null
+tail -30 gpurun_out/profile_round_r04.log

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 bash scripts/profile_round.sh r04 > gpurun_out/profile_round_r04.log 2>&1 < /dev/null
-tail -30 gpurun_out/profile_round_r04.log
+timeout 1500 python bench.py > gpurun_out/bench_r04_b.json 2> gpurun_out/bench_r04_b.err < /dev/null
+echo rc=$?
+tail -30 gpurun_out/bench_r04_b.err

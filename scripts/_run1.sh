@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python bench.py > gpurun_out/bench_r04_b.json 2> gpurun_out/bench_r04_b.err < /dev/null
-echo rc=$?
-tail -30 gpurun_out/bench_r04_b.err
+timeout 600 python bench.py --only one_page --no-cpu-baseline > gpurun_out/b_x.json 2> gpurun_out/b_x.err < /dev/null
+grep bench gpurun_out/b_x.err
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3

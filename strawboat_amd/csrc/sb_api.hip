@@ -493,6 +493,11 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     if (zb_on) off = align_up(off + 64, 64);
     const size_t o_zb_frames = off;
     if (zb_on) off = align_up(off + job_cap * sizeof(ZbFrame), 64);
+    // long multi-frame Zstd buffers (a one-page column written by this library): frames found by a scan (sb_decode.hip)
+    const bool zs_on = zb_on && !sizes_only && max_page_len >= (1u << 20);
+    const uint64_t zs_seg_cap = zs_on ? pages_bytes / 16384 + 2 * P + 64 : 0;
+    const size_t o_zs = off;
+    if (zs_on) off = align_up(off + 256 + zs_seg_cap * 32, 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
     StageSlot* slot = acquire_slot(ctx, upload_bytes + n * sizeof(uint64_t));
@@ -618,6 +623,14 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     // more (64 KiB pages of incompressible values — the reference's bench shape — stay with the one-wave copy path)
     const uint32_t big_min = 2 * P >= 4096 ? 2 * LZ4_BIG_MIN : LZ4_BIG_MIN / 4;
     a.lz4_big_min = max_page_len >= big_min ? big_min : 0xFFFFFFFFu;
+    a.zs_hdr = a.zs_segs = nullptr;
+    a.zs_seg_cap = 0;
+    if (zs_on) {
+        a.zs_hdr = (uint32_t*)(tb + o_zs);
+        a.zs_segs = (uint32_t*)(tb + o_zs + 256);
+        a.zs_seg_cap = (uint32_t)std::min<uint64_t>(zs_seg_cap, 0x7FFFFFFFu);
+        (void)hipMemsetAsync(tb + o_zs, 0, 256 + zs_seg_cap * 32, s);
+    }
     memset(&a.zb, 0, sizeof a.zb);
     if (zb_on) {
         a.zb.blocks = (ZbBlock*)ctx->zb_blocks.p;

@@ -192,6 +192,12 @@ struct DecodeArgs {
     uint32_t job_cap_a, job_cap_b;  // entries of the two job queues (2 * n_pages + room for the frames of split Zstd buffers)
     uint32_t lz4_big_min;  // LZ4 blocks of at least this many compressed bytes go to k_inflate_lz4_big (0xFFFFFFFF: the call has no page that long)
     ZbPools zb;            // block-parallel Zstd pipeline (zb.blocks == nullptr: not launched for this call)
+    // frame split of LONG multi-frame Zstd buffers (k_zsplit_scan / k_zsplit_chain; null: every buffer is walked by one lane):
+    // zs_hdr[0] = entries listed, [1] = segment records handed out, [16 + 2 i], [17 + 2 i] = (queue entry, first record) of
+    // listed entry i; zs_segs: records of 8 words (count | 7 positions of the frame magic inside a 16 KiB segment)
+    uint32_t* zs_hdr;
+    uint32_t* zs_segs;
+    uint32_t zs_seg_cap;
 };
 constexpr uint32_t LZ4_BIG_MIN = 64u << 10;
 

@@ -148,7 +148,243 @@ __device__ inline bool zstd_frame_extent_fast(const uint8_t* src, uint32_t n, ui
 // up to the entry's output is replaced by one entry per frame (the walk reads a few bytes per frame).  Anything else stays
 // as it is and is decoded by one wave, frame after frame.  Threads only look at entries below *n0_p, so the entries other
 // threads append meanwhile are never walked.
-__global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt, const uint32_t* n0_p, uint32_t cap, Status* st) {
+// the frames of queue entry j, found by one lane walking the buffer
+__device__ void zstd_split_walk(InflateJob* q, uint32_t* cnt, uint32_t cap, uint32_t j, const InflateJob& job) {
+    // ONE walk: the frames go to queue slots reserved SPLIT_BATCH at a time as they are found; when the buffer turns
+    // out not to be a plain chain of frames the slots written so far are marked "skip" and the entry keeps its frames
+    // (the queue's consumers are launched after this kernel)
+    constexpr uint32_t SPLIT_BATCH = 64, MAX_BATCHES = 16;   // batch k holds 64 (k + 1) slots: 16 reservations reach 8 704 frames
+    uint32_t first_pos, first_fs = 0, first_fc = 0;
+    if (!zstd_frame_extent_fast(job.src, job.csize, 0, &first_fs, &first_fc) || first_fs >= job.csize || first_fc > job.out_len) return;
+    first_pos = first_fs;   // (a single frame: nothing to split)
+    uint32_t bases[MAX_BATCHES], nb = 0, room = 0, at = 0, nf = 0, pos = 0, total = 0;
+    bool ok = true;
+    uint32_t fs = first_fs, fc = first_fc;
+    (void)first_pos;
+    for (;;) {
+        if (room == 0) {
+            if (nb == MAX_BATCHES) {
+                ok = false;
+                break;
+            }
+            const uint32_t want = SPLIT_BATCH * (nb + 1);
+            const uint32_t b = atomicAdd(cnt, want);
+            if (b + want > cap) {   // no room: the part of the reservation inside the queue is marked "skip" (slots at
+                ok = false;         // or beyond cap are never read: the consumers clamp the count to cap)
+                for (uint32_t k = b; k < cap && k < b + want; k++) q[k].codec = CODEC_SPLIT;
+                break;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < MAX_BATCHES; k++)
+                if (k == nb) bases[k] = b;
+            at = b;
+            room = want;
+            nb++;
+        }
+        InflateJob f = job;
+        f.src = job.src + pos;
+        f.dst = job.dst + total;
+        f.csize = fs;
+        f.out_len = fc;
+        q[at++] = f;
+        room--;
+        nf++;
+        pos += fs;
+        total += fc;
+        if (pos >= job.csize) break;
+        if (!zstd_frame_extent_fast(job.src, job.csize, pos, &fs, &fc) || fc > job.out_len - total) {
+            ok = false;
+            break;
+        }
+    }
+    ok = ok && nf >= 2 && total == job.out_len && pos == job.csize;
+#pragma unroll
+    for (uint32_t k = 0; k < MAX_BATCHES; k++) {   // the unused tail of the last batch — or, on failure, every slot of mine
+        if (k >= nb) break;
+        const uint32_t want = SPLIT_BATCH * (k + 1);
+        const uint32_t lo = ok ? (k + 1 == nb ? at : bases[k] + want) : bases[k];
+        for (uint32_t i = lo; i < bases[k] + want; i++) q[i].codec = CODEC_SPLIT;
+    }
+    if (ok) q[j].codec = CODEC_SPLIT;
+}
+
+// ---- LONG buffers (>= ZS_BIG bytes: a one-page column): the walk above is a chain of dependent HBM reads, one per frame —
+// 3 000 frames, 4.6 ms for a 96 MB page.  Every frame begins with the magic number, so: all workgroups scan the buffer for
+// it (a candidate per hit, filed under its 16 KiB segment); one workgroup per buffer then lists the candidates in position
+// order in LDS, computes every candidate's extent in parallel (one 16-byte load each), links candidate -> the candidate
+// at its end by binary search, and ONE lane follows the links from position 0 through LDS (30 ns per frame).  A magic
+// inside compressed data is just a candidate off the chain.  Anything unexpected (a segment with > 7 hits, > 4096
+// candidates, a broken chain) falls back to zstd_split_walk for that buffer.
+constexpr uint32_t ZS_BIG = 1u << 20, ZS_SEG = 16384, ZS_SLOTS = 7, ZS_LIST = 16, ZS_MAXC = 4096;
+__global__ void __launch_bounds__(WG) k_zsplit_scan(const InflateJob* q, DecodeArgs a) {
+    const uint32_t e = blockIdx.y;
+    if (e >= min(a.zs_hdr[0], ZS_LIST)) return;
+    const uint32_t j = a.zs_hdr[16 + 2 * e], seg0 = a.zs_hdr[17 + 2 * e];
+    if (j == 0xFFFFFFFFu) return;
+    const InflateJob job = q[j];
+    const uint32_t nseg = (job.csize + ZS_SEG - 1) / ZS_SEG;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        uint32_t* rec = a.zs_segs + (uint64_t)(seg0 + seg) * 8;
+        const uint32_t b = seg * ZS_SEG + threadIdx.x;   // lane = byte position: a wave's load is one or two cache lines
+#pragma unroll 8
+        for (uint32_t k = 0; k < ZS_SEG / WG; k++) {
+            const uint32_t pos = b + k * WG;
+            if (pos + 4 > job.csize) break;
+            if (ldu32(job.src + pos) == 0xFD2FB528u) {
+                const uint32_t r = atomicAdd(&rec[0], 1u);
+                if (r < ZS_SLOTS) rec[1 + r] = pos;
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(WG) k_zsplit_chain(InflateJob* q, uint32_t* cnt, uint32_t cap, DecodeArgs a) {
+    __shared__ uint32_t s_pos[ZS_MAXC], s_fc[ZS_MAXC];
+    __shared__ uint16_t s_nxt[ZS_MAXC], s_path[ZS_MAXC];
+    __shared__ uint32_t s_w[8], s_state[4];   // s_state: [0] fail, [1] frames on the chain, [2] queue base
+    const uint32_t e = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (e >= min(a.zs_hdr[0], ZS_LIST)) return;
+    const uint32_t j = a.zs_hdr[16 + 2 * e], seg0 = a.zs_hdr[17 + 2 * e];
+    if (j == 0xFFFFFFFFu) return;
+    const InflateJob job = q[j];
+    const uint32_t nseg = (job.csize + ZS_SEG - 1) / ZS_SEG;
+    constexpr uint32_t DEAD = 0xFFFF, END = 0xFFFE;
+    if (t == 0) s_state[0] = 0;
+    __syncthreads();
+    // ---- candidates in position order
+    uint32_t C = 0;
+    for (uint32_t g0 = 0; g0 < nseg; g0 += WG) {
+        const uint32_t seg = g0 + t;
+        uint32_t p[ZS_SLOTS], n = 0;
+        if (seg < nseg) {
+            const uint32_t* rec = a.zs_segs + (uint64_t)(seg0 + seg) * 8;
+            n = rec[0];
+            if (n > ZS_SLOTS) {
+                s_state[0] = 1;
+                n = 0;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < ZS_SLOTS; k++) p[k] = k < n ? rec[1 + k] : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t x = 0; x < ZS_SLOTS; x++)   // (7 values: a few compare-exchanges)
+#pragma unroll
+                for (uint32_t y = 0; y + 1 < ZS_SLOTS - x; y++)
+                    if (p[y] > p[y + 1]) {
+                        const uint32_t tmp = p[y];
+                        p[y] = p[y + 1];
+                        p[y + 1] = tmp;
+                    }
+        }
+        const uint32_t incl = wave_incl_scan(n);
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t base = C + incl - n;
+        for (uint32_t x = 0; x < w; x++) base += s_w[x];
+        const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (base + n <= ZS_MAXC) {
+#pragma unroll
+            for (uint32_t k = 0; k < ZS_SLOTS; k++)
+                if (k < n) s_pos[base + k] = p[k];
+        }
+        C += tot;
+        __syncthreads();
+        if (C > ZS_MAXC) break;
+    }
+    if (t == 0 && (C > ZS_MAXC || C < 2 || s_pos[0] != 0)) s_state[0] = 1;
+    __syncthreads();
+    if (!s_state[0]) {
+        // ---- extents, links
+        for (uint32_t c = t; c < C; c += WG) {
+            uint32_t fs = 0, fc = 0;
+            uint32_t nx = DEAD;
+            if (zstd_frame_extent_fast(job.src, job.csize, s_pos[c], &fs, &fc)) {
+                const uint32_t target = s_pos[c] + fs;
+                if (target == job.csize) {
+                    nx = END;
+                } else {
+                    uint32_t lo = c, hi = C;   // positions ascend: the candidate at `target`, if any, is behind c
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pos[mid] <= target) lo = mid;
+                        else hi = mid;
+                    }
+                    if (s_pos[lo] == target && lo != c) nx = lo;
+                }
+            }
+            s_nxt[c] = (uint16_t)nx;
+            s_fc[c] = fc;
+        }
+        __syncthreads();
+        // ---- the chain from position 0, by one lane through LDS
+        if (t == 0) {
+            uint32_t c = 0, k = 0, total = 0;
+            bool ok = true;
+            for (;;) {
+                s_path[k++] = (uint16_t)c;
+                if (s_fc[c] > job.out_len - total) {
+                    ok = false;
+                    break;
+                }
+                total += s_fc[c];
+                const uint32_t nx = s_nxt[c];
+                if (nx == END) break;
+                if (nx == DEAD || k >= C) {
+                    ok = false;
+                    break;
+                }
+                c = nx;
+            }
+            ok = ok && k >= 2 && total == job.out_len;
+            if (ok) {
+                const uint32_t b = atomicAdd(cnt, k);
+                if (b + k > cap) {   // no room: the slots inside the queue are marked "skip" below, the buffer keeps its frames
+                    s_state[3] = 1;
+                } else {
+                    s_state[3] = 0;
+                }
+                s_state[2] = b;
+            }
+            s_state[0] = ok ? 0u : 1u;
+            s_state[1] = k;
+        }
+        __syncthreads();
+    }
+    if (s_state[0]) {   // not a plain chain of frames (or too many of them): the one-lane walk decides
+        if (t == 0) zstd_split_walk(q, cnt, cap, j, job);
+        return;
+    }
+    const uint32_t nf = s_state[1], qb = s_state[2];
+    if (s_state[3]) {
+        for (uint32_t k = qb + t; k < cap && k < qb + nf; k += WG) q[k].codec = CODEC_SPLIT;
+        return;
+    }
+    // ---- one queue entry per frame: destinations = prefix sums of the content sizes along the chain
+    uint32_t run = 0;
+    for (uint32_t k0 = 0; k0 < nf; k0 += WG) {
+        const uint32_t k = k0 + t;
+        const uint32_t c = k < nf ? s_path[k] : 0u;
+        const uint32_t fc = k < nf ? s_fc[c] : 0u;
+        const uint32_t incl = wave_incl_scan(fc);
+        __syncthreads();
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t at = run + incl - fc;
+        for (uint32_t x = 0; x < w; x++) at += s_w[x];
+        if (k < nf) {
+            const uint32_t pos = s_pos[c];
+            const uint32_t end = k + 1 < nf ? s_pos[s_path[k + 1]] : job.csize;
+            InflateJob f = job;
+            f.src = job.src + pos;
+            f.dst = job.dst + at;
+            f.csize = end - pos;
+            f.out_len = fc;
+            q[qb + k] = f;
+        }
+        run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
+    if (t == 0) q[j].codec = CODEC_SPLIT;
+}
+
+__global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt, const uint32_t* n0_p, uint32_t cap, Status* st, DecodeArgs a) {
     const uint32_t n0 = *n0_p;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n0 || j >= cap) return;
@@ -156,62 +392,20 @@ __global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt,
         const InflateJob job = q[j];
         if ((job.codec & ~JOB_REL) != SB_CODEC_ZSTD) return;
         if (!(st->kinds & KIND_ZSTD)) atomicOr(&st->kinds, KIND_ZSTD);   // (the host sizes the block pipeline's pools for later calls)
-        // ONE walk: the frames go to queue slots reserved SPLIT_BATCH at a time as they are found; when the buffer turns
-        // out not to be a plain chain of frames the slots written so far are marked "skip" and the entry keeps its frames
-        // (the queue's consumers are launched after this kernel)
-        constexpr uint32_t SPLIT_BATCH = 64, MAX_BATCHES = 16;   // batch k holds 64 (k + 1) slots: 16 reservations reach 8 704 frames
-        uint32_t first_pos, first_fs = 0, first_fc = 0;
-        if (!zstd_frame_extent_fast(job.src, job.csize, 0, &first_fs, &first_fc) || first_fs >= job.csize || first_fc > job.out_len) return;
-        first_pos = first_fs;   // (a single frame: nothing to split)
-        uint32_t bases[MAX_BATCHES], nb = 0, room = 0, at = 0, nf = 0, pos = 0, total = 0;
-        bool ok = true;
-        uint32_t fs = first_fs, fc = first_fc;
-        (void)first_pos;
-        for (;;) {
-            if (room == 0) {
-                if (nb == MAX_BATCHES) {
-                    ok = false;
-                    break;
+        if (a.zs_segs && job.csize >= ZS_BIG) {   // a long buffer: listed for the scan kernels when there is room
+            const uint32_t slot = atomicAdd(&a.zs_hdr[0], 1u);
+            if (slot < ZS_LIST) {
+                const uint32_t nseg = (job.csize + ZS_SEG - 1) / ZS_SEG;
+                const uint32_t s0 = atomicAdd(&a.zs_hdr[1], nseg);
+                if (s0 + nseg <= a.zs_seg_cap) {
+                    a.zs_hdr[16 + 2 * slot] = j;
+                    a.zs_hdr[17 + 2 * slot] = s0;
+                    return;
                 }
-                const uint32_t want = SPLIT_BATCH * (nb + 1);
-                const uint32_t b = atomicAdd(cnt, want);
-                if (b + want > cap) {   // no room: the part of the reservation inside the queue is marked "skip" (slots at
-                    ok = false;         // or beyond cap are never read: the consumers clamp the count to cap)
-                    for (uint32_t k = b; k < cap && k < b + want; k++) q[k].codec = CODEC_SPLIT;
-                    break;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < MAX_BATCHES; k++)
-                    if (k == nb) bases[k] = b;
-                at = b;
-                room = want;
-                nb++;
-            }
-            InflateJob f = job;
-            f.src = job.src + pos;
-            f.dst = job.dst + total;
-            f.csize = fs;
-            f.out_len = fc;
-            q[at++] = f;
-            room--;
-            nf++;
-            pos += fs;
-            total += fc;
-            if (pos >= job.csize) break;
-            if (!zstd_frame_extent_fast(job.src, job.csize, pos, &fs, &fc) || fc > job.out_len - total) {
-                ok = false;
-                break;
+                a.zs_hdr[16 + 2 * slot] = 0xFFFFFFFFu;
             }
         }
-        ok = ok && nf >= 2 && total == job.out_len && pos == job.csize;
-#pragma unroll
-        for (uint32_t k = 0; k < MAX_BATCHES; k++) {   // the unused tail of the last batch — or, on failure, every slot of mine
-            if (k >= nb) break;
-            const uint32_t want = SPLIT_BATCH * (k + 1);
-            const uint32_t lo = ok ? (k + 1 == nb ? at : bases[k] + want) : bases[k];
-            for (uint32_t i = lo; i < bases[k] + want; i++) q[i].codec = CODEC_SPLIT;
-        }
-        if (ok) q[j].codec = CODEC_SPLIT;
+        zstd_split_walk(q, cnt, cap, j, job);
     }
 }
 // true in every thread of the LAST workgroup of the grid to get here (all threads of every workgroup must call it)
@@ -2385,6 +2579,15 @@ void launch_freq_scatter(sb_ctx* ctx, const FreqEntry* entries, uint32_t n, cons
 // for the frames of queue A and — calls with binary columns — of queue Z in one pass; the frames of queue A are executed
 // right away, those of queue Z after k_colscan (launch_zb_exec).  Frames the pipeline takes are marked CODEC_ZB; k_inflate,
 // launched after it, decodes the rest (and the frames handed back).
+// multi-frame Zstd buffers of a queue -> one entry per frame (long buffers: frames found by the scan kernels)
+static void launch_zstd_split(const DecodeArgs& a, InflateJob* q, uint32_t* cnt, const uint32_t* n0_p, uint32_t cap, hipStream_t s) {
+    k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(q, cnt, n0_p, cap, a.status, a);
+    if (a.zs_segs) {
+        k_zsplit_scan<<<dim3(1024, ZS_LIST), WG, 0, s>>>(q, a);
+        k_zsplit_chain<<<ZS_LIST, WG, 0, s>>>(q, cnt, cap, a);
+        (void)hipMemsetAsync(a.zs_hdr, 0, 4, s);   // the list is per queue (the segment records are handed out once per call)
+    }
+}
 static RelCtx rel_ctx(const DecodeArgs& a) {
     RelCtx rc;
     rc.cols = a.cols;
@@ -2442,8 +2645,8 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     {
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, a.status);
-        if (a.jobs_z) k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_z, a.job_counts + 10, a.job_counts + 11, a.job_cap_a, a.status);
+        launch_zstd_split(a, a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, s);
+        if (a.jobs_z) launch_zstd_split(a, a.jobs_z, a.job_counts + 10, a.job_counts + 11, a.job_cap_a, s);
     }
     launch_zb(ctx, a);
     {
@@ -2452,11 +2655,11 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     {
         KScope k(ctx, "k_inflate_lz4");
-        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
+        k_inflate_lz4<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
     }
     if (a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big");
-        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
+        k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
     }
     {
         KScope k(ctx, K_PLAN);
@@ -2465,7 +2668,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     if (any_binary) {  // (without binary columns the host knows every values_len itself)
         KScope k(ctx, K_COLSCAN);
         k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
-        k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_b, a.job_counts + 1, a.job_counts + 9, a.job_cap_b, a.status);
+        launch_zstd_split(a, a.jobs_b, a.job_counts + 1, a.job_counts + 9, a.job_cap_b, s);
     }
     if (a.jobs_z) {   // queue Z: the frames the pipeline took are executed now that every page has its place; the rest by k_inflate
         launch_zb_exec(ctx, a, 1u);
@@ -2476,11 +2679,11 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k(ctx, K_INFLATE_B);
         k_inflate<<<min(a.job_cap_b, INFLATE_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
         KScope k2(ctx, "k_inflate_lz4(values)");
-        k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
+        k_inflate_lz4<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
     }
     if (any_binary && a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big(values)");
-        k_inflate_lz4_big<<<min(2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
+        k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
     }
     // the three expand kernels work on disjoint pages (page-level RLE, tiles of primitives, tiles of binary columns): side
     // by side on streams of their own when the call has both kinds of columns (a mixed schema), joined before the call ends
@@ -2506,10 +2709,10 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
     k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-    k_zstd_split<<<(2 * a.n_pages + WG - 1) / WG, WG, 0, s>>>(a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, a.status);
+    launch_zstd_split(a, a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, s);
     launch_zb(ctx, a);
     k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
-    k_inflate_lz4<<<min(2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu, a.job_cap_a);
+    k_inflate_lz4<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu, a.job_cap_a);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
     k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
 }

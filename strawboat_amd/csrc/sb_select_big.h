@@ -23,6 +23,7 @@
 constexpr uint64_t SEL_BIG_ROWS = 1ull << 18;
 constexpr uint32_t SEL_BIG_SECTIONS = 256;    // at most, per page
 constexpr uint32_t SEL_BIG_MIN_SEC = 16384;   // rows of a section: a power of two, at least this
+constexpr uint32_t BIG_COUNT_SPLIT = 1;       // workgroups per section in k_sel_big_count (measured, 12 M sorted rows: 1 -> 0.33 ms, 4 -> 0.40: the CAS traffic on the table bounds it, not the chains)
 constexpr uint32_t BIG_KCAP = SEL_LDS_SLOTS / 4;   // keys of an LDS set (KSLOTS / 2 of the page selectors)
 
 __host__ __device__ __forceinline__ uint64_t big_sec_rows(uint64_t N) {
@@ -532,7 +533,8 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
     BigPage* bp = big_page_rec(slot);
     const bool need_uq = bp->need_uq && p.aux_bytes, need_mc = bp->need_mc;
     if (!need_uq && !need_mc) return;
-    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    // (BIG_COUNT_SPLIT workgroups per section: the probes are latency chains, the more of them in flight the better)
+    const uint64_t N = p.rows, SR = big_sec_rows(N) / BIG_COUNT_SPLIT;
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
     const uint64_t s1 = min(N, s0 + SR);

@@ -452,7 +452,11 @@ __device__ __forceinline__ bool rle_by_page(const ColDesc& c, const PageDesc& d)
            c.width <= 8;
 }
 
-__device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p) {
+// (what a page asks of the wave afterwards: its tile entries)
+struct TileReq {
+    uint32_t need, base, ntiles, col;
+};
+__device__ __forceinline__ TileReq parse_page(const DecodeArgs& a, const uint32_t p) {
     const PageTask t = a.tasks[p];
     const ColDesc c = a.cols[t.col];
     PageDesc d;
@@ -464,11 +468,11 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
     do {                                  \
         raise(a.status, (code), p, (tag)); \
         a.descs[p] = d;                   \
-        return;                           \
+        return TileReq{0, 0, 0, 0};       \
     } while (0)
     if (c.ptype == SB_TYPE_NULL) {  // empty pages (src/read/array/null.rs:48-52)
         a.descs[p] = d;
-        return;
+        return TileReq{0, 0, 0, 0};
     }
     if (t.in_off + t.length > c.pages_len) FAIL(SB_ERR_IO, 1);
     const uint8_t* cur = c.pages + t.in_off;
@@ -624,7 +628,7 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
             if (!a.freq_log) {  // header-only pass (sb_read_columns_sizes): nothing to log
                 d.ok = 1;
                 a.descs[p] = d;
-                return;
+                return TileReq{0, 0, 0, 0};
             }
             const uint32_t slot = atomicAdd(a.freq_count, 1u);
             if (slot >= a.freq_cap) FAIL(SB_ERR_INVALID, 39);
@@ -747,18 +751,24 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
         d.tile_base = tbase;
     }
     a.descs[p] = d;
-    // the tile entries of the wave's pages, written by the lanes of the wave together (a 1 M-row page has 245 tiles: one
-    // thread writing them one by one was 44 us of a 0.46 ms C1 decode)
+    return TileReq{need_tiles ? 1u : 0u, tbase, ntiles, t.col};
+#undef FAIL
+}
+__global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    TileReq tr{0, 0, 0, 0};
+    if (p < a.n_pages) tr = parse_page(a, p);
+    // the tile entries of the wave's pages, written by ALL lanes of the wave together — also the lanes without a page (a 1 M-row
+    // page has 245 tiles: one thread writing them one by one was 44 us of a 0.46 ms C1 decode; a call with ONE 12 M-row
+    // page has one lane with a page: 2 930 entries, 0.14 ms of a 0.19 ms decode)
     {
-        uint64_t m = __ballot(need_tiles);
-        const uint64_t active = __ballot(true);
-        const uint32_t lane = threadIdx.x & 63, nact = (uint32_t)__popcll(active);
-        const uint32_t rank = (uint32_t)__popcll(active & ((1ull << lane) - 1));
+        uint64_t m = __ballot(tr.need != 0);
+        const uint32_t lane = threadIdx.x & 63;
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const uint32_t b = __shfl(tbase, l, 64), nt = __shfl(ntiles, l, 64), pg = __shfl(p, l, 64), col = __shfl(t.col, l, 64);
-            for (uint32_t i = rank; i < nt; i += nact) {
+            const uint32_t b = __shfl(tr.base, l, 64), nt = __shfl(tr.ntiles, l, 64), pg = __shfl(p, l, 64), col = __shfl(tr.col, l, 64);
+            for (uint32_t i = lane; i < nt; i += 64) {
                 TileTask tt;
                 tt.page = pg;
                 tt.tile = i;
@@ -768,11 +778,6 @@ __device__ __forceinline__ void parse_page(const DecodeArgs& a, const uint32_t p
             }
         }
     }
-#undef FAIL
-}
-__global__ void __launch_bounds__(WG) k_parse(DecodeArgs a) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < a.n_pages) parse_page(a, p);
     // queue A is complete when the last workgroup is done: its length goes to job_counts[8] for k_zstd_split
     if (last_workgroup_done(&a.job_counts[5]) && threadIdx.x == 0) {
         a.job_counts[8] = __hip_atomic_load(&a.job_counts[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

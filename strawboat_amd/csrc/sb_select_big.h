@@ -41,10 +41,23 @@ struct BigPage {   // 256 bytes at the start of the slot
     uint64_t tmax, maj_k;
     uint32_t set_unique, ksent, need_uq, need_mc;
     uint32_t uq, mc;   // k_sel_big_count's results (atomics)
-    uint32_t pad[50];
+    uint32_t uq_sent;  // the all-ones key (the table's "empty") was met
+    uint32_t pad[49];
 };
 constexpr uint32_t BIG_SEC_STRIDE = 64 + BIG_KCAP * 8;
 static_assert(sizeof(BigSec) == 64 && sizeof(BigPage) == 256, "records of the long-page selector");
+// slots of the page's HBM table: every section stops once the count has passed Dict's limit (N - 1) / 3, checked before each
+// batch of WG * 8 rows, so the table never holds more than limit + sections * WG * 8 keys — a quarter of the 2 N slots the
+// page selectors clear
+// The slots hold the KEYS (8 bytes; the page selectors' tables hold row indices and read the row's key to compare): a
+// probe is one load, an insert one CAS, nothing else.  M * 8 < 15 N bytes always fits the aux area ((2^k >= 2 N) + 3 N words).
+__host__ __device__ __forceinline__ uint64_t big_tab_slots(uint64_t N) {
+    const uint64_t SR = big_sec_rows(N), nsec = (N + SR - 1) / SR;
+    const uint64_t need = 2 * ((N - 1) / 3 + nsec * BIG_COUNT_SPLIT * WG * 8 + 64);
+    uint64_t M = 64;
+    while (M < need) M <<= 1;
+    return M;
+}
 __device__ __forceinline__ BigPage* big_page_rec(uint8_t* slot) { return (BigPage*)slot; }
 __device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { return (BigSec*)(slot + 256 + (uint64_t)s * BIG_SEC_STRIDE); }
 
@@ -514,11 +527,10 @@ __global__ void __launch_bounds__(WG) k_sel_big_clear(EncodeArgs a, const uint32
     if (c.width != 4 && c.width != 8) return;
     const BigPage* bp = big_page_rec(page_slot(a, c, p));
     if (!bp->need_uq || !p.aux_bytes) return;
-    uint64_t M = 64;
-    while (M < 2 * p.rows) M <<= 1;
+    const uint64_t M = big_tab_slots(p.rows);
     u32x4* tab = (u32x4*)(a.scratch + p.aux_off);   // (aux areas are 16-byte aligned)
     const u32x4 e = {SEL_EMPTY, SEL_EMPTY, SEL_EMPTY, SEL_EMPTY};
-    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < M / 4; i += (uint64_t)gridDim.x * WG) tab[i] = e;
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < M / 2; i += (uint64_t)gridDim.x * WG) tab[i] = e;
 }
 
 template <int W>
@@ -556,54 +568,56 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
     }
     if (!need_uq) return;
     // distinct keys of the page: row indices in the page's HBM table (dict.rs:109-120 wants unique * 3 < N exactly)
-    uint64_t M = 64;
-    while (M < 2 * N) M <<= 1;
-    const SlotTable tab{(uint32_t*)(a.scratch + p.aux_off), false};
+    const uint64_t M = big_tab_slots(N);
+    unsigned long long* tab = (unsigned long long*)(a.scratch + p.aux_off);
+    constexpr unsigned long long EMPTY = ~0ull;
     const uint32_t mask = (uint32_t)(M - 1);
     const uint32_t limit = (uint32_t)((N - 1) / 3);
+    uint32_t sent = 0;
     for (uint64_t base = s0; base < s1; base += WG * 8) {
         __syncthreads();
         if (t == 0) s_stop = __hip_atomic_load(&bp->uq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit ? 1u : 0u;
         __syncthreads();
         if (s_stop) break;
-        uint64_t iu[8];
-        uint32_t hu[8], cu[8];
+        unsigned long long xu[8], cu[8];
+        uint32_t hu[8];
         uint32_t pend = 0, newc = 0;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            iu[u] = base + (uint64_t)u * WG + t;
-            if (iu[u] < s1) pend |= 1u << u;
-            else iu[u] = s0;
-            hu[u] = stat_hash<W>(key(iu[u])) & mask;
+            const uint64_t i = base + (uint64_t)u * WG + t;
+            const Val<W> kv = key(i < s1 ? i : s0);
+            xu[u] = k64(kv);
+            hu[u] = stat_hash<W>(kv) & mask;
+            if (i < s1) {
+                if (xu[u] == EMPTY) sent = 1;
+                else pend |= 1u << u;
+            }
         }
         while (pend) {
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                if ((pend >> u) & 1) cu[u] = tab.ld(hu[u]);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (!((pend >> u) & 1) || cu[u] != SEL_EMPTY) continue;
-                const uint32_t old = tab.cas(hu[u], SEL_EMPTY, (uint32_t)iu[u]);
-                if (old == SEL_EMPTY) {
-                    newc++;
-                    pend &= ~(1u << u);
-                } else {
-                    cu[u] = old;
-                }
-            }
-            bool same[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) same[u] = bits_eq<W>(key(((pend >> u) & 1) ? (uint64_t)cu[u] : iu[u]), key(iu[u]));
+                if ((pend >> u) & 1) cu[u] = __hip_atomic_load(tab + hu[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 if (!((pend >> u) & 1)) continue;
-                if (same[u]) pend &= ~(1u << u);
+                if (cu[u] == EMPTY) {
+                    unsigned long long e = EMPTY;
+                    __hip_atomic_compare_exchange_strong(tab + hu[u], &e, xu[u], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e == EMPTY) {
+                        newc++;
+                        pend &= ~(1u << u);
+                        continue;
+                    }
+                    cu[u] = e;
+                }
+                if (cu[u] == xu[u]) pend &= ~(1u << u);
                 else hu[u] = (hu[u] + 1) & mask;
             }
         }
         const uint32_t tot = wg_sum32(newc, s4);
         if (t == 0 && tot) atomicAdd(&bp->uq, tot);
     }
+    if (sent) bp->uq_sent = 1;
 }
 
 template <int W>
@@ -617,6 +631,6 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const ui
     if (!big_page_of(a, big, W, &page, &p, &c)) return;   // (chosen by k_sel_big_merge already)
     const BigPage bp = *big_page_rec(page_slot(a, c, p));
     // without an aux area (cannot happen while Dict is a candidate) the count stays unknown: "more than the limit"
-    const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes ? bp.uq : 0xFFFFFFFEu, bp.mc};
+    const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
     big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
 }

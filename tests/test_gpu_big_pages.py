@@ -44,6 +44,9 @@ def cases():
     k = rng.integers(0, 1 << 40, 3000)
     v = k[rng.integers(0, 3000, ROWS)].astype(np.int64)                 # > 2048 keys in the page, fewer in a section?  no: all
     out["union_overflows_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    v = out["midcard_i64"]["values"].copy()
+    v[::1000] = -1                                                       # the all-ones key is the count table's "empty" word
+    out["midcard_with_minus_one_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
     v = (np.arange(ROWS) // 16384 * 50 + rng.integers(0, 50, ROWS)).astype(np.int32)   # 50 keys per section, 1 900 in the page
     out["sets_unite_i32"] = dict(ptype=S.T_I32, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
     v = (np.arange(ROWS) // 16384 * 60 + rng.integers(0, 60, ROWS)).astype(np.int32)   # 60 per section: 2 280 > 2 048 in the page

@@ -309,7 +309,11 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     // status word travels with the stream
     hipError_t e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(Status), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) ctx->kinds_seen |= ctx->h_status->kinds;
+    if (e == hipSuccess) {
+        ctx->kinds_seen |= ctx->h_status->kinds & KIND_ZSTD;
+        // (not sticky: what the calls since the last synchronize looked like decides the order of the next call's entropy kernels)
+        if (ctx->h_status->kinds & KIND_ZSTD) ctx->zb_seq_long = (ctx->h_status->kinds & KIND_ZSEQ_LONG) != 0;
+    }
     if (e != hipSuccess) {
         rc = check_hip(ctx, e, "sb_ctx_synchronize");
     } else if (ctx->h_status->code != 0) {
@@ -646,6 +650,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         a.zb.min_csize = ctx->zb_min_csize;
         a.zb.wg_exec = ctx->zb_wg_exec;
         a.zb.stats = ctx->zb_stats;
+        a.zb.kinds = &ctx->d_status->kinds;
     }
     a.freq_log = nullptr;
     a.freq_count = nullptr;

@@ -88,6 +88,7 @@ struct Status {
     uint32_t kinds; // KIND_* bits of what the calls have met so far (never cleared: the host sizes later calls by it)
 };
 constexpr uint32_t KIND_ZSTD = 1u;   // a Zstd buffer was queued
+constexpr uint32_t KIND_ZSEQ_LONG = 2u;   // a Zstd block of >= 8192 sequences was met (zb_hdr): the sequence chains are the long pole
 
 // one general-purpose block (LZ4 / Zstd / Snappy) to inflate: src -> dst
 struct InflateJob {
@@ -155,6 +156,7 @@ struct ZbPools {
     uint32_t min_csize;     // frames shorter than this stay with the one-wave / lane-per-frame paths
     uint32_t wg_exec;       // 0: every frame through the wave executor (SB_ZSTD_BLOCKS_WG=0)
     unsigned long long* stats;   // totals of the context: [0] frames decoded, [1] frames handed back, [2] blocks, [3] sequences
+    uint32_t* kinds;             // Status.kinds of the call
 };
 
 

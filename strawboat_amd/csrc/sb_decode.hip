@@ -2627,16 +2627,23 @@ static void launch_zb(sb_ctx* ctx, const DecodeArgs& a) {
     }
     // literals and sequences of a block are independent of each other (different pools): side by side on two streams
     const bool multi = !ctx->profile && side_streams(ctx);
-    if (multi) side_fork(ctx, 1u);
-    {
-        KScope k(ctx, "zb_lit");
-        zb_lit<<<std::min<uint32_t>((a.zb.block_cap + ZL_BLOCKS - 1) / ZL_BLOCKS, 768u), 64, 0, s>>>(a.zb);
-    }
+    // Both are pools of 768 one-wave workgroups with ~53 KB of LDS each: either fills every CU's LDS, so the one on the
+    // call's stream runs first and the other (on a low-priority side stream) moves into the LDS its workgroups free as they
+    // retire.  The longer one should go first.  Frames libzstd wrote: zb_seq — its time is its longest chain (a 128 KiB
+    // block of 28 800 sequences: 4.6 ms) while most of its workgroups retire long before that (C5 leaves written by
+    // libzstd: 79 -> 95 GB/s).  This library's frames (mostly literals): zb_lit (the other order costs C5 1 ms of 7).
+    // Which case a context is in comes back with Status.kinds (zb_hdr met a block of >= 8192 sequences in the last calls).
+    const bool seq_first = ctx->zb_seq_long;
+    if (multi) side_fork(ctx, 2u);
     {
         KScope k(ctx, "zb_seq");
-        zb_seq<<<std::min<uint32_t>((a.zb.block_cap + ZS_BLOCKS - 1) / ZS_BLOCKS + 4, 768u), 64, 0, multi ? ctx->side[0] : s>>>(a.zb);
+        zb_seq<<<std::min<uint32_t>((a.zb.block_cap + ZS_BLOCKS - 1) / ZS_BLOCKS + 4, 768u), 64, 0, (multi && !seq_first) ? ctx->side[1] : s>>>(a.zb);
     }
-    if (multi) side_join(ctx, 1u);
+    {
+        KScope k(ctx, "zb_lit");
+        zb_lit<<<std::min<uint32_t>((a.zb.block_cap + ZL_BLOCKS - 1) / ZL_BLOCKS, 768u), 64, 0, (multi && seq_first) ? ctx->side[1] : s>>>(a.zb);
+    }
+    if (multi) side_join(ctx, 2u);
     launch_zb_exec(ctx, a, 0u);
 }
 

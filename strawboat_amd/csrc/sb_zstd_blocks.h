@@ -379,6 +379,7 @@ __global__ void __launch_bounds__(WG) zb_hdr(ZbPools zp) {
             const uint32_t cls = b.nseq >= 8192 ? 0u : b.nseq >= 2048 ? 1u : b.nseq >= 512 ? 2u : 3u;
             const uint32_t at = atomicAdd(&zp.counters[8 + cls], 1u);
             if (at < zp.block_cap) zp.lists[(size_t)cls * zp.block_cap + at] = i;
+            if (cls == 0 && at == 0 && zp.kinds) atomicOr(zp.kinds, KIND_ZSEQ_LONG);
         }
     }
 }

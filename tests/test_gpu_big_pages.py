@@ -115,3 +115,60 @@ def test_five_million_rows_one_page(gpu_ctx):
     sel_check(gpu_ctx, col, ratio=2.0, forbidden=())
     col = gen.prim(S.T_I64, 4_500_001, uniq=1 << 40, sorted_=True, seed=22)
     sel_check(gpu_ctx, col, ratio=2.0, default_compression=S.LZ4, forbidden=())
+
+
+def _zstd_one_page_round_trip(ctx, values):
+    """write one Basic(Zstd) page with the default encoder (one frame per 32 KiB piece), read it back"""
+    from strawboat_amd import read, write, WriteOptions
+    from tests.test_gpu_encode import to_device_column
+    col = dict(ptype=S.T_U8, nullable=False, rows=values.size, values=values, validity=None, offsets=None)
+    enc = write.write(ctx, to_device_column(ctx, col), WriteOptions(default_compression=S.ZSTD))
+    assert enc.n_pages == 1
+    pages, metas = enc.pages_numpy(), enc.metas_array()
+    want = gen.oracle_read(col, pages, metas)["values"]           # the oracle reads what the device wrote
+    assert np.array_equal(want, values)
+    for _ in range(2):   # (the second read runs with the context knowing about Zstd: block pipeline + scan-based frame split)
+        got = read.read_simple(ctx, read.ColumnPages(col["ptype"], False, enc.pages[:enc.length], metas))
+        assert np.array_equal(got.values_numpy(), values)
+    return pages, metas
+
+
+def test_long_multi_frame_zstd_buffers_split_by_scan(gpu_ctx):
+    """buffers of >= 1 MiB made of many frames: the frames are found by a scan for the frame magic (k_zsplit_scan /
+    k_zsplit_chain).  Incompressible data is stored in raw blocks, so a magic number planted in the DATA shows up inside
+    the frames: sparse plants are candidates off the chain, dense ones (> 7 per 16 KiB) send the buffer to the one-lane walk"""
+    from strawboat_amd._native import NativeError
+    from strawboat_amd import read
+    rng = np.random.default_rng(99)
+    magic = np.frombuffer((0xFD2FB528).to_bytes(4, "little"), np.uint8)
+    plain = rng.integers(0, 256, 6_000_000).astype(np.uint8)
+    _zstd_one_page_round_trip(gpu_ctx, plain)
+    sparse_plants = plain.copy()
+    for pos in range(1000, sparse_plants.size - 8, 50_001):
+        sparse_plants[pos:pos + 4] = magic
+    _zstd_one_page_round_trip(gpu_ctx, sparse_plants)
+    dense = plain.copy()
+    for pos in range(100, dense.size - 8, 997):
+        dense[pos:pos + 4] = magic
+    _zstd_one_page_round_trip(gpu_ctx, dense)
+    text = np.frombuffer(b" ".join(b"w%d" % (i * 7919 % 5000) for i in range(1_500_000)), np.uint8).copy()   # frames with sequences
+    pages, metas = _zstd_one_page_round_trip(gpu_ctx, text)
+    # damage in the middle of the buffer: an error or the oracle's bytes, never a fault
+    col = dict(ptype=S.T_U8, nullable=False, rows=text.size, values=text, validity=None, offsets=None)
+    for pos in (pages.size // 2, pages.size // 3 + 5, 40):
+        bad = pages.copy()
+        bad[pos] ^= 0x40
+        try:
+            want = gen.oracle_read(col, bad, metas)["values"]
+        except Exception:
+            want = None
+        try:
+            import torch
+            got = read.read_simple(gpu_ctx, read.ColumnPages(col["ptype"], False, torch.from_numpy(bad).to(gpu_ctx.torch_device), metas)).values_numpy()
+        except NativeError:
+            got = None
+        if want is None:
+            assert got is None
+        elif got is not None:
+            assert np.array_equal(got, want)
+    _zstd_one_page_round_trip(gpu_ctx, plain[:2_000_000])   # the context still works

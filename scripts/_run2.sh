@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_big_pages.py -x -q -k "zstd_buffers" 2>&1 | tail -15
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3

@@ -3557,6 +3557,13 @@ __global__ void __launch_bounds__(WG, SB_RUNS_OCC) k_enc_select_runs(EncodeArgs 
     if (c.ptype == SB_TYPE_NULL || c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY) return;
     if (c.width != (uint32_t)KIND || (c.fkind != 0) != (FK != 0)) return;
     const uint64_t N = p.rows;
+    if (N >= SEL_BIG_ROWS) {   // long pages: section-parallel selection and RLE (sb_select_big.h), not one workgroup's walk
+        if (threadIdx.x == 0) {
+            a.codecs[page] = CODEC_PENDING;
+            atomicAdd(&a.codec_counts[31], 1u);
+        }
+        return;
+    }
     SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
     SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
     if (sc.gtab) {  // the Dict aux area starts with a table of pow2 >= 2N slots
@@ -5779,9 +5786,25 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                         if (kd == 4) k_sel_big_count<4><<<cg, WG, 0, st>>>(aa, list);
                         else k_sel_big_count<8><<<cg, WG, 0, st>>>(aa, list);
                     }
-                    KScope k(ctx, "k_sel_big_decide");
-                    if (kd == 4) k_sel_big_decide<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
-                    else k_sel_big_decide<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                    {
+                        KScope k(ctx, "k_sel_big_decide");
+                        if (kd == 4) k_sel_big_decide<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                        else k_sel_big_decide<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                    }
+                    if (!((forb >> SB_CODEC_RLE) & 1)) {   // the long pages that chose RLE: section-parallel too
+                        KScope k(ctx, "k_rle_big");
+                        if (kd == 4) {
+                            k_rle_big_count<4><<<sg, WG, 0, st>>>(aa, list);
+                            k_rle_big_plan<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                            k_rle_big_emit<4><<<sg, WG, 0, st>>>(aa, list);
+                            k_rle_big_done<4><<<dim3(1, nbig), 64, 0, st>>>(aa, list);
+                        } else {
+                            k_rle_big_count<8><<<sg, WG, 0, st>>>(aa, list);
+                            k_rle_big_plan<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
+                            k_rle_big_emit<8><<<sg, WG, 0, st>>>(aa, list);
+                            k_rle_big_done<8><<<dim3(1, nbig), 64, 0, st>>>(aa, list);
+                        }
+                    }
                 }
                 return;
             }

@@ -634,3 +634,336 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const ui
     const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
     big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
 }
+
+// ---------------------------------------------------------------------------------------------------- RLE of a long page
+// integer/rle.rs:64-104: records (u32 count | value); a run boundary is a VALID row whose canonical key differs from the key
+// of the previous valid row, nulls extend the current run, run 0 starts at row 0.  Everything a section needs from the
+// rows before it is three words — is there a valid row before me, its key, the row where the current run began — so:
+//   k_rle_big_count  (sections x pages)   the section walked as if it were the start of a page: boundaries found, first /
+//                                         last valid key, last boundary row
+//   k_rle_big_plan   (1 workgroup / page) scans over the sections: carry-in of every section (key, run start, records
+//                                         before it); closes the last run, def levels, block header, page record
+//   k_rle_big_emit   (sections x pages)   the same walk again from its carry-in, records written in place
+// The walk is select_rle_page's (speculative RLE of the page selectors), restricted to a section.
+struct RleSec {   // 64 bytes per section, at the tail of the page's slot (behind anything an RLE page can write)
+    uint32_t nb, has, first_row_lo, pad0;        // boundaries inside the section (its first valid row not counted)
+    uint64_t first_key, last_key;                // canonical keys of its first / last valid row
+    uint64_t last_boundary;                      // row + 1 of its last boundary, 0 = none
+    uint64_t first_row;                          // its first valid row
+    // carry-in, written by k_rle_big_plan
+    uint32_t in_has, in_nrec;
+    uint64_t in_key, in_start;
+};
+static_assert(sizeof(RleSec) <= 96, "RleSec fits its stride");
+constexpr uint32_t RLE_SEC_STRIDE = 96;
+template <int W>
+__device__ __forceinline__ RleSec* rle_sec_rec(uint8_t* slot, uint64_t N, bool nullable, uint32_t s) {
+    // slot capacity >= 64 + def + 18 + N (W + 8) + 68 (slot_fixed_bytes); an RLE page ends below def + 9 + (N + 1) (4 + W)
+    const uint64_t off = (64 + (nullable ? def_section_bytes(N) : 0) + 18 + N * (uint64_t)(W + 8) - SEL_BIG_SECTIONS * RLE_SEC_STRIDE) & ~(uint64_t)15;
+    return (RleSec*)(slot + off + (uint64_t)s * RLE_SEC_STRIDE);
+}
+
+// rows [s0, s1) of the page: boundaries among its valid rows.  STORE: records are written (carry-in state given);
+// otherwise only the state is tracked.  Returns through the references: have / last (key of the last valid row) / run_start
+// (row where the current run began) / nrec (boundaries so far); first_* describe the first valid row met.
+template <int W, bool STORE>
+__device__ void rle_walk_section(const uint8_t* vals, const ValidView& vv, uint32_t nk, uint64_t N, uint64_t s0, uint64_t s1, uint8_t* dst,
+                                 bool& have, Val<W>& last, uint64_t& run_start, uint32_t& nrec, bool& first_seen, Val<W>& first_key,
+                                 uint64_t& first_row, uint32_t* sA, uint32_t* sB) {
+    constexpr int K = 16;
+    constexpr uint32_t CHUNK = WG * K;
+    constexpr int REC = 4 + W;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t lt = (1ull << lane) - 1;
+    auto getv = [=](uint64_t i) { return ld_val<W>(vals + i * W); };
+    auto lds_barrier = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    const uint64_t vtotal = vv.off + N;
+    uint32_t par = 0;
+    for (uint64_t cb = s0; cb < s1; cb += CHUNK, par ^= 1) {
+        const uint32_t n = (uint32_t)min((uint64_t)CHUNK, s1 - cb);
+        const uint32_t r0 = (uint32_t)t * K;
+        const uint32_t mine = r0 < n ? min((uint32_t)K, n - r0) : 0u;
+        Val<W> v[K];
+        if (r0 + K <= n) {
+            constexpr int NV = K * W / 16;
+            u32x4 q[NV];
+#pragma unroll
+            for (int u = 0; u < NV; u++) q[u] = ldu128(vals + (cb + r0) * W + 16 * u);
+            __builtin_memcpy(v, q, K * W);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; j++) v[j] = getv(cb + (r0 + j < n ? r0 + j : n - 1));
+        }
+        VWord vw = vword_issue(vv.bits, vv.off + cb + r0, vtotal, mine);
+        if (!mine) vw.mask = 0;
+        const uint32_t m = vw.word();
+        uint32_t bmask = 0;  // valid rows whose key differs from the previous VALID row of this thread: run starts
+        Val<W> ek = val_zero<W>(), firstk = val_zero<W>(), firstv = val_zero<W>();
+        bool seen = false;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            if ((m >> j) & 1) {
+                const Val<W> kj = stat_key<W>(v[j], nk);
+                if (!seen) {
+                    firstk = kj;
+                    firstv = v[j];
+                } else if (!bits_eq<W>(kj, ek)) {
+                    bmask |= 1u << j;
+                }
+                ek = kj;
+                seen = true;
+            }
+        }
+        uint32_t* s_has = sA + par * 16;
+        uint32_t* s_cnt = sA + par * 16 + 4;
+        uint32_t* s_blast = sA + par * 16 + 8;
+        Val<W>* s_last = (Val<W>*)sB + par * 4;
+        const Val<W> lastk = ek;
+        const uint64_t hm = __ballot(m != 0);
+        const bool has_w = hm != 0;
+        const Val<W> last_w = readlane_val<W>(lastk, has_w ? top_bit(hm) : 0);
+        if (lane == 0) {
+            s_has[w] = has_w;
+            s_last[w] = last_w;
+        }
+        lds_barrier();
+        bool chas = have;
+        Val<W> cval = last;
+        for (int pw = 0; pw < 3; pw++)
+            if (pw < w && s_has[pw]) {
+                chas = true;
+                cval = s_last[pw];
+            }
+        const uint64_t pm = hm & lt;
+        const Val<W> pvs = shfl_val<W>(lastk, pm ? top_bit(pm) : 0);
+        const bool pc = pm ? true : chas;
+        const Val<W> pvk = pm ? pvs : cval;
+        if (m) {
+            const int f = __ffs((int)m) - 1;
+            if (!pc) {   // the first valid row of everything walked so far (with the carry-in: of the page)
+                if (STORE) st_val<W>(dst + 4, firstv);
+                if (!first_seen) {   // (one thread: nobody before it has a valid row)
+                    first_key = firstk;
+                    first_row = cb + r0 + f;
+                }
+            } else if (!bits_eq<W>(pvk, firstk)) {
+                bmask |= 1u << f;
+            }
+        }
+        // who saw the first valid row?  the lowest lane of the lowest wave with one: broadcast through LDS below
+        const uint32_t cnt = (uint32_t)__popc(bmask);
+        const uint32_t blast = bmask ? r0 + (31u - (uint32_t)__clz((int)bmask)) + 1 : 0;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint64_t bmk = __ballot(bmask != 0);
+        const uint64_t pb = bmk & lt;
+        const uint32_t prev_blast = __shfl(blast, pb ? top_bit(pb) : 0, 64);
+        const uint32_t cnt_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t blast_w = (uint32_t)__builtin_amdgcn_readlane((int)blast, bmk ? top_bit(bmk) : 0);
+        if (lane == 0) {
+            s_cnt[w] = cnt_w;
+            s_blast[w] = bmk ? blast_w : 0;
+        }
+        // the section's first valid row (key, row): held by one thread; pass it to everybody through LDS
+        unsigned long long* s_first = (unsigned long long*)(sB + 64) + par * 2;   // [0] key bits, [1] row + 1
+        if (t == 0) s_first[1] = 0;
+        lds_barrier();
+        if (!first_seen && m && !pc) {
+            uint64_t kb = 0;
+            __builtin_memcpy(&kb, &firstk, W);
+            s_first[0] = kb;
+            s_first[1] = cb + r0 + (uint32_t)(__ffs((int)m) - 1) + 1;
+        }
+        uint32_t base = nrec;
+        uint64_t start_prev = run_start;
+        for (int pw = 0; pw < 3; pw++)
+            if (pw < w) {
+                base += s_cnt[pw];
+                if (s_blast[pw]) start_prev = cb + s_blast[pw] - 1;
+            }
+        if (STORE && bmask) {
+            uint8_t* rec = dst + (uint64_t)(base + incl - cnt) * REC;
+            uint64_t start = pb ? cb + prev_blast - 1 : start_prev;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                if (!((bmask >> j) & 1)) continue;
+                const uint64_t row = cb + r0 + j;
+                stu32(rec, (uint32_t)(row - start));  // count of the run that ends here
+                st_val<W>(rec + REC + 4, v[j]);       // value of the run that starts here
+                rec += REC;
+                start = row;
+            }
+        }
+        for (int pw = 0; pw < 4; pw++) {
+            if (s_has[pw]) {
+                have = true;
+                last = s_last[pw];
+            }
+            nrec += s_cnt[pw];
+            if (s_blast[pw]) run_start = cb + s_blast[pw] - 1;
+        }
+        lds_barrier();
+        if (!first_seen && s_first[1]) {
+            first_seen = true;
+            const unsigned long long kb = s_first[0];
+            __builtin_memcpy(&first_key, &kb, W);
+            first_row = s_first[1] - 1;
+        }
+    }
+}
+
+template <int W>
+__device__ __forceinline__ bool rle_big_page_of(const EncodeArgs& a, const uint32_t* big, uint32_t* page, EncPage* p, EncCol* c) {
+    *page = big[blockIdx.y];
+    *p = a.pages[*page];
+    *c = a.cols[p->col];
+    return (int)c->width == W && p->rows >= SEL_BIG_ROWS && a.codecs[*page] == (int32_t)SB_CODEC_RLE && a.outs[*page].length == 0;
+}
+
+template <int W>
+__global__ void __launch_bounds__(WG, 4) k_rle_big_count(EncodeArgs a, const uint32_t* big) {
+    __shared__ uint32_t sA[32];
+    __shared__ __attribute__((aligned(16))) uint32_t sB[64 + 8];
+    if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    const uint64_t s0 = (uint64_t)blockIdx.x * SR;
+    if (s0 >= N) return;
+    const uint64_t s1 = min(N, s0 + SR);
+    const uint8_t* vals = c.values + p.row0 * W;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    bool have = false, first_seen = false;
+    Val<W> last = val_zero<W>(), first_key = val_zero<W>();
+    uint64_t run_start = 0, first_row = 0;
+    uint32_t nrec = 0;
+    rle_walk_section<W, false>(vals, vv, c.nk, N, s0, s1, nullptr, have, last, run_start, nrec, first_seen, first_key, first_row, sA, sB);
+    if (threadIdx.x == 0) {
+        RleSec* r = rle_sec_rec<W>(page_slot(a, c, p), N, c.nullable != 0, blockIdx.x);
+        RleSec o;
+        __builtin_memset(&o, 0, sizeof o);
+        o.nb = nrec;
+        o.has = have ? 1u : 0u;
+        __builtin_memcpy(&o.first_key, &first_key, W);
+        __builtin_memcpy(&o.last_key, &last, W);
+        o.last_boundary = nrec ? run_start + 1 : 0;
+        o.first_row = first_row;
+        *r = o;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(WG) k_rle_big_plan(EncodeArgs a, const uint32_t* big) {
+    if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    constexpr int REC = 4 + W;
+    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
+    uint8_t* slot = page_slot(a, c, p);
+    const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
+    uint8_t* dst = slot + pos + 9;
+    // <= 256 sections: every thread fetches one record, one thread walks them in LDS, every thread stores its carry-in
+    __shared__ RleSec s_sec[SEL_BIG_SECTIONS];
+    __shared__ uint32_t s_total;
+    __shared__ unsigned long long s_last_start;
+    __shared__ uint32_t s_any;
+    if (threadIdx.x < nsec) s_sec[threadIdx.x] = *rle_sec_rec<W>(slot, N, c.nullable != 0, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool has = false;
+        uint64_t key = 0, start = 0;
+        uint32_t nrec = 0;
+        for (uint32_t s = 0; s < nsec; s++) {
+            RleSec& o = s_sec[s];
+            o.in_has = has ? 1u : 0u;
+            o.in_key = key;
+            o.in_start = start;
+            o.in_nrec = nrec;
+            if (o.has) {
+                if (has && o.first_key != key) {   // the section's first valid row opens a run
+                    nrec++;
+                    start = o.first_row;
+                }
+                nrec += o.nb;
+                if (o.last_boundary) start = o.last_boundary - 1;
+                has = true;
+                key = o.last_key;
+            }
+        }
+        s_total = nrec;
+        s_last_start = start;
+        s_any = has ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < nsec) *rle_sec_rec<W>(slot, N, c.nullable != 0, threadIdx.x) = s_sec[threadIdx.x];
+    if (c.nullable) {
+        uint8_t* bits = def_header(slot, N);
+        def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nrec = s_total;
+        uint8_t* r = dst + (uint64_t)nrec * REC;
+        stu32(r, (uint32_t)(N - s_last_start));   // the last run
+        if (!s_any) st_val<W>(r + 4, val_zero<W>());
+        const uint64_t body = (uint64_t)(nrec + 1) * REC;
+        put_hdr9(slot + pos, SB_CODEC_RLE, (uint32_t)body, (uint32_t)(N * W));
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(WG, 4) k_rle_big_emit(EncodeArgs a, const uint32_t* big) {
+    __shared__ uint32_t sA[32];
+    __shared__ __attribute__((aligned(16))) uint32_t sB[64 + 8];
+    if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    const uint64_t s0 = (uint64_t)blockIdx.x * SR;
+    if (s0 >= N) return;
+    const uint64_t s1 = min(N, s0 + SR);
+    const uint8_t* vals = c.values + p.row0 * W;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    uint8_t* slot = page_slot(a, c, p);
+    const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
+    uint8_t* dst = slot + pos + 9;
+    const RleSec in = *rle_sec_rec<W>(slot, N, c.nullable != 0, blockIdx.x);
+    bool have = in.in_has != 0, first_seen = true;
+    Val<W> last, first_key = val_zero<W>();
+    __builtin_memcpy(&last, &in.in_key, W);
+    uint64_t run_start = in.in_start, first_row = 0;
+    uint32_t nrec = in.in_nrec;
+    rle_walk_section<W, true>(vals, vv, c.nk, N, s0, s1, dst, have, last, run_start, nrec, first_seen, first_key, first_row, sA, sB);
+}
+
+// the page records of the RLE pages written above (after k_rle_big_emit: a.outs marks a page as emitted)
+template <int W>
+__global__ void k_rle_big_done(EncodeArgs a, const uint32_t* big) {
+    if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
+    uint32_t page;
+    EncPage p;
+    EncCol c;
+    if (threadIdx.x) return;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    uint8_t* slot = page_slot(a, c, p);
+    const uint64_t pos = c.nullable ? def_section_bytes(p.rows) : 0;
+    const uint32_t body = ldu32(slot + pos + 1);
+    EncOut out;
+    out.length = pos + 9 + body;
+    out.out_off = 0;
+    out.slot = slot;
+    out.codec = SB_CODEC_RLE;
+    out.pad = 1;   // emitted here: k_enc_emit_pages<., RLE> leaves the page alone
+    a.outs[page] = out;
+}

@@ -44,6 +44,17 @@ def cases():
     k = rng.integers(0, 1 << 40, 3000)
     v = k[rng.integers(0, 3000, ROWS)].astype(np.int64)                 # > 2048 keys in the page, fewer in a section?  no: all
     out["union_overflows_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    out["runs_nullable_f64"] = gen.prim(S.T_F64, ROWS_ODD, uniq=50, runs=40, null_density=0.1, seed=31)
+    c = gen.prim(S.T_I32, ROWS, uniq=30, runs=25, null_density=0.02, seed=32)
+    bits = np.unpackbits(c["validity"], bitorder="little")[:ROWS].copy()
+    bits[20_000:70_000] = 0            # whole sections without a valid row (runs carried across them)
+    bits[300_000:300_010] = 0
+    bits[:5] = 0                       # leading nulls join the first run
+    bits[-40_000:] = 0                 # the page ends in nulls
+    c["validity"] = np.packbits(bits, bitorder="little")
+    out["runs_null_sections_i32"] = c
+    c = gen.prim(S.T_I64, ROWS, uniq=9, runs=2000, null_density=0.5, seed=33)
+    out["long_runs_half_null_i64"] = c
     v = out["midcard_i64"]["values"].copy()
     v[::1000] = -1                                                       # the all-ones key is the count table's "empty" word
     out["midcard_with_minus_one_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)

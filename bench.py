@@ -465,9 +465,11 @@ def run_configs(h, only, cpu_on, log):
         n64 = 12_000_000
         i64 = dict(ptype=W.T_I64, nullable=False, rows=n64, values=np.sort(rng.integers(0, 1 << 40, n64)).astype(np.int64), validity=None, offsets=None)
         utf8 = W.zipf_utf8(3_000_000, 42)
+        runs = dict(i64, values=np.repeat(rng.integers(0, 200, n64 // 50 + 1), 50)[:n64].astype(np.int64))
         one = {}
         for nm, col, o, desc in (
                 ("int64_adaptive", i64, WriteOptions(default_compress_ratio=2.0), "sorted Int64 (40-bit), adaptive (ratio 2.0), no default compression -> a plain page"),
+                ("int64_runs_adaptive", runs, WriteOptions(default_compress_ratio=2.0), "Int64 in runs of 50 rows, adaptive -> ONE RLE page (written and read section-parallel)"),
                 ("int64_zstd", i64, WriteOptions(default_compression=C.ZSTD), "the same column, Basic(Zstd)"),
                 ("int64_lz4", i64, WriteOptions(default_compression=C.LZ4), "the same column, Basic(LZ4): one LZ4 block of 68 MB, decoded by one workgroup"),
                 ("utf8_zstd", utf8, WriteOptions(default_compression=C.ZSTD), "Utf8 (zipf over 10 000 words), Basic(Zstd)"),
@@ -476,7 +478,7 @@ def run_configs(h, only, cpu_on, log):
             one[nm] = config_entry(nm, res, None, {"workload": "ONE page of %d rows: %s" % (col["rows"], desc)})
             log("one_page %s: encode %.1f GB/s, decode %.1f GB/s" % (nm, one[nm]["encode"]["GBps"], one[nm]["decode"]["GBps"]))
         out["one_page"] = one
-        del i64, utf8
+        del i64, utf8, runs
     if want("host_boundary"):
         try:
             out["host_boundary"] = {"c2": run_host_boundary(h, "c2"), "c1": run_host_boundary(h, "c1"),

@@ -425,7 +425,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     if (n == 0) return SB_OK;
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    uint64_t P = 0, T = 0, max_page_len = 0;
+    uint64_t P = 0, T = 0, max_page_len = 0, max_page_rows = 0;
     bool any_binary = false, any_prim = false;
     for (uint64_t i = 0; i < n; i++) {
         sb_column_read& c = cols[i];
@@ -437,6 +437,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             rows += c.metas[p].num_values;
             T += (c.metas[p].num_values + TILE_ROWS - 1) / TILE_ROWS;
             max_page_len = std::max<uint64_t>(max_page_len, c.metas[p].length);
+            max_page_rows = std::max<uint64_t>(max_page_rows, c.metas[p].num_values);
         }
         c.rows = rows;
         c.values_len = 0;
@@ -502,6 +503,10 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     const uint64_t zs_seg_cap = zs_on ? pages_bytes / 16384 + 2 * P + 64 : 0;
     const size_t o_zs = off;
     if (zs_on) off = align_up(off + 256 + zs_seg_cap * 32, 64);
+    // long RLE pages: few pages of many rows are shared by several workgroups each (sb_decode.hip: k_rle_sums)
+    const uint32_t rle_parts = (!sizes_only && max_page_rows >= (1u << 18) && P > 0 && P <= 1024) ? (uint32_t)std::min<uint64_t>(256, 2048 / P) : 1u;
+    const size_t o_rle = off;
+    if (rle_parts > 1) off = align_up(off + P * rle_parts * sizeof(uint64_t), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
     StageSlot* slot = acquire_slot(ctx, upload_bytes + n * sizeof(uint64_t));
@@ -627,6 +632,8 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     // more (64 KiB pages of incompressible values — the reference's bench shape — stay with the one-wave copy path)
     const uint32_t big_min = 2 * P >= 4096 ? 2 * LZ4_BIG_MIN : LZ4_BIG_MIN / 4;
     a.lz4_big_min = max_page_len >= big_min ? big_min : 0xFFFFFFFFu;
+    a.rle_parts = rle_parts;
+    a.rle_sums = rle_parts > 1 ? (uint64_t*)(tb + o_rle) : nullptr;
     a.zs_hdr = a.zs_segs = nullptr;
     a.zs_seg_cap = 0;
     if (zs_on) {

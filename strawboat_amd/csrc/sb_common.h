@@ -200,6 +200,9 @@ struct DecodeArgs {
     uint32_t* zs_hdr;
     uint32_t* zs_segs;
     uint32_t zs_seg_cap;
+    // long RLE pages (a call with few pages of >= 2^18 rows): `rle_parts` workgroups per page, rle_sums[page * parts + part]
+    uint32_t rle_parts;
+    uint64_t* rle_sums;
 };
 constexpr uint32_t LZ4_BIG_MIN = 64u << 10;
 

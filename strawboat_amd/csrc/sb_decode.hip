@@ -2382,7 +2382,8 @@ constexpr uint32_t RLE_CHUNK = WG * RLE_RPT;    // 1024 runs
 
 template <int W>
 __device__ void expand_rle_page(const ColDesc& c, const PageTask& t, const PageDesc& d, uint32_t* s_flag, uint8_t* s_vals_raw,
-                                uint32_t* s_w, uint64_t* s_w64, Status* st, uint32_t page) {
+                                uint32_t* s_w, uint64_t* s_w64, Status* st, uint32_t page, uint32_t part = 0, uint32_t parts = 1,
+                                const uint64_t* sums = nullptr /* rows covered by each part's runs (k_rle_sums), parts > 1 */) {
     constexpr int REC = 4 + W;
     const int tid = threadIdx.x;
     const uint64_t N = t.num_values;
@@ -2403,10 +2404,19 @@ __device__ void expand_rle_page(const ColDesc& c, const PageTask& t, const PageD
             nval[j] = in ? ld_val<W>(r + 4) : Val<W>{};
         }
     };
-    if (max_runs) fetch(0);
+    // a long page is shared by `parts` workgroups: each takes a range of run chunks, its first row comes from the sums of
+    // the ranges before it
+    const uint32_t nchunks = (max_runs + RLE_CHUNK - 1) / RLE_CHUNK, cpp = (nchunks + parts - 1) / parts;
+    const uint32_t b0 = part * cpp * RLE_CHUNK;
+    const bool owns_end = (uint64_t)(part + 1) * cpp >= nchunks;
+    const uint64_t b1 = owns_end ? ~0ull : (uint64_t)(part + 1) * cpp * RLE_CHUNK;
+    if (part && b0 >= max_runs) return;   // (the part that owns the end reports runs that stop short of N)
     uint64_t carry = 0;  // rows covered by the chunks before this one
-    for (uint32_t base = 0; carry < N; base += RLE_CHUNK) {
-        if (base >= max_runs) {
+    for (uint32_t q = 0; q < part; q++) carry += sums[q];
+    if (max_runs) fetch(b0);
+    for (uint64_t base64 = b0; carry < N && base64 < b1; base64 += RLE_CHUNK) {
+        const uint32_t base = (uint32_t)base64;
+        if (base64 >= max_runs) {
             if (tid == 0) raise(st, SB_ERR_IO, page, 200);  // runs end before N rows (read_u32 EOF upstream)
             return;
         }
@@ -2510,21 +2520,45 @@ __global__ void __launch_bounds__(WG) k_expand_rle(DecodeArgs a) {
     const PageTask t = a.tasks[p];
     const ColDesc c = a.cols[t.col];
     if (!rle_by_page(c, d)) return;
-    if (d.def_bits) page_copy_bits(c.validity, t.out_row, d.def_bits, t.num_values, c.bits_aligned);
+    const uint32_t part = blockIdx.y, parts = gridDim.y;
+    const uint64_t* sums = parts > 1 ? a.rle_sums + (uint64_t)p * parts : nullptr;
+    if (d.def_bits && part == 0) page_copy_bits(c.validity, t.out_row, d.def_bits, t.num_values, c.bits_aligned);
     switch (c.width) {
         case 1:
-            expand_rle_page<1>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            expand_rle_page<1>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p, part, parts, sums);
             break;
         case 2:
-            expand_rle_page<2>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            expand_rle_page<2>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p, part, parts, sums);
             break;
         case 4:
-            expand_rle_page<4>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            expand_rle_page<4>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p, part, parts, sums);
             break;
         default:
-            expand_rle_page<8>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p);
+            expand_rle_page<8>(c, t, d, s_flag, s_vals, s_w, s_w64, a.status, p, part, parts, sums);
             break;
     }
+}
+
+// rows covered by the runs of every part of a long RLE page (grid = pages x parts, parts > 1: see expand_rle_page)
+__global__ void __launch_bounds__(WG) k_rle_sums(DecodeArgs a) {
+    __shared__ uint64_t s_w64[4];
+    if (a.job_counts[4] == 0) return;
+    const uint32_t p = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+    const PageDesc d = a.descs[p];
+    const PageTask t = a.tasks[p];
+    const ColDesc c = a.cols[t.col];
+    if (!rle_by_page(c, d)) return;
+    const uint32_t REC = 4 + c.width;
+    const uint8_t* page_end = c.pages + t.in_off + t.length;
+    const uint32_t max_runs = (uint32_t)((uint64_t)(page_end - d.body) / REC);
+    const uint32_t nchunks = (max_runs + RLE_CHUNK - 1) / RLE_CHUNK, cpp = (nchunks + parts - 1) / parts;
+    const uint64_t r0 = (uint64_t)part * cpp * RLE_CHUNK, r1 = min((uint64_t)max_runs, r0 + (uint64_t)cpp * RLE_CHUNK);
+    uint64_t sum = 0;
+    for (uint64_t k = r0 + threadIdx.x; k < r1; k += WG) sum += ldu32(d.body + k * REC);
+    sum = wave_incl_scan64(sum);
+    if ((threadIdx.x & 63) == 63) s_w64[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) a.rle_sums[(uint64_t)p * parts + part] = s_w64[0] + s_w64[1] + s_w64[2] + s_w64[3];
 }
 
 __device__ void expand_binary_tile(const DecodeArgs& a, uint32_t ti, uint32_t* s_a, uint32_t* s_len, uint32_t* s_w) {
@@ -2704,7 +2738,8 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     if (multi) side_fork(ctx, 3u);
     if (any_prim) {
         KScope k(ctx, K_EXPAND_RLE);
-        k_expand_rle<<<a.n_pages, WG, 0, s>>>(a);
+        if (a.rle_parts > 1) k_rle_sums<<<dim3(a.n_pages, a.rle_parts), WG, 0, s>>>(a);
+        k_expand_rle<<<dim3(a.n_pages, std::max<uint32_t>(1u, a.rle_parts)), WG, 0, s>>>(a);
     }
     if (a.n_tiles && any_prim) {
         KScope k(ctx, K_EXPAND);

@@ -1360,6 +1360,41 @@ __device__ bool plan_bp(const uint8_t* body, uint32_t csize, uint64_t N, bool de
         s_err = 0;
     }
     __syncthreads();
+    // Long pages (a one-page column: 93 750 blocks for 12 M rows, 16 ms of one-lane walking): the blocks of a stretch
+    // usually share one width, so GUESS that the blocks from s_blk on all have the width of the first of them, let every
+    // thread check its share of the predicted header positions, accept the stretch up to the first header that disagrees
+    // and guess again from there; after a few stretches (widths that keep changing) the one-lane walk takes the rest.
+    if (nblk >= 4096) {
+        __shared__ uint32_t s_bad;
+        for (int round = 0; round < 16 && s_blk < nblk && !s_err; round++) {
+            const uint32_t blk0 = s_blk, pos0 = s_pos;
+            if (pos0 >= csize) break;   // (the walk below reports it)
+            const uint32_t nb = body[pos0];
+            if (nb > 32) break;
+            const uint32_t stride = 1 + 16 * nb;
+            const uint32_t fit = (uint32_t)min((uint64_t)(nblk - blk0), ((uint64_t)csize - pos0) / stride);   // blocks that lie inside the body
+            __syncthreads();
+            if (t == 0) s_bad = fit;
+            __syncthreads();
+            uint32_t bad = fit;
+            for (uint32_t k = t; k < fit; k += WG)
+                if (body[pos0 + (uint64_t)k * stride] != nb) {
+                    bad = k;
+                    break;
+                }
+            if (bad < fit) atomicMin(&s_bad, bad);
+            __syncthreads();
+            const uint32_t good = s_bad;   // blocks blk0 .. blk0 + good - 1 have this width
+            for (uint32_t k = t; k < good; k += WG) aux[blk0 + k] = pos0 + k * stride;
+            __syncthreads();
+            if (t == 0) {
+                s_blk = blk0 + good;
+                s_pos = pos0 + good * stride;
+            }
+            __syncthreads();
+            if (good == 0) break;
+        }
+    }
     while (s_blk < nblk && !s_err) {
         const uint32_t win0 = s_pos;
         const uint32_t wlen = min((uint32_t)BP_WINDOW, csize - min(csize, win0));

@@ -2663,14 +2663,17 @@ __device__ uint32_t choose_bool(const uint8_t* bits, uint64_t boff, const ValidV
     if (o.force >= 0 && !forbidden((uint32_t)o.force)) return (uint32_t)o.force;
     if (!o.has_ratio || N == 0) return o.default_codec;
     uint32_t* s4 = sc.s_misc + 2 * WG;
+    // valid trues / falses, 32 rows per step (a bit per step was 10 ms for a 12 M-row page)
     uint32_t nt = 0, nf = 0;
-    for (uint64_t i = threadIdx.x; i < N; i += WG)
-        if (vv.get(i)) {
-            if (bit_at(bits, boff + i))
-                nt++;
-            else
-                nf++;
-        }
+    const uint64_t nwords = (N + 31) / 32;
+    for (uint64_t g = threadIdx.x; g < nwords; g += WG) {
+        const uint64_t left = N - g * 32;
+        const uint32_t mask = left >= 32 ? 0xFFFFFFFFu : (1u << left) - 1;
+        const uint32_t v = bits32(bits, boff + g * 32, boff + N);
+        const uint32_t m = vv.bits ? bits32(vv.bits, vv.off + g * 32, vv.off + N) & mask : mask;
+        nt += (uint32_t)__popc(v & m);
+        nf += (uint32_t)__popc(~v & m);
+    }
     const uint32_t true_count = wg_sum32(nt, s4), false_count = wg_sum32(nf, s4);
     double max_ratio = o.ratio;
     uint32_t result = o.default_codec;

@@ -1,7 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 bash scripts/profile_round.sh r04 > gpurun_out/profile_round_r04.log 2>&1 < /dev/null
-tail -3 gpurun_out/profile_round_r04.log
-cd $GRAFT_REPO_ROOT
-timeout 1500 python bench.py > gpurun_out/bench_r04_c.json 2> gpurun_out/bench_r04_c.err < /dev/null
-echo rc=$?
-grep bench gpurun_out/bench_r04_c.err
+timeout 600 python bench.py --only c5,one_page --no-cpu-baseline > gpurun_out/b_x.json 2> gpurun_out/b_x.err < /dev/null
+grep bench gpurun_out/b_x.err | tail -8

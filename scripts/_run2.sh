@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 300 python tests/probes/one_page_time.py 12000000 "bool" 2>&1 | grep -v amdgpu.ids | head -3
+for f in c5_i64_32k c5_str_32k; do for b in 1 2048; do echo "== $f blocks $b"; timeout 120 scripts/micro/lz4_probe.bin scripts/micro/$f.raw $b 2>&1 | grep -A12 "zstd encode"; done; done

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(64) k_dec(const uint8_t* comp, uint32_t cap, c
 __global__ void __launch_bounds__(64) k_zenc(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t* sizes, uint8_t* scratch) {
     __shared__ ZEncLds lds;
     // inputs of up to 16 KiB are compressed the way the chunk kernel does it (a frame of its own: zstd_compress_block_alone)
-    const uint32_t sz = n <= 16384 ? zstd_compress_block_alone(src, n, 0, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK), 16384)
+    const uint32_t sz = n <= 32768 ? zstd_compress_block_alone(src, n, 0, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK), 32768)
                                    : zstd_compress_wave(src, n, dst + (size_t)blockIdx.x * cap, lds, scratch + (size_t)blockIdx.x * zstd_scratch_bytes(ZE_BLOCK));
     if (threadIdx.x == 0) sizes[blockIdx.x] = sz;
 }

@@ -18,6 +18,9 @@
 namespace sb {
 
 constexpr uint32_t ZE_BLOCK = 128 * 1024;
+#ifndef ZE_PROBE
+#define ZE_PROBE 2048u   // bytes of a piece parsed before deciding whether sequences pay (ze_block); 1024: C5 write 157 -> 109 GB/s (pieces that should be literals-only take the full parse)
+#endif
 constexpr uint32_t ZE_HUF_MAXBITS = 11;
 constexpr uint32_t ZE_LITONLY_MAXBITS = 9;   // == ZH_MAXBITS (sb_zstd.h): literals-only pieces are read lane per stream
 
@@ -652,7 +655,7 @@ __device__ uint32_t ze_block(const uint8_t* src, uint32_t n, uint32_t c0, uint32
             nseq += (uint32_t)__popcll(mt.C);
             mt.advance();
             LZP(10);
-            if (ALONE && !probed && blk >= 4096 && mt.anchor - c0 >= 2048) {
+            if (ALONE && !probed && blk >= 4096 && mt.anchor - c0 >= ZE_PROBE) {
                 // After the first 2 KiB of a piece that is a frame of its own: are sequences worth their bits here?  A sequence
                 // costs ~20 bits of FSE codes and offset; entropy-coded as a literal, a byte costs h = (Huffman bits of the
                 // piece's byte histogram) / 8 bytes.  Matches of avg_ml bytes pay off only if avg_ml * h > 2.5 bytes — they do

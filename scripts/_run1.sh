@@ -1,3 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py --only c5,one_page --no-cpu-baseline > gpurun_out/b_x.json 2> gpurun_out/b_x.err < /dev/null
-grep bench gpurun_out/b_x.err | tail -8
+timeout 2400 bash scripts/profile_round.sh r04 > gpurun_out/profile_round_r04.log 2>&1 < /dev/null
+cd $GRAFT_REPO_ROOT
+timeout 1500 python bench.py > gpurun_out/bench_r04_d.json 2> gpurun_out/bench_r04_d.err < /dev/null
+echo rc=$?
+grep bench gpurun_out/bench_r04_d.err
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2

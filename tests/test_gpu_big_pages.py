@@ -108,16 +108,53 @@ def test_long_and_short_pages_in_one_call(gpu_ctx):
     import torch
     from strawboat_amd import write, WriteOptions
     from tests.test_gpu_encode import to_device_column
-    names = ["lowcard_i32", "midcard_i64", "random_u32", "sparse_i64", "small_u32"]
+    from strawboat_amd import read
+    names = ["lowcard_i32", "midcard_i64", "random_u32", "sparse_i64", "small_u32", "runs_i64", "runs_null_sections_i32", "long_runs_half_null_i64"]
     cols = [CASES[n] for n in names]
     for mps in (None, 300_000, 262_144):
-        wo = WriteOptions(default_compress_ratio=2.0, max_page_size=mps, lz4_exact=True)
+        wo = WriteOptions(default_compress_ratio=2.0, max_page_size=mps, lz4_exact=True, forbidden_compressions=[S.DICT] if mps == 300_000 else [])
+        forb = (S.DICT,) if mps == 300_000 else ()
         encs = write.encode_columns(gpu_ctx, [to_device_column(gpu_ctx, c) for c in cols], wo)
         gpu_ctx.synchronize()
         for c, e in zip(cols, encs):
-            want_pages, want_metas = gen.oracle_write(c, ratio=2.0, max_page_size=mps, forbidden=())
+            want_pages, want_metas = gen.oracle_write(c, ratio=2.0, max_page_size=mps, forbidden=forb)
             assert np.array_equal(e.metas_array(), want_metas)
             assert np.array_equal(e.pages_numpy(), want_pages)
+        # and back, all columns in one call (long RLE / Dict / plain pages next to short ones)
+        cps = [read.ColumnPages(c["ptype"], c["nullable"], e.pages[:e.length], e.metas_array()) for c, e in zip(cols, encs)]
+        got = read.batch_read_columns(gpu_ctx, cps)
+        gpu_ctx.synchronize()
+        for c, e, g in zip(cols, encs, got):
+            want = gen.oracle_read(c, e.pages_numpy(), e.metas_array())
+            assert np.array_equal(g.values_numpy(), want["values"])
+            if c["nullable"]:
+                assert np.array_equal(g.validity_numpy(), want["validity"])
+
+
+def test_damaged_long_rle_page(gpu_ctx):
+    """a long RLE page whose run counts were changed: the parts of the page agree with the oracle — an error, never a fault"""
+    import torch
+    from strawboat_amd import read
+    from strawboat_amd._native import NativeError
+    col = CASES["runs_i64"]
+    pages, metas = gen.oracle_write(col, ratio=2.0, forbidden=())
+    assert S.stat_column(col["ptype"], col["nullable"], pages, metas)[0].tolist() == [S.RLE]
+    for pos, val in ((9 + 12 * 1000, 7), (9 + 12 * 5000, 0xFF), (pages.size - 12, 1)):   # a count in the middle, a huge one, the last run
+        bad = pages.copy()
+        bad[pos] = (int(bad[pos]) + val) & 0xFF
+        try:
+            want = gen.oracle_read(col, bad, metas)["values"]
+        except Exception:
+            want = None
+        try:
+            got = read.read_simple(gpu_ctx, read.ColumnPages(col["ptype"], False, torch.from_numpy(bad).to(gpu_ctx.torch_device), metas)).values_numpy()
+        except NativeError:
+            got = None
+        if want is None:
+            assert got is None, "the oracle refuses the page damaged at byte %d, the device decoded it" % pos
+        else:
+            assert got is not None and np.array_equal(got, want)
+    dec_check(gpu_ctx, col, ratio=2.0, forbidden=())   # the context still works
 
 
 def test_five_million_rows_one_page(gpu_ctx):

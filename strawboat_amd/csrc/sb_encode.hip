@@ -125,6 +125,7 @@ struct EncodeArgs {
     uint32_t redo;                  // k_enc_select: second pass over the binary pages k_enc_bin_verify failed (no tags, exact count)
 };
 constexpr uint32_t ZPAR_CH = 32768;      // a Zstd frame's blocks when they are compressed by waves of their own (measured on C5, write / read GB/s: 16 KiB 129 / 171, 32 KiB 147 / 201, 64 KiB 90 / 175)
+constexpr uint32_t ZPAR_CH_SMALL = 16384; // ... in calls with fewer pieces than chunk waves
 constexpr uint32_t ZPAR_WAVES = 2048;     // 8 per CU: what 20 KB of LDS per wave (and 221 VGPRs) keep resident; a larger pool runs a second, thin round
 constexpr uint32_t LZC_CH = 65536;                                         // chunk bytes (a multiple of 1024)
 constexpr uint32_t LZC_SLOT = (16 + LZC_CH + LZC_CH / 255 + 16 + 15) / 16 * 16;   // u32 size | u32 tail anchor | 8 pad | sequences
@@ -4805,10 +4806,10 @@ __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
         const bool second = d.idx >> 31;
         const uint8_t* src = second ? b.src_b : b.src_a;
         const uint32_t n = second ? b.n_b : b.n_a;
-        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * ZPAR_CH, c1 = min(n, c0 + ZPAR_CH);
+        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * a.lzc_chunk, c1 = min(n, c0 + a.lzc_chunk);
         uint8_t* slot = a.lzc_pool + (uint64_t)i * LZC_SLOT;
         wave_sync();
-        const uint32_t len = zstd_compress_block_alone(src, n, c0, c1, slot + 16, Z, scratch, ZPAR_CH);
+        const uint32_t len = zstd_compress_block_alone(src, n, c0, c1, slot + 16, Z, scratch, a.lzc_chunk);
         if (threadIdx.x == 0) stu32(slot, len);
         wave_stores_visible();
     }
@@ -5297,9 +5298,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     const bool sn_possible = host_codec == SB_CODEC_SNAPPY || (adaptive && opts->default_compression == SB_CODEC_SNAPPY);
     const bool lz_possible = zs_possible || sn_possible || (!(opts->flags & SB_WRITE_LZ4_EXACT) &&
                              (host_codec == SB_CODEC_LZ4 || (adaptive && opts->default_compression == SB_CODEC_LZ4)));
-    const uint64_t lz_chunk = zs_possible ? ZPAR_CH : LZC_CH;
-    uint64_t lz_cap = 0;
-    bool lz_any = false;
+    uint64_t lz_chunk = zs_possible ? ZPAR_CH : LZC_CH;
+    uint64_t lz_cap = 0, lz_cap_small = 0;   // (_small: with Zstd pieces of ZPAR_CH_SMALL bytes, see below)
+    bool lz_any = false, lz_any_small = false;
     for (uint64_t i = 0; i < n; i++) {
         sb_column_write& c = cols[i];
         if (c.physical_type < 0 || c.physical_type > SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "bad physical_type");
@@ -5340,17 +5341,29 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 const uint64_t fb = first_block(N);
                 lz_cap += (fb + lz_chunk - 1) / lz_chunk;
                 lz_any |= fb > lz_chunk;
+                lz_cap_small += (fb + ZPAR_CH_SMALL - 1) / ZPAR_CH_SMALL;
+                lz_any_small |= fb > ZPAR_CH_SMALL;
             }
             if (bin) {
                 lz_cap += c.values_len / lz_chunk + np + 1;
                 lz_any |= c.values_len > lz_chunk;
+                lz_cap_small += c.values_len / ZPAR_CH_SMALL + np + 1;
+                lz_any_small |= c.values_len > ZPAR_CH_SMALL;
             }
         }
+    }
+    // a call with fewer Zstd pieces than chunk waves (one nested array, a short column): smaller pieces, more waves — the
+    // call's time is the latency of one piece there, not the chip's throughput
+    if (zs_possible && !hit && lz_cap < ZPAR_WAVES) {
+        lz_chunk = ZPAR_CH_SMALL;
+        lz_cap = lz_cap_small;
+        lz_any = lz_any_small;
     }
     if (!lz_any) lz_cap = 0;
     if (hit) {
         max_tiles = plan.max_tiles;
         lz_cap = plan.lz_cap;
+        lz_chunk = plan.lz_chunk;
     }
     if (lz_cap >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many LZ4 chunks in one call");
     if (P >= 0x7FFFFFFFull) return ctx->fail(SB_ERR_INVALID, "too many pages in one call");
@@ -5639,6 +5652,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         plan.max_tiles = max_tiles;
         plan.max_chunks = max_chunks;
         plan.lz_cap = lz_cap;
+        plan.lz_chunk = lz_chunk;
         plan.any_tiles = any_tiles;
         plan.any_pages = any_pages;
         plan.any_compact = any_compact;

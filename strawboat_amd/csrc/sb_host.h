@@ -140,7 +140,7 @@ struct sb_ctx {
     struct EncPlan {
         bool valid = false;
         uint64_t key = 0, n = 0;
-        uint64_t P = 0, max_tiles = 1, max_chunks = 1, lz_cap = 0;
+        uint64_t P = 0, max_tiles = 1, max_chunks = 1, lz_cap = 0, lz_chunk = 0;
         bool any_tiles = false, any_pages = false, any_compact = false, any_lz4 = false;
         size_t scratch_total = 0, lz_pool_off = 0, zpar_off = 0;
         std::vector<uint64_t> key_words;   // the words the key was hashed from (compared on a hit)

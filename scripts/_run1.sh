@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for p in fuzz_decode fuzz_nested edge_alloc edge_out fuzz_big fuzz_zstd_frames fuzz_zb; do
-  echo "== $p"; timeout 900 python tests/probes/$p.py 2>&1 | grep -v amdgpu.ids | tail -2
-done
-timeout 900 python tests/probes/big_pages.py 3000000 2>&1 | grep -v amdgpu.ids | tail -6
+fails=0
+for i in $(seq 0 62); do timeout 200 python tests/probes/fuzz_decode.py $i 40 > /tmp/fz_$i.txt 2>&1 || { echo "CASE $i FAILED"; tail -3 /tmp/fz_$i.txt; fails=$((fails+1)); }; done
+echo "fuzz_decode: $fails failed cases"
+tail -1 /tmp/fz_5.txt /tmp/fz_30.txt /tmp/fz_60.txt

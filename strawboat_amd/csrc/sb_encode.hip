@@ -3422,6 +3422,13 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
         if (is_bool || is_bin || c.width != (uint32_t)KIND) return;
     }
     const uint64_t N = p.rows;
+    if constexpr (KIND == 1 || KIND == 2) {
+        // long pages in the adaptive wave of a flat call: left to the section-parallel selector (launched after this kernel)
+        if (a.use_counts && !a.redo && a.page_base == 0 && page < a.n_pages && N >= SEL_BIG_ROWS) {
+            if (threadIdx.x == 0) a.codecs[page] = CODEC_PENDING;
+            return;
+        }
+    }
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
     SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
     SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
@@ -5442,9 +5449,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         plan.col_first.assign(n, 0);
         plan.col_pages.assign(n, 0);
         plan.hro.assign(n, 0);
-        plan.big4.clear();
-        plan.big8.clear();
-        plan.big_secs4 = plan.big_secs8 = 0;
+        for (int k = 0; k < 4; k++) {
+            plan.bigw[k].clear();
+            plan.big_secs[k] = 0;
+        }
     }
 
     size_t scratch_off = 0;
@@ -5502,12 +5510,12 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             p.icodec = opts->force_index_codec;
             p.seed = page_seed_of(opts->rng_seed, c.first_page_index + k);
             p.direct = direct ? 1 : 0;
-            if (adaptive && !bin && N >= SEL_BIG_ROWS && (d.width == 4 || d.width == 8) && c.physical_type != SB_TYPE_BOOLEAN &&
+            if (adaptive && !bin && N >= SEL_BIG_ROWS && d.width <= 8 && c.physical_type != SB_TYPE_BOOLEAN &&
                 c.physical_type != SB_TYPE_NULL) {
                 const uint32_t secs = (uint32_t)((N + big_sec_rows(N) - 1) / big_sec_rows(N));
-                (d.width == 4 ? plan.big4 : plan.big8).push_back((uint32_t)pi);
-                uint32_t& mx = d.width == 4 ? plan.big_secs4 : plan.big_secs8;
-                mx = std::max(mx, secs);
+                const int k = d.width == 1 ? 0 : d.width == 2 ? 1 : d.width == 4 ? 2 : 3;
+                plan.bigw[k].push_back((uint32_t)pi);
+                plan.big_secs[k] = std::max(plan.big_secs[k], secs);
             }
             if (direct) {
                 p.direct_off = direct_off;
@@ -5637,10 +5645,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (!hit) {   // the page table goes to the plan's own device buffer and stays there
         e = hipMemcpyAsync(plan.pages.p, hp, P * sizeof(EncPage), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return check_hip(ctx, e, "page table upload");
-        if (const size_t nb = plan.big4.size() + plan.big8.size()) {   // (pageable source: the copy is staged before the call returns)
+        if (const size_t nb = plan.bigw[0].size() + plan.bigw[1].size() + plan.bigw[2].size() + plan.bigw[3].size()) {   // (pageable source: the copy is staged before the call returns)
             if (!ensure(ctx, plan.big, nb * sizeof(uint32_t) + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(long-page list) failed");
-            std::vector<uint32_t> both(plan.big4);
-            both.insert(both.end(), plan.big8.begin(), plan.big8.end());
+            std::vector<uint32_t> both;
+            for (int k = 0; k < 4; k++) both.insert(both.end(), plan.bigw[k].begin(), plan.bigw[k].end());
             e = hipMemcpyAsync(plan.big.p, both.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);   // (`both` goes out of scope; plan misses are rare)
             if (e != hipSuccess) return check_hip(ctx, e, "long-page list upload");
@@ -5743,6 +5751,51 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             KScope k(ctx, "k_enc_bin_hash");
             k_enc_bin_hash<<<tile_grid, WG, 0, st>>>(aa);
         };
+        // long pages (>= 2^18 rows) of 1- / 2- / 4- / 8-byte values: section-parallel statistics, the same decision, and the
+        // RLE pages among them written section-parallel too (sb_select_big.h); they were left CODEC_PENDING by the page selectors
+        auto launch_big = [&](int kd, hipStream_t st) {
+            const int k = kd == 1 ? 0 : kd == 2 ? 1 : kd == 4 ? 2 : kd == 8 ? 3 : -1;
+            if (k < 0 || aa.page_base != 0) return;
+            const uint32_t nbig = (uint32_t)plan.bigw[k].size();
+            if (!nbig) return;
+            size_t skip = 0;
+            for (int q = 0; q < k; q++) skip += plan.bigw[q].size();
+            const uint32_t* list = (const uint32_t*)plan.big.p + skip;
+            const dim3 sg(plan.big_secs[k], nbig), pg(1, nbig);
+#define SB_BIG_W(KERNEL, GRID, THREADS)                                    \
+    do {                                                                   \
+        if (kd == 1) KERNEL<1><<<GRID, THREADS, 0, st>>>(aa, list);        \
+        else if (kd == 2) KERNEL<2><<<GRID, THREADS, 0, st>>>(aa, list);   \
+        else if (kd == 4) KERNEL<4><<<GRID, THREADS, 0, st>>>(aa, list);   \
+        else KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list);                \
+    } while (0)
+            {
+                KScope kk(ctx, "k_sel_big_sec");
+                SB_BIG_W(k_sel_big_sec, sg, WG);
+            }
+            {
+                KScope kk(ctx, "k_sel_big_merge");
+                SB_BIG_W(k_sel_big_merge, pg, WG);
+            }
+            {
+                KScope kk(ctx, "k_sel_big_count");
+                k_sel_big_clear<<<sg, WG, 0, st>>>(aa, list);
+                const dim3 cg(sg.x * BIG_COUNT_SPLIT, nbig);
+                SB_BIG_W(k_sel_big_count, cg, WG);
+            }
+            {
+                KScope kk(ctx, "k_sel_big_decide");
+                SB_BIG_W(k_sel_big_decide, pg, WG);
+            }
+            if (!((forb >> SB_CODEC_RLE) & 1)) {
+                KScope kk(ctx, "k_rle_big");
+                SB_BIG_W(k_rle_big_count, sg, WG);
+                SB_BIG_W(k_rle_big_plan, pg, WG);
+                SB_BIG_W(k_rle_big_emit, sg, WG);
+                SB_BIG_W(k_rle_big_done, pg, 64);
+            }
+#undef SB_BIG_W
+        };
         auto launch_selectors = [&](int kd, hipStream_t st) {
             if (nested && (kd <= 0 || kd > 8)) return;
             if (!nested && (kd == 4 || kd == 8)) {  // statistics + speculative RLE in one pass
@@ -5781,54 +5834,16 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                     else
                         k_enc_select_rle<8, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
                 }
-                // long pages the run-level selector left: section-parallel statistics, then the same decision
-                const uint32_t nbig = (uint32_t)(kd == 4 ? plan.big4.size() : plan.big8.size());
-                if (nbig && aa.page_base == 0) {
-                    const uint32_t* list = (const uint32_t*)plan.big.p + (kd == 4 ? 0 : plan.big4.size());
-                    const dim3 sg(kd == 4 ? plan.big_secs4 : plan.big_secs8, nbig);
-                    {
-                        KScope k(ctx, "k_sel_big_sec");
-                        if (kd == 4) k_sel_big_sec<4><<<sg, WG, 0, st>>>(aa, list);
-                        else k_sel_big_sec<8><<<sg, WG, 0, st>>>(aa, list);
-                    }
-                    {
-                        KScope k(ctx, "k_sel_big_merge");
-                        if (kd == 4) k_sel_big_merge<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
-                        else k_sel_big_merge<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
-                    }
-                    {
-                        KScope k(ctx, "k_sel_big_count");
-                        k_sel_big_clear<<<sg, WG, 0, st>>>(aa, list);
-                        const dim3 cg(sg.x * BIG_COUNT_SPLIT, nbig);
-                        if (kd == 4) k_sel_big_count<4><<<cg, WG, 0, st>>>(aa, list);
-                        else k_sel_big_count<8><<<cg, WG, 0, st>>>(aa, list);
-                    }
-                    {
-                        KScope k(ctx, "k_sel_big_decide");
-                        if (kd == 4) k_sel_big_decide<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
-                        else k_sel_big_decide<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
-                    }
-                    if (!((forb >> SB_CODEC_RLE) & 1)) {   // the long pages that chose RLE: section-parallel too
-                        KScope k(ctx, "k_rle_big");
-                        if (kd == 4) {
-                            k_rle_big_count<4><<<sg, WG, 0, st>>>(aa, list);
-                            k_rle_big_plan<4><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
-                            k_rle_big_emit<4><<<sg, WG, 0, st>>>(aa, list);
-                            k_rle_big_done<4><<<dim3(1, nbig), 64, 0, st>>>(aa, list);
-                        } else {
-                            k_rle_big_count<8><<<sg, WG, 0, st>>>(aa, list);
-                            k_rle_big_plan<8><<<dim3(1, nbig), WG, 0, st>>>(aa, list);
-                            k_rle_big_emit<8><<<sg, WG, 0, st>>>(aa, list);
-                            k_rle_big_done<8><<<dim3(1, nbig), 64, 0, st>>>(aa, list);
-                        }
-                    }
-                }
+                launch_big(kd, st);
                 return;
             }
             char nm[48];
             snprintf(nm, sizeof nm, "k_enc_select<%d>", kd);
-            KScope k(ctx, nm);
-            enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, st>>>(aa);
+            {
+                KScope k(ctx, nm);
+                enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, st>>>(aa);
+            }
+            if (!nested && (kd == 1 || kd == 2)) launch_big(kd, st);
         };
         // the dictionaries the binary selectors handed over: strings checked tile-parallel, pages that failed selected again
         // exactly (workgroups of all other pages return at once); kd_only: the one binary kind of this stream, or 0 = both

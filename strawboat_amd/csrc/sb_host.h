@@ -148,9 +148,9 @@ struct sb_ctx {
         std::vector<uint64_t> hro;
         sb::DevBuf pages;   // EncPage[P] on the device
         // long pages of 4- / 8-byte values (adaptive calls): selected section-parallel (sb_select_big.h); page indices on
-        // the device as [big4 | big8], grid.x = the most sections any of them has
-        std::vector<uint32_t> big4, big8;
-        uint32_t big_secs4 = 0, big_secs8 = 0;
+        // the device as [1-byte | 2-byte | 4-byte | 8-byte pages], grid.x = the most sections any page of a width has
+        std::vector<uint32_t> bigw[4];          // by log2(width): 1-, 2-, 4-, 8-byte values
+        uint32_t big_secs[4] = {0, 0, 0, 0};
         sb::DevBuf big;
     } enc_plan;
     std::vector<uint64_t> enc_plan_probe;   // the key words of the call at hand

@@ -44,6 +44,12 @@ def cases():
     k = rng.integers(0, 1 << 40, 3000)
     v = k[rng.integers(0, 3000, ROWS)].astype(np.int64)                 # > 2048 keys in the page, fewer in a section?  no: all
     out["union_overflows_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    # 1- and 2-byte values go through the same long-page kernels
+    out["lowcard_i8"] = gen.prim(S.T_I8, ROWS, uniq=90, seed=41)
+    out["runs_nullable_u8"] = gen.prim(S.T_U8, ROWS_ODD, uniq=60, runs=30, null_density=0.1, seed=42)
+    out["midcard_u16"] = gen.prim(S.T_U16, ROWS, uniq=40_000, seed=43)          # more keys than the LDS sets take
+    out["runs_i16"] = gen.prim(S.T_I16, ROWS, uniq=500, runs=20, seed=44)
+    out["sparse_i16"] = sparse(S.T_I16, ROWS, 0.03, 45)
     out["runs_nullable_f64"] = gen.prim(S.T_F64, ROWS_ODD, uniq=50, runs=40, null_density=0.1, seed=31)
     c = gen.prim(S.T_I32, ROWS, uniq=30, runs=25, null_density=0.02, seed=32)
     bits = np.unpackbits(c["validity"], bitorder="little")[:ROWS].copy()

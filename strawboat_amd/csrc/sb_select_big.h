@@ -5,7 +5,7 @@
 // page can hold millions of rows.  The page selectors above stream a page through ONE workgroup (3 000 latency-bound
 // chunk iterations for 12 M rows: 60-85 ms), and when the page holds more distinct values than the LDS set takes they
 // count them exactly on an HBM table — still one workgroup, one probe chain at a time.  Pages of SEL_BIG_ROWS rows or more
-// (1- to 8-byte values) go through these kernels instead; the choice is decide_prim's, fed with the same statistics:
+// (4- and 8-byte values) go through these kernels instead; the choice is decide_prim's, fed with the same statistics:
 //
 //   k_sel_big_sec    (sections x pages)   gen_stats of one section of <= 256 per page: flags, null count, typed maximum,
 //                                         Boyer-Moore vote, the section's distinct keys (LDS set, <= 2048, dumped to HBM)

@@ -418,6 +418,13 @@ uint32_t sb_ctx_profile_read(sb_ctx* ctx, sb_kernel_stat* out, uint32_t cap);
  * Synchronises the context. */
 int32_t sb_ctx_zstd_block_stats(sb_ctx* ctx, uint64_t out[4]);
 
+/* Calls since the context was created whose kernels were spread over side streams next to the call's stream (a mixed
+ * schema in one adaptive sb_write_columns call: the binary chain beside the primitive kinds; sb_read_columns with
+ * primitive and binary pages; the Zstd block pipeline).  Diagnostics only: the parity tests use it to show that the
+ * multi-stream path — whose kernels exchange a page's scratch areas across streams through fork / join events — is
+ * the one that ran.  Does not synchronise. */
+uint64_t sb_ctx_side_forks(sb_ctx* ctx);
+
 /* version / build info string ("strawboat-hip <ver> gfx950") */
 const char* sb_version(void);
 

@@ -74,6 +74,10 @@ class Context:
         self._check(self._lib.sb_ctx_zstd_block_stats(self._h, out), drain=False)
         return tuple(int(x) for x in out)
 
+    def side_forks(self):
+        """calls so far whose kernels were spread over side streams next to this context's stream (diagnostics)"""
+        return int(self._lib.sb_ctx_side_forks(self._h))
+
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated up to the last synchronize()."""
         arr = (N.KernelStatC * 96)()

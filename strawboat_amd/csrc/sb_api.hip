@@ -57,6 +57,7 @@ bool side_streams(sb_ctx* ctx) {
     return true;
 }
 void side_fork(sb_ctx* ctx, uint32_t used_mask) {
+    if (used_mask) ctx->side_forks++;
     (void)hipEventRecord(ctx->fork_ev, ctx->stream);
     for (int i = 0; i < sb_ctx::NSIDE; i++)
         if ((used_mask >> i) & 1) (void)hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0);
@@ -377,6 +378,8 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     ctx->sticky = 0;
     return rc;
 }
+
+uint64_t sb_ctx_side_forks(sb_ctx* ctx) { return ctx ? ctx->side_forks : 0; }
 
 int32_t sb_ctx_zstd_block_stats(sb_ctx* ctx, uint64_t out[4]) {
     if (!ctx || !out) return SB_ERR_INVALID;

@@ -5,6 +5,29 @@
 // page's headers into a PageDesc and fills the tile table; every later kernel is indexed
 // either by page (plan kernels, one workgroup per page) or by tile (expand kernels, one
 // workgroup per TILE_ROWS rows of one page).
+//
+// MEMORY-ORDER CONTRACT for scratch areas in HBM (slot tables, row hashes, tag tables, run records, tile entries).
+// Fences inside the page kernels are WORKGROUP scope (an agent-scope release / acquire writes back and invalidates the
+// XCD's L2: ~100 us per fence once the chip is busy).  Workgroup scope orders the accesses of the waves of ONE workgroup —
+// they share a CU and its vector L1 — and says nothing to another CU.  So every scratch area obeys one of two rules:
+//   (1) SINGLE OWNER inside a kernel: between two kernel boundaries, the bytes of a scratch area that one workgroup
+//       writes are read by that workgroup only.  The owner is fixed by the launch geometry: blockIdx.x = page for the page
+//       kernels, (blockIdx.x, blockIdx.y) = (page, tile / section) for the tile- and section-parallel ones, whose
+//       areas are indexed by that pair.  A workgroup never reads another (page, tile)'s scratch inside the kernel
+//       that wrote it.
+//   (2) KERNEL BOUNDARY between owners: a consumer with another geometry (k_enc_bin_hash's (page, tile) grid -> the
+//       page selector -> k_enc_bin_verify's grid -> the page emitters; k_sel_big_count -> _merge -> _sec; k_rle_big_count
+//       -> _plan -> _emit; k_parse -> k_plan -> k_expand*) is a LATER KERNEL, ordered after the producer by stream order
+//       or by a fork / join event edge when the chain runs on a side stream (side_fork / side_join, sb_api.hip): the
+//       end-of-kernel release and start-of-kernel acquire are agent scope and do what the in-kernel fences do not.
+// What workgroups of ONE launch do share is touched with AGENT-scope operations only, and says so where it stands: job
+// queues and counters (atomicAdd / __hip_atomic_fetch_add, push_job_if), the key tables in HBM that all sections of a long
+// page insert into (SlotTable / k_sel_big_count: agent-scope load, CAS and fetch_min — a table is complete at the kernel
+// boundary; the one in-kernel read of shared progress is the relaxed agent-scope load of the distinct counter by which
+// sections stop early once Dict's limit is passed), and last_workgroup_done (sb_decode.hip: __threadfence() = agent-scope
+// release before the counter, acquire after it in the workgroup that finds itself last).
+// tests/test_gpu_configs.py::test_c4_all_columns_in_one_call runs the binary chain on the side stream next to the
+// primitive kinds (sb_ctx_side_forks shows it did) and compares every page with the oracle's.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -160,6 +160,7 @@ struct sb_ctx {
     static constexpr int NSIDE = 3;
     hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[NSIDE] = {nullptr, nullptr, nullptr};
+    uint64_t side_forks = 0;   // calls whose kernels ran on side streams next to the call's stream (sb_ctx_side_forks)
     bool side_ready = false;
     struct ProfEntry {
         std::string name;  // the kernel's name as rocprofv3 prints it, without "void sb::" and the argument list

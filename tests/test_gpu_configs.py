@@ -218,3 +218,47 @@ def test_c5_level_sections_match_oracle_full_size(gpu_ctx):
             assert int(got.level_bytes[p]) == len(want), p
             assert bytes(sec[off:off + len(want)]) == bytes(want), "level section of page %d differs" % p
             off += len(want)
+
+
+def test_c4_all_columns_in_one_call(gpu_ctx):
+    """C4's eight columns in ONE adaptive sb_write_columns call and ONE sb_read_columns call — the shape bench.py's `c4`
+    entry times.  A call that mixes binary and primitive kinds runs the binary chain (k_enc_bin_hash -> selector ->
+    k_enc_bin_verify -> page emitters) on the high-priority side stream next to the primitive kinds, joined by events
+    (sb_encode.hip `multi`; the reader likewise, sb_decode.hip): the scratch areas a page's kernels hand to each other
+    cross kernel boundaries on ANOTHER stream there (the memory-order contract at the top of csrc/sb_common.h).  Every
+    page must still be the oracle's, byte for byte, on repeated calls (the plan cache reuses the device page table), and
+    sb_ctx_side_forks must show that the multi-stream path is the one that ran.  Primitive kinds alone alternate between
+    the call's stream and a second side stream."""
+    from strawboat_amd import read, write, WriteOptions
+    from tests.test_gpu_encode import to_device_column
+    named = workloads.c4_columns(ROWS)
+    opt = dict(max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+    want = {n: gen.oracle_write(c, **opt) for n, c in named}
+    wo = WriteOptions(default_compression=S.LZ4, default_compress_ratio=2.0, max_page_size=65536, lz4_exact=True)
+    for names in ([n for n, _ in named],                                       # binary + primitives + boolean
+                  ["int32_0", "float64_0", "int32_1", "float64_1"],            # two primitive kinds
+                  ["utf8_1", "boolean_0", "int32_1"]):
+        cols = [dict(named)[n] for n in names]
+        dev = [to_device_column(gpu_ctx, c) for c in cols]
+        for rep in range(3):
+            before = gpu_ctx.side_forks()
+            encs = write.encode_columns(gpu_ctx, dev, wo)
+            gpu_ctx.synchronize()
+            assert gpu_ctx.side_forks() > before, "the call did not use the side streams"
+            for n, e in zip(names, encs):
+                assert np.array_equal(e.metas_array(), want[n][1]), "%s (call %d): PageMeta" % (n, rep)
+                assert np.array_equal(e.pages_numpy(), want[n][0]), "%s (call %d): page bytes differ from the oracle's" % (n, rep)
+        cps = [read.ColumnPages(c["ptype"], c["nullable"], e.pages[:e.length], e.metas_array()) for c, e in zip(cols, encs)]
+        for rep in range(2):
+            before = gpu_ctx.side_forks()
+            got = read.batch_read_columns(gpu_ctx, cps)
+            gpu_ctx.synchronize()
+            if any(c["offsets"] is not None for c in cols):
+                assert gpu_ctx.side_forks() > before, "the read did not use the side streams"
+            for n, c, g in zip(names, cols, got):
+                back = gen.oracle_read(c, *want[n])
+                assert np.array_equal(g.values_numpy(), back["values"]), n
+                if c["nullable"]:
+                    assert np.array_equal(g.validity_numpy(), back["validity"]), n
+                if c["offsets"] is not None:
+                    assert np.array_equal(g.offsets_numpy(), back["offsets"]), n

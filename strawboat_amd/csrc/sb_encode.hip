@@ -4248,11 +4248,15 @@ __device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPag
     }
 }
 
-__global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a, EncCol* cols_rw, EncPage* pages_rw) {
+__global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a_in, EncCol* cols_rw, EncPage* pages_rw) {
     // tile array | s_w | container counts | vote scratch (a second tile array in the exact-count path)
     __shared__ __attribute__((aligned(16))) uint32_t lds[SIDX_WORDS + 8 + FREQ_MAX_CONTAINERS + SIDX_WORDS + 16];
     static_assert(SIDX_WORDS + 16 >= 4 + WG + 8 + 8 * WG, "vote scratch");
-    if (*a.freq_count == 0) return;
+    if (*a_in.freq_count == 0) return;
+    // The page functions below are real calls that take the arguments by reference, so the kernel keeps a copy of them
+    // in private memory.  Made from `a` itself that copy is written in the prologue, before the return above: 192 bytes
+    // per lane, 49 MB per launch of a batch without a Freq page (profiles/r04_c2_pmc_traffic.json of the build before).
+    const EncodeArgs a = a_in;
   for (uint32_t page = blockIdx.x; page < a.n_pages; page += gridDim.x) {
     __syncthreads();
     const EncPage p = get_page(a, page);
@@ -4424,13 +4428,14 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
 }
 // a few hundred workgroups walk all virtual pages: a batch without Freq pages costs a short launch
 template <int W>
-__global__ void __launch_bounds__(WG) k_enc_nested(EncodeArgs a) {
+__global__ void __launch_bounds__(WG) k_enc_nested(EncodeArgs a_in) {
     // three tile arrays for the emitters; the selector lays its hash set, misc words and sample area over them
     constexpr int SEL_WORDS = SEL_LDS_SLOTS + 2 * WG + 16 + (SAMPLE_CAP * (W + 1) + 16 + 3) / 4;
     __shared__ __attribute__((aligned(16))) uint32_t lds[SEL_WORDS > 3 * SIDX_WORDS ? SEL_WORDS : 3 * SIDX_WORDS];
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_misc2[2];
-    if (*a.freq_count == 0) return;
+    if (*a_in.freq_count == 0) return;
+    const EncodeArgs a = a_in;   // (the private copy the block functions are called with: after the return, see k_enc_freq_prep)
     for (uint32_t q = blockIdx.x; q < a.n_pages; q += gridDim.x) {
         enc_nested_block<W>(a, a.n_pages + q, lds, s_w, s_misc2);
         __syncthreads();

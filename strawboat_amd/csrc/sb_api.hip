@@ -574,7 +574,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             t.col = (uint32_t)i;
             t.first_tile = (uint32_t)tile_i;
             t.aux_off = scratch_off;
-            scratch_off += align_up((L / 4 + N / 128 + 2 * ntiles + 16) * 4, 16);
+            scratch_off += align_up((L / 4 + N / 128 + 4 * ntiles + 16) * 4, 16);   // (4 * ntiles: tile_k0 / tile_base + tile_bytes, and the u64 tile totals of a long binary Dict page)
             t.infl_off = scratch_off;
             scratch_off += align_up((N + 1) * 8 + 16, 16);
             in_off += L;

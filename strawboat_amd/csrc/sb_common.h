@@ -202,7 +202,7 @@ struct DecodeArgs {
     // Zstd pipeline runs its entropy stages for queue A and queue Z in ONE pass, before k_plan; the frames of queue Z are
     // executed after k_colscan.  null: no such queue in this call.
     InflateJob* jobs_z;
-    uint32_t* job_counts;  // [0] = queue A, [1] = queue B, [2] tiles, [3] planned pages, [4] page-level RLE, [5] / [6] workgroups of k_parse / k_colscan that are done, [8] / [9] / [11] lengths of A / B / Z when complete, [10] = queue Z
+    uint32_t* job_counts;  // [0] = queue A, [1] = queue B, [2] tiles, [3] planned pages, [4] page-level RLE, [5] / [6] workgroups of k_parse / k_colscan that are done, [8] / [9] / [11] lengths of A / B / Z when complete, [10] = queue Z, [12] = binary Dict pages whose tile totals k_plan left to k_bin_tile_sums
     uint8_t* zlit;         // Zstd literal buffers, one per inflate wave
     uint64_t* zrec;        // Zstd sequence records, one arena per inflate wave (k_inflate's lane-per-frame pre-decode)
     uint32_t n_pages;

@@ -1258,6 +1258,15 @@ __device__ __forceinline__ uint32_t idx_aux_words(uint32_t codec, uint32_t n_run
     return 0;
 }
 
+// binary Dict pages of at least this many tiles leave their per-tile byte totals to k_bin_tile_sums / k_bin_tile_scan
+// (every tile by a workgroup of its own) instead of walking the tiles one after the other inside the page's k_plan
+constexpr uint32_t BIN_DEFER_TILES = 4;
+constexpr uint64_t VAL_BYTES_DEFERRED = ~0ull;   // PageDesc.val_bytes of such a page between k_plan and k_bin_tile_scan
+// their exact 64-bit totals per tile, behind tile_bytes[ntiles + 1]
+__device__ __forceinline__ uint64_t* bin_tile_sums(const uint32_t* tile_bytes, uint32_t ntiles) {
+    return (uint64_t*)(((uintptr_t)(tile_bytes + ntiles + 1) + 7) & ~(uintptr_t)7);
+}
+
 // RLE plan: scan the run counts of `body` (records of 4+W bytes) until they cover N rows.
 // Returns the number of runs (uniform).  LDS: s_a (SIDX_WORDS u32).
 __device__ uint32_t plan_rle(const uint8_t* body, uint32_t csize, uint32_t rec, uint64_t N, uint32_t* aux,
@@ -1643,11 +1652,13 @@ __device__ uint64_t roaring_walk(const uint8_t* rb, uint32_t rb_len, uint32_t* s
 // LDS) and per-tile byte totals of the page.
 __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, const uint8_t* page_end, uint32_t* aux,
                               uint32_t aux_cap_words, uint8_t* s_win, uint32_t* s_a, uint32_t* s_w, uint64_t* s_w64,
-                              Status* st, uint32_t page, uint32_t gap = 0 /* bytes between entry 0 and entry 1 (Freq) */) {
+                              Status* st, uint32_t page, uint32_t* defer_count /* NULL: tile totals here */,
+                              uint32_t gap = 0 /* bytes between entry 0 and entry 1 (Freq) */) {
     const int t = threadIdx.x;
     const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
     const uint32_t D = d.dict_n;
-    if ((uint64_t)D + 1 + ntiles + 1 > aux_cap_words) {
+    const bool defer = defer_count && ntiles >= BIN_DEFER_TILES;
+    if ((uint64_t)D + 1 + ntiles + 1 + (defer ? 2ull * ntiles + 2 : 0) > aux_cap_words) {
         if (t == 0) raise(st, SB_ERR_INVALID, page, 220);
         return false;
     }
@@ -1791,6 +1802,13 @@ __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, cons
     if (t == 0) ent_off[D] = s_pos;
     __syncthreads();
     PTL(2);
+    if (defer) {   // the tiles' totals by (page, tile) workgroups, their prefix by k_bin_tile_scan
+        if (t == 0) {
+            d.val_bytes = VAL_BYTES_DEFERRED;
+            atomicAdd(defer_count, 1u);
+        }
+        return true;
+    }
     uint64_t carry = 0;
     for (uint32_t tl = 0; tl < ntiles; tl++) {
         const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, N - (uint64_t)tl * TILE_ROWS);
@@ -1837,6 +1855,7 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
     uint32_t* aux = (uint32_t*)(a.scratch + t.aux_off);
     const uint32_t aux_cap = (uint32_t)((t.infl_off - t.aux_off) / 4);
     const uint8_t* page_end = c.pages + t.in_off + t.length;
+    uint32_t* defer_count = a.sizes_only ? nullptr : a.job_counts + 12;   // (sb_read_columns_sizes launches no tile kernels)
     bool changed = false;
     if (c.ptype == SB_TYPE_BOOLEAN) {
         if (d.codec == SB_CODEC_RLE) {  // runs of u32 count | u8 value (boolean/rle.rs:41-55)
@@ -1931,7 +1950,7 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
             const uint32_t used = idx_aux_words(ic, d.n_runs, N);
             U32Stream is{d.isrc, aux, ic, d.n_runs, N};
             __syncthreads();
-            if (!plan_bin_dict(d, is, N, page_end, aux + used, aux_cap - used, s_win, s_a, s_w, s_w64, a.status, p))
+            if (!plan_bin_dict(d, is, N, page_end, aux + used, aux_cap - used, s_win, s_a, s_w, s_w64, a.status, p, defer_count))
                 d.ok = 0;
             changed = true;
         }
@@ -1955,7 +1974,7 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
         } else {
             d.dict_n = s_inrange + 1;
             U32Stream is{(const uint8_t*)idx, aux, SB_CODEC_NONE, 0, N};
-            if (!plan_bin_dict(d, is, N, page_end, aux, aux_cap, s_win, s_a, s_w, s_w64, a.status, p, 4 + d.vcsize)) d.ok = 0;
+            if (!plan_bin_dict(d, is, N, page_end, aux, aux_cap, s_win, s_a, s_w, s_w64, a.status, p, defer_count, 4 + d.vcsize)) d.ok = 0;
         }
         changed = true;
     }
@@ -1969,6 +1988,82 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
         changed = true;
     }
     if (changed && threadIdx.x == 0) a.descs[p] = d;
+}
+
+// -------------------------------------------------------------------------------- binary Dict: tile totals of long pages
+// The value bytes a tile of a binary Dict page produces (what plan_bin_dict's second half adds up tile after tile): one
+// workgroup per entry of the compact tile list, for the pages k_plan left to it (val_bytes == VAL_BYTES_DEFERRED).  A
+// 3 M-row page is 732 tiles: 3.3 ms inside its k_plan workgroup, one round of the chip here.
+__global__ void __launch_bounds__(WG) k_bin_tile_sums(DecodeArgs a) {
+    __shared__ uint32_t s_a[SIDX_WORDS];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint64_t s_w64[4];
+    if (a.job_counts[12] == 0) return;
+    const uint32_t count = a.job_counts[2];
+    for (uint32_t ti = blockIdx.x; ti < count; ti += gridDim.x) {
+        const TileTask tt = a.tiles[ti];
+        const PageDesc d = a.descs[tt.page];
+        if (!d.ok || d.val_bytes != VAL_BYTES_DEFERRED) continue;
+        const PageTask t = a.tasks[tt.page];
+        const uint64_t N = t.num_values;
+        const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+        const uint32_t* aux = (const uint32_t*)(a.scratch + t.aux_off);
+        const uint32_t gap = d.codec == SB_CODEC_FREQ ? 4 + d.vcsize : 0;
+        const U32Stream is{d.isrc, aux, d.icodec, d.n_runs, N};
+        const uint32_t used = d.codec == SB_CODEC_FREQ ? 0 : idx_aux_words(d.icodec, d.n_runs, N);
+        const uint32_t* ent_off = aux + used;
+        const uint32_t D = d.dict_n;
+        uint64_t* sums = bin_tile_sums(ent_off + D + 1, ntiles);
+        const uint32_t rows = (uint32_t)min((uint64_t)TILE_ROWS, N - (uint64_t)tt.tile * TILE_ROWS);
+        __syncthreads();
+        u32_tile_to_lds(is, tt.tile, rows, s_a, s_w);
+        uint64_t acc = 0;
+        bool bad = false;
+        for (uint32_t i = threadIdx.x; i < rows; i += WG) {
+            const uint32_t k = s_a[sidx((int)i)];
+            if (k >= D) {
+                bad = true;
+                break;
+            }
+            const uint64_t pr = ldu64((const uint8_t*)(ent_off + k));
+            acc += (uint32_t)(pr >> 32) - (uint32_t)pr - 8 - (k == 0 ? gap : 0);
+        }
+        if (bad) raise(a.status, SB_ERR_OUT_OF_SPEC, tt.page, 222);
+        const uint64_t total = wg_sum64(acc, s_w64);
+        if (threadIdx.x == 0) sums[tt.tile] = total;
+    }
+}
+// exclusive prefix of a deferred page's tile totals -> tile_bytes, the page's val_bytes / off_last; one wave per page
+__global__ void __launch_bounds__(WG) k_bin_tile_scan(DecodeArgs a) {
+    if (a.job_counts[12] == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t p = blockIdx.x * (WG / 64) + (threadIdx.x >> 6); p < a.n_pages; p += gridDim.x * (WG / 64)) {
+        const PageDesc d = a.descs[p];
+        if (!d.ok || d.val_bytes != VAL_BYTES_DEFERRED) continue;
+        const PageTask t = a.tasks[p];
+        const uint64_t N = t.num_values;
+        const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+        uint32_t* aux = (uint32_t*)(a.scratch + t.aux_off);
+        const uint32_t used = d.codec == SB_CODEC_FREQ ? 0 : idx_aux_words(d.icodec, d.n_runs, N);
+        uint32_t* tile_bytes = aux + used + d.dict_n + 1;
+        const uint64_t* sums = bin_tile_sums(tile_bytes, ntiles);
+        uint64_t carry = 0;
+        for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
+            const uint64_t v = t0 + lane < ntiles ? sums[t0 + lane] : 0;
+            uint64_t incl = v;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint64_t u = __shfl_up(incl, o, 64);
+                if ((int)lane >= o) incl += u;
+            }
+            if (t0 + lane < ntiles) tile_bytes[t0 + lane] = (uint32_t)(carry + incl - v);
+            carry += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) {
+            tile_bytes[ntiles] = (uint32_t)carry;
+            a.descs[p].val_bytes = carry;
+            a.descs[p].off_last = carry;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------- colscan
@@ -2745,6 +2840,11 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     {
         KScope k(ctx, K_PLAN);
         k_plan<<<a.n_pages, WG, 0, s>>>(a);
+    }
+    if (any_binary && a.n_tiles >= BIN_DEFER_TILES) {   // long binary Dict pages: the tiles' value bytes by a workgroup per tile
+        KScope k(ctx, "k_bin_tile_sums");
+        k_bin_tile_sums<<<min(a.n_tiles, TILE_GRID), WG, 0, s>>>(a);
+        k_bin_tile_scan<<<min((a.n_pages + WG / 64 - 1) / (WG / 64), 1024u), WG, 0, s>>>(a);
     }
     if (any_binary) {  // (without binary columns the host knows every values_len itself)
         KScope k(ctx, K_COLSCAN);

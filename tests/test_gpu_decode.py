@@ -186,3 +186,83 @@ def test_binary_dict_entries_with_zero_bytes_and_empty_strings(gpu_ctx):
         enc = gpu_encode(gpu_ctx, col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
         wp, wm = gen.oracle_write(col, max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
         assert np.array_equal(enc.metas_array(), wm) and np.array_equal(enc.pages_numpy(), wp)
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_binary_dict_tile_totals_by_tile(gpu_ctx, large):
+    """Binary Dict pages of four tiles (4096 rows each) or more leave the value bytes of their tiles to k_bin_tile_sums /
+    k_bin_tile_scan — a workgroup per tile instead of a walk inside the page's k_plan workgroup — shorter pages keep the
+    walk: pages around the limit (3 tiles, exactly 4, 4 and a row, a last tile of one row), pages of both kinds in one
+    call, every index codec the reference nests in a Dict block (binary/dict.rs:60-62), nulls, and a 700 000-row page."""
+    for rows, mps in ((12_288, None), (12_289, None), (16_384, None), (16_385, None), (20_000, None), (100_000, 16_385),
+                      (90_000, 20_000), (163_840, 16_384), (700_001, None)):
+        for icodec in (None, S.RLE, S.BITPACK, S.LZ4):
+            if rows > 100_000 and icodec in (S.RLE, S.LZ4):
+                continue
+            col = gen.binary(rows, uniq=700, null_density=0.1 if rows % 2 else None, large=large, zipf=1.2, maxlen=20, seed=rows)
+            opt = dict(max_page_size=mps, force_codec=S.DICT)
+            if icodec is not None:
+                opt["force_index_codec"] = icodec
+            if icodec == S.BITPACK and (rows % 128 or (mps or 128) % 128):   # (the crate asserts whole 128-blocks)
+                continue
+            check(gpu_ctx, col, **opt)
+    # adaptive, LZ4 default: Dict pages with bit-packed indices next to a short last page, two columns in one call
+    import torch
+    from strawboat_amd import read
+    cols = [gen.binary(150_000, uniq=900, zipf=1.1, maxlen=24, large=large, seed=5),
+            gen.binary(70_000, uniq=50, null_density=0.2, large=large, seed=6)]
+    enc = [gen.oracle_write(c, max_page_size=65536, default_compression=S.LZ4, ratio=2.0) for c in cols]
+    cps = [read.ColumnPages(c["ptype"], c["nullable"], torch.from_numpy(p).to(gpu_ctx.torch_device), m) for c, (p, m) in zip(cols, enc)]
+    got = read.batch_read_columns(gpu_ctx, cps)
+    gpu_ctx.synchronize()
+    for c, (p, m), g in zip(cols, enc, got):
+        want = gen.oracle_read(c, p, m)
+        assert np.array_equal(g.values_numpy(), want["values"])
+        assert np.array_equal(g.offsets_numpy(), want["offsets"])
+        if c["nullable"]:
+            assert np.array_equal(g.validity_numpy(), want["validity"])
+
+
+def test_binary_freq_page_tile_totals_by_tile(gpu_ctx):
+    """a binary Freq page is read as a virtual Dict page (entry 0 = the top value, then the exception records behind the
+    bitmap): 40 000 rows = 10 tiles, so its tile totals come from the tile kernels too (the gap between entry 0 and 1)"""
+    rng = np.random.default_rng(3)
+    n = 40_000
+    words = [b"top-value"] + [("exception-%d" % k).encode() for k in range(400)]
+    idx = np.where(rng.random(n) < 0.04, rng.integers(1, len(words), n), 0)
+    lens = np.array([len(w) for w in words], np.int64)[idx]
+    offs = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"".join(words[i] for i in idx), np.uint8).copy()
+    for nulls in (None, 0.1):
+        col = dict(ptype=S.T_BIN32, nullable=nulls is not None, rows=n, values=data,
+                   validity=None if nulls is None else gen.pack_bits(rng.random(n) >= nulls), offsets=offs.astype(np.int32))
+        pages, metas = check(gpu_ctx, col, force_codec=S.FREQ)
+        assert S.stat_column(col["ptype"], col["nullable"], pages, metas)[0].tolist() == [S.FREQ]
+
+
+def test_binary_dict_long_page_with_an_index_out_of_range(gpu_ctx):
+    """an index beyond the dictionary in a tile of a long page: OutOfSpec from the tile kernel, like the walk (and the oracle)"""
+    from strawboat_amd._native import NativeError
+    seen = set()
+    for uniq, value in ((200, 255), (200, 3), (2000, 1999), (2000, 40_000)):
+        c = gen.binary(30_000, uniq=uniq, maxlen=10, seed=9)
+        pages, metas = gen.oracle_write(c, force_codec=S.DICT, force_index_codec=S.NONE)
+        bad = pages.copy()
+        # plain u32 indices: hdr9 Dict | hdr9 None | N * 4 bytes; row 25 000 (tile 6) gets another index
+        pos = 9 + 9 + 25_000 * 4
+        bad[pos:pos + 4] = np.frombuffer(np.uint32(value).tobytes(), np.uint8)
+        try:
+            want = gen.oracle_read(c, bad, metas)
+        except Exception:
+            want = None
+        seen.add(want is None)
+        try:
+            got = gpu_decode(gpu_ctx, c, bad, metas)
+            gpu_ctx.synchronize()
+        except NativeError as e:
+            assert want is None and e.code == -1
+            continue
+        assert want is not None, "the oracle refuses index %d, the device decoded the page" % value
+        assert np.array_equal(got.values_numpy(), want["values"]) and np.array_equal(got.offsets_numpy(), want["offsets"])
+    assert seen == {True, False}

@@ -2070,36 +2070,55 @@ __global__ void __launch_bounds__(WG) k_bin_tile_scan(DecodeArgs a) {
 // binary columns: value-byte base and offset base of each page (the running `last` of
 // decompress_binary, binary/mod.rs:121,136-144, and values.len()), queue-B inflate jobs for
 // compressed values blocks, and the column's total value bytes.
+// One WAVE per column, a lane per page, 64 pages per step: the bases are exclusive wave scans of the pages' value bytes and
+// last offsets plus the carry of the steps before.  (One thread per column walked its pages one dependent load after the
+// other: 76 us for the 153 pages of a C4 column, and a column of many short pages by the millisecond.)
 __device__ __forceinline__ void colscan_column(const DecodeArgs& a, uint64_t* col_values_len, const uint32_t ci) {
+    const uint32_t lane = threadIdx.x & 63;
     const ColDesc c = a.cols[ci];
     if (!is_binary(c.ptype)) {
-        col_values_len[ci] = c.ptype == SB_TYPE_BOOLEAN ? (c.rows + 7) / 8 : c.rows * c.width;
+        if (lane == 0) col_values_len[ci] = c.ptype == SB_TYPE_BOOLEAN ? (c.rows + 7) / 8 : c.rows * c.width;
         return;
     }
-    uint64_t vbase = 0, obase = 0;
-    for (uint32_t k = 0; k < c.n_pages; k++) {
-        const uint32_t p = c.first_page + k;
-        PageDesc d = a.descs[p];
-        d.val_base = vbase;
+    uint64_t vbase = 0, obase = 0;   // (wave-uniform carries)
+    for (uint32_t k0 = 0; k0 < c.n_pages; k0 += 64) {
+        const bool in = k0 + lane < c.n_pages;
+        const uint32_t p = c.first_page + min(k0 + lane, c.n_pages - 1);
+        const PageDesc d = a.descs[p];
+        const bool was_ok = in && d.ok;
+        // a page that was not ok adds nothing; one that does not fit still counts (the column's values_len is reported)
+        const uint64_t vb = was_ok ? d.val_bytes : 0, ob = was_ok ? d.off_last : 0;
+        uint64_t vi = vb, oi = ob;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t uv = __shfl_up(vi, o, 64), uo = __shfl_up(oi, o, 64);
+            if ((int)lane >= o) {
+                vi += uv;
+                oi += uo;
+            }
+        }
+        const uint64_t my_vbase = vbase + vi - vb;
         // page 0's offsets are taken verbatim (incl. offsets[0]); later pages add the running last offset
-        d.off_base = obase;
+        const uint64_t my_obase = obase + oi - ob;
         // a page whose value bytes do not fit the caller's buffer is not expanded at all (the tile kernels
         // skip !ok pages): nothing is written past values_cap, the column's values_len is still reported
-        const bool fits = vbase + d.val_bytes <= c.values_cap;
-        const bool was_ok = d.ok;
-        if (!fits) d.ok = 0;
-        a.descs[p] = d;
-        if (!was_ok) continue;
-        if (fits && is_basic(d.codec) && d.codec != SB_CODEC_NONE && !(d.codec == SB_CODEC_ZSTD && a.jobs_z))
-            push_job(a.jobs_b, a.job_counts + 1, d.vbody, d.vcsize, c.values + vbase, d.vusize, d.codec, p);
-        vbase += d.val_bytes;
-        obase += d.off_last;
+        const bool fits = my_vbase + d.val_bytes <= c.values_cap;
+        if (in) {
+            a.descs[p].val_base = my_vbase;
+            a.descs[p].off_base = my_obase;
+            if (!fits && d.ok) a.descs[p].ok = 0;
+        }
+        const bool job = was_ok && fits && is_basic(d.codec) && d.codec != SB_CODEC_NONE && !(d.codec == SB_CODEC_ZSTD && a.jobs_z);
+        push_job_if(job, a.jobs_b, a.job_counts + 1, d.vbody, d.vcsize, c.values + my_vbase, d.vusize, d.codec, p);
+        vbase += __shfl(vi, 63, 64);
+        obase += __shfl(oi, 63, 64);
     }
-    col_values_len[ci] = vbase;
-    if (vbase > c.values_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 300);
+    if (lane == 0) {
+        col_values_len[ci] = vbase;
+        if (vbase > c.values_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 300);
+    }
 }
-__global__ void k_colscan(DecodeArgs a, uint64_t* col_values_len) {
-    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) k_colscan(DecodeArgs a, uint64_t* col_values_len) {
+    const uint32_t ci = blockIdx.x;   // (one wave per column)
     if (ci < a.n_cols) colscan_column(a, col_values_len, ci);
     // queue B is complete now (k_parse's deferred payloads + the value blocks queued above): split its multi-frame entries
     if (!a.sizes_only && last_workgroup_done(&a.job_counts[6]) && threadIdx.x == 0)   // queue B is complete: its length for k_zstd_split
@@ -2848,7 +2867,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     if (any_binary) {  // (without binary columns the host knows every values_len itself)
         KScope k(ctx, K_COLSCAN);
-        k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
+        k_colscan<<<a.n_cols, 64, 0, s>>>(a, col_values_len);
         launch_zstd_split(a, a.jobs_b, a.job_counts + 1, a.job_counts + 9, a.job_cap_b, s);
     }
     if (a.jobs_z) {   // queue Z: the frames the pipeline took are executed now that every page has its place; the rest by k_inflate
@@ -2896,7 +2915,7 @@ void launch_parse_sizes(sb_ctx* ctx, const DecodeArgs& a, uint64_t* col_values_l
     k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
     k_inflate_lz4<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, 0xFFFFFFFFu, a.job_cap_a);
     k_plan<<<a.n_pages, WG, 0, s>>>(a);
-    k_colscan<<<(a.n_cols + 63) / 64, 64, 0, s>>>(a, col_values_len);
+    k_colscan<<<a.n_cols, 64, 0, s>>>(a, col_values_len);
 }
 
 }  // namespace sb

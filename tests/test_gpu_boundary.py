@@ -141,3 +141,52 @@ def test_freq_records_of_a_failed_interval_are_dropped(gpu_ctx):
         p2, m2 = gen.oracle_write(b, max_page_size=4096, force_codec=S.FREQ)
         got = read.read_simple(gpu_ctx, read.ColumnPages(S.T_I64, False, _dev(gpu_ctx, p2), m2))
         assert np.array_equal(got.values_numpy().view(np.int64), b["values"])
+
+
+def test_columns_of_many_pages_take_their_bases_from_wave_scans(gpu_ctx):
+    """k_colscan gives every page of a binary column its value-byte base and offset base: a wave per column, 64 pages per
+    step (binary/mod.rs:121,136-144: the running `last`).  Columns of 1, 63, 64, 65, 130 and 333 pages in ONE call, Dict /
+    Basic(LZ4) / plain / OneValue pages (the LZ4 value blocks are queued by the scan), i32 and i64 offsets, nulls; then a
+    values buffer that ends inside the 100th page: SB_ERR_INVALID, the size reported, nothing written behind the buffer."""
+    import torch
+    from strawboat_amd import _native as N
+    from strawboat_amd import read
+    specs = [(1, S.DICT, False), (63, S.LZ4, False), (64, S.NONE, True), (65, S.DICT, True), (130, S.LZ4, True), (333, S.DICT, False),
+             (70, S.ONEVALUE, False)]
+    cols, encs = [], []
+    for k, (npages, codec, large) in enumerate(specs):
+        rows = npages * 300 - 7
+        col = gen.binary(rows, uniq=1 if codec == S.ONEVALUE else 40 + k, null_density=0.1 if k % 2 else None, large=large, maxlen=30, seed=20 + k)
+        pages, metas = gen.oracle_write(col, max_page_size=300, force_codec=codec)
+        assert metas.shape[0] == npages
+        cols.append(col)
+        encs.append((pages, metas))
+    cps = [read.ColumnPages(c["ptype"], c["nullable"], _dev(gpu_ctx, p), m) for c, (p, m) in zip(cols, encs)]
+    got = read.batch_read_columns(gpu_ctx, cps)
+    gpu_ctx.synchronize()
+    for c, (p, m), g in zip(cols, encs, got):
+        want = gen.oracle_read(c, p, m)
+        assert np.array_equal(g.values_numpy(), want["values"])
+        assert np.array_equal(g.offsets_numpy(), want["offsets"])
+        if c["nullable"]:
+            assert np.array_equal(g.validity_numpy(), want["validity"])
+    # the 333-page Dict column into a buffer that ends inside page 100
+    col, (pages, metas) = cols[5], encs[5]
+    want = gen.oracle_read(col, pages, metas)
+    need = want["values"].size
+    cap = int(want["offsets"][100 * 300 + 150])
+    buf = torch.full((need + 4096,), 0xAB, dtype=torch.uint8, device=gpu_ctx.torch_device)
+    batch = read.ReadBatch(gpu_ctx, [cps[5]], values_capacity=[need])
+    c = batch._arr[0]
+    c.values = C.c_void_p(buf.data_ptr())
+    c.values_capacity = cap
+    batch.enqueue()
+    with pytest.raises(N.NativeError) as ei:
+        gpu_ctx.synchronize()
+    assert ei.value.code == N.SB_ERR_INVALID
+    assert int(c.values_len) == need
+    assert (buf[cap:].cpu().numpy() == 0xAB).all()
+    c.values_capacity = need
+    batch.enqueue()
+    gpu_ctx.synchronize()
+    assert np.array_equal(buf[:need].cpu().numpy(), want["values"])

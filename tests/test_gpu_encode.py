@@ -253,3 +253,30 @@ def test_host_memory_boundary_binary(gpu_ctx):
     assert cr[0].values_len == want["values"].size
     assert np.array_equal(v_out[:cr[0].values_len], want["values"]) and (v_out[cr[0].values_len:] == 0x5A).all()
     assert np.array_equal(o_out, want["offsets"]) and np.array_equal(b_out[:(col["rows"] + 7) // 8], want["validity"])
+
+
+def test_columns_of_many_pages_in_one_call(gpu_ctx):
+    """k_enc_layout places the pages of a column behind each other — a wave per column, 64 pages per step: columns of 1, 63,
+    64, 65, 130 and 333 pages of mixed types in ONE call, adaptive (RLE / Dict / plain / LZ4 pages of very different sizes),
+    PageMeta and bytes against the oracle's (write::write walks the pages one after the other, src/write/serialize.rs:36-49)"""
+    from strawboat_amd import write, WriteOptions
+    specs = [(1, S.T_I64), (63, S.T_F64), (64, S.T_I32), (65, None), (130, S.T_U16), (333, S.T_I64), (70, "bool")]
+    cols = []
+    for k, (npages, what) in enumerate(specs):
+        rows = npages * 500 - 3
+        if what is None:
+            cols.append(gen.binary(rows, uniq=60, null_density=0.1, maxlen=20, seed=50 + k))
+        elif what == "bool":
+            cols.append(gen.boolean(rows, null_density=0.1, runs=7, seed=50 + k))
+        else:
+            cols.append(gen.prim(what, rows, uniq=[3, 1 << 30, 200][k % 3], runs=[9, 1, 2][k % 3], null_density=0.2 if k % 2 else None, seed=50 + k))
+    for opt in (dict(max_page_size=500, ratio=2.0), dict(max_page_size=500, default_compression=S.LZ4)):
+        wo = WriteOptions(default_compression=opt.get("default_compression", 0), default_compress_ratio=opt.get("ratio"),
+                          max_page_size=500, lz4_exact=True)
+        encs = write.encode_columns(gpu_ctx, [to_device_column(gpu_ctx, c) for c in cols], wo)
+        gpu_ctx.synchronize()
+        for (npages, _), c, e in zip(specs, cols, encs):
+            want_pages, want_metas = gen.oracle_write(c, **opt)
+            assert want_metas.shape[0] == npages
+            assert np.array_equal(e.metas_array(), want_metas)
+            assert np.array_equal(e.pages_numpy(), want_pages)

@@ -78,16 +78,20 @@ def gen_parallel(fn, seeds):
         return list(ex.map(fn, seeds))
 
 
-def cpu_baseline(cols, sbo_opts, arrow_bytes, sample_desc, rep_for_all_cores=True):
+def cpu_baseline(cols, sbo_opts, arrow_bytes, sample_desc, rep_for_all_cores=True, all_cores=True, iters=2):
     """CPU restatement (oracle) over the (column, page) items of `cols`: 1 thread — how the reference runs —
     and page-parallel over all host cores.  Bounded: the sample is sized by the caller."""
     from oracle import sbo
     cores = host_cores()
     sysc = sbo.system_codecs(True)   # Basic(LZ4 / Zstd) blocks through the box's liblz4 / libzstd (BASELINE.md section 5)
-    tw, tr, _ = sbo.time_pages_mt(cols, sbo_opts, threads=1, iters=2)
+    tw, tr, _ = sbo.time_pages_mt(cols, sbo_opts, threads=1, iters=iters)
     one = {"value": round(2.0 * arrow_bytes / (tw + tr) / 1e9, 3), "encode": round(arrow_bytes / tw / 1e9, 3),
            "decode": round(arrow_bytes / tr / 1e9, 3)}
     rep = 1
+    if not all_cores:   # (a one-page column is ONE work item for the reference: there is no all-cores leg)
+        sbo.system_codecs(False)
+        return {"value": one["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": sample_desc, "one_thread": one,
+                "all_cores": None, "cpu_model": cpu_model()}
     if rep_for_all_cores:
         ps = sbo_opts.max_page_size or max(c["rows"] for c in cols)
         pages = sum((c["rows"] + ps - 1) // ps for c in cols)
@@ -466,6 +470,11 @@ def run_configs(h, only, cpu_on, log):
         i64 = dict(ptype=W.T_I64, nullable=False, rows=n64, values=np.sort(rng.integers(0, 1 << 40, n64)).astype(np.int64), validity=None, offsets=None)
         utf8 = W.zipf_utf8(3_000_000, 42)
         runs = dict(i64, values=np.repeat(rng.integers(0, 200, n64 // 50 + 1), 50)[:n64].astype(np.int64))
+        lowc = dict(ptype=W.T_I32, nullable=False, rows=n64, values=rng.integers(0, 500, n64).astype(np.int32), validity=None, offsets=None)
+        sp = np.full(n64, 1_000_000, dtype=np.int32)
+        spi = rng.random(n64) < 0.02
+        sp[spi] = rng.integers(0, 1 << 30, int(spi.sum())).astype(np.int32)
+        sparse = dict(lowc, values=sp)
         one = {}
         for nm, col, o, desc in (
                 ("int64_adaptive", i64, WriteOptions(default_compress_ratio=2.0), "sorted Int64 (40-bit), adaptive (ratio 2.0), no default compression -> a plain page"),
@@ -473,12 +482,17 @@ def run_configs(h, only, cpu_on, log):
                 ("int64_zstd", i64, WriteOptions(default_compression=C.ZSTD), "the same column, Basic(Zstd)"),
                 ("int64_lz4", i64, WriteOptions(default_compression=C.LZ4), "the same column, Basic(LZ4): one LZ4 block of 68 MB, decoded by one workgroup"),
                 ("utf8_zstd", utf8, WriteOptions(default_compression=C.ZSTD), "Utf8 (zipf over 10 000 words), Basic(Zstd)"),
-                ("utf8_adaptive", utf8, WriteOptions(default_compress_ratio=2.0), "the same column, adaptive -> one Dict page (one workgroup builds it)")):
+                ("utf8_adaptive", utf8, WriteOptions(default_compress_ratio=2.0), "the same column, adaptive -> one Dict page"),
+                ("int32_lowcard_adaptive", lowc, WriteOptions(default_compress_ratio=2.0), "Int32 with 500 distinct values, adaptive -> one Dict page"),
+                ("int32_sparse_adaptive", sparse, WriteOptions(default_compress_ratio=2.0), "Int32, 98 % one value, adaptive -> one Freq page")):
             res = h.measure_flat([col], o, reps=3, check=1)
-            one[nm] = config_entry(nm, res, None, {"workload": "ONE page of %d rows: %s" % (col["rows"], desc)})
+            cpu = None
+            if cpu_on:   # the reference works through a page on ONE thread
+                cpu = cpu_baseline([col], sbo_options(o), W.arrow_bytes(col), "the same one-page column, encode+decode, 1 thread", all_cores=False, iters=1)
+            one[nm] = config_entry(nm, res, cpu, {"workload": "ONE page of %d rows: %s" % (col["rows"], desc)})
             log("one_page %s: encode %.1f GB/s, decode %.1f GB/s" % (nm, one[nm]["encode"]["GBps"], one[nm]["decode"]["GBps"]))
         out["one_page"] = one
-        del i64, utf8, runs
+        del i64, utf8, runs, lowc, sparse, sp
     if want("host_boundary"):
         try:
             out["host_boundary"] = {"c2": run_host_boundary(h, "c2"), "c1": run_host_boundary(h, "c1"),
@@ -900,45 +914,131 @@ def self_launch(n, backend):
 
 
 def kernel_source_sha():
-    """first 16 hex digits of the sha256 over the encode kernels' sources: a PMC profile is this run's traffic only if it was
-    collected for the same sources (scripts/pmc_traffic.py stamps it)"""
+    """first 16 hex digits of the sha256 over EVERY kernel source of the library (csrc/*.hip, *.h, *.cpp, sorted by name): a
+    PMC profile is this run's traffic only if it was collected for the same sources (scripts/summarize_pmc.py stamps it)"""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("sb_encode.hip", "sb_select_runs.h", "sb_select_rle.h", "sb_select_big.h", "sb_select.h", "sb_common.h"):
-        with open(os.path.join(ROOT, "strawboat_amd", "csrc", f), "rb") as fh:
-            hsh.update(fh.read())
+    d = os.path.join(ROOT, "strawboat_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, f), "rb") as fh:
+                hsh.update(f.encode() + b"\0" + fh.read())
     return hsh.hexdigest()[:16]
 
 
+LINE_LIMIT = 8192      # the driver's record parser takes ONE short stdout line (round 4's 40 KB line came back `parsed: null`)
+STR_LIMIT = 120        # ... and cuts strings at 128 characters
+
+
+def _f(x):
+    """3 significant digits, no exponent"""
+    if x is None:
+        return "n/a"
+    x = float(x)
+    if x >= 100:
+        return "%.0f" % x
+    if x >= 10:
+        return "%.1f" % x
+    if x >= 1:
+        return "%.2f" % x
+    if x >= 0.01 or x == 0:
+        return ("%.3f" % x).lstrip("0") or "0"
+    return ("%.5f" % x).lstrip("0")
+
+
 def config_summary(configs):
-    """one line per configuration (the driver's record keeps `config`, not `configs`): Arrow GB/s and HBM fraction per direction"""
+    """ONE short string per configuration (the driver's record keeps `config` and cuts strings at 128 characters): GB/s of
+    Arrow bytes and the fraction of the 8 TB/s HBM peak reached by the direction's algorithmic bytes, per direction, and
+    the CPU restatement (1 thread / all cores, encode+decode) where the entry has one"""
     out = {}
     for k, e in (configs or {}).items():
         if not isinstance(e, dict):
             continue
         if "encode" in e and "decode" in e:
-            out[k] = "enc %.1f GB/s (%.3f of HBM peak), dec %.1f GB/s (%.3f)" % (
-                e["encode"]["GBps"], e["encode"]["frac_hbm"], e["decode"]["GBps"], e["decode"]["frac_hbm"])
-            for rk in ("leaf_pages_reference_written",):
-                if isinstance(e.get(rk), dict) and "decode" in e[rk]:
-                    out[k] += "; pages written by the reference's codec: dec %.1f GB/s" % e[rk]["decode"]["GBps"]
-            if isinstance(e.get("cpu_baseline"), dict):
-                c = e["cpu_baseline"]
-                out[k] += "; CPU 1 thread %.2f, %d threads %.1f GB/s (enc+dec)" % (c["one_thread"]["value"], c["all_cores"]["cores"], c["all_cores"]["value"])
+            s = "enc %s GB/s (%s of HBM) dec %s (%s)" % (_f(e["encode"]["GBps"]), _f(e["encode"]["frac_hbm"]),
+                                                             _f(e["decode"]["GBps"]), _f(e["decode"]["frac_hbm"]))
+            r = e.get("leaf_pages_reference_written")
+            if isinstance(r, dict) and "decode" in r:
+                s += "; libzstd pages dec %s" % _f(r["decode"]["GBps"])
+            c = e.get("cpu_baseline")
+            if isinstance(c, dict):
+                s += "; CPU 1t %s" % _f(c["one_thread"]["value"])
+                if isinstance(c.get("all_cores"), dict):
+                    s += " %dt %s" % (c["all_cores"]["cores"], _f(c["all_cores"]["value"]))
+            sa = e.get("single_array")
+            if isinstance(sa, dict) and "encode_ms" in sa:
+                s += "; 1 array %s/%s ms" % (_f(sa["encode_ms"]), _f(sa["decode_ms"]))
+            out[k] = s
         elif "decode" in e and "written_by" in e:
-            out[k] = "dec %.1f GB/s (%.3f of HBM peak)" % (e["decode"]["GBps"], e["decode"]["frac_hbm"])
+            out[k] = "dec %s GB/s (%s of HBM peak)" % (_f(e["decode"]["GBps"]), _f(e["decode"]["frac_hbm"]))
         elif "encdec_GBps" in e:
-            out[k] = "enc+dec %.1f GB/s over %d GPU(s), %.3f ms per step" % (e["encdec_GBps"], e.get("n_gpus", 1), e.get("ms_per_step", 0.0))
+            out[k] = "enc+dec %s GB/s over %d GPU(s), %s ms per step" % (_f(e["encdec_GBps"]), e.get("n_gpus", 1), _f(e.get("ms_per_step", 0.0)))
         elif k == "host_boundary" and "c2" in e:
-            out[k] = "PCIe-inclusive (SB_MEM_HOST, pinned): C2 enc %.1f / dec %.1f GB/s, C1 enc %.1f / dec %.1f GB/s of Arrow bytes; link peak 63 GB/s" % (
-                e["c2"]["encode_GBps"], e["c2"]["decode_GBps"], e["c1"]["encode_GBps"], e["c1"]["decode_GBps"])
+            out[k] = "PCIe-inclusive, pinned host (link 63): C2 enc %s dec %s, C1 enc %s dec %s GB/s" % (
+                _f(e["c2"]["encode_GBps"]), _f(e["c2"]["decode_GBps"]), _f(e["c1"]["encode_GBps"]), _f(e["c1"]["decode_GBps"]))
+            if e.get("cpu_1t_GBps"):
+                out[k] += "; CPU 1t C2 %s C1 %s" % (_f(e["cpu_1t_GBps"].get("c2")), _f(e["cpu_1t_GBps"].get("c1")))
         elif "error" in e:
-            out[k] = "error: %s" % e["error"]
+            out[k] = ("error: %s" % e["error"])
         else:
             sub = config_summary(e)
             for kk, vv in sub.items():
-                out["%s.%s" % (k, kk)] = vv
+                out["%s_%s" % (k, kk)] = vv
+    return {k: v[:STR_LIMIT] for k, v in out.items()}
+
+
+def assemble_line(head, cfg_head, roof, north, cpu, configs):
+    """The ONE stdout line of a run (dict; `bench_line` turns it into text).  Short by construction: the headline keys of the
+    bench contract, `config` = the workload + one short string per configuration, `roofline`, `north_star_decode`,
+    `cpu_baseline`.  Everything longer (per-configuration entries with their kernels) goes to the sidecar file, not here."""
+    cfg = dict(cfg_head)
+    for k, v in config_summary(configs).items():
+        cfg[k] = v
+    if north:
+        cfg["north_star_decode"] = ("C1 1 M-row Int64 page decode: %s of HBM peak end to end, %s for k_expand alone (target 0.40)"
+                                    % (_f(north.get("frac_end_to_end")), _f(north.get("frac_kernel"))))[:STR_LIMIT]
+    cb = None
+    if cpu:
+        cb = {k: cpu[k] for k in ("value", "unit", "cores", "kind") if k in cpu}
+        cb["sample"] = str(cpu.get("sample", ""))[:STR_LIMIT]
+        cb["cpu_model"] = str(cpu.get("cpu_model", ""))[:60]
+        if isinstance(cpu.get("all_cores"), dict):
+            cb["all_cores_value"] = cpu["all_cores"]["value"]
+            cb["all_cores"] = cpu["all_cores"]["cores"]
+        cb["note"] = "C++ restatement of the reference's algorithm (oracle/), Basic blocks via the box's liblz4 / libzstd"
+    out = dict(head)
+    out["config"] = cfg
+    out["roofline"] = roof
+    out["north_star_decode"] = north
+    out["cpu_baseline"] = cb
     return out
+
+
+def bench_line(out):
+    """json text of the line; sheds the longest config strings rather than exceed LINE_LIMIT"""
+    line = json.dumps(out, separators=(",", ":"))
+    cfg = out.get("config") or {}
+    while len(line) >= LINE_LIMIT:
+        longest = max((k for k, v in cfg.items() if isinstance(v, str) and k != "workload"), key=lambda k: len(cfg[k]), default=None)
+        if longest is None or len(cfg[longest]) <= 24:
+            break
+        cfg[longest] = cfg[longest][:len(cfg[longest]) // 2]
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def write_detail(detail):
+    """the long record (every configuration with its kernels, the headline's kernels): `bench_detail.json` at the repo root
+    and under gpurun_out/ (what travels back from a GPU box), and one line on stderr"""
+    txt = json.dumps(detail)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_detail.json"), "w") as fh:
+                fh.write(txt)
+        except OSError:
+            pass
+    print("[bench-detail] " + txt, file=sys.stderr, flush=True)
 
 
 def main():
@@ -1006,7 +1106,8 @@ def main():
     harness = GpuHarness(ctx)
     if args.only:
         res = run_configs(harness, set(args.only.split(",")), not args.no_cpu_baseline, log)
-        print(json.dumps({"metric": METRIC, "configs": res, "hbm_peak_GBps": HBM_PEAK_GBS}))
+        write_detail({"metric": METRIC, "configs": res, "hbm_peak_GBps": HBM_PEAK_GBS, "kernel_source_sha16": kernel_source_sha()})
+        print(bench_line({"metric": METRIC, "config": dict({"workload": "only: " + args.only}, **config_summary(res)), "hbm_peak_GBps": HBM_PEAK_GBS}))
         return
 
     B = args.columns
@@ -1120,7 +1221,7 @@ def main():
         # HBM traffic of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate passes of this same command; summary committed under profiles/)
         src_sha = kernel_source_sha()
-        for pf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+        for pf in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 pc = pmc["config"]
@@ -1155,14 +1256,17 @@ def main():
             del wbatch, rbatch, enc, dec, pages, cols
             torch.cuda.empty_cache()
             configs = run_configs(harness, None, not args.no_cpu_baseline, log)
-        summ = config_summary(configs)
+            hb = configs.get("host_boundary")
+            if isinstance(hb, dict) and "c2" in hb and cpu:   # the CPU path has no PCIe leg: its C2 / C1 rates are the ones to hold against
+                c1cpu = (configs.get("c1") or {}).get("cpu_baseline") or {}
+                hb["cpu_1t_GBps"] = {"c2": cpu["value"], "c1": c1cpu.get("value")}
         north = None
         c1e = (configs or {}).get("c1")
         if isinstance(c1e, dict) and "decode" in c1e:   # BASELINE.json north_star: >= 40 % of HBM peak on 1 M-row primitive-page decode
             dk = c1e["decode"]
             A1 = (c1e["arrow_MB"] + c1e["page_MB"]) * 1e6
             kms = dk["kernels_ms"].get("k_expand")
-            north = {"config": "C1 (128 x 1 M-row Int64 pages, one page per column, no compression)", "target_frac": 0.40,
+            north = {"config": "C1: 128 x 1 M-row Int64, one page per column, no compression", "target_frac": 0.40,
                      "frac_end_to_end": dk["frac_hbm"], "decode_ms": dk["ms"],
                      "frac_kernel": round(A1 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms else None, "kernel": "k_expand", "kernel_ms": kms}
         cfg = {"workload": "C2: %d x 1M-row nullable Float64 columns per GPU, 64Ki-row pages, codec %s, "
@@ -1170,22 +1274,18 @@ def main():
                "columns_per_gpu": B, "rows_per_column": ROWS, "page_rows": PAGE,
                "arrow_bytes_per_step": U, "page_bytes_per_step": page_bytes,
                "parallelism": "pages of independent columns sharded across %d GPU(s)" % world,
-               "note": "C2 is the most compressible configuration (RLE, 16x); the keys below are one line per other configuration "
-                       "(GB/s of Arrow bytes, fraction of the 8 TB/s HBM peak reached by the direction's algorithmic bytes)"}
-        for k, v in summ.items():   # flat, string-valued: the driver's record keeps `config`
-            cfg[k.replace(".", "_")] = v
-        out = {
+               "note": "C2 is the FRIENDLIEST config (RLE 16x); the keys below: one line per other config, GB/s of Arrow bytes"}
+        head = {
             "metric": METRIC,
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 bit patterns (integer/bit work, no arithmetic)",
             "data": "synthetic",
-            "config": cfg,
-            "roofline": roof, "north_star_decode": north, "cpu_baseline": cpu, "kernels": kernels, "configs": configs,
         }
-        # the line is long (every configuration with its kernels): the short keys go LAST so that a tail of the output holds them
-        out["summary"] = summ
-        print(json.dumps(out))
+        out = assemble_line(head, cfg, roof, north, cpu, configs)
+        write_detail(dict(head, config=cfg, roofline=roof, north_star_decode=north, cpu_baseline=cpu, kernels=kernels, configs=configs,
+                          kernel_source_sha16=src_sha))
+        print(bench_line(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

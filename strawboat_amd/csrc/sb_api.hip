@@ -180,6 +180,9 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
     if (const char* e = getenv("SB_ZSTD_BLOCKS")) ctx->zb_mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
     if (const char* e = getenv("SB_ZSTD_BLOCKS_WG")) ctx->zb_wg_exec = e[0] != '0';
     if (const char* e = getenv("SB_ZSTD_BLOCKS_MIN")) ctx->zb_min_csize = (uint32_t)strtoul(e, nullptr, 10);
+    // tests: divide the block pipeline's pool estimates so that a call runs out of pool space part-way (frames that do not
+    // fit go back to the frame-serial decoder)
+    if (const char* e = getenv("SB_ZSTD_BLOCKS_POOL_DIV")) ctx->zb_pool_div = std::max<uint32_t>(1, (uint32_t)strtoul(e, nullptr, 10));
     *out = ctx;
     return SB_OK;
 }
@@ -314,6 +317,9 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         ctx->kinds_seen |= ctx->h_status->kinds & KIND_ZSTD;
         // (not sticky: what the calls since the last synchronize looked like decides the order of the next call's entropy kernels)
         if (ctx->h_status->kinds & KIND_ZSTD) ctx->zb_seq_long = (ctx->h_status->kinds & KIND_ZSEQ_LONG) != 0;
+        // the device only ever sets bits: the word is cleared here so that it describes the calls of ONE interval (the host's
+        // kinds_seen keeps what must stay)
+        if (ctx->h_status->kinds) (void)hipMemsetAsync(&ctx->d_status->kinds, 0, sizeof ctx->d_status->kinds, ctx->stream);
     }
     if (e != hipSuccess) {
         rc = check_hip(ctx, e, "sb_ctx_synchronize");
@@ -600,9 +606,16 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             const uint64_t rows = cols[i].rows;
             out_bytes += sizes_only ? rows * 8 + 64 : cols[i].values_capacity + (is_binary_t(cols[i].physical_type) ? cols[i].offsets_capacity : 0) + rows * 8 + 64;
         }
-        zb_block_cap = std::min<uint64_t>(pages_bytes / 2048 + 2 * job_cap + 64, 1u << 23);
-        zb_lit_cap = std::min<uint64_t>(4 * pages_bytes, out_bytes) + 16 * zb_block_cap + (1u << 16);
-        zb_rec_cap = std::min<uint64_t>(pages_bytes / 2, out_bytes / 3) + (1u << 14);
+        // Sized from the OUTPUT, not from the stream: a 128 KiB block of repetitive data is a few hundred stream bytes, RLE
+        // literals expand 1 byte to 128 KiB, RLE / repeat-mode tables spend well under a byte per sequence.
+        zb_block_cap = std::min<uint64_t>(std::max<uint64_t>(pages_bytes / 2048, out_bytes / 8192) + 2 * job_cap + 64, 1u << 23);
+        zb_lit_cap = out_bytes + 16 * zb_block_cap + (1u << 16);
+        zb_rec_cap = std::min<uint64_t>(4 * pages_bytes, out_bytes / 3) + (1u << 14);
+        if (ctx->zb_pool_div > 1) {
+            zb_block_cap = std::max<uint64_t>(zb_block_cap / ctx->zb_pool_div, 4);
+            zb_lit_cap = std::max<uint64_t>(zb_lit_cap / ctx->zb_pool_div, 4096);
+            zb_rec_cap = std::max<uint64_t>(zb_rec_cap / ctx->zb_pool_div, 64);
+        }
         if (!ensure(ctx, ctx->zb_blocks, zb_block_cap * (sizeof(ZbBlock) + 16)) || !ensure(ctx, ctx->zb_lit, zb_lit_cap + 64) ||
             !ensure(ctx, ctx->zb_rec, zb_rec_cap * 12 + 16))
             return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zstd block pools) failed");

@@ -63,6 +63,7 @@ struct sb_ctx {
     bool zb_seq_long = false;    // the last Zstd calls held blocks of >= 8192 sequences: zb_seq is submitted before zb_lit
     int zb_mode = 2;             // 0 off, 1 always, 2 once Zstd has been seen
     uint32_t zb_wg_exec = 1;     // SB_ZSTD_BLOCKS_WG=0: frames of many short sequences through the wave executor too
+    uint32_t zb_pool_div = 1;    // SB_ZSTD_BLOCKS_POOL_DIV (tests): pool estimates divided by this
     uint32_t zb_min_csize = 0;   // SB_ZSTD_BLOCKS_MIN: frames shorter than this keep the one-wave / lane-per-frame paths
 
     static constexpr int NSLOTS = 8;

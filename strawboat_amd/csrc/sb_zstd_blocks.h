@@ -21,9 +21,13 @@
 //   zb_exec   wave / frame     blocks in order: repeat offsets resolved, records executed through the LDS output ring
 //                              (sb_lz4.h LzSeqExec), raw / RLE blocks copied
 //
-// Anything the pipeline does not take (several frames in one buffer, pools exhausted, a malformed stream) stays with — or
-// is handed back to — the one-wave decoder, which also owns the error codes: a frame is "punted" by restoring its queue
-// entry before k_inflate runs.
+// Anything the pipeline does not take (several frames in one buffer, pools exhausted, a stream whose headers or entropy
+// stages are malformed) stays with — or is handed back to — the one-wave decoder, which owns the error codes of those
+// cases: a frame is "punted" by restoring its queue entry before k_inflate runs.  The one exception: faults that only
+// show while the records are EXECUTED (an offset beyond the output so far, an overrun, a length mismatch) are raised by
+// zb_exec / zb_exec_wg themselves as SB_ERR_EXTERNAL with detail 120 + n — part of dst may be written by then, as with the
+// one-wave decoder, but the detail code of the same damaged frame can differ between SB_ZSTD_BLOCKS=0 and 1 (both refuse
+// it; tests/test_gpu_zstd_blocks.py compares accept / refuse and the decoded bytes with the oracle, not the detail).
 #pragma once
 #include "sb_zstd.h"
 #include "sb_lz4_big.h"   // wave_scan_max_dpp; zb_exec_wg copies windows the way lz4_inflate_block_wg does
@@ -201,14 +205,29 @@ __global__ void __launch_bounds__(WG) zb_scan(InflateJob* q, const uint32_t* cou
         }
         if (ip != n || known_out > job.out_len) continue;   // several frames / trailing bytes: the one-wave path walks them
         // ---- pool areas
+        // The reservation is all-or-nothing for the consumers: zb_hdr / zb_lit / zb_seq walk EVERY slot below counters[0], and
+        // the block pool is neither cleared between calls nor by ensure() — a slot this thread reserved and then gave up
+        // (another pool full) would still hold the previous call's descriptor, naming a live frame index of THIS call.  Every
+        // path that gives up after the block atomicAdd therefore stores inert descriptors (frame = ZB_NONE: no consumer
+        // looks further) into the part of its range that lies inside the pool.
         const uint32_t b0 = atomicAdd(&zp.counters[0], nb);
-        if ((uint64_t)b0 + nb > zp.block_cap) continue;
+        auto give_up = [&]() {
+            ZbBlock v;
+            __builtin_memset(&v, 0, sizeof v);
+            v.frame = ZB_NONE;
+            v.btype = 3;
+            v.huf_def = ZB_NONE;
+            v.def[0] = v.def[1] = v.def[2] = ZB_NONE;
+            for (uint64_t k = b0; k < (uint64_t)b0 + nb && k < zp.block_cap; k++) zp.blocks[k] = v;
+            if (zp.stats) atomicAdd(&zp.stats[1], 1ull);   // counted with the frames handed back (sb_ctx_zstd_block_stats)
+        };
+        if ((uint64_t)b0 + nb > zp.block_cap) { give_up(); continue; }
         const uint64_t l0 = atomicAdd((unsigned long long*)&zp.counters[4], (unsigned long long)lit_need);
-        if (l0 + lit_need > zp.lit_cap) continue;
+        if (l0 + lit_need > zp.lit_cap) { give_up(); continue; }
         const uint64_t r0 = atomicAdd((unsigned long long*)&zp.counters[6], (unsigned long long)rec_need);
-        if (r0 + rec_need > zp.rec_cap) continue;
+        if (r0 + rec_need > zp.rec_cap) { give_up(); continue; }
         const uint32_t f = atomicAdd(&zp.counters[1], 1u);
-        if (f >= zp.frame_cap) continue;
+        if (f >= zp.frame_cap) { give_up(); continue; }
         // ---- second walk: the descriptors
         ip = ip0;
         uint32_t huf_def = ZB_NONE, d_ll = ZB_NONE, d_of = ZB_NONE, d_ml = ZB_NONE;

@@ -216,3 +216,54 @@ def test_pipeline_off_matches_on():
         assert ctx.zstd_block_stats()[0] == 0
     finally:
         ctx.close()
+
+
+def test_partial_pool_exhaustion_on_a_reused_context():
+    """a frame whose pool reservation fails part-way must leave INERT block descriptors behind — the block
+    pool is not cleared between calls, so the slots it gave up still hold the previous call's descriptors, which name frame
+    indices that are live in this call.  A context first decodes a large call (the pools fill with descriptors), then — with
+    the pool estimates divided so that only some frames fit — calls with many tiny blocks and many sequences per byte; the
+    refused frames go through the frame-serial decoder, and every column must equal the oracle's decode."""
+    import torch
+    from strawboat_amd import read
+    rng = np.random.default_rng(77)
+    old = os.environ.get("SB_ZSTD_BLOCKS_POOL_DIV")
+    try:
+        for div in ("1", "6", "40", "400"):
+            os.environ["SB_ZSTD_BLOCKS_POOL_DIV"] = div
+            ctx = _ctx("1")
+            try:
+                # 1. a large call: descriptors of many frames / blocks stay in the pool afterwards
+                roundtrip(ctx, SHAPES["words"], 3, max_page_size=SHAPES["words"]["rows"] // 9)
+                roundtrip(ctx, SHAPES["zipf_text"], 3)
+                # 2. calls of several columns in which only part of the frames fits the (divided) pools
+                cols, pages = [], []
+                for k in range(5):
+                    if k % 2 == 0:   # many sequences per stream byte: short repeats of few words
+                        words = [b"w%d" % j for j in range(30)]
+                        c = u8col(np.frombuffer(b"".join(words[i] for i in rng.integers(0, 30, 120_000)), np.uint8))
+                    else:            # highly compressible: 128 KiB blocks of a few hundred stream bytes
+                        c = u8col(np.tile(rng.integers(0, 256, 100 + k).astype(np.uint8), 4000))
+                    p, m = gen.oracle_write(c, max_page_size=c["rows"] // (3 + k))
+                    cols.append(c)
+                    pages.append(recompress(c, p, m, 3 if k < 3 else 19))
+                before = ctx.zstd_block_stats()
+                for _ in range(2):
+                    cps = [read.ColumnPages(c["ptype"], c["nullable"], torch.from_numpy(p).to(ctx.torch_device), m) for c, (p, m) in zip(cols, pages)]
+                    got = read.batch_read_columns(ctx, cps)
+                    ctx.synchronize()
+                    for c, g, (p, m) in zip(cols, got, pages):
+                        want = gen.oracle_read(c, p, m)
+                        assert np.array_equal(g.values_numpy(), want["values"]), "pool divisor %s: a column differs from the oracle's decode" % div
+                after = ctx.zstd_block_stats()
+                if div == "400":
+                    assert after[1] > before[1], "no frame was refused although the pools were cut to 1/400"
+                if div == "1":
+                    assert after[1] == before[1] and after[0] > before[0]
+            finally:
+                ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("SB_ZSTD_BLOCKS_POOL_DIV", None)
+        else:
+            os.environ["SB_ZSTD_BLOCKS_POOL_DIV"] = old

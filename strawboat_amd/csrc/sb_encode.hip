@@ -78,6 +78,7 @@ struct EncPage {
     uint32_t forb_extra;  // codecs forbidden for this block in addition to the options'
     uint64_t h64_off;     // binary pages: scratch offset of one u64 hash per row (~0: none), written by bin_hash_rows
     uint64_t zst_off;     // Basic(Zstd) pages: scratch of the Zstd encoder (zstd_scratch_bytes; ~0: none)
+    uint64_t bigx_off;    // long pages (>= SEL_BIG_ROWS rows) that may become Dict pages: work area of sb_dict_big.h (0: none)
 };
 
 struct EncOut {
@@ -3256,6 +3257,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
 #include "sb_select_rle.h"
 #include "sb_select_runs.h"
 #include "sb_select_big.h"
+#include "sb_dict_big.h"
 
 // Binary pages hash strings: a probe that misses the LDS tier costs a random HBM access per row (13 GB of traffic for
 // 1.15 GB of C3 input when the table sat in HBM), so their LDS table is 16 Ki slots (~10 000 distinct strings per page).
@@ -3658,8 +3660,9 @@ __global__ void __launch_bounds__(WG, (emit_pages_occupancy<KIND, CODEC>()))
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
     if (codec_of(a, p, page) != CODEC) return;
-    if constexpr (CODEC == SB_CODEC_RLE) {
-        if (a.outs[page].pad == 1 && a.outs[page].length != 0) return;  // already emitted by the fused select + RLE pass
+    if constexpr (CODEC == SB_CODEC_RLE || CODEC == SB_CODEC_DICT) {
+        // already emitted: by the fused select + RLE pass / by the section-parallel writers of long pages (sb_dict_big.h)
+        if (a.outs[page].pad == 1 && a.outs[page].length != 0) return;
     }
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
@@ -5306,6 +5309,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         }
     }
     uint64_t P = 0, max_tiles = 1, max_chunks = 1;
+    bool big_possible = false;
     // LZ4 blocks of more than LZC_CH bytes are compressed chunk by chunk (flat pages, the matcher that is free to choose)
     const bool zs_possible = host_codec == SB_CODEC_ZSTD || (adaptive && opts->default_compression == SB_CODEC_ZSTD);
     const bool sn_possible = host_codec == SB_CODEC_SNAPPY || (adaptive && opts->default_compression == SB_CODEC_SNAPPY);
@@ -5328,6 +5332,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const uint64_t ps = page_size_of(c.rows, opts);
         const uint64_t np = c.page_rows ? c.n_pages_in : (c.rows + ps - 1) / ps;
         if (np > c.n_pages_capacity || !c.out_metas) return ctx->fail(SB_ERR_INVALID, "out_metas too small");
+        // (long pages that may become Dict pages run their index arrays as virtual pages: sb_dict_big.h)
+        big_possible |= adaptive && !((forb >> SB_CODEC_DICT) & 1) && !enc_is_binary(c.physical_type) && c.rows >= SEL_BIG_ROWS;
         if (!c.out_pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "out_pages is null");
         P += np;
         if (hit) continue;   // (the per-page arithmetic of this shape is in the plan)
@@ -5434,9 +5440,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     const size_t o_lzplan = off;                             // (inside the region zeroed per call: count | per-page plans)
     off = align_up(off + (lz_cap ? 64 + P * sizeof(LzChunkPlan) : 0), 64);
     const size_t o_vcols = off;
-    off = align_up(off + (freq_possible ? P : 0) * sizeof(EncCol), 64);
+    off = align_up(off + (freq_possible || big_possible ? P : 0) * sizeof(EncCol), 64);
     const size_t o_vpages = off;
-    off = align_up(off + (freq_possible ? P : 0) * sizeof(EncPage), 64);
+    off = align_up(off + (freq_possible || big_possible ? P : 0) * sizeof(EncPage), 64);
     const size_t o_lzlist = off;
     off = align_up(off + lz_cap * sizeof(LzChunkDesc), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
@@ -5522,6 +5528,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 const int k = d.width == 1 ? 0 : d.width == 2 ? 1 : d.width == 4 ? 2 : 3;
                 plan.bigw[k].push_back((uint32_t)pi);
                 plan.big_secs[k] = std::max(plan.big_secs[k], secs);
+                if (!((forb >> SB_CODEC_DICT) & 1)) p.bigx_off = 1;   // (placed with the aux areas below)
             }
             if (direct) {
                 p.direct_off = direct_off;
@@ -5601,6 +5608,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             scratch_off = align_up(scratch_off, 16);
             hp[q].h64_off = scratch_off;
             scratch_off += hp[q].rows * 8;
+        }
+        if (hp[q].bigx_off == 1) {
+            scratch_off = align_up(scratch_off, 64);
+            hp[q].bigx_off = scratch_off;
+            scratch_off += dbig_layout(hp[q].rows).total;
         }
         if (hp[q].zst_off == 0) {   // (one block is at most 128 KiB whatever the page holds)
             scratch_off = align_up(scratch_off, 16);
@@ -5770,10 +5782,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             const dim3 sg(plan.big_secs[k], nbig), pg(1, nbig);
 #define SB_BIG_W(KERNEL, GRID, THREADS)                                    \
     do {                                                                   \
-        if (kd == 1) KERNEL<1><<<GRID, THREADS, 0, st>>>(aa, list);        \
-        else if (kd == 2) KERNEL<2><<<GRID, THREADS, 0, st>>>(aa, list);   \
-        else if (kd == 4) KERNEL<4><<<GRID, THREADS, 0, st>>>(aa, list);   \
-        else KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list);                \
+        if (kd == 1) KERNEL<1><<<GRID, THREADS, 0, st>>>(aa, list, 0u);        \
+        else if (kd == 2) KERNEL<2><<<GRID, THREADS, 0, st>>>(aa, list, 0u);   \
+        else if (kd == 4) KERNEL<4><<<GRID, THREADS, 0, st>>>(aa, list, 0u);   \
+        else KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list, 0u);                \
     } while (0)
             {
                 KScope kk(ctx, "k_sel_big_sec");
@@ -5785,7 +5797,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             }
             {
                 KScope kk(ctx, "k_sel_big_count");
-                k_sel_big_clear<<<sg, WG, 0, st>>>(aa, list);
+                k_sel_big_clear<<<sg, WG, 0, st>>>(aa, list, 0u);
                 const dim3 cg(sg.x * BIG_COUNT_SPLIT, nbig);
                 SB_BIG_W(k_sel_big_count, cg, WG);
             }
@@ -5801,6 +5813,58 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 SB_BIG_W(k_rle_big_done, pg, 64);
             }
 #undef SB_BIG_W
+            if (!((forb >> SB_CODEC_DICT) & 1)) {   // long Dict pages: sb_dict_big.h
+                const dim3 gg(256, nbig);
+                const uint32_t vo = (uint32_t)P;
+#define SB_DBIG_W(KERNEL, GRID, THREADS)                                   \
+    do {                                                                   \
+        if (kd == 1) KERNEL<1><<<GRID, THREADS, 0, st>>>(aa, list);        \
+        else if (kd == 2) KERNEL<2><<<GRID, THREADS, 0, st>>>(aa, list);   \
+        else if (kd == 4) KERNEL<4><<<GRID, THREADS, 0, st>>>(aa, list);   \
+        else KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list);                \
+    } while (0)
+                {
+                    KScope kk(ctx, "k_dict_big_insert");
+                    SB_DBIG_W(k_dict_big_clear, gg, WG);
+                    SB_DBIG_W(k_dict_big_insert, sg, WG);
+                }
+                {
+                    KScope kk(ctx, "k_dict_big_ids");
+                    SB_DBIG_W(k_dict_big_mark, gg, WG);
+                    SB_DBIG_W(k_dict_big_rank, sg, WG);
+                    SB_DBIG_W(k_dict_big_ids, gg, WG);
+                }
+                {
+                    KScope kk(ctx, "k_dict_big_idx");
+                    SB_DBIG_W(k_dict_big_idx, sg, WG);
+                }
+                {   // the index arrays as virtual pages of u32: selected ...
+                    KScope kk(ctx, "k_sel_big(indices)");
+                    k_sel_big_sec<4><<<sg, WG, 0, st>>>(aa, list, vo);
+                    k_sel_big_merge<4><<<pg, WG, 0, st>>>(aa, list, vo);
+                    k_sel_big_count<4><<<sg, WG, 0, st>>>(aa, list, vo);
+                    k_sel_big_decide<4><<<pg, WG, 0, st>>>(aa, list, vo);
+                }
+                {   // ... and written
+                    KScope kk(ctx, "k_nested_big");
+                    if (!((forb >> SB_CODEC_RLE) & 1)) {
+                        k_rle_big_count<4><<<sg, WG, 0, st>>>(aa, list, vo);
+                        k_rle_big_plan<4><<<pg, WG, 0, st>>>(aa, list, vo);
+                        k_rle_big_emit<4><<<sg, WG, 0, st>>>(aa, list, vo);
+                    }
+                    const dim3 tg((uint32_t)std::min<uint64_t>(max_tiles, 4096), nbig);
+                    k_bp_big<0><<<tg, WG, 0, st>>>(aa, list);
+                    k_bp_big<1><<<pg, WG, 0, st>>>(aa, list);
+                    k_bp_big<2><<<tg, WG, 0, st>>>(aa, list);
+                    k_plain_big<<<dim3(1024, nbig), WG, 0, st>>>(aa, list);
+                }
+                {
+                    KScope kk(ctx, "k_dict_big_finish");
+                    SB_DBIG_W(k_dict_big_finish, pg, WG);
+                    SB_DBIG_W(k_dict_big_values, gg, WG);
+                }
+#undef SB_DBIG_W
+            }
         };
         auto launch_selectors = [&](int kd, hipStream_t st) {
             if (nested && (kd <= 0 || kd > 8)) return;

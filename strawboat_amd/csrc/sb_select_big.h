@@ -61,11 +61,14 @@ __host__ __device__ __forceinline__ uint64_t big_tab_slots(uint64_t N) {
 __device__ __forceinline__ BigPage* big_page_rec(uint8_t* slot) { return (BigPage*)slot; }
 __device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { return (BigSec*)(slot + 256 + (uint64_t)s * BIG_SEC_STRIDE); }
 
-__device__ __forceinline__ bool big_page_of(const EncodeArgs& a, const uint32_t* big, int W, uint32_t* page, EncPage* p, EncCol* c) {
-    *page = big[blockIdx.y];
-    *p = a.pages[*page];
-    *c = a.cols[p->col];
-    return (int)c->width == W && a.codecs[*page] == CODEC_PENDING;   // (k_enc_select_runs may have taken the page)
+// voff: 0 = the pages of the list; n_pages = their VIRTUAL pages (the u32 index array of a long Dict page, sb_dict_big.h),
+// whose table entries exist only once k_dict_big_idx has written them — the codec word says so
+__device__ __forceinline__ bool big_page_of(const EncodeArgs& a, const uint32_t* big, int W, uint32_t* page, EncPage* p, EncCol* c, uint32_t voff = 0) {
+    *page = big[blockIdx.y] + voff;
+    if (a.codecs[*page] != CODEC_PENDING) return false;   // (k_enc_select_runs may have taken the page)
+    *p = get_page(a, *page);
+    *c = get_col(a, p->col);
+    return (int)c->width == W;
 }
 
 // one step of the merge of two Boyer-Moore states
@@ -85,7 +88,7 @@ __device__ __forceinline__ void vote_merge(unsigned long long& k0, uint32_t& n0,
 }
 
 template <int W>
-__global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint32_t* big) {
+__global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     constexpr int K = 16;
     constexpr uint32_t CHUNK = WG * K;
     constexpr uint64_t SENT = ~0ull;
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
     uint32_t page;
     EncPage p;
     EncCol c;
-    if (!big_page_of(a, big, W, &page, &p, &c)) return;
+    if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;
     const uint64_t N = p.rows, SR = big_sec_rows(N);
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
@@ -355,7 +358,7 @@ __device__ void big_decide(const EncodeArgs& a, const EncCol& c, const EncPage& 
 }
 
 template <int W>
-__global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uint32_t* big) {
+__global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     constexpr uint64_t SENT = ~0ull;
     constexpr uint32_t KSLOTS = SEL_LDS_SLOTS / 2;
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     uint32_t page;
     EncPage p;
     EncCol c;
-    if (!big_page_of(a, big, W, &page, &p, &c)) return;
+    if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;
     const uint64_t N = p.rows, SR = big_sec_rows(N);
     const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
     const int t = threadIdx.x;
@@ -519,11 +522,11 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
 }
 
-__global__ void __launch_bounds__(WG) k_sel_big_clear(EncodeArgs a, const uint32_t* big) {
-    const uint32_t page = big[blockIdx.y];
+__global__ void __launch_bounds__(WG) k_sel_big_clear(EncodeArgs a, const uint32_t* big, uint32_t voff) {
+    const uint32_t page = big[blockIdx.y] + voff;
     if (a.codecs[page] != CODEC_PENDING) return;
-    const EncPage p = a.pages[page];
-    const EncCol c = a.cols[p.col];
+    const EncPage p = get_page(a, page);
+    const EncCol c = get_col(a, p.col);
     if (c.width > 8) return;
     const BigPage* bp = big_page_rec(page_slot(a, c, p));
     if (!bp->need_uq || !p.aux_bytes) return;
@@ -534,13 +537,13 @@ __global__ void __launch_bounds__(WG) k_sel_big_clear(EncodeArgs a, const uint32
 }
 
 template <int W>
-__global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uint32_t* big) {
+__global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     __shared__ uint32_t s4[4];
     __shared__ uint32_t s_stop;
     uint32_t page;
     EncPage p;
     EncCol c;
-    if (!big_page_of(a, big, W, &page, &p, &c)) return;
+    if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;
     uint8_t* slot = page_slot(a, c, p);
     BigPage* bp = big_page_rec(slot);
     const bool need_uq = bp->need_uq && p.aux_bytes, need_mc = bp->need_mc;
@@ -621,14 +624,14 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
 }
 
 template <int W>
-__global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const uint32_t* big) {
+__global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
     __shared__ uint32_t s_misc[2 * WG + 16];
     __shared__ __attribute__((aligned(16))) uint8_t sample_mem[SAMPLE_CAP * (W + 1) + 16];
     uint32_t page;
     EncPage p;
     EncCol c;
-    if (!big_page_of(a, big, W, &page, &p, &c)) return;   // (chosen by k_sel_big_merge already)
+    if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;   // (chosen by k_sel_big_merge already)
     const BigPage bp = *big_page_rec(page_slot(a, c, p));
     // without an aux area (cannot happen while Dict is a candidate) the count stays unknown: "more than the limit"
     const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
@@ -817,22 +820,23 @@ __device__ void rle_walk_section(const uint8_t* vals, const ValidView& vv, uint3
 }
 
 template <int W>
-__device__ __forceinline__ bool rle_big_page_of(const EncodeArgs& a, const uint32_t* big, uint32_t* page, EncPage* p, EncCol* c) {
-    *page = big[blockIdx.y];
-    *p = a.pages[*page];
-    *c = a.cols[p->col];
-    return (int)c->width == W && p->rows >= SEL_BIG_ROWS && a.codecs[*page] == (int32_t)SB_CODEC_RLE && a.outs[*page].length == 0;
+__device__ __forceinline__ bool rle_big_page_of(const EncodeArgs& a, const uint32_t* big, uint32_t* page, EncPage* p, EncCol* c, uint32_t voff) {
+    *page = big[blockIdx.y] + voff;
+    if (a.codecs[*page] != (int32_t)SB_CODEC_RLE || a.outs[*page].length != 0) return false;
+    *p = get_page(a, *page);
+    *c = get_col(a, p->col);
+    return (int)c->width == W && p->rows >= SEL_BIG_ROWS;
 }
 
 template <int W>
-__global__ void __launch_bounds__(WG, 4) k_rle_big_count(EncodeArgs a, const uint32_t* big) {
+__global__ void __launch_bounds__(WG, 4) k_rle_big_count(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     __shared__ uint32_t sA[32];
     __shared__ __attribute__((aligned(16))) uint32_t sB[64 + 8];
     if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
     uint32_t page;
     EncPage p;
     EncCol c;
-    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c, voff)) return;
     const uint64_t N = p.rows, SR = big_sec_rows(N);
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
@@ -859,12 +863,12 @@ __global__ void __launch_bounds__(WG, 4) k_rle_big_count(EncodeArgs a, const uin
 }
 
 template <int W>
-__global__ void __launch_bounds__(WG) k_rle_big_plan(EncodeArgs a, const uint32_t* big) {
+__global__ void __launch_bounds__(WG) k_rle_big_plan(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
     uint32_t page;
     EncPage p;
     EncCol c;
-    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c, voff)) return;
     constexpr int REC = 4 + W;
     const uint64_t N = p.rows, SR = big_sec_rows(N);
     const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
@@ -921,14 +925,14 @@ __global__ void __launch_bounds__(WG) k_rle_big_plan(EncodeArgs a, const uint32_
 }
 
 template <int W>
-__global__ void __launch_bounds__(WG, 4) k_rle_big_emit(EncodeArgs a, const uint32_t* big) {
+__global__ void __launch_bounds__(WG, 4) k_rle_big_emit(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     __shared__ uint32_t sA[32];
     __shared__ __attribute__((aligned(16))) uint32_t sB[64 + 8];
     if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
     uint32_t page;
     EncPage p;
     EncCol c;
-    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c, voff)) return;
     const uint64_t N = p.rows, SR = big_sec_rows(N);
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
@@ -949,13 +953,13 @@ __global__ void __launch_bounds__(WG, 4) k_rle_big_emit(EncodeArgs a, const uint
 
 // the page records of the RLE pages written above (after k_rle_big_emit: a.outs marks a page as emitted)
 template <int W>
-__global__ void k_rle_big_done(EncodeArgs a, const uint32_t* big) {
+__global__ void k_rle_big_done(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     if (a.use_counts && a.codec_counts[SB_CODEC_RLE] == 0) return;
     uint32_t page;
     EncPage p;
     EncCol c;
     if (threadIdx.x) return;
-    if (!rle_big_page_of<W>(a, big, &page, &p, &c)) return;
+    if (!rle_big_page_of<W>(a, big, &page, &p, &c, voff)) return;
     uint8_t* slot = page_slot(a, c, p);
     const uint64_t pos = c.nullable ? def_section_bytes(p.rows) : 0;
     const uint32_t body = ldu32(slot + pos + 1);

@@ -68,6 +68,24 @@ def cases():
     out["sets_unite_i32"] = dict(ptype=S.T_I32, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
     v = (np.arange(ROWS) // 16384 * 60 + rng.integers(0, 60, ROWS)).astype(np.int32)   # 60 per section: 2 280 > 2 048 in the page
     out["sets_unite_overflow_i32"] = dict(ptype=S.T_I32, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    # Dict pages written section-parallel (sb_dict_big.h): float keys are raw bits, NaNs never equal anything (every NaN row is
+    # a dictionary entry of its own), +0.0 / -0.0 are two entries, a leading null interns T::default()
+    v = rng.integers(0, 40, ROWS).astype(np.float64)
+    v[rng.integers(0, ROWS, 300)] = np.nan
+    v[rng.integers(0, ROWS, 50)] = np.frombuffer(np.uint64(0x7FF8000000000123).tobytes(), np.float64)[0]   # a NaN with a payload
+    v[rng.integers(0, ROWS, 2000)] = -0.0
+    out["lowcard_f64_nans_and_zeros"] = dict(ptype=S.T_F64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    c = gen.prim(S.T_I32, ROWS_ODD, uniq=700, null_density=0.3, seed=51)
+    bits = np.unpackbits(c["validity"], bitorder="little")[:ROWS_ODD].copy()
+    bits[:9] = 0                       # leading nulls: row 0 interns 0
+    bits[100_000:140_000] = 0          # sections without a keyed row (the index is carried across them)
+    c["validity"] = np.packbits(bits, bitorder="little")
+    out["lowcard_null_sections_i32"] = c
+    v = np.repeat(rng.integers(0, 3000, ROWS // 64 + 1), 64)[:ROWS].astype(np.int64)   # Dict whose indices come in runs (nested RLE)
+    out["dict_runs_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v * 1_000_003, validity=None, offsets=None)
+    v = rng.integers(0, 20, ROWS).astype(np.int64)
+    v[rng.random(ROWS) < 0.97] = 5     # mostly one value with a maximum below 256: Dict with Freq-coded indices
+    out["dict_freq_indices_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
     return out
 
 

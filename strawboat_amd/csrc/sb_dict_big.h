@@ -28,6 +28,7 @@
 // The bigx area of a page (host-allocated for pages of >= SEL_BIG_ROWS rows when Dict is a candidate): record | idx[N] |
 // firsts[N] | bitmap[N/32] | word prefixes[N/32] | first rows / ids of the table slots | the nested block's slot.
 constexpr uint32_t DBIG_LDS_SLOTS = 4096, DBIG_LDS_CAP = 3072;
+constexpr uint32_t DBIG_SPLIT = 4;   // workgroups per section in the row passes (insert, idx): 184 sections of a 12 M-row page leave CUs idle
 constexpr unsigned long long DBIG_EMPTY = ~0ull;
 
 struct DictBigRec {   // 4096 bytes
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_insert(EncodeArgs a, const u
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
     if (!dbig_page_of<W>(a, big, &d)) return;
-    const uint64_t N = d.p.rows, SR = big_sec_rows(N);
+    const uint64_t N = d.p.rows, SR = big_sec_rows(N) / DBIG_SPLIT;
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
     const uint64_t s1 = min(N, s0 + SR);
@@ -336,9 +337,9 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
     if (!dbig_page_of<W>(a, big, &d)) return;
     const uint64_t N = d.p.rows, SR = big_sec_rows(N);
     const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
-    const uint64_t s0 = (uint64_t)blockIdx.x * SR;
+    const uint64_t s0 = (uint64_t)blockIdx.x * (SR / DBIG_SPLIT);
     if (s0 >= N) return;
-    const uint64_t s1 = min(N, s0 + SR);
+    const uint64_t s1 = min(N, s0 + SR / DBIG_SPLIT);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint8_t* vals = d.c.values + d.p.row0 * W;
     const ValidView vv{d.c.validity, d.c.validity_bit_offset + d.p.row0};
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
     uint32_t carry = 0;
     const bool fill = vv.bits != nullptr;
     if (fill && s0 > 0) {
-        // (one wave looks back 64 rows at a time; sections start at multiples of 16 384 rows)
+        // (every wave looks back 64 rows at a time)
         uint64_t hi = s0;
         uint32_t found = 0xFFFFFFFFu;
         while (found == 0xFFFFFFFFu) {

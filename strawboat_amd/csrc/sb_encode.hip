@@ -5789,6 +5789,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     } while (0)
             {
                 KScope kk(ctx, "k_sel_big_sec");
+                k_sel_big_init<<<dim3(4, nbig), WG, 0, st>>>(aa, list, 0u);
                 SB_BIG_W(k_sel_big_sec, sg, WG);
             }
             {
@@ -5814,7 +5815,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             }
 #undef SB_BIG_W
             if (!((forb >> SB_CODEC_DICT) & 1)) {   // long Dict pages: sb_dict_big.h
-                const dim3 gg(256, nbig);
+                const dim3 gg(256, nbig), sg4(sg.x * DBIG_SPLIT, nbig);
                 const uint32_t vo = (uint32_t)P;
 #define SB_DBIG_W(KERNEL, GRID, THREADS)                                   \
     do {                                                                   \
@@ -5826,7 +5827,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 {
                     KScope kk(ctx, "k_dict_big_insert");
                     SB_DBIG_W(k_dict_big_clear, gg, WG);
-                    SB_DBIG_W(k_dict_big_insert, sg, WG);
+                    SB_DBIG_W(k_dict_big_insert, sg4, WG);
                 }
                 {
                     KScope kk(ctx, "k_dict_big_ids");
@@ -5836,10 +5837,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 }
                 {
                     KScope kk(ctx, "k_dict_big_idx");
-                    SB_DBIG_W(k_dict_big_idx, sg, WG);
+                    SB_DBIG_W(k_dict_big_idx, sg4, WG);
                 }
                 {   // the index arrays as virtual pages of u32: selected ...
                     KScope kk(ctx, "k_sel_big(indices)");
+                    k_sel_big_init<<<dim3(4, nbig), WG, 0, st>>>(aa, list, vo);
                     k_sel_big_sec<4><<<sg, WG, 0, st>>>(aa, list, vo);
                     k_sel_big_merge<4><<<pg, WG, 0, st>>>(aa, list, vo);
                     k_sel_big_count<4><<<sg, WG, 0, st>>>(aa, list, vo);

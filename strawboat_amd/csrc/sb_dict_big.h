@@ -45,13 +45,17 @@ __host__ __device__ __forceinline__ uint64_t dbig_slots(uint64_t unique) {
 }
 __host__ __device__ __forceinline__ uint64_t dbig_slots_max(uint64_t N) { return dbig_slots((N - 1) / 3 + 2); }
 __host__ __device__ __forceinline__ uint64_t dbig_nblk_cap(uint64_t N) { return (64 + 9 + 9 + N * 12 + 4 + 64 + 64 + 15) & ~15ull; }
+constexpr uint64_t BIGX_FREQ_OFF = 4096, BIGX_FREQ_BYTES = 65536;   // the long-page Freq writer's record (sb_freq_big.h)
+constexpr uint64_t BIGX_HEAD = BIGX_FREQ_OFF + BIGX_FREQ_BYTES;     // a page for which Dict is forbidden has only this much
+constexpr uint32_t VBIG_ROWS = 65536;   // virtual pages (index arrays, Freq exceptions) of this many rows take the section-parallel path
+constexpr uint32_t VPAD_ACTIVE = 7, VPAD_PLANNED = 6;   // EncOut.pad of a virtual page on that path: not written yet / sized, being written
 struct DictBigLayout {
     uint64_t o_idx, o_firsts, o_bits, o_wpref, o_frow, o_nblk, total, nwords;
 };
 __host__ __device__ __forceinline__ DictBigLayout dbig_layout(uint64_t N) {
     DictBigLayout l;
     l.nwords = (N + 31) / 32;
-    l.o_idx = 4096;
+    l.o_idx = BIGX_HEAD;
     l.o_firsts = l.o_idx + ((N * 4 + 63) & ~63ull);
     l.o_bits = l.o_firsts + ((N * 4 + 63) & ~63ull);
     l.o_wpref = l.o_bits + ((l.nwords * 4 + 63) & ~63ull);
@@ -457,24 +461,26 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
         int32_t ic = d.p.icodec >= 0 ? d.p.icodec : (a.has_ratio ? CODEC_PENDING : (int32_t)a.default_compression);
         a.codecs[a.n_pages + d.page] = ic;
         if (ic >= 0) atomicAdd(&a.codec_counts[ic & 31], 1u);
+        EncOut vo;
+        __builtin_memset(&vo, 0, sizeof vo);
+        vo.pad = VPAD_ACTIVE;
+        a.outs[a.n_pages + d.page] = vo;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- nested writers
-// The virtual page of the list entry's long Dict page when its codec is one of `cmask` and it has not been written.  (The
-// codec words are zeroed per call, and 0 is a codec: the parent's state says whether the entry is in use.)
+// The virtual page of a list entry when it is on the section-parallel path (EncOut.pad says so: the codec words are zeroed
+// per call, and 0 is a codec), its codec is one of `cmask` and it is in state `want_pad`.
 __device__ __forceinline__ bool vbig_page_of(const EncodeArgs& a, const uint32_t* big, uint32_t cmask, uint32_t* page, EncPage* p, EncCol* c,
-                                             int32_t* codec) {
-    const uint32_t parent = big[blockIdx.y];
-    if (a.codecs[parent] != (int32_t)SB_CODEC_DICT || a.outs[parent].length != 0) return false;
-    const EncPage pp = a.pages[parent];
-    if (!pp.bigx_off || !((const DictBigRec*)(a.scratch + pp.bigx_off))->active) return false;
-    *page = parent + a.n_pages;
+                                             int32_t* codec, uint32_t want_pad = VPAD_ACTIVE) {
+    *page = big[blockIdx.y] + a.n_pages;
+    const EncOut vo = a.outs[*page];
+    if (vo.pad != want_pad || (want_pad == VPAD_ACTIVE && vo.length != 0)) return false;
     *codec = a.codecs[*page];
-    if (*codec < 0 || *codec > 31 || !((cmask >> *codec) & 1) || a.outs[*page].length != 0) return false;
+    if (*codec < 0 || *codec > 31 || !((cmask >> *codec) & 1)) return false;
     *p = get_page(a, *page);
     *c = get_col(a, p->col);
-    return c->width == 4 && p->rows >= SEL_BIG_ROWS;
+    return p->rows >= VBIG_ROWS;
 }
 __device__ __forceinline__ bool vbig_any(const EncodeArgs& a, uint32_t cmask) {   // (adaptive waves: nobody chose one of these codecs)
     if (!a.use_counts) return true;
@@ -569,7 +575,7 @@ __global__ void __launch_bounds__(WG) k_bp_big(EncodeArgs a, const uint32_t* big
     EncPage p;
     EncCol c;
     int32_t codec;
-    if (!vbig_page_of(a, big, CM, &page, &p, &c, &codec) || p.rows % 128 != 0) return;
+    if (!vbig_page_of(a, big, CM, &page, &p, &c, &codec, PASS == 2 ? VPAD_PLANNED : VPAD_ACTIVE) || p.rows % 128 != 0 || c.width != 4) return;
     const uint64_t N = p.rows, ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
     uint8_t* slot = page_slot(a, c, p);
     uint32_t* tb = bp_big_tilebytes(slot, p);
@@ -593,6 +599,13 @@ __global__ void __launch_bounds__(WG) k_bp_big(EncodeArgs a, const uint32_t* big
         if (threadIdx.x == 0) {
             if (run > 0xFFFFFFF0ull) raise(a.status, SB_ERR_INVALID, page, 560);
             put_hdr9(slot, (uint32_t)codec, (uint32_t)run, (uint32_t)(N * 4));
+            EncOut o;
+            o.length = 9 + run;
+            o.out_off = 0;
+            o.slot = slot;
+            o.codec = (uint32_t)codec;
+            o.pad = VPAD_PLANNED;
+            a.outs[page] = o;
         }
         return;
     }
@@ -618,8 +631,11 @@ __global__ void __launch_bounds__(WG) k_plain_big(EncodeArgs a, const uint32_t* 
     EncCol c;
     int32_t codec;
     if (!vbig_page_of(a, big, CM, &page, &p, &c, &codec)) return;
+    // (the one-literal-run LZ4 block is what enc_u32_block writes for the INDEX array of a Dict page; the exceptions block of
+    // a Freq page goes through the matcher: enc_nested_block)
+    if (codec == SB_CODEC_LZ4 && a.codecs[page - a.n_pages] != (int32_t)SB_CODEC_DICT) return;
     uint8_t* slot = page_slot(a, c, p);
-    const uint64_t nbytes = p.rows * 4;
+    const uint64_t nbytes = p.rows * c.width;
     uint32_t hdr = 0;
     if (codec == SB_CODEC_LZ4) hdr = 1 + (nbytes >= 15 ? 1 + (uint32_t)((nbytes - 15) / 255) : 0);
     const uint64_t tid = (uint64_t)blockIdx.x * WG + threadIdx.x, nth = (uint64_t)gridDim.x * WG;
@@ -632,12 +648,22 @@ __global__ void __launch_bounds__(WG) k_plain_big(EncodeArgs a, const uint32_t* 
             if (tid == 0) o[1 + nff] = (uint8_t)((nbytes - 15) % 255);
         }
     }
-    if (tid == 0) put_hdr9(slot, (uint32_t)codec, (uint32_t)(hdr + nbytes), (uint32_t)nbytes);
-    const uint8_t* src = c.values + p.row0 * 4;
+    const uint8_t* src = c.values + p.row0 * c.width;
     uint8_t* dst = slot + 9 + hdr;
     // (dst is not 16-byte aligned: the copy is by dwords, source aligned)
     const uint64_t nd = nbytes / 4;
     for (uint64_t i = tid; i < nd; i += nth) stu32(dst + 4 * i, ldu32(src + 4 * i));
+    if (tid == 0) {
+        for (uint64_t i = nd * 4; i < nbytes; i++) dst[i] = src[i];
+        put_hdr9(slot, (uint32_t)codec, (uint32_t)(hdr + nbytes), (uint32_t)nbytes);
+        EncOut o;
+        o.length = 9 + hdr + nbytes;
+        o.out_off = 0;
+        o.slot = slot;
+        o.codec = (uint32_t)codec;
+        o.pad = 1;
+        a.outs[page] = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- finish
@@ -661,12 +687,11 @@ __global__ void __launch_bounds__(WG, 2) k_dict_big_finish(EncodeArgs a, const u
     const uint32_t vpage = a.n_pages + d.page;
     const int32_t ic = a.codecs[vpage];
     const uint32_t D = d.rec->D;
-    const bool exact_lz4 = ic == SB_CODEC_LZ4 && (a.flags & SB_WRITE_LZ4_EXACT);
-    const bool par = (ic == SB_CODEC_NONE || (ic == SB_CODEC_LZ4 && !exact_lz4) || ic == SB_CODEC_RLE ||
-                      ((ic == SB_CODEC_BITPACKING || ic == SB_CODEC_DELTA_BITPACKING) && N % 128 == 0));
+    const EncOut vout = a.outs[vpage];
+    const bool par = vout.length != 0 && (vout.pad == 1 || vout.pad == VPAD_PLANNED);
     uint64_t ib;
     if (par) {   // written by the section- / tile-parallel kernels into the nested slot
-        ib = 9 + (uint64_t)ldu32(d.nblk + 1);
+        ib = vout.length;
         if (threadIdx.x == 0) d.rec->nested_ok = 1;
     } else if (ic == SB_CODEC_FREQ) {
         // mostly one index: the Freq kernels finish the page (see emit_prim_page<Dict>)

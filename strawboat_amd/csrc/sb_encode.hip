@@ -4251,6 +4251,8 @@ __device__ void freq_prep_bin(const EncodeArgs& a, const EncCol& c, const EncPag
     }
 }
 
+#include "sb_freq_big.h"
+
 __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a_in, EncCol* cols_rw, EncPage* pages_rw) {
     // tile array | s_w | container counts | vote scratch (a second tile array in the exact-count path)
     __shared__ __attribute__((aligned(16))) uint32_t lds[SIDX_WORDS + 8 + FREQ_MAX_CONTAINERS + SIDX_WORDS + 16];
@@ -4294,6 +4296,7 @@ __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a_in, EncCol
         continue;
     }
     if (pcodec != SB_CODEC_FREQ) continue;
+    if (a.outs[page].length != 0 && a.outs[page].codec == SB_CODEC_FREQ) continue;   // a long page, prepared container-parallel (sb_freq_big.h)
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_NULL || p.rows == 0) {
         if (threadIdx.x == 0) raise(a.status, SB_ERR_OUT_OF_SPEC, page, 542);  // no Freq for booleans upstream
@@ -4350,6 +4353,10 @@ __device__ void enc_nested_block(const EncodeArgs& a, uint32_t page, uint32_t* l
             if (rc != SB_CODEC_FREQ) return;
             if (ro.length == 0 || ro.codec != SB_CODEC_FREQ || ro.pad == 2) return;  // prep raised / binary page (no nested block)
         }
+    }
+    {   // written by the section- / tile-parallel kernels already (sb_dict_big.h: virtual pages of >= VBIG_ROWS rows)
+        const EncOut vo = a.outs[page];
+        if (vo.length != 0 && (vo.pad == 1 || vo.pad == VPAD_PLANNED)) return;
     }
     const EncPage p = get_page(a, page);
     const EncCol c = get_col(a, p.col);
@@ -5333,7 +5340,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const uint64_t np = c.page_rows ? c.n_pages_in : (c.rows + ps - 1) / ps;
         if (np > c.n_pages_capacity || !c.out_metas) return ctx->fail(SB_ERR_INVALID, "out_metas too small");
         // (long pages that may become Dict pages run their index arrays as virtual pages: sb_dict_big.h)
-        big_possible |= adaptive && !((forb >> SB_CODEC_DICT) & 1) && !enc_is_binary(c.physical_type) && c.rows >= SEL_BIG_ROWS;
+        big_possible |= adaptive && !enc_is_binary(c.physical_type) && c.rows >= SEL_BIG_ROWS;
         if (!c.out_pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "out_pages is null");
         P += np;
         if (hit) continue;   // (the per-page arithmetic of this shape is in the plan)
@@ -5528,7 +5535,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 const int k = d.width == 1 ? 0 : d.width == 2 ? 1 : d.width == 4 ? 2 : 3;
                 plan.bigw[k].push_back((uint32_t)pi);
                 plan.big_secs[k] = std::max(plan.big_secs[k], secs);
-                if (!((forb >> SB_CODEC_DICT) & 1)) p.bigx_off = 1;   // (placed with the aux areas below)
+                if (!((forb >> SB_CODEC_DICT) & 1) || freq_possible) p.bigx_off = 1;   // (placed with the aux areas below)
             }
             if (direct) {
                 p.direct_off = direct_off;
@@ -5612,7 +5619,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (hp[q].bigx_off == 1) {
             scratch_off = align_up(scratch_off, 64);
             hp[q].bigx_off = scratch_off;
-            scratch_off += dbig_layout(hp[q].rows).total;
+            scratch_off += ((forb >> SB_CODEC_DICT) & 1) ? BIGX_HEAD : dbig_layout(hp[q].rows).total;
         }
         if (hp[q].zst_off == 0) {   // (one block is at most 128 KiB whatever the page holds)
             scratch_off = align_up(scratch_off, 16);
@@ -5853,6 +5860,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                         k_rle_big_count<4><<<sg, WG, 0, st>>>(aa, list, vo);
                         k_rle_big_plan<4><<<pg, WG, 0, st>>>(aa, list, vo);
                         k_rle_big_emit<4><<<sg, WG, 0, st>>>(aa, list, vo);
+                        k_rle_big_done<4><<<pg, 64, 0, st>>>(aa, list, vo);
                     }
                     const dim3 tg((uint32_t)std::min<uint64_t>(max_tiles, 4096), nbig);
                     k_bp_big<0><<<tg, WG, 0, st>>>(aa, list);
@@ -6034,6 +6042,62 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     {
         const int32_t rc = run_wave(a, adaptive, host_codec, false);
         if (rc != SB_OK) return rc;
+    }
+    if (freq_possible && adaptive) {
+        // long pages that chose Freq: prepared container-parallel, their exceptions block (a virtual page) selected and
+        // written section-parallel when it has VBIG_ROWS rows or more (sb_freq_big.h, sb_dict_big.h)
+        const uint32_t vo = (uint32_t)P;
+        EncCol* vcols_rw = (EncCol*)(tb + o_vcols);
+        EncPage* vpages_rw = (EncPage*)(tb + o_vpages);
+        for (int k = 0; k < 4; k++) {
+            const uint32_t nbig = (uint32_t)plan.bigw[k].size();
+            if (!nbig) continue;
+            size_t skip = 0;
+            for (int q = 0; q < k; q++) skip += plan.bigw[q].size();
+            const uint32_t* list = (const uint32_t*)plan.big.p + skip;
+            const dim3 sg(plan.big_secs[k], nbig), pg(1, nbig);
+            const dim3 cg((uint32_t)((max_tiles * TILE_ROWS + 65535) / 65536), nbig);
+#define SB_FBIG_W(KERNEL, GRID, THREADS, ...)                                             \
+    do {                                                                                  \
+        if (k == 0) KERNEL<1><<<GRID, THREADS, 0, s>>>(a, list, ##__VA_ARGS__);           \
+        else if (k == 1) KERNEL<2><<<GRID, THREADS, 0, s>>>(a, list, ##__VA_ARGS__);      \
+        else if (k == 2) KERNEL<4><<<GRID, THREADS, 0, s>>>(a, list, ##__VA_ARGS__);      \
+        else KERNEL<8><<<GRID, THREADS, 0, s>>>(a, list, ##__VA_ARGS__);                  \
+    } while (0)
+            {
+                KScope kk(ctx, "k_freq_big");
+                SB_FBIG_W(k_freq_big_count, dim3(cg.x * 4, nbig), WG);
+                SB_FBIG_W(k_freq_big_plan, pg, WG, vcols_rw, vpages_rw);
+                SB_FBIG_W(k_freq_big_emit, cg, WG);
+                SB_FBIG_W(k_freq_big_done, pg, 64);
+            }
+            {
+                KScope kk(ctx, "k_sel_big(exceptions)");
+                k_sel_big_init<<<dim3(4, nbig), WG, 0, s>>>(a, list, vo);
+                SB_FBIG_W(k_sel_big_sec, sg, WG, vo);
+                SB_FBIG_W(k_sel_big_merge, pg, WG, vo);
+                k_sel_big_clear<<<sg, WG, 0, s>>>(a, list, vo);
+                SB_FBIG_W(k_sel_big_count, sg, WG, vo);
+                SB_FBIG_W(k_sel_big_decide, pg, WG, vo);
+            }
+            {
+                KScope kk(ctx, "k_nested_big");
+                if (!((forb >> SB_CODEC_RLE) & 1)) {
+                    SB_FBIG_W(k_rle_big_count, sg, WG, vo);
+                    SB_FBIG_W(k_rle_big_plan, pg, WG, vo);
+                    SB_FBIG_W(k_rle_big_emit, sg, WG, vo);
+                    SB_FBIG_W(k_rle_big_done, pg, 64, vo);
+                }
+                if (k == 2) {
+                    const dim3 tg((uint32_t)std::min<uint64_t>(max_tiles, 4096), nbig);
+                    k_bp_big<0><<<tg, WG, 0, s>>>(a, list);
+                    k_bp_big<1><<<pg, WG, 0, s>>>(a, list);
+                    k_bp_big<2><<<tg, WG, 0, s>>>(a, list);
+                }
+                k_plain_big<<<dim3(1024, nbig), WG, 0, s>>>(a, list);
+            }
+#undef SB_FBIG_W
+        }
     }
     if (freq_possible) {  // Freq pages: bitmap + exceptions, then the exceptions block like any other block
         {

@@ -65,7 +65,7 @@ __device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { retu
 // whose table entries exist only once k_dict_big_idx has written them — the codec word says so
 // The union of the sections' key sets: a table of BIG_UNION_SLOTS keys behind the section records, filled by the sections
 // themselves at their end (agent-scope CAS; the count beside it).  One workgroup uniting 184 sets of 500 keys took 0.27 ms.
-constexpr uint32_t BIG_UNION_SLOTS = 8192;
+constexpr uint32_t BIG_UNION_SLOTS = 8192, BIG_UNION_PROBES = 32;
 __device__ __forceinline__ unsigned long long* big_union_tab(uint8_t* slot, uint32_t nsec) {
     return (unsigned long long*)(slot + 256 + (uint64_t)nsec * BIG_SEC_STRIDE + 64);
 }
@@ -310,29 +310,44 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
         r.ksent = want_set ? s_ksent : 0u;
         *rec = r;
     }
-    if (want_set && kc <= BIG_KCAP) {   // the section's keys join the page's set
+    if (want_set) {   // the section's keys join the page's set
+        // One add per SECTION to the count (8 192 single adds to one word took 0.5 ms: same-address atomics queue up in L2), and
+        // no count to stop at: a probe that meets BIG_UNION_PROBES occupied slots in a row calls the union too big — at a
+        // quarter full that does not happen, and a false alarm only sends the page to the exact count (k_sel_big_count).
         const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
         unsigned long long* gt = big_union_tab(slot, nsec);
         uint32_t* gc = big_union_cnt(slot, nsec);
-        for (uint32_t i = t; i < KSLOTS; i += WG) {
+        uint32_t newc = 0;
+        bool over = kc > BIG_KCAP;
+        for (uint32_t i = t; i < KSLOTS && !over; i += WG) {
             const unsigned long long x = kset[i];
             if (x == SENT) continue;
+            if (__hip_atomic_load(gc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // somebody saw it overflow
             uint32_t h = (((uint32_t)x ^ (uint32_t)(x >> 32) * 0x85EBCA6Bu) * 0x9E3779B1u >> 13) & (BIG_UNION_SLOTS - 1);
-            for (;;) {
-                if (__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > BIG_KCAP) break;   // the union overflowed: nobody needs the rest
+            for (uint32_t steps = 0;; steps++) {
+                if (steps >= BIG_UNION_PROBES) {
+                    over = true;
+                    break;
+                }
                 const unsigned long long cur = __hip_atomic_load(gt + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == x) break;
                 if (cur == SENT) {
                     unsigned long long e = SENT;
                     __hip_atomic_compare_exchange_strong(gt + h, &e, x, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (e == SENT) {
-                        __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        newc++;
                         break;
                     }
                     if (e == x) break;
                 }
                 h = (h + 1) & (BIG_UNION_SLOTS - 1);
             }
+        }
+        if (over) __hip_atomic_store(gc + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tot = wg_sum32(newc, s4);
+        if (t == 0 && tot) {
+            const uint32_t before = __hip_atomic_fetch_add(gc, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + tot > BIG_KCAP) __hip_atomic_store(gc + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -465,8 +480,8 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     bool set_ok = false;
     uint32_t set_unique = 0;
     if (want_set && !over) {   // (the sections united their sets in the page's table: k_sel_big_sec)
-        const uint32_t uc = *big_union_cnt(slot, nsec);
-        set_ok = uc <= BIG_KCAP;
+        const uint32_t uc = big_union_cnt(slot, nsec)[0], uover = big_union_cnt(slot, nsec)[1];
+        set_ok = !uover && uc <= BIG_KCAP;
         set_unique = uc + (ksent ? 1u : 0u);
     }
     // ---- what is missing for the decision?
@@ -801,7 +816,7 @@ __device__ __forceinline__ bool rle_big_page_of(const EncodeArgs& a, const uint3
     if (a.codecs[*page] != (int32_t)SB_CODEC_RLE || a.outs[*page].length != 0) return false;
     *p = get_page(a, *page);
     *c = get_col(a, p->col);
-    return (int)c->width == W && p->rows >= SEL_BIG_ROWS;
+    return (int)c->width == W && p->rows >= (voff ? 65536u : SEL_BIG_ROWS);   // (virtual pages: VBIG_ROWS, sb_dict_big.h)
 }
 
 template <int W>

@@ -86,6 +86,25 @@ def cases():
     v = rng.integers(0, 20, ROWS).astype(np.int64)
     v[rng.random(ROWS) < 0.97] = 5     # mostly one value with a maximum below 256: Dict with Freq-coded indices
     out["dict_freq_indices_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=v, validity=None, offsets=None)
+    # Freq pages prepared container-parallel (sb_freq_big.h); 65 536 exceptions or more: their block is selected and written
+    # section-parallel too
+    big = 1_600_000
+    out["sparse_many_exceptions_i32"] = sparse(S.T_I32, big, 0.08, 61)              # 128 k random exceptions -> a plain / LZ4 block
+    c = gen.prim(S.T_I64, big, uniq=5000, null_density=0.93, seed=62)               # >= 90 % null: every valid row is an exception
+    out["mostly_null_many_exceptions_i64"] = c
+    v = np.full(big, 77, np.int32)
+    m = rng.random(big) < 0.07
+    v[m] = np.repeat(rng.integers(1000, 1200, int(m.sum()) // 40 + 1), 40)[:int(m.sum())]   # exceptions in runs (nested RLE)
+    out["sparse_exceptions_in_runs_i32"] = dict(ptype=S.T_I32, nullable=False, rows=big, values=v, validity=None, offsets=None)
+    v = np.full(big, 1 << 20, np.int32)
+    v[m] = rng.integers(100_000, 100_300, int(m.sum()))                             # low-cardinality exceptions (nested Dict: one workgroup)
+    out["sparse_exceptions_lowcard_i32"] = dict(ptype=S.T_I32, nullable=False, rows=big, values=v, validity=None, offsets=None)
+    v = np.full(big, 3.5, np.float64)
+    v[rng.random(big) < 0.9] = 3.5
+    v[m] = rng.random(int(m.sum()))
+    v[::65536 * 3] = np.nan
+    c = dict(ptype=S.T_F64, nullable=True, rows=big, values=v, validity=np.packbits(rng.random(big) < 0.97, bitorder="little"), offsets=None)
+    out["sparse_nullable_f64"] = c
     return out
 
 

@@ -32,9 +32,11 @@ constexpr uint32_t DBIG_SPLIT = 4;   // workgroups per section in the row passes
 constexpr unsigned long long DBIG_EMPTY = ~0ull;
 
 struct DictBigRec {   // 4096 bytes
-    uint32_t active, M3, D, sent_first, sent_id, nested_ok, pad0[2];
+    uint32_t active, M3, D, sent_first, sent_id, nested_ok, bad, pad0;
     uint32_t sectot[SEL_BIG_SECTIONS];
-    uint32_t pad1[1024 - 8 - SEL_BIG_SECTIONS];
+    unsigned long long secbytes[SEL_BIG_SECTIONS];   // binary pages: entry bytes (8 + len of every first row) per section
+    unsigned long long sent_eoff, etotal;
+    uint32_t pad1[1024 - 8 - 3 * SEL_BIG_SECTIONS - 4];
 };
 static_assert(sizeof(DictBigRec) == 4096, "record of the long-page Dict writer");
 
@@ -51,8 +53,9 @@ constexpr uint32_t VBIG_ROWS = 65536;   // virtual pages (index arrays, Freq exc
 constexpr uint32_t VPAD_ACTIVE = 7, VPAD_PLANNED = 6;   // EncOut.pad of a virtual page on that path: not written yet / sized, being written
 struct DictBigLayout {
     uint64_t o_idx, o_firsts, o_bits, o_wpref, o_frow, o_nblk, total, nwords;
+    uint64_t o_keys, o_wbytes, o_eoff;   // binary pages: the key table (the aux area holds the selector's), byte prefixes, entry offsets
 };
-__host__ __device__ __forceinline__ DictBigLayout dbig_layout(uint64_t N) {
+__host__ __device__ __forceinline__ DictBigLayout dbig_layout(uint64_t N, bool binary = true) {
     DictBigLayout l;
     l.nwords = (N + 31) / 32;
     l.o_idx = BIGX_HEAD;
@@ -61,7 +64,13 @@ __host__ __device__ __forceinline__ DictBigLayout dbig_layout(uint64_t N) {
     l.o_wpref = l.o_bits + ((l.nwords * 4 + 63) & ~63ull);
     l.o_frow = l.o_wpref + ((l.nwords * 4 + 63) & ~63ull);
     l.o_nblk = l.o_frow + dbig_slots_max(N) * 4;
-    l.total = l.o_nblk + dbig_nblk_cap(N);
+    l.o_keys = l.o_nblk + dbig_nblk_cap(N);
+    l.total = l.o_keys;
+    if (binary) {
+        l.o_wbytes = l.o_keys + dbig_slots_max(N) * 8;
+        l.o_eoff = l.o_wbytes + ((l.nwords * 8 + 63) & ~63ull);
+        l.total = l.o_eoff + ((N - 1) / 3 + 64) * 8;
+    }
     return l;
 }
 
@@ -76,17 +85,24 @@ struct DictBigCtx {
     uint32_t *idx, *firsts, *bits, *wpref, *frow;
     uint8_t* nblk;
 };
-// the page of this block (blockIdx.y) if it is a long primitive page of width W that chose Dict and has not been written
-template <int W>
+// the page of this block (blockIdx.y) if it is a long page of kind KIND (1 / 2 / 4 / 8: primitives of that width; -4 / -8:
+// Binary / LargeBinary) that chose Dict and has not been written
+template <int KIND>
 __device__ __forceinline__ bool dbig_page_of(const EncodeArgs& a, const uint32_t* big, DictBigCtx* d, bool need_active = true) {
     d->page = big[blockIdx.y];
+    if (a.codecs[d->page] != (int32_t)SB_CODEC_DICT || a.outs[d->page].length != 0) return false;
     d->p = a.pages[d->page];
     d->c = a.cols[d->p.col];
-    if ((int)d->c.width != W || !d->p.bigx_off || a.codecs[d->page] != (int32_t)SB_CODEC_DICT || a.outs[d->page].length != 0) return false;
+    if (!d->p.bigx_off) return false;
+    if constexpr (KIND > 0) {
+        if (big_is_bin(d->c) || (int)d->c.width != KIND) return false;
+    } else {
+        if (d->c.ptype != (KIND == -4 ? SB_TYPE_BINARY : SB_TYPE_LARGE_BINARY) || d->p.h64_off == ~0ull) return false;
+    }
     d->bigx = a.scratch + d->p.bigx_off;
     d->rec = (DictBigRec*)d->bigx;
     d->l = dbig_layout(d->p.rows);
-    d->keys = (unsigned long long*)(a.scratch + d->p.aux_off);
+    d->keys = KIND > 0 ? (unsigned long long*)(a.scratch + d->p.aux_off) : (unsigned long long*)(d->bigx + d->l.o_keys);
     d->idx = (uint32_t*)(d->bigx + d->l.o_idx);
     d->firsts = (uint32_t*)(d->bigx + d->l.o_firsts);
     d->bits = (uint32_t*)(d->bigx + d->l.o_bits);
@@ -94,6 +110,29 @@ __device__ __forceinline__ bool dbig_page_of(const EncodeArgs& a, const uint32_t
     d->frow = (uint32_t*)(d->bigx + d->l.o_frow);
     d->nblk = d->bigx + d->l.o_nblk;
     return !need_active || d->rec->active != 0;
+}
+// the key of row i: the value's raw bits (a leading null interns T::default(), dict.rs:46-50) / the 64-bit hash of the
+// row's string (binary/dict.rs:55-93 interns the slot's bytes whatever the validity says)
+template <int KIND>
+struct DbigKeys {
+    const uint8_t* vals;   // page values / the page's h64 array
+    __device__ __forceinline__ unsigned long long key(uint64_t i, bool valid) const {
+        constexpr int W = KIND > 0 ? KIND : 8;
+        unsigned long long x = 0;
+        if constexpr (KIND > 0) {
+            Val<W> v = ld_val<W>(vals + i * W);
+            if (i == 0 && !valid) v = val_zero<W>();
+            __builtin_memcpy(&x, &v, W);
+        } else {
+            x = ldu64(vals + i * 8);
+        }
+        return x;
+    }
+};
+template <int KIND>
+__device__ __forceinline__ DbigKeys<KIND> dbig_keys(const EncodeArgs& a, const DictBigCtx& d) {
+    if constexpr (KIND > 0) return DbigKeys<KIND>{d.c.values + d.p.row0 * KIND};
+    else return DbigKeys<KIND>{a.scratch + d.p.h64_off};
 }
 template <int W>
 __device__ __forceinline__ bool dbig_is_nan(uint64_t x, uint32_t fkind) {
@@ -131,17 +170,18 @@ __device__ __forceinline__ uint32_t dbig_global_find(const unsigned long long* k
     }
 }
 
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG) k_dict_big_clear(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
-    if (!dbig_page_of<W>(a, big, &d, false)) return;
+    if (!dbig_page_of<KIND>(a, big, &d, false)) return;
     const uint64_t N = d.p.rows;
     const BigPage bp = *big_page_rec(page_slot(a, d.c, d.p));
     const bool known = bp.set_ok || bp.need_uq;
     const uint64_t unique = bp.set_ok ? bp.set_unique : (uint64_t)bp.uq + bp.uq_sent;
     const uint64_t M3 = dbig_slots(unique);
-    const bool ok = known && M3 <= dbig_slots_max(N) && M3 * 8 <= d.p.aux_bytes && N < 0xFFFFFFF0ull;
+    const bool ok = known && M3 <= dbig_slots_max(N) && (KIND < 0 || M3 * 8 <= d.p.aux_bytes) && N < 0xFFFFFFF0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.rec->active = ok ? 1u : 0u;
         d.rec->M3 = (uint32_t)M3;
@@ -149,6 +189,9 @@ __global__ void __launch_bounds__(WG) k_dict_big_clear(EncodeArgs a, const uint3
         d.rec->sent_first = 0xFFFFFFFFu;
         d.rec->sent_id = 0;
         d.rec->nested_ok = 0;
+        d.rec->bad = 0;
+        d.rec->sent_eoff = 0;
+        d.rec->etotal = 0;
     }
     if (!ok) return;
     const uint64_t tid = (uint64_t)blockIdx.x * WG + threadIdx.x, nth = (uint64_t)gridDim.x * WG;
@@ -159,20 +202,21 @@ __global__ void __launch_bounds__(WG) k_dict_big_clear(EncodeArgs a, const uint3
     for (uint64_t i = tid; i < d.l.nwords; i += nth) d.bits[i] = 0;
 }
 
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG, 3) k_dict_big_insert(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     __shared__ unsigned long long lk[DBIG_LDS_SLOTS];
     __shared__ uint32_t lr[DBIG_LDS_SLOTS];
     __shared__ uint32_t s_cnt;
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
-    if (!dbig_page_of<W>(a, big, &d)) return;
+    if (!dbig_page_of<KIND>(a, big, &d)) return;
     const uint64_t N = d.p.rows, SR = big_sec_rows(N) / DBIG_SPLIT;
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
     const uint64_t s1 = min(N, s0 + SR);
     const int t = threadIdx.x;
-    const uint8_t* vals = d.c.values + d.p.row0 * W;
+    const DbigKeys<KIND> kf = dbig_keys<KIND>(a, d);
     const ValidView vv{d.c.validity, d.c.validity_bit_offset + d.p.row0};
     const uint32_t fkind = d.c.fkind;
     const uint32_t mask = d.rec->M3 - 1;
@@ -190,10 +234,7 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_insert(EncodeArgs a, const u
             const uint64_t i = base + (uint64_t)u * WG + t;
             const bool in = i < s1;
             const bool valid = in && vv.get(i);
-            Val<W> v = ld_val<W>(vals + (in ? i : s0) * W);
-            if (in && i == 0 && !valid) v = val_zero<W>();   // a leading null interns T::default() (dict.rs:46-50)
-            xu[u] = 0;
-            __builtin_memcpy(&xu[u], &v, W);
+            xu[u] = kf.key(in ? i : s0, valid);
             if (valid || (in && i == 0)) keyed |= 1u << u;
         }
 #pragma unroll
@@ -240,11 +281,12 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_insert(EncodeArgs a, const u
     }
 }
 
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG) k_dict_big_mark(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
-    if (!dbig_page_of<W>(a, big, &d)) return;
+    if (!dbig_page_of<KIND>(a, big, &d)) return;
     const uint64_t M3 = d.rec->M3;
     const uint64_t tid = (uint64_t)blockIdx.x * WG + threadIdx.x, nth = (uint64_t)gridDim.x * WG;
     for (uint64_t i = tid; i < M3; i += nth) {
@@ -255,31 +297,55 @@ __global__ void __launch_bounds__(WG) k_dict_big_mark(EncodeArgs a, const uint32
     if (tid == 0 && d.rec->sent_first != 0xFFFFFFFFu) atomicOr(d.bits + (d.rec->sent_first >> 5), 1u << (d.rec->sent_first & 31));
 }
 
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG) k_dict_big_rank(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     __shared__ uint32_t s4[4];
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
-    if (!dbig_page_of<W>(a, big, &d)) return;
+    if (!dbig_page_of<KIND>(a, big, &d)) return;
     const uint64_t N = d.p.rows, SR = big_sec_rows(N);
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
     const uint64_t w0 = s0 / 32, w1 = min(d.l.nwords, (s0 + SR) / 32);
     const int t = threadIdx.x;
     uint32_t run = 0;
+    unsigned long long brun = 0;
+    __shared__ unsigned long long s8[4];
+    unsigned long long* wbytes = (unsigned long long*)(d.bigx + d.l.o_wbytes);
     for (uint64_t wb = w0; wb < w1; wb += WG) {
         const uint64_t w = wb + t;
-        const uint32_t c = w < w1 ? (uint32_t)__popc(d.bits[w]) : 0u;
+        const uint32_t word = w < w1 ? d.bits[w] : 0u;
+        const uint32_t c = (uint32_t)__popc(word);
         const uint32_t incl = wave_incl_scan(c);
+        unsigned long long by = 0, bincl = 0;
+        if constexpr (KIND < 0) {   // entry bytes of the word's first rows: u64 len | bytes (binary/dict.rs:77-90)
+            for (uint32_t m = word; m; m &= m - 1) by += big_bin_weight(d.c, d.p, w * 32 + (uint32_t)__ffs((int)m) - 1);
+            bincl = wave_incl_scan64(by);
+        }
         __syncthreads();
-        if ((t & 63) == 63) s4[t >> 6] = incl;
+        if ((t & 63) == 63) {
+            s4[t >> 6] = incl;
+            s8[t >> 6] = bincl;
+        }
         __syncthreads();
         uint32_t base = run;
-        for (int q = 0; q < (t >> 6); q++) base += s4[q];
-        if (w < w1) d.wpref[w] = base + incl - c;
+        unsigned long long bbase = brun;
+        for (int q = 0; q < (t >> 6); q++) {
+            base += s4[q];
+            bbase += s8[q];
+        }
+        if (w < w1) {
+            d.wpref[w] = base + incl - c;
+            if constexpr (KIND < 0) wbytes[w] = bbase + bincl - by;
+        }
         run += s4[0] + s4[1] + s4[2] + s4[3];
+        brun += s8[0] + s8[1] + s8[2] + s8[3];
     }
-    if (t == 0) d.rec->sectot[blockIdx.x] = run;
+    if (t == 0) {
+        d.rec->sectot[blockIdx.x] = run;
+        d.rec->secbytes[blockIdx.x] = brun;
+    }
 }
 
 // exclusive prefix of the sections' entry counts into s_base[0 .. nsec] (all threads call; WG >= SEL_BIG_SECTIONS)
@@ -299,16 +365,37 @@ __device__ __forceinline__ uint32_t dbig_rank(const DictBigCtx& d, const uint32_
     return s_base[row / SR] + d.wpref[row >> 5] + (uint32_t)__popc(d.bits[row >> 5] & ((1u << (row & 31)) - 1u));
 }
 
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG) k_dict_big_ids(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     __shared__ uint32_t s_base[WG + 1];
     __shared__ uint32_t s4[4];
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
-    if (!dbig_page_of<W>(a, big, &d)) return;
+    if (!dbig_page_of<KIND>(a, big, &d)) return;
     const uint64_t N = d.p.rows, SR = big_sec_rows(N);
     const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
     dbig_sec_bases(d.rec, nsec, s_base, s4);
+    __shared__ unsigned long long s_bbase[SEL_BIG_SECTIONS + 1];
+    if constexpr (KIND < 0) {
+        if (threadIdx.x == 0) {
+            unsigned long long r = 0;
+            for (uint32_t q = 0; q < nsec; q++) {
+                s_bbase[q] = r;
+                r += d.rec->secbytes[q];
+            }
+            s_bbase[nsec] = r;
+        }
+        __syncthreads();
+    }
+    const unsigned long long* wbytes = (const unsigned long long*)(d.bigx + d.l.o_wbytes);
+    unsigned long long* eoff = (unsigned long long*)(d.bigx + d.l.o_eoff);
+    auto entry_off = [&](uint32_t r) -> unsigned long long {   // bytes of the entries in front of the one whose first row is r
+        unsigned long long o = s_bbase[r / SR] + wbytes[r >> 5];
+        for (uint32_t m = d.bits[r >> 5] & ((1u << (r & 31)) - 1u); m; m &= m - 1)
+            o += big_bin_weight(d.c, d.p, (uint64_t)(r & ~31u) + (uint32_t)__ffs((int)m) - 1);
+        return o;
+    };
     const uint64_t M3 = d.rec->M3;
     const uint64_t tid = (uint64_t)blockIdx.x * WG + threadIdx.x, nth = (uint64_t)gridDim.x * WG;
     for (uint64_t i = tid; i < M3; i += nth) {
@@ -317,20 +404,24 @@ __global__ void __launch_bounds__(WG) k_dict_big_ids(EncodeArgs a, const uint32_
         const uint32_t id = dbig_rank(d, s_base, SR, r);
         d.firsts[id] = r;
         d.frow[i] = id;
+        if constexpr (KIND < 0) eoff[id] = entry_off(r);
     }
     if (tid == 0) {
         d.rec->D = s_base[nsec];
+        if constexpr (KIND < 0) d.rec->etotal = s_bbase[nsec];
         const uint32_t sf = d.rec->sent_first;
         if (sf != 0xFFFFFFFFu) {
             const uint32_t id = dbig_rank(d, s_base, SR, sf);
             d.firsts[id] = sf;
             d.rec->sent_id = id;
+            if constexpr (KIND < 0) eoff[id] = entry_off(sf);
         }
     }
 }
 
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     __shared__ unsigned long long lk[DBIG_LDS_SLOTS];
     __shared__ uint32_t li[DBIG_LDS_SLOTS];
     __shared__ uint32_t s_base[WG + 1];
@@ -338,14 +429,14 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
     __shared__ uint32_t s_has[2][4], s_last[2][4];
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
-    if (!dbig_page_of<W>(a, big, &d)) return;
+    if (!dbig_page_of<KIND>(a, big, &d)) return;
     const uint64_t N = d.p.rows, SR = big_sec_rows(N);
     const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
     const uint64_t s0 = (uint64_t)blockIdx.x * (SR / DBIG_SPLIT);
     if (s0 >= N) return;
     const uint64_t s1 = min(N, s0 + SR / DBIG_SPLIT);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint8_t* vals = d.c.values + d.p.row0 * W;
+    const DbigKeys<KIND> kf = dbig_keys<KIND>(a, d);
     const ValidView vv{d.c.validity, d.c.validity_bit_offset + d.p.row0};
     const uint32_t fkind = d.c.fkind;
     const uint32_t M3 = d.rec->M3, mask = M3 - 1;
@@ -360,11 +451,7 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
     }
     __syncthreads();
     auto id_of = [&](uint64_t row) -> uint32_t {   // row is keyed
-        const bool valid = vv.get(row);
-        Val<W> v = ld_val<W>(vals + row * W);
-        if (row == 0 && !valid) v = val_zero<W>();
-        unsigned long long x = 0;
-        __builtin_memcpy(&x, &v, W);
+        const unsigned long long x = kf.key(row, vv.get(row));
         if (dbig_is_nan<W>(x, fkind)) {   // its own entry: id = rank of the row among the first rows
             const uint32_t id = dbig_rank(d, s_base, SR, (uint32_t)row);
             d.firsts[id] = (uint32_t)row;
@@ -667,13 +754,15 @@ __global__ void __launch_bounds__(WG) k_plain_big(EncodeArgs a, const uint32_t* 
 }
 
 // ---------------------------------------------------------------------------------------------------- finish
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG, 2) k_dict_big_finish(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * SIDX_WORDS];
     __shared__ uint32_t s_w[4];
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     DictBigCtx d;
-    if (!dbig_page_of<W>(a, big, &d)) return;
+    if (!dbig_page_of<KIND>(a, big, &d)) return;
+    if (KIND < 0 && d.rec->bad) return;   // two different strings with one hash: k_enc_emit_pages builds the page exactly
     uint32_t *sA = lds, *sB = lds + SIDX_WORDS, *sC = lds + 2 * SIDX_WORDS;
     const uint64_t N = d.p.rows;
     uint8_t* slot = page_slot(a, d.c, d.p);
@@ -720,9 +809,11 @@ __global__ void __launch_bounds__(WG, 2) k_dict_big_finish(EncodeArgs a, const u
     }
     if (threadIdx.x == 0) {
         stu32(blk + 9 + ib, D);
-        put_hdr9(blk, SB_CODEC_DICT, (uint32_t)(ib + 4 + (uint64_t)D * W), (uint32_t)(N * W));
+        // entries: n x value / n x {u64 len | bytes}; a binary block's uncompressed_size = array.values().len() (binary/mod.rs:88)
+        const uint64_t ebytes = KIND > 0 ? (uint64_t)D * W : d.rec->etotal;
+        put_hdr9(blk, SB_CODEC_DICT, (uint32_t)(ib + 4 + ebytes), KIND > 0 ? (uint32_t)(N * W) : (uint32_t)d.c.values_len_total);
         EncOut o;
-        o.length = pos + 9 + ib + 4 + (uint64_t)D * W;
+        o.length = pos + 9 + ib + 4 + ebytes;
         o.out_off = 0;
         o.slot = slot;
         o.codec = SB_CODEC_DICT;
@@ -731,14 +822,20 @@ __global__ void __launch_bounds__(WG, 2) k_dict_big_finish(EncodeArgs a, const u
     }
 }
 
-template <int W>
+template <int KIND>
 __global__ void __launch_bounds__(WG) k_dict_big_values(EncodeArgs a, const uint32_t* big) {
+    [[maybe_unused]] constexpr int W = KIND > 0 ? KIND : 8;   // bytes of a key
     if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
     const uint32_t page = big[blockIdx.y];
     const EncPage p = a.pages[page];
     const EncCol c = a.cols[p.col];
     // (after k_dict_big_finish: the page record exists, pad == 1 marks this path)
-    if ((int)c.width != W || !p.bigx_off || a.codecs[page] != (int32_t)SB_CODEC_DICT || a.outs[page].pad != 1 || a.outs[page].length == 0) return;
+    if (!p.bigx_off || a.codecs[page] != (int32_t)SB_CODEC_DICT || a.outs[page].pad != 1 || a.outs[page].length == 0) return;
+    if constexpr (KIND > 0) {
+        if (big_is_bin(c) || (int)c.width != KIND) return;
+    } else {
+        if (c.ptype != (KIND == -4 ? SB_TYPE_BINARY : SB_TYPE_LARGE_BINARY)) return;
+    }
     uint8_t* bigx = a.scratch + p.bigx_off;
     const DictBigRec* rec = (const DictBigRec*)bigx;
     if (!rec->active) return;
@@ -762,13 +859,62 @@ __global__ void __launch_bounds__(WG) k_dict_big_values(EncodeArgs a, const uint
         ib = 9 + (uint64_t)ldu32(blk + 9 + 1);
     }
     const uint32_t D = rec->D;
-    const uint8_t* vals = c.values + p.row0 * W;
-    const bool lead_null = c.validity && !bit_at(c.validity, c.validity_bit_offset + p.row0);
     uint8_t* q = blk + 9 + ib + 4;
-    for (uint64_t k = tid; k < D; k += nth) {
-        const uint32_t r = firsts[k];
-        Val<W> v = ld_val<W>(vals + (uint64_t)r * W);
-        if (r == 0 && lead_null) v = val_zero<W>();
-        __builtin_memcpy(q + k * W, &v, W);
+    if constexpr (KIND > 0) {
+        const uint8_t* vals = c.values + p.row0 * W;
+        const bool lead_null = c.validity && !bit_at(c.validity, c.validity_bit_offset + p.row0);
+        for (uint64_t k = tid; k < D; k += nth) {
+            const uint32_t r = firsts[k];
+            Val<W> v = ld_val<W>(vals + (uint64_t)r * W);
+            if (r == 0 && lead_null) v = val_zero<W>();
+            __builtin_memcpy(q + k * W, &v, W);
+        }
+    } else {   // u64 len | bytes per entry, at the offsets k_dict_big_ids found
+        using O = typename std::conditional<KIND == -4, int32_t, int64_t>::type;
+        const BinKeys<O> bk{c.offsets + p.row0 * sizeof(O), c.values, ValidView{nullptr, 0}};
+        const unsigned long long* eoff = (const unsigned long long*)(bigx + l.o_eoff);
+        for (uint64_t k = tid; k < D; k += nth) {
+            const uint64_t r = firsts[k];
+            const uint64_t b = bk.beg(r), e = bk.beg(r + 1);
+            uint8_t* dd = q + eoff[k];
+            stu64(dd, e - b);
+            uint64_t j = 0;
+            for (; j + 16 <= e - b; j += 16) stu128(dd + 8 + j, ldu128(c.values + b + j));   // (unaligned 16-byte moves)
+            for (; j + 8 <= e - b; j += 8) stu64(dd + 8 + j, ldu64(c.values + b + j));
+            for (; j < e - b; j++) *(gptr)(dd + 8 + j) = ldu8(c.values + b + j);
+        }
     }
+}
+
+// binary pages: the dictionary was formed on 64-bit hashes — every keyed row's string against the string of its entry's
+// first row (the index array names the entry).  A mismatch (two strings with one hash: never seen) sets the page's `bad`
+// word: k_dict_big_finish leaves the page to k_enc_emit_pages, whose builder compares strings.
+template <int KIND>
+__global__ void __launch_bounds__(WG) k_dict_big_verify(EncodeArgs a, const uint32_t* big) {
+    static_assert(KIND < 0, "binary pages only");
+    if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
+    DictBigCtx d;
+    if (!dbig_page_of<KIND>(a, big, &d)) return;
+    using O = typename std::conditional<KIND == -4, int32_t, int64_t>::type;
+    const uint64_t N = d.p.rows, SR = big_sec_rows(N) / DBIG_SPLIT;
+    const uint64_t s0 = (uint64_t)blockIdx.x * SR;
+    if (s0 >= N) return;
+    const uint64_t s1 = min(N, s0 + SR);
+    const ValidView vv{d.c.validity, d.c.validity_bit_offset + d.p.row0};
+    const BinKeysHashed<O> kh{BinKeys<O>{d.c.offsets + d.p.row0 * sizeof(O), d.c.values, vv}, (const uint64_t*)(a.scratch + d.p.h64_off), d.c.values_len};
+    bool ok = !(a.flags & SB_WRITE_DEBUG_VERIFY_FAIL_BIT);   // (tests: every page fails)
+    constexpr int VU = 8;
+    for (uint64_t base = s0 + threadIdx.x; base < s1 && ok; base += (uint64_t)WG * VU) {
+        uint32_t f[VU];
+        uint64_t row[VU];
+#pragma unroll
+        for (int u = 0; u < VU; u++) {
+            row[u] = base + (uint64_t)u * WG;
+            const bool keyed = row[u] < s1 && (row[u] == 0 || vv.get(row[u]));
+            f[u] = keyed ? d.firsts[d.idx[row[u]]] : EMPTY;
+            if (f[u] == (uint32_t)row[u]) f[u] = EMPTY;   // a first row needs no check
+        }
+        if (!kh.template exact_batch<VU>(f, row)) ok = false;
+    }
+    if (!ok) d.rec->bad = 1;
 }

@@ -3431,6 +3431,15 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
             return;
         }
     }
+    if constexpr (KIND < 0) {
+        // long binary pages: the statistics over their row hashes section-parallel, the Dict pages among them too
+        // (sb_select_big.h / sb_dict_big.h, launched after this kernel)
+        if (a.use_counts && !a.redo && a.page_base == 0 && page < a.n_pages && N >= SEL_BIG_ROWS && p.bigx_off && p.h64_off != ~0ull &&
+            a.pre_hashed) {
+            if (threadIdx.x == 0) a.codecs[page] = CODEC_PENDING;
+            return;
+        }
+    }
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
     SelectOpts so{a.ratio, a.has_ratio, a.forbidden | p.forb_extra, a.default_compression, -1, p.seed, p.depth};
     SelScratch sc{lds_tab, s_misc, sample_mem, p.aux_bytes ? (uint32_t*)(a.scratch + p.aux_off) : nullptr, 0};
@@ -5340,7 +5349,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const uint64_t np = c.page_rows ? c.n_pages_in : (c.rows + ps - 1) / ps;
         if (np > c.n_pages_capacity || !c.out_metas) return ctx->fail(SB_ERR_INVALID, "out_metas too small");
         // (long pages that may become Dict pages run their index arrays as virtual pages: sb_dict_big.h)
-        big_possible |= adaptive && !enc_is_binary(c.physical_type) && c.rows >= SEL_BIG_ROWS;
+        big_possible |= adaptive && c.rows >= SEL_BIG_ROWS;
         if (!c.out_pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "out_pages is null");
         P += np;
         if (hit) continue;   // (the per-page arithmetic of this shape is in the plan)
@@ -5468,7 +5477,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         plan.col_first.assign(n, 0);
         plan.col_pages.assign(n, 0);
         plan.hro.assign(n, 0);
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             plan.bigw[k].clear();
             plan.big_secs[k] = 0;
         }
@@ -5536,6 +5545,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 plan.bigw[k].push_back((uint32_t)pi);
                 plan.big_secs[k] = std::max(plan.big_secs[k], secs);
                 if (!((forb >> SB_CODEC_DICT) & 1) || freq_possible) p.bigx_off = 1;   // (placed with the aux areas below)
+            } else if (adaptive && bin && N >= SEL_BIG_ROWS && !((forb >> SB_CODEC_DICT) & 1)) {   // (row hashes exist: Dict is a candidate)
+                const uint32_t secs = (uint32_t)((N + big_sec_rows(N) - 1) / big_sec_rows(N));
+                plan.bigw[4].push_back((uint32_t)pi);
+                plan.big_secs[4] = std::max(plan.big_secs[4], secs);
+                p.bigx_off = 1;
             }
             if (direct) {
                 p.direct_off = direct_off;
@@ -5619,7 +5633,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (hp[q].bigx_off == 1) {
             scratch_off = align_up(scratch_off, 64);
             hp[q].bigx_off = scratch_off;
-            scratch_off += ((forb >> SB_CODEC_DICT) & 1) ? BIGX_HEAD : dbig_layout(hp[q].rows).total;
+            scratch_off += ((forb >> SB_CODEC_DICT) & 1) ? BIGX_HEAD : dbig_layout(hp[q].rows, enc_is_binary(hc[hp[q].col].ptype)).total;
         }
         if (hp[q].zst_off == 0) {   // (one block is at most 128 KiB whatever the page holds)
             scratch_off = align_up(scratch_off, 16);
@@ -5670,10 +5684,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (!hit) {   // the page table goes to the plan's own device buffer and stays there
         e = hipMemcpyAsync(plan.pages.p, hp, P * sizeof(EncPage), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return check_hip(ctx, e, "page table upload");
-        if (const size_t nb = plan.bigw[0].size() + plan.bigw[1].size() + plan.bigw[2].size() + plan.bigw[3].size()) {   // (pageable source: the copy is staged before the call returns)
+        if (const size_t nb = plan.bigw[0].size() + plan.bigw[1].size() + plan.bigw[2].size() + plan.bigw[3].size() + plan.bigw[4].size()) {   // (pageable source: the copy is staged before the call returns)
             if (!ensure(ctx, plan.big, nb * sizeof(uint32_t) + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(long-page list) failed");
             std::vector<uint32_t> both;
-            for (int k = 0; k < 4; k++) both.insert(both.end(), plan.bigw[k].begin(), plan.bigw[k].end());
+            for (int k = 0; k < 5; k++) both.insert(both.end(), plan.bigw[k].begin(), plan.bigw[k].end());
             e = hipMemcpyAsync(plan.big.p, both.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);   // (`both` goes out of scope; plan misses are rare)
             if (e != hipSuccess) return check_hip(ctx, e, "long-page list upload");
@@ -5779,7 +5793,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         // long pages (>= 2^18 rows) of 1- / 2- / 4- / 8-byte values: section-parallel statistics, the same decision, and the
         // RLE pages among them written section-parallel too (sb_select_big.h); they were left CODEC_PENDING by the page selectors
         auto launch_big = [&](int kd, hipStream_t st) {
-            const int k = kd == 1 ? 0 : kd == 2 ? 1 : kd == 4 ? 2 : kd == 8 ? 3 : -1;
+            const int k = kd == 1 ? 0 : kd == 2 ? 1 : kd == 4 ? 2 : kd == 8 ? 3 : kd < 0 ? 4 : -1;   // (binary pages: a list of their own)
             if (k < 0 || aa.page_base != 0) return;
             const uint32_t nbig = (uint32_t)plan.bigw[k].size();
             if (!nbig) return;
@@ -5792,7 +5806,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (kd == 1) KERNEL<1><<<GRID, THREADS, 0, st>>>(aa, list, 0u);        \
         else if (kd == 2) KERNEL<2><<<GRID, THREADS, 0, st>>>(aa, list, 0u);   \
         else if (kd == 4) KERNEL<4><<<GRID, THREADS, 0, st>>>(aa, list, 0u);   \
-        else KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list, 0u);                \
+        else KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list, 0u);   /* 8-byte values, and binary pages as their u64 row hashes */ \
     } while (0)
             {
                 KScope kk(ctx, "k_sel_big_sec");
@@ -5804,8 +5818,11 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 SB_BIG_W(k_sel_big_merge, pg, WG);
             }
             {
-                KScope kk(ctx, "k_sel_big_count");
+                KScope kk(ctx, "k_sel_big_clear");
                 k_sel_big_clear<<<sg, WG, 0, st>>>(aa, list, 0u);
+            }
+            {
+                KScope kk(ctx, "k_sel_big_count");
                 const dim3 cg(sg.x * BIG_COUNT_SPLIT, nbig);
                 SB_BIG_W(k_sel_big_count, cg, WG);
             }
@@ -5813,7 +5830,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 KScope kk(ctx, "k_sel_big_decide");
                 SB_BIG_W(k_sel_big_decide, pg, WG);
             }
-            if (!((forb >> SB_CODEC_RLE) & 1)) {
+            if (!((forb >> SB_CODEC_RLE) & 1) && kd > 0) {
                 KScope kk(ctx, "k_rle_big");
                 SB_BIG_W(k_rle_big_count, sg, WG);
                 SB_BIG_W(k_rle_big_plan, pg, WG);
@@ -5829,7 +5846,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (kd == 1) KERNEL<1><<<GRID, THREADS, 0, st>>>(aa, list);        \
         else if (kd == 2) KERNEL<2><<<GRID, THREADS, 0, st>>>(aa, list);   \
         else if (kd == 4) KERNEL<4><<<GRID, THREADS, 0, st>>>(aa, list);   \
-        else KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list);                \
+        else if (kd == 8) KERNEL<8><<<GRID, THREADS, 0, st>>>(aa, list);   \
+        else if (kd == -4) KERNEL<-4><<<GRID, THREADS, 0, st>>>(aa, list); \
+        else KERNEL<-8><<<GRID, THREADS, 0, st>>>(aa, list);               \
     } while (0)
                 {
                     KScope kk(ctx, "k_dict_big_insert");
@@ -5845,6 +5864,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 {
                     KScope kk(ctx, "k_dict_big_idx");
                     SB_DBIG_W(k_dict_big_idx, sg4, WG);
+                    if (kd == -4) k_dict_big_verify<-4><<<sg4, WG, 0, st>>>(aa, list);
+                    else if (kd == -8) k_dict_big_verify<-8><<<sg4, WG, 0, st>>>(aa, list);
                 }
                 {   // the index arrays as virtual pages of u32: selected ...
                     KScope kk(ctx, "k_sel_big(indices)");
@@ -5923,7 +5944,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 KScope k(ctx, nm);
                 enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, st>>>(aa);
             }
-            if (!nested && (kd == 1 || kd == 2)) launch_big(kd, st);
+            if (!nested && (kd == 1 || kd == 2 || kd < 0)) launch_big(kd, st);
         };
         // the dictionaries the binary selectors handed over: strings checked tile-parallel, pages that failed selected again
         // exactly (workgroups of all other pages return at once); kd_only: the one binary kind of this stream, or 0 = both

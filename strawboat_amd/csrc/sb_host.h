@@ -150,8 +150,8 @@ struct sb_ctx {
         sb::DevBuf pages;   // EncPage[P] on the device
         // long pages of 4- / 8-byte values (adaptive calls): selected section-parallel (sb_select_big.h); page indices on
         // the device as [1-byte | 2-byte | 4-byte | 8-byte pages], grid.x = the most sections any page of a width has
-        std::vector<uint32_t> bigw[4];          // by log2(width): 1-, 2-, 4-, 8-byte values
-        uint32_t big_secs[4] = {0, 0, 0, 0};
+        std::vector<uint32_t> bigw[5];          // by log2(width): 1-, 2-, 4-, 8-byte values; [4]: binary pages
+        uint32_t big_secs[5] = {0, 0, 0, 0, 0};
         sb::DevBuf big;
     } enc_plan;
     std::vector<uint64_t> enc_plan_probe;   // the key words of the call at hand

@@ -42,7 +42,9 @@ struct BigPage {   // 256 bytes at the start of the slot
     uint32_t set_unique, ksent, need_uq, need_mc;
     uint32_t uq, mc;   // k_sel_big_count's results (atomics)
     uint32_t uq_sent;  // the all-ones key (the table's "empty") was met
-    uint32_t pad[49];
+    uint32_t pad1;
+    unsigned long long tus;   // binary pages: bytes of the distinct strings (8 + len each: binary/dict.rs:43-53), k_sel_big_count
+    uint32_t pad[46];
 };
 constexpr uint32_t BIG_SEC_STRIDE = 64 + BIG_KCAP * 8;
 static_assert(sizeof(BigSec) == 64 && sizeof(BigPage) == 256, "records of the long-page selector");
@@ -76,7 +78,28 @@ __device__ __forceinline__ bool big_page_of(const EncodeArgs& a, const uint32_t*
     if (a.codecs[*page] != CODEC_PENDING) return false;   // (k_enc_select_runs may have taken the page)
     *p = get_page(a, *page);
     *c = get_col(a, p->col);
+    if (c->ptype == SB_TYPE_BINARY || c->ptype == SB_TYPE_LARGE_BINARY) {
+        // a long binary page: the statistics run over one 64-bit hash per row (k_enc_bin_hash wrote them before the selector;
+        // equal hashes count as equal strings, as in choose_bin) — the page as a column of u64 keys.  ptype and offsets stay:
+        // page_slot and the string lengths need them.
+        if (W != 8 || p->h64_off == ~0ull) return false;
+        c->values = a.scratch + p->h64_off - p->row0 * 8;
+        c->width = 8;
+        c->nk = NK_UNSIGNED;
+        c->fkind = 0;
+        return true;
+    }
     return (int)c->width == W;
+}
+__device__ __forceinline__ bool big_is_bin(const EncCol& c) { return c.ptype == SB_TYPE_BINARY || c.ptype == SB_TYPE_LARGE_BINARY; }
+// 8 + len of row i of a binary page (c: the column as big_page_of left it)
+__device__ __forceinline__ uint32_t big_bin_weight(const EncCol& c, const EncPage& p, uint64_t i) {
+    if (c.ptype == SB_TYPE_BINARY) {
+        const uint8_t* o = c.offsets + (p.row0 + i) * 4;
+        return ldu32(o + 4) - ldu32(o) + 8;
+    }
+    const uint8_t* o = c.offsets + (p.row0 + i) * 8;
+    return (uint32_t)(ldu64(o + 8) - ldu64(o)) + 8;
 }
 
 // one step of the merge of two Boyer-Moore states
@@ -135,7 +158,8 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
     Val<W> tmax = getv(0);
     uint64_t vote_k = 0;
     uint32_t vote_n = 0;
-    const bool want_set = !((forb >> SB_CODEC_DICT) & 1) && N >= 3;
+    // (binary pages need the bytes of the distinct strings beside their number: always the exact count, k_sel_big_count)
+    const bool want_set = !((forb >> SB_CODEC_DICT) & 1) && N >= 3 && !big_is_bin(c);
     const bool want_vote = !((forb >> SB_CODEC_FREQ) & 1);
     for (uint32_t i = t; i < KSLOTS; i += WG) kset[i] = SENT;
     if (t == 0) {
@@ -412,6 +436,50 @@ __device__ void big_decide(const EncodeArgs& a, const EncCol& c, const EncPage& 
     }
 }
 
+// choose_compressor for a long binary page (binary/mod.rs:293-348; choose_bin_impl with the numbers the sections and
+// k_sel_big_count found): thread 0 decides
+__device__ void big_decide_bin(const EncodeArgs& a, const EncCol& c, const EncPage& p, uint32_t page, const BigPage& bp) {
+    if (threadIdx.x) return;
+    const uint64_t N = p.rows;
+    const uint32_t forb = a.forbidden | p.forb_extra;
+    const bool all_equal = !(bp.flags & 1u);
+    const double tuple_count = (double)N;
+    const uint64_t ow = c.ptype == SB_TYPE_BINARY ? 4 : 8;
+    const double total_bytes = (double)(c.values_len_total + (N + 1) * ow);
+    double max_ratio = a.ratio;
+    uint32_t result = a.default_compression;
+    static const uint8_t ORDER[3] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT};
+    for (int oi = 0; oi < 3; oi++) {
+        const uint32_t cd = ORDER[oi];
+        if ((forb >> cd) & 1u) continue;
+        double r = 0.0;
+        if (cd == SB_CODEC_ONEVALUE) {
+            r = all_equal ? tuple_count : 0.0;
+        } else if (cd == SB_CODEC_FREQ) {
+            if (!all_equal) {
+                if ((double)bp.nulls / tuple_count >= 0.9) r = (double)(N - 1);
+                else if (bp.need_mc && (double)bp.mc / tuple_count >= 0.9) r = (double)(N - 1);   // (no need_mc: the vote rules a 90 % majority out)
+            }
+        } else if (N >= 3 && bp.need_uq) {
+            const uint64_t uq = (uint64_t)bp.uq + bp.uq_sent;
+            if (uq * 3 < N) {
+                uint64_t after = bp.tus + N * (uint64_t)(bits_needed(uq) / 8);
+                after += N * 2 / 128;
+                r = total_bytes / (double)after;
+            }
+        }
+        if (r > max_ratio) {
+            max_ratio = r;
+            result = cd;
+            if (r == tuple_count) break;
+        }
+    }
+    a.codecs[page] = (int32_t)result;
+    atomicAdd(&a.codec_counts[result & 31], 1u);
+    if (!has_device_encoder(result)) raise(a.status, SB_ERR_NYI, page, 700 + result);
+    else if (result == SB_CODEC_FREQ) atomicAdd(a.freq_count, 1u);
+}
+
 template <int W>
 __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     __shared__ uint32_t lds_tab[SEL_LDS_SLOTS];
@@ -479,7 +547,8 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     // ---- the union of the sections' key sets
     bool set_ok = false;
     uint32_t set_unique = 0;
-    if (want_set && !over) {   // (the sections united their sets in the page's table: k_sel_big_sec)
+    const bool bin = big_is_bin(c);
+    if (want_set && !over && !bin) {   // (the sections united their sets in the page's table: k_sel_big_sec)
         const uint32_t uc = big_union_cnt(slot, nsec)[0], uover = big_union_cnt(slot, nsec)[1];
         set_ok = !uover && uc <= BIG_KCAP;
         set_unique = uc + (ksent ? 1u : 0u);
@@ -487,7 +556,8 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     // ---- what is missing for the decision?
     const bool all_equal = !(flags & 1u);
     const double tuple_count = (double)N;
-    const bool need_uq = want_set && !all_equal && !set_ok;
+    // (binary: set_ok is never true; choose_bin_impl looks at Dict's ratio on an all-equal page too unless OneValue took it)
+    const bool need_uq = bin ? want_set && !(all_equal && !((forb >> SB_CODEC_ONEVALUE) & 1)) : want_set && !all_equal && !set_ok;
     const bool need_mc = want_vote && !all_equal && !((double)null_count / tuple_count >= 0.9) && ((double)maj_n + 1.0 >= 0.8 * tuple_count);
     if (t == 0) {
         BigPage b;
@@ -510,7 +580,8 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     const BigPage bp = s_bp;
     const PrimCounts pc{false, false, 0, 0};
     __syncthreads();
-    big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
+    if (bin) big_decide_bin(a, c, p, page, bp);
+    else big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
 }
 
 __global__ void __launch_bounds__(WG) k_sel_big_clear(EncodeArgs a, const uint32_t* big, uint32_t voff) {
@@ -531,6 +602,12 @@ template <int W>
 __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uint32_t* big, uint32_t voff) {
     __shared__ uint32_t s4[4];
     __shared__ uint32_t s_stop;
+    // keys this section has looked up already: a column with a few frequent values (zipf text: the top ten words are 40 %
+    // of the rows) would send every one of those rows to the SAME few words of the page's table — loads of one address from
+    // all CUs queue up in one L2 channel (3 M zipf rows: 1.6 ms for the pass)
+    constexpr uint32_t LSLOTS = 4096, LCAP = 3072;
+    __shared__ unsigned long long lseen[LSLOTS];
+    __shared__ uint32_t s_lcnt;
     uint32_t page;
     EncPage p;
     EncCol c;
@@ -556,7 +633,16 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
     if (need_mc) {   // rows whose key is the vote's candidate (freq.rs:129-151 counts them exactly)
         const uint64_t mk = bp->maj_k;
         uint32_t mine = 0;
-        for (uint64_t i = s0 + t; i < s1; i += WG) mine += k64(key(i)) == mk ? 1u : 0u;
+        for (uint64_t i0 = s0 + t; i0 < s1; i0 += (uint64_t)WG * 8) {   // (eight loads in flight: the loop is latency otherwise)
+            unsigned long long kx[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = i0 + (uint64_t)u * WG;
+                kx[u] = k64(key(i < s1 ? i : s0));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) mine += (i0 + (uint64_t)u * WG < s1 && kx[u] == mk) ? 1u : 0u;
+        }
         const uint32_t tot = wg_sum32(mine, s4);
         if (t == 0 && tot) atomicAdd(&bp->mc, tot);
     }
@@ -568,6 +654,9 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
     const uint32_t mask = (uint32_t)(M - 1);
     const uint32_t limit = (uint32_t)((N - 1) / 3);
     uint32_t sent = 0;
+    const bool bin = big_is_bin(c);
+    for (uint32_t i = t; i < LSLOTS; i += WG) lseen[i] = EMPTY;
+    if (t == 0) s_lcnt = 0;
     for (uint64_t base = s0; base < s1; base += WG * 8) {
         __syncthreads();
         if (t == 0) s_stop = __hip_atomic_load(&bp->uq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit ? 1u : 0u;
@@ -575,7 +664,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
         if (s_stop) break;
         unsigned long long xu[8], cu[8];
         uint32_t hu[8];
-        uint32_t pend = 0, newc = 0;
+        uint32_t pend = 0, newc = 0, neww = 0;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint64_t i = base + (uint64_t)u * WG + t;
@@ -583,8 +672,37 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
             xu[u] = k64(kv);
             hu[u] = stat_hash<W>(kv) & mask;
             if (i < s1) {
-                if (xu[u] == EMPTY) sent = 1;
-                else pend |= 1u << u;
+                if (xu[u] == EMPTY) {
+                    // (binary: the all-ones hash's string counts once — whoever flips the flag adds its bytes)
+                    if (bin && !sent && atomicCAS(&bp->uq_sent, 0u, 1u) == 0u) neww += big_bin_weight(c, p, i);
+                    sent = 1;
+                } else {
+                    // the first row of this section to meet a key looks it up in the page's table; the others know it is there
+                    uint32_t lh = (uint32_t)((xu[u] * 0x9E3779B97F4A7C15ull) >> 44) & (LSLOTS - 1);
+                    bool seen = false;
+                    const bool room = s_lcnt < LCAP;   // (racy count: LSLOTS - LCAP slots of slack)
+                    for (uint32_t st = 0; st < 16; st++) {
+                        const unsigned long long cur = lseen[lh];
+                        if (cur == xu[u]) {
+                            seen = true;
+                            break;
+                        }
+                        if (cur == EMPTY) {
+                            if (!room) break;
+                            const unsigned long long old = atomicCAS(&lseen[lh], EMPTY, xu[u]);
+                            if (old == EMPTY) {
+                                atomicAdd(&s_lcnt, 1u);
+                                break;
+                            }
+                            if (old == xu[u]) {
+                                seen = true;
+                                break;
+                            }
+                        }
+                        lh = (lh + 1) & (LSLOTS - 1);
+                    }
+                    if (!seen) pend |= 1u << u;
+                }
             }
         }
         while (pend) {
@@ -599,6 +717,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
                     __hip_atomic_compare_exchange_strong(tab + hu[u], &e, xu[u], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (e == EMPTY) {
                         newc++;
+                        if (bin) neww += big_bin_weight(c, p, base + (uint64_t)u * WG + t);
                         pend &= ~(1u << u);
                         continue;
                     }
@@ -610,6 +729,10 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
         }
         const uint32_t tot = wg_sum32(newc, s4);
         if (t == 0 && tot) atomicAdd(&bp->uq, tot);
+        if (bin) {   // (a batch is 2 048 rows of strings: their bytes fit 32 bits)
+            const uint32_t wt = wg_sum32(neww, s4);
+            if (t == 0 && wt) atomicAdd(&bp->tus, (unsigned long long)wt);
+        }
     }
     if (sent) bp->uq_sent = 1;
 }
@@ -626,7 +749,8 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const ui
     const BigPage bp = *big_page_rec(page_slot(a, c, p));
     // without an aux area (cannot happen while Dict is a candidate) the count stays unknown: "more than the limit"
     const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
-    big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
+    if (big_is_bin(c)) big_decide_bin(a, c, p, page, bp);
+    else big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
 }
 
 // ---------------------------------------------------------------------------------------------------- RLE of a long page

@@ -263,3 +263,63 @@ def test_long_multi_frame_zstd_buffers_split_by_scan(gpu_ctx):
         elif got is not None:
             assert np.array_equal(got, want)
     _zstd_one_page_round_trip(gpu_ctx, plain[:2_000_000])   # the context still works
+
+
+def binary_cases():
+    rng = np.random.default_rng(91)
+    out = {
+        "utf8_zipf": gen.binary(ROWS_ODD, uniq=8000, zipf=1.2, maxlen=24, seed=71),                 # a Dict page, bit-packing impossible (rows % 128)
+        "utf8_zipf_128": gen.binary(ROWS, uniq=5000, zipf=1.3, maxlen=16, seed=72),                 # Dict, bit-packed indices
+        "utf8_lowcard_nullable": gen.binary(ROWS_ODD, uniq=300, null_density=0.15, maxlen=20, seed=73),
+        "large_utf8_midcard": gen.binary(ROWS, uniq=120_000, maxlen=10, large=True, seed=74),       # 64-bit offsets, 120 k entries
+        "utf8_unique": gen.binary(400_000, uniq=600_000, minlen=8, maxlen=14, seed=75),             # no Dict: most strings differ
+        "utf8_one_value": gen.binary(300_000, uniq=1, minlen=5, maxlen=5, seed=76),
+        "utf8_sparse": None,
+        "utf8_leading_nulls": None,
+        "utf8_runs": None,
+    }
+    c = gen.binary(ROWS, uniq=2, minlen=3, maxlen=3, seed=77)                                       # one string in 97 % of the rows -> Freq
+    words = [b"top", b"x1", b"yy22", b"zzz333"]
+    idx = np.where(rng.random(ROWS) < 0.97, 0, rng.integers(1, 4, ROWS))
+    lens = np.array([len(w) for w in words], np.int64)[idx]
+    offs = np.zeros(ROWS + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    out["utf8_sparse"] = dict(c, values=np.frombuffer(b"".join(words[i] for i in idx), np.uint8).copy(), offsets=offs.astype(np.int32))
+    c = gen.binary(ROWS_ODD, uniq=900, null_density=0.3, maxlen=12, seed=78)
+    bits = np.unpackbits(c["validity"], bitorder="little")[:ROWS_ODD].copy()
+    bits[:7] = 0                        # row 0 is null: its slot's bytes are interned all the same (binary/dict.rs:55-93)
+    bits[200_000:260_000] = 0           # sections without a keyed row
+    c["validity"] = np.packbits(bits, bitorder="little")
+    out["utf8_leading_nulls"] = c
+    c = gen.binary(ROWS, uniq=4000, maxlen=9, seed=79)                                              # Dict whose indices come in runs (nested RLE)
+    vocab_idx = np.repeat(rng.integers(0, 4000, ROWS // 50 + 1), 50)[:ROWS]
+    voc = [("k%d" % i).encode() for i in range(4000)]
+    lens = np.array([len(v) for v in voc], np.int64)[vocab_idx]
+    offs = np.zeros(ROWS + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    out["utf8_runs"] = dict(c, values=np.frombuffer(b"".join(voc[i] for i in vocab_idx), np.uint8).copy(), offsets=offs.astype(np.int32))
+    return out
+
+
+BIN_CASES = binary_cases()
+
+
+@pytest.mark.parametrize("name", sorted(BIN_CASES))
+def test_one_page_binary_columns_match_the_oracle(gpu_ctx, name):
+    """one-page ADAPTIVE Utf8 columns (Dict pages of 600 k+ rows, low cardinality, sparse, unique),
+    bytes == the oracle's, through the section-parallel binary selector and Dict writer"""
+    col = BIN_CASES[name]
+    assert col["rows"] >= 1 << 18
+    for opt in (dict(ratio=2.0, forbidden=()), dict(ratio=1.2, default_compression=S.LZ4, forbidden=())):
+        sel_check(gpu_ctx, col, **opt)
+    dec_check(gpu_ctx, col, ratio=2.0, forbidden=())
+
+
+def test_one_page_binary_dict_falls_back_when_the_string_check_fails(gpu_ctx):
+    """SB_WRITE_DEBUG_VERIFY_FAIL: the hash-formed dictionary of a long page is declared bad, the exact builder writes the page"""
+    from tests.test_gpu_select import gpu_encode
+    col = BIN_CASES["utf8_zipf"]
+    want_pages, want_metas = gen.oracle_write(col, ratio=2.0, forbidden=())
+    enc = gpu_encode(gpu_ctx, col, ratio=2.0, forbidden=(), debug_verify_fail=True)
+    assert np.array_equal(enc.metas_array(), want_metas)
+    assert np.array_equal(enc.pages_numpy(), want_pages)

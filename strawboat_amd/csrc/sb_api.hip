@@ -211,6 +211,7 @@ void sb_ctx_destroy(sb_ctx* ctx) {
     if (ctx->zb_stats) (void)hipFree(ctx->zb_stats);
     if (ctx->zb_blocks.p) (void)hipFree(ctx->zb_blocks.p);
     if (ctx->zb_lit.p) (void)hipFree(ctx->zb_lit.p);
+    if (ctx->lzg_pool.p) (void)hipFree(ctx->lzg_pool.p);
     if (ctx->zb_rec.p) (void)hipFree(ctx->zb_rec.p);
     if (ctx->enc_plan.pages.p) (void)hipFree(ctx->enc_plan.pages.p);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
@@ -648,6 +649,32 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     // more (64 KiB pages of incompressible values — the reference's bench shape — stay with the one-wave copy path)
     const uint32_t big_min = 2 * P >= 4096 ? 2 * LZ4_BIG_MIN : LZ4_BIG_MIN / 4;
     a.lz4_big_min = max_page_len >= big_min ? big_min : 0xFFFFFFFFu;
+    // LZ4 blocks of megabytes (a one-page column): block-parallel (sb_lz4_giant.h) — tables and entries in a pool of their own
+    memset(&a.lzg, 0, sizeof a.lzg);
+    a.lzg_chunks = a.lzg_wins = a.lzg_rounds = 0;
+    if (!sizes_only && max_page_len >= LZG_MIN) {
+        uint64_t out_total = 0, out_max = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t o = std::max<uint64_t>(cols[i].values_capacity, (cols[i].rows + 1) * 8);
+            out_total += o + (is_binary_t(cols[i].physical_type) ? (cols[i].rows + 1) * 8 : 0);
+            out_max = std::max(out_max, o);
+        }
+        const uint64_t pool = pages_bytes * 16 + pages_bytes / 512 + LZG_JOBS * (uint64_t)LZG_LITS * 16 + out_total * 4 + out_total / 2048 + (LZG_JOBS + 1) * (6 * 256 + (uint64_t)LZG_CH * 8 + 4096) +
+                              LZG_JOBS * sizeof(LzgJob) + 1024;
+        if (ensure(ctx, ctx->lzg_pool, pool)) {
+            a.lzg.jobs = (LzgJob*)ctx->lzg_pool.p;
+            a.lzg.njobs = (uint32_t*)(ctx->lzg_pool.p + LZG_JOBS * sizeof(LzgJob));
+            const uint64_t head = (LZG_JOBS * sizeof(LzgJob) + 64 + 255) & ~255ull;
+            a.lzg.pool = ctx->lzg_pool.p + head;
+            a.lzg.pool_bytes = pool - head;
+            a.lzg.st = ctx->d_status;
+            a.lzg_chunks = (uint32_t)((max_page_len + LZG_CH - 1) / LZG_CH);
+            a.lzg_wins = (uint32_t)std::min<uint64_t>((out_max + LZG_WIN - 1) / LZG_WIN, 0x7FFFFFFFu);
+            uint32_t bits = 1;
+            while ((1ull << bits) < out_max + 1 && bits < 32) bits++;
+            a.lzg_rounds = bits / 2 + 2;   // (a launch of k_lzg_jump is two rounds)
+        }
+    }
     a.rle_parts = rle_parts;
     a.rle_sums = rle_parts > 1 ? (uint64_t*)(tb + o_rle) : nullptr;
     a.zs_hdr = a.zs_segs = nullptr;

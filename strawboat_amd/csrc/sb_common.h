@@ -187,6 +187,37 @@ struct ZbPools {
 constexpr uint32_t INFLATE_POOL = 2048;          // waves
 constexpr uint32_t ZREC_PER_WAVE = 128 * 1024;   // pre-decoded Zstd sequence records (8 bytes each) per pool wave
 
+// one LZ4 block of megabytes decoded by the whole chip (sb_lz4_giant.h)
+constexpr uint32_t LZG_MIN = 2u << 20;     // compressed bytes
+constexpr uint32_t LZG_JOBS = 16;
+constexpr uint32_t LZG_CH = 4096;          // positions per chunk
+constexpr uint32_t LZG_GROUP = 64;         // chunks per group
+constexpr uint32_t LZG_WIN = 8192;         // entries per window of k_lzg_jump
+constexpr uint32_t LZG_LITS = 4096, LZG_LIT_MIN = 32768;
+struct LzgJob {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint32_t n, out_len, page, nchunks, ngroups, nwin;
+    uint32_t err, left;     // first error (0: none); windows with unresolved entries
+    uint32_t queue, slot;   // where the job came from
+    uint32_t* eo;           // [n][2]: exit of the chunk from the position, output bytes up to there
+    uint32_t* gtab;         // [n][2]: exit of the GROUP from the position, output bytes up to there (k_lzg_groups)
+    uint32_t* gent;         // [ngroups][2]: the chain's entry position / output position (LZG_NONE: the chain skips the group)
+    uint32_t* cent;         // [nchunks][2]
+    uint32_t* ent;          // [out_len] entries
+    uint32_t* wdone;        // [nwin]
+    uint32_t* lits;         // [LZG_LITS][4]: literal runs of >= LZG_LIT_MIN bytes (source position, output position, length), copied by all workgroups
+    uint32_t nlits, pad0;
+};
+struct LzgArgs {
+    LzgJob* jobs;           // LZG_JOBS
+    uint32_t* njobs;
+    uint8_t* pool;
+    uint64_t pool_bytes;
+    Status* st;
+};
+
+
 struct DecodeArgs {
     const ColDesc* cols;
     const PageTask* tasks;
@@ -226,6 +257,9 @@ struct DecodeArgs {
     // long RLE pages (a call with few pages of >= 2^18 rows): `rle_parts` workgroups per page, rle_sums[page * parts + part]
     uint32_t rle_parts;
     uint64_t* rle_sums;
+    // LZ4 blocks of LZG_MIN compressed bytes and more, block-parallel (sb_lz4_giant.h); lzg.jobs == nullptr: not in this call
+    LzgArgs lzg;
+    uint32_t lzg_chunks, lzg_wins, lzg_rounds;   // grid sizes: the longest page / the largest output of the call
 };
 constexpr uint32_t LZ4_BIG_MIN = 64u << 10;
 

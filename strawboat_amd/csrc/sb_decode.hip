@@ -23,6 +23,7 @@
 #include "sb_zstd_blocks.h"
 #include "sb_lz4.h"
 #include "sb_lz4_big.h"
+#include "sb_lz4_giant.h"
 
 namespace sb {
 
@@ -2834,6 +2835,37 @@ static void launch_zb(sb_ctx* ctx, const DecodeArgs& a) {
 void debug_lzx_timers(uint64_t* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lzx_t), 8 * sizeof(uint64_t)); }
 #endif
 
+// LZ4 blocks of LZG_MIN compressed bytes and more of one queue, block-parallel (sb_lz4_giant.h)
+static void launch_lzg(sb_ctx* ctx, const DecodeArgs& a, InflateJob* q, const uint32_t* nq, uint32_t cap) {
+    if (!a.lzg.jobs || !a.lzg_chunks) return;
+    hipStream_t s = ctx->stream;
+    const LzgArgs g = a.lzg;
+    const uint32_t ngroups = (a.lzg_chunks + LZG_GROUP - 1) / LZG_GROUP;
+    {
+        KScope k(ctx, "k_lzg_exits");
+        k_lzg_pick<<<1, 256, 0, s>>>(g, q, nq, nullptr, nullptr, cap);
+        k_lzg_clear<<<dim3(64, LZG_JOBS), 256, 0, s>>>(g);
+        k_lzg_exits<<<dim3(a.lzg_chunks, LZG_JOBS), 256, 0, s>>>(g);
+    }
+    {
+        KScope k(ctx, "k_lzg_chain");
+        k_lzg_groups<<<dim3(ngroups, LZG_JOBS), 256, 0, s>>>(g);
+        k_lzg_chain<<<LZG_JOBS, 64, 0, s>>>(g);
+        k_lzg_cents<<<dim3(ngroups, LZG_JOBS), 64, 0, s>>>(g);
+    }
+    {
+        KScope k(ctx, "k_lzg_windows");
+        k_lzg_windows<<<dim3(a.lzg_chunks, LZG_JOBS), LB_T, 0, s>>>(g);
+        k_lzg_lits<<<dim3(512, LZG_JOBS), 256, 0, s>>>(g);
+    }
+    {
+        KScope k(ctx, "k_lzg_jump");
+        for (uint32_t r = 0; r < a.lzg_rounds; r++) k_lzg_jump<<<dim3(a.lzg_wins, LZG_JOBS), 256, 0, s>>>(g);
+    }
+    KScope k(ctx, "k_lzg_pack");
+    k_lzg_pack<<<dim3(std::min<uint32_t>(a.lzg_wins * 2 + 1, 4096u), LZG_JOBS), 256, 0, s>>>(g);
+}
+
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
@@ -2852,6 +2884,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k(ctx, "k_inflate_lz4");
         k_inflate_lz4<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
     }
+    launch_lzg(ctx, a, a.jobs_a, a.job_counts, a.job_cap_a);
     if (a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big");
         k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
@@ -2881,6 +2914,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         KScope k2(ctx, "k_inflate_lz4(values)");
         k_inflate_lz4<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
     }
+    if (any_binary) launch_lzg(ctx, a, a.jobs_b, a.job_counts + 1, a.job_cap_a);
     if (any_binary && a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big(values)");
         k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);

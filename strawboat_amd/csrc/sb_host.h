@@ -48,6 +48,7 @@ struct sb_ctx {
     std::string last_error;
     int32_t sticky = 0;  // first host-side error since the last synchronize
 
+    sb::DevBuf lzg_pool;   // sb_lz4_giant.h: tables and entries of LZ4 blocks of megabytes
     sb::DevBuf tables;   // ColDesc / PageTask / PageDesc / TileTask / jobs / counters
     sb::DevBuf scratch;  // per-page aux + inflate areas, encode slots
     sb::DevBuf staging;  // device staging for SB_MEM_HOST callers

@@ -145,6 +145,70 @@ __device__ __forceinline__ LbSeq lb_seq(RD rd, uint32_t i, uint32_t lim, uint32_
     return s;
 }
 
+// The same by a whole WAVE (all 64 lanes call it with the same arguments), for headers with thousands of length bytes: a
+// literal run of megabytes has one 255 per 255 bytes, and one lane reading them from HBM byte by byte is a chain of
+// dependent loads (4 ms per megabyte of literals).  Every lane looks at 16 bytes, a ballot finds the first byte that is
+// not 255.  `src` points at the token, `room` = bytes up to the block's end.
+__device__ inline LbSeq lb_seq_wave(const uint8_t* src, uint32_t room) {
+    const uint32_t lane = threadIdx.x & 63;
+    LbSeq s;
+    s.ll = s.lit = s.ml = s.off = s.end = 0;
+    s.kind = 3;
+    // length bytes from position j on: returns the sum, moves j behind the last one; false: they run into the block's end
+    auto ext = [&](uint32_t& j, uint32_t& acc) -> bool {
+        for (;;) {
+            const uint32_t p = j + 16 * lane;
+            uint32_t lead = 0;   // leading 255s among my 16 bytes (bytes beyond the block count as "not 255")
+            if (p + 16 <= room) {
+                const u32x4 v = ldu128(src + p);
+                const uint64_t a = ~((uint64_t)v.x | ((uint64_t)v.y << 32)), b = ~((uint64_t)v.z | ((uint64_t)v.w << 32));
+                lead = a ? (uint32_t)__builtin_ctzll(a) / 8 : (b ? 8 + (uint32_t)__builtin_ctzll(b) / 8 : 16u);
+            } else {
+                while (lead < 16 && p + lead < room && ldu8(src + p + lead) == 255) lead++;
+            }
+            const uint64_t full = __ballot(lead == 16);
+            if (full == ~0ull) {
+                if (acc > 0xF0000000u) return false;
+                acc += 255u * 1024u;
+                j += 1024;
+                continue;
+            }
+            const uint32_t f = (uint32_t)__builtin_ctzll(~full);
+            const uint32_t lf = rdlane(lead, f);
+            const uint32_t n255 = 16 * f + lf;
+            const uint32_t at = j + n255;   // the byte that ends the run
+            if (at >= room) return false;
+            if (acc > 0xF0000000u) return false;
+            acc += 255u * n255 + (uint32_t)ldu8(src + at);
+            j = at + 1;
+            return true;
+        }
+    };
+    if (room == 0) return s;
+    const uint32_t t = ldu8(src);
+    uint32_t j = 1, ll = t >> 4;
+    if (ll == 15 && !ext(j, ll)) return s;
+    s.ll = ll;
+    s.lit = j;
+    if (ll > room - j) return s;
+    j += ll;
+    if (j == room) {
+        s.kind = 1;
+        s.end = j;
+        return s;
+    }
+    if (j + 2 > room) return s;
+    s.off = (uint32_t)ldu8(src + j) | ((uint32_t)ldu8(src + j + 1) << 8);
+    j += 2;
+    uint32_t ml = t & 15;
+    if (ml == 15 && !ext(j, ml)) return s;
+    if (ml > 0xFFFFFF00u - 4) return s;
+    s.ml = ml + 4;
+    s.end = j;
+    s.kind = s.off ? 0u : 3u;
+    return s;
+}
+
 // The common shape of a sequence header, without loops: at most one extension byte per length, everything up to the
 // byte behind the match-length extension inside the staged input.  tok = in[i], b1 = in[i + 1]; `e` = position of the first
 // byte behind the offset.  Returns false when the general parser has to look (255 extension bytes, the last sequence,
@@ -169,11 +233,21 @@ __device__ __forceinline__ uint32_t wave_scan_max_dpp(uint32_t v) {
 }
 
 // One block by the workgroup (LB_T threads).  Returns 0 or an error code (uniform).
-__device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out_len, Lz4BigLds& L) {
+// GIANT (sb_lz4_giant.h): the workgroup takes the sequences that START in [c_begin, c_end) of a block whose chain of
+// sequence starts has been found block-wide — c_begin is on the chain, op_begin the output position of its sequence — and
+// writes one u32 ENTRY per output byte instead of bytes: 0x80000000 | byte, or the absolute output position the byte
+// copies when that lies in front of the window (the windows of other workgroups are not written yet: the entries are
+// resolved by pointer jumping over the whole block afterwards).  In the window's LDS entries such a byte is a ROOT like
+// a literal: 0x4000 | its window position.
+constexpr uint32_t LB_ROOT = 0x4000u;
+template <bool GIANT = false>
+__device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t out_len, Lz4BigLds& L, uint32_t c_begin = 0,
+                                         uint32_t c_end = 0, uint32_t op_begin = 0, uint32_t* ent32 = nullptr, uint32_t* lits = nullptr,
+                                         uint32_t* nlits = nullptr) {
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (n == 0) return out_len != 0 ? 100u : 0u;
-    uint32_t c0 = 0;   // input position of the next sequence
-    uint32_t op = 0;   // output bytes produced
+    uint32_t c0 = c_begin;   // input position of the next sequence
+    uint32_t op = op_begin;  // output bytes produced
     if (t == 0) L.err = 0;
     LBP_BEGIN
     for (;;) {
@@ -181,7 +255,7 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
         // ------------------------------------------------------------------ parse: the chunk that starts at c0
         const uint32_t room = n - c0;
         const uint32_t sl = min(LB_S, room);
-        const uint32_t npos = min(LB_CH, room);
+        const uint32_t npos = GIANT ? min(min(LB_CH, room), c_end - c0) : min(LB_CH, room);   // (GIANT: sequences from c_end on are the next workgroup's)
         __syncthreads();   // (the window entries of the round before are dead)
         for (uint32_t k = t * 16; k < sl; k += LB_T * 16) {
             if (c0 + k + 16 <= n) {
@@ -203,9 +277,10 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
         // length bytes and literals are not looked at: in a run of 255s every one of them would walk the whole run).
         const bool lone = sl > 1 && (L.in[0] >> 4) == 15 && L.in[1] == 255;   // (uniform)
         if (lone) {
-            if (t == 0) {
-                const LbSeq sq = lb_seq(rd_mix, 0, room, room);
-                if (sq.kind == 3) {
+            if (wv == 0) {   // (its length bytes may be thousands: the wave reads them 1 KiB at a time)
+                const LbSeq sq = lb_seq_wave(src + c0, room);
+                if (t != 0) {
+                } else if (sq.kind == 3) {
                     L.err = 101;
                 } else {
                     L.r_lit[0] = c0 + sq.lit;
@@ -401,8 +476,45 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
         if (lone) {   // its literals go straight from the input to the output; what is left of the record is its match
             const uint32_t ll = L.r_ll[0];
             if (ll > out_len - op) return 103;
-            uint8_t* d = dst + op;
             const uint8_t* g = src + L.r_lit[0];
+            if constexpr (GIANT) {
+                // a run of tens of kilobytes and more is listed for k_lzg_lits (every workgroup of the chip copies a share:
+                // one workgroup moving a 5 MB run entry by entry took 17 ms); shorter ones 16 bytes per thread and step
+                __syncthreads();
+                if (t == 0) {
+                    L.total = 0;
+                    if (ll >= LZG_LIT_MIN && lits) {
+                        const uint32_t at = atomicAdd(nlits, 1u);
+                        if (at < LZG_LITS) {
+                            lits[4 * at] = L.r_lit[0];
+                            lits[4 * at + 1] = op;
+                            lits[4 * at + 2] = ll;
+                            L.total = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (!L.total) {
+                    for (uint32_t k = t * 16; k < ll; k += LB_T * 16) {
+                        if (k + 16 <= ll) {
+                            const u32x4 v = ldu128(g + k);
+                            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                u32x4 o;
+                                o.x = 0x80000000u | (w[q] & 0xFFu);
+                                o.y = 0x80000000u | ((w[q] >> 8) & 0xFFu);
+                                o.z = 0x80000000u | ((w[q] >> 16) & 0xFFu);
+                                o.w = 0x80000000u | (w[q] >> 24);
+                                __builtin_memcpy(ent32 + (uint64_t)op + k + 4 * q, &o, 16);
+                            }
+                        } else {
+                            for (uint32_t b = k; b < ll; b++) ent32[(uint64_t)op + b] = 0x80000000u | (uint32_t)ldu8(g + b);
+                        }
+                    }
+                }
+            } else {
+            uint8_t* d = dst + op;
             uint32_t head = (uint32_t)((16 - ((uintptr_t)d & 15)) & 15);
             if (head > ll) head = ll;
             if (t < head) d[t] = ldu8(g + t);
@@ -410,6 +522,7 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
             for (uint32_t k = t; k < nvec; k += LB_T) stu128(d + head + 16 * (uint64_t)k, ldu128(g + head + 16 * (uint64_t)k));
             const uint32_t done = head + 16 * nvec;
             if (t < ll - done) d[done + t] = ldu8(g + done + t);
+            }
             wave_stores_visible();
             op += ll;
             __syncthreads();
@@ -542,6 +655,8 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
                         } else if (x[u] <= p) {
                             L.ent[p] = (uint16_t)(p - x[u]);
                             pend |= 1u << (k0 + u);
+                        } else if (GIANT) {
+                            L.ent[p] = (uint16_t)(LB_ROOT | p);   // a root: its source is another workgroup's window
                         } else {
                             gmask |= 1u << (k0 + u);   // (ent[p] keeps the record until the second pass)
                         }
@@ -587,7 +702,7 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
                     for (int u = 0; u < 4; u++) {
                         if (kq[u] < 32) {
                             L.ent[t + LB_T * kq[u]] = (uint16_t)ss[u];
-                            if (ss[u] & 0x8000u)
+                            if (ss[u] & (0x8000u | (GIANT ? LB_ROOT : 0u)))
                                 pend &= ~(1u << kq[u]);
                             else
                                 any = 1;
@@ -598,7 +713,26 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
             }
             LBP(8);
             // window -> HBM: 16-byte groups of the line frame of dst + w0
-            {
+            if constexpr (GIANT) {
+                // entries: a byte, or where the byte's root copies from (the root's record by a search over the round's records)
+                for (uint32_t pp = t; pp < wl; pp += LB_T) {
+                    const uint32_t e = L.ent[pp];
+                    uint32_t v;
+                    if (e & 0x8000u) {
+                        v = 0x80000000u | (e & 0xFFu);
+                    } else {
+                        const uint32_t sp = e & (LB_ROOT - 1), x = w0 + sp;
+                        uint32_t lo = 0, hi = nrec;   // largest r with r_out[r] <= x
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (L.r_out[mid] <= x) lo = mid;
+                            else hi = mid;
+                        }
+                        v = x - L.r_off[lo];   // (< x: checked above, error 104)
+                    }
+                    ent32[(uint64_t)w0 + pp] = v;
+                }
+            } else {
                 const uint32_t a0 = (uint32_t)((uintptr_t)(dst + w0) & 15);
                 uint8_t* gb = dst + w0 - a0;
                 const uint32_t ng = (a0 + wl + 15) >> 4;
@@ -626,6 +760,7 @@ __device__ uint32_t lz4_inflate_block_wg(const uint8_t* src, uint32_t n, uint8_t
         op = o_end;
         c0 = next;
         if (fin) break;
+        if (GIANT && c0 >= c_end) return 0;   // the sequences behind belong to the next workgroup
         if (c0 >= n) return 105;   // the input ended without a literals-only last sequence
     }
     LBP_END;

@@ -491,3 +491,154 @@ def test_big_block_decoder_rejects_malformed(gpu_ctx, bad):
     pages, metas = lz4_page(good, _py_lz4(good).size)
     got = device_read(gpu_ctx, bytes_column(np.zeros(1, np.uint8)), pages, metas)
     assert np.array_equal(got.values_numpy(), _py_lz4(good))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# blocks of 2 MiB of compressed bytes and more: the block-parallel decoder (strawboat_amd/csrc/sb_lz4_giant.h).  The
+# reference's default paging makes a column ONE page and a Basic(LZ4) page is ONE block (src/compression/basic.rs:87-91).
+def _lz4_out_len(blk):
+    """output bytes of a well-formed block (headers only)"""
+    ip, out, n = 0, 0, len(blk)
+    while ip < n:
+        tok = blk[ip]; ip += 1
+        ll = tok >> 4
+        if ll == 15:
+            while True:
+                b = blk[ip]; ip += 1; ll += b
+                if b != 255:
+                    break
+        ip += ll; out += ll
+        if ip >= n:
+            break
+        ip += 2
+        ml = tok & 15
+        if ml == 15:
+            while True:
+                b = blk[ip]; ip += 1; ml += b
+                if b != 255:
+                    break
+        out += ml + 4
+    return out
+
+
+def _giant_blocks():
+    rng = np.random.default_rng(29)
+    lit = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    # what the reference's writer produces for one-page columns (liblz4's parse through the oracle)
+    yield "sorted_i64", bytes(S.block_compress(S.LZ4, np.cumsum(rng.integers(0, 1 << 20, 1_500_000)).astype(np.int64).view(np.uint8)))
+    words = [b"w%d" % i + b"x" * (i % 9) for i in range(3000)]
+    text = np.frombuffer(b" ".join(words[i] for i in rng.zipf(1.1, 2_200_000) % 3000), np.uint8)
+    yield "text", bytes(S.block_compress(S.LZ4, text))
+    yield "random", bytes(S.block_compress(S.LZ4, rng.integers(0, 256, 2_500_000, dtype=np.uint8)))   # ONE literal run: 9 800 length bytes of 255
+    yield "small_ints", bytes(S.block_compress(S.LZ4, rng.integers(0, 1000, 1_500_000).astype(np.uint32).view(np.uint8)))
+    v = np.zeros(40_000_000, np.uint8)
+    v[::1_000_003] = 7
+    yield "zeros", bytes(S.block_compress(S.LZ4, v)) + b""     # tiny: stays with the other decoders (a control)
+    # hand-built: three-byte sequences (more than 1 300 sequence starts per chunk of 4 KiB), chains of matches through
+    # EVERY window (offset 1 / 8 / 65 535), literal runs longer than the chunk tables cover, sequences across chunk borders
+    dense = [_seq(bytes(range(64)), 4, 64)]
+    for i in range(900_000):
+        dense.append(_seq(b"", 4 + (i % 15), 1 + (i * 13) % 64))
+    dense.append(_seq(b"final"))
+    yield "dense", b"".join(dense)
+    parts = [_seq(lit(70_000), 300_000, 1), _seq(lit(281), 4, 65_000), _seq(lit(5000), 40_000, 65_535)]
+    for i in range(260_000):
+        parts.append(_seq(lit(i % 11), 4 + (i % 40), 1 + (i * 31) % 60_000))
+        if i % 5000 == 0:
+            parts.append(_seq(lit(300 + i % 9000), 20_000 + i, 3 + i % 7))
+        if i % 40_000 == 7:
+            parts.append(_seq(lit(17_000 + i % 3000), 70_000, 8))          # headers of more than 64 length bytes
+    parts.append(_seq(lit(66_000), 5, 2))
+    parts.append(_seq(b"", 1_000_000, 65_535))
+    parts.append(_seq(b"abcde"))
+    yield "long_and_far", b"".join(parts)
+    parts = [_seq(lit(20), 8, 3)]
+    for i in range(9000):
+        parts.append(_seq(lit(255 + 15 + (i % 40)), 4 + 15 + (255 if i % 3 == 0 else i % 7), 1 + (i * 17) % 20))
+    parts.append(_seq(b"tail!"))
+    yield "ext_borders", b"".join(parts)
+
+
+GIANT = None
+
+
+def _giant():
+    global GIANT
+    if GIANT is None:
+        GIANT = dict(_giant_blocks())
+    return GIANT
+
+
+@pytest.mark.parametrize("name", ["sorted_i64", "text", "random", "small_ints", "zeros", "dense", "long_and_far", "ext_borders"])
+def test_giant_block_decoder(gpu_ctx, name):
+    blk = _giant()[name]
+    n_out = _lz4_out_len(blk)
+    want = S.block_decompress(S.LZ4, np.frombuffer(blk, np.uint8), n_out)
+    assert name == "zeros" or len(blk) >= 2 << 20, len(blk)
+    pages, metas = lz4_page(blk, n_out)
+    for shift in (0, 5):
+        pre = np.arange(shift, dtype=np.uint8)
+        if shift:
+            p0 = np.frombuffer(bytes([S.NONE]) + shift.to_bytes(4, "little") * 2 + bytes(pre), np.uint8)
+            pg = np.concatenate([p0, pages])
+            mt = np.concatenate([np.array([[9 + shift, shift]], np.uint64), metas])
+        else:
+            pg, mt = pages, metas
+        got = device_read(gpu_ctx, bytes_column(np.concatenate([pre, want])), pg, mt).values_numpy()
+        exp = np.concatenate([pre, want])
+        bad = np.flatnonzero(got != exp)
+        assert bad.size == 0, (name, shift, int(bad[0]), int(bad.size))
+
+
+def test_giant_blocks_next_to_others(gpu_ctx):
+    """three giant blocks, big ones and small ones in one call: every decoder takes its own entries of the queue"""
+    from strawboat_amd import read
+    G, B = _giant(), _big()
+    blks = [G["text"], B["dense"], G["dense"], _seq(b"abcd", 8, 2) + _seq(b"12345"), G["small_ints"], B["text"]]
+    cols, want = [], []
+    for blk in blks:
+        n_out = _lz4_out_len(blk)
+        pages, metas = lz4_page(blk, n_out)
+        cols.append(read.ColumnPages(S.T_U8, False, up(gpu_ctx, pages), metas))
+        want.append(S.block_decompress(S.LZ4, np.frombuffer(blk, np.uint8), n_out))
+    for _ in range(2):   # (the second call reuses the pool)
+        got = read.batch_read_columns(gpu_ctx, cols)
+        gpu_ctx.synchronize()
+        for g, w in zip(got, want):
+            assert np.array_equal(g.values_numpy(), w)
+
+
+@pytest.mark.parametrize("bad", ["offset0", "offset_too_far", "truncated", "short_output", "long_output", "no_last_literals",
+                                 "garbage_tail", "literal_overrun"])
+def test_giant_block_decoder_rejects_malformed(gpu_ctx, bad):
+    from strawboat_amd._native import NativeError
+    rng = np.random.default_rng(6)
+    lit = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    body = [_seq(lit(1 + i % 9), 4 + i % 30, 1 + (i * 7) % min(1 + i, 60_000)) for i in range(320_000)]
+    good = b"".join(body) + _seq(b"final")
+    assert len(good) >= 2 << 20
+    n = _lz4_out_len(good)
+    if bad == "offset0":
+        blk = b"".join(body[:190_000]) + _seq(b"ab", 9, 0) + b"".join(body[190_000:]) + _seq(b"final")
+        n += 11
+    elif bad == "offset_too_far":
+        blk = _seq(b"abcd", 8, 5) + good
+        n += 12
+    elif bad == "truncated":
+        blk = good[:-3]
+    elif bad == "short_output":
+        blk, n = good, n - 1
+    elif bad == "long_output":
+        blk, n = good, n + 1
+    elif bad == "no_last_literals":
+        blk = b"".join(body)
+        n -= 5
+    elif bad == "garbage_tail":
+        blk = good + b"\x00\x00\x00"
+    else:
+        blk = b"".join(body) + bytes([0xF0, 255, 255, 3]) + b"xy"
+    pages, metas = lz4_page(blk, n)
+    with pytest.raises(NativeError):
+        device_read(gpu_ctx, bytes_column(np.zeros(n, np.uint8)), pages, metas)
+    # the context still works
+    test_giant_block_decoder(gpu_ctx, "ext_borders")

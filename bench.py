@@ -344,7 +344,7 @@ def direction_summary(U, pb, ms, kernels, encode):
     """GB/s of Arrow bytes, fraction of the HBM roofline reached by the direction's algorithmic bytes
     (A_enc = Arrow bytes read + page bytes written, A_dec = page bytes read + Arrow bytes written),
     and the kernel that dominates the direction"""
-    ks = {k: v for k, v in kernels.items() if k.startswith(("k_enc", "k_sel_", "k_rle_big")) == encode}
+    ks = {k: v for k, v in kernels.items() if k.startswith(("k_enc", "k_sel_", "k_rle_big", "k_dict_big", "k_freq_big", "k_nested_big")) == encode}
     tot = sum(v[1] for v in ks.values()) or 1.0
     top = max(ks.items(), key=lambda kv: kv[1][1]) if ks else (None, (0, 0.0))
     A = U + pb

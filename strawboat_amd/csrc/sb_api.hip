@@ -83,7 +83,7 @@ StageSlot* acquire_slot(sb_ctx* ctx, size_t need) {
     if (s.host)
         for (auto& p : ctx->pending) {
             if (p.host < s.host || p.host >= s.host + s.cap) continue;
-            const size_t nb = p.kind == Pending::READ_COL ? 8 : (size_t)(2 * p.n + 1) * 8;
+            const size_t nb = p.kind == Pending::READ_COL ? 8 : p.kind == Pending::ENC_HINT ? 128 : (size_t)(2 * p.n + 1) * 8;
             ctx->rescued.emplace_back(p.host, p.host + nb);
             p.host = ctx->rescued.back().data();
         }
@@ -316,6 +316,9 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) {
         ctx->kinds_seen |= ctx->h_status->kinds & KIND_ZSTD;
+        if (ctx->h_status->kinds & KIND_LZ4_GIANT) ctx->lzg_state = 1;
+        else if (ctx->lzg_long_pages && ctx->lzg_state == 1) ctx->lzg_state = 2;
+        ctx->lzg_long_pages = false;
         // (not sticky: what the calls since the last synchronize looked like decides the order of the next call's entropy kernels)
         if (ctx->h_status->kinds & KIND_ZSTD) ctx->zb_seq_long = (ctx->h_status->kinds & KIND_ZSEQ_LONG) != 0;
         // the device only ever sets bits: the word is cleared here so that it describes the calls of ONE interval (the host's
@@ -358,6 +361,11 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
             uint64_t v;
             memcpy(&v, p.host, 8);
             c->values_len = v;
+        } else if (p.kind == Pending::ENC_HINT) {
+            if (ctx->enc_plan.valid && ctx->enc_plan.key == p.n && rc == SB_OK) {
+                memcpy(ctx->enc_plan.last_counts, p.host, 128);
+                ctx->enc_plan.counts_valid = true;
+            }
         } else {
             sb_column_write* c = (sb_column_write*)p.user;
             const uint64_t* lens = (const uint64_t*)p.host;  // [n_pages lengths][n_pages num_values][total]
@@ -435,7 +443,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     if (n == 0) return SB_OK;
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    uint64_t P = 0, T = 0, max_page_len = 0, max_page_rows = 0;
+    uint64_t P = 0, T = 0, max_page_len = 0, max_page_rows = 0, lzg_pages = 0;
     bool any_binary = false, any_prim = false;
     for (uint64_t i = 0; i < n; i++) {
         sb_column_read& c = cols[i];
@@ -447,6 +455,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             rows += c.metas[p].num_values;
             T += (c.metas[p].num_values + TILE_ROWS - 1) / TILE_ROWS;
             max_page_len = std::max<uint64_t>(max_page_len, c.metas[p].length);
+            if (c.metas[p].length >= LZG_MIN) lzg_pages += is_binary_t(c.physical_type) ? 2 : 1;   // (blocks that may go block-parallel: sb_lz4_giant.h)
             max_page_rows = std::max<uint64_t>(max_page_rows, c.metas[p].num_values);
         }
         c.rows = rows;
@@ -651,7 +660,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     a.lz4_big_min = max_page_len >= big_min ? big_min : 0xFFFFFFFFu;
     // LZ4 blocks of megabytes (a one-page column): block-parallel (sb_lz4_giant.h) — tables and entries in a pool of their own
     memset(&a.lzg, 0, sizeof a.lzg);
-    a.lzg_chunks = a.lzg_wins = a.lzg_rounds = 0;
+    a.lzg_chunks = a.lzg_wins = a.lzg_rounds = a.lzg_jobs = 0;
     if (!sizes_only && max_page_len >= LZG_MIN) {
         uint64_t out_total = 0, out_max = 0;
         for (uint64_t i = 0; i < n; i++) {
@@ -669,10 +678,12 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
             a.lzg.pool_bytes = pool - head;
             a.lzg.st = ctx->d_status;
             a.lzg_chunks = (uint32_t)((max_page_len + LZG_CH - 1) / LZG_CH);
+            a.lzg_jobs = (uint32_t)std::min<uint64_t>(lzg_pages, LZG_JOBS);
+            ctx->lzg_long_pages = true;
             a.lzg_wins = (uint32_t)std::min<uint64_t>((out_max + LZG_WIN - 1) / LZG_WIN, 0x7FFFFFFFu);
             uint32_t bits = 1;
             while ((1ull << bits) < out_max + 1 && bits < 32) bits++;
-            a.lzg_rounds = bits / 2 + 2;   // (a launch of k_lzg_jump is two rounds)
+            a.lzg_rounds = bits / 4 + 2;   // (a launch of k_lzg_jump is LZG_PASSES passes; a chain halves per pass at least — in practice a launch or two)
         }
     }
     a.rle_parts = rle_parts;

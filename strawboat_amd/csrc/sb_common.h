@@ -111,6 +111,7 @@ struct Status {
     uint32_t kinds; // KIND_* bits of what the calls have met so far (never cleared: the host sizes later calls by it)
 };
 constexpr uint32_t KIND_ZSTD = 1u;   // a Zstd buffer was queued
+constexpr uint32_t KIND_LZ4_GIANT = 4u;   // an LZ4 block of >= LZG_MIN compressed bytes was queued (sb_lz4_giant.h is launched for contexts that meet them)
 constexpr uint32_t KIND_ZSEQ_LONG = 2u;   // a Zstd block of >= 8192 sequences was met (zb_hdr): the sequence chains are the long pole
 
 // one general-purpose block (LZ4 / Zstd / Snappy) to inflate: src -> dst
@@ -259,7 +260,7 @@ struct DecodeArgs {
     uint64_t* rle_sums;
     // LZ4 blocks of LZG_MIN compressed bytes and more, block-parallel (sb_lz4_giant.h); lzg.jobs == nullptr: not in this call
     LzgArgs lzg;
-    uint32_t lzg_chunks, lzg_wins, lzg_rounds;   // grid sizes: the longest page / the largest output of the call
+    uint32_t lzg_chunks, lzg_wins, lzg_rounds, lzg_jobs;   // grid sizes: the longest page / the largest output of the call / pages long enough
 };
 constexpr uint32_t LZ4_BIG_MIN = 64u << 10;
 

@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt,
     if (j >= n0 || j >= cap) return;
     {
         const InflateJob job = q[j];
+        if (job.codec == SB_CODEC_LZ4 && job.csize >= (2u << 20) && !(st->kinds & KIND_LZ4_GIANT)) atomicOr(&st->kinds, KIND_LZ4_GIANT);
         if ((job.codec & ~JOB_REL) != SB_CODEC_ZSTD) return;
         if (!(st->kinds & KIND_ZSTD)) atomicOr(&st->kinds, KIND_ZSTD);   // (the host sizes the block pipeline's pools for later calls)
         if (a.zs_segs && job.csize >= ZS_BIG) {   // a long buffer: listed for the scan kernels when there is room
@@ -2838,32 +2839,44 @@ void debug_lzx_timers(uint64_t* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMB
 // LZ4 blocks of LZG_MIN compressed bytes and more of one queue, block-parallel (sb_lz4_giant.h)
 static void launch_lzg(sb_ctx* ctx, const DecodeArgs& a, InflateJob* q, const uint32_t* nq, uint32_t cap) {
     if (!a.lzg.jobs || !a.lzg_chunks) return;
+    // Twenty launches over grids sized for the longest page cost a call without such blocks ~0.1 ms (a plain 1 M-row page
+    // is long enough to qualify), so a context launches them only once it has met an LZ4 block of megabytes: the first call
+    // with long pages looks (one host round trip, once per context), later calls go by what the last interval met
+    // (Status.kinds, read at every synchronize).
+    if (ctx->lzg_state == 2) return;
     hipStream_t s = ctx->stream;
     const LzgArgs g = a.lzg;
+    const uint32_t NJ = std::max<uint32_t>(1u, a.lzg_jobs);
     const uint32_t ngroups = (a.lzg_chunks + LZG_GROUP - 1) / LZG_GROUP;
     {
         KScope k(ctx, "k_lzg_exits");
         k_lzg_pick<<<1, 256, 0, s>>>(g, q, nq, nullptr, nullptr, cap);
-        k_lzg_clear<<<dim3(64, LZG_JOBS), 256, 0, s>>>(g);
-        k_lzg_exits<<<dim3(a.lzg_chunks, LZG_JOBS), 256, 0, s>>>(g);
+        if (ctx->lzg_state == 0) {
+            uint32_t nj = 0;
+            if (hipMemcpyAsync(&nj, g.njobs, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) nj = 1;
+            ctx->lzg_state = nj ? 1 : 2;
+            if (!nj) return;
+        }
+        k_lzg_clear<<<dim3(64, NJ), 256, 0, s>>>(g);
+        k_lzg_exits<<<dim3(a.lzg_chunks, NJ), 256, 0, s>>>(g);
     }
     {
         KScope k(ctx, "k_lzg_chain");
-        k_lzg_groups<<<dim3(ngroups, LZG_JOBS), 256, 0, s>>>(g);
-        k_lzg_chain<<<LZG_JOBS, 64, 0, s>>>(g);
-        k_lzg_cents<<<dim3(ngroups, LZG_JOBS), 64, 0, s>>>(g);
+        k_lzg_groups<<<dim3(ngroups, NJ), 256, 0, s>>>(g);
+        k_lzg_chain<<<NJ, 64, 0, s>>>(g);
+        k_lzg_cents<<<dim3(ngroups, NJ), 64, 0, s>>>(g);
     }
     {
         KScope k(ctx, "k_lzg_windows");
-        k_lzg_windows<<<dim3(a.lzg_chunks, LZG_JOBS), LB_T, 0, s>>>(g);
-        k_lzg_lits<<<dim3(512, LZG_JOBS), 256, 0, s>>>(g);
+        k_lzg_windows<<<dim3(a.lzg_chunks, NJ), LB_T, 0, s>>>(g);
+        k_lzg_lits<<<dim3(512, NJ), 256, 0, s>>>(g);
     }
     {
         KScope k(ctx, "k_lzg_jump");
-        for (uint32_t r = 0; r < a.lzg_rounds; r++) k_lzg_jump<<<dim3(a.lzg_wins, LZG_JOBS), 256, 0, s>>>(g);
+        for (uint32_t r = 0; r < a.lzg_rounds; r++) k_lzg_jump<<<dim3(a.lzg_wins, NJ), 256, 0, s>>>(g);
     }
     KScope k(ctx, "k_lzg_pack");
-    k_lzg_pack<<<dim3(std::min<uint32_t>(a.lzg_wins * 2 + 1, 4096u), LZG_JOBS), 256, 0, s>>>(g);
+    k_lzg_pack<<<dim3(std::min<uint32_t>(a.lzg_wins * 2 + 1, 4096u), NJ), 256, 0, s>>>(g);
 }
 
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {

@@ -5465,7 +5465,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
 
     // staging: [cols | result offsets | readback of the results | (plan miss) the page table]
     const size_t o_hres = upload_bytes;
-    const size_t o_hpages = align_up(o_hres + results_words * sizeof(uint64_t), 64);
+    const size_t o_hcounts = align_up(o_hres + results_words * sizeof(uint64_t), 64);   // codec counts of the call (ENC_HINT)
+    const size_t o_hpages = o_hcounts + 128;
     StageSlot* slot = acquire_slot(ctx, o_hpages + (hit ? 0 : P * sizeof(EncPage)) + 64);
     if (!slot) return ctx->fail(SB_ERR_EXTERNAL, "hipHostMalloc(staging) failed");
     EncCol* hc = (EncCol*)(slot->host + o_cols);
@@ -5473,6 +5474,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     uint64_t* hro = (uint64_t*)(slot->host + o_resoff);
     if (!hit) {
         plan.valid = false;
+        plan.counts_valid = false;
         if (!ensure(ctx, plan.pages, P * sizeof(EncPage) + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(page table) failed");
         plan.col_first.assign(n, 0);
         plan.col_pages.assign(n, 0);
@@ -5760,6 +5762,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     }
     // One wave of select + emit kernels over the table entries [aa.page_base, aa.page_base + P).
     // wave_adaptive: codecs are chosen on the device; wave_codec: the one codec otherwise (-1: several possible).
+    // (what the last call with this plan chose: see EncPlan.last_counts)
+    const bool big_hint = hit && plan.counts_valid && adaptive;
     auto run_wave = [&](const EncodeArgs& aa_in, bool wave_adaptive, int32_t wave_codec, bool nested) -> int32_t {
         EncodeArgs aa = aa_in;
         aa.use_counts = wave_adaptive && !nested ? 1u : 0u;
@@ -5838,7 +5842,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 SB_BIG_W(k_rle_big_done, pg, 64);
             }
 #undef SB_BIG_W
-            if (!((forb >> SB_CODEC_DICT) & 1)) {   // long Dict pages: sb_dict_big.h
+            if (!((forb >> SB_CODEC_DICT) & 1) && (!big_hint || plan.last_counts[SB_CODEC_DICT])) {   // long Dict pages: sb_dict_big.h
                 const dim3 gg(256, nbig), sg4(sg.x * DBIG_SPLIT, nbig);
                 const uint32_t vo = (uint32_t)P;
 #define SB_DBIG_W(KERNEL, GRID, THREADS)                                   \
@@ -6064,7 +6068,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const int32_t rc = run_wave(a, adaptive, host_codec, false);
         if (rc != SB_OK) return rc;
     }
-    if (freq_possible && adaptive) {
+    if (freq_possible && adaptive && (!big_hint || plan.last_counts[SB_CODEC_FREQ])) {
         // long pages that chose Freq: prepared container-parallel, their exceptions block (a virtual page) selected and
         // written section-parallel when it has VBIG_ROWS rows or more (sb_freq_big.h, sb_dict_big.h)
         const uint32_t vo = (uint32_t)P;
@@ -6168,6 +6172,16 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     uint8_t* hres = slot->host + o_hres;
     e = hipMemcpyAsync(hres, a.results, results_words * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return check_hip(ctx, e, "metas readback");
+    if (adaptive) {   // the pages per codec, for the next call with this plan
+        e = hipMemcpyAsync(slot->host + o_hcounts, a.codec_counts, 128, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return check_hip(ctx, e, "codec counts readback");
+        Pending pd;
+        pd.kind = Pending::ENC_HINT;
+        pd.user = nullptr;
+        pd.host = slot->host + o_hcounts;
+        pd.n = plan_key;
+        ctx->pending.push_back(pd);
+    }
     (void)hipEventRecord(slot->done, s);
     slot->in_flight = true;
     for (uint64_t i = 0; i < n; i++) {

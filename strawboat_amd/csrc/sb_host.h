@@ -23,7 +23,7 @@ struct StageSlot {
 };
 
 struct Pending {  // results to hand back to the caller's structs at synchronize
-    enum Kind { READ_COL, WRITE_COL } kind;
+    enum Kind { READ_COL, WRITE_COL, ENC_HINT } kind;   // ENC_HINT: the codec counts of a write call (n = the plan's key), 32 words
     void* user;            // sb_column_read* / sb_column_write*
     const uint8_t* host;   // where the readback lands (pinned)
     uint64_t n;            // WRITE_COL: number of pages
@@ -48,6 +48,8 @@ struct sb_ctx {
     std::string last_error;
     int32_t sticky = 0;  // first host-side error since the last synchronize
 
+    int lzg_state = 0;        // sb_lz4_giant.h: 0 = not known yet, 1 = this context meets LZ4 blocks of megabytes, 2 = it does not
+    bool lzg_long_pages = false;   // a call since the last synchronize had pages long enough
     sb::DevBuf lzg_pool;   // sb_lz4_giant.h: tables and entries of LZ4 blocks of megabytes
     sb::DevBuf tables;   // ColDesc / PageTask / PageDesc / TileTask / jobs / counters
     sb::DevBuf scratch;  // per-page aux + inflate areas, encode slots
@@ -154,6 +156,11 @@ struct sb_ctx {
         std::vector<uint32_t> bigw[5];          // by log2(width): 1-, 2-, 4-, 8-byte values; [4]: binary pages
         uint32_t big_secs[5] = {0, 0, 0, 0, 0};
         sb::DevBuf big;
+        // pages per codec the last completed call with this plan chose (read back with its results): calls whose long pages
+        // did not choose Dict / Freq skip the launches of sb_dict_big.h / sb_freq_big.h — a page that does after all is
+        // written by the one-workgroup kernels as before, so a wrong guess only costs time
+        uint32_t last_counts[32] = {0};
+        bool counts_valid = false;
     } enc_plan;
     std::vector<uint64_t> enc_plan_probe;   // the key words of the call at hand
     // side streams: kernels of a call that work on disjoint pages (the selector / emit chains of different column kinds, the

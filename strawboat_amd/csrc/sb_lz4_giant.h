@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(256) k_lzg_clear(LzgArgs g) {
 // longer header (a literal run / match of > 16 000 bytes: the chain walkers parse it, once), 3 = malformed.  In a run of
 // 255s every position is such a header: unbounded, each of them would walk the run.
 constexpr uint32_t LZG_EXT = 64;
+constexpr int LZG_PASSES = 12;   // passes of k_lzg_jump per launch
 template <class RD>
 __device__ __forceinline__ LbSeq lzg_seq(RD rd, uint32_t i, uint32_t room) {
     LbSeq s;
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(64) k_lzg_cents(LzgArgs g) {   // a wave per g
 }
 
 // ---------------------------------------------------------------------------------------------------- bytes
-__global__ void __launch_bounds__(LB_T, 2) k_lzg_windows(LzgArgs g) {
+__global__ void __launch_bounds__(LB_T, 4) k_lzg_windows(LzgArgs g) {
     __shared__ Lz4BigLds lds;
     if (blockIdx.y >= *g.njobs) return;
     LzgJob* jp = g.jobs + blockIdx.y;
@@ -482,7 +483,9 @@ __global__ void __launch_bounds__(256) k_lzg_jump(LzgArgs g) {
         const uint32_t p = threadIdx.x + 256 * k;
         v[k] = p < wl ? ent[p] : 0x80000000u;
     }
-    for (int it = 0; it < 2; it++) {
+    // (workgroups start in window order and a window's sources lie in earlier windows: by the time a window runs, most of what
+    // it points at is final — a few passes inside one launch do what a launch per pass needed fourteen of)
+    for (int it = 0; it < LZG_PASSES; it++) {
         uint32_t mine = 0;
         uint32_t s[EPT];
 #pragma unroll

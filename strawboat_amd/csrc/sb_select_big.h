@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
     // all CUs queue up in one L2 channel (3 M zipf rows: 1.6 ms for the pass)
     constexpr uint32_t LSLOTS = 4096, LCAP = 3072;
     __shared__ unsigned long long lseen[LSLOTS];
-    __shared__ uint32_t s_lcnt;
+    __shared__ uint32_t s_lcnt, s_use;
     uint32_t page;
     EncPage p;
     EncCol c;
@@ -656,7 +656,10 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
     uint32_t sent = 0;
     const bool bin = big_is_bin(c);
     for (uint32_t i = t; i < LSLOTS; i += WG) lseen[i] = EMPTY;
-    if (t == 0) s_lcnt = 0;
+    if (t == 0) {
+        s_lcnt = 0;
+        s_use = 1;
+    }
     for (uint64_t base = s0; base < s1; base += WG * 8) {
         __syncthreads();
         if (t == 0) s_stop = __hip_atomic_load(&bp->uq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit ? 1u : 0u;
@@ -664,7 +667,8 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
         if (s_stop) break;
         unsigned long long xu[8], cu[8];
         uint32_t hu[8];
-        uint32_t pend = 0, newc = 0, neww = 0;
+        uint32_t pend = 0, newc = 0, neww = 0, nhit = 0;
+        const bool use_lds = s_use != 0;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint64_t i = base + (uint64_t)u * WG + t;
@@ -678,10 +682,11 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
                     sent = 1;
                 } else {
                     // the first row of this section to meet a key looks it up in the page's table; the others know it is there
+                    // (once the section's table is full and hardly anything hits it — distinct values — it is left alone)
                     uint32_t lh = (uint32_t)((xu[u] * 0x9E3779B97F4A7C15ull) >> 44) & (LSLOTS - 1);
                     bool seen = false;
                     const bool room = s_lcnt < LCAP;   // (racy count: LSLOTS - LCAP slots of slack)
-                    for (uint32_t st = 0; st < 16; st++) {
+                    for (uint32_t st = 0; st < (use_lds ? 16u : 0u); st++) {
                         const unsigned long long cur = lseen[lh];
                         if (cur == xu[u]) {
                             seen = true;
@@ -702,6 +707,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
                         lh = (lh + 1) & (LSLOTS - 1);
                     }
                     if (!seen) pend |= 1u << u;
+                    else nhit++;
                 }
             }
         }
@@ -726,6 +732,10 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
                 if (cu[u] == xu[u]) pend &= ~(1u << u);
                 else hu[u] = (hu[u] + 1) & mask;
             }
+        }
+        if (use_lds && s_lcnt >= LCAP) {   // is the full table still worth its probes?
+            const uint32_t hits = wg_sum32(nhit, s4);
+            if (t == 0 && hits * 8 < WG * 8) s_use = 0;
         }
         const uint32_t tot = wg_sum32(newc, s4);
         if (t == 0 && tot) atomicAdd(&bp->uq, tot);

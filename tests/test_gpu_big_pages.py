@@ -323,3 +323,23 @@ def test_one_page_binary_dict_falls_back_when_the_string_check_fails(gpu_ctx):
     enc = gpu_encode(gpu_ctx, col, ratio=2.0, forbidden=(), debug_verify_fail=True)
     assert np.array_equal(enc.metas_array(), want_metas)
     assert np.array_equal(enc.pages_numpy(), want_pages)
+
+
+def test_launch_hints_never_change_the_bytes(gpu_ctx):
+    """a write call remembers which codecs the last call with the same plan chose and skips the long-page Dict / Freq
+    launches nobody needed; a column of the same shape that needs them after all is written by the one-workgroup kernels:
+    the same bytes either way.  Columns of one shape (plan) whose pages choose Dict, Freq, plain, Dict, Freq in turn."""
+    from tests.test_gpu_select import gpu_encode
+    rng = np.random.default_rng(123)
+    n = ROWS
+    sp = np.full(n, 1_000_000, np.int32)
+    m = rng.random(n) < 0.03
+    sp[m] = rng.integers(0, 1 << 30, int(m.sum()))
+    variants = [rng.integers(0, 400, n).astype(np.int32), sp, rng.integers(0, 1 << 30, n).astype(np.int32),
+                rng.integers(0, 300, n).astype(np.int32), sp[::-1].copy()]
+    for k, v in enumerate(variants + variants[:2]):
+        col = dict(ptype=S.T_I32, nullable=False, rows=n, values=v, validity=None, offsets=None)
+        want_pages, want_metas = gen.oracle_write(col, ratio=2.0, forbidden=())
+        enc = gpu_encode(gpu_ctx, col, ratio=2.0, forbidden=())
+        assert np.array_equal(enc.metas_array(), want_metas), k
+        assert np.array_equal(enc.pages_numpy(), want_pages), k

@@ -316,6 +316,11 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) {
         ctx->kinds_seen |= ctx->h_status->kinds & KIND_ZSTD;
+        // what the LAST interval's read calls met decides what the next ones launch: a context that read Zstd pages once and
+        // LZ4 / plain pages ever since stops paying for the block pipeline's launches (7 kernels, ~40 us of a 0.6 ms call)
+        if (ctx->h_status->kinds & KIND_ZSTD) ctx->zstd_recent = true;
+        else if (ctx->read_calls) ctx->zstd_recent = false;
+        ctx->read_calls = 0;
         if (ctx->h_status->kinds & KIND_LZ4_GIANT) ctx->lzg_state = 1;
         else if (ctx->lzg_long_pages && ctx->lzg_state == 1) ctx->lzg_state = 2;
         ctx->lzg_long_pages = false;
@@ -512,7 +517,8 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     const size_t o_vlen = off;
     off = align_up(off + n * sizeof(uint64_t), 64);
     // the block-parallel Zstd pipeline: frames + counters here, blocks / literals / records in pools of their own
-    const bool zb_on = ctx->zb_mode == 1 || (ctx->zb_mode == 2 && (ctx->kinds_seen & KIND_ZSTD));
+    const bool zb_on = ctx->zb_mode == 1 || (ctx->zb_mode == 2 && ctx->zstd_recent);
+    ctx->read_calls++;
     const size_t o_zb_counts = off;
     if (zb_on) off = align_up(off + 64, 64);
     const size_t o_zb_frames = off;
@@ -605,7 +611,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     if (!ensure(ctx, ctx->zlit, (size_t)INFLATE_POOL * (128 * 1024 + 64))) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(zlit) failed");
     // (the lane-per-frame record arena only for calls that can hold >= 4 x INFLATE_POOL frames of 16 KiB, and only in a
     // context that has met Zstd pages: LZ4 / plain / Dict-only readers never pay for it)
-    const bool zrec_wanted = pages_bytes >= (48ull << 20) && (ctx->zb_mode == 1 || (ctx->kinds_seen & KIND_ZSTD));
+    const bool zrec_wanted = pages_bytes >= (48ull << 20) && (ctx->zb_mode == 1 || ctx->zstd_recent);
     uint64_t zb_block_cap = 0, zb_lit_cap = 0, zb_rec_cap = 0;
     if (zb_on) {
         // blocks: libzstd's are 128 KiB of content (sub-blocks of a few KiB when it splits them); literals: at most the

@@ -63,6 +63,8 @@ struct sb_ctx {
     sb::DevBuf zb_blocks, zb_lit, zb_rec;
     unsigned long long* zb_stats = nullptr;   // device: sb_ctx_zstd_block_stats
     uint32_t kinds_seen = 0;
+    bool zstd_recent = false;   // the read calls of the last synchronize interval met a Zstd buffer
+    uint32_t read_calls = 0;     // read calls since the last synchronize
     bool zb_seq_long = false;    // the last Zstd calls held blocks of >= 8192 sequences: zb_seq is submitted before zb_lit
     int zb_mode = 2;             // 0 off, 1 always, 2 once Zstd has been seen
     uint32_t zb_wg_exec = 1;     // SB_ZSTD_BLOCKS_WG=0: frames of many short sequences through the wave executor too

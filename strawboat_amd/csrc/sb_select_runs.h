@@ -23,6 +23,9 @@
 // A chunk (4096 rows) with more than RUNS_CAP raw runs (runs shorter than ~6 rows on average) makes
 // the page FALL BACK to select_rle_page (k_enc_select_rle runs after this kernel and takes the pages
 // marked CODEC_PENDING): lane = run pays off only when there are runs.
+#ifndef SB_RUNS_DMA
+#define SB_RUNS_DMA 0
+#endif
 constexpr int32_t CODEC_PENDING = -100;
 constexpr uint32_t RUNS_CAP = 640;
 
@@ -113,10 +116,46 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
         vword = 0xFFFFFFFFu;
         if (t < (int)(CHUNK / 32) && (uint32_t)t * 32 < n && vv.bits) vword = bits32(vv.bits, vv.off + cb + (uint32_t)t * 32, vtotal);
     };
+#if SB_RUNS_DMA
+    // EXPERIMENT (scripts/micro/runs_dma.hip): the rows of chunk k + 1 travel HBM -> LDS with
+    // global_load_lds_dwordx4 while chunk k is worked on — no VGPRs are held for them — and are read out of the stage
+    // (8 x ds_read_b128 per thread, conflict-free: the stage is [wave][piece][lane] x 16 bytes, the layout the DMA writes)
+    // at the top of the next iteration.  One stage of CHUNK * W bytes (32 KB for 8-byte values) on top of the 32 KB key
+    // set: 2 workgroups per CU instead of 4.
+    __shared__ __attribute__((aligned(16))) uint8_t dma_stage[CHUNK * W];
+    constexpr int NV_DMA = K * W / 16;
+    auto dma_issue = [&](uint64_t cb) {
+        const uint8_t* g = vals + (cb + (uint64_t)t * K) * W;
+#pragma unroll
+        for (int u = 0; u < NV_DMA; u++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16 * u),
+                                             (__attribute__((address_space(3))) void*)(dma_stage + ((w * NV_DMA + u) * 64) * 16), 16, 0, 0);
+    };
+    if (N >= CHUNK) dma_issue(0);
+#endif
     STL(0);
     for (uint64_t cb = 0; cb < N; cb += CHUNK) {
         XTL(0);
+#if SB_RUNS_DMA
+        if (N - cb >= CHUNK) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): my pieces have landed
+            {
+                u32x4 q[NV_DMA];
+#pragma unroll
+                for (int u = 0; u < NV_DMA; u++) q[u] = *(const u32x4*)(dma_stage + ((w * NV_DMA + u) * 64 + lane) * 16);
+                __builtin_memcpy(v, q, K * W);
+            }
+            if (lane == 0) pv0 = getv(cb + (uint64_t)t * K > 0 ? cb + (uint64_t)t * K - 1 : 0);
+            vword = 0xFFFFFFFFu;
+            if (t < (int)(CHUNK / 32) && vv.bits) vword = bits32(vv.bits, vv.off + cb + (uint32_t)t * 32, vtotal);
+            // (a wave reads only what it wrote: no barrier between the read-out and the next issue)
+            if (N - (cb + CHUNK) >= CHUNK && cb + CHUNK < N) dma_issue(cb + CHUNK);
+        } else {
+            request(cb);
+        }
+#else
         request(cb);
+#endif
         const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
         const uint32_t r0 = (uint32_t)t * K;
         const uint32_t mine = r0 < n ? min((uint32_t)K, n - r0) : 0u;

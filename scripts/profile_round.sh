@@ -4,7 +4,7 @@
 # Usage (on the GPU box, from the repo root): scripts/profile_round.sh r03 ; then, per configuration,
 #   python scripts/summarize_rocpd.py gpurun_out/prof_r03 r03 <cfg> '<config json>'
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -21,11 +21,12 @@ run() {  # name, pmc (0/1), bench args...
 }
 run c2 1 --no-configs --no-cpu-baseline --steps 10
 run c1 1 --only c1 --no-cpu-baseline
-run c3 0 --only c3,c3_lz4 --no-cpu-baseline
-run c4 0 --only c4 --no-cpu-baseline
+run c3 1 --only c3,c3_lz4 --no-cpu-baseline
+run c4 1 --only c4 --no-cpu-baseline
 run c5 1 --only c5 --no-cpu-baseline
+run one_page 1 --only one_page --no-cpu-baseline
 find $OUT -name "*.db" -o -name "*.csv" | head -80 > $OUT/files.txt
-for cfg in c2 c1 c3 c4 c5; do
+for cfg in c2 c1 c3 c4 c5 one_page; do
     timeout 120 python $R/scripts/summarize_rocpd.py $OUT $TAG $cfg "{\"workload\": \"$cfg (bench.py, see profiles/${TAG}_${cfg}_stdout.txt)\"}" > $OUT/${cfg}_summary.txt 2>&1
     cp $OUT/${cfg}_stdout.txt $R/profiles/${TAG}_${cfg}_stdout.txt 2>/dev/null
 done

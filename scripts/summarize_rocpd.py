@@ -52,6 +52,9 @@ for k, v in sorted(res.items()):
     kern[k] = {"fetch_size_kb_raw": round(fsz, 1), "write_size_kb_raw": round(wsz, 1), "hbm_bytes_per_launch": int((2 * fsz + wsz) * 1024)}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as _bench  # noqa: E402  (kernel_source_sha: bench.py reports this file's traffic only for the sources it was collected for)
+if not kern:   # (no counter pass for this configuration: no file rather than an empty one)
+    print(cfg, "no PMC passes found: no pmc_traffic file written")
+    sys.exit(0)
 json.dump({"config": cfg_desc, "kernel_source_sha16": _bench.kernel_source_sha(),
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3 --pmc, separate passes)",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half for wide coalesced streams)",

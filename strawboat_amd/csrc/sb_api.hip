@@ -318,8 +318,13 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         ctx->kinds_seen |= ctx->h_status->kinds & KIND_ZSTD;
         // what the LAST interval's read calls met decides what the next ones launch: a context that read Zstd pages once and
         // LZ4 / plain pages ever since stops paying for the block pipeline's launches (7 kernels, ~40 us of a 0.6 ms call)
-        if (ctx->h_status->kinds & KIND_ZSTD) ctx->zstd_recent = true;
-        else if (ctx->read_calls) ctx->zstd_recent = false;
+        // (two read intervals in a row without one: a nested reader alternates level calls — no Zstd — and leaf calls)
+        if (ctx->h_status->kinds & KIND_ZSTD) {
+            ctx->zstd_recent = true;
+            ctx->zstd_idle = 0;
+        } else if (ctx->read_calls && ++ctx->zstd_idle >= 2) {
+            ctx->zstd_recent = false;
+        }
         ctx->read_calls = 0;
         if (ctx->h_status->kinds & KIND_LZ4_GIANT) ctx->lzg_state = 1;
         else if (ctx->lzg_long_pages && ctx->lzg_state == 1) ctx->lzg_state = 2;

@@ -65,6 +65,7 @@ struct sb_ctx {
     uint32_t kinds_seen = 0;
     bool zstd_recent = false;   // the read calls of the last synchronize interval met a Zstd buffer
     uint32_t read_calls = 0;     // read calls since the last synchronize
+    uint32_t zstd_idle = 0;      // read intervals in a row that met no Zstd buffer
     bool zb_seq_long = false;    // the last Zstd calls held blocks of >= 8192 sequences: zb_seq is submitted before zb_lit
     int zb_mode = 2;             // 0 off, 1 always, 2 once Zstd has been seen
     uint32_t zb_wg_exec = 1;     // SB_ZSTD_BLOCKS_WG=0: frames of many short sequences through the wave executor too

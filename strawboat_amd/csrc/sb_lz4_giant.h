@@ -489,8 +489,11 @@ __global__ void __launch_bounds__(256) k_lzg_jump(LzgArgs g) {
         uint32_t mine = 0;
         uint32_t s[EPT];
 #pragma unroll
-        for (uint32_t k = 0; k < EPT; k++)
-            s[k] = (v[k] & 0x80000000u) ? v[k] : __hip_atomic_load(j.ent + v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t k = 0; k < EPT; k++) {
+            // (a position is always in front of its entry: checked when the windows were written — the clamp only keeps a
+            // damaged table from reading outside the entries)
+            s[k] = (v[k] & 0x80000000u) ? v[k] : __hip_atomic_load(j.ent + min(v[k], j.out_len - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
         for (uint32_t k = 0; k < EPT; k++) {
             if (!(v[k] & 0x80000000u)) {

@@ -3434,7 +3434,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
     if constexpr (KIND < 0) {
         // long binary pages: the statistics over their row hashes section-parallel, the Dict pages among them too
         // (sb_select_big.h / sb_dict_big.h, launched after this kernel)
-        if (a.use_counts && !a.redo && a.page_base == 0 && page < a.n_pages && N >= SEL_BIG_ROWS && p.bigx_off && p.h64_off != ~0ull &&
+        if (a.use_counts && !a.redo && a.page_base == 0 && page < a.n_pages && N >= BIN_BIG_ROWS && p.bigx_off && p.h64_off != ~0ull &&
             a.pre_hashed) {
             if (threadIdx.x == 0) a.codecs[page] = CODEC_PENDING;
             return;
@@ -5349,7 +5349,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         const uint64_t np = c.page_rows ? c.n_pages_in : (c.rows + ps - 1) / ps;
         if (np > c.n_pages_capacity || !c.out_metas) return ctx->fail(SB_ERR_INVALID, "out_metas too small");
         // (long pages that may become Dict pages run their index arrays as virtual pages: sb_dict_big.h)
-        big_possible |= adaptive && c.rows >= SEL_BIG_ROWS;
+        big_possible |= adaptive && c.rows >= std::min<uint64_t>(SEL_BIG_ROWS, BIN_BIG_ROWS);
         if (!c.out_pages && c.physical_type != SB_TYPE_NULL) return ctx->fail(SB_ERR_INVALID, "out_pages is null");
         P += np;
         if (hit) continue;   // (the per-page arithmetic of this shape is in the plan)
@@ -5547,7 +5547,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 plan.bigw[k].push_back((uint32_t)pi);
                 plan.big_secs[k] = std::max(plan.big_secs[k], secs);
                 if (!((forb >> SB_CODEC_DICT) & 1) || freq_possible) p.bigx_off = 1;   // (placed with the aux areas below)
-            } else if (adaptive && bin && N >= SEL_BIG_ROWS && !((forb >> SB_CODEC_DICT) & 1)) {   // (row hashes exist: Dict is a candidate)
+            } else if (adaptive && bin && N >= BIN_BIG_ROWS && !((forb >> SB_CODEC_DICT) & 1)) {   // (row hashes exist: Dict is a candidate)
                 const uint32_t secs = (uint32_t)((N + big_sec_rows(N) - 1) / big_sec_rows(N));
                 plan.bigw[4].push_back((uint32_t)pi);
                 plan.big_secs[4] = std::max(plan.big_secs[4], secs);

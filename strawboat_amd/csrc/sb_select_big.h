@@ -21,6 +21,10 @@
 // for these pages; >= 12 bytes of slot per row against 16.5 KB per section of >= 16 384 rows).  integer/mod.rs:179-308,
 // double/mod.rs:178-307.
 constexpr uint64_t SEL_BIG_ROWS = 1ull << 18;
+#ifndef SB_BIN_BIG_ROWS
+#define SB_BIN_BIG_ROWS (1ull << 18)
+#endif
+constexpr uint64_t BIN_BIG_ROWS = SB_BIN_BIG_ROWS;   // binary pages of this many rows take the section-parallel selector / Dict writer
 constexpr uint32_t SEL_BIG_SECTIONS = 256;    // at most, per page
 constexpr uint32_t SEL_BIG_MIN_SEC = 16384;   // rows of a section: a power of two, at least this
 constexpr uint32_t BIG_COUNT_SPLIT = 1;       // workgroups per section in k_sel_big_count (measured, 12 M sorted rows: 1 -> 0.33 ms, 4 -> 0.40: the CAS traffic on the table bounds it, not the chains)
@@ -60,8 +64,11 @@ __host__ __device__ __forceinline__ uint64_t big_tab_slots(uint64_t N) {
     while (M < need) M <<= 1;
     return M;
 }
-__device__ __forceinline__ BigPage* big_page_rec(uint8_t* slot) { return (BigPage*)slot; }
-__device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { return (BigSec*)(slot + 256 + (uint64_t)s * BIG_SEC_STRIDE); }
+// (the slot of a binary page starts behind the column's value bytes before it — any byte; the records hold 8-byte words and
+// words that are the target of atomics, so they start at the next multiple of 16)
+__device__ __forceinline__ uint8_t* big_rec_base(uint8_t* slot) { return (uint8_t*)(((uintptr_t)slot + 15) & ~(uintptr_t)15); }
+__device__ __forceinline__ BigPage* big_page_rec(uint8_t* slot) { return (BigPage*)big_rec_base(slot); }
+__device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { return (BigSec*)(big_rec_base(slot) + 256 + (uint64_t)s * BIG_SEC_STRIDE); }
 
 // voff: 0 = the pages of the list; n_pages = their VIRTUAL pages (the u32 index array of a long Dict page, sb_dict_big.h),
 // whose table entries exist only once k_dict_big_idx has written them — the codec word says so
@@ -69,9 +76,9 @@ __device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { retu
 // themselves at their end (agent-scope CAS; the count beside it).  One workgroup uniting 184 sets of 500 keys took 0.27 ms.
 constexpr uint32_t BIG_UNION_SLOTS = 8192, BIG_UNION_PROBES = 32;
 __device__ __forceinline__ unsigned long long* big_union_tab(uint8_t* slot, uint32_t nsec) {
-    return (unsigned long long*)(slot + 256 + (uint64_t)nsec * BIG_SEC_STRIDE + 64);
+    return (unsigned long long*)(big_rec_base(slot) + 256 + (uint64_t)nsec * BIG_SEC_STRIDE + 64);
 }
-__device__ __forceinline__ uint32_t* big_union_cnt(uint8_t* slot, uint32_t nsec) { return (uint32_t*)(slot + 256 + (uint64_t)nsec * BIG_SEC_STRIDE); }
+__device__ __forceinline__ uint32_t* big_union_cnt(uint8_t* slot, uint32_t nsec) { return (uint32_t*)(big_rec_base(slot) + 256 + (uint64_t)nsec * BIG_SEC_STRIDE); }
 
 __device__ __forceinline__ bool big_page_of(const EncodeArgs& a, const uint32_t* big, int W, uint32_t* page, EncPage* p, EncCol* c, uint32_t voff = 0) {
     *page = big[blockIdx.y] + voff;

@@ -343,3 +343,16 @@ def test_launch_hints_never_change_the_bytes(gpu_ctx):
         enc = gpu_encode(gpu_ctx, col, ratio=2.0, forbidden=())
         assert np.array_equal(enc.metas_array(), want_metas), k
         assert np.array_equal(enc.pages_numpy(), want_pages), k
+
+
+@pytest.mark.parametrize("nulls", [None, 0.1])
+def test_several_long_binary_pages_per_column(gpu_ctx, nulls):
+    """a binary page's slot starts behind the column's value bytes before it — at ANY byte: the long-page selector's records
+    (8-byte words, targets of atomics) must not sit there unaligned.  Columns of four long pages each (the first page's slot
+    is aligned by construction, the others are not), two columns in one call."""
+    cols = [gen.binary(1_200_000, uniq=3000, zipf=1.2, maxlen=20, seed=5, null_density=nulls),
+            gen.binary(900_001, uniq=40_000, maxlen=11, seed=6, null_density=nulls, large=True)]
+    for col in cols:
+        for opt in (dict(ratio=2.0, max_page_size=300_000, forbidden=()), dict(ratio=1.2, max_page_size=262_144, default_compression=S.LZ4, forbidden=())):
+            sel_check(gpu_ctx, col, **opt)
+        dec_check(gpu_ctx, col, ratio=2.0, max_page_size=300_000, forbidden=())

@@ -326,3 +326,50 @@ def test_batch_objects_run_repeatedly(gpu_ctx):
         for a in arrs:
             a.leaf.values.zero_()
             a.offsets[0].zero_()
+
+
+@pytest.mark.parametrize("what", ["lowcard_i64", "sparse_i32", "utf8", "runs_f64"])
+def test_long_leaf_pages_adaptive(gpu_ctx, what):
+    """a nested array written without max_page_size: its leaf pages hold hundreds of thousands of slots and go through the
+    section-parallel selector and the long-page Dict / Freq / RLE writers (sb_select_big.h, sb_dict_big.h, sb_freq_big.h)
+    behind their level sections; bytes == the oracle's, and the pages read back"""
+    from strawboat_amd import WriteOptions, nested
+    from strawboat_amd.read import ColumnPages
+    from strawboat_amd.write import DeviceColumn
+    levels, rows = make_nested("list_struct", 700_000, 21)
+    leaf = levels[-1]
+    n = leaf["length"]
+    assert n >= 2 * (1 << 18) + 40_000, n
+    rng = np.random.default_rng(8)
+    offs = None
+    if what == "lowcard_i64":
+        ptype, values = S.T_I64, rng.integers(0, 300, n).astype(np.int64) * 1_000_003
+    elif what == "sparse_i32":
+        ptype, values = S.T_I32, np.where(rng.random(n) < 0.02, rng.integers(0, 1 << 30, n), 1_000_000).astype(np.int32)
+    elif what == "runs_f64":
+        ptype, values = S.T_F64, np.repeat(rng.integers(0, 50, n // 40 + 1), 40)[:n].astype(np.float64)
+    else:
+        ptype = S.T_BIN32
+        col = gen.binary(n, uniq=2000, zipf=1.2, maxlen=16, seed=3)
+        values, offs = col["values"], col["offsets"]
+    page_rows = 350_000   # two pages: the second one's leaf slots start in the middle of the buffers
+    want_pages, want_metas = _oracle_nested_pages(levels, ptype, values, offs, rows, page_rows, ratio=2.0, forbidden=())
+    dcol = DeviceColumn(ptype, False, n, up(gpu_ctx, values), up(gpu_ctx, leaf.get("validity")), up(gpu_ctx, offs))
+    enc = nested.write_nested(gpu_ctx, device_levels(gpu_ctx, levels), dcol,
+                              WriteOptions(max_page_size=page_rows, default_compress_ratio=2.0, forbidden_compressions=[], lz4_exact=True))
+    assert np.array_equal(enc.metas_array(), want_metas)
+    got = enc.pages_numpy()
+    assert got.size == want_pages.size and np.array_equal(got, want_pages), "first mismatch at %d" % int(np.argmax(got[:want_pages.size] != want_pages[:got.size]))
+    arr = nested.read_nested(gpu_ctx, ColumnPages(ptype, False, enc.pages[:enc.length].contiguous(), enc.metas_array()),
+                             [lv["kind"] for lv in levels], [bool(lv["is_optional"]) for lv in levels])
+    valid = np.unpackbits(np.asarray(leaf["validity"]), bitorder="little")[:n].astype(bool) if leaf.get("validity") is not None else np.ones(n, bool)
+    if offs is None:
+        gv = arr.leaf.values_numpy().view(values.dtype)[:n]
+        assert np.array_equal(gv[valid], values[valid])
+    else:   # (a null slot decodes to the string of the index before it: the valid slots are the input's)
+        go = arr.leaf.offsets_numpy().view(np.int32)[:n + 1].astype(np.int64)
+        gvals = arr.leaf.values_numpy()
+        o64 = offs.astype(np.int64)
+        assert np.array_equal((go[1:] - go[:-1])[valid], (o64[1:n + 1] - o64[:n])[valid])
+        for i in np.flatnonzero(valid)[::211]:
+            assert bytes(gvals[go[i]:go[i + 1]]) == bytes(values[o64[i]:o64[i + 1]]), i

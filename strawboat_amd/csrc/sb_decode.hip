@@ -2862,7 +2862,7 @@ static void launch_lzg(sb_ctx* ctx, const DecodeArgs& a, InflateJob* q, const ui
     }
     {
         KScope k(ctx, "k_lzg_chain");
-        k_lzg_groups<<<dim3(ngroups, NJ), 256, 0, s>>>(g);
+        k_lzg_groups<<<dim3(ngroups, NJ), LZG_GT, 0, s>>>(g);
         k_lzg_chain<<<NJ, 64, 0, s>>>(g);
         k_lzg_cents<<<dim3(ngroups, NJ), 64, 0, s>>>(g);
     }

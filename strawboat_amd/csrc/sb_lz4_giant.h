@@ -316,7 +316,8 @@ __device__ inline bool lzg_hop(const LzgJob& j, LzgJob* jp, uint32_t& pos, uint6
 // the group's; a position of chunk c whose chunk exit lies inside the group takes over what that exit position has (one
 // gather per position and pass, 64 dependent passes per group, all groups side by side).  A chain that enters a group
 // anywhere — long literal runs jump over chunks — leaves it with ONE lookup.
-__global__ void __launch_bounds__(256) k_lzg_groups(LzgArgs g) {
+constexpr uint32_t LZG_GT = 1024;   // threads of k_lzg_groups: a pass is a latency chain, four positions per thread
+__global__ void __launch_bounds__(LZG_GT) k_lzg_groups(LzgArgs g) {
     if (blockIdx.y >= *g.njobs) return;
     const LzgJob j = g.jobs[blockIdx.y];
     const uint32_t grp = blockIdx.x;
@@ -325,15 +326,15 @@ __global__ void __launch_bounds__(256) k_lzg_groups(LzgArgs g) {
     const uint64_t g1 = min((uint64_t)j.n, (uint64_t)clast * LZG_CH);
     for (uint32_t c = clast; c-- > cfirst;) {
         const uint64_t p0 = (uint64_t)c * LZG_CH;
-        uint32_t e[LZG_CH / 256], b[LZG_CH / 256], e2[LZG_CH / 256], b2[LZG_CH / 256];
+        uint32_t e[LZG_CH / LZG_GT], b[LZG_CH / LZG_GT], e2[LZG_CH / LZG_GT], b2[LZG_CH / LZG_GT];
 #pragma unroll
-        for (uint32_t k = 0; k < LZG_CH / 256; k++) {
-            const uint64_t p = p0 + threadIdx.x + 256 * k;
+        for (uint32_t k = 0; k < LZG_CH / LZG_GT; k++) {
+            const uint64_t p = p0 + threadIdx.x + LZG_GT * k;
             e[k] = p < j.n ? j.eo[2 * p] : LZG_STOP_BAD;
             b[k] = p < j.n ? j.eo[2 * p + 1] : 0u;
         }
 #pragma unroll
-        for (uint32_t k = 0; k < LZG_CH / 256; k++) {
+        for (uint32_t k = 0; k < LZG_CH / LZG_GT; k++) {
             const bool in = e[k] != LZG_STOP_BAD && !(e[k] & LZG_STOP_LONG) && e[k] < g1;   // (stops end the table: the walker takes single hops from there)
             e2[k] = in ? j.gtab[2 * (uint64_t)e[k]] : 0u;
             b2[k] = in ? j.gtab[2 * (uint64_t)e[k] + 1] : 0u;
@@ -351,8 +352,8 @@ __global__ void __launch_bounds__(256) k_lzg_groups(LzgArgs g) {
             }
         }
 #pragma unroll
-        for (uint32_t k = 0; k < LZG_CH / 256; k++) {
-            const uint64_t p = p0 + threadIdx.x + 256 * k;
+        for (uint32_t k = 0; k < LZG_CH / LZG_GT; k++) {
+            const uint64_t p = p0 + threadIdx.x + LZG_GT * k;
             if (p < j.n) {
                 j.gtab[2 * p] = e2[k];
                 j.gtab[2 * p + 1] = b2[k];

@@ -667,9 +667,12 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
         s_lcnt = 0;
         s_use = 1;
     }
+    uint32_t nbatch = 0;
     for (uint64_t base = s0; base < s1; base += WG * 8) {
+        // (the page's count is looked at before the first batch and every eighth; in between the add below tells)
         __syncthreads();
-        if (t == 0) s_stop = __hip_atomic_load(&bp->uq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit ? 1u : 0u;
+        if (t == 0 && (nbatch & 7) == 0) s_stop = __hip_atomic_load(&bp->uq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit ? 1u : 0u;
+        nbatch++;
         __syncthreads();
         if (s_stop) break;
         unsigned long long xu[8], cu[8];
@@ -745,7 +748,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
             if (t == 0 && hits * 8 < WG * 8) s_use = 0;
         }
         const uint32_t tot = wg_sum32(newc, s4);
-        if (t == 0 && tot) atomicAdd(&bp->uq, tot);
+        if (t == 0 && tot && atomicAdd(&bp->uq, tot) + tot > limit) s_stop = 1;
         if (bin) {   // (a batch is 2 048 rows of strings: their bytes fit 32 bits)
             const uint32_t wt = wg_sum32(neww, s4);
             if (t == 0 && wt) atomicAdd(&bp->tus, (unsigned long long)wt);

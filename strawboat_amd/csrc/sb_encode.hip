@@ -5592,6 +5592,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 while (M < 2 * N) M <<= 1;
                 p.aux_bytes = (M + 3 * N) * 4;
             }
+            // (a long page counts its distinct keys exactly in a table of 8-byte keys at the start of the aux area: sb_select_big.h)
+            if (p.aux_bytes && p.bigx_off && N >= std::min<uint64_t>(SEL_BIG_ROWS, BIN_BIG_ROWS))
+                p.aux_bytes = std::max<uint64_t>(p.aux_bytes, big_tab_slots(N) * 8);
             p.h64_off = ~0ull;
             if (bin && p.aux_bytes && N) p.h64_off = 0;   // (placed with the aux areas below)
             p.zst_off = ~0ull;

@@ -467,7 +467,7 @@ __device__ void big_decide_bin(const EncodeArgs& a, const EncCol& c, const EncPa
                 if ((double)bp.nulls / tuple_count >= 0.9) r = (double)(N - 1);
                 else if (bp.need_mc && (double)bp.mc / tuple_count >= 0.9) r = (double)(N - 1);   // (no need_mc: the vote rules a 90 % majority out)
             }
-        } else if (N >= 3 && bp.need_uq) {
+        } else if (N >= 3 && bp.need_uq && p.aux_bytes >= big_tab_slots(N) * 8) {
             const uint64_t uq = (uint64_t)bp.uq + bp.uq_sent;
             if (uq * 3 < N) {
                 uint64_t after = bp.tus + N * (uint64_t)(bits_needed(uq) / 8);
@@ -598,8 +598,8 @@ __global__ void __launch_bounds__(WG) k_sel_big_clear(EncodeArgs a, const uint32
     const EncCol c = get_col(a, p.col);
     if (c.width > 8) return;
     const BigPage* bp = big_page_rec(page_slot(a, c, p));
-    if (!bp->need_uq || !p.aux_bytes) return;
     const uint64_t M = big_tab_slots(p.rows);
+    if (!bp->need_uq || p.aux_bytes < M * 8) return;   // (the host sizes the aux area of a long page for this table)
     u32x4* tab = (u32x4*)(a.scratch + p.aux_off);   // (aux areas are 16-byte aligned)
     const u32x4 e = {SEL_EMPTY, SEL_EMPTY, SEL_EMPTY, SEL_EMPTY};
     for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < M / 2; i += (uint64_t)gridDim.x * WG) tab[i] = e;
@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_count(EncodeArgs a, const uin
     if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;
     uint8_t* slot = page_slot(a, c, p);
     BigPage* bp = big_page_rec(slot);
-    const bool need_uq = bp->need_uq && p.aux_bytes, need_mc = bp->need_mc;
+    const bool need_uq = bp->need_uq && p.aux_bytes >= big_tab_slots(p.rows) * 8, need_mc = bp->need_mc;
     if (!need_uq && !need_mc) return;
     // (BIG_COUNT_SPLIT workgroups per section: the probes are latency chains, the more of them in flight the better)
     const uint64_t N = p.rows, SR = big_sec_rows(N) / BIG_COUNT_SPLIT;
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const ui
     if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;   // (chosen by k_sel_big_merge already)
     const BigPage bp = *big_page_rec(page_slot(a, c, p));
     // without an aux area (cannot happen while Dict is a candidate) the count stays unknown: "more than the limit"
-    const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
+    const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes >= big_tab_slots(p.rows) * 8 ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
     if (big_is_bin(c)) big_decide_bin(a, c, p, page, bp);
     else big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
 }

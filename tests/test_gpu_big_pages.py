@@ -356,3 +356,15 @@ def test_several_long_binary_pages_per_column(gpu_ctx, nulls):
         for opt in (dict(ratio=2.0, max_page_size=300_000, forbidden=()), dict(ratio=1.2, max_page_size=262_144, default_compression=S.LZ4, forbidden=())):
             sel_check(gpu_ctx, col, **opt)
         dec_check(gpu_ctx, col, ratio=2.0, max_page_size=300_000, forbidden=())
+
+
+@pytest.mark.parametrize("rows", [262_144, 315_000, 393_217, 524_289])
+def test_exact_count_table_fits_its_area(gpu_ctx, rows):
+    """the exact distinct count of a long page works on a table of 8-byte keys in the page's aux area whose size is a power
+    of two that depends on the row count, the sections and the workgroups per section: row counts on both sides of the
+    rounding steps, keys that need the exact count (more than the section sets hold), Int64 and Utf8"""
+    col = gen.prim(S.T_I64, rows, uniq=rows // 5, seed=rows % 97)
+    sel_check(gpu_ctx, col, ratio=2.0, forbidden=())
+    col = gen.binary(rows, uniq=rows // 40, maxlen=12, seed=rows % 89, null_density=0.05)
+    sel_check(gpu_ctx, col, ratio=1.5, forbidden=())
+    dec_check(gpu_ctx, col, ratio=1.5, forbidden=())

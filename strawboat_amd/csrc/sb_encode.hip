@@ -4814,7 +4814,7 @@ __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
         const bool second = d.idx >> 31;
         const uint8_t* src = second ? b.src_b : b.src_a;
         const uint32_t n = second ? b.n_b : b.n_a;
-        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * LZC_CH, c1 = min(n, c0 + LZC_CH);
+        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * a.lzc_chunk, c1 = min(n, c0 + a.lzc_chunk);   // (LZC_CH, or less in a call with few chunks)
         uint8_t* slot = a.lzc_pool + (uint64_t)i * LZC_SLOT;
         uint32_t anchor = c0;
         wave_sync();
@@ -5022,14 +5022,14 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_stitch(EncodeArgs a) {
     const uint32_t part = blockIdx.y, parts = gridDim.y;
     const uint32_t s1 = zstd ? zstd_stitch_frame<false>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh, part, parts)
                         : snap ? zstd_stitch_frame<true>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh, part, parts)
-                             : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_a, b.n_a, pl.n_a, blk + 9, sh, part, parts);
+                             : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, a.lzc_chunk, b.src_a, b.n_a, pl.n_a, blk + 9, sh, part, parts);
     if (threadIdx.x == 0 && part == 0) put_hdr9(blk, codec, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
     uint64_t length = pos + 9 + s1;
     if (b.src_b) {
         uint8_t* b2 = blk + 9 + s1;
         const uint32_t s2 = zstd ? zstd_stitch_frame<false>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh, part, parts)
                             : snap ? zstd_stitch_frame<true>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh, part, parts)
-                                 : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, LZC_CH, b.src_b, b.n_b, pl.n_b, b2 + 9, sh, part, parts);
+                                 : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, a.lzc_chunk, b.src_b, b.n_b, pl.n_b, b2 + 9, sh, part, parts);
         if (threadIdx.x == 0 && part == 0) put_hdr9(b2, codec, s2, b.n_b);
         length += 9 + s2;
     }
@@ -5400,6 +5400,16 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         lz_chunk = ZPAR_CH_SMALL;
         lz_cap = lz_cap_small;
         lz_any = lz_any_small;
+    }
+    // the same for LZ4 / Snappy: a one-page column of 96 MB is 1 465 chunks of 64 KiB on 2 816 resident chunk waves — one
+    // round whose length is a chunk's (2.3 ms), and 2 930 chunks of 32 KiB are two rounds of half that; only with three
+    // or more chunks per resident wave does the kernel run at the chip's rate (the waves of a finished chunk are replaced)
+    if (!zs_possible && lz_possible && !hit && lz_any) {
+        while (lz_chunk > ZPAR_CH_SMALL && lz_cap * (LZC_CH / lz_chunk) < 3 * 2816) lz_chunk /= 2;
+        if (lz_chunk != LZC_CH) {
+            lz_cap = lz_cap_small;   // (an upper bound for 32 KiB too)
+            lz_any = lz_any_small;
+        }
     }
     if (!lz_any) lz_cap = 0;
     if (hit) {

@@ -192,8 +192,11 @@ class GpuHarness:
         npages = sum(e.n_pages for e in enc)
         wb, rb = write.WriteBatch(ctx, dc, opts, out=enc), read.ReadBatch(ctx, pages, out=dec)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        wb.enqueue()
-        rb.enqueue()
+        # warm-up: a context keeps eight pinned staging slots, each grown (hipHostMalloc, ~0.3 ms for the 4 MB of tables a
+        # 65 536-page batch uploads) the first time a call of this size lands on it — once per context and size, not per step
+        for _ in range(4):
+            wb.enqueue()
+            rb.enqueue()
         ctx.synchronize()
         with torch.cuda.stream(ctx.torch_stream):
             ev[0].record()

@@ -16,8 +16,8 @@ __device__ unsigned long long g_prof[32];
 using namespace sb;
 
 __global__ void __launch_bounds__(64) k_enc(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t* sizes) {
-    __shared__ Lz4EncLds<12, 13> lds;
-    const uint32_t sz = lz4_compress_wave_fast<12, 13>(src, n, dst + (size_t)blockIdx.x * cap, lds);
+    __shared__ Lz4EncLds<11, 13> lds;
+    const uint32_t sz = lz4_compress_wave_fast<11, 13>(src, n, dst + (size_t)blockIdx.x * cap, lds);
     if (threadIdx.x == 0) sizes[blockIdx.x] = sz;
 }
 __global__ void __launch_bounds__(64) k_dec(const uint8_t* comp, uint32_t cap, const uint32_t* sizes, uint8_t* out, uint32_t n, uint32_t* errs) {
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(64) k_zdec(const uint8_t* comp, uint32_t cap, 
     if (threadIdx.x == 0) errs[blockIdx.x] = wk.err ? (uint32_t)wk.err : (got == n ? 0u : 999u);
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
-static const char* ENC[] = {"fill", "probe+cand+ext", "select", "emit", "flush_out", "last", "", ""};
+static const char* ENC[] = {"fill", "probe+cand+ext", "select", "emit", "flush_out", "last", "sizes+scan", ""};
 static const char* DEC[] = {"refill", "parse", "walk", "literals", "records", "far", "groups", "flush", "big"};
 int main(int argc, char** argv) {
     if (argc < 2) return 1;
@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
             printf("encode: %u -> %u bytes, %d blocks, %.3f ms  (%.1f MB/s per wave, %.1f GB/s aggregate)\n", n, sz, blocks, ms, n / ms / 1e3, (double)n * blocks / ms / 1e6);
             unsigned long long tot = 0;
             for (int i = 0; i < 8; i++) tot += prof[i];
-            for (int i = 0; i < 6; i++) printf("   %-16s %12llu ticks %5.1f %%\n", ENC[i], prof[i], 100.0 * prof[i] / (tot ? tot : 1));
+            for (int i = 0; i < 7; i++) printf("   %-16s %12llu ticks %5.1f %%\n", ENC[i], prof[i], 100.0 * prof[i] / (tot ? tot : 1));
             printf("   steps %llu, sequences %llu, big-path steps %llu\n", prof[16], prof[17], prof[18]);
         }
     }

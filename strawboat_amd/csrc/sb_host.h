@@ -75,6 +75,8 @@ struct sb_ctx {
     static constexpr int NSLOTS = 8;
     sb::StageSlot slots[NSLOTS];
     int next_slot = 0;
+    size_t slot_cap_max = 0;                // largest staging request so far: a slot that grows, grows to this
+    std::vector<void*> stale_host;          // outgrown staging buffers, freed at the next synchronize (hipHostFree drains the device)
 
     std::vector<sb::Pending> pending;
     std::deque<std::vector<uint8_t>> rescued;  // readbacks moved out of a recycled staging slot (acquire_slot)

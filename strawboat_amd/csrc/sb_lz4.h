@@ -38,11 +38,19 @@
 #define LZP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); lzp_acc[i] += n_ - lzp_t; lzp_t = n_; } while (0)
 #define LZP_CNT(i, v) do { lzp_acc[i] += (v); } while (0)
 #define LZP_END do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 24; i_++) g_prof[i_] += lzp_acc[i_]; } while (0)
+#define LZP_RESET do { lzp_t = __builtin_readcyclecounter(); } while (0)
+#define MTP_START do { pt = __builtin_readcyclecounter(); } while (0)
+#define MTP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (prof) prof[i] += n_ - pt; pt = n_; } while (0)
+#define MTP_CNT(i, v) do { if (prof) prof[i] += (v); } while (0)
 #else
 #define LZP_BEGIN
 #define LZP(i)
 #define LZP_CNT(i, v)
 #define LZP_END
+#define LZP_RESET
+#define MTP_START
+#define MTP(i)
+#define MTP_CNT(i, v)
 #endif
 
 namespace sb {
@@ -882,7 +890,8 @@ struct LzMatcher {
     // results of next()
     uint64_t C = 0;
     uint32_t p = 0, mlen = 0, cand = 0, covered = 0;
-    unsigned long long* prof = nullptr;
+    unsigned long long* prof = nullptr;   // (SB_LZ4_PROFILE builds: the caller's phase accumulators)
+    unsigned long long pt = 0;
 
     __device__ LzMatcher(Lz4EncLds<HB, RB>& l, const uint8_t* s, uint32_t nn) : L(l), src(s), n(nn) {}
     __device__ void init() {
@@ -947,8 +956,11 @@ struct LzMatcher {
     // true: a step with chosen matches is ready; false: the chunk is exhausted (anchor = start of its trailing literals)
     __device__ bool next() {
         const uint32_t lane = threadIdx.x & 63;
+        MTP_START;
         while (base <= mflimit) {
             fill(base + LZE_AHEAD);
+            MTP(0);
+            MTP_CNT(16, 1);
             const uint32_t lo_valid = max(hi > R ? hi - R : 0, lo0);   // positions below are not in the ring
             p = base + lane * stride;
             // a probe needs its LZE_CAP + 16 bytes of look-ahead in the ring (a step spread wider probes only its front part)
@@ -1011,6 +1023,7 @@ struct LzMatcher {
                 }
             }
             const uint64_t mm = __ballot(mlen >= 4);
+            MTP(1);
             if (!mm) {
                 base += 64 * stride;
                 if (stride < 24) stride++;
@@ -1074,6 +1087,7 @@ struct LzMatcher {
                     covered = pl + ml_l;
                 }
             }
+            MTP(2);
             return true;
         }
         return false;
@@ -1117,12 +1131,16 @@ __device__ uint32_t lz4_compress_range(const uint8_t* src, uint32_t n, uint32_t 
     *tail_anchor = c0;
     if (n < 13 || c0 + 12 > n) return 0;   // LZ4_minLength = mflimit + 1: no match possible
     LzMatcher<HB, RB> mt(L, src, n);
+#ifdef SB_LZ4_PROFILE
+    mt.prof = lzp_acc;
+#endif
     mt.init();
     if (ALONE)
         mt.begin_alone(c0, min(c1 - 4, n - 12), min(c1, n - 5));
     else
         mt.begin_chunk(c0, n - 12, n - 5);
     while (mt.next()) {
+        LZP_RESET;
         const bool chosen = (mt.C >> lane) & 1;
         uint32_t lit_start_v = mt.anchor;
         {
@@ -1140,7 +1158,7 @@ __device__ uint32_t lz4_compress_range(const uint8_t* src, uint32_t n, uint32_t 
         const uint32_t incl_sz = wave_scan_dpp(sz);
         const uint32_t out_off_v = incl_sz - sz;
         const uint32_t run = rdlane(incl_sz, 63);
-        LZP(2);
+        LZP(6);
         LZP_CNT(17, __popcll(mt.C));
         if (big || run > LZE_OUT) LZP_CNT(18, 1);
         if (!big && run <= LZE_OUT) {
@@ -1174,6 +1192,7 @@ __device__ uint32_t lz4_compress_range(const uint8_t* src, uint32_t n, uint32_t 
             }
             on += run;
             wave_sync();
+            LZP(3);
         } else {
             // ---- one sequence at a time, straight to dst (long literal runs)
             flush_out();

@@ -129,6 +129,11 @@ constexpr uint32_t ZPAR_CH = 32768;      // a Zstd frame's blocks when they are 
 constexpr uint32_t ZPAR_CH_SMALL = 16384; // ... in calls with fewer pieces than chunk waves
 constexpr uint32_t ZPAR_WAVES = 2048;     // 8 per CU: what 20 KB of LDS per wave (and 221 VGPRs) keep resident; a larger pool runs a second, thin round
 constexpr uint32_t LZC_CH = 65536;                                         // chunk bytes (a multiple of 1024)
+// A block of LZC_LONG bytes and more is cut into LZC_CH_LONG-byte chunks: a one-page column of 96 MB is 1 465 chunks of 64 KiB on
+// 2 816 resident chunk waves — one round whose length is a chunk's (2.3 ms) — but 5 860 of 16 KiB, which keep the chip full
+// (1.6 ms).  A function of the BLOCK, not of the call: a page's bytes do not depend on what else the call writes.
+constexpr uint32_t LZC_LONG = 8u << 20, LZC_CH_LONG = 16384;
+__host__ __device__ __forceinline__ uint32_t lz4_chunk_bytes(uint64_t block_bytes) { return block_bytes >= LZC_LONG ? LZC_CH_LONG : 65536u; }
 constexpr uint32_t LZC_SLOT = (16 + LZC_CH + LZC_CH / 255 + 16 + 15) / 16 * 16;   // u32 size | u32 tail anchor | 8 pad | sequences
 struct LzChunkPlan { uint32_t base, n_a, n_b, pad; };   // chunks [base, base + n_a) = first block, then n_b of a binary page's values block
 struct LzChunkDesc { uint32_t page, idx; };             // idx: chunk of its block; bit 31: the values block
@@ -4630,6 +4635,8 @@ __device__ __forceinline__ LzBlocks lz4_page_blocks(const EncodeArgs& a, const E
     }
     return b;
 }
+// chunk bytes of a block of n bytes: the call's piece size (Zstd), or by the block's length (LZ4, Snappy)
+__device__ __forceinline__ uint32_t lzc_chunk_of(const EncodeArgs& a, uint32_t n) { return a.lzc_codec == SB_CODEC_ZSTD ? a.lzc_chunk : lz4_chunk_bytes(n); }
 // chunk by chunk (k_enc_lz4_plan / _chunks / _stitch) or as one block by one wave (k_enc_emit_lz4)?  A pure function of
 // the page, so that every kernel decides alike.
 __device__ __forceinline__ bool lz4_page_chunked(const EncodeArgs& a, int32_t bc, uint32_t page, const LzBlocks& b, uint64_t zst_off = ~0ull) {
@@ -4780,7 +4787,8 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
         }
     }
     if (blockIdx.y) return;
-    const uint32_t na = (b.n_a + a.lzc_chunk - 1) / a.lzc_chunk, nb = (b.n_b + a.lzc_chunk - 1) / a.lzc_chunk;
+    const uint32_t ch_a = lzc_chunk_of(a, b.n_a), ch_b = lzc_chunk_of(a, b.n_b);
+    const uint32_t na = (b.n_a + ch_a - 1) / ch_a, nb = (b.n_b + ch_b - 1) / ch_b;
     if (threadIdx.x == 0) {
         uint32_t base = atomicAdd(a.lzc_count, na + nb);
         if (base + na + nb > a.lzc_cap) {   // (offsets that run past values_len)
@@ -4814,7 +4822,8 @@ __global__ void __launch_bounds__(64) k_enc_lz4_chunks(EncodeArgs a) {
         const bool second = d.idx >> 31;
         const uint8_t* src = second ? b.src_b : b.src_a;
         const uint32_t n = second ? b.n_b : b.n_a;
-        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * a.lzc_chunk, c1 = min(n, c0 + a.lzc_chunk);   // (LZC_CH, or less in a call with few chunks)
+        const uint32_t ch = lz4_chunk_bytes(n);
+        const uint32_t c0 = (d.idx & 0x7FFFFFFFu) * ch, c1 = min(n, c0 + ch);
         uint8_t* slot = a.lzc_pool + (uint64_t)i * LZC_SLOT;
         uint32_t anchor = c0;
         wave_sync();
@@ -5022,14 +5031,14 @@ __global__ void __launch_bounds__(WG) k_enc_lz4_stitch(EncodeArgs a) {
     const uint32_t part = blockIdx.y, parts = gridDim.y;
     const uint32_t s1 = zstd ? zstd_stitch_frame<false>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh, part, parts)
                         : snap ? zstd_stitch_frame<true>(a, b.n_a, pl.base, pl.n_a, blk + 9, sh, part, parts)
-                             : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, a.lzc_chunk, b.src_a, b.n_a, pl.n_a, blk + 9, sh, part, parts);
+                             : lz4_stitch_block(a.lzc_pool + (uint64_t)pl.base * LZC_SLOT, LZC_SLOT, lz4_chunk_bytes(b.n_a), b.src_a, b.n_a, pl.n_a, blk + 9, sh, part, parts);
     if (threadIdx.x == 0 && part == 0) put_hdr9(blk, codec, s1, c.ptype == SB_TYPE_BOOLEAN ? (uint32_t)N : b.n_a);
     uint64_t length = pos + 9 + s1;
     if (b.src_b) {
         uint8_t* b2 = blk + 9 + s1;
         const uint32_t s2 = zstd ? zstd_stitch_frame<false>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh, part, parts)
                             : snap ? zstd_stitch_frame<true>(a, b.n_b, pl.base + pl.n_a, pl.n_b, b2 + 9, sh, part, parts)
-                                 : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, a.lzc_chunk, b.src_b, b.n_b, pl.n_b, b2 + 9, sh, part, parts);
+                                 : lz4_stitch_block(a.lzc_pool + (uint64_t)(pl.base + pl.n_a) * LZC_SLOT, LZC_SLOT, lz4_chunk_bytes(b.n_b), b.src_b, b.n_b, pl.n_b, b2 + 9, sh, part, parts);
         if (threadIdx.x == 0 && part == 0) put_hdr9(b2, codec, s2, b.n_b);
         length += 9 + s2;
     }
@@ -5381,13 +5390,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 const uint64_t N = c.page_rows ? c.page_rows[q] : std::min<uint64_t>(ps, c.rows - r);
                 r += N;
                 const uint64_t fb = first_block(N);
-                lz_cap += (fb + lz_chunk - 1) / lz_chunk;
+                const uint64_t ch = zs_possible ? lz_chunk : lz4_chunk_bytes(fb);
+                lz_cap += (fb + ch - 1) / ch;
                 lz_any |= fb > lz_chunk;
                 lz_cap_small += (fb + ZPAR_CH_SMALL - 1) / ZPAR_CH_SMALL;
                 lz_any_small |= fb > ZPAR_CH_SMALL;
             }
-            if (bin) {
-                lz_cap += c.values_len / lz_chunk + np + 1;
+            if (bin) {   // (a page's value bytes are not known here: LZC_LONG of them in one page need that many in the column)
+                lz_cap += c.values_len / (zs_possible ? lz_chunk : lz4_chunk_bytes(c.values_len)) + np + 1;
                 lz_any |= c.values_len > lz_chunk;
                 lz_cap_small += c.values_len / ZPAR_CH_SMALL + np + 1;
                 lz_any_small |= c.values_len > ZPAR_CH_SMALL;
@@ -5400,16 +5410,6 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         lz_chunk = ZPAR_CH_SMALL;
         lz_cap = lz_cap_small;
         lz_any = lz_any_small;
-    }
-    // the same for LZ4 / Snappy: a one-page column of 96 MB is 1 465 chunks of 64 KiB on 2 816 resident chunk waves — one
-    // round whose length is a chunk's (2.3 ms), and 2 930 chunks of 32 KiB are two rounds of half that; only with three
-    // or more chunks per resident wave does the kernel run at the chip's rate (the waves of a finished chunk are replaced)
-    if (!zs_possible && lz_possible && !hit && lz_any) {
-        while (lz_chunk > ZPAR_CH_SMALL && lz_cap * (LZC_CH / lz_chunk) < 3 * 2816) lz_chunk /= 2;
-        if (lz_chunk != LZC_CH) {
-            lz_cap = lz_cap_small;   // (an upper bound for 32 KiB too)
-            lz_any = lz_any_small;
-        }
     }
     if (!lz_any) lz_cap = 0;
     if (hit) {
@@ -5835,7 +5835,8 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             {
                 KScope kk(ctx, "k_sel_big_sec");
                 k_sel_big_init<<<dim3(4, nbig), WG, 0, st>>>(aa, list, 0u);
-                SB_BIG_W(k_sel_big_sec, sg, WG);
+                const dim3 sgp(sg.x * BIG_SEC_SPLIT, nbig);
+                SB_BIG_W(k_sel_big_sec, sgp, WG);
             }
             {
                 KScope kk(ctx, "k_sel_big_merge");
@@ -5894,9 +5895,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 {   // the index arrays as virtual pages of u32: selected ...
                     KScope kk(ctx, "k_sel_big(indices)");
                     k_sel_big_init<<<dim3(4, nbig), WG, 0, st>>>(aa, list, vo);
-                    k_sel_big_sec<4><<<sg, WG, 0, st>>>(aa, list, vo);
+                    k_sel_big_sec<4><<<dim3(sg.x * BIG_SEC_SPLIT, nbig), WG, 0, st>>>(aa, list, vo);
                     k_sel_big_merge<4><<<pg, WG, 0, st>>>(aa, list, vo);
-                    k_sel_big_count<4><<<sg, WG, 0, st>>>(aa, list, vo);
+                    k_sel_big_count<4><<<dim3(sg.x * BIG_COUNT_SPLIT, nbig), WG, 0, st>>>(aa, list, vo);   // (BIG_COUNT_SPLIT workgroups per section)
                     k_sel_big_decide<4><<<pg, WG, 0, st>>>(aa, list, vo);
                 }
                 {   // ... and written
@@ -6120,10 +6121,10 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             {
                 KScope kk(ctx, "k_sel_big(exceptions)");
                 k_sel_big_init<<<dim3(4, nbig), WG, 0, s>>>(a, list, vo);
-                SB_FBIG_W(k_sel_big_sec, sg, WG, vo);
+                SB_FBIG_W(k_sel_big_sec, dim3(sg.x * BIG_SEC_SPLIT, nbig), WG, vo);
                 SB_FBIG_W(k_sel_big_merge, pg, WG, vo);
                 k_sel_big_clear<<<sg, WG, 0, s>>>(a, list, vo);
-                SB_FBIG_W(k_sel_big_count, sg, WG, vo);
+                SB_FBIG_W(k_sel_big_count, dim3(sg.x * BIG_COUNT_SPLIT, nbig), WG, vo);
                 SB_FBIG_W(k_sel_big_decide, pg, WG, vo);
             }
             {

@@ -28,6 +28,7 @@ constexpr uint64_t BIN_BIG_ROWS = SB_BIN_BIG_ROWS;   // binary pages of this man
 constexpr uint32_t SEL_BIG_SECTIONS = 256;    // at most, per page
 constexpr uint32_t SEL_BIG_MIN_SEC = 16384;   // rows of a section: a power of two, at least this
 constexpr uint32_t BIG_COUNT_SPLIT = 4;       // workgroups per section in k_sel_big_count (12 M rows, round 5 with the LDS set in front: sorted / distinct 0.37 ms either way, 98 % one value 0.42 -> 0.13 ms)
+constexpr uint32_t BIG_SEC_SPLIT = 4;         // workgroups per section in k_sel_big_sec, a partial record each (12 M rows are 184 sections: fewer workgroups than CUs, each a chain of 16 chunk steps)
 constexpr uint32_t BIG_KCAP = SEL_LDS_SLOTS / 4;   // keys of an LDS set (KSLOTS / 2 of the page selectors)
 
 __host__ __device__ __forceinline__ uint64_t big_sec_rows(uint64_t N) {
@@ -35,7 +36,7 @@ __host__ __device__ __forceinline__ uint64_t big_sec_rows(uint64_t N) {
     while (r * SEL_BIG_SECTIONS < N) r <<= 1;
     return r;
 }
-struct BigSec {   // 64 bytes, followed by the section's keys (BIG_KCAP x u64)
+struct BigSec {   // 64 bytes: the record of the section's first part, the other parts' behind it (BIG_SEC_STRIDE bytes per section)
     uint32_t flags, nulls, vote_n, kcnt;   // flags: neq0 | unsorted << 1 | neg << 2; kcnt > BIG_KCAP: the set overflowed
     uint64_t tmax, vote_k;
     uint32_t ksent, pad[7];
@@ -68,7 +69,10 @@ __host__ __device__ __forceinline__ uint64_t big_tab_slots(uint64_t N) {
 // words that are the target of atomics, so they start at the next multiple of 16)
 __device__ __forceinline__ uint8_t* big_rec_base(uint8_t* slot) { return (uint8_t*)(((uintptr_t)slot + 15) & ~(uintptr_t)15); }
 __device__ __forceinline__ BigPage* big_page_rec(uint8_t* slot) { return (BigPage*)big_rec_base(slot); }
-__device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s) { return (BigSec*)(big_rec_base(slot) + 256 + (uint64_t)s * BIG_SEC_STRIDE); }
+__device__ __forceinline__ BigSec* big_sec_rec(uint8_t* slot, uint32_t s, uint32_t part = 0) {
+    return (BigSec*)(big_rec_base(slot) + 256 + (uint64_t)s * BIG_SEC_STRIDE + part * 64);
+}
+static_assert(BIG_SEC_SPLIT * 64 <= BIG_SEC_STRIDE && SEL_BIG_MIN_SEC % BIG_SEC_SPLIT == 0, "partial records of a section");
 
 // voff: 0 = the pages of the list; n_pages = their VIRTUAL pages (the u32 index array of a long Dict page, sb_dict_big.h),
 // whose table entries exist only once k_dict_big_idx has written them — the codec word says so
@@ -143,7 +147,8 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
     EncPage p;
     EncCol c;
     if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;
-    const uint64_t N = p.rows, SR = big_sec_rows(N);
+    // (blockIdx.x = section * BIG_SEC_SPLIT + part: a part is a section of its own to everything below but the record's place)
+    const uint64_t N = p.rows, SR_full = big_sec_rows(N), SR = SR_full / BIG_SEC_SPLIT;
     const uint64_t s0 = (uint64_t)blockIdx.x * SR;
     if (s0 >= N) return;
     const uint64_t s1 = min(N, s0 + SR);
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
         mx = s_vk[0];
     }
     uint8_t* slot = page_slot(a, c, p);
-    BigSec* rec = big_sec_rec(slot, blockIdx.x);
+    BigSec* rec = big_sec_rec(slot, blockIdx.x / BIG_SEC_SPLIT, blockIdx.x % BIG_SEC_SPLIT);
     const uint32_t kc = want_set ? s_kcnt : 0u;
     if (t == 0) {
         BigSec r;
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
         // One add per SECTION to the count (8 192 single adds to one word took 0.5 ms: same-address atomics queue up in L2), and
         // no count to stop at: a probe that meets BIG_UNION_PROBES occupied slots in a row calls the union too big — at a
         // quarter full that does not happen, and a false alarm only sends the page to the exact count (k_sel_big_count).
-        const uint32_t nsec = (uint32_t)((N + SR - 1) / SR);
+        const uint32_t nsec = (uint32_t)((N + SR_full - 1) / SR_full);
         unsigned long long* gt = big_union_tab(slot, nsec);
         uint32_t* gc = big_union_cnt(slot, nsec);
         uint32_t newc = 0;
@@ -511,7 +516,23 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     BigSec r;
     __builtin_memset(&r, 0, sizeof r);
     const bool has = (uint32_t)t < nsec;
-    if (has) r = *big_sec_rec(slot, (uint32_t)t);
+    if (has) {   // the records of the section's parts (the first one always exists)
+        r = *big_sec_rec(slot, (uint32_t)t);
+        for (uint32_t q = 1; q < BIG_SEC_SPLIT && (uint64_t)t * SR + q * (SR / BIG_SEC_SPLIT) < N; q++) {
+            const BigSec o = *big_sec_rec(slot, (uint32_t)t, q);
+            r.flags |= o.flags;
+            r.nulls += o.nulls;
+            r.ksent |= o.ksent;
+            r.kcnt = max(r.kcnt, o.kcnt);   // (only "some part's set overflowed" is read from it)
+            Val<W> x, y;
+            __builtin_memcpy(&x, &r.tmax, W);
+            __builtin_memcpy(&y, &o.tmax, W);
+            if (!is_float && int_lt<W>(x, y, nk)) r.tmax = o.tmax;
+            unsigned long long vk0 = r.vote_k;
+            vote_merge(vk0, r.vote_n, o.vote_k, o.vote_n);
+            r.vote_k = vk0;
+        }
+    }
     const uint32_t flags = wg_or32(r.flags, s4);
     const uint32_t null_count = wg_sum32(r.nulls, s4);
     const uint32_t ksent = wg_or32(r.ksent, s4);

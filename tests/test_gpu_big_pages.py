@@ -99,6 +99,14 @@ def cases():
     v = np.full(big, 1 << 20, np.int32)
     v[m] = rng.integers(100_000, 100_300, int(m.sum()))                             # low-cardinality exceptions (nested Dict: one workgroup)
     out["sparse_exceptions_lowcard_i32"] = dict(ptype=S.T_I32, nullable=False, rows=big, values=v, validity=None, offsets=None)
+    v = np.full(big, 1 << 20, np.int32)
+    mm = rng.random(big) < 0.09
+    e = np.full(int(mm.sum()), 4242, np.int32)      # 144 k exceptions: the first quarter one value, the rest 60 % distinct values
+    rare = rng.random(e.size) < 0.60                 # -> more than N / 3 distinct (no Dict), which only a count over ALL sections'
+    rare[: e.size // 4] = False                      # rows sees (the count kernel runs BIG_COUNT_SPLIT workgroups per section)
+    e[rare] = rng.integers(0, 1 << 30, int(rare.sum()))
+    v[mm] = e
+    out["sparse_exceptions_late_distinct_i32"] = dict(ptype=S.T_I32, nullable=False, rows=big, values=v, validity=None, offsets=None)
     v = np.full(big, 3.5, np.float64)
     v[rng.random(big) < 0.9] = 3.5
     v[m] = rng.random(int(m.sum()))

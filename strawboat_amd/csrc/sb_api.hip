@@ -543,6 +543,8 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     const uint32_t rle_parts = (!sizes_only && max_page_rows >= (1u << 18) && P > 0 && P <= 1024) ? (uint32_t)std::min<uint64_t>(256, 2048 / P) : 1u;
     const size_t o_rle = off;
     if (rle_parts > 1) off = align_up(off + P * rle_parts * sizeof(uint64_t), 64);
+    const size_t o_bpg = off;
+    if (rle_parts > 1) off = align_up(off + P * sizeof(uint32_t), 64);
     if (!ensure(ctx, ctx->tables, off)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(tables) failed");
 
     StageSlot* slot = acquire_slot(ctx, upload_bytes + n * sizeof(uint64_t));
@@ -705,6 +707,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     }
     a.rle_parts = rle_parts;
     a.rle_sums = rle_parts > 1 ? (uint64_t*)(tb + o_rle) : nullptr;
+    a.bp_guess = rle_parts > 1 ? (uint32_t*)(tb + o_bpg) : nullptr;
     a.zs_hdr = a.zs_segs = nullptr;
     a.zs_seg_cap = 0;
     if (zs_on) {

@@ -258,6 +258,8 @@ struct DecodeArgs {
     // long RLE pages (a call with few pages of >= 2^18 rows): `rle_parts` workgroups per page, rle_sums[page * parts + part]
     uint32_t rle_parts;
     uint64_t* rle_sums;
+    // long bit-packed pages (the same calls): bp_guess[page] = blocks from the first on that share its width (k_bp_guess)
+    uint32_t* bp_guess;
     // LZ4 blocks of LZG_MIN compressed bytes and more, block-parallel (sb_lz4_giant.h); lzg.jobs == nullptr: not in this call
     LzgArgs lzg;
     uint32_t lzg_chunks, lzg_wins, lzg_rounds, lzg_jobs;   // grid sizes: the longest page / the largest output of the call / pages long enough

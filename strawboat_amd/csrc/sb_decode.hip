@@ -1359,11 +1359,48 @@ __device__ uint32_t plan_rle(const uint8_t* body, uint32_t csize, uint32_t rec, 
 // The walk is a serial pointer chase (block k+1's position depends on block k's header); the
 // body is staged through LDS in windows so each step costs an LDS read, not an HBM miss.
 constexpr int BP_WINDOW = 16 * 1024;   // (k_plan: 17 KB of tile words + this window + <= 128 VGPRs = 4 workgroups per CU)
+// The head of a long bit-packed body: its first BPG_HEAD bytes walked block by block by one lane (the ids of a Dict page
+// grow with the rows: 7, 8, 9 ... bits in the first blocks, one width from there on).  Every thread calls; returns the
+// first block not walked and its position (s_hw: 2 words of LDS); aux (optional) receives the walked blocks' positions.
+constexpr uint32_t BPG_HEAD = 4096;
+__device__ __forceinline__ void bp_head_walk(const uint8_t* body, uint32_t csize, uint32_t nblk, uint8_t* s_win, uint32_t* s_hw, uint32_t* aux,
+                                             uint32_t* blk_s, uint32_t* pos_s) {
+    const uint32_t wlen = min(csize, BPG_HEAD);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x * 16; i < wlen; i += WG * 16) {
+        if (i + 16 <= wlen) {
+            *(u32x4*)(s_win + i) = ldu128(body + i);
+        } else {
+            for (uint32_t b = i; b < wlen; b++) s_win[b] = body[b];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t pos = 0, blk = 0;
+        while (blk < nblk && pos < wlen) {
+            const uint32_t nb = s_win[pos];
+            if (nb > 32 || pos + 1 + 16 * nb > csize) break;   // (left to the caller's walk, which reports it)
+            if (aux) aux[blk] = pos;
+            pos += 1 + 16 * nb;
+            blk++;
+        }
+        s_hw[0] = blk;
+        s_hw[1] = pos;
+    }
+    __syncthreads();
+    *blk_s = s_hw[0];
+    *pos_s = s_hw[1];
+}
+
+// guess: k_bp_guess's answer for this body (the blocks behind its head that share the first one's width), or null
 __device__ bool plan_bp(const uint8_t* body, uint32_t csize, uint64_t N, bool delta, uint32_t* aux,
-                        uint8_t* s_win, uint32_t* s_a, uint32_t* s_w, Status* st, uint32_t page) {
+                        uint8_t* s_win, uint32_t* s_a, uint32_t* s_w, Status* st, uint32_t page, const uint32_t* guess = nullptr) {
     const int t = threadIdx.x;
     const uint32_t nblk = (uint32_t)(N / 128);
     const uint32_t ntiles = (uint32_t)((N + TILE_ROWS - 1) / TILE_ROWS);
+#ifdef SB_PLAN_PRINTF
+    const unsigned long long pp0 = __builtin_readcyclecounter();
+#endif
     __shared__ uint32_t s_pos, s_blk, s_err;
     if (t == 0) {
         s_pos = 0;
@@ -1377,6 +1414,25 @@ __device__ bool plan_bp(const uint8_t* body, uint32_t csize, uint64_t N, bool de
     // and guess again from there; after a few stretches (widths that keep changing) the one-lane walk takes the rest.
     if (nblk >= 4096) {
         __shared__ uint32_t s_bad;
+        if (guess) {   // the head block by block, then the stretch k_bp_guess checked (94 000 header bytes 145 bytes apart touch
+                       // every line of the body: 13.6 MB through ONE CU were 0.13 ms of this page's plan)
+            uint32_t blk0, pos0;
+            bp_head_walk(body, csize, nblk, s_win, s_w, aux, &blk0, &pos0);
+            if (blk0 < nblk && pos0 < csize && body[pos0] <= 32) {
+                const uint32_t stride = 1 + 16 * (uint32_t)body[pos0];
+                const uint32_t fit = (uint32_t)min((uint64_t)(nblk - blk0), ((uint64_t)csize - pos0) / stride);
+                const uint32_t good = min(fit, *guess);
+                for (uint32_t k = t; k < good; k += WG) aux[blk0 + k] = pos0 + k * stride;
+                blk0 += good;
+                pos0 += good * stride;
+            }
+            __syncthreads();
+            if (t == 0) {
+                s_blk = blk0;
+                s_pos = pos0;
+            }
+            __syncthreads();
+        }
         for (int round = 0; round < 16 && s_blk < nblk && !s_err; round++) {
             const uint32_t blk0 = s_blk, pos0 = s_pos;
             if (pos0 >= csize) break;   // (the walk below reports it)
@@ -1388,11 +1444,18 @@ __device__ bool plan_bp(const uint8_t* body, uint32_t csize, uint64_t N, bool de
             if (t == 0) s_bad = fit;
             __syncthreads();
             uint32_t bad = fit;
-            for (uint32_t k = t; k < fit; k += WG)
-                if (body[pos0 + (uint64_t)k * stride] != nb) {
-                    bad = k;
-                    break;
+            constexpr uint32_t HF = 8;   // header bytes of a thread in flight
+            for (uint32_t k0 = t; k0 < fit && bad == fit; k0 += HF * WG) {
+                uint32_t hb[HF];
+#pragma unroll
+                for (uint32_t u = 0; u < HF; u++) {
+                    const uint32_t k = k0 + u * WG;
+                    hb[u] = k < fit ? (uint32_t)body[pos0 + (uint64_t)k * stride] : nb;
                 }
+#pragma unroll
+                for (uint32_t u = 0; u < HF; u++)
+                    if (hb[u] != nb) bad = min(bad, k0 + u * WG);
+            }
             if (bad < fit) atomicMin(&s_bad, bad);
             __syncthreads();
             const uint32_t good = s_bad;   // blocks blk0 .. blk0 + good - 1 have this width
@@ -1442,6 +1505,9 @@ __device__ bool plan_bp(const uint8_t* body, uint32_t csize, uint64_t N, bool de
     }
     if (t == 0) aux[nblk] = s_pos;
     __syncthreads();
+#ifdef SB_PLAN_PRINTF
+    if (t == 0 && nblk >= 4096) printf("plan_bp page %u: hdr0 %u hdr@145 %u hdr@aux1 %u aux1 %u aux2 %u nblk %u csize %u guess %d/%u cycles %llu delta %d\n", page, body[0], body[145], body[aux[1]], aux[1], aux[2], nblk, csize, guess ? 1 : 0, guess ? *guess : 0u, __builtin_readcyclecounter() - pp0, (int)delta);
+#endif
     uint32_t* tile_base = aux + nblk + 1;
     if (!delta) return true;
     // delta pages: value[j] = sum of all deltas up to j (initial 0, delta_bp.rs:73,88); the
@@ -1840,10 +1906,63 @@ __device__ bool plan_bin_dict(PageDesc& d, const U32Stream& is, uint64_t N, cons
     return true;
 }
 
+// The bit-packed body k_plan will walk for a page of 4096 blocks and more (a top-level page, or the indices of a Dict page),
+// or null.  plan_bp guesses that the blocks behind the body's head (bp_head_walk) all have one width; the guess is checked
+// here by BPG_PARTS workgroups per page: bp_guess[page] = the first of them that disagrees (~0 from the host's memset: none).
+constexpr uint32_t BPG_PARTS = 64;
+__device__ __forceinline__ const uint8_t* bp_long_body(const DecodeArgs& a, const PageDesc& d, const PageTask& t, const ColDesc& c, uint32_t* csize) {
+    if (!d.ok || c.ptype == SB_TYPE_BOOLEAN || t.num_values / 128 < 4096 || rle_by_page(c, d)) return nullptr;
+    if (d.codec == SB_CODEC_BITPACKING || d.codec == SB_CODEC_DELTA_BITPACKING) {
+        *csize = (uint32_t)(c.pages + t.in_off + t.length - d.body);
+        return d.body;
+    }
+    if (d.codec == SB_CODEC_DICT && (d.icodec == SB_CODEC_BITPACKING || d.icodec == SB_CODEC_DELTA_BITPACKING)) {
+        *csize = d.icsize;
+        return d.ibody;
+    }
+    return nullptr;
+}
+__global__ void __launch_bounds__(WG) k_bp_guess(DecodeArgs a) {
+    if (a.job_counts[3] == 0) return;
+    const uint32_t p = blockIdx.y;
+    const PageDesc d = a.descs[p];
+    const PageTask t = a.tasks[p];
+    const ColDesc c = a.cols[t.col];
+    uint32_t csize = 0;
+    const uint8_t* body = bp_long_body(a, d, t, c, &csize);
+    if (!body || csize == 0) return;
+    const uint32_t nblk = (uint32_t)(t.num_values / 128);
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[BPG_HEAD];
+    __shared__ uint32_t s_hw[2];
+    uint32_t blk0, pos0;
+    bp_head_walk(body, csize, nblk, s_win, s_hw, nullptr, &blk0, &pos0);   // (every workgroup of the page: 4 KB, a few dozen blocks)
+    if (blk0 >= nblk || pos0 >= csize) return;
+    const uint32_t nb = body[pos0];
+    if (nb > 32) return;
+    const uint32_t stride = 1 + 16 * nb;
+    const uint32_t fit = (uint32_t)min((uint64_t)(nblk - blk0), ((uint64_t)csize - pos0) / stride);
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t k0 = blockIdx.x * WG + threadIdx.x; k0 < fit && bad == 0xFFFFFFFFu; k0 += 4 * WG * gridDim.x) {
+        uint32_t hb[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t k = k0 + u * WG * gridDim.x;
+            hb[u] = k < fit ? (uint32_t)body[pos0 + (uint64_t)k * stride] : nb;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            if (hb[u] != nb) bad = min(bad, k0 + u * WG * gridDim.x);
+    }
+    if (bad != 0xFFFFFFFFu) atomicMin(a.bp_guess + p, bad);
+}
+
 // 4 workgroups per CU (LDS and registers): a 64-column x 16-page batch is 1024 pages = ONE round of the chip; at 3 per CU
 // it took two, and a page's plan is a latency chain of ~1 ms whatever else runs
 __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
     if (a.job_counts[3] == 0) return;  // no page of this call needs a plan (k_parse counts them)
+#ifdef SB_PLAN_PRINTF
+    const unsigned long long kp0 = __builtin_readcyclecounter();
+#endif
     const uint32_t p = blockIdx.x;
     __shared__ uint32_t s_a[SIDX_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t s_win[BP_WINDOW];
@@ -1875,8 +1994,10 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
         d.n_runs = R;
         changed = true;
     } else if (d.codec == SB_CODEC_BITPACKING || d.codec == SB_CODEC_DELTA_BITPACKING) {
+        uint32_t gcs = 0;
+        const uint32_t* guess = a.bp_guess && bp_long_body(a, d, t, c, &gcs) == d.body ? a.bp_guess + p : nullptr;
         if (!plan_bp(d.body, (uint32_t)(page_end - d.body), N, d.codec == SB_CODEC_DELTA_BITPACKING, aux, s_win, s_a,
-                     s_w, a.status, p)) {
+                     s_w, a.status, p, guess)) {
             d.ok = 0;
             changed = true;
         }
@@ -1942,11 +2063,19 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
             changed = true;
         } else if (ic == SB_CODEC_BITPACKING || ic == SB_CODEC_DELTA_BITPACKING) {
             PTL(0);
-            if (!plan_bp(d.ibody, d.icsize, N, ic == SB_CODEC_DELTA_BITPACKING, aux, s_win, s_a, s_w, a.status, p)) {
+#ifdef SB_PLAN_PRINTF
+            if (threadIdx.x == 0) printf("  before plan_bp: %llu  bp_guess %p ic %u body==%d\n", __builtin_readcyclecounter() - kp0, (void*)a.bp_guess, ic, (int)(d.ibody != nullptr));
+#endif
+            uint32_t gcs = 0;
+            const uint32_t* guess = a.bp_guess && ic == d.icodec && bp_long_body(a, d, t, c, &gcs) == d.ibody ? a.bp_guess + p : nullptr;
+            if (!plan_bp(d.ibody, d.icsize, N, ic == SB_CODEC_DELTA_BITPACKING, aux, s_win, s_a, s_w, a.status, p, guess)) {
                 d.ok = 0;
                 changed = true;
             }
             PTL(1);
+#ifdef SB_PLAN_PRINTF
+            if (threadIdx.x == 0) printf("  after plan_bp: %llu\n", __builtin_readcyclecounter() - kp0);
+#endif
         }
         if (d.ok && is_binary(c.ptype)) {
             const uint32_t used = idx_aux_words(ic, d.n_runs, N);
@@ -1990,6 +2119,9 @@ __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
         changed = true;
     }
     if (changed && threadIdx.x == 0) a.descs[p] = d;
+#ifdef SB_PLAN_PRINTF
+    if (threadIdx.x == 0 && N >= (1u << 19)) printf("k_plan page %u: codec %u icodec %u N %llu cycles %llu\n", p, d.codec, d.icodec, (unsigned long long)N, __builtin_readcyclecounter() - kp0);
+#endif
 }
 
 // -------------------------------------------------------------------------------- binary Dict: tile totals of long pages
@@ -2904,6 +3036,10 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     }
     {
         KScope k(ctx, K_PLAN);
+        if (a.bp_guess) {   // (calls with few, long pages)
+            (void)hipMemsetAsync(a.bp_guess, 0xFF, (size_t)a.n_pages * sizeof(uint32_t), s);
+            k_bp_guess<<<dim3(BPG_PARTS, a.n_pages), WG, 0, s>>>(a);
+        }
         k_plan<<<a.n_pages, WG, 0, s>>>(a);
     }
     if (any_binary && a.n_tiles >= BIN_DEFER_TILES) {   // long binary Dict pages: the tiles' value bytes by a workgroup per tile

@@ -376,3 +376,54 @@ def test_exact_count_table_fits_its_area(gpu_ctx, rows):
     col = gen.binary(rows, uniq=rows // 40, maxlen=12, seed=rows % 89, null_density=0.05)
     sel_check(gpu_ctx, col, ratio=1.5, forbidden=())
     dec_check(gpu_ctx, col, ratio=1.5, forbidden=())
+
+
+@pytest.mark.parametrize("shape", ["one_width", "head_grows", "changes_midway", "changes_often"])
+@pytest.mark.parametrize("codec", [S.BITPACK, S.DELTABP])
+def test_long_bitpacked_pages_block_widths(gpu_ctx, shape, codec):
+    """a bit-packed page of 4096 blocks and more: the reader walks the head of the body block by block, takes the stretch of
+    equal-width blocks behind it from k_bp_guess (checked by many workgroups) and guesses / walks the rest — whatever the
+    widths do (src/compression/integer/bp.rs:67-94, delta_bp.rs:73-103: a width byte in front of every 128 values)"""
+    from tests.test_gpu_decode import gpu_decode
+    rng = np.random.default_rng(5)
+    n = 128 * 6000 + (0 if codec == S.BITPACK else 0)
+    if shape == "one_width":
+        v = rng.integers(256, 512, n)
+    elif shape == "head_grows":        # the ids of a Dict page: 7, 8, 9 ... bits in the first blocks
+        v = np.minimum(rng.integers(0, 1 << 20, n), np.arange(n) // 64 + 1)
+    elif shape == "changes_midway":    # the guessed stretch ends at block 3000
+        v = rng.integers(0, 1 << 9, n)
+        v[128 * 3000:] = rng.integers(0, 1 << 21, n - 128 * 3000)
+    else:                              # a new width every few blocks: the guesses give up, one lane walks
+        w = rng.integers(1, 25, n // 128 // 3 + 1).repeat(3)[: n // 128]
+        v = rng.integers(0, 1 << 30, n) & ((1 << w.repeat(128)) - 1)
+    if codec == S.DELTABP:
+        v = np.cumsum(v % (1 << 12))    # (deltas of the widths above, sums that stay below 2^32)
+    col = dict(ptype=S.T_U32, nullable=False, rows=n, values=v.astype(np.uint32), validity=None, offsets=None)
+    page, metas = S.write_column(S.T_U32, False, n, col["values"], options=S.make_options(force_codec=codec))
+    got = gpu_decode(gpu_ctx, col, page, metas)
+    assert np.array_equal(got.values_numpy(), col["values"].view(np.uint8))
+
+
+def test_long_bitpacked_page_with_a_damaged_width_byte(gpu_ctx):
+    """a width byte > 32 in the guessed stretch, and one that makes the body end early: refused like the oracle refuses them"""
+    from tests.test_gpu_decode import gpu_decode
+    rng = np.random.default_rng(6)
+    n = 128 * 5000
+    col = dict(ptype=S.T_U32, nullable=False, rows=n, values=rng.integers(0, 1 << 9, n).astype(np.uint32), validity=None, offsets=None)
+    page, metas = S.write_column(S.T_U32, False, n, col["values"], options=S.make_options(force_codec=S.BITPACK))
+    for blk, byte in ((2500, 77), (4000, 32), (10, 1)):
+        bad = np.array(page, dtype=np.uint8).copy()
+        bad[9 + blk * (1 + 16 * 9)] = byte
+        try:
+            want = S.read_column(S.T_U32, False, bad, metas)["values"]
+        except Exception:
+            want = None
+        try:
+            got = gpu_decode(gpu_ctx, col, bad, metas).values_numpy()
+        except Exception:
+            got = None
+        if want is None:
+            assert got is None, (blk, byte)
+        elif got is not None:
+            assert np.array_equal(got, want.view(np.uint8)), (blk, byte)

@@ -37,9 +37,9 @@ __host__ __device__ __forceinline__ uint64_t big_sec_rows(uint64_t N) {
     return r;
 }
 struct BigSec {   // 64 bytes: the record of the section's first part, the other parts' behind it (BIG_SEC_STRIDE bytes per section)
-    uint32_t flags, nulls, vote_n, kcnt;   // flags: neq0 | unsorted << 1 | neg << 2; kcnt > BIG_KCAP: the set overflowed
+    uint32_t flags, nulls, vote_n, kcnt;   // flags: neq0 | unsorted << 1 | neg << 2 | step down << 3; kcnt > BIG_KCAP: the set overflowed
     uint64_t tmax, vote_k;
-    uint32_t ksent, pad[7];
+    uint32_t ksent, runs, pad[6];          // runs: rows whose key differs from the row before (the page's first row counts)
 };
 struct BigPage {   // 256 bytes at the start of the slot
     uint32_t flags, nulls, maj_n, set_ok;
@@ -47,9 +47,9 @@ struct BigPage {   // 256 bytes at the start of the slot
     uint32_t set_unique, ksent, need_uq, need_mc;
     uint32_t uq, mc;   // k_sel_big_count's results (atomics)
     uint32_t uq_sent;  // the all-ones key (the table's "empty") was met
-    uint32_t pad1;
+    uint32_t sorted_uq;   // integers that never step down: the distinct keys are the runs (run_uq), no count pass
     unsigned long long tus;   // binary pages: bytes of the distinct strings (8 + len each: binary/dict.rs:43-53), k_sel_big_count
-    uint32_t pad[46];
+    uint32_t run_uq, pad[45];
 };
 constexpr uint32_t BIG_SEC_STRIDE = 64 + BIG_KCAP * 8;
 static_assert(sizeof(BigSec) == 64 && sizeof(BigPage) == 256, "records of the long-page selector");
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
         return x;
     };
     const Val<W> k0 = stat_key<W>(getv(0), nk);
-    uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, nulls = 0;
+    uint32_t f_neq0 = 0, f_unsorted = 0, f_neg = 0, f_down = 0, nulls = 0, runs = 0;
     Val<W> tmax = getv(0);
     uint64_t vote_k = 0;
     uint32_t vote_n = 0;
@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
                     if (int_lt<W>(tmax, v[j], nk)) tmax = v[j];
                     if (W == 4 && nk == NK_SIGNED && (int32_t)as_i64<W>(v[j], nk) < 0) f_neg = 1;
                     if (W == 4 && (j > 0 || has_prev_row) && int_lt<W>(v[j], pv_int, nk)) f_unsorted = 1;
+                    if (W != 4 && (j > 0 || has_prev_row) && int_lt<W>(v[j], pv_int, nk)) f_down = 1;
                 }
                 if (want_vote && in) {
                     const uint64_t x = k64(kj);
@@ -266,6 +267,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
                 pv_int = v[j];
             }
         }
+        runs += (uint32_t)__popc(sbm);
         // a section's first row always goes to the section's set (the key may be new to THIS section)
         if (cb == s0 && t == 0 && mine) sbm |= 1u;
         {
@@ -297,8 +299,9 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
     flush();
     __syncthreads();
     // ---- the section's record
-    const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2), s4);
+    const uint32_t flags = wg_or32(f_neq0 | (f_unsorted << 1) | (f_neg << 2) | ((f_down | f_unsorted) << 3), s4);
     const uint32_t null_count = wg_sum32(nulls, s4);
+    const uint32_t run_count = wg_sum32(runs, s4);
     s_vk[t] = vote_k;
     s_vn[t] = vote_n;
     __syncthreads();
@@ -344,6 +347,7 @@ __global__ void __launch_bounds__(WG, 4) k_sel_big_sec(EncodeArgs a, const uint3
         r.kcnt = kc;
         r.tmax = mx;
         r.ksent = want_set ? s_ksent : 0u;
+        r.runs = run_count;
         *rec = r;
     }
     if (want_set) {   // the section's keys join the page's set
@@ -532,6 +536,7 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
             const BigSec o = *big_sec_rec(slot, (uint32_t)t, q);
             r.flags |= o.flags;
             r.nulls += o.nulls;
+            r.runs += o.runs;
             r.ksent |= o.ksent;
             r.kcnt = max(r.kcnt, o.kcnt);   // (only "some part's set overflowed" is read from it)
             Val<W> x, y;
@@ -547,6 +552,7 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
     const uint32_t null_count = wg_sum32(r.nulls, s4);
     const uint32_t ksent = wg_or32(r.ksent, s4);
     const uint32_t over = wg_or32(has && r.kcnt > BIG_KCAP ? 1u : 0u, s4);
+    const uint32_t run_total = wg_sum32(has ? r.runs : 0u, s4);
     unsigned long long* vk = (unsigned long long*)sample_mem;
     uint32_t* vn = s_misc;
     vk[t] = r.vote_k;
@@ -591,11 +597,14 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
         set_ok = !uover && uc <= BIG_KCAP;
         set_unique = uc + (ksent ? 1u : 0u);
     }
+    // integers that never step down (sorted ids, timestamps): equal keys are neighbours, so the distinct keys are the runs —
+    // no table, no count pass (a sorted 12 M-row Int64 page: k_sel_big_clear + k_sel_big_count were 0.4 of its 0.6 ms)
+    const bool sorted_uq = want_set && !bin && !set_ok && !is_float && !(flags & 8u);
     // ---- what is missing for the decision?
     const bool all_equal = !(flags & 1u);
     const double tuple_count = (double)N;
     // (binary: set_ok is never true; choose_bin_impl looks at Dict's ratio on an all-equal page too unless OneValue took it)
-    const bool need_uq = bin ? want_set && !(all_equal && !((forb >> SB_CODEC_ONEVALUE) & 1)) : want_set && !all_equal && !set_ok;
+    const bool need_uq = bin ? want_set && !(all_equal && !((forb >> SB_CODEC_ONEVALUE) & 1)) : want_set && !all_equal && !set_ok && !sorted_uq;
     const bool need_mc = want_vote && !all_equal && !((double)null_count / tuple_count >= 0.9) && ((double)maj_n + 1.0 >= 0.8 * tuple_count);
     if (t == 0) {
         BigPage b;
@@ -610,13 +619,15 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_merge(EncodeArgs a, const uin
         b.ksent = ksent ? 1u : 0u;
         b.need_uq = need_uq ? 1u : 0u;
         b.need_mc = need_mc ? 1u : 0u;
+        b.sorted_uq = sorted_uq ? 1u : 0u;
+        b.run_uq = run_total;
         s_bp = b;
         *big_page_rec(slot) = b;
     }
     __syncthreads();
     if (need_uq || need_mc) return;   // k_sel_big_count, then k_sel_big_decide
     const BigPage bp = s_bp;
-    const PrimCounts pc{false, false, 0, 0};
+    const PrimCounts pc{bp.sorted_uq != 0, false, bp.run_uq, 0};
     __syncthreads();
     if (bin) big_decide_bin(a, c, p, page, bp);
     else big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
@@ -799,7 +810,8 @@ __global__ void __launch_bounds__(WG, 2) k_sel_big_decide(EncodeArgs a, const ui
     if (!big_page_of(a, big, W, &page, &p, &c, voff)) return;   // (chosen by k_sel_big_merge already)
     const BigPage bp = *big_page_rec(page_slot(a, c, p));
     // without an aux area (cannot happen while Dict is a candidate) the count stays unknown: "more than the limit"
-    const PrimCounts pc{bp.need_uq != 0, bp.need_mc != 0, p.aux_bytes >= big_tab_slots(p.rows) * 8 ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
+    const PrimCounts pc{bp.need_uq != 0 || bp.sorted_uq != 0, bp.need_mc != 0,
+                        bp.sorted_uq ? bp.run_uq : p.aux_bytes >= big_tab_slots(p.rows) * 8 ? bp.uq + bp.uq_sent : 0xFFFFFFFEu, bp.mc};
     if (big_is_bin(c)) big_decide_bin(a, c, p, page, bp);
     else big_decide<W>(a, c, p, page, bp, pc, lds_tab, s_misc, sample_mem);
 }

@@ -107,6 +107,18 @@ def cases():
     e[rare] = rng.integers(0, 1 << 30, int(rare.sum()))
     v[mm] = e
     out["sparse_exceptions_late_distinct_i32"] = dict(ptype=S.T_I32, nullable=False, rows=big, values=v, validity=None, offsets=None)
+    # integers that never step down: the distinct keys are the runs, counted by the section kernel itself (no table pass)
+    out["sorted_midcard_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=np.sort(rng.integers(-50_000, 50_000, ROWS)).astype(np.int64),
+                                     validity=None, offsets=None)                                  # 100 000 keys < N / 3: Dict is a candidate
+    out["sorted_highcard_i64"] = dict(ptype=S.T_I64, nullable=False, rows=ROWS, values=np.sort(rng.integers(0, 230_000, ROWS)).astype(np.int64),
+                                      validity=None, offsets=None)                                 # just around Dict's limit of N / 3
+    out["sorted_midcard_u16"] = dict(ptype=S.T_U16, nullable=False, rows=ROWS_ODD, values=np.sort(rng.integers(0, 40_000, ROWS_ODD)).astype(np.uint16),
+                                     validity=None, offsets=None)
+    out["sorted_descending_i32"] = dict(ptype=S.T_I32, nullable=False, rows=ROWS, values=np.sort(rng.integers(0, 100_000, ROWS))[::-1].astype(np.int32).copy(),
+                                        validity=None, offsets=None)                               # steps down: the count pass
+    c = dict(ptype=S.T_I64, nullable=True, rows=ROWS, values=np.sort(rng.integers(0, 100_000, ROWS)).astype(np.int64),
+             validity=np.packbits(rng.random(ROWS) < 0.9, bitorder="little"), offsets=None)
+    out["sorted_midcard_nullable_i64"] = c
     v = np.full(big, 3.5, np.float64)
     v[rng.random(big) < 0.9] = 3.5
     v[m] = rng.random(int(m.sum()))

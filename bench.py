@@ -1230,7 +1230,7 @@ def main():
                 pc = pmc["config"]
                 if pmc.get("kernel_source_sha16") != src_sha:   # the counters belong to another version of the kernel: not this run's traffic
                     if roof:
-                        roof["traffic_stale"] = "profiles/%s was collected for kernel sources %s, this build is %s" % (pf, pmc.get("kernel_source_sha16"), src_sha)
+                        roof["traffic_stale"] = "profiles/%s: kernel sources %s, this build %s" % (pf, pmc.get("kernel_source_sha16"), src_sha)
                     continue
                 if roof and str(pc.get("workload", "")).lower().startswith("c2") and pc.get("columns_per_gpu", B) == B \
                         and pc.get("codec", args.codec) == args.codec:

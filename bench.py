@@ -1243,7 +1243,7 @@ def main():
                 pass
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # (the CPU leg is a property of the box: timed at N = 1 only)
             from oracle import sbo
             if codec < 0:
                 o = sbo.make_options(max_page_size=PAGE, ratio=2.0, forbidden=())

@@ -8,6 +8,8 @@
 #include "../../strawboat_amd/csrc/sb_encode.hip"
 #include <cstdio>
 #include <random>
+#define SB_STR2(x) #x
+#define SB_STR(x) SB_STR2(x)
 using namespace sb;
 
 int main(int argc, char** argv) {
@@ -56,7 +58,7 @@ int main(int argc, char** argv) {
     hipMemcpy(ho.data(), outs, P * sizeof(EncOut), hipMemcpyDeviceToHost);
     for (uint64_t i = 0; i < P; i++) { rle += hc[i] == SB_CODEC_RLE; sum += ho[i].length; }
     const double A = (double)P * (N * 8 + N / 8) + (double)sum;   // algorithmic bytes: Arrow bytes read once + pages written
-    printf("SB_RUNS_DMA=%d occupancy %d: %.3f ms per launch of %llu pages -> %.2f TB/s algorithmic = %.3f of 8 TB/s; %llu RLE pages, %llu page bytes\n",
+    printf("SB_RUNS_DMA=%d SB_RUNS_TOUCH=" SB_STR(SB_RUNS_TOUCH) " occupancy %d: %.3f ms per launch of %llu pages -> %.2f TB/s algorithmic = %.3f of 8 TB/s; %llu RLE pages, %llu page bytes\n",
            (int)SB_RUNS_DMA, (int)SB_RUNS_OCC, ms / 10, (unsigned long long)P, A / (ms / 10) / 1e9, A / (ms / 10) / 1e9 / 8.0,
            (unsigned long long)rle, (unsigned long long)sum);
     return 0;

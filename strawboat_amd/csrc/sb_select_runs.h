@@ -23,6 +23,9 @@
 // A chunk (4096 rows) with more than RUNS_CAP raw runs (runs shorter than ~6 rows on average) makes
 // the page FALL BACK to select_rle_page (k_enc_select_rle runs after this kernel and takes the pages
 // marked CODEC_PENDING): lane = run pays off only when there are runs.
+#ifndef SB_RUNS_TOUCH
+#define SB_RUNS_TOUCH 0   // EXPERIMENT (scripts/micro/runs_dma.hip): one dword of the NEXT chunk's 128 bytes per thread, to have them in L2
+#endif
 #ifndef SB_RUNS_DMA
 #define SB_RUNS_DMA 0
 #endif
@@ -155,6 +158,13 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
         }
 #else
         request(cb);
+#endif
+#if SB_RUNS_TOUCH
+        uint32_t touch = 0;
+        if (cb + CHUNK + (uint64_t)(t + 1) * K <= N) {
+            const uint8_t* tp = vals + (cb + CHUNK + (uint64_t)t * K) * W;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(tp) : "memory");
+        }
 #endif
         const uint32_t n = (uint32_t)min((uint64_t)CHUNK, N - cb);
         const uint32_t r0 = (uint32_t)t * K;
@@ -347,6 +357,10 @@ __device__ uint32_t select_runs_page(const EncodeArgs& a, const EncCol& c, const
             }
         }
         XTL(10);
+#if SB_RUNS_TOUCH
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (long landed: the chunk's own loads were waited for above)
+        asm volatile("" ::"v"(touch));                      // the register stays the load's until here
+#endif
         if (!spec) lds_barrier();  // (the run list and the validity words are rewritten by the next chunk)
         // runs shorter than 4 rows on average: RLE is unlikely to be chosen, stop paying for it
         if ((uint64_t)nrec * 4 > cb + n + 256) spec = false;

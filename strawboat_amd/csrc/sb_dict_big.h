@@ -450,8 +450,7 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
         }
     }
     __syncthreads();
-    auto id_of = [&](uint64_t row) -> uint32_t {   // row is keyed
-        const unsigned long long x = kf.key(row, vv.get(row));
+    auto id_of_key = [&](unsigned long long x, uint64_t row) -> uint32_t {   // row is keyed, x its key
         if (dbig_is_nan<W>(x, fkind)) {   // its own entry: id = rank of the row among the first rows
             const uint32_t id = dbig_rank(d, s_base, SR, (uint32_t)row);
             d.firsts[id] = (uint32_t)row;
@@ -465,6 +464,7 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
         }
         return d.frow[dbig_global_find(d.keys, mask, x)];
     };
+    auto id_of = [&](uint64_t row) -> uint32_t { return id_of_key(kf.key(row, vv.get(row)), row); };
     // carry-in: the index of the last keyed row before the section (row 0 is always keyed)
     uint32_t carry = 0;
     const bool fill = vv.bits != nullptr;
@@ -483,7 +483,31 @@ __global__ void __launch_bounds__(WG, 3) k_dict_big_idx(EncodeArgs a, const uint
         carry = id_of(found);
     }
     uint32_t par = 0;
-    for (uint64_t base = s0; base < s1; base += (uint64_t)WG * 8) {
+    // no validity bitmap: every row is keyed and nothing is carried — the keys of eight rows per thread in flight, then their ids
+    // (one load per thread and iteration is a latency chain: 64 iterations of ~1.5 us for a 16 384-row part, 0.09 ms of a
+    // 12 M-row page's 0.54)
+    if (!fill) {
+        for (uint64_t base = s0; base < s1; base += (uint64_t)WG * 8) {
+            unsigned long long xu[8];
+            uint32_t idv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG + t;
+                xu[u] = kf.key(i < s1 ? i : s0, true);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG + t;
+                idv[u] = i < s1 ? id_of_key(xu[u], i) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = base + (uint64_t)u * WG + t;
+                if (i < s1) d.idx[i] = idv[u];
+            }
+        }
+    }
+    for (uint64_t base = s0; fill && base < s1; base += (uint64_t)WG * 8) {
 #pragma unroll 1
         for (int u = 0; u < 8; u++, par ^= 1) {
             const uint64_t g0 = base + (uint64_t)u * WG;   // this group's first row (uniform)

@@ -563,19 +563,24 @@ def run_c5(h, cpu_on, arrays=64):
         pairs = [(dl, dc) for dl, dc, _, _ in its]
         wb = nested.NestedWriteBatch(ctx, pairs, opts)      # descriptors and buffers once, like WriteBatch for flat columns
         encs = wb.run()                                     # warm-up + outputs
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        tes = []
+        for _ in range(reps):                               # (a run ends in a synchronize: timed one by one, the MEDIAN reported —
+            t0 = time.perf_counter()                        #  one run in ~30 of a day's runs stalled for 0.3 s on the host side)
             encs = wb.run()
-        te = (time.perf_counter() - t0) / reps * 1e3
+            tes.append((time.perf_counter() - t0) * 1e3)
+        te = sorted(tes)[len(tes) // 2]
         cps = [ColumnPages(c["ptype"], False, e.pages[:e.length].contiguous(), e.metas_array()) for e, (_, _, c, _) in zip(encs, its)]
         kinds = [[lv["kind"] for lv in lv_] for _, _, _, lv_ in its]
         opt = [[bool(lv["is_optional"]) for lv in lv_] for _, _, _, lv_ in its]
         rb = nested.NestedReadBatch(ctx, cps, kinds, opt)
         arrs = rb.run()
-        t0 = time.perf_counter()
+        tds = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             arrs = rb.run()
-        td = (time.perf_counter() - t0) / reps * 1e3
+            tds.append((time.perf_counter() - t0) * 1e3)
+        td = sorted(tds)[len(tds) // 2]
+        measure.spread = {"encode_ms_runs": [round(x, 3) for x in tes], "decode_ms_runs": [round(x, 3) for x in tds]}
         return pairs, encs, cps, kinds, opt, arrs, te, td, wb, rb
     pairs, encs, cps, kinds, opt, arrs, te, td, wb, rb = measure(items, 3)
     # round trip: list offsets and leaf buffers of the first array
@@ -593,6 +598,7 @@ def run_c5(h, cpu_on, arrays=64):
     ctx.profile(False)
     pb = sum(e.length for e in encs)
     res = dict(U=U, page_bytes=pb, n_pages=sum(e.n_pages for e in encs), enc_ms=te, dec_ms=td, kernels={})
+    spread = getattr(measure, "spread", None)
     cpu = None
     if cpu_on:   # one array: its two leaf columns' blocks + the level sections of their 2 x 16 pages (write_nested_validity / read_validity_nested)
         from oracle import sbo
@@ -652,6 +658,8 @@ def run_c5(h, cpu_on, arrays=64):
                                 kernels_ms={kk: round(vv[1], 3) for kk, vv in sorted(st.items(), key=lambda kv: -kv[1][1])[:6]})
     top(st_e, "encode")
     top(st_d, "decode")
+    if spread:
+        e["runs_ms"] = spread   # (every timed run; encode / decode above are their medians)
     if cpu_on:
         from oracle import sbo
         o = sbo.make_options(default_compression=sbo.ZSTD, max_page_size=PAGE)

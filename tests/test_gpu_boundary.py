@@ -62,6 +62,26 @@ def test_many_calls_before_one_synchronize(gpu_ctx):
         assert np.array_equal(got.offsets_numpy().view(np.int32), want["offsets"].view(np.int32)), k
 
 
+def test_staging_slots_outgrown_while_results_are_pending(gpu_ctx):
+    """calls whose page tables grow 3 x from one to the next, none synchronized: every one of the eight pinned staging slots
+    is outgrown (twice) while the results of the calls before still sit in it — they are moved out first, the old buffers are
+    freed at the synchronize, every call gets its own metas and pages"""
+    from strawboat_amd import write
+    from strawboat_amd.types import WriteOptions
+    encs, wants = [], []
+    npages = 2
+    for k in range(18):
+        rows = npages * 64
+        col = gen.prim(S.T_I32, rows, uniq=7 + k, null_density=0.1 if k % 2 else None, seed=300 + k, runs=5 if k % 3 == 0 else None)
+        wants.append(gen.oracle_write(col, max_page_size=64, ratio=2.0))
+        encs.append(write.encode_columns(gpu_ctx, [_dcol(gpu_ctx, col)], WriteOptions(max_page_size=64, default_compress_ratio=2.0))[0])
+        npages = npages * 3 if k % 2 else npages + 5      # (2 ... ~20 000 pages)
+    gpu_ctx.synchronize()
+    for k in range(18):
+        assert np.array_equal(encs[k].metas_array(), wants[k][1]), "call %d: metas of another call" % k
+        assert np.array_equal(encs[k].pages_numpy(), wants[k][0]), "call %d" % k
+
+
 @pytest.mark.parametrize("codec", [S.ONEVALUE, S.DICT, S.NONE, S.LZ4, S.FREQ])
 def test_undersized_values_capacity_is_not_overrun(gpu_ctx, codec):
     """binary pages that expand beyond the caller's values buffer (a OneValue / Dict page expands far

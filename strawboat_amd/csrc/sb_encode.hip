@@ -4749,6 +4749,7 @@ __global__ void __launch_bounds__(WG) k_enc_emit_lz4(EncodeArgs a) {
 // plan: def levels + staged first block + the chunk list (one workgroup per page).
 __global__ void __launch_bounds__(WG) k_enc_lz4_plan(EncodeArgs a) {
     __shared__ uint32_t s_base;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.lzc_count[1] = 0;   // the ticket of k_enc_zstd_chunks' waves
     if (a.use_counts && a.codec_counts[a.lzc_codec & 31] == 0) return;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
@@ -4845,7 +4846,13 @@ __global__ void __launch_bounds__(64) k_enc_zstd_chunks(EncodeArgs a) {
     if (a.lzc_codec != SB_CODEC_ZSTD) return;
     const uint32_t total = min(*a.lzc_count, a.lzc_cap);
     uint8_t* scratch = a.zpar_scratch + (uint64_t)blockIdx.x * zstd_scratch_bytes(ZPAR_CH);
-    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+    // pieces are handed out by a ticket: a piece with sequences takes a wave ~2 ms, a literals-only one a tenth of that, and a
+    // fixed stride gave some waves several of the long ones
+    for (;;) {
+        uint32_t i = 0;
+        if ((threadIdx.x & 63) == 0) i = atomicAdd(a.lzc_count + 1, 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (i >= total) break;
         const LzChunkDesc d = a.lzc_list[i];
         const EncPage p = get_page(a, d.page);
         const EncCol c = get_col(a, p.col);

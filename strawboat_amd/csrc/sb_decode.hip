@@ -1252,7 +1252,7 @@ __global__ void __launch_bounds__(64) k_inflate(const InflateJob* jobs, const ui
 
 // LZ4 blocks: one wave per block from a pool of waves that loops over the job queue (sb_lz4.h: compressed
 // bytes and an 8 KiB output window in LDS, speculative 64-position token parse, matches batched)
-constexpr uint32_t LZ4_POOL = 4096;
+constexpr uint32_t LZ4_POOL = 2816;   // = the waves that are resident (13.4 KB of LDS each: 11 per CU); 4096 left a thin second round (continuity i64 read 1840 -> 1900 GB/s, utf8 695 -> 730)
 __global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min, uint32_t cap) {
     __shared__ Lz4DecLds lds;
     const uint32_t njobs = min(*count, cap);

@@ -182,6 +182,7 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
     (void)hipMemsetAsync(ctx->zb_stats, 0, 16 * sizeof(unsigned long long), ctx->stream);
     if (const char* e = getenv("SB_ZSTD_BLOCKS")) ctx->zb_mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
     if (const char* e = getenv("SB_ZSTD_BLOCKS_WG")) ctx->zb_wg_exec = e[0] != '0';
+    if (const char* e = getenv("SB_BIN_FUSED")) ctx->bin_fused = e[0] != '0';
     if (const char* e = getenv("SB_ZSTD_BLOCKS_MIN")) ctx->zb_min_csize = (uint32_t)strtoul(e, nullptr, 10);
     // tests: divide the block pipeline's pool estimates so that a call runs out of pool space part-way (frames that do not
     // fit go back to the frame-serial decoder)

@@ -1,0 +1,512 @@
+// strawboat-hip: the codec choice AND the dictionary of an adaptive Binary / LargeBinary page in ONE pass over its strings
+// (included by sb_encode.hip inside namespace sb, behind k_enc_select).
+//
+// Replaces, for pages of BP_MIN_ROWS .. 65 536 rows, the chain k_enc_bin_hash -> k_enc_select<-4 / -8> -> k_enc_bin_verify
+// (-> redo) of rounds 3-5: that chain wrote an 8-byte hash per row to HBM, read it back three times, and read the strings
+// twice (hash, verify) — 6.8 GB of traffic for the 1.37 GB of C3 — in four latency-bound kernels of 256-thread workgroups,
+// two per CU.  Here ONE workgroup of 1024 threads per page (one per CU: the 32 Ki-slot table is 128 KB of LDS) streams the
+// rows once:
+//   * row -> (offset pair, <= 32 bytes of the string in registers) -> 64-bit hash -> slot of an LDS table whose word is
+//     tag15 | unkeyed | row16; a probe that meets its tag compares the STRINGS (the row's bytes are in registers, the
+//     representative's come from L1 / L2: the frequent strings' first rows are hot) — the table is exact, so there is no
+//     verify pass and no redo; equal strings always meet in one slot (linear probing, no deletions), atomicMin keeps the
+//     smallest KEYED row (row 0 and the valid rows intern keys, binary/dict.rs:55-93), else the smallest row;
+//   * the slot of every row goes to HBM as a u16 (L2-resident: 128 KB per page), the only per-row product;
+//   * the statistics of binary/mod.rs:265-348 fall out of the same pass: distinct strings = inserts (the pass stops once
+//     Dict's limit (N - 1) / 3 is passed: the table can never fill), their bytes = the inserters' lengths, all_equal =
+//     one insert, nulls from the validity words, the Freq majority by a Boyer-Moore vote over slot numbers + one count
+//     pass over the u16 slots;
+//   * a page that chooses Dict gets its ids in first-occurrence order from a bitmap of the first keyed rows + prefix
+//     popcounts (id = rank), the table is overwritten with slot -> id, and the u32 index array (a null row repeats the
+//     index before it) is written for the page's emitter: k_enc_emit_pages<-4 / -8, Dict> starts at the nested selection.
+// reference: src/compression/binary/mod.rs:293-348 (choose_compressor), binary/dict.rs:38-100, binary/freq.rs:147-169,
+// binary/one_value.rs:42-48.
+
+__device__ __forceinline__ uint32_t bp_sum(uint32_t v, uint32_t* s16) {   // sum over the 1024 threads
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < BP_WG / 64; k++) r += s16[k];
+    return r;
+}
+// The hash of a string: a function of its bytes alone (dwords little-endian, the last one zero-padded), in two forms — from
+// the 8 masked dwords of a string of <= 32 bytes in registers, and bytewise from memory (long strings, and the last rows of a
+// column, whose 32-byte loads would leave the buffer) — so that the copies of a string meet in one probe sequence wherever they sit.
+constexpr uint32_t BP_REGW = 6;   // dwords of a string held in registers by the row loop (longer strings: the second loop)
+__device__ __forceinline__ uint32_t bp_hash_step(uint32_t h, uint32_t d) {
+    h = (h ^ d) * 0xCC9E2D51u;
+    return (h << 13) | (h >> 19);
+}
+__device__ __forceinline__ uint32_t bp_hash_fin(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+__device__ __forceinline__ uint32_t bp_hash_init(uint32_t n) { return n * 0x9E3779B1u + 0x85EBCA6Bu; }
+__device__ uint32_t bp_hash_mem(const uint8_t* values, uint64_t b, uint32_t n) {
+    uint32_t h = bp_hash_init(n);
+    for (uint32_t k = 0; k < n; k += 4) {
+        uint32_t d = 0;
+        for (uint32_t q = 0; q < 4 && k + q < n; q++) d |= (uint32_t)ldu8(values + b + k + q) << (8 * q);
+        h = bp_hash_step(h, d);
+    }
+    return bp_hash_fin(h);
+}
+__device__ __forceinline__ uint32_t bp_dmask(uint32_t n, uint32_t k) {   // mask of the bytes of dword k that belong to a string of n bytes
+    const uint32_t have = n > 4 * k ? n - 4 * k : 0;
+    return have >= 4 ? 0xFFFFFFFFu : (1u << (8 * have)) - 1u;
+}
+template <class O>
+__global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
+    __shared__ uint32_t tab[BP_SLOTS];
+    __shared__ uint32_t s_x[2048];   // vote candidates | bitmap of first rows | last keyed id per 64-row chunk
+    __shared__ uint32_t s_y[2048];   // vote counts | word prefixes | carried id per chunk
+    __shared__ uint32_t s_w[BP_WG / 64];
+    __shared__ uint32_t s_cnt;
+    __shared__ unsigned long long s_tus;
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
+    const EncPage p = get_page(a, page);
+    if (!bp_page_ok(a, p, page)) return;
+    const EncCol c = get_col(a, p.col);
+    if (c.ptype != (sizeof(O) == 4 ? SB_TYPE_BINARY : SB_TYPE_LARGE_BINARY)) return;
+    const uint32_t N = (uint32_t)p.rows;
+    uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
+    uint16_t* slot16 = (uint16_t*)(aux + bp_w_slot16(N));
+    const uint8_t* offs = c.offsets + p.row0 * sizeof(O);
+    const uint8_t* values = c.values;
+    const uint64_t vlen = c.values_len;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    const BinKeys<O> bk{offs, values, vv};
+    for (uint32_t i = t; i < BP_SLOTS; i += BP_WG) tab[i] = BP_EMPTY;
+    if (t == 0) {
+        s_cnt = 0;
+        s_tus = 0;
+    }
+    __syncthreads();
+    const uint32_t limit = (N - 1) / 3;
+    uint32_t bm_c = 0, bm_n = 0;
+    unsigned long long my_tus = 0, slow_rows = 0;   // (bit k: row k * BP_WG + t)
+    constexpr int U = 4;
+    const uint8_t* dummy = (const uint8_t*)aux;   // 64 readable bytes for the loads of lanes that have nothing to load
+    for (uint32_t base = 0; base < N; base += BP_WG * U) {
+        // (no barrier in the loop: every wave adds its inserts before it looks again, so the count overshoots the limit by at
+        // most one step of the 16 waves = 4096 keys)
+        if (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > limit) break;
+        // Every phase issues the loads of its U rows together, unconditionally (idle lanes read `dummy`): the step is four
+        // round trips — offsets, bytes, the representatives' offsets, their bytes — whatever the rows hold.
+        uint64_t b[U];
+        uint32_t len[U], home[U], word[U], w[U][BP_REGW];
+        uint32_t pend = 0, fastm = 0, keyedm = 0;
+        {
+            uint64_t o0[U], o1[U];
+            uint32_t vb[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = base + (uint32_t)u * BP_WG + t;
+                const uint32_t ic = i < N ? i : N - 1;
+                if constexpr (sizeof(O) == 4) {
+                    o0[u] = ldu64(offs + (uint64_t)ic * 4);
+                } else {
+                    o0[u] = ldu64(offs + (uint64_t)ic * 8);
+                    o1[u] = ldu64(offs + (uint64_t)ic * 8 + 8);
+                }
+                vb[u] = vv.bits ? (uint32_t)ldu8(vv.bits + ((vv.off + ic) >> 3)) : 0xFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = base + (uint32_t)u * BP_WG + t;
+                const uint32_t ic = i < N ? i : N - 1;
+                uint64_t e;
+                if constexpr (sizeof(O) == 4) {
+                    b[u] = (uint64_t)(int64_t)(int32_t)(uint32_t)o0[u];
+                    e = (uint64_t)(int64_t)(int32_t)(uint32_t)(o0[u] >> 32);
+                } else {
+                    b[u] = o0[u];
+                    e = o1[u];
+                }
+                len[u] = (uint32_t)(e - b[u]);
+                if (i < N && e - b[u] <= 4 * BP_REGW && b[u] + 32 <= vlen) fastm |= 1u << u;
+                else if (i < N) slow_rows |= 1ull << (base / BP_WG + (uint32_t)u);   // (long strings, the column's last rows: second loop)
+                if (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1)) keyedm |= 1u << u;
+            }
+        }
+        {
+            u32x4 q0[U], q1[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint8_t* pa = ((fastm >> u) & 1) ? values + b[u] : dummy;
+                q0[u] = ldu128(pa);
+                q1[u] = ldu128(pa + 16);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t n = ((fastm >> u) & 1) ? len[u] : 0;
+                const uint32_t qq[8] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, q1[u].x, q1[u].y, q1[u].z, q1[u].w};
+#pragma unroll
+                for (uint32_t k = 0; k < BP_REGW; k++) w[u][k] = qq[k] & bp_dmask(n, k);
+            }
+        }
+        pend = fastm;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = base + (uint32_t)u * BP_WG + t;
+            uint32_t h = bp_hash_init(len[u]);
+#pragma unroll
+            for (uint32_t k = 0; k < BP_REGW; k++) {
+                const uint32_t hn = bp_hash_step(h, w[u][k]);
+                h = 4 * k < len[u] ? hn : h;
+            }
+            h = bp_hash_fin(h);
+            home[u] = h & (BP_SLOTS - 1);
+            uint32_t tag = (h >> 15) & 0x7FFFu;
+            if (tag == 0x7FFFu) tag = 0x7FFEu;
+            word[u] = (tag << 17) | (((keyedm >> u) & 1) ? 0u : BP_UNKEYED) | (i & 0xFFFFu);
+        }
+        uint32_t newk = 0;
+        while (pend) {
+            uint32_t cur[U], rep[U];
+            uint32_t cmp = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u] = tab[home[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                rep[u] = 0;
+                if (!((pend >> u) & 1)) continue;
+                uint32_t cw = cur[u];
+                if (cw == BP_EMPTY) {
+                    cw = atomicCAS(&tab[home[u]], BP_EMPTY, word[u]);
+                    if (cw == BP_EMPTY) {
+                        newk++;
+                        my_tus += (unsigned long long)len[u] + 8;
+                        pend &= ~(1u << u);
+                        continue;
+                    }
+                }
+                if ((cw >> 17) == (word[u] >> 17)) {
+                    cmp |= 1u << u;
+                    rep[u] = cw & 0xFFFFu;
+                    cur[u] = cw;
+                } else {
+                    home[u] = (home[u] + 1) & (BP_SLOTS - 1);
+                }
+            }
+            if (cmp) {
+                uint64_t rb[U];
+                uint32_t rl[U], cf = 0;
+                {
+                    uint64_t o0[U], o1[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if constexpr (sizeof(O) == 4) {
+                            o0[u] = ldu64(offs + (uint64_t)rep[u] * 4);
+                        } else {
+                            o0[u] = ldu64(offs + (uint64_t)rep[u] * 8);
+                            o1[u] = ldu64(offs + (uint64_t)rep[u] * 8 + 8);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if constexpr (sizeof(O) == 4) {
+                            rb[u] = (uint64_t)(int64_t)(int32_t)(uint32_t)o0[u];
+                            rl[u] = (uint32_t)((uint64_t)(int64_t)(int32_t)(uint32_t)(o0[u] >> 32) - rb[u]);
+                        } else {
+                            rb[u] = o0[u];
+                            rl[u] = (uint32_t)(o1[u] - rb[u]);
+                        }
+                        if (((cmp >> u) & 1) && rl[u] == len[u]) cf |= 1u << u;   // (a representative in here is a row of this loop: 32 readable bytes)
+                    }
+                }
+                uint32_t eq = 0;
+                {
+                    u32x4 q0[U], q1[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint8_t* pa = ((cf >> u) & 1) ? values + rb[u] : dummy;
+                        q0[u] = ldu128(pa);
+                        q1[u] = ldu128(pa + 16);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t n = len[u];
+                        const uint32_t qq[8] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, q1[u].x, q1[u].y, q1[u].z, q1[u].w};
+                        uint32_t d = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < BP_REGW; k++) d |= (qq[k] & bp_dmask(n, k)) ^ w[u][k];
+                        if (((cf >> u) & 1) && d == 0) eq |= 1u << u;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (!((cmp >> u) & 1)) continue;
+                    if ((eq >> u) & 1) {
+                        if (word[u] < cur[u]) atomicMin(&tab[home[u]], word[u]);   // (later rows of a class: nothing to do)
+                        pend &= ~(1u << u);
+                    } else {
+                        home[u] = (home[u] + 1) & (BP_SLOTS - 1);
+                    }
+                }
+            }
+        }
+        if (newk) atomicAdd(&s_cnt, newk);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = base + (uint32_t)u * BP_WG + t;
+            if (!((fastm >> u) & 1)) continue;
+            *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)home[u];
+            if (bm_n == 0) {
+                bm_c = home[u];
+                bm_n = 1;
+            } else if (home[u] == bm_c) {
+                bm_n++;
+            } else {
+                bm_n--;
+            }
+        }
+    }
+    // ---- the rows the loop above left: strings of more than 4 * BP_REGW bytes and the last rows of the column (a 32-byte load
+    // would leave the buffer), one at a time, hashed and compared from memory.  A class's smallest row does not depend on the
+    // order of the inserts, and the representatives the first loop compared with were rows of the first loop.
+    __syncthreads();   // (from here on a representative may sit at the buffer's end)
+    while (slow_rows) {
+        if (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > limit) break;
+        const uint32_t k = (uint32_t)__ffsll((long long)slow_rows) - 1;
+        slow_rows &= slow_rows - 1;
+        const uint32_t i = k * BP_WG + t;
+        const uint64_t b0 = bk.beg(i);
+        const uint32_t n = (uint32_t)(bk.beg((uint64_t)i + 1) - b0);
+        const uint32_t h = bp_hash_mem(values, b0, n);
+        uint32_t hm = h & (BP_SLOTS - 1);
+        uint32_t tag = (h >> 15) & 0x7FFFu;
+        if (tag == 0x7FFFu) tag = 0x7FFEu;
+        const uint32_t wd = (tag << 17) | ((i == 0 || vv.get(i)) ? 0u : BP_UNKEYED) | (i & 0xFFFFu);
+        for (;;) {
+            uint32_t cw = tab[hm];
+            if (cw == BP_EMPTY) {
+                cw = atomicCAS(&tab[hm], BP_EMPTY, wd);
+                if (cw == BP_EMPTY) {
+                    atomicAdd(&s_cnt, 1u);
+                    my_tus += (unsigned long long)n + 8;
+                    break;
+                }
+            }
+            if ((cw >> 17) == tag && bk.eq(cw & 0xFFFFu, i)) {
+                if (wd < cw) atomicMin(&tab[hm], wd);
+                break;
+            }
+            hm = (hm + 1) & (BP_SLOTS - 1);
+        }
+        *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)hm;
+        if (bm_n == 0) {
+            bm_c = hm;
+            bm_n = 1;
+        } else if (hm == bm_c) {
+            bm_n++;
+        } else {
+            bm_n--;
+        }
+    }
+    if (my_tus) atomicAdd(&s_tus, my_tus);
+    uint32_t nulls = 0;
+    if (vv.bits)
+        for (uint32_t w = t; w * 32 < N; w += BP_WG) {
+            const uint32_t nb = min(32u, N - w * 32);
+            const uint32_t wd = bits32(vv.bits, vv.off + (uint64_t)w * 32, vv.off + N) & (nb >= 32 ? 0xFFFFFFFFu : (1u << nb) - 1);
+            nulls += nb - (uint32_t)__popc(wd);
+        }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t null_count = bp_sum(nulls, s_w);
+    const uint32_t uq = s_cnt;
+    const uint64_t tus = s_tus;
+    const bool over = uq > limit;   // Dict is out; more than a third of the rows are distinct, so no value has a majority either
+    const bool all_equal = !over && uq == 1;
+    const uint32_t forb = a.forbidden | p.forb_extra;
+    auto forbidden = [&](uint32_t cd) { return (forb >> cd) & 1u; };
+    const double tuple_count = (double)N;
+    // ---- the Freq majority (binary/freq.rs:147-169): Boyer-Moore vote over slot numbers, then the candidate's exact count
+    uint32_t mc = 0;
+    const bool want_mc = !forbidden(SB_CODEC_FREQ) && !all_equal && !over && !((double)null_count / tuple_count >= 0.9) &&
+                         (uint64_t)uq * 10 <= (uint64_t)N + 10;   // (a 90 % majority leaves room for N / 10 other strings)
+    if (want_mc) {
+        s_x[t] = bm_c;
+        s_y[t] = bm_n;
+        __syncthreads();
+        for (uint32_t stride = BP_WG / 2; stride > 0; stride >>= 1) {
+            if (t < stride) {
+                const uint32_t c0 = s_x[t], n0 = s_y[t], c1 = s_x[t + stride], n1 = s_y[t + stride];
+                uint32_t cc = c0, nn = n0;
+                if (n1) {
+                    if (n0 == 0) {
+                        cc = c1;
+                        nn = n1;
+                    } else if (c0 == c1) {
+                        nn = n0 + n1;
+                    } else if (n1 > n0) {
+                        cc = c1;
+                        nn = n1 - n0;
+                    } else {
+                        nn = n0 - n1;
+                    }
+                }
+                s_x[t] = cc;
+                s_y[t] = nn;
+            }
+            __syncthreads();
+        }
+        const uint32_t cand = s_x[0], cn = s_y[0];
+        __syncthreads();
+        uint32_t mine = 0;
+        if (cn) {
+            for (uint32_t k = t; 2 * k < N; k += BP_WG) {
+                const uint32_t pr = 2 * k + 1 < N ? gld32((const uint32_t*)(slot16 + 2 * k)) : ((uint32_t)ldu16((const uint8_t*)(slot16 + 2 * k)) | 0xFFFF0000u);
+                mine += ((pr & 0xFFFFu) == cand) + ((pr >> 16) == cand && 2 * k + 1 < N);
+            }
+        }
+        mc = bp_sum(mine, s_w);
+    }
+    // ---- choose_compressor (binary/mod.rs:293-348), the arithmetic of choose_bin_impl
+    const double total_bytes = (double)(c.values_len_total + ((uint64_t)N + 1) * sizeof(O));
+    double max_ratio = a.ratio;
+    uint32_t result = a.default_compression;
+    static const uint8_t ORDER[3] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_DICT};
+    for (int oi = 0; oi < 3; oi++) {
+        const uint32_t cd = ORDER[oi];
+        if (forbidden(cd)) continue;
+        double r = 0.0;
+        if (cd == SB_CODEC_ONEVALUE) {
+            r = all_equal ? tuple_count : 0.0;
+        } else if (cd == SB_CODEC_FREQ) {
+            if (!all_equal) {
+                if ((double)null_count / tuple_count >= 0.9)
+                    r = (double)(N - 1);
+                else if ((double)mc / tuple_count >= 0.9)
+                    r = (double)(N - 1);
+            }
+        } else {
+            if (!over && (uint64_t)uq * 3 < N) {
+                uint64_t after = tus + (uint64_t)N * (uint64_t)(bits_needed(uq) / 8);
+                after += (uint64_t)N * 2 / 128;
+                r = total_bytes / (double)after;
+            }
+        }
+        if (r > max_ratio) {
+            max_ratio = r;
+            result = cd;
+            if (r == tuple_count) break;
+        }
+    }
+    const uint32_t codec = result;
+    uint32_t D = 0;
+    if (codec == SB_CODEC_DICT) {
+        // ---- ids in first-occurrence order: bitmap of the first KEYED rows, prefix popcounts, id = rank
+        s_x[t] = 0;
+        s_x[t + BP_WG] = 0;
+        __syncthreads();
+        for (uint32_t sl = t; sl < BP_SLOTS; sl += BP_WG) {
+            const uint32_t wd = tab[sl];
+            if (wd != BP_EMPTY && !(wd & BP_UNKEYED)) atomicOr(&s_x[(wd & 0xFFFFu) >> 5], 1u << (wd & 31u));
+        }
+        __syncthreads();
+        {
+            const uint32_t m0 = (uint32_t)__popc(s_x[2 * t]), m1 = (uint32_t)__popc(s_x[2 * t + 1]);
+            const uint32_t incl = wave_incl_scan(m0 + m1);
+            if (lane == 63) s_w[wv] = incl;
+            __syncthreads();
+            uint32_t run = incl - (m0 + m1);
+            for (uint32_t pw = 0; pw < wv; pw++) run += s_w[pw];
+#pragma unroll
+            for (int k = 0; k < BP_WG / 64; k++) D += s_w[k];
+            s_y[2 * t] = run;
+            s_y[2 * t + 1] = run + m0;
+        }
+        __syncthreads();
+        uint32_t* firsts = aux + BP_W_FIRSTS;
+        for (uint32_t sl = t; sl < BP_SLOTS; sl += BP_WG) {
+            const uint32_t wd = tab[sl];
+            if (wd == BP_EMPTY) continue;
+            uint32_t id = 0xFFFFFFFFu;
+            if (!(wd & BP_UNKEYED)) {
+                const uint32_t r = wd & 0xFFFFu;
+                id = s_y[r >> 5] + (uint32_t)__popc(s_x[r >> 5] & ((1u << (r & 31)) - 1u));
+                gst32(firsts + id, r);
+            }
+            tab[sl] = id;
+        }
+        __syncthreads();
+        // ---- the u32 index array (the last N words of the aux area, where the emitter's LZ4 scratch does not reach)
+        uint32_t* idx = aux + bh_table_slots(N) + 2 * (uint64_t)N;
+        if (!vv.bits) {
+            for (uint32_t k = t; 2 * k < N; k += BP_WG) {
+                if (2 * k + 1 < N) {
+                    const uint32_t pr = gld32((const uint32_t*)(slot16 + 2 * k));
+                    gst64((uint64_t*)(idx + 2 * k), (uint64_t)tab[pr & 0xFFFFu] | ((uint64_t)tab[pr >> 16] << 32));
+                } else {
+                    gst32(idx + 2 * k, tab[ldu16((const uint8_t*)(slot16 + 2 * k))]);
+                }
+            }
+        } else {
+            // a null row repeats the index before it (dict.rs:46-55): per 64-row chunk (a wave's step) the last keyed id, an
+            // inclusive "last one that has any" scan over the <= 1024 chunks, then the rows with the carry of the chunk before
+            const uint32_t nch = (N + 63) / 64;
+            for (uint32_t base = 0; base < N; base += BP_WG) {
+                const uint32_t i = base + t;
+                const bool kd = i < N && (i == 0 || vv.get(i));
+                const uint32_t sid = kd ? tab[ldu16((const uint8_t*)(slot16 + i))] : 0u;
+                const uint64_t km = __ballot(kd);
+                const uint32_t last = __shfl(sid, km ? 63 - __clzll((long long)km) : 0, 64);
+                if (lane == 0 && base / 64 + wv < nch) s_x[base / 64 + wv] = km ? last : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            {
+                const uint32_t v = t < nch ? s_x[t] : 0xFFFFFFFFu;
+                const uint64_t hm = __ballot(v != 0xFFFFFFFFu);
+                const uint64_t below = hm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+                const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
+                const uint32_t got = __shfl(v, (int)src, 64);
+                uint32_t incl = below ? got : 0xFFFFFFFFu;
+                if (lane == 63) s_w[wv] = incl;
+                __syncthreads();
+                if (incl == 0xFFFFFFFFu)
+                    for (int pw = (int)wv - 1; pw >= 0; pw--)
+                        if (s_w[pw] != 0xFFFFFFFFu) {
+                            incl = s_w[pw];
+                            break;
+                        }
+                s_y[t] = incl;
+            }
+            __syncthreads();
+            for (uint32_t base = 0; base < N; base += BP_WG) {
+                const uint32_t i = base + t;
+                const bool kd = i < N && (i == 0 || vv.get(i));
+                const uint32_t sid = kd ? tab[ldu16((const uint8_t*)(slot16 + i))] : 0u;
+                const uint64_t km = __ballot(kd);
+                const uint64_t below = km & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+                const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
+                const uint32_t got = __shfl(sid, (int)src, 64);
+                const uint32_t ch = base / 64 + wv;
+                const uint32_t carry = ch ? s_y[ch - 1] : 0u;
+                if (i < N) gst32(idx + i, below ? got : carry);
+            }
+        }
+    }
+    if (t == 0) {
+        gst32(aux + BH_W_D, D);
+        gst32(aux + BH_W_BAD, 0u);
+        gst32(aux + BH_W_MAGIC, codec == SB_CODEC_DICT ? BH_MAGIC2 : 0u);
+        gst32(aux + BH_W_FUSED, BP_DONE);
+        a.codecs[page] = (int32_t)codec;
+        atomicAdd(&a.codec_counts[codec & 31], 1u);
+        if (!has_device_encoder(codec))
+            raise(a.status, SB_ERR_NYI, page, 700 + codec);
+        else if (codec == SB_CODEC_FREQ)
+            atomicAdd(a.freq_count, 1u);
+    }
+}

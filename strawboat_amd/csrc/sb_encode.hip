@@ -124,6 +124,7 @@ struct EncodeArgs {
     uint8_t* zpar_scratch;          // Zstd: encoder scratch of the chunk waves (ZPAR_WAVES x zstd_scratch_bytes(ZPAR_CH))
     uint32_t pre_hashed;            // k_enc_bin_hash ran before the selector: the h64 arrays of adaptive binary pages are filled
     uint32_t redo;                  // k_enc_select: second pass over the binary pages k_enc_bin_verify failed (no tags, exact count)
+    uint32_t bin_fused;             // k_enc_bin_page (sb_bin_page.h) ran in front of the binary chain: the pages it decided are skipped
 };
 constexpr uint32_t ZPAR_CH = 32768;      // a Zstd frame's blocks when they are compressed by waves of their own (measured on C5, write / read GB/s: 16 KiB 129 / 171, 32 KiB 147 / 201, 64 KiB 90 / 175)
 constexpr uint32_t ZPAR_CH_SMALL = 16384; // ... in calls with fewer pieces than chunk waves
@@ -3038,6 +3039,35 @@ __device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const E
 // The builder's side of bin_dict_handover: the selector of this launch left id16[slot], firsts[id], D and the slot of every
 // row in the aux area; what remains is the index of every row — a keyed row takes its key's id, a null row repeats the
 // index before it (binary/dict.rs:55-93) — one streaming pass with the id table in LDS.
+// ---- k_enc_bin_page (sb_bin_page.h): what the page kernels below need to know about it
+#ifndef SB_BIN_BIG_ROWS
+#define SB_BIN_BIG_ROWS (1ull << 18)
+#endif
+constexpr uint64_t BP_BIG_ROWS = SB_BIN_BIG_ROWS;   // (= BIN_BIG_ROWS of sb_select_big.h: such pages take the section-parallel path)
+constexpr int BP_WG = 1024;
+constexpr uint32_t BP_SLOTS = 32768;          // limit (<= 21 845) + one step of the whole workgroup (4096) never fills it
+constexpr uint32_t BP_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t BP_UNKEYED = 0x10000u;
+constexpr uint64_t BP_MIN_ROWS = 512;
+constexpr uint32_t BH_W_FUSED = 3;            // aux word: BP_DONE when this kernel decided the page in this call
+constexpr uint32_t BP_DONE = 0x46555345u;
+constexpr uint32_t BH_MAGIC2 = 0x48444232u;   // aux[BH_W_MAGIC]: a dictionary in the layout below was handed over
+constexpr uint32_t BP_W_FIRSTS = 16;          // firsts[<= (N - 1) / 3], then slot16[N]; idx in the last N words of the aux area
+__host__ __device__ __forceinline__ uint64_t bp_w_slot16(uint64_t N) { return (BP_W_FIRSTS + N / 3 + 2 + 3) & ~3ull; }
+__host__ __device__ __forceinline__ bool bp_fits(uint64_t N, uint64_t aux_bytes) {
+    const uint64_t M = bh_table_slots(N);
+    return N >= BP_MIN_ROWS && N <= 65536 && bp_w_slot16(N) + (N + 1) / 2 + 4 <= M && aux_bytes / 4 >= M + 3 * N;
+}
+// the pages this kernel takes: a pure function of the launch and the page (every later kernel asks the same question)
+__device__ __forceinline__ bool bp_page_ok(const EncodeArgs& a, const EncPage& p, uint32_t page) {
+    return a.bin_fused && a.use_counts && a.page_base == 0 && page < a.n_pages && a.has_ratio && p.codec == CODEC_ON_DEVICE &&
+           p.h64_off != ~0ull && p.aux_bytes && bp_fits(p.rows, p.aux_bytes) && !(p.rows >= BP_BIG_ROWS && p.bigx_off) &&
+           !(((a.forbidden | p.forb_extra) >> SB_CODEC_DICT) & 1);
+}
+__device__ __forceinline__ bool bp_page_done(const EncodeArgs& a, const EncPage& p, uint32_t page) {
+    return bp_page_ok(a, p, page) && gld32((const uint32_t*)(a.scratch + p.aux_off) + BH_W_FUSED) == BP_DONE;
+}
+
 template <class O>
 __device__ uint32_t bin_dict_from_handover(const BinKeys<O>& bk, uint64_t N, uint32_t* aux, uint32_t** idx_out, uint32_t** firsts_out,
                                            uint32_t* sA, uint32_t* sB, uint32_t* lds_id16 /* BH_SLOTS / 2 words */, uint32_t* s_w) {
@@ -3132,7 +3162,11 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         // the selector of this launch built the dictionary (tables in the aux area) and k_enc_bin_verify compared the strings
         const bool handed = p.codec == CODEC_ON_DEVICE && p.h64_off != ~0ull && lds_slots >= BH_SLOTS && bh_fits(N, p.aux_bytes) &&
                             gld32(aux + BH_W_MAGIC) == BH_MAGIC && gld32(aux + BH_W_BAD) == 0;
-        if (handed) {
+        if (bp_page_done(a, p, page) && gld32(aux + BH_W_MAGIC) == BH_MAGIC2) {   // ids, first rows and the index array by k_enc_bin_page
+            idx = aux + bh_table_slots(N) + 2 * N;
+            firsts = aux + BP_W_FIRSTS;
+            D = gld32(aux + BH_W_D);
+        } else if (handed) {
             D = bin_dict_from_handover<O>(ko, N, aux, &idx, &firsts, sA, sB, sC, s_w);
             STL(27);
         } else if (p.h64_off != ~0ull) {   // hashed rows: computed by the selector of this call, or here when the codec was forced
@@ -3263,6 +3297,7 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
 #include "sb_select_runs.h"
 #include "sb_select_big.h"
 #include "sb_dict_big.h"
+#include "sb_bin_page.h"
 
 // Binary pages hash strings: a probe that misses the LDS tier costs a random HBM access per row (13 GB of traffic for
 // 1.15 GB of C3 input when the table sat in HBM), so their LDS table is 16 Ki slots (~10 000 distinct strings per page).
@@ -3283,6 +3318,7 @@ __global__ void __launch_bounds__(WG) k_enc_bin_hash(EncodeArgs a) {
     if (p.codec != CODEC_ON_DEVICE || p.h64_off == ~0ull) return;
     const uint64_t r0 = (uint64_t)blockIdx.y * BH_ROWS;
     if (r0 >= p.rows) return;
+    if (bp_page_done(a, p, page)) return;   // decided by k_enc_bin_page
     const EncCol c = get_col(a, p.col);
     const uint64_t r1 = min(p.rows, r0 + BH_ROWS);
     uint64_t* h64 = (uint64_t*)(a.scratch + p.h64_off);
@@ -3331,6 +3367,7 @@ __global__ void __launch_bounds__(WG) k_enc_bin_verify(EncodeArgs a, uint32_t ti
     if (p.codec != CODEC_ON_DEVICE || p.h64_off == ~0ull || !p.aux_bytes) return;
     const uint64_t r0 = (uint64_t)tile * BV_ROWS;
     if (r0 >= p.rows) return;
+    if (bp_page_done(a, p, page)) return;   // decided by k_enc_bin_page: its table compares the strings
     uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
     if (!bh_fits(p.rows, p.aux_bytes)) return;
     const uint32_t magic = gld32(aux + BH_W_MAGIC);
@@ -3444,6 +3481,7 @@ __global__ void __launch_bounds__(WG) k_enc_select(EncodeArgs a) {
         }
     }
     if constexpr (KIND < 0) {
+        if (bp_page_done(a, p, page)) return;   // codec and dictionary by k_enc_bin_page (sb_bin_page.h)
         // long binary pages: the statistics over their row hashes section-parallel, the Dict pages among them too
         // (sb_select_big.h / sb_dict_big.h, launched after this kernel)
         if (a.use_counts && !a.redo && a.page_base == 0 && page < a.n_pages && N >= BIN_BIG_ROWS && p.bigx_off && p.h64_off != ~0ull &&
@@ -5499,6 +5537,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (!hit) {
         plan.valid = false;
         plan.counts_valid = false;
+        plan.bin_pages = plan.bin_unfused = false;
         if (!ensure(ctx, plan.pages, P * sizeof(EncPage) + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(page table) failed");
         plan.col_first.assign(n, 0);
         plan.col_pages.assign(n, 0);
@@ -5614,6 +5653,12 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
                 p.aux_bytes = std::max<uint64_t>(p.aux_bytes, big_tab_slots(N) * 8);
             p.h64_off = ~0ull;
             if (bin && p.aux_bytes && N) p.h64_off = 0;   // (placed with the aux areas below)
+            if (bin && adaptive) {
+                plan.bin_pages = true;
+                if (!(p.h64_off == 0 && opts->has_default_compress_ratio && bp_fits(N, p.aux_bytes) && !(N >= BP_BIG_ROWS && p.bigx_off) &&
+                      !((forb >> SB_CODEC_DICT) & 1)))
+                    plan.bin_unfused = true;
+            }
             p.zst_off = ~0ull;
             if (c.physical_type != SB_TYPE_NULL &&
                 (codec == SB_CODEC_ZSTD || (adaptive && opts->default_compression == SB_CODEC_ZSTD)))
@@ -5796,6 +5841,9 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         aa.use_counts = wave_adaptive && !nested ? 1u : 0u;
         aa.pre_hashed = 0;
         aa.redo = 0;
+        // binary pages of BP_MIN_ROWS .. 65 536 rows: codec and dictionary in one pass (sb_bin_page.h); the chain below only for the rest
+        aa.bin_fused = wave_adaptive && !nested && ctx->bin_fused && plan.bin_pages && !(opts->flags & SB_WRITE_DEBUG_VERIFY_FAIL_BIT) ? 1u : 0u;
+        const bool old_chain = !aa.bin_fused || plan.bin_unfused;
         int n_bin_kinds = 0;
         for (int kd : kinds) n_bin_kinds += kd < 0 ? 1 : 0;
         const bool any_bin = n_bin_kinds > 0;
@@ -5818,6 +5866,14 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         if (multi) side_mask = n_bin_kinds ? 1u : 2u;
         if (multi && n_bin_kinds == (int)kinds.size()) side_mask = 0;   // (only binary kinds: nothing to overlap with)
         auto launch_hash = [&](hipStream_t st) {   // row hashes of the binary pages, tile-parallel, before their selector
+            if (aa.bin_fused) {
+                KScope k(ctx, "k_enc_bin_page");
+                for (int kd : kinds) {
+                    if (kd == -4) k_enc_bin_page<int32_t><<<(uint32_t)P, BP_WG, 0, st>>>(aa);
+                    if (kd == -8) k_enc_bin_page<int64_t><<<(uint32_t)P, BP_WG, 0, st>>>(aa);
+                }
+            }
+            if (!old_chain) return;
             KScope k(ctx, "k_enc_bin_hash");
             k_enc_bin_hash<<<tile_grid, WG, 0, st>>>(aa);
         };
@@ -5972,7 +6028,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
             }
             char nm[48];
             snprintf(nm, sizeof nm, "k_enc_select<%d>", kd);
-            {
+            if (kd > 0 || kd == 0 || old_chain) {
                 KScope k(ctx, nm);
                 enc_select_kernel(kd)<<<(uint32_t)P, WG, 0, st>>>(aa);
             }
@@ -5981,6 +6037,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
         // the dictionaries the binary selectors handed over: strings checked tile-parallel, pages that failed selected again
         // exactly (workgroups of all other pages return at once); kd_only: the one binary kind of this stream, or 0 = both
         auto launch_verify = [&](int kd_only, hipStream_t st) {
+            if (!old_chain) return;
             {
                 KScope k(ctx, "k_enc_bin_verify");
                 const uint32_t tpp = (uint32_t)((max_rows + BV_ROWS - 1) / BV_ROWS);

@@ -166,7 +166,11 @@ struct sb_ctx {
         // written by the one-workgroup kernels as before, so a wrong guess only costs time
         uint32_t last_counts[32] = {0};
         bool counts_valid = false;
+        // binary pages of an adaptive call: any of them, and any that k_enc_bin_page (sb_bin_page.h) does not take (too
+        // short / long): only those still need the hash -> select -> verify chain
+        bool bin_pages = false, bin_unfused = false;
     } enc_plan;
+    bool bin_fused = true;   // SB_BIN_FUSED=0: binary pages through the round-3 chain (A/B measurements, tests)
     std::vector<uint64_t> enc_plan_probe;   // the key words of the call at hand
     // side streams: kernels of a call that work on disjoint pages (the selector / emit chains of different column kinds, the
     // three expand kernels of a read) run side by side between a fork and a join on `stream`; seen from outside the call is

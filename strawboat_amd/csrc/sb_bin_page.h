@@ -51,20 +51,17 @@ __device__ __forceinline__ uint32_t bp_hash_fin(uint32_t h) {
 __device__ __forceinline__ uint32_t bp_hash_init(uint32_t n) { return n * 0x9E3779B1u + 0x85EBCA6Bu; }
 __device__ uint32_t bp_hash_mem(const uint8_t* values, uint64_t b, uint32_t n) {
     uint32_t h = bp_hash_init(n);
-    for (uint32_t k = 0; k < n; k += 4) {
+    const uint32_t nd = n <= 4 * BP_REGW ? 4 * BP_REGW : n;   // (the register form runs over all its dwords, zeros included)
+    for (uint32_t k = 0; k < nd; k += 4) {
         uint32_t d = 0;
         for (uint32_t q = 0; q < 4 && k + q < n; q++) d |= (uint32_t)ldu8(values + b + k + q) << (8 * q);
         h = bp_hash_step(h, d);
     }
     return bp_hash_fin(h);
 }
-__device__ __forceinline__ uint32_t bp_dmask(uint32_t n, uint32_t k) {   // mask of the bytes of dword k that belong to a string of n bytes
-    const uint32_t have = n > 4 * k ? n - 4 * k : 0;
-    return have >= 4 ? 0xFFFFFFFFu : (1u << (8 * have)) - 1u;
-}
 template <class O>
 __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
-    __shared__ uint32_t tab[BP_SLOTS];
+    __shared__ __attribute__((aligned(16))) uint32_t tab[BP_SLOTS];
     __shared__ uint32_t s_x[2048];   // vote candidates | bitmap of first rows | last keyed id per 64-row chunk
     __shared__ uint32_t s_y[2048];   // vote counts | word prefixes | carried id per chunk
     __shared__ uint32_t s_w[BP_WG / 64];
@@ -84,73 +81,89 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     const uint64_t vlen = c.values_len;
     const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
     const BinKeys<O> bk{offs, values, vv};
+    STL(60);
     for (uint32_t i = t; i < BP_SLOTS; i += BP_WG) tab[i] = BP_EMPTY;
     if (t == 0) {
         s_cnt = 0;
         s_tus = 0;
     }
     __syncthreads();
+    STL(61);
     const uint32_t limit = (N - 1) / 3;
     uint32_t bm_c = 0, bm_n = 0;
     unsigned long long my_tus = 0, slow_rows = 0;   // (bit k: row k * BP_WG + t)
     constexpr int U = 4;
     const uint8_t* dummy = (const uint8_t*)aux;   // 64 readable bytes for the loads of lanes that have nothing to load
+    const uint8_t* vsafe = vlen >= 32 ? values : dummy;   // (uniform) base of the 32-byte loads: idle lanes read its first bytes
+    using Off = typename std::conditional<sizeof(O) == 4, uint32_t, uint64_t>::type;   // (Arrow offsets are not negative)
+    // The table is 8192 BUCKETS of four slots (one ds_read_b128 per probe): a key takes the first free slot of its bucket —
+    // slots fill in order and are never freed, so a string's copies find it there — and moves on to the next bucket only
+    // when all four hold other keys.  With one slot per probe a tenth of the rows needed a second round, and a round costs
+    // the whole wave ~500 instructions whatever the number of lanes that still look.
+    constexpr uint32_t NBUCK = BP_SLOTS / 4;
+    // offsets and validity bytes of a step are requested one step ahead (they depend on nothing)
+    uint64_t po0[U], po1[U];
+    uint32_t pvb[U];
+    auto request = [&](uint32_t base) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = base + (uint32_t)u * BP_WG + t;
+            const uint32_t ic = i < N ? i : N - 1;
+            if constexpr (sizeof(O) == 4) {
+                po0[u] = ldu64(offs + (uint64_t)ic * 4);
+                po1[u] = 0;
+            } else {
+                po0[u] = ldu64(offs + (uint64_t)ic * 8);
+                po1[u] = ldu64(offs + (uint64_t)ic * 8 + 8);
+            }
+            pvb[u] = vv.bits ? (uint32_t)ldu8(vv.bits + ((vv.off + ic) >> 3)) : 0xFFu;
+        }
+    };
+    request(0);
     for (uint32_t base = 0; base < N; base += BP_WG * U) {
+        STL(80 + base / (BP_WG * U));
         // (no barrier in the loop: every wave adds its inserts before it looks again, so the count overshoots the limit by at
         // most one step of the 16 waves = 4096 keys)
         if (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > limit) break;
-        // Every phase issues the loads of its U rows together, unconditionally (idle lanes read `dummy`): the step is four
-        // round trips — offsets, bytes, the representatives' offsets, their bytes — whatever the rows hold.
-        uint64_t b[U];
-        uint32_t len[U], home[U], word[U], w[U][BP_REGW];
-        uint32_t pend = 0, fastm = 0, keyedm = 0;
-        {
-            uint64_t o0[U], o1[U];
-            uint32_t vb[U];
+        // Every phase issues the loads of its U rows together, unconditionally (idle lanes read the buffer's first bytes): a
+        // step is three round trips — bytes, the representatives' offsets, their bytes — whatever the rows hold.
+        Off b[U];
+        uint32_t len[U], hb[U], fin[U], word[U], w[U][BP_REGW];   // hb: the bucket a row looks at; fin: the slot it settled in
+        uint32_t pend = 0, fastm = 0, keyedm = 0, skip = 0;   // skip: 4 bits per row, slots of the bucket whose string differs
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t i = base + (uint32_t)u * BP_WG + t;
-                const uint32_t ic = i < N ? i : N - 1;
-                if constexpr (sizeof(O) == 4) {
-                    o0[u] = ldu64(offs + (uint64_t)ic * 4);
-                } else {
-                    o0[u] = ldu64(offs + (uint64_t)ic * 8);
-                    o1[u] = ldu64(offs + (uint64_t)ic * 8 + 8);
-                }
-                vb[u] = vv.bits ? (uint32_t)ldu8(vv.bits + ((vv.off + ic) >> 3)) : 0xFFu;
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = base + (uint32_t)u * BP_WG + t;
+            const uint32_t ic = i < N ? i : N - 1;
+            Off e;
+            if constexpr (sizeof(O) == 4) {
+                b[u] = (uint32_t)po0[u];
+                e = (uint32_t)(po0[u] >> 32);
+            } else {
+                b[u] = po0[u];
+                e = po1[u];
             }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t i = base + (uint32_t)u * BP_WG + t;
-                const uint32_t ic = i < N ? i : N - 1;
-                uint64_t e;
-                if constexpr (sizeof(O) == 4) {
-                    b[u] = (uint64_t)(int64_t)(int32_t)(uint32_t)o0[u];
-                    e = (uint64_t)(int64_t)(int32_t)(uint32_t)(o0[u] >> 32);
-                } else {
-                    b[u] = o0[u];
-                    e = o1[u];
-                }
-                len[u] = (uint32_t)(e - b[u]);
-                if (i < N && e - b[u] <= 4 * BP_REGW && b[u] + 32 <= vlen) fastm |= 1u << u;
-                else if (i < N) slow_rows |= 1ull << (base / BP_WG + (uint32_t)u);   // (long strings, the column's last rows: second loop)
-                if (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1)) keyedm |= 1u << u;
-            }
+            len[u] = (uint32_t)(e - b[u]);
+            if (i < N && (Off)(e - b[u]) <= 4 * BP_REGW && (uint64_t)b[u] + 32 <= vlen) fastm |= 1u << u;
+            else if (i < N) slow_rows |= 1ull << (base / BP_WG + (uint32_t)u);   // (long strings, the column's last rows: second loop)
+            if (i == 0 || ((pvb[u] >> ((vv.off + ic) & 7)) & 1)) keyedm |= 1u << u;
         }
+        if (base + BP_WG * U < N) request(base + BP_WG * U);
         {
-            u32x4 q0[U], q1[U];
+            u32x4 q0[U];
+            uint64_t q1[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint8_t* pa = ((fastm >> u) & 1) ? values + b[u] : dummy;
-                q0[u] = ldu128(pa);
-                q1[u] = ldu128(pa + 16);
+                const Off o = ((fastm >> u) & 1) ? b[u] : (Off)0;
+                q0[u] = ldu128(vsafe + o);
+                q1[u] = ldu64(vsafe + o + 16);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t n = ((fastm >> u) & 1) ? len[u] : 0;
-                const uint32_t qq[8] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, q1[u].x, q1[u].y, q1[u].z, q1[u].w};
+                const uint32_t nf = n >> 2, tm = (1u << ((n & 3) * 8)) - 1u;
+                const uint32_t qq[6] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, (uint32_t)q1[u], (uint32_t)(q1[u] >> 32)};
 #pragma unroll
-                for (uint32_t k = 0; k < BP_REGW; k++) w[u][k] = qq[k] & bp_dmask(n, k);
+                for (uint32_t k = 0; k < BP_REGW; k++) w[u][k] = qq[k] & (k < nf ? 0xFFFFFFFFu : (k == nf ? tm : 0u));
             }
         }
         pend = fastm;
@@ -159,47 +172,71 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
             const uint32_t i = base + (uint32_t)u * BP_WG + t;
             uint32_t h = bp_hash_init(len[u]);
 #pragma unroll
-            for (uint32_t k = 0; k < BP_REGW; k++) {
-                const uint32_t hn = bp_hash_step(h, w[u][k]);
-                h = 4 * k < len[u] ? hn : h;
-            }
+            for (uint32_t k = 0; k < BP_REGW; k++) h = bp_hash_step(h, w[u][k]);   // (all six dwords, zeros included: see bp_hash_mem)
             h = bp_hash_fin(h);
-            home[u] = h & (BP_SLOTS - 1);
-            uint32_t tag = (h >> 15) & 0x7FFFu;
+            hb[u] = h & (NBUCK - 1);
+            fin[u] = 0;
+            uint32_t tag = (h >> 13) & 0x7FFFu;
             if (tag == 0x7FFFu) tag = 0x7FFEu;
             word[u] = (tag << 17) | (((keyedm >> u) & 1) ? 0u : BP_UNKEYED) | (i & 0xFFFFu);
         }
         uint32_t newk = 0;
+#ifdef SB_BP_DEBUG
+        uint32_t dbg_it = 0;
+        const uint32_t dbg_f0 = fastm;
+#endif
         while (pend) {
-            uint32_t cur[U], rep[U];
-            uint32_t cmp = 0;
+#ifdef SB_BP_DEBUG
+            dbg_it++;
+#endif
+            u32x4 bk4[U];
+            uint32_t rep[U], cur[U];
+            uint32_t cmp = 0, selm = 0;   // selm: two bits per row, the slot of its bucket a row compares with
 #pragma unroll
-            for (int u = 0; u < U; u++) cur[u] = tab[home[u]];
+            for (int u = 0; u < U; u++) {   // (four u32 reads of one aligned bucket: the compiler makes them a ds_read_b128)
+                const l32p bp = (l32p)tab + hb[u] * 4;
+                bk4[u] = u32x4{bp[0], bp[1], bp[2], bp[3]};
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 rep[u] = 0;
+                cur[u] = 0;
                 if (!((pend >> u) & 1)) continue;
-                uint32_t cw = cur[u];
+                // the first slot of the bucket that is free or carries my tag (and was not found to hold another string)
+                const uint32_t sk = (skip >> (4 * u)) & 15u, tg = word[u] >> 17;
+                const uint32_t s4[4] = {bk4[u].x, bk4[u].y, bk4[u].z, bk4[u].w};
+                uint32_t sel = 4, cw = 0;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const bool ok = (s4[k] == BP_EMPTY || (s4[k] >> 17) == tg) && !((sk >> k) & 1);
+                    sel = ok ? (uint32_t)k : sel;
+                    cw = ok ? s4[k] : cw;
+                }
+                if (sel == 4) {   // four other keys: the next bucket
+                    hb[u] = (hb[u] + 1) & (NBUCK - 1);
+                    skip &= ~(15u << (4 * u));
+                    continue;
+                }
+                const uint32_t si = hb[u] * 4 + sel;
                 if (cw == BP_EMPTY) {
-                    cw = atomicCAS(&tab[home[u]], BP_EMPTY, word[u]);
+                    cw = atomicCAS(&tab[si], BP_EMPTY, word[u]);
                     if (cw == BP_EMPTY) {
                         newk++;
                         my_tus += (unsigned long long)len[u] + 8;
                         pend &= ~(1u << u);
+                        fin[u] = si;
                         continue;
                     }
+                    if ((cw >> 17) != tg) continue;   // (another key took the slot: look at the bucket again)
                 }
-                if ((cw >> 17) == (word[u] >> 17)) {
-                    cmp |= 1u << u;
-                    rep[u] = cw & 0xFFFFu;
-                    cur[u] = cw;
-                } else {
-                    home[u] = (home[u] + 1) & (BP_SLOTS - 1);
-                }
+                cmp |= 1u << u;
+                rep[u] = cw & 0xFFFFu;
+                cur[u] = cw;
+                selm |= sel << (2 * u);
             }
             if (cmp) {
-                uint64_t rb[U];
-                uint32_t rl[U], cf = 0;
+                Off rb[U];
+                uint32_t cf = 0;
                 {
                     uint64_t o0[U], o1[U];
 #pragma unroll
@@ -213,43 +250,48 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
                     }
 #pragma unroll
                     for (int u = 0; u < U; u++) {
+                        uint32_t rl;
                         if constexpr (sizeof(O) == 4) {
-                            rb[u] = (uint64_t)(int64_t)(int32_t)(uint32_t)o0[u];
-                            rl[u] = (uint32_t)((uint64_t)(int64_t)(int32_t)(uint32_t)(o0[u] >> 32) - rb[u]);
+                            rb[u] = (uint32_t)o0[u];
+                            rl = (uint32_t)(o0[u] >> 32) - (uint32_t)o0[u];
                         } else {
                             rb[u] = o0[u];
-                            rl[u] = (uint32_t)(o1[u] - rb[u]);
+                            rl = (uint32_t)(o1[u] - o0[u]);
                         }
-                        if (((cmp >> u) & 1) && rl[u] == len[u]) cf |= 1u << u;   // (a representative in here is a row of this loop: 32 readable bytes)
+                        if (((cmp >> u) & 1) && rl == len[u]) cf |= 1u << u;   // (a representative in here is a row of this loop: 32 readable bytes)
                     }
                 }
                 uint32_t eq = 0;
                 {
-                    u32x4 q0[U], q1[U];
+                    u32x4 q0[U];
+                    uint64_t q1[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        const uint8_t* pa = ((cf >> u) & 1) ? values + rb[u] : dummy;
-                        q0[u] = ldu128(pa);
-                        q1[u] = ldu128(pa + 16);
+                        const Off o = ((cf >> u) & 1) ? rb[u] : (Off)0;
+                        q0[u] = ldu128(vsafe + o);
+                        q1[u] = ldu64(vsafe + o + 16);
                     }
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         const uint32_t n = len[u];
-                        const uint32_t qq[8] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, q1[u].x, q1[u].y, q1[u].z, q1[u].w};
+                        const uint32_t nf = n >> 2, tm = (1u << ((n & 3) * 8)) - 1u;
+                        const uint32_t qq[6] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, (uint32_t)q1[u], (uint32_t)(q1[u] >> 32)};
                         uint32_t d = 0;
 #pragma unroll
-                        for (uint32_t k = 0; k < BP_REGW; k++) d |= (qq[k] & bp_dmask(n, k)) ^ w[u][k];
+                        for (uint32_t k = 0; k < BP_REGW; k++) d |= (qq[k] & (k < nf ? 0xFFFFFFFFu : (k == nf ? tm : 0u))) ^ w[u][k];
                         if (((cf >> u) & 1) && d == 0) eq |= 1u << u;
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     if (!((cmp >> u) & 1)) continue;
+                    const uint32_t sel = (selm >> (2 * u)) & 3u, si = hb[u] * 4 + sel;
                     if ((eq >> u) & 1) {
-                        if (word[u] < cur[u]) atomicMin(&tab[home[u]], word[u]);   // (later rows of a class: nothing to do)
+                        if (word[u] < cur[u]) atomicMin(&tab[si], word[u]);   // (later rows of a class: nothing to do)
                         pend &= ~(1u << u);
+                        fin[u] = si;
                     } else {
-                        home[u] = (home[u] + 1) & (BP_SLOTS - 1);
+                        skip |= 1u << (4 * u + sel);   // (one tag, another string)
                     }
                 }
             }
@@ -259,11 +301,15 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
         for (int u = 0; u < U; u++) {
             const uint32_t i = base + (uint32_t)u * BP_WG + t;
             if (!((fastm >> u) & 1)) continue;
-            *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)home[u];
+            const uint32_t sl = fin[u];
+#ifdef SB_BP_DEBUG
+            gst32(aux + bh_table_slots(N) + 2 * (uint64_t)N + i, 0xD0000000u | (dbg_it << 16) | (dbg_f0 << 8) | (fastm << 4) | pend);
+#endif
+            *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)sl;
             if (bm_n == 0) {
-                bm_c = home[u];
+                bm_c = sl;
                 bm_n = 1;
-            } else if (home[u] == bm_c) {
+            } else if (sl == bm_c) {
                 bm_n++;
             } else {
                 bm_n--;
@@ -273,7 +319,9 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     // ---- the rows the loop above left: strings of more than 4 * BP_REGW bytes and the last rows of the column (a 32-byte load
     // would leave the buffer), one at a time, hashed and compared from memory.  A class's smallest row does not depend on the
     // order of the inserts, and the representatives the first loop compared with were rows of the first loop.
+    STL(62);
     __syncthreads();   // (from here on a representative may sit at the buffer's end)
+    STL(63);
     while (slow_rows) {
         if (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > limit) break;
         const uint32_t k = (uint32_t)__ffsll((long long)slow_rows) - 1;
@@ -282,14 +330,16 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
         const uint64_t b0 = bk.beg(i);
         const uint32_t n = (uint32_t)(bk.beg((uint64_t)i + 1) - b0);
         const uint32_t h = bp_hash_mem(values, b0, n);
-        uint32_t hm = h & (BP_SLOTS - 1);
-        uint32_t tag = (h >> 15) & 0x7FFFu;
+        uint32_t hbk = h & (NBUCK - 1);
+        uint32_t tag = (h >> 13) & 0x7FFFu;
         if (tag == 0x7FFFu) tag = 0x7FFEu;
         const uint32_t wd = (tag << 17) | ((i == 0 || vv.get(i)) ? 0u : BP_UNKEYED) | (i & 0xFFFFu);
-        for (;;) {
-            uint32_t cw = tab[hm];
+        uint32_t si = 0;
+        for (uint32_t q = 0;; q++) {   // slot q & 3 of the bucket; slots fill in order
+            si = hbk * 4 + (q & 3);
+            uint32_t cw = tab[si];
             if (cw == BP_EMPTY) {
-                cw = atomicCAS(&tab[hm], BP_EMPTY, wd);
+                cw = atomicCAS(&tab[si], BP_EMPTY, wd);
                 if (cw == BP_EMPTY) {
                     atomicAdd(&s_cnt, 1u);
                     my_tus += (unsigned long long)n + 8;
@@ -297,16 +347,16 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
                 }
             }
             if ((cw >> 17) == tag && bk.eq(cw & 0xFFFFu, i)) {
-                if (wd < cw) atomicMin(&tab[hm], wd);
+                if (wd < cw) atomicMin(&tab[si], wd);
                 break;
             }
-            hm = (hm + 1) & (BP_SLOTS - 1);
+            if ((q & 3) == 3) hbk = (hbk + 1) & (NBUCK - 1);
         }
-        *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)hm;
+        *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)si;
         if (bm_n == 0) {
-            bm_c = hm;
+            bm_c = si;
             bm_n = 1;
-        } else if (hm == bm_c) {
+        } else if (si == bm_c) {
             bm_n++;
         } else {
             bm_n--;
@@ -323,6 +373,49 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    STL(64);
+#ifdef SB_BP_DEBUG
+    if (s_cnt <= limit) {   // every row's slot holds a key
+        uint32_t bad = 0, badrow = 0, badslot = 0;
+        for (uint32_t i = t; i < N; i += BP_WG) {
+            const uint32_t sl = ldu16((const uint8_t*)(slot16 + i));
+            if (tab[sl] == BP_EMPTY) {
+                if (!bad) { badrow = i; badslot = sl; }
+                bad++;
+            }
+        }
+        uint32_t neq = 0, neqrow = 0;
+        for (uint32_t i = t; i < N; i += BP_WG) {
+            const uint32_t sl = ldu16((const uint8_t*)(slot16 + i));
+            const uint32_t wd = tab[sl];
+            if (wd != BP_EMPTY && !bk.eq(wd & 0xFFFFu, i)) {
+                if (!neq) neqrow = i;
+                neq++;
+            }
+        }
+        if (neq && page == 0 && t < 400) {
+            const uint32_t i = neqrow;
+            const uint64_t b0 = bk.beg(i);
+            const uint32_t n = (uint32_t)(bk.beg((uint64_t)i + 1) - b0);
+            const uint32_t h = bp_hash_mem(values, b0, n);
+            const uint32_t sl = ldu16((const uint8_t*)(slot16 + i));
+            uint32_t found = 0xFFFFFFFFu;
+            for (uint32_t q = 0; q < BP_SLOTS; q++) {
+                const uint32_t wd = tab[q];
+                if (wd != BP_EMPTY && bk.eq(wd & 0xFFFFu, i)) { found = q; break; }
+            }
+            printf("dbg %08x ", gld32(aux + bh_table_slots(N) + 2 * (uint64_t)N + i));
+            printf("page %u thread %u row %u (+%u more) len %u: slot16 %u holds %08x; hash %08x bucket %u tag %04x; string found in slot %u (%08x)\n", page, t, i, neq - 1, n, sl,
+                   tab[sl], h, h & 8191, (h >> 13) & 0x7FFF, found, found != 0xFFFFFFFFu ? tab[found] : 0u);
+        }
+        if (t == 0) printf("page %u: s_cnt %u\n", page, s_cnt);
+        if (bad) {
+            raise(a.status, SB_ERR_INVALID, page, 900000 + bad);
+            printf("page %u thread %u: %u rows in empty slots, first row %u slot %u\n", page, t, bad, badrow, badslot);
+        }
+    }
+    __syncthreads();
+#endif
     const uint32_t null_count = bp_sum(nulls, s_w);
     const uint32_t uq = s_cnt;
     const uint64_t tus = s_tus;
@@ -364,14 +457,25 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
         const uint32_t cand = s_x[0], cn = s_y[0];
         __syncthreads();
         uint32_t mine = 0;
-        if (cn) {
-            for (uint32_t k = t; 2 * k < N; k += BP_WG) {
-                const uint32_t pr = 2 * k + 1 < N ? gld32((const uint32_t*)(slot16 + 2 * k)) : ((uint32_t)ldu16((const uint8_t*)(slot16 + 2 * k)) | 0xFFFF0000u);
-                mine += ((pr & 0xFFFFu) == cand) + ((pr >> 16) == cand && 2 * k + 1 < N);
+        if (cn) {   // (eight independent loads per thread and step; the word behind an odd N's last row belongs to the area)
+            const uint32_t npair = (N + 1) / 2;
+            for (uint32_t k0 = t; k0 < npair; k0 += BP_WG * 8) {
+                uint32_t pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
+                    pr[u] = gld32((const uint32_t*)slot16 + (k < npair ? k : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
+                    if (k < npair) mine += ((pr[u] & 0xFFFFu) == cand) + ((pr[u] >> 16) == cand && 2 * k + 1 < N);
+                }
             }
         }
         mc = bp_sum(mine, s_w);
     }
+    STL(65);
     // ---- choose_compressor (binary/mod.rs:293-348), the arithmetic of choose_bin_impl
     const double total_bytes = (double)(c.values_len_total + ((uint64_t)N + 1) * sizeof(O));
     double max_ratio = a.ratio;
@@ -406,6 +510,7 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     const uint32_t codec = result;
     uint32_t D = 0;
     if (codec == SB_CODEC_DICT) {
+        STL(66);
         // ---- ids in first-occurrence order: bitmap of the first KEYED rows, prefix popcounts, id = rank
         s_x[t] = 0;
         s_x[t + BP_WG] = 0;
@@ -441,28 +546,52 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
             tab[sl] = id;
         }
         __syncthreads();
+        STL(67);
         // ---- the u32 index array (the last N words of the aux area, where the emitter's LZ4 scratch does not reach)
         uint32_t* idx = aux + bh_table_slots(N) + 2 * (uint64_t)N;
         if (!vv.bits) {
-            for (uint32_t k = t; 2 * k < N; k += BP_WG) {
-                if (2 * k + 1 < N) {
-                    const uint32_t pr = gld32((const uint32_t*)(slot16 + 2 * k));
-                    gst64((uint64_t*)(idx + 2 * k), (uint64_t)tab[pr & 0xFFFFu] | ((uint64_t)tab[pr >> 16] << 32));
-                } else {
-                    gst32(idx + 2 * k, tab[ldu16((const uint8_t*)(slot16 + 2 * k))]);
+            const uint32_t npair = (N + 1) / 2;
+            for (uint32_t k0 = t; k0 < npair; k0 += BP_WG * 8) {
+                uint32_t pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
+                    pr[u] = gld32((const uint32_t*)slot16 + (k < npair ? k : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
+                    if (k >= npair) continue;
+                    const uint32_t i0 = tab[pr[u] & 0xFFFFu];
+                    if (2 * k + 1 < N)
+                        gst64((uint64_t*)(idx + 2 * k), (uint64_t)i0 | ((uint64_t)tab[pr[u] >> 16] << 32));
+                    else
+                        gst32(idx + 2 * k, i0);
                 }
             }
         } else {
             // a null row repeats the index before it (dict.rs:46-55): per 64-row chunk (a wave's step) the last keyed id, an
             // inclusive "last one that has any" scan over the <= 1024 chunks, then the rows with the carry of the chunk before
             const uint32_t nch = (N + 63) / 64;
-            for (uint32_t base = 0; base < N; base += BP_WG) {
-                const uint32_t i = base + t;
-                const bool kd = i < N && (i == 0 || vv.get(i));
-                const uint32_t sid = kd ? tab[ldu16((const uint8_t*)(slot16 + i))] : 0u;
-                const uint64_t km = __ballot(kd);
-                const uint32_t last = __shfl(sid, km ? 63 - __clzll((long long)km) : 0, 64);
-                if (lane == 0 && base / 64 + wv < nch) s_x[base / 64 + wv] = km ? last : 0xFFFFFFFFu;
+            constexpr int V = 4;   // (the loads of four steps together)
+            for (uint32_t base = 0; base < N; base += BP_WG * V) {
+                uint32_t sl[V], vb[V];
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    sl[u] = ldu16((const uint8_t*)(slot16 + ic));
+                    vb[u] = ldu8(vv.bits + ((vv.off + ic) >> 3));
+                }
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    const bool kd = i < N && (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1));
+                    const uint32_t sid = kd ? tab[sl[u]] : 0u;
+                    const uint64_t km = __ballot(kd);
+                    const uint32_t last = __shfl(sid, km ? 63 - __clzll((long long)km) : 0, 64);
+                    const uint32_t ch = (base + (uint32_t)u * BP_WG) / 64 + wv;
+                    if (lane == 0 && ch < nch) s_x[ch] = km ? last : 0xFFFFFFFFu;
+                }
             }
             __syncthreads();
             {
@@ -483,20 +612,31 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
                 s_y[t] = incl;
             }
             __syncthreads();
-            for (uint32_t base = 0; base < N; base += BP_WG) {
-                const uint32_t i = base + t;
-                const bool kd = i < N && (i == 0 || vv.get(i));
-                const uint32_t sid = kd ? tab[ldu16((const uint8_t*)(slot16 + i))] : 0u;
-                const uint64_t km = __ballot(kd);
-                const uint64_t below = km & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
-                const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
-                const uint32_t got = __shfl(sid, (int)src, 64);
-                const uint32_t ch = base / 64 + wv;
-                const uint32_t carry = ch ? s_y[ch - 1] : 0u;
-                if (i < N) gst32(idx + i, below ? got : carry);
+            for (uint32_t base = 0; base < N; base += BP_WG * V) {
+                uint32_t sl[V], vb[V];
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    sl[u] = ldu16((const uint8_t*)(slot16 + ic));
+                    vb[u] = ldu8(vv.bits + ((vv.off + ic) >> 3));
+                }
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    const bool kd = i < N && (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1));
+                    const uint32_t sid = kd ? tab[sl[u]] : 0u;
+                    const uint64_t km = __ballot(kd);
+                    const uint64_t below = km & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+                    const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
+                    const uint32_t got = __shfl(sid, (int)src, 64);
+                    const uint32_t ch = (base + (uint32_t)u * BP_WG) / 64 + wv;
+                    const uint32_t carry = ch && ch <= nch ? s_y[ch - 1] : 0u;
+                    if (i < N) gst32(idx + i, below ? got : carry);
+                }
             }
         }
     }
+    STL(68);
     if (t == 0) {
         gst32(aux + BH_W_D, D);
         gst32(aux + BH_W_BAD, 0u);

@@ -37,9 +37,8 @@ __device__ __forceinline__ uint32_t bp_sum(uint32_t v, uint32_t* s16) {   // sum
 // the 8 masked dwords of a string of <= 32 bytes in registers, and bytewise from memory (long strings, and the last rows of a
 // column, whose 32-byte loads would leave the buffer) — so that the copies of a string meet in one probe sequence wherever they sit.
 constexpr uint32_t BP_REGW = 6;   // dwords of a string held in registers by the row loop (longer strings: the second loop)
-__device__ __forceinline__ uint32_t bp_hash_step(uint32_t h, uint32_t d) {
-    h = (h ^ d) * 0xCC9E2D51u;
-    return (h << 13) | (h >> 19);
+__device__ __forceinline__ uint32_t bp_hash_step(uint32_t h, uint32_t d) {   // rotate + add: v_mul_lo_u32 is quarter rate, six of them
+    return ((h << 5) | (h >> 27)) + d;                                           // per row were a third of the row loop's issue time
 }
 __device__ __forceinline__ uint32_t bp_hash_fin(uint32_t h) {
     h ^= h >> 16;
@@ -48,7 +47,7 @@ __device__ __forceinline__ uint32_t bp_hash_fin(uint32_t h) {
     h *= 0xC2B2AE35u;
     return h ^ (h >> 16);
 }
-__device__ __forceinline__ uint32_t bp_hash_init(uint32_t n) { return n * 0x9E3779B1u + 0x85EBCA6Bu; }
+__device__ __forceinline__ uint32_t bp_hash_init(uint32_t n) { return n + 0x85EBCA6Bu; }
 __device__ uint32_t bp_hash_mem(const uint8_t* values, uint64_t b, uint32_t n) {
     uint32_t h = bp_hash_init(n);
     const uint32_t nd = n <= 4 * BP_REGW ? 4 * BP_REGW : n;   // (the register form runs over all its dwords, zeros included)
@@ -67,6 +66,9 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     __shared__ uint32_t s_w[BP_WG / 64];
     __shared__ uint32_t s_cnt;
     __shared__ unsigned long long s_tus;
+    // byte masks of the six dwords of a string of n <= 24 bytes (row n, eight words): two LDS reads per use instead of ~30
+    // compare / select instructions (each v_cmp -> v_cndmask pair costs a wait state on top)
+    __shared__ __attribute__((aligned(32))) uint32_t s_msk[(4 * BP_REGW + 1) * 8];
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
     const EncPage p = get_page(a, page);
@@ -83,6 +85,10 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     const BinKeys<O> bk{offs, values, vv};
     STL(60);
     for (uint32_t i = t; i < BP_SLOTS; i += BP_WG) tab[i] = BP_EMPTY;
+    if (t < (4 * BP_REGW + 1) * 8) {
+        const uint32_t n = t >> 3, k = t & 7, have = n > 4 * k ? n - 4 * k : 0;
+        s_msk[t] = have >= 4 ? 0xFFFFFFFFu : (1u << (8 * have)) - 1u;
+    }
     if (t == 0) {
         s_cnt = 0;
         s_tus = 0;
@@ -153,17 +159,19 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
             uint64_t q1[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const Off o = ((fastm >> u) & 1) ? b[u] : (Off)0;
-                q0[u] = ldu128(vsafe + o);
-                q1[u] = ldu64(vsafe + o + 16);
+                // (a gather costs the CU's address unit a cycle per ACTIVE lane: idle lanes and short strings stay out)
+                q0[u] = u32x4{0, 0, 0, 0};
+                q1[u] = 0;
+                if ((fastm >> u) & 1) q0[u] = ldu128(values + b[u]);
+                if (((fastm >> u) & 1) && len[u] > 16) q1[u] = ldu64(values + b[u] + 16);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t n = ((fastm >> u) & 1) ? len[u] : 0;
-                const uint32_t nf = n >> 2, tm = (1u << ((n & 3) * 8)) - 1u;
+                const l32p mp = (l32p)s_msk + n * 8;
                 const uint32_t qq[6] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, (uint32_t)q1[u], (uint32_t)(q1[u] >> 32)};
 #pragma unroll
-                for (uint32_t k = 0; k < BP_REGW; k++) w[u][k] = qq[k] & (k < nf ? 0xFFFFFFFFu : (k == nf ? tm : 0u));
+                for (uint32_t k = 0; k < BP_REGW; k++) w[u][k] = qq[k] & mp[k];
             }
         }
         pend = fastm;
@@ -241,6 +249,8 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
                     uint64_t o0[U], o1[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
+                        o0[u] = o1[u] = 0;
+                        if (!((cmp >> u) & 1)) continue;
                         if constexpr (sizeof(O) == 4) {
                             o0[u] = ldu64(offs + (uint64_t)rep[u] * 4);
                         } else {
@@ -267,18 +277,18 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
                     uint64_t q1[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        const Off o = ((cf >> u) & 1) ? rb[u] : (Off)0;
-                        q0[u] = ldu128(vsafe + o);
-                        q1[u] = ldu64(vsafe + o + 16);
+                        q0[u] = u32x4{0, 0, 0, 0};
+                        q1[u] = 0;
+                        if ((cf >> u) & 1) q0[u] = ldu128(values + rb[u]);
+                        if (((cf >> u) & 1) && len[u] > 16) q1[u] = ldu64(values + rb[u] + 16);
                     }
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        const uint32_t n = len[u];
-                        const uint32_t nf = n >> 2, tm = (1u << ((n & 3) * 8)) - 1u;
+                        const l32p mp = (l32p)s_msk + (((cf >> u) & 1) ? len[u] : 0u) * 8;
                         const uint32_t qq[6] = {q0[u].x, q0[u].y, q0[u].z, q0[u].w, (uint32_t)q1[u], (uint32_t)(q1[u] >> 32)};
                         uint32_t d = 0;
 #pragma unroll
-                        for (uint32_t k = 0; k < BP_REGW; k++) d |= (qq[k] & (k < nf ? 0xFFFFFFFFu : (k == nf ? tm : 0u))) ^ w[u][k];
+                        for (uint32_t k = 0; k < BP_REGW; k++) d |= (qq[k] & mp[k]) ^ w[u][k];
                         if (((cf >> u) & 1) && d == 0) eq |= 1u << u;
                     }
                 }

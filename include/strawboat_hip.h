@@ -425,6 +425,13 @@ int32_t sb_ctx_zstd_block_stats(sb_ctx* ctx, uint64_t out[4]);
  * the one that ran.  Does not synchronise. */
 uint64_t sb_ctx_side_forks(sb_ctx* ctx);
 
+/* Synchronize intervals since the context was created that were issued a second time: a call skips kernels that the
+ * previous calls of the same shape did not need (long-page Dict / Freq writers, the block-parallel LZ4 reader, emitters of
+ * codecs no page chose); when a page needs one after all it is left undone, and sb_ctx_synchronize re-issues the
+ * interval's sb_write_columns / sb_read_columns calls with everything launched before it returns.  Results are the same
+ * either way; the counter lets tests show which path ran.  Does not synchronise. */
+uint64_t sb_ctx_replays(sb_ctx* ctx);
+
 /* version / build info string ("strawboat-hip <ver> gfx950") */
 const char* sb_version(void);
 

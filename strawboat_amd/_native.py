@@ -17,7 +17,7 @@ SB_WRITE_LZ4_EXACT = 1
 # every symbol include/strawboat_hip.h declares
 EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
            "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns",
-           "sb_ctx_profile", "sb_ctx_profile_read", "sb_ctx_zstd_block_stats", "sb_ctx_side_forks", "sb_nested_levels_bound", "sb_nested_write_levels",
+           "sb_ctx_profile", "sb_ctx_profile_read", "sb_ctx_zstd_block_stats", "sb_ctx_side_forks", "sb_ctx_replays", "sb_nested_levels_bound", "sb_nested_write_levels",
            "sb_nested_read_levels", "sb_nested_write_levels_batch", "sb_nested_read_levels_batch", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
            "sb_file_writer_write_column", "sb_file_writer_finish", "sb_file_writer_close", "sb_file_reader_open",
            "sb_file_reader_n_columns", "sb_file_reader_column", "sb_file_reader_schema", "sb_file_reader_read_pages",
@@ -143,6 +143,8 @@ def load():
     L.sb_ctx_profile.argtypes = [C.c_void_p, C.c_int32]
     L.sb_ctx_side_forks.restype = C.c_uint64
     L.sb_ctx_side_forks.argtypes = [C.c_void_p]
+    L.sb_ctx_replays.restype = C.c_uint64
+    L.sb_ctx_replays.argtypes = [C.c_void_p]
     L.sb_ctx_zstd_block_stats.restype = C.c_int32
     L.sb_ctx_zstd_block_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.sb_ctx_profile_read.restype = C.c_uint32

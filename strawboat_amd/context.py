@@ -78,6 +78,10 @@ class Context:
         """calls so far whose kernels were spread over side streams next to this context's stream (diagnostics)"""
         return int(self._lib.sb_ctx_side_forks(self._h))
 
+    def replays(self):
+        """synchronize intervals so far that were issued a second time because a kernel skipped on a hint was needed after all"""
+        return int(self._lib.sb_ctx_replays(self._h))
+
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated up to the last synchronize()."""
         arr = (N.KernelStatC * 96)()

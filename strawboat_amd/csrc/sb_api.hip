@@ -183,6 +183,7 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
     if (const char* e = getenv("SB_ZSTD_BLOCKS")) ctx->zb_mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
     if (const char* e = getenv("SB_ZSTD_BLOCKS_WG")) ctx->zb_wg_exec = e[0] != '0';
     if (const char* e = getenv("SB_BIN_FUSED")) ctx->bin_fused = e[0] != '0';
+    if (const char* e = getenv("SB_NO_HINTS")) ctx->no_hints = e[0] != '0';
     if (const char* e = getenv("SB_ZSTD_BLOCKS_MIN")) ctx->zb_min_csize = (uint32_t)strtoul(e, nullptr, 10);
     // tests: divide the block pipeline's pool estimates so that a call runs out of pool space part-way (frames that do not
     // fit go back to the frame-serial decoder)
@@ -331,8 +332,16 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
             ctx->zstd_recent = false;
         }
         ctx->read_calls = 0;
-        if (ctx->h_status->kinds & KIND_LZ4_GIANT) ctx->lzg_state = 1;
-        else if (ctx->lzg_long_pages && ctx->lzg_state == 1) ctx->lzg_state = 2;
+        // (three intervals with long pages and no such block before the chain is dropped: a reader that alternates giant-LZ4
+        // columns with long plain ones keeps it; a wrong 2 costs a replay, not a one-workgroup walk)
+        if (ctx->h_status->kinds & KIND_LZ4_GIANT) {
+            ctx->lzg_state = 1;
+            ctx->lzg_idle = 0;
+        } else if (ctx->lzg_long_pages && ctx->lzg_state == 0) {
+            ctx->lzg_state = 2;
+        } else if (ctx->lzg_long_pages && ctx->lzg_state == 1 && ++ctx->lzg_idle >= 3) {
+            ctx->lzg_state = 2;
+        }
         ctx->lzg_long_pages = false;
         // (not sticky: what the calls since the last synchronize looked like decides the order of the next call's entropy kernels)
         if (ctx->h_status->kinds & KIND_ZSTD) ctx->zb_seq_long = (ctx->h_status->kinds & KIND_ZSEQ_LONG) != 0;
@@ -340,6 +349,46 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         // kinds_seen keeps what must stay)
         if (ctx->h_status->kinds) (void)hipMemsetAsync(&ctx->d_status->kinds, 0, sizeof ctx->d_status->kinds, ctx->stream);
     }
+    // A page was left undone because a kernel it needed had been skipped on a hint (KIND_REPLAY): drop what the interval
+    // produced and issue its calls again with every kernel launched.  One extra pass instead of a one-workgroup walk.
+    if (e == hipSuccess && (ctx->h_status->kinds & KIND_REPLAY) && ctx->h_status->code == 0 && rc == SB_OK && !ctx->in_replay &&
+        !ctx->calls.empty()) {
+        for (auto& s : ctx->slots) s.in_flight = false;
+        for (auto& sp : ctx->spans) {
+            ctx->free_events.push_back(sp.a);
+            ctx->free_events.push_back(sp.b);
+        }
+        ctx->spans.clear();
+        ctx->pending.clear();
+        ctx->rescued.clear();
+        for (void* p : ctx->stale_host) (void)hipHostFree(p);
+        ctx->stale_host.clear();
+        ctx->copybacks.clear();
+        for (void* p : ctx->temp_dev) (void)hipFree(p);
+        ctx->temp_dev.clear();
+        ctx->stage_rewind();
+        for (auto& log : ctx->freq_logs) {
+            log.reserved = 0;
+            (void)hipMemsetAsync(log.dev, 0, 16, ctx->stream);
+        }
+        std::vector<sb_ctx::Call> calls;
+        calls.swap(ctx->calls);
+        const bool saved = ctx->no_hints;
+        ctx->no_hints = true;
+        ctx->in_replay = true;
+        ctx->replays++;
+        ctx->lzg_state = 1;
+        for (auto& cl : calls) {
+            rc = cl.kind ? sb_write_columns(ctx, (sb_column_write*)cl.cols, cl.n, &cl.opts, cl.mem) : sb_read_columns(ctx, (sb_column_read*)cl.cols, cl.n, cl.mem);
+            if (rc != SB_OK) break;
+        }
+        ctx->no_hints = saved;
+        if (rc != SB_OK) ctx->sticky = rc;
+        rc = sb_ctx_synchronize(ctx);
+        ctx->in_replay = false;
+        return rc;
+    }
+    ctx->calls.clear();
     if (e != hipSuccess) {
         rc = check_hip(ctx, e, "sb_ctx_synchronize");
     } else if (ctx->h_status->code != 0) {
@@ -412,6 +461,7 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
 }
 
 uint64_t sb_ctx_side_forks(sb_ctx* ctx) { return ctx ? ctx->side_forks : 0; }
+uint64_t sb_ctx_replays(sb_ctx* ctx) { return ctx ? ctx->replays : 0; }
 
 int32_t sb_ctx_zstd_block_stats(sb_ctx* ctx, uint64_t out[4]) {
     if (!ctx || !out) return SB_ERR_INVALID;
@@ -681,14 +731,30 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     // LZ4 blocks of megabytes (a one-page column): block-parallel (sb_lz4_giant.h) — tables and entries in a pool of their own
     memset(&a.lzg, 0, sizeof a.lzg);
     a.lzg_chunks = a.lzg_wins = a.lzg_rounds = a.lzg_jobs = 0;
-    if (!sizes_only && max_page_len >= LZG_MIN) {
-        uint64_t out_total = 0, out_max = 0;
+    a.lzg_skipped = 0;
+    if (!sizes_only && max_page_len >= LZG_MIN && ctx->lzg_state == 2 && !ctx->no_hints) {
+        // the context's last intervals met no LZ4 block of megabytes: no pool, no launches; k_inflate_lz4_big leaves such
+        // a block alone and asks for the replay (it used to walk it with one workgroup: 0.8 s for 68 MB)
+        a.lzg_skipped = 1;
+        ctx->lzg_long_pages = true;
+    } else if (!sizes_only && max_page_len >= LZG_MIN) {
+        // the pool holds what the (at most LZG_JOBS) picked blocks need: 16 bytes per compressed byte and 4 per output byte of
+        // the largest candidate pages — not of every page of the call (128 plain 1 M-row columns pinned 27 GB that way)
+        uint64_t out_max = 0;
+        std::vector<std::pair<uint64_t, uint64_t>> cand;   // (page bytes, output bytes of its column's share)
         for (uint64_t i = 0; i < n; i++) {
             const uint64_t o = std::max<uint64_t>(cols[i].values_capacity, (cols[i].rows + 1) * 8);
-            out_total += o + (is_binary_t(cols[i].physical_type) ? (cols[i].rows + 1) * 8 : 0);
             out_max = std::max(out_max, o);
+            for (uint64_t k = 0; k < cols[i].n_pages; k++)
+                if (cols[i].metas[k].length >= LZG_MIN) cand.push_back({cols[i].metas[k].length, o + (is_binary_t(cols[i].physical_type) ? (cols[i].rows + 1) * 8 : 0)});
         }
-        const uint64_t pool = pages_bytes * 16 + pages_bytes / 512 + LZG_JOBS * (uint64_t)LZG_LITS * 16 + out_total * 4 + out_total / 2048 + (LZG_JOBS + 1) * (6 * 256 + (uint64_t)LZG_CH * 8 + 4096) +
+        std::sort(cand.begin(), cand.end(), [](const std::pair<uint64_t, uint64_t>& x, const std::pair<uint64_t, uint64_t>& y) { return x.first + x.second > y.first + y.second; });
+        uint64_t pages_sel = 0, out_sel = 0;
+        for (size_t q = 0; q < cand.size() && q < 2 * LZG_JOBS; q++) {   // (a page holds up to two blocks: queue A and queue B)
+            pages_sel += cand[q].first;
+            out_sel += cand[q].second;
+        }
+        const uint64_t pool = pages_sel * 16 + pages_sel / 512 + LZG_JOBS * (uint64_t)LZG_LITS * 16 + out_sel * 4 + out_sel / 2048 + (LZG_JOBS + 1) * (6 * 256 + (uint64_t)LZG_CH * 8 + 4096) +
                               LZG_JOBS * sizeof(LzgJob) + 1024;
         if (ensure(ctx, ctx->lzg_pool, pool)) {
             a.lzg.jobs = (LzgJob*)ctx->lzg_pool.p;
@@ -812,7 +878,9 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
 }
 
 int32_t sb_read_columns(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem) {
-    return read_columns_impl(ctx, cols, n, mem, false);
+    const int32_t rc = read_columns_impl(ctx, cols, n, mem, false);
+    if (rc == SB_OK && ctx && n && !ctx->in_replay) ctx->calls.push_back(sb_ctx::Call{0, cols, n, sb_write_options{}, mem});
+    return rc;
 }
 
 int32_t sb_read_columns_sizes(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem) {

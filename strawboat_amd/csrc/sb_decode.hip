@@ -1266,12 +1266,17 @@ __global__ void __launch_bounds__(64) k_inflate_lz4(const InflateJob* jobs, cons
 // LZ4 blocks of LZ4_BIG_MIN compressed bytes and more: one workgroup per block (sb_lz4_big.h: sequence starts and match
 // chains by pointer doubling).  Launched only when a page of the call is that long (DecodeArgs.lz4_big_min).
 constexpr uint32_t LZ4_BIG_POOL = 4096;   // (1024 are resident; blocks differ in size by 20 x, so a workgroup per block — handed out by the hardware as slots free — beats a strided pool)
-__global__ void __launch_bounds__(LB_T, 4) k_inflate_lz4_big(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min, uint32_t cap) {
+__global__ void __launch_bounds__(LB_T, 4) k_inflate_lz4_big(const InflateJob* jobs, const uint32_t* count, Status* st, uint32_t big_min, uint32_t cap,
+                                                             uint32_t lzg_skipped) {
     __shared__ Lz4BigLds lds;
     const uint32_t njobs = min(*count, cap);
     for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
         const InflateJob j = jobs[job];
         if (j.codec != SB_CODEC_LZ4 || j.csize < big_min) continue;
+        if (lzg_skipped && j.csize >= LZG_MIN) {   // a block for the block-parallel chain, which this call did not launch: replay
+            if (threadIdx.x == 0) atomicOr(&st->kinds, KIND_REPLAY);
+            continue;
+        }
         const uint32_t e = lz4_inflate_block_wg(j.src, j.csize, j.dst, j.out_len, lds);
         if (e && threadIdx.x == 0) raise(st, SB_ERR_EXTERNAL, j.page, e);
         __syncthreads();
@@ -3013,7 +3018,7 @@ static void launch_lzg(sb_ctx* ctx, const DecodeArgs& a, InflateJob* q, const ui
     // is long enough to qualify), so a context launches them only once it has met an LZ4 block of megabytes: the first call
     // with long pages looks (one host round trip, once per context), later calls go by what the last interval met
     // (Status.kinds, read at every synchronize).
-    if (ctx->lzg_state == 2) return;
+    if (ctx->lzg_state == 2 && !ctx->no_hints) return;
     hipStream_t s = ctx->stream;
     const LzgArgs g = a.lzg;
     const uint32_t NJ = std::max<uint32_t>(1u, a.lzg_jobs);
@@ -3024,7 +3029,7 @@ static void launch_lzg(sb_ctx* ctx, const DecodeArgs& a, InflateJob* q, const ui
         if (ctx->lzg_state == 0) {
             uint32_t nj = 0;
             if (hipMemcpyAsync(&nj, g.njobs, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) nj = 1;
-            ctx->lzg_state = nj ? 1 : 2;
+            if (nj) ctx->lzg_state = 1;   // (none in this queue: the other queue looks for itself; sb_ctx_synchronize settles on 2)
             if (!nj) return;
         }
         k_lzg_clear<<<dim3(64, NJ), 256, 0, s>>>(g);
@@ -3070,7 +3075,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     launch_lzg(ctx, a, a.jobs_a, a.job_counts, a.job_cap_a);
     if (a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big");
-        k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
+        k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a, a.lzg_skipped);
     }
     {
         KScope k(ctx, K_PLAN);
@@ -3104,7 +3109,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
     if (any_binary) launch_lzg(ctx, a, a.jobs_b, a.job_counts + 1, a.job_cap_a);
     if (any_binary && a.lz4_big_min != 0xFFFFFFFFu) {
         KScope k(ctx, "k_inflate_lz4_big(values)");
-        k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a);
+        k_inflate_lz4_big<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_BIG_POOL), LB_T, 0, s>>>(a.jobs_b, a.job_counts + 1, a.status, a.lz4_big_min, a.job_cap_a, a.lzg_skipped);
     }
     // the three expand kernels work on disjoint pages (page-level RLE, tiles of primitives, tiles of binary columns): side
     // by side on streams of their own when the call has both kinds of columns (a mixed schema), joined before the call ends

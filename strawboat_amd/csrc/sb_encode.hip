@@ -125,7 +125,10 @@ struct EncodeArgs {
     uint32_t pre_hashed;            // k_enc_bin_hash ran before the selector: the h64 arrays of adaptive binary pages are filled
     uint32_t redo;                  // k_enc_select: second pass over the binary pages k_enc_bin_verify failed (no tags, exact count)
     uint32_t bin_fused;             // k_enc_bin_page (sb_bin_page.h) ran in front of the binary chain: the pages it decided are skipped
+    uint32_t skips;                 // SKIP_* bits: kernels this call left out because the last call with the same plan did not need them; a page
+                                    // that needs one after all is left unwritten, and k_enc_layout asks for the replay (KIND_REPLAY)
 };
+constexpr uint32_t SKIP_DICT_BIG = 1u, SKIP_FREQ_BIG = 2u, SKIP_EMIT = 4u;
 constexpr uint32_t ZPAR_CH = 32768;      // a Zstd frame's blocks when they are compressed by waves of their own (measured on C5, write / read GB/s: 16 KiB 129 / 171, 32 KiB 147 / 201, 64 KiB 90 / 175)
 constexpr uint32_t ZPAR_CH_SMALL = 16384; // ... in calls with fewer pieces than chunk waves
 constexpr uint32_t ZPAR_WAVES = 2048;     // 8 per CU: what 20 KB of LDS per wave (and 221 VGPRs) keep resident; a larger pool runs a second, thin round
@@ -3723,6 +3726,11 @@ __global__ void __launch_bounds__(WG, (emit_pages_occupancy<KIND, CODEC>()))
         // already emitted: by the fused select + RLE pass / by the section-parallel writers of long pages (sb_dict_big.h)
         if (a.outs[page].pad == 1 && a.outs[page].length != 0) return;
     }
+    if constexpr (CODEC == SB_CODEC_DICT) {
+        // a long page whose section-parallel writers were skipped on a hint: not one workgroup's walk over millions of rows —
+        // the page stays unwritten and the call is replayed (k_enc_layout)
+        if ((a.skips & SKIP_DICT_BIG) && p.bigx_off && page < a.n_pages) return;
+    }
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
     const bool is_bool = c.ptype == SB_TYPE_BOOLEAN;
@@ -4356,6 +4364,7 @@ __global__ void __launch_bounds__(WG, 2) k_enc_freq_prep(EncodeArgs a_in, EncCol
     }
     if (pcodec != SB_CODEC_FREQ) continue;
     if (a.outs[page].length != 0 && a.outs[page].codec == SB_CODEC_FREQ) continue;   // a long page, prepared container-parallel (sb_freq_big.h)
+    if ((a.skips & SKIP_FREQ_BIG) && p.bigx_off && p.rows >= SEL_BIG_ROWS) continue;   // ... whose kernels were skipped on a hint: replay (k_enc_layout)
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_BOOLEAN || c.ptype == SB_TYPE_NULL || p.rows == 0) {
         if (threadIdx.x == 0) raise(a.status, SB_ERR_OUT_OF_SPEC, page, 542);  // no Freq for booleans upstream
@@ -5219,7 +5228,7 @@ __global__ void __launch_bounds__(64) k_enc_layout(EncodeArgs a, const uint64_t*
         }
         const uint64_t my_off = off + incl - sz;
         if (in) {
-            if (length == 0 && c.ptype != SB_TYPE_NULL) bad = true;
+            if ((length == 0 || a.outs[pg].pad == 3) && c.ptype != SB_TYPE_NULL) bad = true;   // (pad 3: a Dict page still waiting for its Freq-coded indices)
             a.outs[pg].out_off = my_off + head;  // the block goes behind the page's head
             res[k] = head + length;
             res[c.n_pages + k] = rows;
@@ -5230,8 +5239,12 @@ __global__ void __launch_bounds__(64) k_enc_layout(EncodeArgs a, const uint64_t*
     const bool any_bad = __ballot(bad) != 0;
     if (lane == 0) {
         res[2 * c.n_pages] = off;
-        if (off > c.out_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 600);
-        if (any_bad) raise(a.status, SB_ERR_EXTERNAL, c.first_page, 601);
+        if (any_bad && a.skips) {   // a page whose kernel was skipped on a hint: the interval is issued again in full
+            atomicOr(&a.status->kinds, KIND_REPLAY);
+        } else {
+            if (off > c.out_cap) raise(a.status, SB_ERR_INVALID, c.first_page, 600);
+            if (any_bad) raise(a.status, SB_ERR_EXTERNAL, c.first_page, 601);
+        }
     }
 }
 
@@ -5319,7 +5332,13 @@ uint64_t sb_write_bound(int32_t physical_type, int32_t is_nullable, uint64_t row
     return total;
 }
 
+static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts, int32_t mem);
 int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts, int32_t mem) {
+    const int32_t rc = write_columns_impl(ctx, cols, n, opts, mem);
+    if (rc == SB_OK && ctx && n && !ctx->in_replay) ctx->calls.push_back(sb_ctx::Call{1, cols, n, *opts, mem});   // (for a replay: sb_host.h)
+    return rc;
+}
+static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts, int32_t mem) {
     if (!ctx || (!cols && n) || !opts) return SB_ERR_INVALID;
     if (n == 0) return SB_OK;
     (void)hipSetDevice(ctx->device);
@@ -5835,7 +5854,13 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     // One wave of select + emit kernels over the table entries [aa.page_base, aa.page_base + P).
     // wave_adaptive: codecs are chosen on the device; wave_codec: the one codec otherwise (-1: several possible).
     // (what the last call with this plan chose: see EncPlan.last_counts)
-    const bool big_hint = hit && plan.counts_valid && adaptive;
+    const bool big_hint = hit && plan.counts_valid && adaptive && !ctx->no_hints;
+    {
+        size_t nbig_prim = plan.bigw[0].size() + plan.bigw[1].size() + plan.bigw[2].size() + plan.bigw[3].size(), nbig = nbig_prim + plan.bigw[4].size();
+        a.skips = 0;
+        if (big_hint && nbig && !((forb >> SB_CODEC_DICT) & 1) && !plan.last_counts[SB_CODEC_DICT]) a.skips |= SKIP_DICT_BIG;
+        if (big_hint && nbig_prim && freq_possible && !plan.last_counts[SB_CODEC_FREQ]) a.skips |= SKIP_FREQ_BIG;
+    }
     auto run_wave = [&](const EncodeArgs& aa_in, bool wave_adaptive, int32_t wave_codec, bool nested) -> int32_t {
         EncodeArgs aa = aa_in;
         aa.use_counts = wave_adaptive && !nested ? 1u : 0u;

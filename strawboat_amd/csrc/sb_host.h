@@ -50,6 +50,7 @@ struct sb_ctx {
 
     int lzg_state = 0;        // sb_lz4_giant.h: 0 = not known yet, 1 = this context meets LZ4 blocks of megabytes, 2 = it does not
     bool lzg_long_pages = false;   // a call since the last synchronize had pages long enough
+    uint32_t lzg_idle = 0;         // intervals in a row with long pages and no LZ4 block of megabytes
     sb::DevBuf lzg_pool;   // sb_lz4_giant.h: tables and entries of LZ4 blocks of megabytes
     sb::DevBuf tables;   // ColDesc / PageTask / PageDesc / TileTask / jobs / counters
     sb::DevBuf scratch;  // per-page aux + inflate areas, encode slots
@@ -170,6 +171,22 @@ struct sb_ctx {
         // short / long): only those still need the hash -> select -> verify chain
         bool bin_pages = false, bin_unfused = false;
     } enc_plan;
+    // Calls of the open synchronize interval, kept so that they can be issued again: kernels whose work the last calls did
+    // not need are skipped on that hint (the long-page Dict / Freq chains, the block-parallel LZ4 reader, emitters of
+    // codecs nobody chose); a page that needed one after all is left undone, the device says so (KIND_REPLAY) and
+    // sb_ctx_synchronize re-issues the interval's calls with every kernel launched — a wrong guess costs one extra pass,
+    // never a one-workgroup walk over a million-row page.  (The callers' column arrays and buffers live until the
+    // synchronize anyway: the results are written into them there.)
+    struct Call {
+        int kind;   // 0 read, 1 write
+        void* cols;
+        uint64_t n;
+        sb_write_options opts;
+        int32_t mem;
+    };
+    std::vector<Call> calls;
+    bool no_hints = false, in_replay = false;   // no_hints: SB_NO_HINTS=1, and during a replay
+    uint64_t replays = 0;                       // sb_ctx_replays
     bool bin_fused = true;   // SB_BIN_FUSED=0: binary pages through the round-3 chain (A/B measurements, tests)
     std::vector<uint64_t> enc_plan_probe;   // the key words of the call at hand
     // side streams: kernels of a call that work on disjoint pages (the selector / emit chains of different column kinds, the

@@ -439,3 +439,39 @@ def test_long_bitpacked_page_with_a_damaged_width_byte(gpu_ctx):
             assert got is None, (blk, byte)
         elif got is not None:
             assert np.array_equal(got, want.view(np.uint8)), (blk, byte)
+
+
+def test_wrong_hints_are_replayed_not_walked(gpu_ctx):
+    """a call skips the long-page Dict / Freq kernels that the last call with the same plan did not need; when a page needs
+    them after all it is left undone, the device says so and sb_ctx_synchronize issues the interval again with everything
+    launched (sb_ctx_replays counts): the bytes are the oracle's, and no call takes the one-workgroup walk (75 ms for a
+    Freq page, 80 ms for a Dict page of this size before).  src/write/common.rs:54-58: one page per column is the default."""
+    import time
+    from tests.test_gpu_select import gpu_encode
+    rng = np.random.default_rng(321)
+    n = 128 * 16000    # 2 M rows
+    sp = np.full(n, 1_000_000, np.int32)
+    m = rng.random(n) < 0.03
+    sp[m] = rng.integers(0, 1 << 30, int(m.sum()))
+    plain = rng.integers(0, 1 << 30, n).astype(np.int32)
+    dic = rng.integers(0, 400, n).astype(np.int32)
+    order = [plain, plain, dic, plain, sp, plain, dic, sp]
+    want = {}
+    for v in (plain, dic, sp):
+        col = dict(ptype=S.T_I32, nullable=False, rows=n, values=v, validity=None, offsets=None)
+        want[id(v)] = gen.oracle_write(col, ratio=2.0, forbidden=())
+    r0 = gpu_ctx.replays()
+    worst = 0.0
+    for k, v in enumerate(order):
+        col = dict(ptype=S.T_I32, nullable=False, rows=n, values=v, validity=None, offsets=None)
+        t0 = time.perf_counter()
+        enc = gpu_encode(gpu_ctx, col, ratio=2.0, forbidden=())
+        dt = time.perf_counter() - t0
+        if k:
+            worst = max(worst, dt)
+        want_pages, want_metas = want[id(v)]
+        assert np.array_equal(enc.metas_array(), want_metas), k
+        assert np.array_equal(enc.pages_numpy(), want_pages), k
+    assert gpu_ctx.replays() - r0 >= 2, "the Dict and Freq pages behind plain ones were written without a replay?"
+    # (host-side wall time of upload + encode + read-back of an 8 MB column: a replay doubles the ~1 ms of kernels)
+    assert worst < 0.060, worst

@@ -642,3 +642,35 @@ def test_giant_block_decoder_rejects_malformed(gpu_ctx, bad):
         device_read(gpu_ctx, bytes_column(np.zeros(n, np.uint8)), pages, metas)
     # the context still works
     test_giant_block_decoder(gpu_ctx, "ext_borders")
+
+
+def test_giant_block_after_plain_long_pages_is_replayed(gpu_ctx):
+    """a context whose last intervals read long pages without an LZ4 block of megabytes stops launching the block-parallel
+    chain; when such a block shows up after all, k_inflate_lz4_big leaves it alone (one workgroup took 0.8 s for 68 MB),
+    the interval is issued again with the chain (sb_ctx_replays) and the bytes are right"""
+    import time
+    from strawboat_amd import read
+    blk = _giant()["sorted_i64"]
+    n_out = _lz4_out_len(blk)
+    want = S.block_decompress(S.LZ4, np.frombuffer(blk, np.uint8), n_out)
+    pages, metas = lz4_page(blk, n_out)
+    plain = np.random.default_rng(1).integers(0, 255, 3 << 20).astype(np.uint8)
+    ppages = np.frombuffer(bytes([S.NONE]) + len(plain).to_bytes(4, "little") * 2 + plain.tobytes(), np.uint8)
+    pmetas = np.array([[9 + len(plain), len(plain)]], np.uint64)
+    pcol = read.ColumnPages(S.T_U8, False, up(gpu_ctx, ppages), pmetas)
+    gcol = read.ColumnPages(S.T_U8, False, up(gpu_ctx, pages), metas)
+    for _ in range(5):      # long pages, no giant block: the chain is dropped
+        got = read.batch_read_columns(gpu_ctx, [pcol])
+        gpu_ctx.synchronize()
+        assert np.array_equal(got[0].values_numpy(), plain)
+    r0 = gpu_ctx.replays()
+    t0 = time.perf_counter()
+    got = read.batch_read_columns(gpu_ctx, [gcol])
+    gpu_ctx.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.array_equal(got[0].values_numpy(), want)
+    assert gpu_ctx.replays() == r0 + 1
+    assert dt < 0.1, dt
+    got = read.batch_read_columns(gpu_ctx, [gcol])     # the chain is on again: no replay
+    gpu_ctx.synchronize()
+    assert np.array_equal(got[0].values_numpy(), want) and gpu_ctx.replays() == r0 + 1

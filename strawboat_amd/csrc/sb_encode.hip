@@ -3726,6 +3726,9 @@ __global__ void __launch_bounds__(WG, (emit_pages_occupancy<KIND, CODEC>()))
         // already emitted: by the fused select + RLE pass / by the section-parallel writers of long pages (sb_dict_big.h)
         if (a.outs[page].pad == 1 && a.outs[page].length != 0) return;
     }
+    if constexpr (CODEC == SB_CODEC_RLE) {
+        if (threadIdx.x == 0 && a.use_counts) atomicAdd(&a.codec_counts[29], 1u);   // (RLE pages the fused selectors did not write: the hint for the next call)
+    }
     if constexpr (CODEC == SB_CODEC_DICT) {
         // a long page whose section-parallel writers were skipped on a hint: not one workgroup's walk over millions of rows —
         // the page stays unwritten and the call is replayed (k_enc_layout)
@@ -5237,6 +5240,7 @@ __global__ void __launch_bounds__(64) k_enc_layout(EncodeArgs a, const uint64_t*
         off += __shfl(incl, 63, 64);
     }
     const bool any_bad = __ballot(bad) != 0;
+    if (lane == 0 && blockIdx.x == 0) a.codec_counts[28] = *a.freq_count;   // (pages that went through the Freq kernels, for the next call's hint)
     if (lane == 0) {
         res[2 * c.n_pages] = off;
         if (any_bad && a.skips) {   // a page whose kernel was skipped on a hint: the interval is issued again in full
@@ -5861,6 +5865,14 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
         if (big_hint && nbig && !((forb >> SB_CODEC_DICT) & 1) && !plan.last_counts[SB_CODEC_DICT]) a.skips |= SKIP_DICT_BIG;
         if (big_hint && nbig_prim && freq_possible && !plan.last_counts[SB_CODEC_FREQ]) a.skips |= SKIP_FREQ_BIG;
     }
+    // launches that the last call with this plan would not have needed (its pages per codec, read back with its results):
+    // skipped; a page that needs one after all stays unwritten and the interval is replayed with everything (k_enc_layout)
+    uint32_t emit_skips = 0;
+    auto unused = [&](int slot) {
+        if (!big_hint || plan.last_counts[slot]) return false;
+        emit_skips |= SKIP_EMIT;
+        return true;
+    };
     auto run_wave = [&](const EncodeArgs& aa_in, bool wave_adaptive, int32_t wave_codec, bool nested) -> int32_t {
         EncodeArgs aa = aa_in;
         aa.use_counts = wave_adaptive && !nested ? 1u : 0u;
@@ -6028,11 +6040,13 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
                         else
                             k_enc_select_runs<8, 2><<<(uint32_t)P, WG, 0, st>>>(aa);
                     }
-                    KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 1>" : "k_enc_select_rle<8, 2>");
-                    if (kd == 4)
-                        k_enc_select_rle<4, 1><<<(uint32_t)P, WG, 0, st>>>(aa);
-                    else
-                        k_enc_select_rle<8, 2><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    if (!unused(31)) {   // (pages the run-level kernel left to the row-level one)
+                        KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 1>" : "k_enc_select_rle<8, 2>");
+                        if (kd == 4)
+                            k_enc_select_rle<4, 1><<<(uint32_t)P, WG, 0, st>>>(aa);
+                        else
+                            k_enc_select_rle<8, 2><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    }
                 }
                 if (any_i) {
                     {
@@ -6042,11 +6056,13 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
                         else
                             k_enc_select_runs<8, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
                     }
-                    KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 0>" : "k_enc_select_rle<8, 0>");
-                    if (kd == 4)
-                        k_enc_select_rle<4, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
-                    else
-                        k_enc_select_rle<8, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    if (!unused(31)) {
+                        KScope k(ctx, kd == 4 ? "k_enc_select_rle<4, 0>" : "k_enc_select_rle<8, 0>");
+                        if (kd == 4)
+                            k_enc_select_rle<4, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
+                        else
+                            k_enc_select_rle<8, 0><<<(uint32_t)P, WG, 0, st>>>(aa);
+                    }
                 }
                 launch_big(kd, st);
                 return;
@@ -6093,6 +6109,8 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
                 }
                 EncPageKernel kf = enc_page_kernel(kd, cd);
                 if (!kf) continue;
+                // (4- / 8-byte RLE pages come out of the fused selectors: slot 29 counts the ones the page kernel had to write)
+                if (wave_adaptive && !nested && unused(cd == SB_CODEC_RLE && (kd == 4 || kd == 8) ? 29 : (int)cd)) continue;
                 char nm[48];
                 snprintf(nm, sizeof nm, "k_enc_emit_pages<%d, %d>", kd, (int)cd);
                 KScope k(ctx, nm);
@@ -6138,13 +6156,19 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
         }
         const int32_t dc = opts->default_compression;
         const bool basic_comp = dc == SB_CODEC_LZ4 || dc == SB_CODEC_ZSTD || dc == SB_CODEC_SNAPPY;
-        if (nested ? (wave_adaptive ? dc == SB_CODEC_NONE : wave_codec == SB_CODEC_NONE) : any_tiles) {
+        if (!nested && wave_adaptive && any_tiles && !aa.null_cols && unused(SB_CODEC_NONE)) {
+            // (no plain page last time; Null columns' empty pages are recorded by this kernel: never skipped then)
+        } else if (nested ? (wave_adaptive ? dc == SB_CODEC_NONE : wave_codec == SB_CODEC_NONE) : any_tiles) {
             KScope k(ctx, K_ENC_TILES);
             // (adaptive: few pages stay plain, so one workgroup per page looks — unless the pages are few and long)
             const uint32_t ty = wave_adaptive ? (uint32_t)std::min<uint64_t>(max_tiles, std::max<uint64_t>(1, 2048 / P)) : (uint32_t)max_tiles;
             k_enc_emit_tiles<<<dim3((uint32_t)P, ty), WG, 0, s>>>(aa, (uint32_t)max_tiles);
         }
-        if (nested ? (wave_adaptive ? basic_comp : (wave_codec >= 1 && wave_codec <= 3)) : any_lz4) {
+        const bool basic_unused = !nested && wave_adaptive && any_lz4 && big_hint && !plan.last_counts[SB_CODEC_LZ4] && !plan.last_counts[SB_CODEC_ZSTD] &&
+                                  !plan.last_counts[SB_CODEC_SNAPPY];
+        if (basic_unused) {
+            emit_skips |= SKIP_EMIT;
+        } else if (nested ? (wave_adaptive ? basic_comp : (wave_codec >= 1 && wave_codec <= 3)) : any_lz4) {
             if (!nested && aa.lzc_plan) {   // blocks of more than one chunk: one wave per chunk, then joined
                 {
                     KScope k(ctx, "k_enc_lz4_plan");
@@ -6235,7 +6259,9 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
 #undef SB_FBIG_W
         }
     }
-    if (freq_possible) {  // Freq pages: bitmap + exceptions, then the exceptions block like any other block
+    if (freq_possible && adaptive && unused(28) ) {
+        // (no page went through the Freq kernels last time: not launched)
+    } else if (freq_possible) {  // Freq pages: bitmap + exceptions, then the exceptions block like any other block
         {
             KScope k(ctx, K_ENC_FREQ);
             k_enc_freq_prep<<<(uint32_t)std::min<uint64_t>(P, 1024), WG, 0, s>>>(a, (EncCol*)(tb + o_vcols), (EncPage*)(tb + o_vpages));
@@ -6269,6 +6295,7 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
         KScope k(ctx, K_ENC_FREQ);
         k_enc_freq_finish<<<(uint32_t)P, WG, 0, s>>>(a);
     }
+    a.skips |= emit_skips;
     {
         KScope k(ctx, K_ENC_LAYOUT);
         k_enc_layout<<<(uint32_t)n, 64, 0, s>>>(a, (const uint64_t*)(tb + o_resoff));

@@ -258,6 +258,11 @@ typedef struct sb_nested_levels_write {
     uint64_t n_pages;               /* result */
 } sb_nested_levels_write;
 int32_t sb_nested_write_levels_batch(sb_ctx* ctx, sb_nested_levels_write* items, uint64_t n, uint64_t max_page_size);
+/* The same without the round trip: enqueues the kernels and returns; items[].n_pages is set at once (host arithmetic),
+ * items[].pages[] are filled by the next sb_ctx_synchronize.  `items` and what it points to must live until then.  A writer
+ * that encodes chunk after chunk of one shape enqueues the level call and the leaf call (sb_write_columns with the page
+ * cut of the chunk before) together and checks the cut afterwards (src/write/serialize.rs:217-232 runs them back to back). */
+int32_t sb_nested_write_levels_enqueue(sb_ctx* ctx, sb_nested_levels_write* items, uint64_t n, uint64_t max_page_size);
 
 /* replaces read_validity_nested (src/read/read_basic.rs:65-173) over all pages of one nested leaf
  * column.  Per level the caller passes DEVICE outputs: `offsets` (lists: column-level i64 offsets,
@@ -291,6 +296,10 @@ typedef struct sb_nested_levels_read {
     uint64_t* page_block_offsets;   /* HOST, n_pages entries, or NULL */
 } sb_nested_levels_read;
 int32_t sb_nested_read_levels_batch(sb_ctx* ctx, sb_nested_levels_read* items, uint64_t n);
+/* The same without the round trip: levels[].length, page_leaf_counts and page_block_offsets are filled by the next
+ * sb_ctx_synchronize; `items` and what it points to must live until then.  A reader that knows the page cut (a second
+ * pass over the same pages) enqueues the level call and sb_read_columns together and compares afterwards. */
+int32_t sb_nested_read_levels_enqueue(sb_ctx* ctx, sb_nested_levels_read* items, uint64_t n);
 int32_t sb_nested_read_levels(sb_ctx* ctx, const uint8_t* pages, uint64_t pages_len, const sb_page_meta* metas,
                               uint64_t n_pages, sb_nested_level_out* levels, uint32_t n_levels,
                               uint8_t* leaf_validity, uint64_t leaf_validity_capacity,

@@ -43,6 +43,15 @@ def main():
         pr.disable()
         st = pstats.Stats(pr)
         st.sort_stats("tottime").print_stats(8)
+        ctx.profile(True)
+        fn()
+        prof = ctx.profile_read()
+        ctx.profile(False)
+        tot = sum(v[1] for v in prof.values())
+        print("%s kernels: %.3f ms in %d launches" % (name, tot, sum(v[0] for v in prof.values())))
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:30]:
+            print("   %-34s %3d  %.3f ms" % (k, v[0], v[1]))
+        print("replays", ctx.replays())
 
 
 if __name__ == "__main__":

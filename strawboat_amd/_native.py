@@ -17,7 +17,7 @@ SB_WRITE_LZ4_EXACT = 1
 # every symbol include/strawboat_hip.h declares
 EXPORTS = ("sb_version", "sb_ctx_create", "sb_ctx_destroy", "sb_ctx_synchronize", "sb_ctx_last_error",
            "sb_ctx_stream", "sb_read_columns", "sb_read_columns_sizes", "sb_write_bound", "sb_write_columns",
-           "sb_ctx_profile", "sb_ctx_profile_read", "sb_ctx_zstd_block_stats", "sb_ctx_side_forks", "sb_ctx_replays", "sb_nested_levels_bound", "sb_nested_write_levels",
+           "sb_ctx_profile", "sb_ctx_profile_read", "sb_ctx_zstd_block_stats", "sb_ctx_side_forks", "sb_ctx_replays", "sb_nested_levels_bound", "sb_nested_write_levels", "sb_nested_write_levels_enqueue", "sb_nested_read_levels_enqueue",
            "sb_nested_read_levels", "sb_nested_write_levels_batch", "sb_nested_read_levels_batch", "sb_file_last_error", "sb_file_writer_open", "sb_file_writer_start",
            "sb_file_writer_write_column", "sb_file_writer_finish", "sb_file_writer_close", "sb_file_reader_open",
            "sb_file_reader_n_columns", "sb_file_reader_column", "sb_file_reader_schema", "sb_file_reader_read_pages",
@@ -163,6 +163,10 @@ def load():
     L.sb_nested_write_levels_batch.argtypes = [C.c_void_p, C.POINTER(NestedLevelsWriteC), C.c_uint64, C.c_uint64]
     L.sb_nested_read_levels_batch.restype = C.c_int32
     L.sb_nested_read_levels_batch.argtypes = [C.c_void_p, C.POINTER(NestedLevelsReadC), C.c_uint64]
+    L.sb_nested_write_levels_enqueue.restype = C.c_int32
+    L.sb_nested_write_levels_enqueue.argtypes = [C.c_void_p, C.POINTER(NestedLevelsWriteC), C.c_uint64, C.c_uint64]
+    L.sb_nested_read_levels_enqueue.restype = C.c_int32
+    L.sb_nested_read_levels_enqueue.argtypes = [C.c_void_p, C.POINTER(NestedLevelsReadC), C.c_uint64]
     L.sb_file_last_error.restype = C.c_char_p
     L.sb_file_writer_open.restype = C.c_int32
     L.sb_file_writer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]

@@ -83,7 +83,8 @@ StageSlot* acquire_slot(sb_ctx* ctx, size_t need) {
     if (s.host)
         for (auto& p : ctx->pending) {
             if (p.host < s.host || p.host >= s.host + s.cap) continue;
-            const size_t nb = p.kind == Pending::READ_COL ? 8 : p.kind == Pending::ENC_HINT ? 128 : (size_t)(2 * p.n + 1) * 8;
+            const size_t nb = p.kind == Pending::READ_COL ? 8 : p.kind == Pending::ENC_HINT ? 128 : (p.kind == Pending::NESTED_W || p.kind == Pending::NESTED_R) ? (size_t)p.bytes
+                                                                                                   : (size_t)(2 * p.n + 1) * 8;
             ctx->rescued.emplace_back(p.host, p.host + nb);
             p.host = ctx->rescued.back().data();
         }
@@ -359,8 +360,16 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
             ctx->free_events.push_back(sp.b);
         }
         ctx->spans.clear();
-        ctx->pending.clear();
-        ctx->rescued.clear();
+        {   // (the page records of enqueued level calls stay: those calls are not issued again)
+            std::vector<Pending> keep;
+            for (auto& p : ctx->pending)
+                if (p.kind == Pending::NESTED_W || p.kind == Pending::NESTED_R) {
+                    ctx->rescued.emplace_back(p.host, p.host + p.bytes);
+                    p.host = ctx->rescued.back().data();
+                    keep.push_back(p);
+                }
+            ctx->pending.swap(keep);
+        }
         for (void* p : ctx->stale_host) (void)hipHostFree(p);
         ctx->stale_host.clear();
         ctx->copybacks.clear();
@@ -430,6 +439,10 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
                 memcpy(ctx->enc_plan.last_counts, p.host, 128);
                 ctx->enc_plan.counts_valid = true;
             }
+        } else if (p.kind == Pending::NESTED_W) {
+            if (rc == SB_OK) nested_write_finish((sb_nested_levels_write*)p.user, p.n, p.host);
+        } else if (p.kind == Pending::NESTED_R) {
+            if (rc == SB_OK) nested_read_finish((sb_nested_levels_read*)p.user, p.n, p.host);
         } else {
             sb_column_write* c = (sb_column_write*)p.user;
             const uint64_t* lens = (const uint64_t*)p.host;  // [n_pages lengths][n_pages num_values][total]

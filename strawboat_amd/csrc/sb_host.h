@@ -23,10 +23,12 @@ struct StageSlot {
 };
 
 struct Pending {  // results to hand back to the caller's structs at synchronize
-    enum Kind { READ_COL, WRITE_COL, ENC_HINT } kind;   // ENC_HINT: the codec counts of a write call (n = the plan's key), 32 words
+    enum Kind { READ_COL, WRITE_COL, ENC_HINT, NESTED_W, NESTED_R } kind;   // ENC_HINT: the codec counts of a write call (n = the plan's key), 32 words
+                                                                           // NESTED_W / _R: the page records of an enqueued level call (user = its items, n = how many)
     void* user;            // sb_column_read* / sb_column_write*
     const uint8_t* host;   // where the readback lands (pinned)
     uint64_t n;            // WRITE_COL: number of pages
+    uint64_t bytes = 0;    // NESTED_*: bytes of the readback at `host`
 };
 
 enum KernelId {
@@ -257,3 +259,7 @@ void side_join(sb_ctx* ctx, uint32_t used_mask);
 StageSlot* acquire_slot(sb_ctx* ctx, size_t need);
 int32_t check_hip(sb_ctx* ctx, hipError_t e, const char* what);
 }  // namespace sb
+
+// sb_nested.hip: the page records of an enqueued level call -> the caller's structs (Pending::NESTED_W / _R)
+void nested_write_finish(sb_nested_levels_write* items, uint64_t n, const uint8_t* host);
+void nested_read_finish(sb_nested_levels_read* items, uint64_t n, const uint8_t* host);

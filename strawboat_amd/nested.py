@@ -97,6 +97,11 @@ class _LevelsWrite:
         if self.n:
             self.ctx._check(self.ctx._lib.sb_nested_write_levels_batch(self.ctx._h, self.items, self.n, self.mps))
 
+    def enqueue(self):
+        """the same without the round trip: info() is valid after the context's next synchronize()"""
+        if self.n:
+            self.ctx._check(self.ctx._lib.sb_nested_write_levels_enqueue(self.ctx._h, self.items, self.n, self.mps))
+
     def info(self, k):
         """(level_bytes, num_values, leaf_start, leaf_count) per page of leaf column k, as the last call() left them"""
         return np.frombuffer(self.keep[k][2], dtype=np.uint64).reshape(-1, 4)[:int(self.items[k].n_pages)]
@@ -201,7 +206,21 @@ class NestedWriteBatch:
         columns alias the batch's output buffers: the next run() overwrites them."""
         ctx = self.ctx
         if not self._fresh:
-            self.lw.call()
+            # The level sections and the leaf BLOCKs are enqueued TOGETHER, the BLOCKs with the page cut of the run before
+            # (src/write/serialize.rs:217-232 writes them back to back); the cut this run's level kernels found comes back
+            # with the results, and only when it differs (other list lengths) are the BLOCKs written again with it.
+            before = [self.lw.info(k).copy() for k in range(self.n)]
+            self.lw.enqueue()
+            try:
+                if self.n:
+                    ctx._check(ctx._lib.sb_write_columns(ctx._h, self.arr, self.n, C.byref(self.oc), N.SB_MEM_DEVICE))
+                ctx.synchronize()
+                same = all(before[k].shape == self.lw.info(k).shape and np.array_equal(before[k][:, (0, 3)], self.lw.info(k)[:, (0, 3)]) for k in range(self.n))
+            except Exception:   # (BLOCKs cut with a stale page table may not even fit: the level call alone, then the checks below)
+                self.lw.call()
+                same = False
+            if same:
+                return [NestedEncodedColumn(pages, metas, self.arr[k], self.lw.info(k)[:, 1].copy()) for k, (pages, metas) in enumerate(self.outs)]
             for k in range(self.n):   # the page cut of THIS call
                 info = self.lw.info(k)
                 if info.shape[0] != self.page_rows[k].shape[0]:
@@ -342,24 +361,51 @@ class NestedReadBatch:
                 self.bufs.append((values, offsets))
         self._fresh = True   # (the level outputs of the first run() are already there)
 
-    def _levels(self):
+    def _levels(self, enqueue_only=False):
         """the level sections of every leaf (one set of launches, one host round trip), then the page table of the BLOCKs"""
         ctx = self.ctx
         if self.n:
+            if enqueue_only:
+                ctx._check(ctx._lib.sb_nested_read_levels_enqueue(ctx._h, self.items, self.n))
+                return
             ctx._check(ctx._lib.sb_nested_read_levels_batch(ctx._h, self.items, self.n))
+        self._page_table()
+
+    def _page_table(self):
+        """leaf counts / BLOCK offsets of the last level call -> the page table of the leaf call; False: nothing changed"""
+        changed = False
         for metas, n_pages, lv, offs, vals, leaf_validity, counts, block_offs, pages, starts, leaf_metas, po in self.prep:
-            leaf_metas[:, 0] = metas[:, 0] - (block_offs[:n_pages] - starts)
+            lm0 = metas[:, 0] - (block_offs[:n_pages] - starts)
+            if not (np.array_equal(leaf_metas[:, 0], lm0) and np.array_equal(leaf_metas[:, 1], counts[:n_pages]) and np.array_equal(po, block_offs[:n_pages])):
+                changed = True
+            leaf_metas[:, 0] = lm0
             leaf_metas[:, 1] = counts[:n_pages]
             po[:] = block_offs[:n_pages]
+        return changed
 
     def run(self) -> List[NestedArray]:
         ctx = self.ctx
         if not self._fresh:
-            self._levels()
-        self._fresh = False
-        if self.n:
-            ctx._check(ctx._lib.sb_read_columns(ctx._h, self.arr, self.n, N.SB_MEM_DEVICE))
-        ctx.synchronize()
+            # level sections and leaf BLOCKs enqueued together, the BLOCKs with the page table of the run before
+            # (src/read/read_basic.rs:65-173 then the leaf decode); the table this run's level kernels found comes back with
+            # the results, and only when it differs (other pages behind the same descriptors) are the BLOCKs read again
+            self._levels(enqueue_only=True)
+            try:
+                if self.n:
+                    ctx._check(ctx._lib.sb_read_columns(ctx._h, self.arr, self.n, N.SB_MEM_DEVICE))
+                ctx.synchronize()
+                again = self._page_table()
+            except Exception:   # (BLOCKs read with a stale page table may look corrupt: the level call alone, then the leaf call)
+                self._levels()
+                again = True
+            if again and self.n:
+                ctx._check(ctx._lib.sb_read_columns(ctx._h, self.arr, self.n, N.SB_MEM_DEVICE))
+                ctx.synchronize()
+        else:
+            self._fresh = False
+            if self.n:
+                ctx._check(ctx._lib.sb_read_columns(ctx._h, self.arr, self.n, N.SB_MEM_DEVICE))
+            ctx.synchronize()
         out = []
         for j in range(self.n):
             d = self.per[j]

@@ -373,3 +373,53 @@ def test_long_leaf_pages_adaptive(gpu_ctx, what):
         assert np.array_equal((go[1:] - go[:-1])[valid], (o64[1:n + 1] - o64[:n])[valid])
         for i in np.flatnonzero(valid)[::211]:
             assert bytes(gvals[go[i]:go[i + 1]]) == bytes(values[o64[i]:o64[i + 1]]), i
+
+
+def test_batch_objects_enqueue_levels_and_leaves_together(gpu_ctx):
+    """run() after the first enqueues the level call and the leaf call TOGETHER, the leaf BLOCKs with the page cut of the
+    run before, and checks the cut when the results are back.  A run whose list lengths moved a leaf slot across a page
+    border (same rows, pages and slots in total) must notice and write / read the BLOCKs again with the new cut."""
+    import torch
+    from strawboat_amd import WriteOptions, nested
+    from strawboat_amd.read import ColumnPages
+    opts = WriteOptions(max_page_size=2048, default_compression=S.LZ4)
+    levels_a, rows = make_nested("list_struct", 20_000, 3)
+    levels_b = [dict(lv) for lv in levels_a]
+    offs = np.asarray(levels_a[0]["offsets"]).copy()
+    r1 = next(r for r in range(100, 2048) if offs[r + 1] - offs[r] >= 1)       # a non-empty list in page 0 ...
+    lvalid = np.unpackbits(np.asarray(levels_a[0]["validity"]), bitorder="little")
+    r2 = next(r for r in range(2048 + 100, 4096) if lvalid[r])                  # ... gives one element to a (non-null) row of page 1
+    offs[r1 + 1:r2 + 1] -= 1
+    levels_b[0] = dict(levels_a[0], offsets=offs)
+    want = {}
+    for name, levels in (("a", levels_a), ("b", levels_b)):
+        dcol, vals, offs_leaf = _leaf_column(gpu_ctx, levels, S.T_I64, 13)
+        enc = nested.write_nested_leaves(gpu_ctx, [(device_levels(gpu_ctx, levels), dcol)], opts)[0]
+        want[name] = (enc.pages_numpy().copy(), enc.metas_array().copy())
+    assert not np.array_equal(want["a"][1], want["b"][1])
+    dl = device_levels(gpu_ctx, levels_a)
+    dcol, vals, offs_leaf = _leaf_column(gpu_ctx, levels_a, S.T_I64, 13)
+    wb = nested.NestedWriteBatch(gpu_ctx, [(dl, dcol)], opts)
+    for name in ("a", "a", "b", "b", "a"):
+        src = levels_a if name == "a" else levels_b
+        dl[0].offsets.copy_(torch.from_numpy(np.ascontiguousarray(src[0]["offsets"]).view(np.uint8).reshape(-1).copy()).to(dl[0].offsets.device))
+        gpu_ctx.synchronize()
+        enc = wb.run()[0]
+        assert np.array_equal(enc.metas_array(), want[name][1]), name
+        assert np.array_equal(enc.pages_numpy(), want[name][0]), name
+    # read side: a stale page table (what a run over other pages would leave) is noticed and the BLOCKs are read again
+    enc = wb.run()[0]
+    kinds = [[lv["kind"] for lv in levels_a]]
+    nul = [[bool(lv["is_optional"]) for lv in levels_a]]
+    cp = ColumnPages(S.T_I64, False, enc.pages[:enc.length].contiguous(), enc.metas_array())
+    ref = nested.read_nested_leaves(gpu_ctx, [cp], kinds, nul)[0]
+    rv, ro = ref.leaf.values_numpy().copy(), ref.offsets_numpy(0).copy()
+    rb = nested.NestedReadBatch(gpu_ctx, [cp], kinds, nul)
+    for rep in range(3):
+        if rep == 1:
+            leaf_metas = rb.prep[0][10]
+            leaf_metas[0, 1] -= 1     # (page 0 one slot short, page 1 one too many)
+            leaf_metas[1, 1] += 1
+        arr = rb.run()[0]
+        assert np.array_equal(arr.leaf.values_numpy(), rv), rep
+        assert np.array_equal(arr.offsets_numpy(0), ro), rep

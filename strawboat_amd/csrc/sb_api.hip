@@ -228,6 +228,8 @@ void sb_ctx_destroy(sb_ctx* ctx) {
         if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -296,6 +298,7 @@ static int32_t freq_second_pass(sb_ctx* ctx) {
         batches.push_back(b);
     }
     if (batches.empty()) return SB_OK;
+    ctx->freq_pass_ran = true;
     for (size_t i = 0; i < ctx->freq_cols.size(); i++) ctx->freq_cols[i].metas = &ctx->freq_metas[i];
     ctx->in_freq_pass = true;
     int32_t rc = read_columns_impl(ctx, ctx->freq_cols.data(), ctx->freq_cols.size(), SB_MEM_DEVICE, false);
@@ -372,7 +375,9 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         }
         for (void* p : ctx->stale_host) (void)hipHostFree(p);
         ctx->stale_host.clear();
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);   // (copies of groups that ran: overwritten by the replay's)
         ctx->copybacks.clear();
+        ctx->pipe_ev_used = 0;
         for (void* p : ctx->temp_dev) (void)hipFree(p);
         ctx->temp_dev.clear();
         ctx->stage_rewind();
@@ -458,14 +463,29 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     ctx->rescued.clear();
     for (void* p : ctx->stale_host) (void)hipHostFree(p);   // (the stream is drained: nothing reads them any more)
     ctx->stale_host.clear();
-    for (auto& cb : ctx->copybacks) {
-        const size_t nb = cb.used ? (size_t)std::min<uint64_t>(cb.n, *cb.used) : cb.n;
-        if (rc == SB_OK && nb) {
-            hipError_t ce = hipMemcpy(cb.host, cb.dev, nb, hipMemcpyDeviceToHost);
-            if (ce != hipSuccess) rc = check_hip(ctx, ce, "copy back");
+    {   // SB_MEM_HOST: what was not sent back while the interval ran (all copies on the copy stream, one wait)
+        hipStream_t cs = ctx->copy_stream_get();
+        bool any = false;
+        for (auto& cb : ctx->copybacks) {
+            if (cb.issued && !ctx->freq_pass_ran) {
+                any = true;
+                continue;
+            }
+            const size_t nb = cb.used ? (size_t)std::min<uint64_t>(cb.n, *cb.used) : cb.n;
+            if (rc == SB_OK && nb) {
+                hipError_t ce = cs ? hipMemcpyAsync(cb.host, cb.dev, nb, hipMemcpyDeviceToHost, cs) : hipMemcpy(cb.host, cb.dev, nb, hipMemcpyDeviceToHost);
+                if (ce != hipSuccess) rc = check_hip(ctx, ce, "copy back");
+                any = true;
+            }
+        }
+        if (any && cs) {
+            hipError_t ce = hipStreamSynchronize(cs);
+            if (ce != hipSuccess && rc == SB_OK) rc = check_hip(ctx, ce, "copy back");
         }
     }
     ctx->copybacks.clear();
+    ctx->freq_pass_ran = false;
+    ctx->pipe_ev_used = 0;
     for (void* p : ctx->temp_dev) (void)hipFree(p);
     ctx->temp_dev.clear();
     ctx->stage_rewind();
@@ -890,8 +910,40 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     return SB_OK;
 }
 
+// SB_MEM_HOST calls of many columns are cut into groups: while group g + 1's pages travel to the device, group g's Arrow
+// buffers travel back on the copy stream — PCIe's two directions are independent, and a call that ran them one after the
+// other (all copies in, kernels, all copies out at the synchronize) used half of the link.  Fixed-size outputs are sent as
+// soon as the group's kernels are done; values of binary columns (length known with the results) at the synchronize.
+static uint64_t host_groups(uint64_t n, uint64_t bytes) {
+    if (n < 4 || bytes < (32ull << 20)) return 1;
+    return std::min<uint64_t>(8, n / 2);
+}
 int32_t sb_read_columns(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem) {
-    const int32_t rc = read_columns_impl(ctx, cols, n, mem, false);
+    int32_t rc = SB_OK;
+    uint64_t groups = 1;
+    if (ctx && cols && mem == SB_MEM_HOST && n >= 4) {
+        uint64_t bytes = 0;
+        for (uint64_t i = 0; i < n; i++) bytes += cols[i].pages_len + cols[i].values_capacity;
+        groups = host_groups(n, bytes);
+    }
+    hipStream_t cs = groups > 1 ? ctx->copy_stream_get() : nullptr;
+    if (!cs) {
+        rc = read_columns_impl(ctx, cols, n, mem, false);
+    } else {
+        const uint64_t per = (n + groups - 1) / groups;
+        for (uint64_t g0 = 0; g0 < n && rc == SB_OK; g0 += per) {
+            const size_t cb0 = ctx->copybacks.size();
+            rc = read_columns_impl(ctx, cols + g0, std::min<uint64_t>(per, n - g0), mem, false);
+            if (rc != SB_OK) break;
+            hipEvent_t ev = ctx->next_pipe_event();
+            if (!ev || hipEventRecord(ev, ctx->stream) != hipSuccess || hipStreamWaitEvent(cs, ev, 0) != hipSuccess) continue;   // (copied at the synchronize)
+            for (size_t k = cb0; k < ctx->copybacks.size(); k++) {
+                auto& cb = ctx->copybacks[k];
+                if (cb.used || !cb.n) continue;
+                if (hipMemcpyAsync(cb.host, cb.dev, cb.n, hipMemcpyDeviceToHost, cs) == hipSuccess) cb.issued = true;
+            }
+        }
+    }
     if (rc == SB_OK && ctx && n && !ctx->in_replay) ctx->calls.push_back(sb_ctx::Call{0, cols, n, sb_write_options{}, mem});
     return rc;
 }

@@ -5337,8 +5337,49 @@ uint64_t sb_write_bound(int32_t physical_type, int32_t is_nullable, uint64_t row
 }
 
 static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts, int32_t mem);
+// SB_MEM_HOST calls of many columns in groups (see sb_read_columns): the pages of group g travel back while group g + 1's
+// Arrow buffers travel in.  How many bytes a column's pages are is known when its results are back, so the host waits for
+// group g's results (its inputs and kernels run behind group g + 1's copies, which are already queued) and sends exactly
+// out_len bytes per column on the copy stream; the last group's pages go at the synchronize.
+static void send_group_pages(sb_ctx* ctx, hipStream_t cs, sb::StageSlot* slot, size_t pd0, size_t pd1, size_t cb0, size_t cb1) {
+    if (!slot || !slot->done || hipEventSynchronize(slot->done) != hipSuccess) return;
+    for (size_t k = cb0; k < cb1; k++) {
+        auto& cb = ctx->copybacks[k];
+        if (cb.issued || !cb.used) continue;
+        for (size_t q = pd0; q < pd1; q++) {
+            const Pending& p = ctx->pending[q];
+            if (p.kind != Pending::WRITE_COL || &((sb_column_write*)p.user)->out_len != cb.used) continue;
+            const uint64_t* lens = (const uint64_t*)p.host;   // [n_pages lengths][n_pages num_values][total]
+            const size_t nb = (size_t)std::min<uint64_t>(cb.n, lens[2 * p.n]);
+            if (nb && hipMemcpyAsync(cb.host, cb.dev, nb, hipMemcpyDeviceToHost, cs) == hipSuccess) cb.issued = true;
+            break;
+        }
+    }
+}
 int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const sb_write_options* opts, int32_t mem) {
-    const int32_t rc = write_columns_impl(ctx, cols, n, opts, mem);
+    int32_t rc = SB_OK;
+    uint64_t groups = 1;
+    if (ctx && cols && opts && mem == SB_MEM_HOST && n >= 4) {
+        uint64_t bytes = 0;
+        for (uint64_t i = 0; i < n; i++) bytes += cols[i].rows * 8 + cols[i].values_len;   // (what travels, roughly)
+        groups = bytes >= (32ull << 20) ? std::min<uint64_t>(8, n / 2) : 1;
+    }
+    hipStream_t cs = groups > 1 ? ctx->copy_stream_get() : nullptr;
+    if (!cs) {
+        rc = write_columns_impl(ctx, cols, n, opts, mem);
+    } else {
+        const uint64_t per = (n + groups - 1) / groups;
+        sb::StageSlot* prev_slot = nullptr;
+        size_t ppd0 = 0, ppd1 = 0, pcb0 = 0, pcb1 = 0;
+        for (uint64_t g0 = 0; g0 < n; g0 += per) {
+            const size_t pd0 = ctx->pending.size(), cb0 = ctx->copybacks.size();
+            rc = write_columns_impl(ctx, cols + g0, std::min<uint64_t>(per, n - g0), opts, mem);
+            if (rc != SB_OK) break;
+            if (prev_slot) send_group_pages(ctx, cs, prev_slot, ppd0, ppd1, pcb0, pcb1);   // (this group's copies in are queued behind it)
+            prev_slot = ctx->last_slot;
+            ppd0 = pd0; ppd1 = ctx->pending.size(); pcb0 = cb0; pcb1 = ctx->copybacks.size();
+        }
+    }
     if (rc == SB_OK && ctx && n && !ctx->in_replay) ctx->calls.push_back(sb_ctx::Call{1, cols, n, *opts, mem});   // (for a replay: sb_host.h)
     return rc;
 }
@@ -6322,6 +6363,7 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
     }
     (void)hipEventRecord(slot->done, s);
     slot->in_flight = true;
+    ctx->last_slot = slot;
     for (uint64_t i = 0; i < n; i++) {
         Pending pd;
         pd.kind = Pending::WRITE_COL;

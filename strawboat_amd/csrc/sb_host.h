@@ -89,7 +89,26 @@ struct sb_ctx {
         const void* dev;
         size_t n;
         const uint64_t* used = nullptr;  // when set: only the first min(n, *used) bytes are copied (pages: out_len)
+        bool issued = false;             // already on its way (copy stream): a call of many columns is cut into groups whose
+                                         // copies back overlap the next group's copies in — the link's two directions are independent
     };
+    hipStream_t copy_stream = nullptr;   // D2H copies of SB_MEM_HOST calls
+    std::vector<hipEvent_t> pipe_ev;     // "group's kernels done" events of the open interval
+    size_t pipe_ev_used = 0;
+    sb::StageSlot* last_slot = nullptr;  // the staging slot of the last enqueued write call (its `done` event = results are back)
+    bool freq_pass_ran = false;          // this synchronize ran the Freq second pass (copies issued early are repeated)
+    hipEvent_t next_pipe_event() {
+        if (pipe_ev_used == pipe_ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            pipe_ev.push_back(e);
+        }
+        return pipe_ev[pipe_ev_used++];
+    }
+    hipStream_t copy_stream_get() {
+        if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) copy_stream = nullptr;
+        return copy_stream;
+    }
     std::vector<Copyback> copybacks;
     std::vector<void*> temp_dev;  // device temporaries to free at synchronize
     // SB_MEM_HOST staging areas: carved out of chunks that stay allocated (hipMalloc / hipFree per buffer and call

@@ -185,6 +185,7 @@ int32_t sb_ctx_create(int32_t device, void* hip_stream, sb_ctx** out) {
     if (const char* e = getenv("SB_ZSTD_BLOCKS_WG")) ctx->zb_wg_exec = e[0] != '0';
     if (const char* e = getenv("SB_BIN_FUSED")) ctx->bin_fused = e[0] != '0';
     if (const char* e = getenv("SB_NO_HINTS")) ctx->no_hints = e[0] != '0';
+    if (const char* e = getenv("SB_HOST_GROUPS")) ctx->host_groups_max = std::max<uint32_t>(1, (uint32_t)strtoul(e, nullptr, 10));
     if (const char* e = getenv("SB_ZSTD_BLOCKS_MIN")) ctx->zb_min_csize = (uint32_t)strtoul(e, nullptr, 10);
     // tests: divide the block pipeline's pool estimates so that a call runs out of pool space part-way (frames that do not
     // fit go back to the frame-serial decoder)
@@ -914,9 +915,9 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
 // buffers travel back on the copy stream — PCIe's two directions are independent, and a call that ran them one after the
 // other (all copies in, kernels, all copies out at the synchronize) used half of the link.  Fixed-size outputs are sent as
 // soon as the group's kernels are done; values of binary columns (length known with the results) at the synchronize.
-static uint64_t host_groups(uint64_t n, uint64_t bytes) {
+static uint64_t host_groups(sb_ctx* ctx, uint64_t n, uint64_t bytes) {
     if (n < 4 || bytes < (32ull << 20)) return 1;
-    return std::min<uint64_t>(8, n / 2);
+    return std::min<uint64_t>(ctx->host_groups_max, n / 2);
 }
 int32_t sb_read_columns(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t mem) {
     int32_t rc = SB_OK;
@@ -924,7 +925,7 @@ int32_t sb_read_columns(sb_ctx* ctx, sb_column_read* cols, uint64_t n, int32_t m
     if (ctx && cols && mem == SB_MEM_HOST && n >= 4) {
         uint64_t bytes = 0;
         for (uint64_t i = 0; i < n; i++) bytes += cols[i].pages_len + cols[i].values_capacity;
-        groups = host_groups(n, bytes);
+        groups = host_groups(ctx, n, bytes);
     }
     hipStream_t cs = groups > 1 ? ctx->copy_stream_get() : nullptr;
     if (!cs) {

@@ -5362,7 +5362,7 @@ int32_t sb_write_columns(sb_ctx* ctx, sb_column_write* cols, uint64_t n, const s
     if (ctx && cols && opts && mem == SB_MEM_HOST && n >= 4) {
         uint64_t bytes = 0;
         for (uint64_t i = 0; i < n; i++) bytes += cols[i].rows * 8 + cols[i].values_len;   // (what travels, roughly)
-        groups = bytes >= (32ull << 20) ? std::min<uint64_t>(8, n / 2) : 1;
+        groups = bytes >= (32ull << 20) ? std::min<uint64_t>(ctx->host_groups_max, n / 2) : 1;
     }
     hipStream_t cs = groups > 1 ? ctx->copy_stream_get() : nullptr;
     if (!cs) {

@@ -92,6 +92,7 @@ struct sb_ctx {
         bool issued = false;             // already on its way (copy stream): a call of many columns is cut into groups whose
                                          // copies back overlap the next group's copies in — the link's two directions are independent
     };
+    uint32_t host_groups_max = 8;        // SB_HOST_GROUPS (1: SB_MEM_HOST calls are never cut into groups)
     hipStream_t copy_stream = nullptr;   // D2H copies of SB_MEM_HOST calls
     std::vector<hipEvent_t> pipe_ev;     // "group's kernels done" events of the open interval
     size_t pipe_ev_used = 0;

@@ -210,3 +210,104 @@ def test_columns_of_many_pages_take_their_bases_from_wave_scans(gpu_ctx):
     batch.enqueue()
     gpu_ctx.synchronize()
     assert np.array_equal(buf[:need].cpu().numpy(), want["values"])
+
+
+def test_host_memory_many_columns_in_groups(gpu_ctx):
+    """SB_MEM_HOST with 64 columns (> 32 MB): the call runs in groups — the pages of one group travel back on the copy
+    stream while the next group's Arrow buffers travel in; fixed-size outputs of a read are sent as soon as a group's kernels
+    are done.  Pageable host buffers, mixed types (Float64 RLE, Int64 plain, Utf8 Dict, an Int32 column that becomes a Freq
+    page: its values are written by the second pass AT the synchronize, after the early copy): every page equals the oracle's
+    and every buffer reads back (src/write/serialize.rs:36-49, src/read/batch_read.rs:27-64)."""
+    import ctypes as C
+    from strawboat_amd import _native as N
+    from strawboat_amd.types import WriteOptions
+    from strawboat_amd.write import options_c
+    rows = 120_000
+    cols = []
+    for k in range(64):
+        if k % 4 == 0:
+            cols.append(gen.prim(S.T_F64, rows, uniq=64, null_density=0.1, runs=9, seed=k))
+        elif k % 4 == 1:
+            cols.append(gen.prim(S.T_I64, rows, uniq=1 << 40, seed=k))
+        elif k % 4 == 2:
+            cols.append(gen.binary(rows, uniq=300, null_density=0.1, seed=k))
+        else:
+            sp = np.full(rows, 1_000_000, np.int32)
+            rng = np.random.default_rng(k)
+            m = rng.random(rows) < 0.02
+            sp[m] = rng.integers(0, 1 << 30, int(m.sum()))
+            cols.append(dict(ptype=S.T_I32, nullable=False, rows=rows, values=sp, validity=None, offsets=None))
+    opt = dict(max_page_size=32768, ratio=2.0, forbidden=())
+    lib, h = gpu_ctx._lib, gpu_ctx._h
+    oc = options_c(WriteOptions(max_page_size=32768, default_compress_ratio=2.0))
+    n = len(cols)
+    cw = (N.ColumnWriteC * n)()
+    keep, outs, metas = [], [], []
+    total = 0
+    for k, col in enumerate(cols):
+        vals = np.ascontiguousarray(col["values"]).view(np.uint8)
+        vlen = vals.size if col["offsets"] is not None else 0
+        npg = C.c_uint64()
+        bound = lib.sb_write_bound(col["ptype"], 1 if col["nullable"] else 0, rows, vlen, C.byref(oc), C.byref(npg))
+        out = np.zeros(bound, np.uint8)
+        mt = (N.PageMetaC * npg.value)()
+        cw[k].physical_type, cw[k].is_nullable, cw[k].rows = col["ptype"], 1 if col["nullable"] else 0, rows
+        cw[k].values, cw[k].values_len = vals.ctypes.data, vlen
+        if col["validity"] is not None:
+            cw[k].validity = col["validity"].ctypes.data
+        if col["offsets"] is not None:
+            cw[k].offsets = col["offsets"].ctypes.data
+        cw[k].out_pages, cw[k].out_capacity = out.ctypes.data, out.size
+        cw[k].out_metas, cw[k].n_pages_capacity = mt, npg.value
+        keep.append(vals)
+        outs.append(out)
+        metas.append(mt)
+        total += vals.size
+    assert total > (32 << 20)
+    for rep in range(2):   # (the second call finds the plan of the groups)
+        gpu_ctx._check(lib.sb_write_columns(h, cw, n, C.byref(oc), N.SB_MEM_HOST))
+        gpu_ctx.synchronize()
+        for kk in (list(range(n)) if rep == 0 else [0, 1, 2, 3, n - 1]):
+            want_pages, want_metas = gen.oracle_write(cols[kk], **opt)
+            assert cw[kk].out_len == want_pages.size and np.array_equal(outs[kk][:cw[kk].out_len], want_pages), (rep, kk)
+    # read everything back into pageable host buffers
+    cr = (N.ColumnReadC * n)()
+    bufs = []
+    for k, col in enumerate(cols):
+        w = 8 if col["ptype"] in (S.T_F64, S.T_I64) else 4
+        m = np.array([[metas[k][q].length, metas[k][q].num_values] for q in range(int(cw[k].n_pages))], np.uint64)
+        want = None
+        if col["offsets"] is not None:   # (a null row of a Dict page reads back as the string before it: sizes and bytes from the oracle's decode)
+            wp, wm = gen.oracle_write(col, **opt)
+            want = gen.oracle_read(col, wp, wm)
+        v_out = np.zeros(want["values"].size + 64 if want is not None else rows * w, np.uint8)
+        b_out = np.zeros((rows + 31) // 32 * 4, np.uint8)
+        o_out = np.zeros((rows + 1) * 4, np.uint8)
+        cr[k].physical_type, cr[k].is_nullable = col["ptype"], 1 if col["nullable"] else 0
+        cr[k].pages, cr[k].pages_len = outs[k].ctypes.data, int(cw[k].out_len)
+        cr[k].metas, cr[k].n_pages = m.ctypes.data_as(C.POINTER(N.PageMetaC)), m.shape[0]
+        cr[k].values, cr[k].values_capacity = v_out.ctypes.data, v_out.size
+        if col["nullable"]:
+            cr[k].validity, cr[k].validity_capacity = b_out.ctypes.data, b_out.size
+        if col["offsets"] is not None:
+            cr[k].offsets, cr[k].offsets_capacity = o_out.ctypes.data, o_out.size
+        bufs.append((m, v_out, b_out, o_out, want))
+    for rep in range(2):
+        for _, v_out, b_out, o_out, _w in bufs:
+            v_out[:] = 0
+        gpu_ctx._check(lib.sb_read_columns(h, cr, n, N.SB_MEM_HOST))
+        gpu_ctx.synchronize()
+        for k, col in enumerate(cols):
+            m, v_out, b_out, o_out, want = bufs[k]
+            if col["offsets"] is not None:
+                assert cr[k].values_len == want["values"].size
+                assert np.array_equal(o_out, want["offsets"]), (rep, k)
+                assert np.array_equal(v_out[:cr[k].values_len], want["values"]), (rep, k)
+                assert np.array_equal(b_out[:(rows + 7) // 8], want["validity"]), (rep, k)
+            elif col["validity"] is not None:
+                valid = np.unpackbits(col["validity"], bitorder="little")[:rows].astype(bool)
+                w = 8
+                assert np.array_equal(v_out.view(np.uint64)[valid], keep[k].view(np.uint64)[valid]), (rep, k)
+                assert np.array_equal(b_out[:(rows + 7) // 8], col["validity"][:(rows + 7) // 8]), (rep, k)
+            else:
+                assert np.array_equal(v_out, keep[k]), (rep, k)

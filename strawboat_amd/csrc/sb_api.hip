@@ -465,7 +465,9 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     for (void* p : ctx->stale_host) (void)hipHostFree(p);   // (the stream is drained: nothing reads them any more)
     ctx->stale_host.clear();
     {   // SB_MEM_HOST: what was not sent back while the interval ran (all copies on the copy stream, one wait)
-        hipStream_t cs = ctx->copy_stream_get();
+        // (the stream exists only in contexts that serve host-memory calls: one more stream in the process changes how the
+        // runtime maps streams to hardware queues — C4's side streams lost their overlap, 1.03 -> 1.55 ms per read)
+        hipStream_t cs = ctx->copybacks.empty() ? ctx->copy_stream : ctx->copy_stream_get();
         bool any = false;
         for (auto& cb : ctx->copybacks) {
             if (cb.issued && !ctx->freq_pass_ran) {

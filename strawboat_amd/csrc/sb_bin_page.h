@@ -646,8 +646,184 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
             }
         }
     }
+    uint32_t bp_bytes = 0, ent_bytes = 0, ent_word = 0;
+    if (codec == SB_CODEC_DICT) {
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (firsts and idx, written above, are read below)
+        const uint32_t* firsts = aux + BP_W_FIRSTS;
+        const uint32_t* idx = aux + bh_table_slots(N) + 2 * (uint64_t)N;
+        // ---- the dictionary's entries (u64 len | bytes, dictionary order: binary/dict.rs:84-93) in a staging area of the aux
+        // words: the emitter places them behind the index block with one coalesced copy (its own pass — first row -> offsets
+        // -> bytes for 20 entries per thread of a 256-thread workgroup — was a fifth of its time)
+        {
+            const uint64_t w0 = (bp_w_slot16(N) + ((uint64_t)N + 1) / 2 + 4 + 3) & ~3ull, M = bh_table_slots(N);
+            if (D && w0 * 4 + tus + 64 <= M * 4) {
+                // (the table's LDS is free by now: entry sizes, then their offsets, one word per entry; entries are taken
+                // lane = entry with the loads of four of them in flight)
+                uint8_t* stage = (uint8_t*)(aux + w0);
+                constexpr int EU = 4;
+                for (uint32_t i0 = t; i0 < D; i0 += BP_WG * EU) {
+                    uint32_t r[EU];
+                    uint64_t pr[EU];
+#pragma unroll
+                    for (int u = 0; u < EU; u++) r[u] = gld32(firsts + min(i0 + (uint32_t)u * BP_WG, D - 1));
+#pragma unroll
+                    for (int u = 0; u < EU; u++) {
+                        if constexpr (sizeof(O) == 4) pr[u] = ldu64(offs + (uint64_t)r[u] * 4);
+                        else pr[u] = ldu64(offs + (uint64_t)r[u] * 8 + 8) - ldu64(offs + (uint64_t)r[u] * 8);
+                    }
+#pragma unroll
+                    for (int u = 0; u < EU; u++) {
+                        const uint32_t id = i0 + (uint32_t)u * BP_WG;
+                        if (id >= D) continue;
+                        const uint32_t L = sizeof(O) == 4 ? (uint32_t)(pr[u] >> 32) - (uint32_t)pr[u] : (uint32_t)pr[u];
+                        tab[id] = L + 8;
+                    }
+                }
+                __syncthreads();
+                const uint32_t per = (D + BP_WG - 1) / BP_WG, e0 = min(D, t * per), e1 = min(D, e0 + per);
+                uint32_t mine = 0;
+                for (uint32_t id = e0; id < e1; id++) mine += tab[id];
+                const uint32_t incl = wave_incl_scan(mine);
+                if (lane == 63) s_w[wv] = incl;
+                __syncthreads();
+                uint32_t at = incl - mine;
+                for (uint32_t pw = 0; pw < wv; pw++) at += s_w[pw];
+                uint32_t total = 0;
+#pragma unroll
+                for (int k = 0; k < BP_WG / 64; k++) total += s_w[k];
+                for (uint32_t id = e0; id < e1; id++) {   // exclusive offsets in place
+                    const uint32_t el = tab[id];
+                    tab[id] = at;
+                    at += el;
+                }
+                __syncthreads();
+                for (uint32_t i0 = t; i0 < D; i0 += BP_WG * EU) {
+                    uint32_t r[EU], eo[EU], L[EU];
+                    uint64_t b0[EU];
+                    u32x4 v0[EU];
+                    uint64_t v1[EU];
+#pragma unroll
+                    for (int u = 0; u < EU; u++) {
+                        const uint32_t id = min(i0 + (uint32_t)u * BP_WG, D - 1);
+                        r[u] = gld32(firsts + id);
+                        eo[u] = tab[id];
+                        L[u] = (id + 1 < D ? tab[id + 1] : total) - eo[u] - 8;
+                    }
+#pragma unroll
+                    for (int u = 0; u < EU; u++) b0[u] = bk.beg(r[u]);
+#pragma unroll
+                    for (int u = 0; u < EU; u++) {   // (24 bytes when they are all there: the common short string)
+                        v0[u] = u32x4{0, 0, 0, 0};
+                        v1[u] = 0;
+                        if (L[u] <= 24 && b0[u] + 24 <= vlen) {
+                            v0[u] = ldu128(values + b0[u]);
+                            v1[u] = ldu64(values + b0[u] + 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < EU; u++) {
+                        const uint32_t id = i0 + (uint32_t)u * BP_WG;
+                        if (id >= D) continue;
+                        uint8_t* d = stage + eo[u];
+                        stu64(d, (uint64_t)L[u]);
+                        uint32_t k = 0;
+                        if (L[u] <= 24 && b0[u] + 24 <= vlen) {   // exact stores out of the registers (the next entry belongs to another lane)
+                            const uint32_t w6[6] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, (uint32_t)v1[u], (uint32_t)(v1[u] >> 32)};
+#pragma unroll
+                            for (uint32_t q = 0; q < 6; q++) {
+                                if (4 * q + 4 <= L[u]) stu32(d + 8 + 4 * q, w6[q]);
+                                else if (4 * q < L[u])
+                                    for (uint32_t bb = 0; 4 * q + bb < L[u]; bb++) *(gptr)(d + 8 + 4 * q + bb) = (uint8_t)(w6[q] >> (8 * bb));
+                            }
+                            continue;
+                        }
+                        for (; k + 16 <= L[u]; k += 16) stu128(d + 8 + k, ldu128(values + b0[u] + k));
+                        for (; k < L[u]; k++) *(gptr)(d + 8 + k) = ldu8(values + b0[u] + k);
+                    }
+                }
+                ent_bytes = total;
+                ent_word = (uint32_t)w0;
+                __syncthreads();
+            }
+        }
+        // ---- the index array bit-packed where the emitter's nested block will stand (integer/bp.rs:45-61; BitPacker4x: a
+        // width byte, then 4 interleaved lanes per block of 128), speculatively: Dict pages of full blocks choose it almost
+        // always, and then the emitter only writes the block's header.  16 384 indices per step through the table's LDS.
+        const uint32_t forb_n = forb | (1u << SB_CODEC_DICT);
+        if (N % 128 == 0 && !((forb_n >> SB_CODEC_BITPACKING) & 1) && p.icodec < 0) {
+            uint8_t* slot = page_slot(a, c, p);
+            uint8_t* dst = slot + (c.nullable ? def_section_bytes(N) : 0) + 18;
+            constexpr uint32_t CH = 32768, NBLK = CH / 128, TPB = BP_WG / NBLK;   // 256 blocks per step, four threads per block
+            uint32_t* s_nb = s_x;              // [NBLK] widths
+            uint32_t* s_off = s_x + NBLK;      // [NBLK + 1] byte offsets inside the step
+            uint32_t out_pos = 0;
+            for (uint32_t cb = 0; cb < N; cb += CH) {
+                const uint32_t n = min(CH, N - cb), nblk = n / 128;
+                __syncthreads();
+                uint32_t acc = 0;
+                {   // 32 consecutive values per thread: staged, and OR-ed for the block's width
+                    const uint32_t v0 = t * (128 / TPB);
+                    if (v0 < n) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(idx + cb + v0 + 4 * q);
+                            *(__attribute__((address_space(3))) u32x4*)((l32p)tab + v0 + 4 * q) = v;
+                            acc |= v.x | v.y | v.z | v.w;
+                        }
+                    }
+                    acc |= __shfl_xor(acc, 1, 64);
+                    acc |= __shfl_xor(acc, 2, 64);
+                    if ((t & (TPB - 1)) == 0 && t / TPB < nblk) s_nb[t / TPB] = acc ? 32 - __clz(acc) : 0;
+                }
+                __syncthreads();
+                if (t < NBLK) {   // byte offsets of the step's blocks (four waves)
+                    const uint32_t nb = t < nblk ? s_nb[t] : 0u;
+                    const uint32_t by = t < nblk ? 1 + 16 * nb : 0u;
+                    const uint32_t ib = wave_incl_scan(by);
+                    if (lane == 63) s_w[wv] = ib;
+                    s_off[t] = ib - by;
+                }
+                __syncthreads();
+                if (t < NBLK) {
+                    uint32_t add = 0;
+                    for (uint32_t pw = 0; pw < wv; pw++) add += s_w[pw];
+                    s_off[t] += add;
+                }
+                const uint32_t step_bytes = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+                __syncthreads();
+                {   // pack: the step's blocks side by side, a word per thread and turn
+                    const uint32_t blk = t / TPB;
+                    if (blk < nblk) {
+                        const uint32_t nb = s_nb[blk], nw = 4 * nb;
+                        uint8_t* bo = dst + out_pos + s_off[blk] + 1;
+                        if ((t & (TPB - 1)) == 0) *(gptr)(bo - 1) = (uint8_t)nb;
+                        for (uint32_t wi = t & (TPB - 1); wi < nw; wi += TPB) {
+                            const uint32_t l = wi & 3, k = wi >> 2;  // word k of lane l
+                            const uint32_t lo_bit = 32 * k, hi_bit = 32 * k + 32;
+                            uint32_t word = 0;
+                            const uint32_t i0 = lo_bit / nb, i1 = min(31u, (hi_bit - 1) / nb);
+                            for (uint32_t i = i0; i <= i1; i++) {
+                                const uint32_t v = tab[blk * 128 + 4 * i + l];
+                                const uint32_t bitpos = i * nb;
+                                if (bitpos >= lo_bit) word |= v << (bitpos - lo_bit);
+                                else if (bitpos + nb > lo_bit) word |= v >> (lo_bit - bitpos);
+                            }
+                            stu32(bo + 4 * wi, word);
+                        }
+                    }
+                }
+                out_pos += step_bytes;
+            }
+            bp_bytes = out_pos;
+        }
+    }
     STL(68);
     if (t == 0) {
+        gst32(aux + BH_W_BPBYTES, bp_bytes);
+        gst32(aux + BH_W_ENTBYTES, ent_bytes);
+        gst32(aux + BH_W_ENTWORD, ent_word);
         gst32(aux + BH_W_D, D);
         gst32(aux + BH_W_BAD, 0u);
         gst32(aux + BH_W_MAGIC, codec == SB_CODEC_DICT ? BH_MAGIC2 : 0u);

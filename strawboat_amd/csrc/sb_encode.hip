@@ -3055,6 +3055,7 @@ constexpr uint64_t BP_MIN_ROWS = 512;
 constexpr uint32_t BH_W_FUSED = 3;            // aux word: BP_DONE when this kernel decided the page in this call
 constexpr uint32_t BP_DONE = 0x46555345u;
 constexpr uint32_t BH_MAGIC2 = 0x48444232u;   // aux[BH_W_MAGIC]: a dictionary in the layout below was handed over
+constexpr uint32_t BH_W_BPBYTES = 4, BH_W_ENTBYTES = 5, BH_W_ENTWORD = 6;   // aux words: the speculative bit-packed index block / the staged entries
 constexpr uint32_t BP_W_FIRSTS = 16;          // firsts[<= (N - 1) / 3], then slot16[N]; idx in the last N words of the aux area
 __host__ __device__ __forceinline__ uint64_t bp_w_slot16(uint64_t N) { return (BP_W_FIRSTS + N / 3 + 2 + 3) & ~3ull; }
 __host__ __device__ __forceinline__ bool bp_fits(uint64_t N, uint64_t aux_bytes) {
@@ -3165,10 +3166,14 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         // the selector of this launch built the dictionary (tables in the aux area) and k_enc_bin_verify compared the strings
         const bool handed = p.codec == CODEC_ON_DEVICE && p.h64_off != ~0ull && lds_slots >= BH_SLOTS && bh_fits(N, p.aux_bytes) &&
                             gld32(aux + BH_W_MAGIC) == BH_MAGIC && gld32(aux + BH_W_BAD) == 0;
+        uint32_t pre_bp = 0, pre_ent = 0, pre_ent_word = 0;   // k_enc_bin_page's speculative bit-packed block / staged entries
         if (bp_page_done(a, p, page) && gld32(aux + BH_W_MAGIC) == BH_MAGIC2) {   // ids, first rows and the index array by k_enc_bin_page
             idx = aux + bh_table_slots(N) + 2 * N;
             firsts = aux + BP_W_FIRSTS;
             D = gld32(aux + BH_W_D);
+            pre_bp = gld32(aux + BH_W_BPBYTES);
+            pre_ent = gld32(aux + BH_W_ENTBYTES);
+            pre_ent_word = gld32(aux + BH_W_ENTWORD);
         } else if (handed) {
             D = bin_dict_from_handover<O>(ko, N, aux, &idx, &firsts, sA, sB, sC, s_w);
             STL(27);
@@ -3220,7 +3225,13 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
             const uint64_t aux_words = p.aux_bytes / 4;
             if (aux_words >= M + 3 * N) lz_tmp = (uint8_t*)(idx == aux ? aux + (aux_words - 2 * N) : aux + M);
         }
-        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags, lz_tmp, 8 * N);
+        uint64_t ib;
+        if (ic == SB_CODEC_BITPACKING && pre_bp) {   // the body stands there already: the block's header
+            if (threadIdx.x == 0) put_hdr9(blk + 9, SB_CODEC_BITPACKING, pre_bp, (uint32_t)(N * 4));
+            ib = 9 + (uint64_t)pre_bp;
+        } else {
+            ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags, lz_tmp, 8 * N);
+        }
         if (ib == 0) return 0;
         STL(31);
         uint8_t* q = blk + 9 + ib;
@@ -3228,7 +3239,11 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         q += 4;
         // entries: u64 len | bytes, in dictionary order; positions = scan of (8 + len)
         uint64_t pos = 0;
-        for (uint32_t kb = 0; kb < D; kb += TILE_ROWS) {
+        if (pre_ent) {   // staged by k_enc_bin_page
+            wg_copy(q, (const uint8_t*)(aux + pre_ent_word), pre_ent);
+            pos = pre_ent;
+        }
+        for (uint32_t kb = pre_ent ? D : 0u; kb < D; kb += TILE_ROWS) {
             const uint32_t n = min((uint32_t)TILE_ROWS, D - kb);
             for (uint32_t i = threadIdx.x; i < TILE_ROWS; i += WG) {
                 uint32_t len = 0;

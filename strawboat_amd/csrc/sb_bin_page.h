@@ -646,13 +646,150 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
             }
         }
     }
-    uint32_t bp_bytes = 0, ent_bytes = 0, ent_word = 0;
+    uint32_t bp_bytes = 0, ent_bytes = 0, ent_word = 0, icodec = 0xFFFFFFFFu;   // icodec: the index block's codec when this kernel chose it
     if (codec == SB_CODEC_DICT) {
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (firsts and idx, written above, are read below)
         const uint32_t* firsts = aux + BP_W_FIRSTS;
         const uint32_t* idx = aux + bh_table_slots(N) + 2 * (uint64_t)N;
+        const uint32_t forb_n = forb | (1u << SB_CODEC_DICT);
+        // ---- the codec of the index block: compress_integer::<u32> with Dict forbidden (binary/dict.rs:60-62 ->
+        // integer/mod.rs:231-347), the arithmetic of choose_prim / decide_prim on what this kernel knows: every id occurs
+        // (maximum D - 1, never negative, no nulls), all_equal and sortedness from one pass over the index array, the Freq
+        // majority by a vote + count, the RLE / Bitpacking / DeltaBitpacking trials on the seeded samples (sb_select.h:
+        // sample_row, sample_rle_runs, sample_bp_size) gathered out of the index array.
+        if (p.icodec < 0) {
+            const uint32_t i00 = gld32(idx);
+            uint32_t f_neq0 = 0, f_uns = 0, vc = 0, vn = 0;
+            for (uint32_t i0 = t * 4; i0 < N; i0 += BP_WG * 4 * 4) {   // (four 16-byte loads per thread and step)
+                u32x4 q[4];
+                uint32_t pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * BP_WG * 4;
+                    q[u] = i + 4 <= N ? *(const __attribute__((address_space(1))) u32x4*)(idx + i) : u32x4{i00, i00, i00, i00};
+                    pv[u] = (i && i < N) ? gld32(idx + i - 1) : 0u;
+                    if (i < N && i + 4 > N) {   // (N % 4 != 0: the last values one by one)
+                        uint32_t w4[4] = {0, 0, 0, 0};
+                        for (uint32_t b = 0; i + b < N; b++) w4[b] = gld32(idx + i + b);
+                        for (uint32_t b = N - i; b < 4; b++) w4[b] = w4[N - i - 1];
+                        q[u] = u32x4{w4[0], w4[1], w4[2], w4[3]};
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * BP_WG * 4;
+                    if (i >= N) continue;
+                    const uint32_t w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                    uint32_t prev = pv[u];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        if (i + b >= N) break;
+                        if (w4[b] != i00) f_neq0 = 1;
+                        if ((i + b) && w4[b] < prev) f_uns = 1;
+                        prev = w4[b];
+                        if (vn == 0) {
+                            vc = w4[b];
+                            vn = 1;
+                        } else if (w4[b] == vc) {
+                            vn++;
+                        } else {
+                            vn--;
+                        }
+                    }
+                }
+            }
+            const uint32_t flags = bp_sum(f_neq0 | (f_uns << 16), s_w);
+            const bool n_all_equal = !(flags & 0xFFFFu), n_sorted = !(flags >> 16);
+            uint32_t nmc = 0;
+            if (!((forb_n >> SB_CODEC_FREQ) & 1) && !n_all_equal && D - 1 >= 256) {
+                s_x[t] = vc;
+                s_y[t] = vn;
+                __syncthreads();
+                for (uint32_t stride = BP_WG / 2; stride > 0; stride >>= 1) {
+                    if (t < stride) {
+                        const uint32_t c0 = s_x[t], n0 = s_y[t], c1 = s_x[t + stride], n1 = s_y[t + stride];
+                        uint32_t cc = c0, nn = n0;
+                        if (n1) {
+                            if (n0 == 0) { cc = c1; nn = n1; }
+                            else if (c0 == c1) nn = n0 + n1;
+                            else if (n1 > n0) { cc = c1; nn = n1 - n0; }
+                            else nn = n0 - n1;
+                        }
+                        s_x[t] = cc;
+                        s_y[t] = nn;
+                    }
+                    __syncthreads();
+                }
+                const uint32_t cand = s_x[0], cn = s_y[0];
+                __syncthreads();
+                uint32_t mine = 0;
+                if (cn && (double)cn + 1.0 >= 0.0)   // (count the candidate: a 90 % majority survives any merge order)
+                    for (uint32_t i0 = t * 4; i0 < N; i0 += BP_WG * 4) {
+                        if (i0 + 4 <= N) {
+                            const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(idx + i0);
+                            mine += (v.x == cand) + (v.y == cand) + (v.z == cand) + (v.w == cand);
+                        } else {
+                            for (uint32_t b = 0; i0 + b < N; b++) mine += gld32(idx + i0 + b) == cand;
+                        }
+                    }
+                nmc = bp_sum(mine, s_w);
+            }
+            // the three trials: 640 sampled rows each (or the whole page when N / 10 <= 64), one row per thread
+            const bool whole = N / SAMPLE_COUNT <= SAMPLE_SIZE;
+            const uint32_t sn = whole ? N : SAMPLE_ROWS;
+            auto trial = [&](uint32_t cd, bool rle) -> uint32_t {   // RLE: runs of the sample; else its bit-packed size
+                __syncthreads();
+                if (t < sn) {
+                    uint64_t row = 0;
+                    sample_row(N, p.seed, p.depth + 1, cd, t, row);
+                    s_x[t] = gld32(idx + row);
+                }
+                if (t < 8) s_y[t] = 0;
+                __syncthreads();
+                uint32_t v = 0;
+                if (rle) {
+                    v = bp_sum(t > 0 && t < sn && s_x[t] != s_x[t - 1] ? 1u : 0u, s_w);
+                    return sn ? v + 1 : 0;
+                }
+                const uint32_t nblk = sn / 128;
+                if (t < nblk * 128) atomicOr(&s_y[t >> 7], s_x[t]);
+                __syncthreads();
+                for (uint32_t b = 0; b < nblk; b++) v += 1 + 16 * (s_y[b] ? 32 - __clz(s_y[b]) : 0);
+                return v;
+            };
+            const double n_tuple = (double)N;
+            double n_max = a.ratio;
+            uint32_t n_res = a.default_compression;
+            static const uint8_t NORD[5] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_RLE, SB_CODEC_BITPACKING, SB_CODEC_DELTA_BITPACKING};
+            for (int oi = 0; oi < 5; oi++) {
+                const uint32_t cd = NORD[oi];
+                if ((forb_n >> cd) & 1) continue;
+                double r = 0.0;
+                if (cd == SB_CODEC_ONEVALUE) {
+                    r = n_all_equal ? n_tuple : 0.0;
+                } else if (cd == SB_CODEC_FREQ) {
+                    if (!n_all_equal && (double)nmc / n_tuple >= 0.9 && (int64_t)(D - 1) >= 256) r = (double)(N - 1);
+                } else if (cd == SB_CODEC_RLE) {
+                    const uint32_t runs = trial(cd, true);
+                    r = (double)((uint64_t)sn * 4) / (double)((uint64_t)runs * 8);
+                } else {
+                    if (N % 128 != 0) continue;
+                    if (cd == SB_CODEC_DELTA_BITPACKING && !n_sorted) continue;
+                    const uint32_t size = trial(cd, false);
+                    r = (double)((uint64_t)sn * 4) / (double)size;
+                    if (cd == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
+                }
+                if (r > n_max) {
+                    n_max = r;
+                    n_res = cd;
+                    if (r == n_tuple) break;
+                }
+            }
+            icodec = n_res;
+            __syncthreads();
+        }
         // ---- the dictionary's entries (u64 len | bytes, dictionary order: binary/dict.rs:84-93) in a staging area of the aux
         // words: the emitter places them behind the index block with one coalesced copy (its own pass — first row -> offsets
         // -> bytes for 20 entries per thread of a 256-thread workgroup — was a fifth of its time)
@@ -751,8 +888,7 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
         // ---- the index array bit-packed where the emitter's nested block will stand (integer/bp.rs:45-61; BitPacker4x: a
         // width byte, then 4 interleaved lanes per block of 128), speculatively: Dict pages of full blocks choose it almost
         // always, and then the emitter only writes the block's header.  16 384 indices per step through the table's LDS.
-        const uint32_t forb_n = forb | (1u << SB_CODEC_DICT);
-        if (N % 128 == 0 && !((forb_n >> SB_CODEC_BITPACKING) & 1) && p.icodec < 0) {
+        if (N % 128 == 0 && icodec == SB_CODEC_BITPACKING) {
             uint8_t* slot = page_slot(a, c, p);
             uint8_t* dst = slot + (c.nullable ? def_section_bytes(N) : 0) + 18;
             constexpr uint32_t CH = 32768, NBLK = CH / 128, TPB = BP_WG / NBLK;   // 256 blocks per step, four threads per block
@@ -821,6 +957,7 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     }
     STL(68);
     if (t == 0) {
+        gst32(aux + BH_W_ICODEC, icodec + 1u);
         gst32(aux + BH_W_BPBYTES, bp_bytes);
         gst32(aux + BH_W_ENTBYTES, ent_bytes);
         gst32(aux + BH_W_ENTWORD, ent_word);

@@ -3055,7 +3055,7 @@ constexpr uint64_t BP_MIN_ROWS = 512;
 constexpr uint32_t BH_W_FUSED = 3;            // aux word: BP_DONE when this kernel decided the page in this call
 constexpr uint32_t BP_DONE = 0x46555345u;
 constexpr uint32_t BH_MAGIC2 = 0x48444232u;   // aux[BH_W_MAGIC]: a dictionary in the layout below was handed over
-constexpr uint32_t BH_W_BPBYTES = 4, BH_W_ENTBYTES = 5, BH_W_ENTWORD = 6;   // aux words: the speculative bit-packed index block / the staged entries
+constexpr uint32_t BH_W_BPBYTES = 4, BH_W_ENTBYTES = 5, BH_W_ENTWORD = 6, BH_W_ICODEC = 7;   // aux words: the speculative bit-packed index block / the staged entries
 constexpr uint32_t BP_W_FIRSTS = 16;          // firsts[<= (N - 1) / 3], then slot16[N]; idx in the last N words of the aux area
 __host__ __device__ __forceinline__ uint64_t bp_w_slot16(uint64_t N) { return (BP_W_FIRSTS + N / 3 + 2 + 3) & ~3ull; }
 __host__ __device__ __forceinline__ bool bp_fits(uint64_t N, uint64_t aux_bytes) {
@@ -3166,11 +3166,12 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         // the selector of this launch built the dictionary (tables in the aux area) and k_enc_bin_verify compared the strings
         const bool handed = p.codec == CODEC_ON_DEVICE && p.h64_off != ~0ull && lds_slots >= BH_SLOTS && bh_fits(N, p.aux_bytes) &&
                             gld32(aux + BH_W_MAGIC) == BH_MAGIC && gld32(aux + BH_W_BAD) == 0;
-        uint32_t pre_bp = 0, pre_ent = 0, pre_ent_word = 0;   // k_enc_bin_page's speculative bit-packed block / staged entries
+        uint32_t pre_bp = 0, pre_ent = 0, pre_ent_word = 0, pre_ic = 0;   // k_enc_bin_page's index codec (+ 1) / bit-packed block / staged entries
         if (bp_page_done(a, p, page) && gld32(aux + BH_W_MAGIC) == BH_MAGIC2) {   // ids, first rows and the index array by k_enc_bin_page
             idx = aux + bh_table_slots(N) + 2 * N;
             firsts = aux + BP_W_FIRSTS;
             D = gld32(aux + BH_W_D);
+            pre_ic = gld32(aux + BH_W_ICODEC);
             pre_bp = gld32(aux + BH_W_BPBYTES);
             pre_ent = gld32(aux + BH_W_ENTBYTES);
             pre_ent_word = gld32(aux + BH_W_ENTWORD);
@@ -3193,7 +3194,9 @@ __device__ uint64_t emit_binary_page(const EncodeArgs& a, const EncCol& c, const
         }
         if (D == EMPTY) return 0;
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
-        if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
+        if (p.icodec < 0 && a.has_ratio && pre_ic) {   // chosen by k_enc_bin_page
+            ic = (int32_t)pre_ic - 1;
+        } else if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
             SelectOpts so{a.ratio, 1u, a.forbidden | p.forb_extra | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, p.depth + 1};
             SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
             const uint32_t* ip = idx;

@@ -58,6 +58,351 @@ __device__ uint32_t bp_hash_mem(const uint8_t* values, uint64_t b, uint32_t n) {
     }
     return bp_hash_fin(h);
 }
+// ---- ids in first-occurrence order out of a settled table (words: tag | BP_UNKEYED | row16, BP_EMPTY), then the u32 index
+// array.  firsts[id] at aux + BP_W_FIRSTS, the indices in the last N words of the aux area; the table is left as slot -> id.
+// Returns the number of entries.  Shared by k_enc_bin_page and k_enc_prim_dict.
+__device__ __forceinline__ uint32_t bp_ids_and_index(uint32_t* tab, const uint32_t nslots, uint32_t* s_x, uint32_t* s_y, uint32_t* s_w, uint32_t* aux,
+                                                     const uint16_t* slot16, const ValidView& vv, const uint32_t N) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t D = 0;
+    {
+        STL(66);
+        // ---- ids in first-occurrence order: bitmap of the first KEYED rows, prefix popcounts, id = rank
+        s_x[t] = 0;
+        s_x[t + BP_WG] = 0;
+        __syncthreads();
+        for (uint32_t sl = t; sl < nslots; sl += BP_WG) {
+            const uint32_t wd = tab[sl];
+            if (wd != BP_EMPTY && !(wd & BP_UNKEYED)) atomicOr(&s_x[(wd & 0xFFFFu) >> 5], 1u << (wd & 31u));
+        }
+        __syncthreads();
+        {
+            const uint32_t m0 = (uint32_t)__popc(s_x[2 * t]), m1 = (uint32_t)__popc(s_x[2 * t + 1]);
+            const uint32_t incl = wave_incl_scan(m0 + m1);
+            if (lane == 63) s_w[wv] = incl;
+            __syncthreads();
+            uint32_t run = incl - (m0 + m1);
+            for (uint32_t pw = 0; pw < wv; pw++) run += s_w[pw];
+#pragma unroll
+            for (int k = 0; k < BP_WG / 64; k++) D += s_w[k];
+            s_y[2 * t] = run;
+            s_y[2 * t + 1] = run + m0;
+        }
+        __syncthreads();
+        uint32_t* firsts = aux + BP_W_FIRSTS;
+        for (uint32_t sl = t; sl < nslots; sl += BP_WG) {
+            const uint32_t wd = tab[sl];
+            if (wd == BP_EMPTY) continue;
+            uint32_t id = 0xFFFFFFFFu;
+            if (!(wd & BP_UNKEYED)) {
+                const uint32_t r = wd & 0xFFFFu;
+                id = s_y[r >> 5] + (uint32_t)__popc(s_x[r >> 5] & ((1u << (r & 31)) - 1u));
+                gst32(firsts + id, r);
+            }
+            tab[sl] = id;
+        }
+        __syncthreads();
+        STL(67);
+        // ---- the u32 index array (the last N words of the aux area, where the emitter's LZ4 scratch does not reach)
+        uint32_t* idx = aux + bh_table_slots(N) + 2 * (uint64_t)N;
+        if (!vv.bits) {
+            const uint32_t npair = (N + 1) / 2;
+            for (uint32_t k0 = t; k0 < npair; k0 += BP_WG * 8) {
+                uint32_t pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
+                    pr[u] = gld32((const uint32_t*)slot16 + (k < npair ? k : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
+                    if (k >= npair) continue;
+                    const uint32_t i0 = tab[pr[u] & 0xFFFFu];
+                    if (2 * k + 1 < N)
+                        gst64((uint64_t*)(idx + 2 * k), (uint64_t)i0 | ((uint64_t)tab[pr[u] >> 16] << 32));
+                    else
+                        gst32(idx + 2 * k, i0);
+                }
+            }
+        } else {
+            // a null row repeats the index before it (dict.rs:46-55): per 64-row chunk (a wave's step) the last keyed id, an
+            // inclusive "last one that has any" scan over the <= 1024 chunks, then the rows with the carry of the chunk before
+            const uint32_t nch = (N + 63) / 64;
+            constexpr int V = 4;   // (the loads of four steps together)
+            for (uint32_t base = 0; base < N; base += BP_WG * V) {
+                uint32_t sl[V], vb[V];
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    sl[u] = ldu16((const uint8_t*)(slot16 + ic));
+                    vb[u] = ldu8(vv.bits + ((vv.off + ic) >> 3));
+                }
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    const bool kd = i < N && (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1));
+                    const uint32_t sid = kd ? tab[sl[u]] : 0u;
+                    const uint64_t km = __ballot(kd);
+                    const uint32_t last = __shfl(sid, km ? 63 - __clzll((long long)km) : 0, 64);
+                    const uint32_t ch = (base + (uint32_t)u * BP_WG) / 64 + wv;
+                    if (lane == 0 && ch < nch) s_x[ch] = km ? last : 0xFFFFFFFFu;
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t v = t < nch ? s_x[t] : 0xFFFFFFFFu;
+                const uint64_t hm = __ballot(v != 0xFFFFFFFFu);
+                const uint64_t below = hm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+                const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
+                const uint32_t got = __shfl(v, (int)src, 64);
+                uint32_t incl = below ? got : 0xFFFFFFFFu;
+                if (lane == 63) s_w[wv] = incl;
+                __syncthreads();
+                if (incl == 0xFFFFFFFFu)
+                    for (int pw = (int)wv - 1; pw >= 0; pw--)
+                        if (s_w[pw] != 0xFFFFFFFFu) {
+                            incl = s_w[pw];
+                            break;
+                        }
+                s_y[t] = incl;
+            }
+            __syncthreads();
+            for (uint32_t base = 0; base < N; base += BP_WG * V) {
+                uint32_t sl[V], vb[V];
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    sl[u] = ldu16((const uint8_t*)(slot16 + ic));
+                    vb[u] = ldu8(vv.bits + ((vv.off + ic) >> 3));
+                }
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+                    const bool kd = i < N && (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1));
+                    const uint32_t sid = kd ? tab[sl[u]] : 0u;
+                    const uint64_t km = __ballot(kd);
+                    const uint64_t below = km & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+                    const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
+                    const uint32_t got = __shfl(sid, (int)src, 64);
+                    const uint32_t ch = (base + (uint32_t)u * BP_WG) / 64 + wv;
+                    const uint32_t carry = ch && ch <= nch ? s_y[ch - 1] : 0u;
+                    if (i < N) gst32(idx + i, below ? got : carry);
+                }
+            }
+        }
+        }
+    return D;
+}
+
+// ---- the codec of a Dict page's index block: compress_integer::<u32> with Dict forbidden (binary/dict.rs:60-62, integer/
+// dict.rs:57-62 -> integer/mod.rs:231-347), the arithmetic of choose_prim / decide_prim on what the fused kernels know.
+__device__ __forceinline__ uint32_t bp_index_codec(const EncodeArgs& a, const EncPage& p, const uint32_t* idx, const uint32_t N, const uint32_t D,
+                                                   const uint32_t forb_n, uint32_t* s_x, uint32_t* s_y, uint32_t* s_w) {
+    const uint32_t t = threadIdx.x;
+    {
+            const uint32_t i00 = gld32(idx);
+            uint32_t f_neq0 = 0, f_uns = 0, vc = 0, vn = 0;
+            for (uint32_t i0 = t * 4; i0 < N; i0 += BP_WG * 4 * 4) {   // (four 16-byte loads per thread and step)
+                u32x4 q[4];
+                uint32_t pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * BP_WG * 4;
+                    q[u] = i + 4 <= N ? *(const __attribute__((address_space(1))) u32x4*)(idx + i) : u32x4{i00, i00, i00, i00};
+                    pv[u] = (i && i < N) ? gld32(idx + i - 1) : 0u;
+                    if (i < N && i + 4 > N) {   // (N % 4 != 0: the last values one by one)
+                        uint32_t w4[4] = {0, 0, 0, 0};
+                        for (uint32_t b = 0; i + b < N; b++) w4[b] = gld32(idx + i + b);
+                        for (uint32_t b = N - i; b < 4; b++) w4[b] = w4[N - i - 1];
+                        q[u] = u32x4{w4[0], w4[1], w4[2], w4[3]};
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * BP_WG * 4;
+                    if (i >= N) continue;
+                    const uint32_t w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                    uint32_t prev = pv[u];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        if (i + b >= N) break;
+                        if (w4[b] != i00) f_neq0 = 1;
+                        if ((i + b) && w4[b] < prev) f_uns = 1;
+                        prev = w4[b];
+                        if (vn == 0) {
+                            vc = w4[b];
+                            vn = 1;
+                        } else if (w4[b] == vc) {
+                            vn++;
+                        } else {
+                            vn--;
+                        }
+                    }
+                }
+            }
+            const uint32_t flags = bp_sum(f_neq0 | (f_uns << 16), s_w);
+            const bool n_all_equal = !(flags & 0xFFFFu), n_sorted = !(flags >> 16);
+            uint32_t nmc = 0;
+            if (!((forb_n >> SB_CODEC_FREQ) & 1) && !n_all_equal && D - 1 >= 256) {
+                s_x[t] = vc;
+                s_y[t] = vn;
+                __syncthreads();
+                for (uint32_t stride = BP_WG / 2; stride > 0; stride >>= 1) {
+                    if (t < stride) {
+                        const uint32_t c0 = s_x[t], n0 = s_y[t], c1 = s_x[t + stride], n1 = s_y[t + stride];
+                        uint32_t cc = c0, nn = n0;
+                        if (n1) {
+                            if (n0 == 0) { cc = c1; nn = n1; }
+                            else if (c0 == c1) nn = n0 + n1;
+                            else if (n1 > n0) { cc = c1; nn = n1 - n0; }
+                            else nn = n0 - n1;
+                        }
+                        s_x[t] = cc;
+                        s_y[t] = nn;
+                    }
+                    __syncthreads();
+                }
+                const uint32_t cand = s_x[0], cn = s_y[0];
+                __syncthreads();
+                uint32_t mine = 0;
+                if (cn && (double)cn + 1.0 >= 0.0)   // (count the candidate: a 90 % majority survives any merge order)
+                    for (uint32_t i0 = t * 4; i0 < N; i0 += BP_WG * 4) {
+                        if (i0 + 4 <= N) {
+                            const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(idx + i0);
+                            mine += (v.x == cand) + (v.y == cand) + (v.z == cand) + (v.w == cand);
+                        } else {
+                            for (uint32_t b = 0; i0 + b < N; b++) mine += gld32(idx + i0 + b) == cand;
+                        }
+                    }
+                nmc = bp_sum(mine, s_w);
+            }
+            // the three trials: 640 sampled rows each (or the whole page when N / 10 <= 64), one row per thread
+            const bool whole = N / SAMPLE_COUNT <= SAMPLE_SIZE;
+            const uint32_t sn = whole ? N : SAMPLE_ROWS;
+            auto trial = [&](uint32_t cd, bool rle) -> uint32_t {   // RLE: runs of the sample; else its bit-packed size
+                __syncthreads();
+                if (t < sn) {
+                    uint64_t row = 0;
+                    sample_row(N, p.seed, p.depth + 1, cd, t, row);
+                    s_x[t] = gld32(idx + row);
+                }
+                if (t < 8) s_y[t] = 0;
+                __syncthreads();
+                uint32_t v = 0;
+                if (rle) {
+                    v = bp_sum(t > 0 && t < sn && s_x[t] != s_x[t - 1] ? 1u : 0u, s_w);
+                    return sn ? v + 1 : 0;
+                }
+                const uint32_t nblk = sn / 128;
+                if (t < nblk * 128) atomicOr(&s_y[t >> 7], s_x[t]);
+                __syncthreads();
+                for (uint32_t b = 0; b < nblk; b++) v += 1 + 16 * (s_y[b] ? 32 - __clz(s_y[b]) : 0);
+                return v;
+            };
+            const double n_tuple = (double)N;
+            double n_max = a.ratio;
+            uint32_t n_res = a.default_compression;
+            static const uint8_t NORD[5] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_RLE, SB_CODEC_BITPACKING, SB_CODEC_DELTA_BITPACKING};
+            for (int oi = 0; oi < 5; oi++) {
+                const uint32_t cd = NORD[oi];
+                if ((forb_n >> cd) & 1) continue;
+                double r = 0.0;
+                if (cd == SB_CODEC_ONEVALUE) {
+                    r = n_all_equal ? n_tuple : 0.0;
+                } else if (cd == SB_CODEC_FREQ) {
+                    if (!n_all_equal && (double)nmc / n_tuple >= 0.9 && (int64_t)(D - 1) >= 256) r = (double)(N - 1);
+                } else if (cd == SB_CODEC_RLE) {
+                    const uint32_t runs = trial(cd, true);
+                    r = (double)((uint64_t)sn * 4) / (double)((uint64_t)runs * 8);
+                } else {
+                    if (N % 128 != 0) continue;
+                    if (cd == SB_CODEC_DELTA_BITPACKING && !n_sorted) continue;
+                    const uint32_t size = trial(cd, false);
+                    r = (double)((uint64_t)sn * 4) / (double)size;
+                    if (cd == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
+                }
+                if (r > n_max) {
+                    n_max = r;
+                    n_res = cd;
+                    if (r == n_tuple) break;
+                }
+            }
+            __syncthreads();
+        return n_res;
+    }
+}
+
+// ---- the index array bit-packed at dst (integer/bp.rs:45-61; BitPacker4x: a width byte, then 4 interleaved lanes per block
+// of 128), 32 768 indices per step through `tab` (the table's LDS, free by then); returns the bytes written.
+__device__ __forceinline__ uint32_t bp_pack_indices(uint8_t* dst, const uint32_t* idx, const uint32_t N, uint32_t* tab, uint32_t* s_x, uint32_t* s_w) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    {
+            constexpr uint32_t CH = 32768, NBLK = CH / 128, TPB = BP_WG / NBLK;   // 256 blocks per step, four threads per block
+            uint32_t* s_nb = s_x;              // [NBLK] widths
+            uint32_t* s_off = s_x + NBLK;      // [NBLK + 1] byte offsets inside the step
+            uint32_t out_pos = 0;
+            for (uint32_t cb = 0; cb < N; cb += CH) {
+                const uint32_t n = min(CH, N - cb), nblk = n / 128;
+                __syncthreads();
+                uint32_t acc = 0;
+                {   // 32 consecutive values per thread: staged, and OR-ed for the block's width
+                    const uint32_t v0 = t * (128 / TPB);
+                    if (v0 < n) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(idx + cb + v0 + 4 * q);
+                            *(__attribute__((address_space(3))) u32x4*)((l32p)tab + v0 + 4 * q) = v;
+                            acc |= v.x | v.y | v.z | v.w;
+                        }
+                    }
+                    acc |= __shfl_xor(acc, 1, 64);
+                    acc |= __shfl_xor(acc, 2, 64);
+                    if ((t & (TPB - 1)) == 0 && t / TPB < nblk) s_nb[t / TPB] = acc ? 32 - __clz(acc) : 0;
+                }
+                __syncthreads();
+                if (t < NBLK) {   // byte offsets of the step's blocks (four waves)
+                    const uint32_t nb = t < nblk ? s_nb[t] : 0u;
+                    const uint32_t by = t < nblk ? 1 + 16 * nb : 0u;
+                    const uint32_t ib = wave_incl_scan(by);
+                    if (lane == 63) s_w[wv] = ib;
+                    s_off[t] = ib - by;
+                }
+                __syncthreads();
+                if (t < NBLK) {
+                    uint32_t add = 0;
+                    for (uint32_t pw = 0; pw < wv; pw++) add += s_w[pw];
+                    s_off[t] += add;
+                }
+                const uint32_t step_bytes = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+                __syncthreads();
+                {   // pack: the step's blocks side by side, a word per thread and turn
+                    const uint32_t blk = t / TPB;
+                    if (blk < nblk) {
+                        const uint32_t nb = s_nb[blk], nw = 4 * nb;
+                        uint8_t* bo = dst + out_pos + s_off[blk] + 1;
+                        if ((t & (TPB - 1)) == 0) *(gptr)(bo - 1) = (uint8_t)nb;
+                        for (uint32_t wi = t & (TPB - 1); wi < nw; wi += TPB) {
+                            const uint32_t l = wi & 3, k = wi >> 2;  // word k of lane l
+                            const uint32_t lo_bit = 32 * k, hi_bit = 32 * k + 32;
+                            uint32_t word = 0;
+                            const uint32_t i0 = lo_bit / nb, i1 = min(31u, (hi_bit - 1) / nb);
+                            for (uint32_t i = i0; i <= i1; i++) {
+                                const uint32_t v = tab[blk * 128 + 4 * i + l];
+                                const uint32_t bitpos = i * nb;
+                                if (bitpos >= lo_bit) word |= v << (bitpos - lo_bit);
+                                else if (bitpos + nb > lo_bit) word |= v >> (lo_bit - bitpos);
+                            }
+                            stu32(bo + 4 * wi, word);
+                        }
+                    }
+                }
+                out_pos += step_bytes;
+            }
+            return out_pos;
+    }
+}
+
 template <class O>
 __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tab[BP_SLOTS];
@@ -520,131 +865,7 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
     const uint32_t codec = result;
     uint32_t D = 0;
     if (codec == SB_CODEC_DICT) {
-        STL(66);
-        // ---- ids in first-occurrence order: bitmap of the first KEYED rows, prefix popcounts, id = rank
-        s_x[t] = 0;
-        s_x[t + BP_WG] = 0;
-        __syncthreads();
-        for (uint32_t sl = t; sl < BP_SLOTS; sl += BP_WG) {
-            const uint32_t wd = tab[sl];
-            if (wd != BP_EMPTY && !(wd & BP_UNKEYED)) atomicOr(&s_x[(wd & 0xFFFFu) >> 5], 1u << (wd & 31u));
-        }
-        __syncthreads();
-        {
-            const uint32_t m0 = (uint32_t)__popc(s_x[2 * t]), m1 = (uint32_t)__popc(s_x[2 * t + 1]);
-            const uint32_t incl = wave_incl_scan(m0 + m1);
-            if (lane == 63) s_w[wv] = incl;
-            __syncthreads();
-            uint32_t run = incl - (m0 + m1);
-            for (uint32_t pw = 0; pw < wv; pw++) run += s_w[pw];
-#pragma unroll
-            for (int k = 0; k < BP_WG / 64; k++) D += s_w[k];
-            s_y[2 * t] = run;
-            s_y[2 * t + 1] = run + m0;
-        }
-        __syncthreads();
-        uint32_t* firsts = aux + BP_W_FIRSTS;
-        for (uint32_t sl = t; sl < BP_SLOTS; sl += BP_WG) {
-            const uint32_t wd = tab[sl];
-            if (wd == BP_EMPTY) continue;
-            uint32_t id = 0xFFFFFFFFu;
-            if (!(wd & BP_UNKEYED)) {
-                const uint32_t r = wd & 0xFFFFu;
-                id = s_y[r >> 5] + (uint32_t)__popc(s_x[r >> 5] & ((1u << (r & 31)) - 1u));
-                gst32(firsts + id, r);
-            }
-            tab[sl] = id;
-        }
-        __syncthreads();
-        STL(67);
-        // ---- the u32 index array (the last N words of the aux area, where the emitter's LZ4 scratch does not reach)
-        uint32_t* idx = aux + bh_table_slots(N) + 2 * (uint64_t)N;
-        if (!vv.bits) {
-            const uint32_t npair = (N + 1) / 2;
-            for (uint32_t k0 = t; k0 < npair; k0 += BP_WG * 8) {
-                uint32_t pr[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
-                    pr[u] = gld32((const uint32_t*)slot16 + (k < npair ? k : 0));
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t k = k0 + (uint32_t)u * BP_WG;
-                    if (k >= npair) continue;
-                    const uint32_t i0 = tab[pr[u] & 0xFFFFu];
-                    if (2 * k + 1 < N)
-                        gst64((uint64_t*)(idx + 2 * k), (uint64_t)i0 | ((uint64_t)tab[pr[u] >> 16] << 32));
-                    else
-                        gst32(idx + 2 * k, i0);
-                }
-            }
-        } else {
-            // a null row repeats the index before it (dict.rs:46-55): per 64-row chunk (a wave's step) the last keyed id, an
-            // inclusive "last one that has any" scan over the <= 1024 chunks, then the rows with the carry of the chunk before
-            const uint32_t nch = (N + 63) / 64;
-            constexpr int V = 4;   // (the loads of four steps together)
-            for (uint32_t base = 0; base < N; base += BP_WG * V) {
-                uint32_t sl[V], vb[V];
-#pragma unroll
-                for (int u = 0; u < V; u++) {
-                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
-                    sl[u] = ldu16((const uint8_t*)(slot16 + ic));
-                    vb[u] = ldu8(vv.bits + ((vv.off + ic) >> 3));
-                }
-#pragma unroll
-                for (int u = 0; u < V; u++) {
-                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
-                    const bool kd = i < N && (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1));
-                    const uint32_t sid = kd ? tab[sl[u]] : 0u;
-                    const uint64_t km = __ballot(kd);
-                    const uint32_t last = __shfl(sid, km ? 63 - __clzll((long long)km) : 0, 64);
-                    const uint32_t ch = (base + (uint32_t)u * BP_WG) / 64 + wv;
-                    if (lane == 0 && ch < nch) s_x[ch] = km ? last : 0xFFFFFFFFu;
-                }
-            }
-            __syncthreads();
-            {
-                const uint32_t v = t < nch ? s_x[t] : 0xFFFFFFFFu;
-                const uint64_t hm = __ballot(v != 0xFFFFFFFFu);
-                const uint64_t below = hm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
-                const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
-                const uint32_t got = __shfl(v, (int)src, 64);
-                uint32_t incl = below ? got : 0xFFFFFFFFu;
-                if (lane == 63) s_w[wv] = incl;
-                __syncthreads();
-                if (incl == 0xFFFFFFFFu)
-                    for (int pw = (int)wv - 1; pw >= 0; pw--)
-                        if (s_w[pw] != 0xFFFFFFFFu) {
-                            incl = s_w[pw];
-                            break;
-                        }
-                s_y[t] = incl;
-            }
-            __syncthreads();
-            for (uint32_t base = 0; base < N; base += BP_WG * V) {
-                uint32_t sl[V], vb[V];
-#pragma unroll
-                for (int u = 0; u < V; u++) {
-                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
-                    sl[u] = ldu16((const uint8_t*)(slot16 + ic));
-                    vb[u] = ldu8(vv.bits + ((vv.off + ic) >> 3));
-                }
-#pragma unroll
-                for (int u = 0; u < V; u++) {
-                    const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
-                    const bool kd = i < N && (i == 0 || ((vb[u] >> ((vv.off + ic) & 7)) & 1));
-                    const uint32_t sid = kd ? tab[sl[u]] : 0u;
-                    const uint64_t km = __ballot(kd);
-                    const uint64_t below = km & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
-                    const uint32_t src = below ? 63 - (uint32_t)__clzll((long long)below) : 0;
-                    const uint32_t got = __shfl(sid, (int)src, 64);
-                    const uint32_t ch = (base + (uint32_t)u * BP_WG) / 64 + wv;
-                    const uint32_t carry = ch && ch <= nch ? s_y[ch - 1] : 0u;
-                    if (i < N) gst32(idx + i, below ? got : carry);
-                }
-            }
-        }
+        D = bp_ids_and_index(tab, BP_SLOTS, s_x, s_y, s_w, aux, slot16, vv, N);
     }
     uint32_t bp_bytes = 0, ent_bytes = 0, ent_word = 0, icodec = 0xFFFFFFFFu;   // icodec: the index block's codec when this kernel chose it
     if (codec == SB_CODEC_DICT) {
@@ -659,137 +880,7 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
         // (maximum D - 1, never negative, no nulls), all_equal and sortedness from one pass over the index array, the Freq
         // majority by a vote + count, the RLE / Bitpacking / DeltaBitpacking trials on the seeded samples (sb_select.h:
         // sample_row, sample_rle_runs, sample_bp_size) gathered out of the index array.
-        if (p.icodec < 0) {
-            const uint32_t i00 = gld32(idx);
-            uint32_t f_neq0 = 0, f_uns = 0, vc = 0, vn = 0;
-            for (uint32_t i0 = t * 4; i0 < N; i0 += BP_WG * 4 * 4) {   // (four 16-byte loads per thread and step)
-                u32x4 q[4];
-                uint32_t pv[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * BP_WG * 4;
-                    q[u] = i + 4 <= N ? *(const __attribute__((address_space(1))) u32x4*)(idx + i) : u32x4{i00, i00, i00, i00};
-                    pv[u] = (i && i < N) ? gld32(idx + i - 1) : 0u;
-                    if (i < N && i + 4 > N) {   // (N % 4 != 0: the last values one by one)
-                        uint32_t w4[4] = {0, 0, 0, 0};
-                        for (uint32_t b = 0; i + b < N; b++) w4[b] = gld32(idx + i + b);
-                        for (uint32_t b = N - i; b < 4; b++) w4[b] = w4[N - i - 1];
-                        q[u] = u32x4{w4[0], w4[1], w4[2], w4[3]};
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * BP_WG * 4;
-                    if (i >= N) continue;
-                    const uint32_t w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-                    uint32_t prev = pv[u];
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        if (i + b >= N) break;
-                        if (w4[b] != i00) f_neq0 = 1;
-                        if ((i + b) && w4[b] < prev) f_uns = 1;
-                        prev = w4[b];
-                        if (vn == 0) {
-                            vc = w4[b];
-                            vn = 1;
-                        } else if (w4[b] == vc) {
-                            vn++;
-                        } else {
-                            vn--;
-                        }
-                    }
-                }
-            }
-            const uint32_t flags = bp_sum(f_neq0 | (f_uns << 16), s_w);
-            const bool n_all_equal = !(flags & 0xFFFFu), n_sorted = !(flags >> 16);
-            uint32_t nmc = 0;
-            if (!((forb_n >> SB_CODEC_FREQ) & 1) && !n_all_equal && D - 1 >= 256) {
-                s_x[t] = vc;
-                s_y[t] = vn;
-                __syncthreads();
-                for (uint32_t stride = BP_WG / 2; stride > 0; stride >>= 1) {
-                    if (t < stride) {
-                        const uint32_t c0 = s_x[t], n0 = s_y[t], c1 = s_x[t + stride], n1 = s_y[t + stride];
-                        uint32_t cc = c0, nn = n0;
-                        if (n1) {
-                            if (n0 == 0) { cc = c1; nn = n1; }
-                            else if (c0 == c1) nn = n0 + n1;
-                            else if (n1 > n0) { cc = c1; nn = n1 - n0; }
-                            else nn = n0 - n1;
-                        }
-                        s_x[t] = cc;
-                        s_y[t] = nn;
-                    }
-                    __syncthreads();
-                }
-                const uint32_t cand = s_x[0], cn = s_y[0];
-                __syncthreads();
-                uint32_t mine = 0;
-                if (cn && (double)cn + 1.0 >= 0.0)   // (count the candidate: a 90 % majority survives any merge order)
-                    for (uint32_t i0 = t * 4; i0 < N; i0 += BP_WG * 4) {
-                        if (i0 + 4 <= N) {
-                            const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(idx + i0);
-                            mine += (v.x == cand) + (v.y == cand) + (v.z == cand) + (v.w == cand);
-                        } else {
-                            for (uint32_t b = 0; i0 + b < N; b++) mine += gld32(idx + i0 + b) == cand;
-                        }
-                    }
-                nmc = bp_sum(mine, s_w);
-            }
-            // the three trials: 640 sampled rows each (or the whole page when N / 10 <= 64), one row per thread
-            const bool whole = N / SAMPLE_COUNT <= SAMPLE_SIZE;
-            const uint32_t sn = whole ? N : SAMPLE_ROWS;
-            auto trial = [&](uint32_t cd, bool rle) -> uint32_t {   // RLE: runs of the sample; else its bit-packed size
-                __syncthreads();
-                if (t < sn) {
-                    uint64_t row = 0;
-                    sample_row(N, p.seed, p.depth + 1, cd, t, row);
-                    s_x[t] = gld32(idx + row);
-                }
-                if (t < 8) s_y[t] = 0;
-                __syncthreads();
-                uint32_t v = 0;
-                if (rle) {
-                    v = bp_sum(t > 0 && t < sn && s_x[t] != s_x[t - 1] ? 1u : 0u, s_w);
-                    return sn ? v + 1 : 0;
-                }
-                const uint32_t nblk = sn / 128;
-                if (t < nblk * 128) atomicOr(&s_y[t >> 7], s_x[t]);
-                __syncthreads();
-                for (uint32_t b = 0; b < nblk; b++) v += 1 + 16 * (s_y[b] ? 32 - __clz(s_y[b]) : 0);
-                return v;
-            };
-            const double n_tuple = (double)N;
-            double n_max = a.ratio;
-            uint32_t n_res = a.default_compression;
-            static const uint8_t NORD[5] = {SB_CODEC_ONEVALUE, SB_CODEC_FREQ, SB_CODEC_RLE, SB_CODEC_BITPACKING, SB_CODEC_DELTA_BITPACKING};
-            for (int oi = 0; oi < 5; oi++) {
-                const uint32_t cd = NORD[oi];
-                if ((forb_n >> cd) & 1) continue;
-                double r = 0.0;
-                if (cd == SB_CODEC_ONEVALUE) {
-                    r = n_all_equal ? n_tuple : 0.0;
-                } else if (cd == SB_CODEC_FREQ) {
-                    if (!n_all_equal && (double)nmc / n_tuple >= 0.9 && (int64_t)(D - 1) >= 256) r = (double)(N - 1);
-                } else if (cd == SB_CODEC_RLE) {
-                    const uint32_t runs = trial(cd, true);
-                    r = (double)((uint64_t)sn * 4) / (double)((uint64_t)runs * 8);
-                } else {
-                    if (N % 128 != 0) continue;
-                    if (cd == SB_CODEC_DELTA_BITPACKING && !n_sorted) continue;
-                    const uint32_t size = trial(cd, false);
-                    r = (double)((uint64_t)sn * 4) / (double)size;
-                    if (cd == SB_CODEC_DELTA_BITPACKING) r *= 1.5;
-                }
-                if (r > n_max) {
-                    n_max = r;
-                    n_res = cd;
-                    if (r == n_tuple) break;
-                }
-            }
-            icodec = n_res;
-            __syncthreads();
-        }
+        if (p.icodec < 0) icodec = bp_index_codec(a, p, idx, N, D, forb_n, s_x, s_y, s_w);
         // ---- the dictionary's entries (u64 len | bytes, dictionary order: binary/dict.rs:84-93) in a staging area of the aux
         // words: the emitter places them behind the index block with one coalesced copy (its own pass — first row -> offsets
         // -> bytes for 20 entries per thread of a 256-thread workgroup — was a fifth of its time)
@@ -888,72 +979,8 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
         // ---- the index array bit-packed where the emitter's nested block will stand (integer/bp.rs:45-61; BitPacker4x: a
         // width byte, then 4 interleaved lanes per block of 128), speculatively: Dict pages of full blocks choose it almost
         // always, and then the emitter only writes the block's header.  16 384 indices per step through the table's LDS.
-        if (N % 128 == 0 && icodec == SB_CODEC_BITPACKING) {
-            uint8_t* slot = page_slot(a, c, p);
-            uint8_t* dst = slot + (c.nullable ? def_section_bytes(N) : 0) + 18;
-            constexpr uint32_t CH = 32768, NBLK = CH / 128, TPB = BP_WG / NBLK;   // 256 blocks per step, four threads per block
-            uint32_t* s_nb = s_x;              // [NBLK] widths
-            uint32_t* s_off = s_x + NBLK;      // [NBLK + 1] byte offsets inside the step
-            uint32_t out_pos = 0;
-            for (uint32_t cb = 0; cb < N; cb += CH) {
-                const uint32_t n = min(CH, N - cb), nblk = n / 128;
-                __syncthreads();
-                uint32_t acc = 0;
-                {   // 32 consecutive values per thread: staged, and OR-ed for the block's width
-                    const uint32_t v0 = t * (128 / TPB);
-                    if (v0 < n) {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(idx + cb + v0 + 4 * q);
-                            *(__attribute__((address_space(3))) u32x4*)((l32p)tab + v0 + 4 * q) = v;
-                            acc |= v.x | v.y | v.z | v.w;
-                        }
-                    }
-                    acc |= __shfl_xor(acc, 1, 64);
-                    acc |= __shfl_xor(acc, 2, 64);
-                    if ((t & (TPB - 1)) == 0 && t / TPB < nblk) s_nb[t / TPB] = acc ? 32 - __clz(acc) : 0;
-                }
-                __syncthreads();
-                if (t < NBLK) {   // byte offsets of the step's blocks (four waves)
-                    const uint32_t nb = t < nblk ? s_nb[t] : 0u;
-                    const uint32_t by = t < nblk ? 1 + 16 * nb : 0u;
-                    const uint32_t ib = wave_incl_scan(by);
-                    if (lane == 63) s_w[wv] = ib;
-                    s_off[t] = ib - by;
-                }
-                __syncthreads();
-                if (t < NBLK) {
-                    uint32_t add = 0;
-                    for (uint32_t pw = 0; pw < wv; pw++) add += s_w[pw];
-                    s_off[t] += add;
-                }
-                const uint32_t step_bytes = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-                __syncthreads();
-                {   // pack: the step's blocks side by side, a word per thread and turn
-                    const uint32_t blk = t / TPB;
-                    if (blk < nblk) {
-                        const uint32_t nb = s_nb[blk], nw = 4 * nb;
-                        uint8_t* bo = dst + out_pos + s_off[blk] + 1;
-                        if ((t & (TPB - 1)) == 0) *(gptr)(bo - 1) = (uint8_t)nb;
-                        for (uint32_t wi = t & (TPB - 1); wi < nw; wi += TPB) {
-                            const uint32_t l = wi & 3, k = wi >> 2;  // word k of lane l
-                            const uint32_t lo_bit = 32 * k, hi_bit = 32 * k + 32;
-                            uint32_t word = 0;
-                            const uint32_t i0 = lo_bit / nb, i1 = min(31u, (hi_bit - 1) / nb);
-                            for (uint32_t i = i0; i <= i1; i++) {
-                                const uint32_t v = tab[blk * 128 + 4 * i + l];
-                                const uint32_t bitpos = i * nb;
-                                if (bitpos >= lo_bit) word |= v << (bitpos - lo_bit);
-                                else if (bitpos + nb > lo_bit) word |= v >> (lo_bit - bitpos);
-                            }
-                            stu32(bo + 4 * wi, word);
-                        }
-                    }
-                }
-                out_pos += step_bytes;
-            }
-            bp_bytes = out_pos;
-        }
+        if (N % 128 == 0 && icodec == SB_CODEC_BITPACKING)
+            bp_bytes = bp_pack_indices(page_slot(a, c, p) + (c.nullable ? def_section_bytes(N) : 0) + 18, idx, N, tab, s_x, s_w);
     }
     STL(68);
     if (t == 0) {
@@ -971,5 +998,122 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
             raise(a.status, SB_ERR_NYI, page, 700 + codec);
         else if (codec == SB_CODEC_FREQ)
             atomicAdd(a.freq_count, 1u);
+    }
+}
+
+// ---- Dict pages of 1- / 2- / 4-byte INTEGERS (the selector chose Dict; integer/dict.rs:33-73): the dictionary, the index
+// array, the index block's codec and its bit-packed body by one workgroup of 1024 threads, as for binary pages — the page
+// kernel (k_enc_emit_pages<W, Dict>: LDS / HBM table, choose_prim over the indices, enc_bp — one 256-thread workgroup, two
+// per CU, 0.5 ms for C4's 306 Int32 pages whatever the load) then writes headers and the dictionary's values.  The table's
+// slot holds the key itself (key32 | row16 in a u64: exact, no gathers); only keyed rows are entered (row 0 and the valid
+// rows: a leading null interns T::default(), dict.rs:46-50).  A page with more than PD_CAP distinct values is left to the
+// page kernel.  Floats stay there too (a NaN equals nothing: every NaN row is an entry of its own).
+template <int W>
+__global__ void __launch_bounds__(BP_WG) k_enc_prim_dict(EncodeArgs a) {
+    static_assert(W == 1 || W == 2 || W == 4, "keys of up to 32 bits");
+    __shared__ __attribute__((aligned(16))) uint32_t tab[BP_SLOTS];   // PD_SLOTS u64 slots, later PD_SLOTS u32 words (bp_ids_and_index)
+    __shared__ uint32_t s_x[2048];
+    __shared__ uint32_t s_y[2048];
+    __shared__ uint32_t s_w[BP_WG / 64];
+    __shared__ uint32_t s_cnt;
+    if (a.use_counts && a.codec_counts[SB_CODEC_DICT] == 0) return;
+    const uint32_t t = threadIdx.x;
+    const uint32_t page = spread_block(blockIdx.x, gridDim.x) + a.page_base;
+    const EncPage p = get_page(a, page);
+    if (codec_of(a, p, page) != SB_CODEC_DICT) return;
+    const EncCol c = get_col(a, p.col);
+    if (!pd_page_ok(a, p, page, c, W)) return;
+    if (a.outs[page].pad == 1 && a.outs[page].length != 0) return;   // (already written)
+    const uint32_t N = (uint32_t)p.rows;
+    uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
+    uint16_t* slot16 = (uint16_t*)(aux + bp_w_slot16(N));
+    const uint8_t* vals = c.values + p.row0 * W;
+    const ValidView vv{c.validity, c.validity_bit_offset + p.row0};
+    unsigned long long* t64 = (unsigned long long*)tab;
+    for (uint32_t i = t; i < PD_SLOTS; i += BP_WG) t64[i] = ~0ull;
+    if (t == 0) {
+        s_cnt = 0;
+        gst32(aux + BH_W_FUSED, 0u);   // (a stale mark of an earlier call must not survive a page this kernel gives up on)
+        gst32(aux + BH_W_MAGIC, 0u);
+    }
+    __syncthreads();
+    constexpr int U = 8;
+    for (uint32_t base = 0; base < N; base += BP_WG * U) {
+        if (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > PD_CAP) break;
+        uint32_t key[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+            if constexpr (W == 4) key[u] = ldu32(vals + (uint64_t)ic * 4);
+            else if constexpr (W == 2) key[u] = ldu16(vals + (uint64_t)ic * 2);
+            else key[u] = ldu8(vals + ic);
+            vb[u] = vv.bits ? (uint32_t)ldu8(vv.bits + ((vv.off + ic) >> 3)) : 0xFFu;
+        }
+        uint32_t newk = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = base + (uint32_t)u * BP_WG + t, ic = i < N ? i : N - 1;
+            if (i >= N) continue;
+            const bool valid = (vb[u] >> ((vv.off + ic) & 7)) & 1;
+            uint32_t sl = 0;
+            if (valid || i == 0) {
+                const uint32_t k = valid ? key[u] : 0u;   // (a leading null interns the default value)
+                uint32_t h = k * 0x9E3779B1u;
+                h ^= h >> 15;
+                h *= 0x85EBCA6Bu;
+                h ^= h >> 13;
+                sl = h & (PD_SLOTS - 1);
+                const unsigned long long wd = ((unsigned long long)k << 32) | (i & 0xFFFFu);
+                for (;;) {
+                    unsigned long long cur = t64[sl];
+                    if (cur == ~0ull) {
+                        cur = atomicCAS(&t64[sl], ~0ull, wd);
+                        if (cur == ~0ull) {
+                            newk++;
+                            break;
+                        }
+                    }
+                    if ((uint32_t)(cur >> 32) == k && (uint32_t)(cur >> 16 & 0xFFFFu) == 0) {
+                        if (wd < cur) atomicMin(&t64[sl], wd);
+                        break;
+                    }
+                    sl = (sl + 1) & (PD_SLOTS - 1);
+                }
+            }
+            *(__attribute__((address_space(1))) uint16_t*)(slot16 + i) = (uint16_t)sl;
+        }
+        if (newk) atomicAdd(&s_cnt, newk);
+    }
+    __syncthreads();
+    if (s_cnt > PD_CAP) return;   // (the page kernel builds this one)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    {   // the u64 slots -> the u32 words bp_ids_and_index reads (keyed, row16), in place: everything is read first
+        unsigned long long cur[PD_SLOTS / BP_WG];
+#pragma unroll
+        for (uint32_t q = 0; q < PD_SLOTS / BP_WG; q++) cur[q] = t64[t + q * BP_WG];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < PD_SLOTS / BP_WG; q++) tab[t + q * BP_WG] = cur[q] == ~0ull ? BP_EMPTY : (uint32_t)(cur[q] & 0xFFFFu);
+        __syncthreads();
+    }
+    const uint32_t D = bp_ids_and_index(tab, PD_SLOTS, s_x, s_y, s_w, aux, slot16, vv, N);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t* idx = aux + bh_table_slots(N) + 2 * (uint64_t)N;
+    const uint32_t forb_n = a.forbidden | p.forb_extra | (1u << SB_CODEC_DICT);
+    const uint32_t icodec = bp_index_codec(a, p, idx, N, D, forb_n, s_x, s_y, s_w);
+    uint32_t bp_bytes = 0;
+    if (N % 128 == 0 && icodec == SB_CODEC_BITPACKING)
+        bp_bytes = bp_pack_indices(page_slot(a, c, p) + (c.nullable ? def_section_bytes(N) : 0) + 18, idx, N, tab, s_x, s_w);
+    if (t == 0) {
+        gst32(aux + BH_W_ICODEC, icodec + 1u);
+        gst32(aux + BH_W_BPBYTES, bp_bytes);
+        gst32(aux + BH_W_ENTBYTES, 0u);
+        gst32(aux + BH_W_D, D);
+        gst32(aux + BH_W_BAD, 0u);
+        gst32(aux + BH_W_MAGIC, BH_MAGIC2);
+        gst32(aux + BH_W_FUSED, PD_DONE);
     }
 }

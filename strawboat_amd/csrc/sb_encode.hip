@@ -2860,6 +2860,48 @@ __device__ __forceinline__ uint32_t spread_block(uint32_t b, uint32_t nblocks) {
     return (g << 3) | ((b + ((g * 0x9E3779B1u) >> 29)) & 7);
 }
 
+// ---- k_enc_bin_page / k_enc_prim_dict (sb_bin_page.h): what the page kernels below need to know about them
+#ifndef SB_BIN_BIG_ROWS
+#define SB_BIN_BIG_ROWS (1ull << 18)
+#endif
+constexpr uint64_t BP_BIG_ROWS = SB_BIN_BIG_ROWS;   // (= BIN_BIG_ROWS of sb_select_big.h: such pages take the section-parallel path)
+constexpr int BP_WG = 1024;
+constexpr uint32_t BP_SLOTS = 32768;          // limit (<= 21 845) + one step of the whole workgroup (4096) never fills it
+constexpr uint32_t BP_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t BP_UNKEYED = 0x10000u;
+constexpr uint64_t BP_MIN_ROWS = 512;
+constexpr uint32_t BH_W_FUSED = 3;            // aux word: BP_DONE when this kernel decided the page in this call
+constexpr uint32_t BP_DONE = 0x46555345u;
+constexpr uint32_t BH_MAGIC2 = 0x48444232u;   // aux[BH_W_MAGIC]: a dictionary in the layout below was handed over
+constexpr uint32_t BH_W_BPBYTES = 4, BH_W_ENTBYTES = 5, BH_W_ENTWORD = 6, BH_W_ICODEC = 7;   // aux words: the speculative bit-packed index block / the staged entries
+constexpr uint32_t BP_W_FIRSTS = 16;          // firsts[<= (N - 1) / 3], then slot16[N]; idx in the last N words of the aux area
+__host__ __device__ __forceinline__ uint64_t bp_w_slot16(uint64_t N) { return (BP_W_FIRSTS + N / 3 + 2 + 3) & ~3ull; }
+__host__ __device__ __forceinline__ bool bp_fits(uint64_t N, uint64_t aux_bytes) {
+    const uint64_t M = bh_table_slots(N);
+    return N >= BP_MIN_ROWS && N <= 65536 && bp_w_slot16(N) + (N + 1) / 2 + 4 <= M && aux_bytes / 4 >= M + 3 * N;
+}
+// the pages this kernel takes: a pure function of the launch and the page (every later kernel asks the same question)
+__device__ __forceinline__ bool bp_page_ok(const EncodeArgs& a, const EncPage& p, uint32_t page) {
+    return a.bin_fused && a.use_counts && a.page_base == 0 && page < a.n_pages && a.has_ratio && p.codec == CODEC_ON_DEVICE &&
+           p.h64_off != ~0ull && p.aux_bytes && bp_fits(p.rows, p.aux_bytes) && !(p.rows >= BP_BIG_ROWS && p.bigx_off) &&
+           !(((a.forbidden | p.forb_extra) >> SB_CODEC_DICT) & 1);
+}
+__device__ __forceinline__ bool bp_page_done(const EncodeArgs& a, const EncPage& p, uint32_t page) {
+    return bp_page_ok(a, p, page) && gld32((const uint32_t*)(a.scratch + p.aux_off) + BH_W_FUSED) == BP_DONE;
+}
+constexpr uint32_t PD_SLOTS = BP_SLOTS / 2, PD_CAP = 10240;
+constexpr uint32_t PD_DONE = 0x50444943u;   // aux[BH_W_FUSED]
+__device__ __forceinline__ bool pd_page_ok(const EncodeArgs& a, const EncPage& p, uint32_t page, const EncCol& c, uint32_t W) {
+    return a.bin_fused && a.use_counts && a.page_base == 0 && page < a.n_pages && a.has_ratio && p.codec == CODEC_ON_DEVICE && p.icodec < 0 &&
+           p.aux_bytes && bp_fits(p.rows, p.aux_bytes) && !(p.rows >= BP_BIG_ROWS && p.bigx_off) && c.fkind == 0 && c.width == W &&
+           c.ptype != SB_TYPE_BOOLEAN && c.ptype != SB_TYPE_BINARY && c.ptype != SB_TYPE_LARGE_BINARY && c.ptype != SB_TYPE_NULL;
+}
+__device__ __forceinline__ bool pd_page_done(const EncodeArgs& a, const EncPage& p, uint32_t page, const EncCol& c, uint32_t W) {
+    if (!pd_page_ok(a, p, page, c, W)) return false;
+    const uint32_t* aux = (const uint32_t*)(a.scratch + p.aux_off);
+    return gld32(aux + BH_W_FUSED) == PD_DONE && gld32(aux + BH_W_MAGIC) == BH_MAGIC2;
+}
+
 // ------------------------------------------------------------------------------ page kernels
 struct PageCtx {
     const EncCol* c;
@@ -2944,12 +2986,25 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
         uint32_t* aux = (uint32_t*)(a.scratch + p.aux_off);
         uint32_t D = DICT_FALLBACK;
         STL(50);
-        if constexpr (W <= 8) D = dict_build_lds<W>(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA);
-        if (D == DICT_FALLBACK) D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
+        uint32_t pre_ic = 0, pre_bp = 0;   // k_enc_prim_dict's index codec (+ 1) / bit-packed block
+        bool pre = false;
+        if constexpr (W <= 4) pre = pd_page_done(a, p, page, c, (uint32_t)W);
+        if (pre) {   // dictionary, indices, index codec (and its bit-packed body) by k_enc_prim_dict
+            idx = aux + bh_table_slots(N) + 2 * N;
+            firsts = aux + BP_W_FIRSTS;
+            D = gld32(aux + BH_W_D);
+            pre_ic = gld32(aux + BH_W_ICODEC);
+            pre_bp = gld32(aux + BH_W_BPBYTES);
+        } else {
+            if constexpr (W <= 8) D = dict_build_lds<W>(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA);
+            if (D == DICT_FALLBACK) D = dict_build(ko, N, aux, p.aux_bytes / 4, &idx, &firsts, sA, sB, s_w, a.status, page);
+        }
         if (D == EMPTY) return 0;
         STL(51);
         int32_t ic = p.icodec >= 0 ? p.icodec : (int32_t)a.default_compression;
-        if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
+        if (p.icodec < 0 && a.has_ratio && pre_ic) {
+            ic = (int32_t)pre_ic - 1;
+        } else if (p.icodec < 0 && a.has_ratio) {  // nested compress_integer::<u32>: same selector, Dict forbidden (dict.rs:60-62)
             SelectOpts so{a.ratio, 1u, a.forbidden | p.forb_extra | (1u << SB_CODEC_DICT), a.default_compression, -1, p.seed, p.depth + 1};
             SelScratch sc{sA, sA + SEL_LDS_SLOTS, (uint8_t*)(sA + SEL_LDS_SLOTS + 2 * WG + 16), nullptr, 0};
             const uint32_t* ip = idx;
@@ -2985,7 +3040,13 @@ __device__ uint64_t emit_prim_page(const EncodeArgs& a, const EncCol& c, const E
             const uint64_t aux_words = p.aux_bytes / 4;
             if (aux_words >= M + 3 * N) lz_tmp = (uint8_t*)(idx == aux ? aux + (aux_words - 2 * N) : aux + M);
         }
-        const uint64_t ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags, lz_tmp, 8 * N);
+        uint64_t ib;
+        if (ic == SB_CODEC_BITPACKING && pre_bp) {   // the body stands there already: the block's header
+            if (threadIdx.x == 0) put_hdr9(blk + 9, SB_CODEC_BITPACKING, pre_bp, (uint32_t)(N * 4));
+            ib = 9 + (uint64_t)pre_bp;
+        } else {
+            ib = enc_u32_block(idx, N, ic, blk + 9, sA, sB, sC, s_w, a.status, page, a.flags, lz_tmp, 8 * N);
+        }
         if (ib == 0) return 0;
         STL(53);
         uint8_t* q = blk + 9 + ib;
@@ -3042,36 +3103,6 @@ __device__ uint64_t emit_bool_page(const EncodeArgs& a, const EncCol& c, const E
 // The builder's side of bin_dict_handover: the selector of this launch left id16[slot], firsts[id], D and the slot of every
 // row in the aux area; what remains is the index of every row — a keyed row takes its key's id, a null row repeats the
 // index before it (binary/dict.rs:55-93) — one streaming pass with the id table in LDS.
-// ---- k_enc_bin_page (sb_bin_page.h): what the page kernels below need to know about it
-#ifndef SB_BIN_BIG_ROWS
-#define SB_BIN_BIG_ROWS (1ull << 18)
-#endif
-constexpr uint64_t BP_BIG_ROWS = SB_BIN_BIG_ROWS;   // (= BIN_BIG_ROWS of sb_select_big.h: such pages take the section-parallel path)
-constexpr int BP_WG = 1024;
-constexpr uint32_t BP_SLOTS = 32768;          // limit (<= 21 845) + one step of the whole workgroup (4096) never fills it
-constexpr uint32_t BP_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t BP_UNKEYED = 0x10000u;
-constexpr uint64_t BP_MIN_ROWS = 512;
-constexpr uint32_t BH_W_FUSED = 3;            // aux word: BP_DONE when this kernel decided the page in this call
-constexpr uint32_t BP_DONE = 0x46555345u;
-constexpr uint32_t BH_MAGIC2 = 0x48444232u;   // aux[BH_W_MAGIC]: a dictionary in the layout below was handed over
-constexpr uint32_t BH_W_BPBYTES = 4, BH_W_ENTBYTES = 5, BH_W_ENTWORD = 6, BH_W_ICODEC = 7;   // aux words: the speculative bit-packed index block / the staged entries
-constexpr uint32_t BP_W_FIRSTS = 16;          // firsts[<= (N - 1) / 3], then slot16[N]; idx in the last N words of the aux area
-__host__ __device__ __forceinline__ uint64_t bp_w_slot16(uint64_t N) { return (BP_W_FIRSTS + N / 3 + 2 + 3) & ~3ull; }
-__host__ __device__ __forceinline__ bool bp_fits(uint64_t N, uint64_t aux_bytes) {
-    const uint64_t M = bh_table_slots(N);
-    return N >= BP_MIN_ROWS && N <= 65536 && bp_w_slot16(N) + (N + 1) / 2 + 4 <= M && aux_bytes / 4 >= M + 3 * N;
-}
-// the pages this kernel takes: a pure function of the launch and the page (every later kernel asks the same question)
-__device__ __forceinline__ bool bp_page_ok(const EncodeArgs& a, const EncPage& p, uint32_t page) {
-    return a.bin_fused && a.use_counts && a.page_base == 0 && page < a.n_pages && a.has_ratio && p.codec == CODEC_ON_DEVICE &&
-           p.h64_off != ~0ull && p.aux_bytes && bp_fits(p.rows, p.aux_bytes) && !(p.rows >= BP_BIG_ROWS && p.bigx_off) &&
-           !(((a.forbidden | p.forb_extra) >> SB_CODEC_DICT) & 1);
-}
-__device__ __forceinline__ bool bp_page_done(const EncodeArgs& a, const EncPage& p, uint32_t page) {
-    return bp_page_ok(a, p, page) && gld32((const uint32_t*)(a.scratch + p.aux_off) + BH_W_FUSED) == BP_DONE;
-}
-
 template <class O>
 __device__ uint32_t bin_dict_from_handover(const BinKeys<O>& bk, uint64_t N, uint32_t* aux, uint32_t** idx_out, uint32_t** firsts_out,
                                            uint32_t* sA, uint32_t* sB, uint32_t* lds_id16 /* BH_SLOTS / 2 words */, uint32_t* s_w) {
@@ -5927,6 +5958,7 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
     // launches that the last call with this plan would not have needed (its pages per codec, read back with its results):
     // skipped; a page that needs one after all stays unwritten and the interval is replayed with everything (k_enc_layout)
     uint32_t emit_skips = 0;
+    auto unused_peek = [&](int slot) { return big_hint && !plan.last_counts[slot]; };
     auto unused = [&](int slot) {
         if (!big_hint || plan.last_counts[slot]) return false;
         emit_skips |= SKIP_EMIT;
@@ -5938,7 +5970,8 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
         aa.pre_hashed = 0;
         aa.redo = 0;
         // binary pages of BP_MIN_ROWS .. 65 536 rows: codec and dictionary in one pass (sb_bin_page.h); the chain below only for the rest
-        aa.bin_fused = wave_adaptive && !nested && ctx->bin_fused && plan.bin_pages && !(opts->flags & SB_WRITE_DEBUG_VERIFY_FAIL_BIT) ? 1u : 0u;
+        // (the flag also switches on k_enc_prim_dict for integer Dict pages: binary pages or not)
+        aa.bin_fused = wave_adaptive && !nested && ctx->bin_fused && !(opts->flags & SB_WRITE_DEBUG_VERIFY_FAIL_BIT) ? 1u : 0u;
         const bool old_chain = !aa.bin_fused || plan.bin_unfused;
         int n_bin_kinds = 0;
         for (int kd : kinds) n_bin_kinds += kd < 0 ? 1 : 0;
@@ -5962,7 +5995,7 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
         if (multi) side_mask = n_bin_kinds ? 1u : 2u;
         if (multi && n_bin_kinds == (int)kinds.size()) side_mask = 0;   // (only binary kinds: nothing to overlap with)
         auto launch_hash = [&](hipStream_t st) {   // row hashes of the binary pages, tile-parallel, before their selector
-            if (aa.bin_fused) {
+            if (aa.bin_fused && plan.bin_pages) {
                 KScope k(ctx, "k_enc_bin_page");
                 for (int kd : kinds) {
                     if (kd == -4) k_enc_bin_page<int32_t><<<(uint32_t)P, BP_WG, 0, st>>>(aa);
@@ -6168,6 +6201,12 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
                 }
                 EncPageKernel kf = enc_page_kernel(kd, cd);
                 if (!kf) continue;
+                if (cd == SB_CODEC_DICT && aa.bin_fused && (kd == 1 || kd == 2 || kd == 4) && !unused_peek(SB_CODEC_DICT)) {
+                    KScope k(ctx, "k_enc_prim_dict");   // integer Dict pages of up to 65 536 rows: sb_bin_page.h
+                    if (kd == 4) k_enc_prim_dict<4><<<(uint32_t)P, BP_WG, 0, st>>>(aa);
+                    else if (kd == 2) k_enc_prim_dict<2><<<(uint32_t)P, BP_WG, 0, st>>>(aa);
+                    else k_enc_prim_dict<1><<<(uint32_t)P, BP_WG, 0, st>>>(aa);
+                }
                 // (4- / 8-byte RLE pages come out of the fused selectors: slot 29 counts the ones the page kernel had to write)
                 if (wave_adaptive && !nested && unused(cd == SB_CODEC_RLE && (kd == 4 || kd == 8) ? 29 : (int)cd)) continue;
                 char nm[48];

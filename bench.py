@@ -217,6 +217,38 @@ class GpuHarness:
         return dict(U=U, page_bytes=pb, n_pages=npages, enc_ms=te, dec_ms=td, kernels=st, enc=enc)
 
 
+def cold_leg(col, o):
+    """A one-page column in a context whose last call with the same plan wrote a PLAIN page (random values of the same shape):
+    the launch hints are wrong for it, the page is left undone and the interval is issued again (sb_ctx_replays) — wall ms of
+    that first write / read (host clock, synchronize included) next to the second call's.  Before round 6 such a call fell
+    to the one-workgroup kernels (75 ms for a Freq page, 832 ms for a 68 MB LZ4 block)."""
+    import strawboat_amd as sb
+    from strawboat_amd import read, write
+    ctx2 = sb.Context(0)
+    h2 = GpuHarness(ctx2)
+    rng = np.random.default_rng(99)
+    v = np.asarray(col["values"])
+    prime = dict(col)
+    prime["values"] = (rng.integers(0, 256, v.nbytes, dtype=np.uint8).view(v.dtype) if col["offsets"] is None
+                       else rng.integers(97, 123, v.size, dtype=np.uint8))
+    out = {}
+    for name, c in (("prime", prime), ("first", col), ("second", col)):
+        dc = [h2.dcol(c)]
+        ctx2.synchronize()
+        t0 = time.perf_counter()
+        enc = write.encode_columns(ctx2, dc, o)
+        ctx2.synchronize()
+        te = (time.perf_counter() - t0) * 1e3
+        pages = [read.ColumnPages(c["ptype"], c["nullable"], enc[0].pages, enc[0].metas_array())]
+        t0 = time.perf_counter()
+        dec = read.batch_read_columns(ctx2, pages)
+        ctx2.synchronize()
+        out[name] = [round(te, 3), round((time.perf_counter() - t0) * 1e3, 3)]
+        del dec
+    return {"first_call_after_a_plain_page_ms": out["first"], "second_call_ms": out["second"], "replays": ctx2.replays(),
+            "note": "host wall clock incl. synchronize; [write, read]"}
+
+
 def measure_reference_pages(h, cols, sbo_opts, reps=3, check_all=False):
     """decode of pages the REFERENCE's codecs wrote: the restatement with the box's liblz4 / libzstd writes the columns'
     pages in the untimed setup (one LZ4 block / one libzstd frame per buffer, src/compression/basic.rs:108-135), the device
@@ -429,12 +461,16 @@ def run_configs(h, only, cpu_on, log):
         cols = gen_parallel(W.c1_int64, range(42, 42 + 128))
         flat("c1", "C1: 128 x 1M-row non-nullable Int64, one page per column, no compression (the north-star "
                    "'1 M-row primitive-page decode' shape)", cols, WriteOptions(), cols[:2], reps=10)
-    if want("c3") or want("c3_lz4"):
+    if want("c3") or want("c3_lz4") or want("c3_512"):
         cols = gen_parallel(lambda s: W.zipf_utf8(ROWS, s), range(42, 42 + 64))
         if want("c3"):
             flat("c3", "C3: 64 x 1M-row Utf8 (zipf 1.1 over 10 000 words of 4..24 B), 64Ki-row pages, LZ4 default, ratio 2.0 "
                        "-> Dict pages with Bitpacking / LZ4 indices", cols,
                  WriteOptions(max_page_size=PAGE, default_compression=C.LZ4, default_compress_ratio=2.0), cols[:1], reps=3)
+        if want("c3_512"):   # the same 64 columns eight times over: C3 at the headline's batch size (8 192 pages), so that the
+            # per-kernel floors of a 1 024-page batch and the throughput can be told apart
+            flat("c3_512", "C3 x 8: 512 x 1M-row Utf8 columns (the 64 columns of c3 eight times), same options", cols * 8,
+                 WriteOptions(max_page_size=PAGE, default_compression=C.LZ4, default_compress_ratio=2.0), cols[:1], reps=2, codecs=False)
         if want("c3_lz4"):
             o_lz4 = WriteOptions(max_page_size=PAGE, default_compression=C.LZ4)
             flat("c3_lz4", "C3': the same columns, Basic(LZ4) pages (offsets block + values block), ratio None", cols, o_lz4, cols[:1], reps=3)
@@ -493,6 +529,10 @@ def run_configs(h, only, cpu_on, log):
             if cpu_on:   # the reference works through a page on ONE thread
                 cpu = cpu_baseline([col], sbo_options(o), W.arrow_bytes(col), "the same one-page column, encode+decode, 1 thread", all_cores=False, iters=1)
             one[nm] = config_entry(nm, res, cpu, {"workload": "ONE page of %d rows: %s" % (col["rows"], desc)})
+            try:
+                one[nm]["cold"] = cold_leg(col, o)
+            except Exception as e:
+                one[nm]["cold"] = {"error": "%s: %s" % (type(e).__name__, e)}
             log("one_page %s: encode %.1f GB/s, decode %.1f GB/s" % (nm, one[nm]["encode"]["GBps"], one[nm]["decode"]["GBps"]))
         out["one_page"] = one
         del i64, utf8, runs, lowc, sparse, sp
@@ -979,6 +1019,10 @@ def config_summary(configs):
             sa = e.get("single_array")
             if isinstance(sa, dict) and "encode_ms" in sa:
                 s += "; 1 array %s/%s ms" % (_f(sa["encode_ms"]), _f(sa["decode_ms"]))
+            cold = e.get("cold")
+            if isinstance(cold, dict) and "first_call_after_a_plain_page_ms" in cold:   # (wrong launch hints: replayed, not walked)
+                f, w = cold["first_call_after_a_plain_page_ms"], cold["second_call_ms"]
+                s += "; cold %s/%s ms (warm %s/%s)" % (_f(f[0]), _f(f[1]), _f(w[0]), _f(w[1]))
             out[k] = s
         elif "decode" in e and "written_by" in e:
             out[k] = "dec %s GB/s (%s of HBM peak)" % (_f(e["decode"]["GBps"]), _f(e["decode"]["frac_hbm"]))

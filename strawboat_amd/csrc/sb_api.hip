@@ -392,7 +392,7 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         ctx->no_hints = true;
         ctx->in_replay = true;
         ctx->replays++;
-        ctx->lzg_state = 1;
+        if (ctx->h_status->kinds & KIND_REPLAY_LZG) ctx->lzg_state = 1;
         for (auto& cl : calls) {
             rc = cl.kind ? sb_write_columns(ctx, (sb_column_write*)cl.cols, cl.n, &cl.opts, cl.mem) : sb_read_columns(ctx, (sb_column_read*)cl.cols, cl.n, cl.mem);
             if (rc != SB_OK) break;
@@ -615,7 +615,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     const size_t o_vlen = off;
     off = align_up(off + n * sizeof(uint64_t), 64);
     // the block-parallel Zstd pipeline: frames + counters here, blocks / literals / records in pools of their own
-    const bool zb_on = ctx->zb_mode == 1 || (ctx->zb_mode == 2 && ctx->zstd_recent);
+    const bool zb_on = ctx->zb_mode == 1 || (ctx->zb_mode == 2 && (ctx->zstd_recent || ctx->no_hints));
     ctx->read_calls++;
     const size_t o_zb_counts = off;
     if (zb_on) off = align_up(off + 64, 64);
@@ -768,6 +768,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     memset(&a.lzg, 0, sizeof a.lzg);
     a.lzg_chunks = a.lzg_wins = a.lzg_rounds = a.lzg_jobs = 0;
     a.lzg_skipped = 0;
+    a.zb_skipped = (!zb_on && ctx->zb_mode == 2 && !sizes_only && max_page_len >= (1u << 20)) ? 1u : 0u;
     if (!sizes_only && max_page_len >= LZG_MIN && ctx->lzg_state == 2 && !ctx->no_hints) {
         // the context's last intervals met no LZ4 block of megabytes: no pool, no launches; k_inflate_lz4_big leaves such
         // a block alone and asks for the replay (it used to walk it with one workgroup: 0.8 s for 68 MB)

@@ -113,6 +113,7 @@ struct Status {
 constexpr uint32_t KIND_ZSTD = 1u;   // a Zstd buffer was queued
 constexpr uint32_t KIND_LZ4_GIANT = 4u;   // an LZ4 block of >= LZG_MIN compressed bytes was queued (sb_lz4_giant.h is launched for contexts that meet them)
 constexpr uint32_t KIND_REPLAY = 8u;      // a page was left undone because a kernel it needed was not launched on a hint: sb_ctx_synchronize re-issues the interval's calls with everything launched
+constexpr uint32_t KIND_REPLAY_LZG = 16u; // ... and it was an LZ4 block of megabytes that asked (the context turns the block-parallel chain on again)
 constexpr uint32_t KIND_ZSEQ_LONG = 2u;   // a Zstd block of >= 8192 sequences was met (zb_hdr): the sequence chains are the long pole
 
 // one general-purpose block (LZ4 / Zstd / Snappy) to inflate: src -> dst
@@ -264,6 +265,7 @@ struct DecodeArgs {
     // LZ4 blocks of LZG_MIN compressed bytes and more, block-parallel (sb_lz4_giant.h); lzg.jobs == nullptr: not in this call
     LzgArgs lzg;
     uint32_t lzg_chunks, lzg_wins, lzg_rounds, lzg_jobs;   // grid sizes: the longest page / the largest output of the call / pages long enough
+    uint32_t zb_skipped;    // the block-parallel Zstd pipeline was left out on a hint (the context's last intervals read no Zstd buffer): a Zstd buffer of a megabyte or more asks for the replay instead of going frame by frame through the one-wave decoder (20 ms for a 96 MB page against 1.3)
     uint32_t lzg_skipped;   // the call has pages long enough but the context's last intervals met no such block: the chain is not launched, a block that shows up after all asks for a replay (KIND_REPLAY)
 };
 constexpr uint32_t LZ4_BIG_MIN = 64u << 10;

@@ -432,6 +432,11 @@ __global__ void __launch_bounds__(WG) k_zstd_split(InflateJob* q, uint32_t* cnt,
         if (job.codec == SB_CODEC_LZ4 && job.csize >= (2u << 20) && !(st->kinds & KIND_LZ4_GIANT)) atomicOr(&st->kinds, KIND_LZ4_GIANT);
         if ((job.codec & ~JOB_REL) != SB_CODEC_ZSTD) return;
         if (!(st->kinds & KIND_ZSTD)) atomicOr(&st->kinds, KIND_ZSTD);   // (the host sizes the block pipeline's pools for later calls)
+        if (a.zb_skipped && job.csize >= (1u << 20)) {   // a long buffer and no pipeline: not decoded now, the interval is replayed with it
+            atomicOr(&st->kinds, KIND_REPLAY);
+            q[j].codec = CODEC_SPLIT;
+            return;
+        }
         if (a.zs_segs && job.csize >= ZS_BIG) {   // a long buffer: listed for the scan kernels when there is room
             const uint32_t slot = atomicAdd(&a.zs_hdr[0], 1u);
             if (slot < ZS_LIST) {
@@ -1274,7 +1279,7 @@ __global__ void __launch_bounds__(LB_T, 4) k_inflate_lz4_big(const InflateJob* j
         const InflateJob j = jobs[job];
         if (j.codec != SB_CODEC_LZ4 || j.csize < big_min) continue;
         if (lzg_skipped && j.csize >= LZG_MIN) {   // a block for the block-parallel chain, which this call did not launch: replay
-            if (threadIdx.x == 0) atomicOr(&st->kinds, KIND_REPLAY);
+            if (threadIdx.x == 0) atomicOr(&st->kinds, KIND_REPLAY | KIND_REPLAY_LZG);
             continue;
         }
         const uint32_t e = lz4_inflate_block_wg(j.src, j.csize, j.dst, j.out_len, lds);

@@ -1531,9 +1531,16 @@ void read_column(int32_t ptype, bool nullable, const uint8_t* pages, uint64_t pa
         } else {
             SBO_DISPATCH_PRIM(ptype, decompress_prim<T>(r, length, out.values));
         }
-        if ((uint64_t)(r.p - page_start) != metas[p].length)
-            out_of_spec("page " + std::to_string(p) + ": consumed " + std::to_string(r.p - page_start) +
+        // The reference never compares what a page's decoders consumed with PageMeta.length: the iterator API hands every page
+        // its own buffer and drops what is left of it (src/read/array/integer.rs:69-81: `reader.into_inner()` goes back to the
+        // page iterator), the batch API reads page after page from one reader (src/read/array/integer.rs:210-238), so a page
+        // that consumes LESS than its length makes the next page start early — garbage or an error.  Restated as: consuming more
+        // than the page is refused, less only on the column's last page (nothing behind it depends on where it ended).
+        const uint64_t used = (uint64_t)(r.p - page_start);
+        if (used > metas[p].length || (used < metas[p].length && p + 1 < n_pages))
+            out_of_spec("page " + std::to_string(p) + ": consumed " + std::to_string(used) +
                         " bytes, PageMeta.length = " + std::to_string(metas[p].length));
+        r.p = page_start + metas[p].length;
     }
     if (ptype == T_BOOL) {
         out.values = std::move(bb.bytes);

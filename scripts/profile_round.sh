@@ -4,7 +4,7 @@
 # Usage (on the GPU box, from the repo root): scripts/profile_round.sh r03 ; then, per configuration,
 #   python scripts/summarize_rocpd.py gpurun_out/prof_r03 r03 <cfg> '<config json>'
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

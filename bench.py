@@ -1276,7 +1276,7 @@ def main():
         # HBM traffic of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate passes of this same command; summary committed under profiles/)
         src_sha = kernel_source_sha()
-        for pf in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+        for pf in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 pc = pmc["config"]

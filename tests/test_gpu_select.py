@@ -207,3 +207,42 @@ def test_hashed_binary_selection_redo_path(gpu_ctx, nulls):
             enc = gpu_encode(gpu_ctx, col, debug_verify_fail=dbg, **opt)
             assert np.array_equal(enc.metas_array(), want_metas), "debug_verify_fail=%s" % dbg
             assert np.array_equal(enc.pages_numpy(), want_pages), "debug_verify_fail=%s" % dbg
+
+
+@pytest.mark.parametrize("nulls", [None, 0.2])
+def test_fused_page_kernels_and_the_kernel_chain_write_the_same_pages(nulls, monkeypatch):
+    """Binary and 1- / 2- / 4-byte integer Dict pages of 512 ... 65 536 rows are selected and built by one 1024-thread
+    workgroup per page (k_enc_bin_page / k_enc_prim_dict); SB_BIN_FUSED=0 (read at sb_ctx_create) sends them through the
+    hash -> select -> verify -> emit chain, which still serves short / long pages and forced codecs.  Both write the
+    oracle's bytes: Dict pages with bit-packed, RLE and LZ4-coded indices, strings longer than the 24 bytes the fused
+    kernel holds in registers, a page that gives up on Dict midway, integer pages with more distinct values than the
+    fused table takes."""
+    import strawboat_amd as sb
+    rng = np.random.default_rng(77)
+
+    def icol(a, pt):
+        validity = None if nulls is None else gen.pack_bits(rng.random(len(a)) >= nulls)
+        return dict(ptype=pt, nullable=validity is not None, rows=a.size, values=a, validity=validity, offsets=None)
+
+    cols = [gen.binary(200_000, uniq=3000, zipf=1.2, null_density=nulls, seed=21),
+            gen.binary(140_000, uniq=300, zipf=1.1, null_density=nulls, seed=22, maxlen=60),     # slow rows: > 24 bytes
+            gen.binary(131_072, uniq=100_000, null_density=nulls, seed=23, maxlen=9),           # stays Basic
+            gen.binary(70_000, uniq=2, zipf=1.5, null_density=nulls, seed=24),
+            icol(rng.integers(0, 500, 200_000).astype(np.int32), S.T_I32),
+            icol(np.sort(rng.integers(0, 9000, 150_000)).astype(np.uint32), S.T_U32),
+            icol(rng.integers(-300, 300, 100_000).astype(np.int16), S.T_I16),
+            icol(rng.integers(0, 20_000, 131_072).astype(np.int32), S.T_I32),                     # > 10 240 keys per page
+            icol(rng.integers(0, 100, 90_000).astype(np.int8), S.T_I8)]
+    opt = dict(max_page_size=65536, default_compression=S.LZ4, ratio=2.0)
+    want = [gen.oracle_write(c, **opt) for c in cols]
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SB_BIN_FUSED", fused)
+        ctx = sb.Context(0)
+        try:
+            for rep in range(2):                      # (the second call runs on the first one's launch hints)
+                for c, (wp, wm) in zip(cols, want):
+                    enc = gpu_encode(ctx, c, **opt)
+                    assert np.array_equal(enc.metas_array(), wm), "SB_BIN_FUSED=%s" % fused
+                    assert np.array_equal(enc.pages_numpy(), wp), "SB_BIN_FUSED=%s" % fused
+        finally:
+            ctx.close()

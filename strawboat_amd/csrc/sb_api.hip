@@ -309,6 +309,8 @@ static int32_t freq_second_pass(sb_ctx* ctx) {
     hipError_t e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(Status), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return check_hip(ctx, e, "freq second pass");
+    // (what this pass met is not what the next interval's calls met: the word was cleared before the pass was queued)
+    if (ctx->h_status->kinds) (void)hipMemsetAsync(&ctx->d_status->kinds, 0, sizeof ctx->d_status->kinds, ctx->stream);
     if (ctx->h_status->code != 0) {
         char buf[160];
         rc = ctx->h_status->code;
@@ -616,7 +618,7 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     off = align_up(off + n * sizeof(uint64_t), 64);
     // the block-parallel Zstd pipeline: frames + counters here, blocks / literals / records in pools of their own
     const bool zb_on = ctx->zb_mode == 1 || (ctx->zb_mode == 2 && (ctx->zstd_recent || ctx->no_hints));
-    ctx->read_calls++;
+    if (!ctx->in_freq_pass) ctx->read_calls++;   // (the Freq second pass runs inside a synchronize: not a call of the next interval)
     const size_t o_zb_counts = off;
     if (zb_on) off = align_up(off + 64, 64);
     const size_t o_zb_frames = off;
@@ -725,8 +727,12 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
         // Sized from the OUTPUT, not from the stream: a 128 KiB block of repetitive data is a few hundred stream bytes, RLE
         // literals expand 1 byte to 128 KiB, RLE / repeat-mode tables spend well under a byte per sequence.
         zb_block_cap = std::min<uint64_t>(std::max<uint64_t>(pages_bytes / 2048, out_bytes / 8192) + 2 * job_cap + 64, 1u << 23);
-        zb_lit_cap = out_bytes + 16 * zb_block_cap + (1u << 16);
-        zb_rec_cap = std::min<uint64_t>(4 * pages_bytes, out_bytes / 3) + (1u << 14);
+        // ... with a ceiling all the same: a C2-shaped read (4 GB out of 250 MB of pages) asked for ~20 GB.  Literals at most
+        // 8 x the pages + 256 MB (what Huffman streams expand to; blocks of RLE literals beyond that overflow the pool), records
+        // at most 2^28 (3 GB; a cap by the stream's bytes is wrong: small integers in repeat mode are several sequences per stream
+        // byte); what does not fit goes to the frame-serial decoder (ZbCounts, tests/test_gpu_zstd_blocks.py).
+        zb_lit_cap = std::min<uint64_t>(out_bytes, 8 * pages_bytes + (256ull << 20)) + 16 * zb_block_cap + (1u << 16);
+        zb_rec_cap = std::min<uint64_t>(std::min<uint64_t>(4 * pages_bytes, out_bytes / 3), 1ull << 28) + (1u << 14);
         if (ctx->zb_pool_div > 1) {
             zb_block_cap = std::max<uint64_t>(zb_block_cap / ctx->zb_pool_div, 4);
             zb_lit_cap = std::max<uint64_t>(zb_lit_cap / ctx->zb_pool_div, 4096);

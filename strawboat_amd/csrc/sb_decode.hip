@@ -3030,7 +3030,7 @@ static void launch_lzg(sb_ctx* ctx, const DecodeArgs& a, InflateJob* q, const ui
     const uint32_t ngroups = (a.lzg_chunks + LZG_GROUP - 1) / LZG_GROUP;
     {
         KScope k(ctx, "k_lzg_exits");
-        k_lzg_pick<<<1, 256, 0, s>>>(g, q, nq, nullptr, nullptr, cap);
+        k_lzg_pick<<<1, 256, 0, s>>>(g, q, nq, nullptr, nullptr, cap, NJ);
         if (ctx->lzg_state == 0) {
             uint32_t nj = 0;
             if (hipMemcpyAsync(&nj, g.njobs, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) nj = 1;

@@ -40,7 +40,8 @@ constexpr uint32_t LZG_NONE = 0xFFFFFFFFu;
 __device__ __forceinline__ void lzg_fail(LzgJob* j, uint32_t code) { atomicCAS(&j->err, 0u, code); }
 
 // ---------------------------------------------------------------------------------------------------- pick
-__global__ void __launch_bounds__(256) k_lzg_pick(LzgArgs g, InflateJob* qa, const uint32_t* na, InflateJob* qb, const uint32_t* nb, uint32_t cap) {
+__global__ void __launch_bounds__(256) k_lzg_pick(LzgArgs g, InflateJob* qa, const uint32_t* na, InflateJob* qb, const uint32_t* nb, uint32_t cap,
+                                                  uint32_t max_jobs /* rows of the worker grids: a job beyond them would never be decoded */) {
     __shared__ uint32_t s_n;
     __shared__ uint32_t s_list[LZG_JOBS][2];
     if (threadIdx.x == 0) s_n = 0;
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(256) k_lzg_pick(LzgArgs g, InflateJob* qa, con
     }
     __syncthreads();
     if (threadIdx.x) return;
-    const uint32_t cand = min(s_n, LZG_JOBS);
+    const uint32_t cand = min(min(s_n, LZG_JOBS), max_jobs);   // (the rest stay with the one-workgroup decoder)
     uint64_t cur = 0;
     uint32_t taken = 0;
     for (uint32_t k = 0; k < cand; k++) {

@@ -93,10 +93,12 @@ int main(int argc, char** argv) {
     hipMemcpy(t.data(), tl, 8 * 4096, hipMemcpyDeviceToHost);
     const char* nm[128] = {};
     nm[60] = "bin_page: start"; nm[61] = "table init"; nm[62] = "row loop (thread 0)"; nm[63] = "barrier"; nm[64] = "nulls"; nm[65] = "sums + vote + count";
-    nm[66] = "decision"; nm[67] = "bitmap, prefixes, ids"; nm[68] = "index array";
+    nm[66] = "decision"; nm[67] = "bitmap, prefixes, ids";
     nm[20] = "emit: start"; nm[30] = "index selector"; nm[31] = "index block"; nm[32] = "entries";
     unsigned long long prev = 0;
-    for (int p : {60, 61, 62, 63, 64, 65, 66, 67, 68, 20, 30, 31, 32}) {
+    nm[69] = "  index array"; nm[70] = "  index codec"; nm[71] = "  bit-packed body"; nm[72] = "  entries";
+    nm[68] = "page finished";
+    for (int p : {60, 61, 62, 63, 64, 65, 66, 67, 69, 70, 71, 72, 68, 20, 30, 31, 32}) {
         const unsigned long long v = t[512 + p];
         if (!v) continue;
         if (p == 60 || p == 20) prev = v;

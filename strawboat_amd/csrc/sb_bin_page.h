@@ -880,16 +880,31 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
         // (maximum D - 1, never negative, no nulls), all_equal and sortedness from one pass over the index array, the Freq
         // majority by a vote + count, the RLE / Bitpacking / DeltaBitpacking trials on the seeded samples (sb_select.h:
         // sample_row, sample_rle_runs, sample_bp_size) gathered out of the index array.
+        STL(69);
         if (p.icodec < 0) icodec = bp_index_codec(a, p, idx, N, D, forb_n, s_x, s_y, s_w);
+        STL(70);
+        // ---- the index array bit-packed where the emitter's nested block will stand (integer/bp.rs:45-61; BitPacker4x: a
+        // width byte, then 4 interleaved lanes per block of 128) when Bitpacking won: 32 768 indices per step through the
+        // table's LDS.
+        uint8_t* const blk = page_slot(a, c, p) + (c.nullable ? def_section_bytes(N) : 0);
+        if (N % 128 == 0 && icodec == SB_CODEC_BITPACKING) bp_bytes = bp_pack_indices(blk + 18, idx, N, tab, s_x, s_w);
+        __syncthreads();
+        STL(71);
+        // With the body in place everything behind it has its place too: the entries go straight into the page and this
+        // kernel finishes it (headers, def levels, EncOut.pad = 1 like a page of the fused RLE selectors) —
+        // k_enc_emit_pages<-4 / -8, Dict> is then not needed for the page (a fifth of C3's encode went there once, 8 % still
+        // with its handed-over form).
+        const bool whole = bp_bytes != 0;
+        uint8_t* const ent_dst = blk + 9 + 9 + bp_bytes + 4;
         // ---- the dictionary's entries (u64 len | bytes, dictionary order: binary/dict.rs:84-93) in a staging area of the aux
         // words: the emitter places them behind the index block with one coalesced copy (its own pass — first row -> offsets
         // -> bytes for 20 entries per thread of a 256-thread workgroup — was a fifth of its time)
         {
             const uint64_t w0 = (bp_w_slot16(N) + ((uint64_t)N + 1) / 2 + 4 + 3) & ~3ull, M = bh_table_slots(N);
-            if (D && w0 * 4 + tus + 64 <= M * 4) {
+            if (D && (whole || w0 * 4 + tus + 64 <= M * 4)) {
                 // (the table's LDS is free by now: entry sizes, then their offsets, one word per entry; entries are taken
                 // lane = entry with the loads of four of them in flight)
-                uint8_t* stage = (uint8_t*)(aux + w0);
+                uint8_t* stage = whole ? ent_dst : (uint8_t*)(aux + w0);
                 constexpr int EU = 4;
                 for (uint32_t i0 = t; i0 < D; i0 += BP_WG * EU) {
                     uint32_t r[EU];
@@ -976,17 +991,33 @@ __global__ void __launch_bounds__(BP_WG) k_enc_bin_page(EncodeArgs a) {
                 __syncthreads();
             }
         }
-        // ---- the index array bit-packed where the emitter's nested block will stand (integer/bp.rs:45-61; BitPacker4x: a
-        // width byte, then 4 interleaved lanes per block of 128), speculatively: Dict pages of full blocks choose it almost
-        // always, and then the emitter only writes the block's header.  16 384 indices per step through the table's LDS.
-        if (N % 128 == 0 && icodec == SB_CODEC_BITPACKING)
-            bp_bytes = bp_pack_indices(page_slot(a, c, p) + (c.nullable ? def_section_bytes(N) : 0) + 18, idx, N, tab, s_x, s_w);
+        STL(72);
+        if (whole && ent_bytes) {
+            const uint64_t pos = c.nullable ? def_section_bytes(N) : 0;
+            if (c.nullable && t < WG) {   // (def_bits_page walks with the page kernels' 256 threads)
+                uint8_t* bits = def_header(blk - pos, N);
+                def_bits_page(bits, ValidView{c.validity, c.validity_bit_offset}, p.row0, N, c.rows);
+            }
+            if (t == 0) {
+                const uint64_t ib = 9 + (uint64_t)bp_bytes, body = ib + 4 + ent_bytes;
+                put_hdr9(blk + 9, SB_CODEC_BITPACKING, bp_bytes, (uint32_t)(N * 4));
+                stu32(blk + 9 + ib, D);
+                put_hdr9(blk, SB_CODEC_DICT, (uint32_t)body, (uint32_t)c.values_len_total);   // (binary/mod.rs:88: the whole shared buffer)
+                EncOut o;
+                o.length = pos + 9 + body;
+                o.out_off = 0;
+                o.slot = blk - pos;
+                o.codec = SB_CODEC_DICT;
+                o.pad = 1;
+                a.outs[page] = o;
+            }
+        }
     }
     STL(68);
     if (t == 0) {
         gst32(aux + BH_W_ICODEC, icodec + 1u);
         gst32(aux + BH_W_BPBYTES, bp_bytes);
-        gst32(aux + BH_W_ENTBYTES, ent_bytes);
+        gst32(aux + BH_W_ENTBYTES, a.outs[page].pad == 1 ? 0u : ent_bytes);   // (a page finished here has nothing staged)
         gst32(aux + BH_W_ENTWORD, ent_word);
         gst32(aux + BH_W_D, D);
         gst32(aux + BH_W_BAD, 0u);

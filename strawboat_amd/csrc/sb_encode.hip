@@ -3782,6 +3782,8 @@ __global__ void __launch_bounds__(WG, (emit_pages_occupancy<KIND, CODEC>()))
         // a long page whose section-parallel writers were skipped on a hint: not one workgroup's walk over millions of rows —
         // the page stays unwritten and the call is replayed (k_enc_layout)
         if ((a.skips & SKIP_DICT_BIG) && p.bigx_off && page < a.n_pages) return;
+        // (binary Dict pages k_enc_bin_page did not finish itself: the hint for the next call)
+        if (KIND < 0 && threadIdx.x == 0 && a.use_counts) atomicAdd(&a.codec_counts[30], 1u);
     }
     const EncCol c = get_col(a, p.col);
     if (c.ptype == SB_TYPE_NULL) return;
@@ -6208,7 +6210,10 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
                     else k_enc_prim_dict<1><<<(uint32_t)P, BP_WG, 0, st>>>(aa);
                 }
                 // (4- / 8-byte RLE pages come out of the fused selectors: slot 29 counts the ones the page kernel had to write)
-                if (wave_adaptive && !nested && unused(cd == SB_CODEC_RLE && (kd == 4 || kd == 8) ? 29 : (int)cd)) continue;
+                // (binary Dict pages come out of k_enc_bin_page whole when their index block is bit-packed: slot 30 likewise)
+                if (wave_adaptive && !nested &&
+                    unused(cd == SB_CODEC_RLE && (kd == 4 || kd == 8) ? 29 : cd == SB_CODEC_DICT && kd < 0 && aa.bin_fused && !old_chain ? 30 : (int)cd))
+                    continue;
                 char nm[48];
                 snprintf(nm, sizeof nm, "k_enc_emit_pages<%d, %d>", kd, (int)cd);
                 KScope k(ctx, nm);

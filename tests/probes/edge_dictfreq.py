@@ -28,7 +28,7 @@ for ptype, npt in ((S.T_I64, np.int64), (S.T_I32, np.int32), (S.T_I16, np.int16)
             for dc in (S.NONE, S.LZ4):
                 keep.clear()
                 want_pages, want_metas = gen.oracle_write(col, max_page_size=8192, ratio=2.0, forbidden=(S.RLE,), default_compression=dc)
-                wo = WriteOptions(max_page_size=8192, default_compression=dc, default_compress_ratio=2.0, forbidden_compressions=[S.RLE])
+                wo = WriteOptions(max_page_size=8192, default_compression=dc, default_compress_ratio=2.0, forbidden_compressions=[S.RLE], lz4_exact=True)   # (byte parity with liblz4 needs the exact parse)
                 dc_ = write.DeviceColumn(ptype, col["nullable"], rows, at_end(col["values"]), at_end(col["validity"]), None)
                 enc = write.encode_columns(ctx, [dc_], wo); ctx.synchronize()
                 n += 1

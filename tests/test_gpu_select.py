@@ -246,3 +246,34 @@ def test_fused_page_kernels_and_the_kernel_chain_write_the_same_pages(nulls, mon
                     assert np.array_equal(enc.pages_numpy(), wp), "SB_BIN_FUSED=%s" % fused
         finally:
             ctx.close()
+
+
+def test_a_skipped_dict_emitter_is_replayed(gpu_ctx):
+    """k_enc_bin_page finishes the Dict pages whose index block it bit-packs, and a call leaves k_enc_emit_pages<-4, Dict> out
+    when the last call with the same plan needed it for no page (codec_counts[30]).  A column of the same shape whose
+    indices come in runs (an RLE index block: the emitter's job) then finds the page unwritten: the interval is issued again
+    with everything launched, the bytes are the oracle's."""
+    rng = np.random.default_rng(99)
+    n = 2 * 65536                                   # full pages only: row counts that are multiples of 128
+    words = np.array([b"w%05d" % k for k in range(800)], dtype=object)
+
+    def col_of(ids):
+        vals = b"".join(words[i] for i in ids)
+        offs = np.zeros(n + 1, np.int32)
+        offs[1:] = np.cumsum([len(words[i]) for i in ids])
+        return dict(ptype=S.T_BIN32, nullable=False, rows=n, values=np.frombuffer(vals, np.uint8),
+                    validity=None, offsets=offs)
+
+    scattered = col_of(rng.integers(0, 800, n))                       # bit-packed indices: finished by k_enc_bin_page
+    runs = col_of(np.repeat(rng.integers(0, 800, n // 64), 64))       # indices in runs of 64: an RLE index block
+    opt = dict(max_page_size=65536, ratio=2.0, forbidden=())
+    want_s, want_r = gen.oracle_write(scattered, **opt), gen.oracle_write(runs, **opt)
+    inner_s = S.stat_column(scattered["ptype"], False, *want_s)[1].tolist()
+    inner_r = S.stat_column(runs["ptype"], False, *want_r)[1].tolist()
+    assert inner_s != inner_r, "the two columns were meant to choose different index codecs"
+    r0 = gpu_ctx.replays()
+    for k, (col, want) in enumerate([(scattered, want_s), (scattered, want_s), (runs, want_r), (scattered, want_s), (runs, want_r)]):
+        enc = gpu_encode(gpu_ctx, col, **opt)
+        assert np.array_equal(enc.metas_array(), want[1]), k
+        assert np.array_equal(enc.pages_numpy(), want[0]), k
+    assert gpu_ctx.replays() > r0, "the page behind a skipped emitter was written without a replay?"

@@ -338,6 +338,10 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
         } else if (ctx->read_calls && ++ctx->zstd_idle >= 2) {
             ctx->zstd_recent = false;
         }
+        if (ctx->read_calls) {
+            ctx->last_read_kinds = ctx->h_status->kinds;
+            ctx->last_read_kinds_valid = true;
+        }
         ctx->read_calls = 0;
         // (three intervals with long pages and no such block before the chain is dropped: a reader that alternates giant-LZ4
         // columns with long plain ones keeps it; a wrong 2 costs a replay, not a one-workgroup walk)
@@ -358,8 +362,10 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
     }
     // A page was left undone because a kernel it needed had been skipped on a hint (KIND_REPLAY): drop what the interval
     // produced and issue its calls again with every kernel launched.  One extra pass instead of a one-workgroup walk.
-    if (e == hipSuccess && (ctx->h_status->kinds & KIND_REPLAY) && ctx->h_status->code == 0 && rc == SB_OK && !ctx->in_replay &&
-        !ctx->calls.empty()) {
+    // (an error code of such an interval is not looked at: kernels behind a skipped one may have met what it did not produce;
+    // a real error shows again in the replay)
+    if (e == hipSuccess && (ctx->h_status->kinds & KIND_REPLAY) && rc == SB_OK && !ctx->in_replay && !ctx->calls.empty()) {
+        if (ctx->h_status->code != 0) (void)hipMemsetAsync(ctx->d_status, 0, sizeof(Status), ctx->stream);
         for (auto& s : ctx->slots) s.in_flight = false;
         for (auto& sp : ctx->spans) {
             ctx->free_events.push_back(sp.a);
@@ -774,6 +780,13 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     memset(&a.lzg, 0, sizeof a.lzg);
     a.lzg_chunks = a.lzg_wins = a.lzg_rounds = a.lzg_jobs = 0;
     a.lzg_skipped = 0;
+    // the inflate kernels of queue A / the tile kernel of primitives are left out when the last read interval queued nothing
+    // for them (C2: four launches that found nothing to do, ~30 us of a 0.9 ms read); k_plan asks for the replay otherwise
+    a.read_skips = 0;
+    if (ctx->last_read_kinds_valid && !ctx->no_hints && !ctx->in_freq_pass && !sizes_only) {
+        if (!(ctx->last_read_kinds & KIND_QUEUE_A)) a.read_skips |= RSKIP_QUEUE_A;
+        if (!(ctx->last_read_kinds & KIND_TILES)) a.read_skips |= RSKIP_TILES;
+    }
     a.zb_skipped = (!zb_on && ctx->zb_mode == 2 && !sizes_only && max_page_len >= (1u << 20)) ? 1u : 0u;
     if (!sizes_only && max_page_len >= LZG_MIN && ctx->lzg_state == 2 && !ctx->no_hints) {
         // the context's last intervals met no LZ4 block of megabytes: no pool, no launches; k_inflate_lz4_big leaves such

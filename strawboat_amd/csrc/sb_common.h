@@ -114,6 +114,8 @@ constexpr uint32_t KIND_ZSTD = 1u;   // a Zstd buffer was queued
 constexpr uint32_t KIND_LZ4_GIANT = 4u;   // an LZ4 block of >= LZG_MIN compressed bytes was queued (sb_lz4_giant.h is launched for contexts that meet them)
 constexpr uint32_t KIND_REPLAY = 8u;      // a page was left undone because a kernel it needed was not launched on a hint: sb_ctx_synchronize re-issues the interval's calls with everything launched
 constexpr uint32_t KIND_REPLAY_LZG = 16u; // ... and it was an LZ4 block of megabytes that asked (the context turns the block-parallel chain on again)
+constexpr uint32_t KIND_QUEUE_A = 32u;    // a read call queued inflate jobs for queue A (Basic blocks of primitive pages, index / offset blocks)
+constexpr uint32_t KIND_TILES = 64u;      // a read call had tile tasks (k_expand / k_expand_binary)
 constexpr uint32_t KIND_ZSEQ_LONG = 2u;   // a Zstd block of >= 8192 sequences was met (zb_hdr): the sequence chains are the long pole
 
 // one general-purpose block (LZ4 / Zstd / Snappy) to inflate: src -> dst
@@ -266,9 +268,11 @@ struct DecodeArgs {
     LzgArgs lzg;
     uint32_t lzg_chunks, lzg_wins, lzg_rounds, lzg_jobs;   // grid sizes: the longest page / the largest output of the call / pages long enough
     uint32_t zb_skipped;    // the block-parallel Zstd pipeline was left out on a hint (the context's last intervals read no Zstd buffer): a Zstd buffer of a megabyte or more asks for the replay instead of going frame by frame through the one-wave decoder (20 ms for a 96 MB page against 1.3)
+    uint32_t read_skips;    // RSKIP_* bits: kernels left out because the context's last read interval had no work for them (k_plan asks for the replay when this call has)
     uint32_t lzg_skipped;   // the call has pages long enough but the context's last intervals met no such block: the chain is not launched, a block that shows up after all asks for a replay (KIND_REPLAY)
 };
 constexpr uint32_t LZ4_BIG_MIN = 64u << 10;
+constexpr uint32_t RSKIP_QUEUE_A = 1u, RSKIP_TILES = 2u;   // k_zstd_split + k_inflate + k_inflate_lz4 of queue A / k_expand
 
 }  // namespace sb
 

@@ -2007,6 +2007,17 @@ __global__ void __launch_bounds__(WG) k_bp_guess(DecodeArgs a) {
 // 4 workgroups per CU (LDS and registers): a 64-column x 16-page batch is 1024 pages = ONE round of the chip; at 3 per CU
 // it took two, and a page's plan is a latency chain of ~1 ms whatever else runs
 __global__ void __launch_bounds__(WG, 4) k_plan(DecodeArgs a) {
+    // what this call queued, for the launches of the next interval's calls (sb_read_columns leaves out the inflate kernels of
+    // queue A / the tile kernel of primitives when the last read interval had nothing for them); a call that has work for a
+    // kernel it left out says so: the interval is issued again with everything (sb_ctx_synchronize)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t na = a.job_counts[0], nt = a.job_counts[2];
+        uint32_t k = (na ? KIND_QUEUE_A : 0u) | (nt ? KIND_TILES : 0u);
+        if (((a.read_skips & RSKIP_QUEUE_A) && na) || ((a.read_skips & RSKIP_TILES) && nt)) k |= KIND_REPLAY;
+        if (k) atomicOr(&a.status->kinds, k);
+    }
+    if (a.read_skips & RSKIP_QUEUE_A)
+        if (a.job_counts[0]) return;   // (nothing was inflated: no plan on what is not there)
     if (a.job_counts[3] == 0) return;  // no page of this call needs a plan (k_parse counts them)
 #ifdef SB_PLAN_PRINTF
     const unsigned long long kp0 = __builtin_readcyclecounter();
@@ -3062,18 +3073,19 @@ static void launch_lzg(sb_ctx* ctx, const DecodeArgs& a, InflateJob* q, const ui
 void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_prim, uint64_t* col_values_len) {
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(a.job_counts, 0, 16 * sizeof(uint32_t), s);
+    const bool qa = !(a.read_skips & RSKIP_QUEUE_A);
     {
         KScope k(ctx, K_PARSE);
         k_parse<<<(a.n_pages + WG - 1) / WG, WG, 0, s>>>(a);
-        launch_zstd_split(a, a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, s);
+        if (qa) launch_zstd_split(a, a.jobs_a, a.job_counts, a.job_counts + 8, a.job_cap_a, s);
         if (a.jobs_z) launch_zstd_split(a, a.jobs_z, a.job_counts + 10, a.job_counts + 11, a.job_cap_a, s);
     }
     launch_zb(ctx, a);
-    {
+    if (qa) {
         KScope k(ctx, K_INFLATE_A);
         k_inflate<<<min(a.job_cap_a, INFLATE_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.zlit, a.zrec, rel_ctx(a), a.job_cap_a);
     }
-    {
+    if (qa) {
         KScope k(ctx, "k_inflate_lz4");
         k_inflate_lz4<<<min(a.zs_segs ? a.job_cap_a : 2 * a.n_pages, LZ4_POOL), 64, 0, s>>>(a.jobs_a, a.job_counts, a.status, a.lz4_big_min, a.job_cap_a);
     }
@@ -3126,7 +3138,7 @@ void launch_decode(sb_ctx* ctx, const DecodeArgs& a, bool any_binary, bool any_p
         if (a.rle_parts > 1) k_rle_sums<<<dim3(a.n_pages, a.rle_parts), WG, 0, s>>>(a);
         k_expand_rle<<<dim3(a.n_pages, std::max<uint32_t>(1u, a.rle_parts)), WG, 0, s>>>(a);
     }
-    if (a.n_tiles && any_prim) {
+    if (a.n_tiles && any_prim && !(a.read_skips & RSKIP_TILES)) {
         KScope k(ctx, K_EXPAND);
         k_expand<<<min(a.n_tiles, TILE_GRID), WG, 0, s1>>>(a);
     }

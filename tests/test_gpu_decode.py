@@ -266,3 +266,38 @@ def test_binary_dict_long_page_with_an_index_out_of_range(gpu_ctx):
         assert want is not None, "the oracle refuses index %d, the device decoded the page" % value
         assert np.array_equal(got.values_numpy(), want["values"]) and np.array_equal(got.offsets_numpy(), want["offsets"])
     assert seen == {True, False}
+
+
+def test_read_kernels_left_out_on_a_hint_are_replayed():
+    """a read call leaves out the inflate kernels of queue A and the tile kernel of primitives when the context's last read
+    interval queued nothing for them (RLE pages: a page kernel expands them); pages that need them after all — LZ4 blocks,
+    plain tiles, Dict pages with an LZ4 index block — show up: the interval is issued again with everything (sb_ctx_replays)
+    and decodes to the oracle's values"""
+    import strawboat_amd as sb
+    ctx = sb.Context(0)
+    try:
+        rle = gen.prim(S.T_F64, 200_000, uniq=50, null_density=0.1, runs=40, seed=5)
+        plain = gen.prim(S.T_I64, 200_000, uniq=1 << 40, seed=6)
+        lz4 = gen.prim(S.T_I32, 200_000, uniq=300, runs=5, seed=7)
+        dict_lz4 = gen.prim(S.T_F64, 128 * 300, uniq=200, null_density=0.1, runs=16, seed=8)
+        r0 = ctx.replays()
+        for _ in range(3):
+            check(ctx, rle, max_page_size=65536, force_codec=S.RLE)          # (neither jobs nor tiles)
+        r1 = ctx.replays()
+        assert r1 == r0
+        check(ctx, plain, max_page_size=65536, force_codec=S.NONE)            # tiles after all
+        assert ctx.replays() == r1 + 1
+        check(ctx, rle, max_page_size=65536, force_codec=S.RLE)
+        check(ctx, rle, max_page_size=65536, force_codec=S.RLE)
+        r2 = ctx.replays()
+        check(ctx, lz4, max_page_size=65536, force_codec=S.LZ4)              # inflate jobs after all
+        assert ctx.replays() == r2 + 1
+        check(ctx, rle, max_page_size=65536, force_codec=S.RLE)
+        check(ctx, rle, max_page_size=65536, force_codec=S.RLE)
+        r3 = ctx.replays()
+        check(ctx, dict_lz4, max_page_size=128 * 100, force_codec=S.DICT, force_index_codec=S.LZ4)   # a plan that needs inflated indices
+        assert ctx.replays() == r3 + 1
+        check(ctx, dict_lz4, max_page_size=128 * 100, force_codec=S.DICT, force_index_codec=S.LZ4)   # (now launched: no replay)
+        assert ctx.replays() == r3 + 1
+    finally:
+        ctx.close()

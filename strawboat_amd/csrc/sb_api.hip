@@ -339,8 +339,8 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
             ctx->zstd_recent = false;
         }
         if (ctx->read_calls) {
-            ctx->last_read_kinds = ctx->h_status->kinds;
-            ctx->last_read_kinds_valid = true;
+            ctx->qa_idle = (ctx->h_status->kinds & KIND_QUEUE_A) ? 0 : ctx->qa_idle + 1;
+            ctx->tiles_idle = (ctx->h_status->kinds & KIND_TILES) ? 0 : ctx->tiles_idle + 1;
         }
         ctx->read_calls = 0;
         // (three intervals with long pages and no such block before the chain is dropped: a reader that alternates giant-LZ4
@@ -783,9 +783,9 @@ static int32_t read_columns_impl(sb_ctx* ctx, sb_column_read* cols, uint64_t n, 
     // the inflate kernels of queue A / the tile kernel of primitives are left out when the last read interval queued nothing
     // for them (C2: four launches that found nothing to do, ~30 us of a 0.9 ms read); k_plan asks for the replay otherwise
     a.read_skips = 0;
-    if (ctx->last_read_kinds_valid && !ctx->no_hints && !ctx->in_freq_pass && !sizes_only) {
-        if (!(ctx->last_read_kinds & KIND_QUEUE_A)) a.read_skips |= RSKIP_QUEUE_A;
-        if (!(ctx->last_read_kinds & KIND_TILES)) a.read_skips |= RSKIP_TILES;
+    if (!ctx->no_hints && !ctx->in_freq_pass && !sizes_only) {
+        if (ctx->qa_idle >= 2) a.read_skips |= RSKIP_QUEUE_A;
+        if (ctx->tiles_idle >= 2) a.read_skips |= RSKIP_TILES;
     }
     a.zb_skipped = (!zb_on && ctx->zb_mode == 2 && !sizes_only && max_page_len >= (1u << 20)) ? 1u : 0u;
     if (!sizes_only && max_page_len >= LZG_MIN && ctx->lzg_state == 2 && !ctx->no_hints) {

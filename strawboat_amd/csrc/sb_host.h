@@ -68,8 +68,8 @@ struct sb_ctx {
     uint32_t kinds_seen = 0;
     bool zstd_recent = false;   // the read calls of the last synchronize interval met a Zstd buffer
     uint32_t read_calls = 0;     // read calls since the last synchronize
-    uint32_t last_read_kinds = 0;       // Status.kinds of the last interval that held read calls (KIND_QUEUE_A, KIND_TILES: what
-    bool last_read_kinds_valid = false; // the next read calls may leave out)
+    uint32_t qa_idle = 0, tiles_idle = 0;   // read intervals in a row that queued no inflate job for queue A / no tile task: from two
+                                            // on the next read calls leave those kernels out (a reader that alternates column kinds keeps them)
     uint32_t zstd_idle = 0;      // read intervals in a row that met no Zstd buffer
     bool zb_seq_long = false;    // the last Zstd calls held blocks of >= 8192 sequences: zb_seq is submitted before zb_lit
     int zb_mode = 2;             // 0 off, 1 always, 2 once Zstd has been seen

@@ -450,7 +450,10 @@ int32_t sb_ctx_synchronize(sb_ctx* ctx) {
             c->values_len = v;
         } else if (p.kind == Pending::ENC_HINT) {
             if (ctx->enc_plan.valid && ctx->enc_plan.key == p.n && rc == SB_OK) {
-                memcpy(ctx->enc_plan.last_counts, p.host, 128);
+                uint32_t now[32];
+                memcpy(now, p.host, 128);
+                for (int i = 0; i < 32; i++) ctx->enc_plan.last_counts[i] = std::max(now[i], ctx->enc_plan.prev_counts[i]);
+                memcpy(ctx->enc_plan.prev_counts, now, 128);
                 ctx->enc_plan.counts_valid = true;
             }
         } else if (p.kind == Pending::NESTED_W) {

@@ -5652,6 +5652,7 @@ static int32_t write_columns_impl(sb_ctx* ctx, sb_column_write* cols, uint64_t n
     if (!hit) {
         plan.valid = false;
         plan.counts_valid = false;
+        memset(plan.prev_counts, 0, sizeof plan.prev_counts);
         plan.bin_pages = plan.bin_unfused = false;
         if (!ensure(ctx, plan.pages, P * sizeof(EncPage) + 64)) return ctx->fail(SB_ERR_EXTERNAL, "hipMalloc(page table) failed");
         plan.col_first.assign(n, 0);

@@ -186,10 +186,11 @@ struct sb_ctx {
         std::vector<uint32_t> bigw[5];          // by log2(width): 1-, 2-, 4-, 8-byte values; [4]: binary pages
         uint32_t big_secs[5] = {0, 0, 0, 0, 0};
         sb::DevBuf big;
-        // pages per codec the last completed call with this plan chose (read back with its results): calls whose long pages
-        // did not choose Dict / Freq skip the launches of sb_dict_big.h / sb_freq_big.h — a page that does after all is
-        // written by the one-workgroup kernels as before, so a wrong guess only costs time
-        uint32_t last_counts[32] = {0};
+        // pages per codec the last TWO completed calls with this plan chose (element-wise maximum; read back with the results):
+        // a call leaves out the launches neither of them needed — a page that needs one after all stays unwritten and the
+        // interval is replayed (k_enc_layout, sb_ctx_synchronize).  Two calls, not one: a writer that alternates two kinds
+        // of data under one plan keeps the kernels of both instead of replaying every other call.
+        uint32_t last_counts[32] = {0}, prev_counts[32] = {0};
         bool counts_valid = false;
         // binary pages of an adaptive call: any of them, and any that k_enc_bin_page (sb_bin_page.h) does not take (too
         // short / long): only those still need the hash -> select -> verify chain

@@ -277,3 +277,10 @@ def test_a_skipped_dict_emitter_is_replayed(gpu_ctx):
         assert np.array_equal(enc.metas_array(), want[1]), k
         assert np.array_equal(enc.pages_numpy(), want[0]), k
     assert gpu_ctx.replays() > r0, "the page behind a skipped emitter was written without a replay?"
+    # a writer that alternates the two kinds under one plan keeps both sets of kernels (the hints are what the last TWO calls
+    # with the plan needed): no replay every other call
+    r1 = gpu_ctx.replays()
+    for k, (col, want) in enumerate([(scattered, want_s), (runs, want_r)] * 3):
+        enc = gpu_encode(gpu_ctx, col, **opt)
+        assert np.array_equal(enc.pages_numpy(), want[0]), k
+    assert gpu_ctx.replays() == r1, "alternating data under one plan is replayed again and again"

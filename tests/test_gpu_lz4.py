@@ -648,6 +648,9 @@ def test_giant_block_after_plain_long_pages_is_replayed(gpu_ctx):
     """a context whose last intervals read long pages without an LZ4 block of megabytes stops launching the block-parallel
     chain; when such a block shows up after all, k_inflate_lz4_big leaves it alone (one workgroup took 0.8 s for 68 MB),
     the interval is issued again with the chain (sb_ctx_replays) and the bytes are right"""
+    import os
+    if os.environ.get("SB_NO_HINTS", "0") != "0":
+        pytest.skip("SB_NO_HINTS: every kernel is launched, nothing to replay")
     import time
     from strawboat_amd import read
     blk = _giant()["sorted_i64"]

@@ -253,6 +253,9 @@ def test_a_skipped_dict_emitter_is_replayed(gpu_ctx):
     when the last call with the same plan needed it for no page (codec_counts[30]).  A column of the same shape whose
     indices come in runs (an RLE index block: the emitter's job) then finds the page unwritten: the interval is issued again
     with everything launched, the bytes are the oracle's."""
+    import os
+    if os.environ.get("SB_NO_HINTS", "0") != "0" or os.environ.get("SB_BIN_FUSED", "1") == "0":
+        pytest.skip("the switches launch the emitter every time")
     rng = np.random.default_rng(99)
     n = 2 * 65536                                   # full pages only: row counts that are multiples of 128
     words = np.array([b"w%05d" % k for k in range(800)], dtype=object)
